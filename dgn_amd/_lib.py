@@ -1,0 +1,101 @@
+"""ctypes binding of libdgn_hip.so (C ABI in include/dgn_hip.h).
+
+There is NO fallback: if the shared library is missing or cannot be loaded, every
+entry point raises -- the product path never computes on the CPU or through torch ops.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``dgn_amd/csrc/build.sh`` (hipcc, --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+DGN_MAX_AGG = 16
+DGN_MAX_CH = 4
+DGN_MAX_SCALERS = 4
+ABI_VERSION = 1
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
+
+# symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward")
+
+
+class DgnGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("indptr", C.c_void_p), ("src", C.c_void_p),
+                ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
+                ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
+                ("hub_chunk", C.c_int32)]
+
+
+class DgnChannel(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("eig_col", C.c_int32), ("alpha", C.c_float), ("eps", C.c_float)]
+
+
+class DgnAggSpec(C.Structure):
+    _fields_ = [("n_agg", C.c_int32), ("agg_op", C.c_int32 * DGN_MAX_AGG), ("agg_ch", C.c_int32 * DGN_MAX_AGG),
+                ("n_ch", C.c_int32), ("n_scalers", C.c_int32), ("scaler", C.c_int32 * DGN_MAX_SCALERS),
+                ("avg_log", C.c_float), ("eps", C.c_float), ("n_towers", C.c_int32), ("agg_total", C.c_int32),
+                ("agg_offset", C.c_int32)]
+
+
+class DgnMsg(C.Structure):
+    _fields_ = [("F", C.c_int64), ("x_src", C.c_void_p), ("ld_src", C.c_int64), ("x_dst", C.c_void_p),
+                ("ld_dst", C.c_int64), ("m_edge", C.c_void_p), ("ld_edge", C.c_int64), ("x_in", C.c_void_p),
+                ("ld_in", C.c_int64)]
+
+
+class DgnMsgGrad(C.Structure):
+    _fields_ = [("g_src", C.c_void_p), ("ld_src", C.c_int64), ("g_dst", C.c_void_p), ("ld_dst", C.c_int64),
+                ("g_edge", C.c_void_p), ("ld_edge", C.c_int64), ("g_in", C.c_void_p), ("ld_in", C.c_int64)]
+
+
+class DgnError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the shared library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DgnError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() "
+                           "or dgn_amd/csrc/build.sh). dgn_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.dgn_abi_version.restype = C.c_int
+        lib.dgn_last_error.restype = C.c_char_p
+        lib.dgn_edge_weights_workspace_bytes.restype = C.c_size_t
+        lib.dgn_edge_weights_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.c_int32]
+        lib.dgn_edge_weights.restype = C.c_int
+        lib.dgn_edge_weights.argtypes = [C.POINTER(DgnGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                         C.POINTER(DgnChannel), C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]
+        lib.dgn_agg_workspace_bytes.restype = C.c_size_t
+        lib.dgn_agg_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64]
+        lib.dgn_agg_forward.restype = C.c_int
+        lib.dgn_agg_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
+                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]
+        lib.dgn_agg_backward.restype = C.c_int
+        lib.dgn_agg_backward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(DgnMsgGrad),
+                                         C.c_void_p, C.c_size_t, C.c_void_p]
+        if lib.dgn_abi_version() != ABI_VERSION:
+            raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise DgnError(f"{what} failed (rc={rc}): {load().dgn_last_error().decode()}")

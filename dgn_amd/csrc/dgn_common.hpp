@@ -1,0 +1,93 @@
+// Shared host/device helpers of libdgn_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dgn_hip.h"
+
+namespace dgn {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;               // 256-thread workgroups
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kXcds = 8;                         // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define DGN_HIP_CHECK(expr)                                         \
+    do {                                                            \
+        hipError_t _e = (expr);                                     \
+        if (_e != hipSuccess) return ::dgn::hip_fail(_e, #expr);    \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float bcast_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8 (observed, speed only).
+// Give every XCD one contiguous eighth of the logical work so that neighbouring rows -- whose
+// sources overlap in batched small graphs -- share one L2.  Returns -1 for padding blocks.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n_logical) {
+    int64_t per = (n_logical + kXcds - 1) / kXcds;
+    int64_t logical = (b % kXcds) * per + b / kXcds;
+    return logical < n_logical ? logical : -1;
+}
+inline int64_t xcd_grid(int64_t n_logical) { return ((n_logical + kXcds - 1) / kXcds) * kXcds; }
+
+template <int VEC>
+__device__ __forceinline__ void ldv(float (&d)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    } else if constexpr (VEC == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        d[0] = t.x; d[1] = t.y;
+    } else {
+        d[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+    } else {
+        *p = d[0];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void ldvi(int (&d)[VEC], const int* p) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] = p[i];
+}
+template <int VEC>
+__device__ __forceinline__ void stvi(int* p, const int (&d)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = d[i];
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    // hardware global_atomic_add_f32 (no CAS loop); result unused
+    __builtin_amdgcn_global_atomic_fadd_f32(p, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+}  // namespace dgn

@@ -1,0 +1,320 @@
+"""DGNLayer operator API of the reference on the MI355X aggregation kernels.
+
+Same factory, constructor arguments, ``.model`` attribute, ``forward(g, h, e, snorm_n)``
+and ``state_dict`` keys/shapes as realworld_benchmark/nets/dgn_layer.py:52-352, so the
+benchmark nets (nets/*/dgn_net.py) can construct and call these layers unchanged.
+
+What differs is everything between ``g.apply_edges`` and the end of ``reduce_func``:
+one fused CSR sweep (``dgn_amd.ops.directional_aggregate``) instead of DGL's degree
+bucketing.  A 1-layer ``pretrans`` (every shipped config) is affine in
+``[h_src || h_dst || ef]`` and is decomposed as ``P[src] + Q[dst] + R[edge]`` with two
+node-level GEMMs, so no ``[E, 2F]`` concat is ever built; all towers run in ONE sweep
+(they are column blocks of the message) and ``posttrans([h || agg])`` is evaluated as two
+GEMMs without materialising the concat.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .graph import DGNGraph, as_dgn_graph
+from .layers import MLP, FCLayer
+from .ops import directional_aggregate
+from .spec import AGGREGATOR_NAMES, SCALER_NAMES, make_plan, parse_aggregator, parse_scaler
+
+
+class _Named:
+    """Registry entry: what ``AGGREGATORS[name]`` / ``SCALERS[name]`` return."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __repr__(self):
+        return f"<{self.__class__.__name__} {self.name}>"
+
+
+class _Registry(dict):
+    def __init__(self, names, parser, cls):
+        super().__init__()
+        self._parser, self._cls = parser, cls
+        for n in names:
+            self[n] = cls(n)
+
+    def __missing__(self, key):
+        self._parser(key)          # raises KeyError for unknown names
+        self[key] = self._cls(key)  # accepted alias (dirK-smooth)
+        return self[key]
+
+
+AGGREGATORS = _Registry(AGGREGATOR_NAMES, parse_aggregator, _Named)   # nets/aggregators.py:74-93
+SCALERS = _Registry(SCALER_NAMES, parse_scaler, _Named)              # nets/scalers.py:21
+
+
+def _names(items: Sequence) -> List[str]:
+    return [x if isinstance(x, str) else x.name for x in items]
+
+
+def _avg_log(avg_d) -> float:
+    v = avg_d["log"]
+    return float(v.item()) if torch.is_tensor(v) else float(v)
+
+
+def _slot_dst(graph: DGNGraph) -> torch.Tensor:
+    if not hasattr(graph, "_dst_slots"):
+        graph._dst_slots = torch.repeat_interleave(torch.arange(graph.num_nodes, device=graph.device), graph.in_degree)
+    return graph._dst_slots
+
+
+def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
+    """(x_src, x_dst, m_edge) such that m_j = x_src[src_j] + x_dst[i] + m_edge[j] equals
+    pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80."""
+    if pretrans.is_single_affine():
+        lin = pretrans.fully_connected[0].linear
+        W = lin.weight                                     # [in, 2*in (+edge_dim)]
+        bias = lin.bias
+        w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
+        b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
+        pq = F.linear(h, w_sd, b_sd)                       # [N, 2*in]: P | Q
+        m_edge = F.linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
+        return pq[:, :in_dim], pq[:, in_dim:], m_edge
+    # general pretrans (ReLU between layers): materialise the messages, directly in slot order
+    z = [h.index_select(0, graph.src.long()), h.index_select(0, _slot_dst(graph))]
+    if edge_features:
+        z.append(graph.to_slot_order(e))
+    return None, None, pretrans(torch.cat(z, dim=1))
+
+
+def _posttrans_split(posttrans: MLP, h, agg, in_dim):
+    """posttrans(cat([h, agg])) without building the concat when posttrans is one Linear."""
+    if posttrans.is_single_affine():
+        lin = posttrans.fully_connected[0].linear
+        return F.linear(agg, lin.weight[:, in_dim:]) + F.linear(h, lin.weight[:, :in_dim], lin.bias)
+    return posttrans(torch.cat([h, agg], dim=1))
+
+
+class DGNLayerSimple(nn.Module):
+    """dgn_layer.py:135-202: message = h[src]; posttrans on the aggregation only."""
+
+    def __init__(self, in_dim, out_dim, dropout, graph_norm, batch_norm, aggregators, scalers, residual, avg_d,
+                 posttrans_layers=1):
+        super().__init__()
+        self.dropout, self.graph_norm, self.batch_norm, self.residual = dropout, graph_norm, batch_norm, residual
+        self.aggregators, self.scalers = _names(aggregators), _names(scalers)
+        self.plan = make_plan(self.aggregators, self.scalers)
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers)) * in_dim, hidden_size=out_dim,
+                             out_size=out_dim, layers=posttrans_layers, mid_activation="relu", last_activation="none")
+        self.avg_d = avg_d
+        self._avg_log = _avg_log(avg_d)
+        if in_dim != out_dim:
+            self.residual = False
+
+    def aggregate(self, g, h):
+        graph = as_dgn_graph(g)
+        return directional_aggregate(graph, self.plan, self._avg_log, x_src=h, x_in=h, eig=g.ndata["eig"])
+
+    def forward(self, g, h, e, snorm_n):
+        h_in = h
+        h = self.posttrans(self.aggregate(g, h))
+        if self.graph_norm:
+            h = h * snorm_n
+        if self.batch_norm:
+            h = self.batchnorm_h(h)
+        h = F.relu(h)
+        if self.residual:
+            h = h_in + h
+        return F.dropout(h, self.dropout, training=self.training)
+
+
+class DGNLayerComplex(nn.Module):
+    """dgn_layer.py:52-132: message = pretrans([h_src || h_dst (|| ef)]); posttrans on [h || agg]."""
+
+    def __init__(self, in_dim, out_dim, dropout, graph_norm, batch_norm, aggregators, scalers, avg_d, residual,
+                 edge_features, edge_dim, pretrans_layers=1, posttrans_layers=1):
+        super().__init__()
+        self.dropout, self.graph_norm, self.batch_norm = dropout, graph_norm, batch_norm
+        self.edge_features, self.residual, self.in_dim = edge_features, residual, in_dim
+        self.aggregators, self.scalers = _names(aggregators), _names(scalers)
+        self.plan = make_plan(self.aggregators, self.scalers)
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.pretrans = MLP(in_size=2 * in_dim + (edge_dim if edge_features else 0), hidden_size=in_dim,
+                            out_size=in_dim, layers=pretrans_layers, mid_activation="relu", last_activation="none")
+        self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers) + 1) * in_dim, hidden_size=out_dim,
+                             out_size=out_dim, layers=posttrans_layers, mid_activation="relu", last_activation="none")
+        self.avg_d = avg_d
+        self._avg_log = _avg_log(avg_d)
+        if in_dim != out_dim:
+            self.residual = False
+
+    def aggregate(self, g, h, e):
+        graph = as_dgn_graph(g)
+        x_src, x_dst, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        return directional_aggregate(graph, self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge, x_in=h,
+                                     eig=g.ndata["eig"])
+
+    def forward(self, g, h, e, snorm_n):
+        h_in = h
+        h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
+        if self.graph_norm:
+            h = h * snorm_n
+        if self.batch_norm:
+            h = self.batchnorm_h(h)
+        h = F.relu(h)
+        if self.residual:
+            h = h_in + h
+        return F.dropout(h, self.dropout, training=self.training)
+
+
+class DGNTower(nn.Module):
+    """dgn_layer.py:205-276.  Holds one tower's parameters (same state_dict keys) and can run on
+    its own; DGNLayerTower normally evaluates all towers in one fused sweep instead."""
+
+    def __init__(self, in_dim, out_dim, dropout, graph_norm, batch_norm, aggregators, scalers, avg_d,
+                 pretrans_layers, posttrans_layers, edge_features, edge_dim):
+        super().__init__()
+        self.dropout, self.graph_norm, self.batch_norm, self.edge_features = dropout, graph_norm, batch_norm, edge_features
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.aggregators, self.scalers = _names(aggregators), _names(scalers)
+        self.plan = make_plan(self.aggregators, self.scalers)
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.pretrans = MLP(in_size=2 * in_dim + (edge_dim if edge_features else 0), hidden_size=in_dim,
+                            out_size=in_dim, layers=pretrans_layers, mid_activation="relu", last_activation="none")
+        self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers) + 1) * in_dim, hidden_size=out_dim,
+                             out_size=out_dim, layers=posttrans_layers, mid_activation="relu", last_activation="none")
+        self.avg_d = avg_d
+        self._avg_log = _avg_log(avg_d)
+
+    def forward(self, g, h, e, snorm_n):
+        graph = as_dgn_graph(g)
+        h = h.contiguous()
+        x_src, x_dst, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        agg = directional_aggregate(graph, self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge, x_in=h,
+                                    eig=g.ndata["eig"])
+        h = _posttrans_split(self.posttrans, h, agg, self.in_dim)
+        if self.graph_norm:
+            h = h * snorm_n
+        if self.batch_norm:
+            h = self.batchnorm_h(h)
+        return F.dropout(h, self.dropout, training=self.training)
+
+
+class DGNLayerTower(nn.Module):
+    """dgn_layer.py:279-325."""
+
+    def __init__(self, in_dim, out_dim, aggregators, scalers, avg_d, dropout, graph_norm, batch_norm, towers=5,
+                 pretrans_layers=1, posttrans_layers=1, divide_input=True, residual=False, edge_features=False,
+                 edge_dim=0):
+        super().__init__()
+        assert ((not divide_input) or in_dim % towers == 0), "if divide_input is set the number of towers has to divide in_dim"
+        assert (out_dim % towers == 0), "the number of towers has to divide the out_dim"
+        assert avg_d is not None
+        self.divide_input = divide_input
+        self.input_tower = in_dim // towers if divide_input else in_dim
+        self.output_tower = out_dim // towers
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.edge_features, self.residual = edge_features, residual
+        self.dropout, self.graph_norm, self.batch_norm = dropout, graph_norm, batch_norm
+        if in_dim != out_dim:
+            self.residual = False
+        self.towers = nn.ModuleList()
+        for _ in range(towers):
+            self.towers.append(DGNTower(in_dim=self.input_tower, out_dim=self.output_tower, aggregators=aggregators,
+                                        scalers=scalers, avg_d=avg_d, pretrans_layers=pretrans_layers,
+                                        posttrans_layers=posttrans_layers, batch_norm=batch_norm, dropout=dropout,
+                                        graph_norm=graph_norm, edge_features=edge_features, edge_dim=edge_dim))
+        self.mixing_network = FCLayer(out_dim, out_dim, activation="LeakyReLU")
+        self.plan = self.towers[0].plan
+        self._avg_log = _avg_log(avg_d)
+
+    def _fusable(self) -> bool:
+        t0 = self.towers[0]
+        return t0.pretrans.is_single_affine() and t0.posttrans.is_single_affine()
+
+    def _fused_towers(self, g, h, e, snorm_n):
+        """All towers in one sweep: towers are column blocks of the message."""
+        graph = as_dgn_graph(g)
+        T, fi, fo = len(self.towers), self.input_tower, self.output_tower
+        lins = [t.pretrans.fully_connected[0].linear for t in self.towers]
+        if self.divide_input:
+            w_s = torch.block_diag(*[l.weight[:, :fi] for l in lins])             # [T*fi, in]
+            w_d = torch.block_diag(*[l.weight[:, fi:2 * fi] for l in lins])
+            x_in = h
+        else:
+            w_s = torch.cat([l.weight[:, :fi] for l in lins], dim=0)              # every tower reads all of h
+            w_d = torch.cat([l.weight[:, fi:2 * fi] for l in lins], dim=0)
+            x_in = h.repeat(1, T)
+        Fm = T * fi
+        bias = torch.cat([l.bias for l in lins])
+        pq = F.linear(h, torch.cat([w_s, w_d], dim=0), torch.cat([torch.zeros_like(bias), bias]))   # [N, 2*Fm]
+        m_edge = None
+        if self.edge_features:
+            m_edge = F.linear(graph.to_slot_order(e), torch.cat([l.weight[:, 2 * fi:] for l in lins], dim=0))
+        agg = directional_aggregate(graph, self.plan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
+                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T)      # [N, T, S*A*fi]
+        posts = [t.posttrans.fully_connected[0].linear for t in self.towers]
+        w_a = torch.stack([l.weight[:, fi:] for l in posts])                         # [T, fo, S*A*fi]
+        w_h = torch.stack([l.weight[:, :fi] for l in posts])                         # [T, fo, fi]
+        b_p = torch.stack([l.bias for l in posts])                                   # [T, fo]
+        N = h.shape[0]
+        y = torch.bmm(agg.view(N, T, -1).transpose(0, 1), w_a.transpose(1, 2))       # [T, N, fo]
+        h_t = x_in.view(N, T, fi).transpose(0, 1)
+        y = y + torch.bmm(h_t, w_h.transpose(1, 2)) + b_p.unsqueeze(1)
+        y = y.transpose(0, 1).reshape(N, T * fo)
+        if self.graph_norm:
+            y = y * snorm_n
+        if self.batch_norm:
+            bns = [t.batchnorm_h for t in self.towers]
+            rm = torch.cat([b.running_mean for b in bns])
+            rv = torch.cat([b.running_var for b in bns])
+            y = F.batch_norm(y, rm, rv, torch.cat([b.weight for b in bns]), torch.cat([b.bias for b in bns]),
+                             self.training, bns[0].momentum, bns[0].eps)
+            if self.training:
+                with torch.no_grad():
+                    for i, b in enumerate(bns):
+                        b.running_mean.copy_(rm[i * fo:(i + 1) * fo])
+                        b.running_var.copy_(rv[i * fo:(i + 1) * fo])
+                        b.num_batches_tracked += 1
+        return F.dropout(y, self.dropout, training=self.training)
+
+    def forward(self, g, h, e, snorm_n):
+        h_in = h
+        if self._fusable():
+            h_cat = self._fused_towers(g, h, e, snorm_n)
+        elif self.divide_input:
+            h_cat = torch.cat([tower(g, h[:, n * self.input_tower:(n + 1) * self.input_tower], e, snorm_n)
+                               for n, tower in enumerate(self.towers)], dim=1)
+        else:
+            h_cat = torch.cat([tower(g, h, e, snorm_n) for tower in self.towers], dim=1)
+        h_out = self.mixing_network(h_cat) if len(self.towers) > 1 else h_cat
+        if self.residual:
+            h_out = h_in + h_out
+        return h_out
+
+
+class DGNLayer(nn.Module):
+    """Factory with the reference's signature (dgn_layer.py:328-352); use ``.model``."""
+
+    def __init__(self, in_dim, out_dim, dropout, graph_norm, batch_norm, aggregators, scalers, avg_d, type_net,
+                 residual, towers=5, divide_input=True, edge_features=None, edge_dim=None, pretrans_layers=1,
+                 posttrans_layers=1):
+        super().__init__()
+        aggregators = [AGGREGATORS[aggr] for aggr in aggregators.split()]
+        scalers = [SCALERS[scale] for scale in scalers.split()]
+        if type_net == "simple":
+            self.model = DGNLayerSimple(in_dim=in_dim, out_dim=out_dim, dropout=dropout, graph_norm=graph_norm,
+                                        batch_norm=batch_norm, residual=residual, aggregators=aggregators,
+                                        scalers=scalers, avg_d=avg_d, posttrans_layers=posttrans_layers)
+        elif type_net == "complex":
+            self.model = DGNLayerComplex(in_dim=in_dim, out_dim=out_dim, dropout=dropout, graph_norm=graph_norm,
+                                         batch_norm=batch_norm, aggregators=aggregators, residual=residual,
+                                         scalers=scalers, avg_d=avg_d, edge_features=edge_features, edge_dim=edge_dim,
+                                         pretrans_layers=pretrans_layers, posttrans_layers=posttrans_layers)
+        elif type_net == "towers":
+            self.model = DGNLayerTower(in_dim=in_dim, out_dim=out_dim, aggregators=aggregators, scalers=scalers,
+                                       avg_d=avg_d, dropout=dropout, graph_norm=graph_norm, batch_norm=batch_norm,
+                                       towers=towers, pretrans_layers=pretrans_layers,
+                                       posttrans_layers=posttrans_layers, divide_input=divide_input, residual=residual,
+                                       edge_features=edge_features, edge_dim=edge_dim)

@@ -1,0 +1,182 @@
+"""Graph batch in the layout the HIP kernels sweep: CSR by destination.
+
+The reference hands a (batched) DGLGraph to every layer and lets DGL 0.4 bucket the
+destinations by in-degree on every call (realworld_benchmark/nets/dgn_layer.py:183-186;
+``dgl.batch`` in data/molecules.py:229).  Here the batch is converted ONCE into
+
+    indptr [N+1] int32, src [E] int32   slots of a destination in ascending edge id
+    eid    [E]   int64                  CSR slot -> original edge id (for edge features)
+    log_deg [N]  fp32                   (float) log((double)(in_degree + 1))  (scalers.py:13)
+    hub rows / slices                   rows longer than ``hub_threshold`` are cut in slices
+
+and the per-edge directional weights derived from ``eig`` are cached on the graph, so
+that the L layers (and all towers) of a forward pass share them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .spec import EPS, AggPlan, Channel
+
+HUB_THRESHOLD = 2048
+HUB_CHUNK = 1024
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class DGNGraph:
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None,
+                 hub_threshold: int = HUB_THRESHOLD, hub_chunk: int = HUB_CHUNK):
+        if src.shape != dst.shape or src.dim() != 1:
+            raise ValueError("src/dst must be 1-D tensors of equal length")
+        device = src.device
+        E = src.numel()
+        dst64 = dst.long()
+        # stable sort by destination keeps ascending edge id inside every row (DGL mailbox order)
+        _, perm = torch.sort(dst64, stable=True)
+        deg = torch.bincount(dst64, minlength=num_nodes)
+        indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
+        indptr[1:] = torch.cumsum(deg, 0)
+        self._init_csr(indptr, src.long()[perm], perm, num_nodes, E, deg, hub_threshold, hub_chunk)
+        self.ndata: Dict[str, torch.Tensor] = {}
+        self.edata: Dict[str, torch.Tensor] = {}
+        if eig is not None:
+            self.ndata["eig"] = eig
+
+    @classmethod
+    def from_csr(cls, indptr: torch.Tensor, src_csr: torch.Tensor, eid: Optional[torch.Tensor] = None,
+                 eig: Optional[torch.Tensor] = None, hub_threshold: int = HUB_THRESHOLD,
+                 hub_chunk: int = HUB_CHUNK) -> "DGNGraph":
+        """Adopt an existing destination-major CSR (no sort)."""
+        self = cls.__new__(cls)
+        n = indptr.numel() - 1
+        deg = (indptr[1:] - indptr[:-1]).long()
+        self._init_csr(indptr.long(), src_csr, eid, n, src_csr.numel(), deg, hub_threshold, hub_chunk)
+        self.ndata, self.edata = {}, {}
+        if eig is not None:
+            self.ndata["eig"] = eig
+        return self
+
+    def _init_csr(self, indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk):
+        if num_nodes >= 2 ** 31 - 1 or E >= 2 ** 31 - 1:
+            raise ValueError("graph exceeds the int32 CSR range")
+        device = indptr.device
+        self.device = device
+        self.num_nodes, self.num_edges = int(num_nodes), int(E)
+        self.indptr = indptr.to(torch.int32).contiguous()
+        self.src = src_csr.to(torch.int32).contiguous()
+        self.eid = eid  # None = identity (messages already in slot order)
+        self.in_degree = deg
+        self.log_deg = torch.log((deg + 1).double()).float().contiguous()
+        self.hub_threshold, self.hub_chunk = int(hub_threshold), int(hub_chunk)
+        hub_rows = torch.nonzero(deg > hub_threshold).flatten()
+        self.n_hub = int(hub_rows.numel())           # one host sync per graph build
+        self._keep = []
+        c = _lib.DgnGraph()
+        c.n_nodes, c.n_edges = self.num_nodes, self.num_edges
+        c.indptr, c.src = self.indptr.data_ptr(), self.src.data_ptr()
+        c.hub_threshold, c.hub_chunk = self.hub_threshold, self.hub_chunk
+        c.n_hub, c.n_chunks = 0, 0
+        if self.n_hub:
+            n_sl = (deg[hub_rows] + hub_chunk - 1) // hub_chunk
+            ptr = torch.zeros(self.n_hub + 1, dtype=torch.int64, device=device)
+            ptr[1:] = torch.cumsum(n_sl, 0)
+            chunk_hub = torch.repeat_interleave(torch.arange(self.n_hub, device=device), n_sl)
+            hub_rows_i, ptr_i, chunk_hub_i = hub_rows.int().contiguous(), ptr.int().contiguous(), chunk_hub.int().contiguous()
+            self._keep += [hub_rows_i, ptr_i, chunk_hub_i]
+            c.n_hub, c.n_chunks = self.n_hub, int(chunk_hub.numel())
+            c.hub_rows, c.hub_chunk_ptr, c.chunk_hub = hub_rows_i.data_ptr(), ptr_i.data_ptr(), chunk_hub_i.data_ptr()
+        self.n_chunks = int(c.n_chunks)
+        self._c = c
+        self._wcache: Dict[tuple, torch.Tensor] = {}
+
+    # ---- DGL-flavoured accessors used by the nets (duck typing) ----
+    def number_of_nodes(self) -> int:
+        return self.num_nodes
+
+    def number_of_edges(self) -> int:
+        return self.num_edges
+
+    @property
+    def c_graph(self) -> _lib.DgnGraph:
+        return self._c
+
+    def to_slot_order(self, per_edge: torch.Tensor) -> torch.Tensor:
+        """[E, ...] in original edge-id order -> CSR slot order (differentiable)."""
+        return per_edge if self.eid is None else per_edge.index_select(0, self.eid)
+
+    # ---- per-edge directional weights (cached per eig tensor version) ----
+    def edge_weights(self, plan: AggPlan, eig: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        if plan.n_channels == 0:
+            return None
+        eig = self.ndata["eig"] if eig is None else eig
+        if eig.device != self.device:
+            eig = eig.to(self.device)       # the reference keeps eig on the CPU (dgn_layer.py:157-159)
+        if eig.dtype != torch.float32 or eig.stride(-1) != 1:
+            eig = eig.float().contiguous()
+        key = (eig.data_ptr(), eig._version, tuple(eig.shape), plan.channels)
+        w = self._wcache.get(key)
+        if w is None:
+            w = compute_edge_weights(self, plan.channels, eig=eig)
+            if len(self._wcache) > 8:
+                self._wcache.clear()
+            self._wcache[key] = w
+            self._keep_eig = eig
+        return w
+
+
+def _channel_array(channels: Tuple[Channel, ...]):
+    arr = (_lib.DgnChannel * len(channels))()
+    for i, (kind, col, alpha) in enumerate(channels):
+        arr[i].kind, arr[i].eig_col, arr[i].alpha, arr[i].eps = kind, col, alpha, EPS
+    return arr
+
+
+def compute_edge_weights(graph: DGNGraph, channels: Tuple[Channel, ...], eig: Optional[torch.Tensor] = None,
+                         eig_s_edge: Optional[torch.Tensor] = None, eig_d_edge: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w [len(channels), E] fp32 in CSR slot order (dgn_edge_weights of the C ABI)."""
+    lib = _lib.load()
+    ref = eig if eig is not None else eig_s_edge
+    if ref is None or not ref.is_cuda:
+        raise _lib.DgnError("dgn_amd runs on the GPU only: eig must be a CUDA tensor")
+    E = graph.num_edges
+    w = torch.empty((len(channels), max(E, 1)), dtype=torch.float32, device=ref.device)
+    ld = ref.stride(0) if ref.dim() == 2 and ref.shape[0] > 0 else ref.shape[-1]
+    stream = torch.cuda.current_stream(ref.device).cuda_stream
+    for c0 in range(0, len(channels), _lib.DGN_MAX_CH):
+        chunk = channels[c0:c0 + _lib.DGN_MAX_CH]
+        for ch in chunk:
+            if ch[1] >= ref.shape[-1]:
+                raise IndexError(f"aggregator needs eig column {ch[1]} but eig has {ref.shape[-1]} columns")
+        nbytes = lib.dgn_edge_weights_workspace_bytes(C.byref(graph.c_graph), len(chunk))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
+        rc = lib.dgn_edge_weights(C.byref(graph.c_graph), _ptr(eig), _ptr(eig_s_edge), _ptr(eig_d_edge), ld, len(chunk),
+                                  _channel_array(chunk), w[c0:].data_ptr(), w.stride(0), _ptr(ws), nbytes, stream)
+        _lib.check(rc, "dgn_edge_weights")
+    return w
+
+
+def as_dgn_graph(g) -> DGNGraph:
+    """Accept a DGNGraph, or anything DGL-shaped (``edges()``/``all_edges()``, ``number_of_nodes()``,
+    ``ndata['eig']``): the converted batch is cached on the object."""
+    if isinstance(g, DGNGraph):
+        return g
+    cached = getattr(g, "_dgn_graph", None)
+    if cached is not None:
+        return cached
+    edges = g.all_edges(order="eid") if hasattr(g, "all_edges") else g.edges()
+    src, dst = edges[0], edges[1]
+    eig = g.ndata["eig"]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = DGNGraph(src.to(dev), dst.to(dev), g.number_of_nodes(), eig=eig.to(dev))
+    try:
+        g._dgn_graph = out
+    except Exception:
+        pass
+    return out

@@ -1,0 +1,162 @@
+"""``directional_aggregate``: the fused aggregation as a torch.autograd.Function over the C ABI.
+
+Replaces ``g.apply_edges(...)`` + ``g.update_all(message_func, reduce_func)`` of the
+reference layers (realworld_benchmark/nets/dgn_layer.py:183-186, :112-115, :261-264).
+GPU only; no CPU path exists in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .graph import DGNGraph, _ptr
+from .spec import EPS, AggPlan
+
+
+def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float):
+    key = (n_towers, float(avg_log))
+    cache = plan.__dict__.setdefault("_spec_cache", {})
+    if key not in cache:
+        specs = []
+        for l in plan.launches:
+            s = _lib.DgnAggSpec()
+            s.n_agg = len(l.ops)
+            for i, (op, ch) in enumerate(zip(l.ops, l.chs)):
+                s.agg_op[i], s.agg_ch[i] = op, ch
+            s.n_ch = len(l.channels)
+            s.n_scalers = plan.n_scalers
+            for i, k in enumerate(plan.applied_scalers):
+                s.scaler[i] = k
+            s.avg_log, s.eps, s.n_towers = float(avg_log), EPS, n_towers
+            s.agg_total, s.agg_offset = plan.n_agg, l.agg_offset
+            specs.append(s)
+        cache[key] = specs
+    return cache[key]
+
+
+def _check(t: Optional[torch.Tensor], name: str, rows: int, F: int):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.DgnError(f"{name} must be a CUDA tensor: dgn_amd has no CPU path")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[0] != rows or t.shape[1] != F or (F > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected fp32 [{rows}, {F}] with unit inner stride, got {tuple(t.shape)} {t.dtype} "
+                         f"strides {t.stride()}")
+
+
+def _ld(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def _msg_struct(F, x_src, x_dst, m_edge, x_in):
+    m = _lib.DgnMsg()
+    m.F = F
+    m.x_src, m.ld_src = _ptr(x_src), _ld(x_src)
+    m.x_dst, m.ld_dst = _ptr(x_dst), _ld(x_dst)
+    m.m_edge, m.ld_edge = _ptr(m_edge), _ld(m_edge)
+    m.x_in, m.ld_in = _ptr(x_in), _ld(x_in)
+    return m
+
+
+class _DirectionalAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in,
+                xin_is_src: bool):
+        lib = _lib.load()
+        ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
+        if ref is None:
+            raise ValueError("the message needs at least one of x_src / x_dst / m_edge")
+        F = ref.shape[1]
+        N, E = graph.num_nodes, graph.num_edges
+        _check(x_src, "x_src", N, F)
+        _check(x_dst, "x_dst", N, F)
+        _check(m_edge, "m_edge", E, F)
+        if xin_is_src:
+            x_in = x_src
+        _check(x_in, "x_in", N, F)
+        if plan.needs_x_in() and x_in is None:
+            raise ValueError("dx aggregators need x_in (h_in of reduce_func)")
+        if ref.device != graph.device:
+            raise ValueError(f"features on {ref.device} but graph on {graph.device}")
+        out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
+        stream = torch.cuda.current_stream(ref.device).cuda_stream
+        specs = _spec_structs(plan, n_towers, avg_log)
+        msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+        g = graph.c_graph
+        for spec, l in zip(specs, plan.launches):
+            nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
+            wl = w[l.ch_offset:] if (w is not None and l.channels) else None
+            rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                     graph.log_deg.data_ptr(), out.data_ptr(), out.stride(0), _ptr(ws), nbytes, stream)
+            _lib.check(rc, "dgn_agg_forward")
+        ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
+        ctx.has = (x_src is not None, x_dst is not None, m_edge is not None, x_in is not None and not xin_is_src)
+        ctx.save_for_backward(w, x_src, x_dst, m_edge, None if xin_is_src else x_in)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        graph, plan, F = ctx.graph, ctx.plan, ctx.F
+        w, x_src, x_dst, m_edge, x_in = ctx.saved_tensors
+        if ctx.xin_is_src:
+            x_in = x_src
+        g_out = g_out.contiguous()
+        need_src, need_dst, need_edge, need_in = ctx.needs_input_grad[5:9]
+        dev = g_out.device
+        g_src = torch.zeros_like(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
+        g_dst = torch.zeros_like(x_dst) if (x_dst is not None and need_dst) else None
+        g_edge = torch.empty_like(m_edge) if (m_edge is not None and need_edge) else None
+        if ctx.xin_is_src:
+            g_in = g_src
+        else:
+            g_in = torch.zeros_like(x_in) if (x_in is not None and need_in and plan.needs_x_in()) else None
+        grads = _lib.DgnMsgGrad()
+        grads.g_src, grads.ld_src = _ptr(g_src), _ld(g_src)
+        grads.g_dst, grads.ld_dst = _ptr(g_dst), _ld(g_dst)
+        grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
+        grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
+        msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        specs = _spec_structs(plan, ctx.n_towers, ctx.avg_log)
+        g = graph.c_graph
+        first_edge = True
+        for spec, l in zip(specs, plan.launches):
+            nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+            wl = w[l.ch_offset:] if (w is not None and l.channels) else None
+            if g_edge is not None and not first_edge:
+                # g_edge is overwritten by every launch: accumulate the slices on the host side
+                tmp = torch.empty_like(g_edge)
+                grads.g_edge = tmp.data_ptr()
+            rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                      graph.log_deg.data_ptr(), g_out.data_ptr(), g_out.stride(0), C.byref(grads),
+                                      _ptr(ws), nbytes, stream)
+            _lib.check(rc, "dgn_agg_backward")
+            if g_edge is not None and not first_edge:
+                g_edge += tmp
+                grads.g_edge = g_edge.data_ptr()
+            first_edge = False
+        if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
+            g_in = torch.zeros_like(x_in)
+        return (None, None, None, None, None, g_src if (need_src or ctx.xin_is_src) else None, g_dst, g_edge,
+                None if ctx.xin_is_src else g_in, None)
+
+
+def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Optional[torch.Tensor] = None,
+                          x_dst: Optional[torch.Tensor] = None, m_edge: Optional[torch.Tensor] = None,
+                          x_in: Optional[torch.Tensor] = None, eig: Optional[torch.Tensor] = None,
+                          n_towers: int = 1, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out [N, T*S*A*(F/T)]: every aggregator of ``plan`` x every applied scaler over the messages
+    ``m_j = x_src[src_j] + x_dst[i] + m_edge[j]`` (``m_edge`` in CSR slot order, see
+    ``DGNGraph.to_slot_order``).  ``x_in`` is ``h_in`` of the reference's reduce_func; if it is the
+    same tensor as ``x_src`` (simple layer) both gradients land in one buffer."""
+    avg = float(avg_log.item()) if torch.is_tensor(avg_log) else float(avg_log)
+    w = weights if weights is not None else graph.edge_weights(plan, eig)
+    xin_is_src = x_in is not None and x_in is x_src
+    return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, x_src, x_dst, m_edge,
+                                       None if xin_is_src else x_in, xin_is_src)

@@ -1,0 +1,175 @@
+/*
+ * dgn_hip.h -- C ABI of libdgn_hip.so: the MI355X (gfx950) implementation of the DGN
+ * directional-aggregation hot path.
+ *
+ * The reference (Saro00/DGN) is pure Python and has no FFI; what this library replaces is
+ * the span between `g.apply_edges(...)` and the end of `reduce_func` inside every DGN layer
+ * variant, i.e. (paths relative to the reference tree)
+ *
+ *   realworld_benchmark/nets/dgn_layer.py:183-186  (DGNLayerSimple:  apply_edges + update_all)
+ *   realworld_benchmark/nets/dgn_layer.py:112-115  (DGNLayerComplex: apply_edges + update_all)
+ *   realworld_benchmark/nets/dgn_layer.py:261-264  (DGNTower:        apply_edges + update_all)
+ *   realworld_benchmark/nets/dgn_layer.py:161-173  (reduce_func: aggregator concat, scaler concat)
+ *   realworld_benchmark/nets/aggregators.py:8-71   (the aggregators)
+ *   realworld_benchmark/nets/scalers.py:7-18       (the degree scalers)
+ *
+ * plus the autograd backward of all of the above.  The reference-side binding a maintainer
+ * would add (a ctypes stub called from a torch.autograd.Function) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C; every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *   - sizes/strides are int64_t, strides ("ld") are in ELEMENTS (floats), not bytes;
+ *   - every call enqueues on the caller's hipStream_t (passed as void*), never synchronises,
+ *     keeps no global mutable state, and is re-entrant from several host threads;
+ *   - return value: 0 = ok, < 0 = error (DGN_ERR_*); dgn_last_error() gives the thread-local text;
+ *   - the graph is CSR by DESTINATION: slot range [indptr[i], indptr[i+1]) holds the in-edges of
+ *     node i in ascending original edge id (the DGL mailbox order the oracle encodes).
+ */
+#ifndef DGN_HIP_H
+#define DGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGN_ABI_VERSION 1
+
+#define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
+#define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
+#define DGN_MAX_SCALERS 4  /* applied scalers                                                   */
+
+enum {
+    DGN_OK = 0,
+    DGN_ERR_INVALID = -1,   /* bad argument / unsupported shape                                 */
+    DGN_ERR_WORKSPACE = -2, /* workspace too small                                              */
+    DGN_ERR_HIP = -3        /* a HIP runtime call failed                                        */
+};
+
+/* aggregator op codes; `ch` = edge-weight channel the op reads (ignored by the first six)      */
+enum {
+    DGN_AGG_MEAN = 0,        /* aggregators.py:8   (1/d) sum_j m_j                              */
+    DGN_AGG_SUM = 1,         /* aggregators.py:31  sum_j m_j                                    */
+    DGN_AGG_MAX = 2,         /* aggregators.py:12                                               */
+    DGN_AGG_MIN = 3,         /* aggregators.py:16                                               */
+    DGN_AGG_STD = 4,         /* aggregators.py:20  sqrt(var + eps)                              */
+    DGN_AGG_VAR = 5,         /* aggregators.py:24  relu(mean(m^2) - mean(m)^2)                  */
+    DGN_AGG_DIR_AV = 6,      /* aggregators.py:35  sum_j |w_j| m_j            (ABSNORM channel) */
+    DGN_AGG_DIR_WSUM = 7,    /* aggregators.py:42  sum_j w_j m_j              (SOFTMAX channel) */
+    DGN_AGG_DIR_DX = 8,      /* aggregators.py:48/:62  |sum_j w_j m_j - (sum_j w_j) x_i|        */
+    DGN_AGG_DIR_DX_NO_ABS = 9 /* aggregators.py:55  sum_j w_j m_j - (sum_j w_j) x_i             */
+};
+
+/* edge-weight channel kinds: how delta_j = eig[src_j,k] - eig[dst,k] becomes a per-edge weight */
+enum {
+    DGN_W_ABSNORM = 0,  /* delta_j / (sum_j |delta_j| + eps)                 aggregators.py:49  */
+    DGN_W_BALANCED = 1, /* (relu(d)/(sum relu(d)+eps) + relu(-d)/(sum relu(-d)+eps)) / 2   :63-69 */
+    DGN_W_SOFTMAX = 2   /* softmax_j(alpha * |delta_j|)                      aggregators.py:43  */
+};
+
+/* degree scalers, scalers.py:7-18; D = in-degree, avg = avg_d['log']                           */
+enum {
+    DGN_SCALE_IDENTITY = 0,
+    DGN_SCALE_AMPLIFICATION = 1, /* x * (log(D+1) / avg)                                        */
+    DGN_SCALE_ATTENUATION = 2    /* x * (avg / log(D+1))                                        */
+};
+
+typedef struct DgnGraph {
+    int64_t n_nodes;
+    int64_t n_edges;
+    const int32_t* indptr;  /* [n_nodes+1]                                                       */
+    const int32_t* src;     /* [n_edges] source node of each CSR slot                            */
+    /* Rows with more than hub_threshold in-edges are "hub rows": the row kernels skip them and
+     * they are processed in slices of hub_chunk edges (partials in the workspace, then a combine).
+     * n_hub == 0 disables the mechanism.                                                        */
+    int64_t n_hub;
+    const int32_t* hub_rows;      /* [n_hub] node ids, ascending                                 */
+    const int32_t* hub_chunk_ptr; /* [n_hub+1] first chunk of every hub row                      */
+    int64_t n_chunks;
+    const int32_t* chunk_hub;     /* [n_chunks] index into hub_rows                              */
+    int32_t hub_threshold;
+    int32_t hub_chunk;
+} DgnGraph;
+
+typedef struct DgnChannel {
+    int32_t kind;     /* DGN_W_*                                                                 */
+    int32_t eig_col;  /* column k of eig                                                         */
+    float alpha;      /* SOFTMAX only                                                            */
+    float eps;        /* 1e-8 on the DGL path (aggregators.py:5)                                 */
+} DgnChannel;
+
+typedef struct DgnAggSpec {
+    int32_t n_agg;
+    int32_t agg_op[DGN_MAX_AGG];
+    int32_t agg_ch[DGN_MAX_AGG];
+    int32_t n_ch;                      /* channels referenced by agg_ch (0..DGN_MAX_CH)          */
+    int32_t n_scalers;                 /* scalers APPLIED; a lone scaler of any name is the
+                                          identity (dgn_layer.py:170)                            */
+    int32_t scaler[DGN_MAX_SCALERS];
+    float avg_log;                     /* avg_d['log']                                           */
+    float eps;                         /* EPS of aggregators.py:5, used by STD                   */
+    int32_t n_towers;                  /* T >= 1: output columns are laid out [T][S][A][F/T];
+                                          T == 1 is the reference order [S][A][F]                */
+    /* A launch may compute a slice of a longer aggregator list: the columns it writes are those of
+     * aggregators [agg_offset, agg_offset + n_agg) out of agg_total (0 = n_agg, offset 0).       */
+    int32_t agg_total;
+    int32_t agg_offset;
+} DgnAggSpec;
+
+/* The message of CSR slot j into node i is  m_j = x_src[src_j] + x_dst[i] + m_edge[j];
+ * any of the three terms may be NULL (at least one must be given).
+ *   simple layer:            x_src = h                                   (dgn_layer.py:154-155)
+ *   complex/towers, 1-layer pretrans:  x_src = h W_s^T, x_dst = h W_d^T + b (+ m_edge = ef W_e^T)
+ *   any other pretrans:      m_edge = materialised messages in CSR slot order
+ * x_in is h_in of reduce_func (dgn_layer.py:162), needed by the dx aggregators.                 */
+typedef struct DgnMsg {
+    int64_t F;
+    const float* x_src;  int64_t ld_src;   /* [n_nodes, ld_src]                                  */
+    const float* x_dst;  int64_t ld_dst;   /* [n_nodes, ld_dst]                                  */
+    const float* m_edge; int64_t ld_edge;  /* [n_edges, ld_edge], CSR slot order                 */
+    const float* x_in;   int64_t ld_in;    /* [n_nodes, ld_in]                                   */
+} DgnMsg;
+
+/* Gradient sinks of dgn_agg_backward.  g_src / g_dst / g_in are ACCUMULATED with atomic adds into
+ * caller-initialised buffers (they may alias each other: the simple layer passes one zeroed
+ * buffer for g_src and g_in); g_edge is overwritten.  NULL = not wanted.                        */
+typedef struct DgnMsgGrad {
+    float* g_src;  int64_t ld_src;
+    float* g_dst;  int64_t ld_dst;
+    float* g_edge; int64_t ld_edge;
+    float* g_in;   int64_t ld_in;
+} DgnMsgGrad;
+
+int dgn_abi_version(void);
+const char* dgn_last_error(void);
+
+/* Per-edge directional weights, once per (graph, eig): w[c*ld_w + j] for channel c, CSR slot j.
+ * Either eig [n_nodes, ld_eig] (gathered through src / the row id), or -- for the reference's
+ * mailbox-level function API (aggregators.py:74-93) -- eig_s_edge / eig_d_edge [n_edges, ld_eig]
+ * given per slot.  Replaces the eig_s/eig_d materialisation of dgn_layer.py:155 and the
+ * per-aggregator weight chains of aggregators.py:35-71.
+ * ws: workspace of at least dgn_edge_weights_workspace_bytes() bytes (hub rows only).          */
+size_t dgn_edge_weights_workspace_bytes(const DgnGraph* g, int32_t n_ch);
+int dgn_edge_weights(const DgnGraph* g, const float* eig, const float* eig_s_edge, const float* eig_d_edge,
+                     int64_t ld_eig, int32_t n_ch, const DgnChannel* ch, float* w, int64_t ld_w,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Fused gather -> directional weighting -> multi-aggregator reduce -> degree scalers, one CSR
+ * sweep.  out [n_nodes, ld_out], columns [T][S][A][F/T]; zero-in-degree rows are zeros.
+ * log_deg [n_nodes] = (float)log((double)(in_degree + 1))  (scalers.py:13 evaluates np.log in
+ * float64 and casts; the division by avg is done in fp32 like the reference).                  */
+size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F);
+int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                    const float* log_deg, float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of dgn_agg_forward for upstream gradient g_out [n_nodes, ld_gout].                  */
+int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                     const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
+                     void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGN_HIP_H */
