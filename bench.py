@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""DGN-layer forward+backward throughput on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2_b128|c1|c3|c4|c5]
+
+A "step" is one pass of the hot path over one batch of synthetic input: per-edge directional weights
+from eig, one DGN layer forward, one backward (fixed random cotangent), and -- for N > 1 -- the flat
+gradient all-reduce.  Inputs (graph CSR, features, eig) are resident in HBM before the timed region.
+The default workload is BASELINE.json configs[1]: ZINC-12k (all 12 000 molecules as one batch),
+DGN towers (5 towers, hidden 70, mean/max/min/dir1-av/dir1-dx, 3 PNA scalers).  For N > 1 every rank
+processes its own 12k-molecule batch (weak scaling), one rank per GPU over RCCL.
+
+Besides the contract keys the line carries
+  roofline      the dominant aggregation kernel's algorithmic bytes / its measured launch duration
+                (HIP events on the launching stream) against the 8 TB/s HBM peak
+  cpu_baseline  the oracle (reference-structured CPU restatement) timed on the host cores on a bounded
+                sample of the same workload -- rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import dgn_amd  # noqa: E402
+from dgn_amd import dist as ddist  # noqa: E402
+from dgn_amd import synth  # noqa: E402
+from dgn_amd.ops import launch_backward, launch_forward  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (generator kwargs, layer config)
+    "c2": dict(desc="ZINC-12k (12000 molecules, one batch), DGN towers: 5 towers, hidden 70, "
+                    "mean max min dir1-av dir1-dx x identity amplification attenuation",
+               gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
+               aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
+    "c2_b128": dict(desc="ZINC batch of 128 molecules, DGN towers (as c2)",
+                    gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
+                    aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
+    "c1": dict(desc="ZINC-12k, DGN simple: hidden 75, mean dir1-dx-no-abs x 3 scalers",
+               gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="simple", hidden=75,
+               aggregators="mean dir1-dx-no-abs", scalers="identity amplification attenuation", towers=1),
+    "c3": dict(desc="CIFAR10-superpixel-like, 128 graphs, 8-NN, DGN simple hidden 65, mean dir1-dx dir2-dx, identity",
+               gen=("knn", dict(n_graphs=128)), type_net="simple", hidden=65,
+               aggregators="mean dir1-dx dir2-dx", scalers="identity", towers=1),
+    "c4": dict(desc="ogbg-molhiv-like, batch 2048, DGN simple hidden 70, mean max min dir1-dx dir1-av x 3 scalers",
+               gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
+               hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
+    "c5": dict(desc="power-law 10M nodes / 200M edges, k=4 eig, hidden 128, forward only: "
+                    "mean max min sum std dir1-dx dir2-dx dir3-dx x 3 scalers",
+               gen=("powerlaw", dict(num_nodes=10_000_000, num_edges=200_000_000)), type_net="op", hidden=128,
+               aggregators="mean max min sum std dir1-dx dir2-dx dir3-dx", scalers="identity amplification attenuation",
+               towers=1),
+}
+
+
+def algorithmic_bytes(N, E, F, A, S, Ku, x, r):
+    """SURVEY.md section 8(d) / BASELINE.md section 4: fp32 values, int32 indices, gather model."""
+    fwd = E * (4 + 4 * F + 4 * Ku) + N * (4 + 4 * Ku + 4 * F * x + 4 * A * S * F)
+    bwd = E * (4 + 4 * Ku + 4 * F * r + 4 * F) + N * (4 + 4 * Ku + 4 * A * S * F + 4 * F * x)
+    return fwd, bwd
+
+
+def plan_model(plan):
+    ops = [op for l in plan.launches for op in l.ops]
+    x = int(any(op in (8, 9) for op in ops))
+    r = int(any(op in (2, 3, 4, 5) for op in ops))
+    return plan.n_agg, plan.n_scalers, plan.n_channels, x, r
+
+
+def event_ms(fn, reps, dev):
+    """Average duration of fn() over `reps` back-to-back enqueues, HIP events on the current stream."""
+    fn()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / reps
+
+
+def build_batch(wl, seed, dev):
+    kind, kw = wl["gen"]
+    if kind == "molecules":
+        b = synth.molecule_batch(seed=seed, **kw)
+    elif kind == "knn":
+        b = synth.knn_batch(seed=seed, **kw)
+    else:
+        raise ValueError(kind)
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), b["num_nodes"], eig=b["eig"].to(dev))
+    return b, graph
+
+
+def cpu_baseline(wl, batch, sample_graphs, reps=5):
+    """Oracle (reference-structured CPU restatement) layer fwd+bwd on the first `sample_graphs` graphs."""
+    from oracle import dgn_oracle as orc
+    sizes = batch["sizes"][:sample_graphs]
+    n = int(sizes.sum())
+    keep = batch["dst"] < n           # graphs are laid out consecutively; edges never cross graphs
+    src, dst = batch["src"][keep], batch["dst"][keep]
+    F_ = wl["hidden"]
+    gen = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(1.0)},
+                             wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=wl["aggregators"], scalers=wl["scalers"], avg_log=torch.tensor(1.0), graph_norm=True,
+               batch_norm=True, residual=True, towers=wl["towers"], divide_input=True, edge_features=False)
+    h = torch.randn(n, F_, generator=gen)
+    eig, snorm = batch["eig"][:n], batch["snorm_n"][:n]
+    ct = torch.randn(n, F_, generator=gen)
+
+    def step():
+        hh = h.clone().requires_grad_(True)
+        y, _ = orc.layer_forward(wl["type_net"], sd, cfg, src, dst, n, eig, hh, None, snorm, training=True)
+        y.backward(ct)
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=src.numel() / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"first {sample_graphs} graphs of the batch ({n} nodes, {src.numel()} edges), layer fwd+bwd, "
+                       f"{reps} timed passes of {dt * 1e3:.1f} ms, torch {torch.__version__} CPU",
+                host_cpus=os.cpu_count())
+
+
+def run_layer_workload(args, wl, rank, world, dev):
+    batch, graph = build_batch(wl, 41 + rank, dev)
+    F_ = wl["hidden"]
+    N, E = graph.num_nodes, graph.num_edges
+    torch.manual_seed(0)
+    avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
+                             wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev)
+    layer.train()
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    h = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = batch["snorm_n"].to(dev)
+    reducer = ddist.FlatGradAllReduce(layer.parameters()) if world > 1 else None
+
+    def step():
+        graph._wcache.clear()              # per-edge weights are recomputed every step (eig flips per batch)
+        h.grad = None
+        for p in layer.parameters():
+            p.grad = None
+        y = layer(graph, h, None, snorm)
+        y.backward(ct)
+        if reducer is not None:
+            reducer()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    ms = ddist.barrier_max_ms(ms, dev)
+    e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(e_total)
+    total_edges = float(e_total.item())
+
+    result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N)
+    if rank != 0:
+        return result
+
+    # ---- roofline of the aggregation kernels (same shapes the layer launches) ----
+    plan = layer.plan
+    T = wl["towers"] if wl["type_net"] == "towers" else 1
+    A, S, Ku, x, r = plan_model(plan)
+    w = graph.edge_weights(plan)
+    hd = h.detach()
+    if wl["type_net"] == "simple":
+        xs, xd = hd, None
+    else:
+        pq = torch.randn(N, 2 * F_, device=dev, generator=gen)
+        xs, xd = pq[:, :F_], pq[:, F_:]
+    out = torch.empty(N, plan.out_width(F_), device=dev)
+    g_out = torch.randn(N, plan.out_width(F_), device=dev, generator=gen)
+    g_src, g_dst, g_in = torch.zeros(N, F_, device=dev), (torch.zeros(N, F_, device=dev) if xd is not None else None), torch.zeros(N, F_, device=dev)
+    reps = 20
+    ms_f = event_ms(lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out), reps, dev)
+    ms_b = event_ms(lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in), reps, dev)
+    ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
+    bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
+    kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK),
+               "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK),
+               "ew_rows": dict(ms=ms_w)}
+    dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
+    result["roofline"] = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
+                              frac=kernels[dom]["frac"], traffic=None, kernels=kernels,
+                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r))
+    return result, batch
+
+
+def run_c5(args, wl, rank, world, dev):
+    """Single forward pass of the fused aggregation on the power-law graph (HBM-roofline run)."""
+    kw = dict(wl["gen"][1])
+    if args.scale != 1.0:
+        kw["num_nodes"] = int(kw["num_nodes"] * args.scale)
+        kw["num_edges"] = int(kw["num_edges"] * args.scale)
+    indptr, src, eig = synth.powerlaw_csr(device=dev, seed=rank, **kw)
+    graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    del indptr
+    N, E, F_ = graph.num_nodes, graph.num_edges, wl["hidden"]
+    plan = dgn_amd.make_plan(wl["aggregators"].split(), wl["scalers"].split())
+    avg_log = float(graph.log_deg.mean().item())
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    X = torch.randn(N, F_, device=dev, generator=gen)
+    out = torch.empty(N, plan.out_width(F_), device=dev)
+    w = graph.edge_weights(plan)
+
+    def step():
+        launch_forward(graph, plan, 1, avg_log, w, X, None, None, X, out)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    ms = ddist.barrier_max_ms((time.perf_counter() - t0) * 1e3 / args.steps, dev)
+    e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(e_total)
+    result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N)
+    if rank == 0:
+        A, S, Ku, x, r = plan_model(plan)
+        ms_f = event_ms(step, max(3, args.steps), dev)
+        ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=eig), 3, dev)
+        bf, _ = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
+        result["roofline"] = dict(bound="hbm", kernel="agg_fwd_rows+hub", achieved=bf / ms_f / 1e6, peak=HBM_PEAK / 1e9,
+                                  unit="GB/s", frac=bf / (ms_f * 1e-3) / HBM_PEAK, traffic=None,
+                                  kernels={"agg_fwd(all launches)": dict(ms=ms_f, bytes=bf), "edge_weights": dict(ms=ms_w)},
+                                  model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, n_hub=graph.n_hub,
+                                             n_slices=graph.n_chunks, max_degree=int(graph.in_degree.max().item())))
+    return result, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="c5 only: scale N and E")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
+    args = ap.parse_args()
+
+    rank, world, local = ddist.init_from_env("nccl")
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    wl = WORKLOADS[args.workload]
+    runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
+    res = runner(args, wl, rank, world, dev)
+    if rank != 0:
+        return
+    result, batch = res
+    line = dict(metric="dgn_layer_fwd_bwd_edges_per_sec" if wl["type_net"] != "op" else "dgn_aggregation_fwd_edges_per_sec",
+                value=result["value"], unit="edges/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                ms_per_step=result["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                data="synthetic",
+                config=dict(workload=args.workload + ": " + wl["desc"], edges_per_gpu=result["edges_per_rank"],
+                            nodes_per_gpu=result["nodes_per_rank"], type_net=wl["type_net"], hidden=wl["hidden"],
+                            aggregators=wl["aggregators"], scalers=wl["scalers"], towers=wl["towers"],
+                            parallelism=f"dp{world} (graphs sharded, flat-gradient all-reduce)" if world > 1 else "single GPU",
+                            step="edge weights + layer forward + backward" if wl["type_net"] != "op" else "aggregation forward"),
+                roofline=result.get("roofline"))
+    if world == 1 and not args.no_cpu_baseline and batch is not None:
+        line["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])))
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,60 @@ def _msg_struct(F, x_src, x_dst, m_edge, x_in):
     return m
 
 
+def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out):
+    """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream."""
+    lib = _lib.load()
+    ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
+    F = ref.shape[1]
+    stream = torch.cuda.current_stream(ref.device).cuda_stream
+    specs = _spec_structs(plan, n_towers, avg_log)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+    g = graph.c_graph
+    for spec, l in zip(specs, plan.launches):
+        nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
+        wl = w[l.ch_offset:] if (w is not None and l.channels) else None
+        rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                 graph.log_deg.data_ptr(), out.data_ptr(), out.stride(0), _ptr(ws), nbytes, stream)
+        _lib.check(rc, "dgn_agg_forward")
+
+
+def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, g_out,
+                    g_src, g_dst, g_edge, g_in):
+    """Enqueue dgn_agg_backward; g_src/g_dst/g_in are accumulated into, g_edge is overwritten."""
+    lib = _lib.load()
+    ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
+    F = ref.shape[1]
+    dev = g_out.device
+    grads = _lib.DgnMsgGrad()
+    grads.g_src, grads.ld_src = _ptr(g_src), _ld(g_src)
+    grads.g_dst, grads.ld_dst = _ptr(g_dst), _ld(g_dst)
+    grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
+    grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    specs = _spec_structs(plan, n_towers, avg_log)
+    g = graph.c_graph
+    first = True
+    for spec, l in zip(specs, plan.launches):
+        nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+        wl = w[l.ch_offset:] if (w is not None and l.channels) else None
+        tmp = None
+        if g_edge is not None and not first:
+            # g_edge is overwritten by every launch: accumulate the slices on the host side
+            tmp = torch.empty_like(g_edge)
+            grads.g_edge = tmp.data_ptr()
+        rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                  graph.log_deg.data_ptr(), g_out.data_ptr(), g_out.stride(0), C.byref(grads),
+                                  _ptr(ws), nbytes, stream)
+        _lib.check(rc, "dgn_agg_backward")
+        if tmp is not None:
+            g_edge += tmp
+            grads.g_edge = g_edge.data_ptr()
+        first = False
+
+
 class _DirectionalAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in,
@@ -82,17 +136,7 @@ class _DirectionalAggregate(torch.autograd.Function):
         if ref.device != graph.device:
             raise ValueError(f"features on {ref.device} but graph on {graph.device}")
         out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
-        stream = torch.cuda.current_stream(ref.device).cuda_stream
-        specs = _spec_structs(plan, n_towers, avg_log)
-        msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
-        g = graph.c_graph
-        for spec, l in zip(specs, plan.launches):
-            nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
-            wl = w[l.ch_offset:] if (w is not None and l.channels) else None
-            rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                     graph.log_deg.data_ptr(), out.data_ptr(), out.stride(0), _ptr(ws), nbytes, stream)
-            _lib.check(rc, "dgn_agg_forward")
+        launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out)
         ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
         ctx.has = (x_src is not None, x_dst is not None, m_edge is not None, x_in is not None and not xin_is_src)
         ctx.save_for_backward(w, x_src, x_dst, m_edge, None if xin_is_src else x_in)
@@ -115,32 +159,7 @@ class _DirectionalAggregate(torch.autograd.Function):
             g_in = g_src
         else:
             g_in = torch.zeros_like(x_in) if (x_in is not None and need_in and plan.needs_x_in()) else None
-        grads = _lib.DgnMsgGrad()
-        grads.g_src, grads.ld_src = _ptr(g_src), _ld(g_src)
-        grads.g_dst, grads.ld_dst = _ptr(g_dst), _ld(g_dst)
-        grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
-        grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
-        msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        specs = _spec_structs(plan, ctx.n_towers, ctx.avg_log)
-        g = graph.c_graph
-        first_edge = True
-        for spec, l in zip(specs, plan.launches):
-            nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
-            wl = w[l.ch_offset:] if (w is not None and l.channels) else None
-            if g_edge is not None and not first_edge:
-                # g_edge is overwritten by every launch: accumulate the slices on the host side
-                tmp = torch.empty_like(g_edge)
-                grads.g_edge = tmp.data_ptr()
-            rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                      graph.log_deg.data_ptr(), g_out.data_ptr(), g_out.stride(0), C.byref(grads),
-                                      _ptr(ws), nbytes, stream)
-            _lib.check(rc, "dgn_agg_backward")
-            if g_edge is not None and not first_edge:
-                g_edge += tmp
-                grads.g_edge = g_edge.data_ptr()
-            first_edge = False
+        launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in)
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
         return (None, None, None, None, None, g_src if (need_src or ctx.xin_is_src) else None, g_dst, g_edge,
