@@ -184,7 +184,9 @@ def run_layer_workload(args, wl, rank, world, dev):
         return result
 
     # ---- roofline of the aggregation kernels (same shapes the layer launches) ----
-    plan = layer.plan
+    # the plan the layer actually launches: the degree scalers are folded into posttrans, so the sweep
+    # runs with S = 1 (dgn_amd/dgn_layer.py: _fold_scalers) and its algorithmic bytes are counted as such
+    plan = layer._kplan
     T = wl["towers"] if wl["type_net"] == "towers" else 1
     A, S, Ku, x, r = plan_model(plan)
     w = graph.edge_weights(plan)

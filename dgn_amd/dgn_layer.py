@@ -23,7 +23,8 @@ import torch.nn.functional as F
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
 from .ops import directional_aggregate
-from .spec import AGGREGATOR_NAMES, SCALER_NAMES, make_plan, parse_aggregator, parse_scaler
+from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, make_plan, parse_aggregator,
+                   parse_scaler)
 
 
 class _Named:
@@ -87,6 +88,37 @@ def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
     return None, None, pretrans(torch.cat(z, dim=1))
 
 
+def _scale_table(graph: DGNGraph, kinds, avg_log: float) -> torch.Tensor:
+    """[N, S] degree-scaler factors of scalers.py:7-18 (log in fp64 -> fp32, fp32 division)."""
+    key = (tuple(kinds), float(avg_log))
+    cache = graph.__dict__.setdefault("_scale_cache", {})
+    if key not in cache:
+        logd = graph.log_deg
+        cols = []
+        for k in kinds:
+            if k == SCALE_IDENTITY:
+                cols.append(torch.ones_like(logd))
+            elif k == SCALE_AMPLIFICATION:
+                cols.append(logd / avg_log)
+            else:
+                # zero in-degree rows aggregate to 0; keep avg/log(1) = inf out of 0 * inf
+                cols.append(torch.where(graph.in_degree > 0, avg_log / logd, torch.zeros_like(logd)))
+        cache[key] = torch.stack(cols, dim=1).contiguous()
+    return cache[key]
+
+
+def _fold_scalers(weight, agg, sc):
+    """``cat_s(scale_s * agg) @ weight^T`` evaluated as ``sum_s scale_s * (agg @ W_s^T)``: the degree
+    scalers are per-row factors, so they commute with the post-aggregation Linear.  The sweep then
+    writes (and the GEMM reads) ``[N, A*F]`` instead of ``[N, S*A*F]``.
+    weight [Fo, S*K], agg [N, K], sc [N, S] -> [N, Fo]"""
+    N, K = agg.shape
+    Fo, S = weight.shape[0], sc.shape[1]
+    w = weight.reshape(Fo, S, K).permute(1, 0, 2).reshape(S * Fo, K)
+    z = F.linear(agg, w)                                        # [N, S*Fo]
+    return (z.view(N, S, Fo) * sc.unsqueeze(-1)).sum(dim=1)
+
+
 def _posttrans_split(posttrans: MLP, h, agg, in_dim):
     """posttrans(cat([h, agg])) without building the concat when posttrans is one Linear."""
     if posttrans.is_single_affine():
@@ -104,6 +136,7 @@ class DGNLayerSimple(nn.Module):
         self.dropout, self.graph_norm, self.batch_norm, self.residual = dropout, graph_norm, batch_norm, residual
         self.aggregators, self.scalers = _names(aggregators), _names(scalers)
         self.plan = make_plan(self.aggregators, self.scalers)
+        self._kplan = make_plan(self.aggregators, ["identity"])      # sweep without scalers (folded into posttrans)
         self.batchnorm_h = nn.BatchNorm1d(out_dim)
         self.posttrans = MLP(in_size=(len(self.aggregators) * len(self.scalers)) * in_dim, hidden_size=out_dim,
                              out_size=out_dim, layers=posttrans_layers, mid_activation="relu", last_activation="none")
@@ -112,13 +145,19 @@ class DGNLayerSimple(nn.Module):
         if in_dim != out_dim:
             self.residual = False
 
-    def aggregate(self, g, h):
+    def aggregate(self, g, h, plan=None):
         graph = as_dgn_graph(g)
-        return directional_aggregate(graph, self.plan, self._avg_log, x_src=h, x_in=h, eig=g.ndata["eig"])
+        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=h, x_in=h, eig=g.ndata["eig"])
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
-        h = self.posttrans(self.aggregate(g, h))
+        if self.posttrans.is_single_affine() and self.plan.n_scalers > 1:
+            graph = as_dgn_graph(g)
+            lin = self.posttrans.fully_connected[0].linear
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+            h = _fold_scalers(lin.weight, self.aggregate(graph, h, self._kplan), sc) + lin.bias
+        else:
+            h = self.posttrans(self.aggregate(g, h))
         if self.graph_norm:
             h = h * snorm_n
         if self.batch_norm:
@@ -139,6 +178,7 @@ class DGNLayerComplex(nn.Module):
         self.edge_features, self.residual, self.in_dim = edge_features, residual, in_dim
         self.aggregators, self.scalers = _names(aggregators), _names(scalers)
         self.plan = make_plan(self.aggregators, self.scalers)
+        self._kplan = make_plan(self.aggregators, ["identity"])
         self.batchnorm_h = nn.BatchNorm1d(out_dim)
         self.pretrans = MLP(in_size=2 * in_dim + (edge_dim if edge_features else 0), hidden_size=in_dim,
                             out_size=in_dim, layers=pretrans_layers, mid_activation="relu", last_activation="none")
@@ -149,15 +189,22 @@ class DGNLayerComplex(nn.Module):
         if in_dim != out_dim:
             self.residual = False
 
-    def aggregate(self, g, h, e):
+    def aggregate(self, g, h, e, plan=None):
         graph = as_dgn_graph(g)
         x_src, x_dst, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
-        return directional_aggregate(graph, self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge, x_in=h,
-                                     eig=g.ndata["eig"])
+        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge,
+                                     x_in=h, eig=g.ndata["eig"])
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
-        h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
+        if self.posttrans.is_single_affine() and self.plan.n_scalers > 1:
+            graph = as_dgn_graph(g)
+            lin = self.posttrans.fully_connected[0].linear
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+            h = (_fold_scalers(lin.weight[:, self.in_dim:], self.aggregate(graph, h, e, self._kplan), sc)
+                 + F.linear(h, lin.weight[:, :self.in_dim], lin.bias))
+        else:
+            h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
         if self.graph_norm:
             h = h * snorm_n
         if self.batch_norm:
@@ -227,6 +274,7 @@ class DGNLayerTower(nn.Module):
                                         graph_norm=graph_norm, edge_features=edge_features, edge_dim=edge_dim))
         self.mixing_network = FCLayer(out_dim, out_dim, activation="LeakyReLU")
         self.plan = self.towers[0].plan
+        self._kplan = make_plan(self.plan.aggregators, ["identity"])
         self._avg_log = _avg_log(avg_d)
 
     def _fusable(self) -> bool:
@@ -252,14 +300,23 @@ class DGNLayerTower(nn.Module):
         m_edge = None
         if self.edge_features:
             m_edge = F.linear(graph.to_slot_order(e), torch.cat([l.weight[:, 2 * fi:] for l in lins], dim=0))
-        agg = directional_aggregate(graph, self.plan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
-                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T)      # [N, T, S*A*fi]
+        # the sweep runs WITHOUT scalers: they are per-row factors and are folded into posttrans below
+        agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
+                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T)      # [N, T, A*fi]
         posts = [t.posttrans.fully_connected[0].linear for t in self.towers]
-        w_a = torch.stack([l.weight[:, fi:] for l in posts])                         # [T, fo, S*A*fi]
+        S = self.plan.n_scalers
+        N = h.shape[0]
+        K = agg.shape[1] // T
+        w_a = torch.stack([l.weight[:, fi:] for l in posts])                         # [T, fo, S*K]
         w_h = torch.stack([l.weight[:, :fi] for l in posts])                         # [T, fo, fi]
         b_p = torch.stack([l.bias for l in posts])                                   # [T, fo]
-        N = h.shape[0]
-        y = torch.bmm(agg.view(N, T, -1).transpose(0, 1), w_a.transpose(1, 2))       # [T, N, fo]
+        w_a = w_a.view(T, fo, S, K).permute(0, 2, 1, 3).reshape(T, S * fo, K)
+        z = torch.bmm(agg.view(N, T, K).transpose(0, 1), w_a.transpose(1, 2))        # [T, N, S*fo]
+        if S > 1:
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)       # [N, S]
+            y = (z.view(T, N, S, fo) * sc.view(1, N, S, 1)).sum(dim=2)               # [T, N, fo]
+        else:
+            y = z
         h_t = x_in.view(N, T, fi).transpose(0, 1)
         y = y + torch.bmm(h_t, w_h.transpose(1, 2)) + b_p.unsqueeze(1)
         y = y.transpose(0, 1).reshape(N, T * fo)

@@ -1,0 +1,30 @@
+"""Test-only stand-in for dgn_amd.ops.directional_aggregate backed by the CPU oracle, so that the host
+logic around the kernels (layer algebra, data-parallel harness) can be exercised without a GPU.
+It is installed by monkeypatching inside tests; the product package never imports it."""
+import torch
+
+from oracle import dgn_oracle as orc
+
+
+def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m_edge=None, x_in=None, eig=None,
+                                 n_towers=1, weights=None):
+    src = graph.src.long()
+    dst = torch.repeat_interleave(torch.arange(graph.num_nodes), graph.in_degree)
+    msg = 0
+    if x_src is not None:
+        msg = msg + x_src[src]
+    if x_dst is not None:
+        msg = msg + x_dst[dst]
+    if m_edge is not None:
+        msg = msg + m_edge
+    eig = graph.ndata["eig"] if eig is None else eig
+    F_ = msg.shape[1]
+    if x_in is None:
+        x_in = torch.zeros(graph.num_nodes, F_)
+    avg = torch.tensor(float(avg_log))
+    out = orc.aggregate_graph(src, dst, graph.num_nodes, msg, eig, x_in, list(plan.aggregators), list(plan.scalers), avg)
+    if n_towers > 1:      # [S][A][T][Ft] -> [T][S][A][Ft]
+        N = out.shape[0]
+        SA = out.shape[1] // F_
+        out = out.view(N, SA, n_towers, F_ // n_towers).permute(0, 2, 1, 3).reshape(N, -1)
+    return out

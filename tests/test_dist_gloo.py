@@ -1,0 +1,173 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes.  Graphs are sharded by edge count, every rank runs
+the layer on its shard, ONE flat all-reduce averages the gradients.  Checked against a single process
+that runs the same shards sequentially and averages the gradients (BatchNorm sees per-shard statistics in
+both).  The aggregation itself is served by the oracle here (tests/oracle_backend.py);
+the product kernels are GPU-only and are covered by the -m gpu tests."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_problem():
+    from dgn_amd import synth
+    b = synth.molecule_batch(12, seed=5, laplacian_eig=False)
+    sizes = b["sizes"].tolist()
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    gid_of_node = torch.repeat_interleave(torch.arange(len(sizes)), b["sizes"])
+    edge_gid = gid_of_node[b["dst"]]
+    edges_per_graph = torch.bincount(edge_gid, minlength=len(sizes)).tolist()
+    gen = torch.Generator().manual_seed(1)
+    h = torch.randn(b["num_nodes"], 10, generator=gen)
+    return b, offs, edge_gid, edges_per_graph, h
+
+
+def _shard_batch(b, offs, edge_gid, h, graph_ids):
+    """Sub-batch holding the given graphs (relabelled consecutively)."""
+    import dgn_amd
+    node_chunks, src, dst, new_off = [], [], [], 0
+    for gi in graph_ids:
+        lo, hi = offs[gi], offs[gi + 1]
+        m = edge_gid == gi
+        src.append(b["src"][m] - lo + new_off)
+        dst.append(b["dst"][m] - lo + new_off)
+        node_chunks.append(torch.arange(lo, hi))
+        new_off += hi - lo
+    nodes = torch.cat(node_chunks)
+    g = dgn_amd.DGNGraph(torch.cat(src), torch.cat(dst), new_off, eig=b["eig"][nodes])
+    return g, h[nodes], b["snorm_n"][nodes]
+
+
+def _build_layer():
+    import dgn_amd
+    torch.manual_seed(3)
+    layer = dgn_amd.DGNLayer(10, 10, 0.0, True, True, "mean max dir1-dx dir1-av", "identity amplification attenuation",
+                             {"log": torch.tensor(1.0)}, "towers", True, towers=5, edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+    return layer
+
+
+def _install_oracle_backend():
+    import dgn_amd.dgn_layer as dl
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import oracle_directional_aggregate
+    dl.directional_aggregate = oracle_directional_aggregate
+
+
+def _loss_backward(layer, g, h, snorm):
+    for p in layer.parameters():
+        p.grad = None
+    y = layer(g, h, None, snorm)
+    (y * y).mean().backward()
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from dgn_amd import dist as ddist
+    r, w, _ = ddist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    _install_oracle_backend()
+    b, offs, edge_gid, epg, h = _make_problem()
+    shards = ddist.shard_by_edges(epg, world)
+    layer = _build_layer()
+    g, hs, sn = _shard_batch(b, offs, edge_gid, h, shards[rank])
+    _loss_backward(layer, g, hs, sn)
+    ddist.FlatGradAllReduce(layer.parameters())()
+    if rank == 0:
+        torch.save({n: p.grad.clone() for n, p in layer.named_parameters()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_by_edges_balances():
+    from dgn_amd.dist import shard_by_edges
+    counts = [50, 10, 40, 30, 20, 60, 5, 45]
+    shards = shard_by_edges(counts, 3)
+    assert sorted(i for s in shards for i in s) == list(range(len(counts)))
+    loads = [sum(counts[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= max(counts)
+    assert shard_by_edges(counts, 3) == shards          # deterministic
+    assert shard_by_edges(counts, 1) == [list(range(len(counts)))]
+
+
+@pytest.mark.timeout(300)
+def test_dp_gradients_match_sequential_shards(tmp_path):
+    world = 2
+    out_path = str(tmp_path / "grads.pt")
+    mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = torch.load(out_path)
+
+    # single process: the same shards one after the other, gradients averaged
+    from dgn_amd import dist as ddist
+    import dgn_amd.dgn_layer as dl
+    saved = dl.directional_aggregate
+    try:
+        _install_oracle_backend()
+        b, offs, edge_gid, epg, h = _make_problem()
+        shards = ddist.shard_by_edges(epg, world)
+        acc = None
+        for rnk in range(world):
+            layer = _build_layer()
+            g, hs, sn = _shard_batch(b, offs, edge_gid, h, shards[rnk])
+            _loss_backward(layer, g, hs, sn)
+            grads = {n: p.grad.clone() for n, p in layer.named_parameters()}
+            acc = grads if acc is None else {n: acc[n] + grads[n] for n in acc}
+        want = {n: v / world for n, v in acc.items()}
+    finally:
+        dl.directional_aggregate = saved
+    assert set(got) == set(want)
+    for n in want:
+        torch.testing.assert_close(got[n], want[n], rtol=1e-5, atol=1e-6, msg=n)
+
+
+def test_layer_algebra_matches_reference_on_cpu(golden):
+    """Host-side layer algebra (P/Q pretrans decomposition, all towers in one sweep, scaler folding, split
+    posttrans) against the reference's layer outputs, with the aggregation served by the oracle."""
+    import numpy as np
+    import dgn_amd
+    import dgn_amd.dgn_layer as dl
+    saved = dl.directional_aggregate
+    T = torch.from_numpy
+    try:
+        _install_oracle_backend()
+        g = golden("g4_layers")
+        src, dst, N = T(g["src"]), T(g["dst"]), int(g["N"])
+        for name in g["cases"].tolist():
+            meta = g[f"{name}/meta"].tolist()
+            layer = dgn_amd.DGNLayer(in_dim=int(meta[1]), out_dim=int(meta[2]), dropout=0.0, graph_norm=True, batch_norm=True,
+                                     aggregators=meta[3], scalers=meta[4], avg_d={"log": torch.tensor(float(meta[5]))},
+                                     type_net=meta[0], residual=True, towers=int(meta[6]), divide_input=bool(int(meta[7])),
+                                     edge_features=bool(int(meta[8])), edge_dim=int(meta[9]),
+                                     pretrans_layers=int(meta[10]), posttrans_layers=int(meta[11])).model
+            layer.load_state_dict({k[len(name) + 5:]: T(g[k]) for k in g.files if k.startswith(f"{name}/sd::")})
+            layer.train(bool(int(meta[12])))
+            graph = dgn_amd.DGNGraph(src, dst, N, eig=T(g[f"{name}/eig"]))
+            h = T(g[f"{name}/h"]).clone().requires_grad_(True)
+            e = T(g[f"{name}/e"]).clone().requires_grad_(True)
+            y = layer(graph, h, e, T(g["snorm_n"]))
+            np.testing.assert_allclose(y.detach().numpy(), g[f"{name}/y"], rtol=2e-5, atol=2e-5, err_msg=name)
+    finally:
+        dl.directional_aggregate = saved
