@@ -76,6 +76,17 @@ def plan_model(plan):
     return plan.n_agg, plan.n_scalers, plan.n_channels, x, r
 
 
+def pmc_traffic(tag, kernels):
+    """HBM bytes per launch of `kernels` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    produced by tools/gpu_profile.sh + tools/profile_report.py for the same bench command); None if absent.
+    bytes = 2 * FETCH_SIZE * 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request) + WRITE_SIZE * 1024."""
+    try:
+        data = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[tag]["kernels"]
+        return sum(2 * 1024 * data[k]["FETCH_SIZE_KiB"] + 1024 * data[k]["WRITE_SIZE_KiB"] for k in kernels)
+    except Exception:
+        return None
+
+
 def event_ms(fn, reps, dev):
     """Average duration of fn() over `reps` back-to-back enqueues, HIP events on the current stream."""
     fn()
@@ -209,7 +220,7 @@ def run_layer_workload(args, wl, rank, world, dev):
                "ew_rows": dict(ms=ms_w)}
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     result["roofline"] = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
-                              frac=kernels[dom]["frac"], traffic=None, kernels=kernels,
+                              frac=kernels[dom]["frac"], traffic=pmc_traffic(args.workload, [dom]), kernels=kernels,
                               model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r))
     return result, batch
 
@@ -256,7 +267,9 @@ def run_c5(args, wl, rank, world, dev):
         ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=eig), 3, dev)
         bf, _ = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
         result["roofline"] = dict(bound="hbm", kernel="agg_fwd_rows+hub", achieved=bf / ms_f / 1e6, peak=HBM_PEAK / 1e9,
-                                  unit="GB/s", frac=bf / (ms_f * 1e-3) / HBM_PEAK, traffic=None,
+                                  unit="GB/s", frac=bf / (ms_f * 1e-3) / HBM_PEAK,
+                                  traffic=pmc_traffic("c5", ["agg_fwd_rows", "agg_hub_slices", "agg_fwd_hub_combine"])
+                                  if args.scale == 1.0 and not args.aggregators and not args.scalers else None,
                                   kernels={"agg_fwd(all launches)": dict(ms=ms_f, bytes=bf), "edge_weights": dict(ms=ms_w)},
                                   model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, n_hub=graph.n_hub,
                                              n_slices=graph.n_chunks, max_degree=int(graph.in_degree.max().item())))
