@@ -631,19 +631,8 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
     float fac[DGN_MAX_SCALERS];
 #pragma unroll
     for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < p.n_scalers ? scaler_factor(scaler_kind(p, s), logd, p.avg_log) : 0.f;
-    for (int a = 0; a < p.n_agg; ++a) {
-        float g[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
-            if (s < p.n_scalers) {
-                float t[VEC];
-                ldv<VEC>(t, grow + sa_col(p, s, a));
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) g[i] += scaler_kind(p, s) == DGN_SCALE_IDENTITY ? t[i] : t[i] * fac[s];
-            }
-        }
+    // one aggregator's share of the coefficients, given its upstream gradient g (scalers already summed in)
+    auto apply = [&](int a, const float (&g)[VEC]) {
         const int op = agg_op(p, a);
         const int c = agg_ch(p, a);
         if (op < DGN_AGG_DIR_AV) {
@@ -661,7 +650,7 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
                     k.c0[i] -= t * st.mean[i];
                 }
             }
-            continue;
+            return;
         }
         float wsv[VEC], wav[VEC], swv, dcs[VEC], dca[VEC];
         pick_channel<C, true>(wsv, wav, swv, acc, c);
@@ -689,6 +678,61 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
                 for (int i = 0; i < VEC; ++i) {
                     k.cs[cc][i] += dcs[i];
                     if constexpr (C::AV) k.ca[cc][i] += dca[i];
+                }
+            }
+        }
+    };
+    // The upstream-gradient loads of several aggregators are issued together (tiles of 4 aggregators when
+    // there is one scaler, 2 otherwise): a one-at-a-time loop would be a chain of n_agg dependent latencies.
+    if (p.n_scalers == 1) {
+        constexpr int AT = 4;
+        for (int a0 = 0; a0 < p.n_agg; a0 += AT) {
+            float t[AT][VEC];
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) t[j][i] = 0.f;
+                if (a0 + j < p.n_agg) ldv<VEC>(t[j], grow + sa_col(p, 0, a0 + j));
+            }
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+                if (a0 + j < p.n_agg) {
+                    if (scaler_kind(p, 0) != DGN_SCALE_IDENTITY) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) t[j][i] *= fac[0];
+                    }
+                    apply(a0 + j, t[j]);
+                }
+            }
+        }
+    } else {
+        constexpr int AT = 2;
+        for (int a0 = 0; a0 < p.n_agg; a0 += AT) {
+            float t[AT][DGN_MAX_SCALERS][VEC];
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+#pragma unroll
+                for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) t[j][s][i] = 0.f;
+                    if (a0 + j < p.n_agg && s < p.n_scalers) ldv<VEC>(t[j][s], grow + sa_col(p, s, a0 + j));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < AT; ++j) {
+                if (a0 + j < p.n_agg) {
+                    float g[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
+                        if (s < p.n_scalers) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i)
+                                g[i] += scaler_kind(p, s) == DGN_SCALE_IDENTITY ? t[j][s][i] : t[j][s][i] * fac[s];
+                        }
+                    }
+                    apply(a0 + j, g);
                 }
             }
         }
@@ -739,8 +783,12 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
             }
             if (p.g_src) {
                 float* dst = p.g_src + (int64_t)s * p.ldg_src + f0;
+#ifdef DGN_EXP_NOATOMIC
+                stv<VEC>(dst, gm);
+#else
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gm[i]);
+#endif
             }
             if (p.g_edge) stv<VEC>(p.g_edge + (int64_t)pos * p.ldg_edge + f0, gm);
         }

@@ -37,6 +37,39 @@ class _Named:
         return f"<{self.__class__.__name__} {self.name}>"
 
 
+class _Aggregator(_Named):
+    """``AGGREGATORS[name](h, eig_s, eig_d, h_in)`` with the reference's mailbox-level signature
+    (nets/aggregators.py:8-71): ``h [n, D, F]`` messages, ``eig_s/eig_d [n, D, K]``, ``h_in [n, F]`` -> ``[n, F]``.
+    Runs on the HIP kernels: the mailbox is a CSR with constant degree D and slot-level eig inputs."""
+
+    def __call__(self, h, eig_s, eig_d, h_in):
+        import numpy as np  # noqa: F401  (kept local: only this convenience path needs nothing else)
+        from .graph import compute_edge_weights
+        n, D, F_ = h.shape
+        dev = h.device
+        indptr = torch.arange(0, (n + 1) * D, D, dtype=torch.int64, device=dev)
+        g = DGNGraph.from_csr(indptr, torch.zeros(n * D, dtype=torch.int64, device=dev))
+        plan = make_plan([self.name], ["identity"])
+        w = None
+        if plan.n_channels:
+            w = compute_edge_weights(g, plan.channels, eig_s_edge=eig_s.reshape(n * D, -1).float().contiguous(),
+                                     eig_d_edge=eig_d.reshape(n * D, -1).float().contiguous())
+        return directional_aggregate(g, plan, 1.0, m_edge=h.reshape(n * D, F_), x_in=h_in, weights=w)
+
+
+class _Scaler(_Named):
+    """``SCALERS[name](h, D, avg_d)`` (nets/scalers.py:7-18): D is the python-int degree of the bucket."""
+
+    def __call__(self, h, D=None, avg_d=None):
+        import numpy as np
+        kind = parse_scaler(self.name)
+        if kind == SCALE_IDENTITY:
+            return h
+        if kind == SCALE_AMPLIFICATION:
+            return h * (np.log(D + 1) / avg_d["log"])
+        return h * (avg_d["log"] / np.log(D + 1))
+
+
 class _Registry(dict):
     def __init__(self, names, parser, cls):
         super().__init__()
@@ -50,8 +83,8 @@ class _Registry(dict):
         return self[key]
 
 
-AGGREGATORS = _Registry(AGGREGATOR_NAMES, parse_aggregator, _Named)   # nets/aggregators.py:74-93
-SCALERS = _Registry(SCALER_NAMES, parse_scaler, _Named)              # nets/scalers.py:21
+AGGREGATORS = _Registry(AGGREGATOR_NAMES, parse_aggregator, _Aggregator)   # nets/aggregators.py:74-93
+SCALERS = _Registry(SCALER_NAMES, parse_scaler, _Scaler)              # nets/scalers.py:21
 
 
 def _names(items: Sequence) -> List[str]:

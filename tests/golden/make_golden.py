@@ -368,10 +368,90 @@ def g5_edge_cases(out):
             out[f"{cname}/{name}/gx"] = (gx if gx is not None else torch.zeros_like(x)).numpy()
 
 
+def _dense_inputs(seed, B, N, F_, K, weighted):
+    g = torch.Generator().manual_seed(seed)
+    adj = (torch.rand(B, N, N, generator=g) < 0.45).float()
+    idx = torch.arange(N)
+    adj[:, idx, idx] = 0
+    adj[:, idx, (idx + 1) % N] = 1          # a ring: no isolated row / column
+    if weighted:
+        adj = adj * (0.5 + torch.rand(B, N, N, generator=g))      # asymmetric positive weights
+    else:
+        adj = ((adj + adj.transpose(1, 2)) > 0).float()
+    X = torch.randn(B, N, N, F_, generator=g)
+    eig = torch.rand(B, N, K, generator=g) * 2 - 1
+    return X, adj, eig
+
+
+def g6_dense(out):
+    """Dense formulation models/pytorch/*: every aggregator that runs on a modern torch, all scalers, and the
+    dense DGNLayer with 1 and 2 towers."""
+    from models.pytorch.aggregators import AGGREGATORS
+    from models.pytorch.scalers import SCALERS
+    from models.pytorch.dgn_layer import DGNLayer
+    names = [n for n in sorted(AGGREGATORS) if n not in ("softmax", "softmin")]
+    out["names"] = np.array(names)
+    out["broken"] = np.array(["softmax", "softmin"])
+    avg_d = {"log": torch.tensor(1.2), "lin": torch.tensor(3.5)}
+    out["avg_log"], out["avg_lin"] = np.array(1.2, dtype=np.float32), np.array(3.5, dtype=np.float32)
+    cases = {"bin6": (11, 2, 6, 3, 6, False), "wgt10": (12, 2, 10, 3, 6, True)}
+    out["cases"] = np.array(sorted(cases))
+    for cname, (seed, B, N, F_, K, weighted) in cases.items():
+        X, adj, eig = _dense_inputs(seed, B, N, F_, K, weighted)
+        out[f"{cname}/X"], out[f"{cname}/adj"], out[f"{cname}/eig"] = X.numpy(), adj.numpy(), eig.numpy()
+        for self_loop in (False, True):
+            for name in names:
+                XX = X.clone().requires_grad_(True)
+                y = AGGREGATORS[name](XX, adj, eigvec=eig, self_loop=self_loop, device="cpu", avg_d=avg_d)
+                ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+                (gX,) = torch.autograd.grad(y, XX, ct)
+                tag = f"{cname}/sl{int(self_loop)}/{name}"
+                out[f"{tag}/y"], out[f"{tag}/cot"], out[f"{tag}/gX"] = y.detach().numpy(), ct.numpy(), gX.numpy()
+        m = torch.randn(B, N, 4, generator=torch.Generator().manual_seed(2))
+        out[f"{cname}/scaler_in"] = m.numpy()
+        for sname in sorted(SCALERS):
+            out[f"{cname}/scaler/{sname}"] = SCALERS[sname](m, adj, avg_d=avg_d).numpy()
+    # dense layers
+    layer_cases = {"dense_t1": (1, ["mean", "max", "min", "std", "dir1-dx", "dir2-smooth"], ["identity", "amplification", "attenuation"], 6, 8, "bin6"),
+                   "dense_t2": (2, ["sum", "var", "dir1-both", "moment3", "normalised_mean"], ["identity", "linear", "inverse_linear"], 6, 6, "wgt10"),
+                   "dense_t2_nodiv": (2, ["mean", "dir2-dx"], ["attenuation"], 4, 6, "wgt10")}
+    out["layer_cases"] = np.array(sorted(layer_cases))
+    for lname, (towers, aggs, scalers, fin, fout, cname) in layer_cases.items():
+        torch.manual_seed(0)
+        layer = DGNLayer(in_features=fin, out_features=fout, aggregators=aggs, scalers=scalers, NN_eig=False, avg_d=avg_d,
+                         eigs=None, towers=towers, self_loop=False, pretrans_layers=1, posttrans_layers=1,
+                         divide_input=not lname.endswith("nodiv"), device="cpu")
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for pn, p_ in layer.named_parameters():
+                if pn.endswith("weight"):
+                    p_.copy_(torch.randn(p_.shape, generator=g) / p_.shape[1] ** 0.5)
+                else:
+                    p_.copy_(0.1 * torch.randn(p_.shape, generator=g))
+        _, adj, eig = _dense_inputs(*cases[cname][:1], *cases[cname][1:])
+        B, N = adj.shape[:2]
+        inp = torch.randn(B, N, fin, generator=g).requires_grad_(True)
+        y = layer(inp, adj, eig)
+        ct = torch.randn(y.shape, generator=g)
+        params = list(layer.parameters())
+        grads = torch.autograd.grad(y, [inp] + params, ct)
+        out[f"{lname}/meta"] = np.array([str(towers), " ".join(aggs), " ".join(scalers), str(fin), str(fout), cname,
+                                        str(int(not lname.endswith("nodiv")))])
+        out[f"{lname}/input"], out[f"{lname}/y"], out[f"{lname}/cot"] = inp.detach().numpy(), y.detach().numpy(), ct.numpy()
+        out[f"{lname}/ginput"] = grads[0].numpy()
+        for k, v in layer.state_dict().items():
+            out[f"{lname}/sd::{k}"] = v.detach().numpy().copy()
+        for (pn, _), gr in zip(layer.named_parameters(), grads[1:]):
+            out[f"{lname}/gp::{pn}"] = gr.numpy()
+
+
 def main():
     _install_stubs()
+    only = sys.argv[1:]
     for fname, fn in (("g1_aggregators", g1_aggregators), ("g2_scalers", g2_scalers), ("g3_reduce", g3_reduce),
-                      ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases)):
+                      ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases), ("g6_dense", g6_dense)):
+        if only and fname not in only:
+            continue
         out = {}
         fn(out)
         path = os.path.join(HERE, fname + ".npz")

@@ -84,6 +84,23 @@ def test_mailbox_aggregators_vs_reference(golden, fixture):
             _close(gx, g[f"{c}/{name}/gx"], msg=f"{c} {name} gx")
 
 
+def test_registry_function_api(golden):
+    """AGGREGATORS[name](h, eig_s, eig_d, h_in) / SCALERS[name](h, D, avg_d): the reference's function API
+    (nets/aggregators.py:74-93, nets/scalers.py:21) served by the kernels."""
+    dev = _dev()
+    import dgn_amd
+    g = golden("g1_aggregators")
+    c = "c4"
+    h, es, ed, x = (T(g[f"{c}/{k}"]).to(dev) for k in ("h", "eig_s", "eig_d", "h_in"))
+    for name in g["names"].tolist():
+        _close(dgn_amd.AGGREGATORS[name](h, es, ed, x), g[f"{c}/{name}/y"], msg=name)
+    g2 = golden("g2_scalers")
+    hh = T(g2["h"]).to(dev)
+    for name in dgn_amd.SCALER_NAMES:
+        got = dgn_amd.SCALERS[name](hh, D=7, avg_d={"log": torch.tensor(1.3, device=dev)})
+        _close(got, g2[f"a1/D7/{name}"], 1e-6, 1e-7, msg=name)
+
+
 def test_graph_level_concat_order(golden):
     dev = _dev()
     import dgn_amd
