@@ -160,7 +160,7 @@ def run_layer_workload(args, wl, rank, world, dev):
     h = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
     ct = torch.randn(N, F_, device=dev, generator=gen)
     snorm = batch["snorm_n"].to(dev)
-    reducer = ddist.FlatGradAllReduce(layer.parameters()) if world > 1 else None
+    reducer = ddist.FlatGradAllReduce(layer.parameters()) if torch.distributed.is_initialized() else None
 
     def step():
         graph._wcache.clear()              # per-edge weights are recomputed every step (eig flips per batch)
@@ -174,19 +174,19 @@ def run_layer_workload(args, wl, rank, world, dev):
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     ms = ddist.barrier_max_ms(ms, dev)
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
     total_edges = float(e_total.item())
 
@@ -247,18 +247,18 @@ def run_c5(args, wl, rank, world, dev):
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     ms = ddist.barrier_max_ms((time.perf_counter() - t0) * 1e3 / args.steps, dev)
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
     result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N)
     if rank == 0:
@@ -303,6 +303,8 @@ def main():
     runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
     res = runner(args, wl, rank, world, dev)
     if rank != 0:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
         return
     result, batch = res
     line = dict(metric="dgn_layer_fwd_bwd_edges_per_sec" if wl["type_net"] != "op" else "dgn_aggregation_fwd_edges_per_sec",
@@ -320,6 +322,8 @@ def main():
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

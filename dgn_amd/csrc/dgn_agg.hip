@@ -52,6 +52,7 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
     if (spec->n_scalers < 1 || spec->n_scalers > DGN_MAX_SCALERS) { set_error("n_scalers=%d outside 1..%d", spec->n_scalers, DGN_MAX_SCALERS); return DGN_ERR_INVALID; }
     if (spec->n_towers < 1 || msg->F < 1 || msg->F % spec->n_towers != 0) { set_error("F=%lld not divisible by n_towers=%d", (long long)msg->F, spec->n_towers); return DGN_ERR_INVALID; }
     if (!msg->x_src && !msg->x_dst && !msg->m_edge) { set_error("message has no term"); return DGN_ERR_INVALID; }
+    if (msg->ld_src > INT32_MAX || msg->ld_dst > INT32_MAX || msg->ld_edge > INT32_MAX || msg->ld_in > INT32_MAX) { set_error("row strides must fit in int32"); return DGN_ERR_INVALID; }
     bool need_scale = false;
     for (int s = 0; s < spec->n_scalers; ++s) {
         if (spec->scaler[s] < DGN_SCALE_IDENTITY || spec->scaler[s] > DGN_SCALE_ATTENUATION) { set_error("unknown scaler %d", spec->scaler[s]); return DGN_ERR_INVALID; }
@@ -81,11 +82,11 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
     p.hub_threshold = g->n_hub > 0 ? g->hub_threshold : INT32_MAX;
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;
     p.F = (int32_t)msg->F; p.Ft = (int32_t)(msg->F / spec->n_towers);
-    p.x_src = msg->x_src; p.ld_src = msg->ld_src;
-    p.x_dst = msg->x_dst; p.ld_dst = msg->ld_dst;
-    p.m_edge = msg->m_edge; p.ld_edge = msg->ld_edge;
-    p.x_in = msg->x_in; p.ld_in = msg->ld_in;
-    p.w = w; p.ld_w = ld_w; p.log_deg = log_deg;
+    p.x_src = msg->x_src; p.ld_src = (int32_t)msg->ld_src;
+    p.x_dst = msg->x_dst; p.ld_dst = (int32_t)msg->ld_dst;
+    p.m_edge = msg->m_edge; p.ld_edge = (int32_t)msg->ld_edge;
+    p.x_in = msg->x_in; p.ld_in = (int32_t)msg->ld_in;
+    p.w = w; p.ld_w = (int32_t)ld_w; p.log_deg = log_deg;
     p.n_agg = spec->n_agg; p.agg_total = spec->agg_total > 0 ? spec->agg_total : spec->n_agg;
     p.agg_offset = spec->agg_total > 0 ? spec->agg_offset : 0;
     p.n_ch = spec->n_ch; p.n_scalers = spec->n_scalers; p.n_towers = spec->n_towers;
@@ -158,7 +159,8 @@ extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const 
     if (g->n_hub > 0 && (!ws || ws_bytes < hub_ws_bytes(g, spec, msg->F))) { set_error("workspace too small: need %zu bytes", hub_ws_bytes(g, spec, msg->F)); return DGN_ERR_WORKSPACE; }
     AggParams p;
     fill_params(p, g, spec, msg, w, ld_w, log_deg);
-    p.out = out; p.ld_out = ld_out;
+    if (ld_out > INT32_MAX) { set_error("ld_out must fit in int32"); return DGN_ERR_INVALID; }
+    p.out = out; p.ld_out = (int32_t)ld_out;
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     const int vec = pick_vec(spec, msg, out, ld_out, nullptr);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
@@ -177,11 +179,12 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     if (g->n_hub > 0 && (!ws || ws_bytes < hub_ws_bytes(g, spec, msg->F))) { set_error("workspace too small: need %zu bytes", hub_ws_bytes(g, spec, msg->F)); return DGN_ERR_WORKSPACE; }
     AggParams p;
     fill_params(p, g, spec, msg, w, ld_w, log_deg);
-    p.g_out = g_out; p.ld_gout = ld_gout;
-    p.g_src = msg->x_src ? grads->g_src : nullptr; p.ldg_src = grads->ld_src;
-    p.g_dst = msg->x_dst ? grads->g_dst : nullptr; p.ldg_dst = grads->ld_dst;
-    p.g_edge = msg->m_edge ? grads->g_edge : nullptr; p.ldg_edge = grads->ld_edge;
-    p.g_in = msg->x_in ? grads->g_in : nullptr; p.ldg_in = grads->ld_in;
+    if (ld_gout > INT32_MAX || grads->ld_src > INT32_MAX || grads->ld_dst > INT32_MAX || grads->ld_edge > INT32_MAX || grads->ld_in > INT32_MAX) { set_error("strides must fit in int32"); return DGN_ERR_INVALID; }
+    p.g_out = g_out; p.ld_gout = (int32_t)ld_gout;
+    p.g_src = msg->x_src ? grads->g_src : nullptr; p.ldg_src = (int32_t)grads->ld_src;
+    p.g_dst = msg->x_dst ? grads->g_dst : nullptr; p.ldg_dst = (int32_t)grads->ld_dst;
+    p.g_edge = msg->m_edge ? grads->g_edge : nullptr; p.ldg_edge = (int32_t)grads->ld_edge;
+    p.g_in = msg->x_in ? grads->g_in : nullptr; p.ldg_in = (int32_t)grads->ld_in;
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));

@@ -56,14 +56,14 @@ struct AggParams {
     const int32_t* chunk_hub;
     int64_t n_hub;
     int64_t n_chunks;
-    // message
+    // message (all strides are int32: a 32x32->64 multiply is 2 scalar ops, a 64x64 one is 9)
     int32_t F;
     int32_t Ft;  // F / n_towers
-    const float* x_src;  int64_t ld_src;
-    const float* x_dst;  int64_t ld_dst;
-    const float* m_edge; int64_t ld_edge;
-    const float* x_in;   int64_t ld_in;
-    const float* w;      int64_t ld_w;
+    const float* x_src;  int32_t ld_src;
+    const float* x_dst;  int32_t ld_dst;
+    const float* m_edge; int32_t ld_edge;
+    const float* x_in;   int32_t ld_in;
+    const float* w;      int32_t ld_w;
     const float* log_deg;
     // spec
     int32_t n_agg;
@@ -82,13 +82,13 @@ struct AggParams {
     uint32_t need;
     bool any_av;
     // forward output / backward input
-    float* out;           int64_t ld_out;
-    const float* g_out;   int64_t ld_gout;
+    float* out;           int32_t ld_out;
+    const float* g_out;   int32_t ld_gout;
     // backward sinks
-    float* g_src;  int64_t ldg_src;
-    float* g_dst;  int64_t ldg_dst;
-    float* g_edge; int64_t ldg_edge;
-    float* g_in;   int64_t ldg_in;
+    float* g_src;  int32_t ldg_src;
+    float* g_dst;  int32_t ldg_dst;
+    float* g_edge; int32_t ldg_edge;
+    float* g_in;   int32_t ldg_in;
     // workspace (hub rows)
     float* part;          // [n_chunks][n_slots][F]
     float* part_sw;       // [n_chunks][DGN_MAX_CH]
@@ -259,31 +259,24 @@ __device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggPa
         SlotBatch<C::NCH, C::NW> b;
         b.load(p, base, end);
         const int cnt = min(kWave, end - base);
-        int k = 0;
-        for (; k + U <= cnt; k += U) {
+        // groups of U gathers in flight; the last (partial) group is predicated, NOT a one-at-a-time loop:
+        // molecule rows have 2-3 slots, and a scalar remainder loop would serialise their gather latencies
+        for (int k = 0; k < cnt; k += U) {
             float m[U][VEC];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int s = bcast_i(b.src, k + u);
-                if (active) load_msg<VEC>(m[u], p, s, base + k + u, f0, xd);
+                if (k + u < cnt) {
+                    const int s = bcast_i(b.src, k + u);
+                    if (active) load_msg<VEC>(m[u], p, s, base + k + u, f0, xd);
+                }
             }
-            if (active) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < U; ++u) {
+                if (k + u < cnt && active) {
                     float wk[C::NW];
                     b.weights(wk, k + u);
                     acc.add(m[u], wk, base + k + u);
                 }
-            }
-        }
-        for (; k < cnt; ++k) {
-            float m[VEC];
-            float wk[C::NW];
-            const int s = bcast_i(b.src, k);
-            b.weights(wk, k);
-            if (active) {
-                load_msg<VEC>(m, p, s, base + k, f0, xd);
-                acc.add(m, wk, base + k);
             }
         }
     }

@@ -22,7 +22,8 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     when WORLD_SIZE > 1 (MASTER_ADDR/MASTER_PORT from the launcher, 127.0.0.1 by default)."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("DGN_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -58,9 +59,10 @@ class FlatGradAllReduce:
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
 
     def __call__(self) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         views, off = [], 0
         for p in self.params:

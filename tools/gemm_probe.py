@@ -26,7 +26,11 @@ def main():
         "linear [N,150]x[150,225] (c1 posttrans)": lambda: (torch.randn(N, 150, device=dev), torch.randn(225, 150, device=dev)),
         "linear [N,350]x[350,70]": lambda: (torch.randn(N, 350, device=dev), torch.randn(70, 350, device=dev)),
     }
-    for lib in ("default", "hipblaslt", "cublas"):
+    if len(sys.argv) > 1 and sys.argv[1] == "tunable":
+        import torch.cuda.tunable as tn
+        tn.enable(True); tn.set_max_tuning_duration(200); tn.set_max_tuning_iterations(20)
+        print("tunable op enabled")
+    for lib in ("default",):
         if lib != "default":
             try:
                 torch.backends.cuda.preferred_blas_library(lib)
