@@ -87,6 +87,28 @@ def pmc_traffic(tag, kernels):
         return None
 
 
+TUNING_FILE = os.path.join(ROOT, "dgn_amd", "tunableop_gfx950.csv")
+
+
+def configure_gemm_tuning(mode):
+    """The skinny fp32 GEMMs around the sweep ([N,70]x[70,140], dW = dZ^T X with N ~ 3e5, per-tower batched
+    GEMMs) hit poor default rocBLAS solutions (0.2-0.7 ms each where 0.1 ms is possible); TunableOp picks the
+    best rocBLAS/hipBLASLt solution per shape.  'file' only replays the committed selection."""
+    if mode == "off":
+        return
+    import torch.cuda.tunable as tn
+    tn.enable(True)
+    tn.set_filename(TUNING_FILE)
+    if mode == "tune":
+        tn.tuning_enable(True)
+        tn.set_max_tuning_duration(150)
+        tn.set_max_tuning_iterations(20)
+    else:
+        tn.tuning_enable(False)
+        if os.path.exists(TUNING_FILE):
+            tn.read_file(TUNING_FILE)
+
+
 def event_ms(fn, reps, dev):
     """Average duration of fn() over `reps` back-to-back enqueues, HIP events on the current stream."""
     fn()
@@ -286,9 +308,13 @@ def main():
     ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-tuning", default="file", choices=["off", "file", "tune"],
+                    help="PyTorch TunableOp for the dense pre/post-aggregation GEMMs (rocBLAS/hipBLASLt solution choice): "
+                         "'file' replays dgn_amd/tunableop_gfx950.csv without tuning, 'tune' tunes and rewrites it")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
     args = ap.parse_args()
 
+    configure_gemm_tuning(args.gemm_tuning)
     rank, world, local = ddist.init_from_env("nccl")
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
