@@ -170,7 +170,10 @@ def cpu_baseline(wl, batch, sample_graphs, reps=5):
 
 
 def run_layer_workload(args, wl, rank, world, dev):
-    batch, graph = build_batch(wl, 41 + rank, dev)
+    # every rank draws the SAME synthetic batch (generator seed 41, BASELINE config seed) so that all ranks run
+    # identical shapes (weak scaling, and the committed GEMM solution file applies to every rank); node features
+    # and cotangents are rank-specific, so the all-reduced gradients are not
+    batch, graph = build_batch(wl, 41, dev)
     F_ = wl["hidden"]
     N, E = graph.num_nodes, graph.num_edges
     torch.manual_seed(0)

@@ -77,7 +77,7 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
 void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                  const float* log_deg) {
     p = AggParams{};
-    p.indptr = g->indptr; p.src = g->src; p.n_nodes = g->n_nodes;
+    p.indptr = g->indptr; p.src = g->src; p.n_nodes = g->n_nodes; p.n_edges = g->n_edges;
     p.n_hub = g->n_hub; p.n_chunks = g->n_hub > 0 ? g->n_chunks : 0;
     p.hub_threshold = g->n_hub > 0 ? g->hub_threshold : INT32_MAX;
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;

@@ -49,6 +49,7 @@ struct AggParams {
     const int32_t* indptr;
     const int32_t* src;
     int64_t n_nodes;
+    int64_t n_edges;
     int32_t hub_threshold;
     int32_t hub_chunk;
     const int32_t* hub_rows;
@@ -504,12 +505,13 @@ __device__ __forceinline__ void load_partial(Acc<C, TRACK>& acc, const AggParams
 // ---- forward kernels --------------------------------------------------------------------------
 
 template <class C>
-__global__ __launch_bounds__(kBlock) void agg_fwd_rows(const AggParams p) {
+__global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
+    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
     constexpr int VEC = C::VEC;
-    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
     if (lb < 0) return;
-    const int64_t row64 = lb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
     if (row64 >= p.n_nodes) return;
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
@@ -526,7 +528,23 @@ __global__ __launch_bounds__(kBlock) void agg_fwd_rows(const AggParams p) {
     if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
     Acc<C, false> acc;
     acc.init();
+#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 1      // ablation: launch + kernargs + row pointers + side inputs only
+    if (xd[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
+    return;
+#endif
+#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 2      // + the slot batch (src ids, weights), no gathers
+    {
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, beg, end);
+        if (b.src + b.w[0] + xd[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
+        return;
+    }
+#endif
     accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
+#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 3      // + gathers and accumulation, no epilogue
+    if (acc.sum[0] + acc.sw[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
+    return;
+#endif
     if (active) write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
 }
 
@@ -816,12 +834,13 @@ __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f
 }
 
 template <class C>
-__global__ __launch_bounds__(kBlock) void agg_bwd_rows(const AggParams p) {
+__global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
+    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
     constexpr int VEC = C::VEC;
-    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
     if (lb < 0) return;
-    const int64_t row64 = lb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
     if (row64 >= p.n_nodes) return;
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
@@ -937,11 +956,22 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_hub_emit(const AggParams p) {
 
 // ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------
 
+// Workgroup shape of the row kernels.  The dispatcher starts ~4.6 workgroups per ns whatever their size
+// (measured: tools/microbench), so one-wave workgroups cap a sweep at ~4.6 rows/ns: fine for power-law graphs
+// (tens of KB per row, and a finished long row frees its slot immediately: +9 % on C5), but molecule-like
+// batches (2-3 edges per row) need 4 rows per workgroup.
+inline int row_waves_per_block(const AggParams& p) {
+    static const char* env = getenv("DGN_ROW_WPB");
+    if (env) return atoi(env) == 1 ? 1 : 4;
+    return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
+}
+
 template <class C>
 int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
-    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int wpb = row_waves_per_block(p);
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_fwd_rows<C>), grid, dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((agg_fwd_rows<C>), grid, dim3(kWave * wpb), 0, stream, p);
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         hipLaunchKernelGGL((agg_hub_slices<C, false>), gs, dim3(kBlock), 0, stream, p);
@@ -954,9 +984,10 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
 
 template <class C>
 int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
-    const int64_t n_blocks = (p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int wpb = row_waves_per_block(p);
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_bwd_rows<C>), grid, dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((agg_bwd_rows<C>), grid, dim3(kWave * wpb), 0, stream, p);
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         dim3 gc((unsigned)((p.n_hub + kWavesPerBlock - 1) / kWavesPerBlock), tiles);

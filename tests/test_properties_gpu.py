@@ -1,0 +1,113 @@
+"""Size-independent properties of the HIP path at BASELINE-scale inputs, where the CPU oracle is too slow:
+linearity of the linear aggregators, algebraic relations between aggregators, hub-slice path == row path,
+gradient of a linear functional, determinism of the forward.  Power-law graph (C5 shape) at 1/10 scale
+(1 M nodes, ~20 M edges, F = 128) and the full ZINC-12k batch (C2 shape)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def powerlaw():
+    import dgn_amd
+    from dgn_amd import synth
+    dev = _dev()
+    indptr, src, eig = synth.powerlaw_csr(1_000_000, 20_000_000, dev, seed=3)
+    g = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    assert g.n_hub > 0 and int(g.in_degree.max()) > 10 * g.hub_threshold      # hub rows are exercised
+    return g
+
+
+def test_powerlaw_linearity_and_relations(powerlaw):
+    import dgn_amd
+    from dgn_amd.ops import directional_aggregate
+    dev = _dev()
+    g = powerlaw
+    N, F_ = g.num_nodes, 128
+    gen = torch.Generator(device=dev).manual_seed(0)
+    X, Y = torch.randn(N, F_, device=dev, generator=gen), torch.randn(N, F_, device=dev, generator=gen)
+    aggs = ["mean", "sum", "max", "min", "std", "var", "dir1-dx-no-abs", "dir2-av", "dir3-0.1"]
+    plan = dgn_amd.make_plan(aggs, ["identity"])
+    out = lambda Z: directional_aggregate(g, plan, 1.0, x_src=Z, x_in=Z).view(N, len(aggs), F_)
+    oX, oY, oL = out(X), out(Y), out(2.0 * X - 0.5 * Y)
+    deg = g.in_degree.float().unsqueeze(1)
+    # linear aggregators: mean, sum, dx-no-abs, av, softmax-weighted sum
+    for name in ("mean", "sum", "dir1-dx-no-abs", "dir2-av", "dir3-0.1"):
+        a = aggs.index(name)
+        ref = 2.0 * oX[:, a] - 0.5 * oY[:, a]
+        err = (oL[:, a] - ref).abs().max() / ref.abs().max().clamp_min(1.0)
+        assert float(err) < 2e-5, (name, float(err))
+    # relations between aggregators of the same messages
+    mean, s, mx, mn, sd, var = (oX[:, aggs.index(k)] for k in ("mean", "sum", "max", "min", "std", "var"))
+    assert float(((s - mean * deg).abs() / (1 + s.abs())).max()) < 1e-4           # sum = deg * mean
+    assert bool((mx >= mean - 1e-4).all()) and bool((mean >= mn - 1e-4).all())    # min <= mean <= max
+    assert float((sd * sd - (var + 1e-8)).abs().max()) < 1e-4                      # std^2 = var + EPS
+    assert bool((var >= 0).all())
+    # dir2-av is a convex combination of the messages (weights |w| sum to <= 1): stays inside [min, max]
+    av = oX[:, aggs.index("dir2-av")]
+    assert bool((av <= torch.clamp(mx, min=0) + 1e-4).all()) and bool((av >= torch.clamp(mn, max=0) - 1e-4).all())
+    # forward is deterministic (no atomics on the forward path)
+    assert torch.equal(out(X), oX)
+
+
+def test_powerlaw_hub_path_equals_row_path(powerlaw):
+    """The same graph with the hub mechanism disabled (threshold above the max degree) must give the same
+    result as the sliced path, forward and backward."""
+    import dgn_amd
+    from dgn_amd.ops import directional_aggregate
+    dev = _dev()
+    g = powerlaw
+    N, F_ = g.num_nodes, 32
+    g_rows = dgn_amd.DGNGraph.from_csr(g.indptr.long(), g.src, eig=g.ndata["eig"], hub_threshold=2 ** 30)
+    assert g_rows.n_hub == 0
+    gen = torch.Generator(device=dev).manual_seed(1)
+    X = torch.randn(N, F_, device=dev, generator=gen)
+    plan = dgn_amd.make_plan(["mean", "max", "std", "dir1-dx", "dir2-dx-balanced"], ["identity", "amplification", "attenuation"])
+    ct = torch.randn(N, plan.out_width(F_), device=dev, generator=gen)
+    res = []
+    for graph in (g, g_rows):
+        Z = X.clone().requires_grad_(True)
+        y = directional_aggregate(graph, plan, 1.7, x_src=Z, x_in=Z)
+        (gz,) = torch.autograd.grad(y, Z, ct)
+        res.append((y.detach(), gz))
+    (y1, g1), (y2, g2) = res
+    sc = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1.0))
+    assert sc(y1, y2) < 2e-5, sc(y1, y2)      # slices are merged in slot order: only the association of sums differs
+    assert sc(g1, g2) < 1e-4, sc(g1, g2)
+
+
+def test_zinc12k_gradient_of_linear_functional():
+    """C2 shape (all 12 000 molecules in one batch, towers layout): for aggregators that are linear in the
+    messages, <agg(X), C> is linear in X, so its gradient must not depend on X and <grad, X> = <agg(X), C>."""
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.ops import directional_aggregate
+    dev = _dev()
+    b = synth.molecule_batch(12000, seed=41, extra_bonds=3.9)
+    g = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), b["num_nodes"], eig=b["eig"].to(dev))
+    N, F_ = g.num_nodes, 70
+    plan = dgn_amd.make_plan(["mean", "sum", "dir1-av", "dir1-dx-no-abs", "dir2-neg-0.1"], ["identity"])
+    gen = torch.Generator(device=dev).manual_seed(2)
+    Cc = torch.randn(N, plan.out_width(F_), device=dev, generator=gen)
+    grads = []
+    for k in range(2):
+        P = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
+        Q = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
+        H = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
+        y = directional_aggregate(g, plan, 1.0, x_src=P, x_dst=Q, x_in=H, n_towers=5)
+        gP, gQ, gH = torch.autograd.grad(y, [P, Q, H], Cc)
+        lhs = float((y * Cc).sum())
+        rhs = float((gP * P).sum() + (gQ * Q).sum() + (gH * H).sum())
+        assert abs(lhs - rhs) <= 2e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+        grads.append((gP, gQ, gH))
+    for a, c in zip(*grads):      # same gradient for different inputs (atomics: last-bit differences only)
+        assert float((a - c).abs().max()) <= 1e-4 * float(a.abs().max())
+    # zero in-degree nodes (none in molecule graphs) and duplicate-free sanity: every node has an in-edge
+    assert int(g.in_degree.min()) >= 1

@@ -67,6 +67,25 @@ __global__ void gather_rows(const float* __restrict__ x, const int* __restrict__
     if (acc.x == 123.456f) *reinterpret_cast<float2*>(out + task * 128 + lane * 2) = acc;
 }
 
+// launch floor: n waves, each reads two ints (a row pointer pair) and does nothing else
+__global__ void launch_floor(const int* __restrict__ ptr, size_t n_waves, float* __restrict__ out) {
+    size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    int wi = __builtin_amdgcn_readfirstlane((int)w);
+    int a = ptr[wi], b = ptr[wi + 1];
+    if (b - a == 123456) out[threadIdx.x] = 1.f;
+}
+
+// the same plus a dependent chain of `depth` loads (each address depends on the previous value)
+__global__ void chain_floor(const int* __restrict__ ptr, size_t n_waves, int depth, size_t n_ptr, float* __restrict__ out) {
+    size_t w = (size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    int v = (int)(w % n_ptr);
+    int lane = threadIdx.x & 63;
+    for (int d = 0; d < depth; ++d) v = ptr[((size_t)v * 97 + lane) % n_ptr] + (int)(w % n_ptr);
+    if (v == -123456) out[threadIdx.x] = 1.f;
+}
+
 template <typename F>
 float time_ms(F&& f, int reps = 5) {
     hipEvent_t a, b;
@@ -83,6 +102,28 @@ float time_ms(F&& f, int reps = 5) {
 
 int main() {
     const size_t GB = 1ull << 30;
+    // launch floor
+    {
+        size_t n_ptr = 1 << 20;
+        std::vector<int> h(n_ptr + 1);
+        for (size_t i = 0; i <= n_ptr; ++i) h[i] = (int)(i % 7);
+        int* ptr; CK(hipMalloc(&ptr, (n_ptr + 1) * 4)); CK(hipMemcpy(ptr, h.data(), (n_ptr + 1) * 4, hipMemcpyHostToDevice));
+        float* out; CK(hipMalloc(&out, 4096));
+        for (size_t n_waves : {(size_t)275167, (size_t)1000000}) {
+            for (int bs : {64, 256}) {
+                unsigned nb = (unsigned)((n_waves + bs / 64 - 1) / (bs / 64));
+                float ms = time_ms([&] { hipLaunchKernelGGL(launch_floor, dim3(nb), dim3(bs), 0, 0, ptr, n_waves, out); }, 20);
+                printf("launch floor: %8zu waves, block %3d : %.4f ms  (%.0f waves/us)\n", n_waves, bs, ms, n_waves / ms / 1e3);
+            }
+            for (int depth : {1, 2, 4, 8}) {
+                unsigned nb = (unsigned)n_waves;
+                float ms = time_ms([&] { hipLaunchKernelGGL(chain_floor, dim3(nb), dim3(64), 0, 0, ptr, n_waves, depth, n_ptr, out); }, 20);
+                printf("  dependent-load chain depth %d, %8zu waves: %.4f ms  (%.0f waves/us)\n", depth, n_waves, ms, n_waves / ms / 1e3);
+            }
+        }
+        CK(hipFree(ptr)); CK(hipFree(out));
+    }
+    if (getenv("FLOOR_ONLY")) return 0;
     // copy
     {
         size_t n = 4 * GB / 16;
