@@ -20,14 +20,14 @@ LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward")
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_backward")
 
 
 class DgnGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("indptr", C.c_void_p), ("src", C.c_void_p),
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
-                ("hub_chunk", C.c_int32)]
+                ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p)]
 
 
 class DgnChannel(C.Structure):
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
                                          C.c_void_p]
         lib.dgn_agg_workspace_bytes.restype = C.c_size_t
         lib.dgn_agg_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64]
+        lib.dgn_agg_backward_workspace_bytes.restype = C.c_size_t
+        lib.dgn_agg_backward_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32]
         lib.dgn_agg_forward.restype = C.c_int
         lib.dgn_agg_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,

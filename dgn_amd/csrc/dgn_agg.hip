@@ -149,6 +149,15 @@ extern "C" size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* s
     return hub_ws_bytes(g, spec, F);
 }
 
+size_t stage_bytes(const DgnGraph* g, int64_t F) { return ((size_t)g->n_edges * F * sizeof(float) + 255) & ~(size_t)255; }
+
+extern "C" size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t deterministic) {
+    if (!g || !spec) return 0;
+    size_t n = hub_ws_bytes(g, spec, F);
+    if (deterministic && g->csc_ptr && g->csc_pos && g->n_edges > 0) n += stage_bytes(g, F);
+    return n;
+}
+
 extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                                const float* log_deg, float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream_) {
     int rc = validate(g, spec, msg, w, log_deg);
@@ -186,6 +195,12 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     p.g_edge = msg->m_edge ? grads->g_edge : nullptr; p.ldg_edge = (int32_t)grads->ld_edge;
     p.g_in = msg->x_in ? grads->g_in : nullptr; p.ldg_in = (int32_t)grads->ld_in;
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
+    // atomic-free scatter when the transposed view and the [E, F] staging buffer are available
+    if (p.g_src && g->csc_ptr && g->csc_pos && g->n_edges > 0 && ws &&
+        ws_bytes >= hub_ws_bytes(g, spec, msg->F) + stage_bytes(g, msg->F)) {
+        p.stage = reinterpret_cast<float*>(static_cast<char*>(ws) + hub_ws_bytes(g, spec, msg->F));
+        p.csc_ptr = g->csc_ptr; p.csc_pos = g->csc_pos;
+    }
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
     return launch(vec, p, tiles, static_cast<hipStream_t>(stream_), true);

@@ -94,6 +94,9 @@ struct AggParams {
     float* part;          // [n_chunks][n_slots][F]
     float* part_sw;       // [n_chunks][DGN_MAX_CH]
     float* coef;          // [n_hub][n_coef][F]  (backward)
+    float* stage;         // [n_edges][F] per-edge gradient rows in csc order (atomic-free backward), or NULL
+    const int32_t* csc_ptr;
+    const int32_t* csc_pos;
     int32_t n_slots;
     int32_t n_coef;
 };
@@ -758,9 +761,11 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
     for (int base = beg; base < end; base += kWave) {
         SlotBatch<C::NCH, C::NW> b;
         b.load(p, base, end);
+        const int my_tpos = (p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
         const int cnt = min(kWave, end - base);
         for (int kk = 0; kk < cnt; ++kk) {
             const int s = bcast_i(b.src, kk);
+            const int tp = bcast_i(my_tpos, kk);
             float wk[C::NW];
             b.weights(wk, kk);
             if (!active) continue;
@@ -793,13 +798,14 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
                 rsum[i] += gm[i];
             }
             if (p.g_src) {
-                float* dst = p.g_src + (int64_t)s * p.ldg_src + f0;
-#ifdef DGN_EXP_NOATOMIC
-                stv<VEC>(dst, gm);
-#else
+                if (p.stage) {
+                    // atomic-free path: park the row at its csc position; seg_sum_rows adds each source's rows
+                    stv<VEC>(p.stage + (int64_t)tp * p.F + f0, gm);
+                } else {
+                    float* dst = p.g_src + (int64_t)s * p.ldg_src + f0;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gm[i]);
-#endif
+                    for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gm[i]);
+                }
             }
             if (p.g_edge) stv<VEC>(p.g_edge + (int64_t)pos * p.ldg_edge + f0, gm);
         }
@@ -954,6 +960,48 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_hub_emit(const AggParams p) {
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, false);
 }
 
+// second phase of the atomic-free backward: g_src[u] += sum of the staged rows of source u (contiguous in csc
+// order).  Flat mapping: one thread per (node, VEC-chunk), so short out-neighbourhoods do not cost a wave each.
+template <int VEC>
+__global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
+    constexpr int PER = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);    // 4 floats per thread whatever the vector width
+    const int nchunk = (p.F + VEC * PER - 1) / (VEC * PER);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_nodes * nchunk) return;
+    const int u = (int)(t / nchunk);
+    const int f0 = (int)(t - (int64_t)u * nchunk) * VEC * PER;
+    const int beg = p.csc_ptr[u], end = p.csc_ptr[u + 1];
+    if (beg == end) return;
+    float acc[PER][VEC];
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
+    for (int k = beg; k < end; ++k) {
+        const float* row = p.stage + (int64_t)k * p.F + f0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (f0 + q * VEC < p.F) {
+                float r[VEC];
+                ldv<VEC>(r, row + q * VEC);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[q][i] += r[i];
+            }
+        }
+    }
+    float* dst = p.g_src + (int64_t)u * p.ldg_src + f0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (f0 + q * VEC < p.F) {
+            float cur[VEC];
+            ldv<VEC>(cur, dst + q * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) cur[i] += acc[q][i];
+            stv<VEC>(dst + q * VEC, cur);
+        }
+    }
+}
+
 // ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------
 
 // Workgroup shape of the row kernels.  The dispatcher starts ~4.6 workgroups per ns whatever their size
@@ -994,6 +1042,11 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
         hipLaunchKernelGGL((agg_hub_slices<C, true>), gs, dim3(kBlock), 0, stream, p);
         hipLaunchKernelGGL((agg_bwd_hub_coef<C>), gc, dim3(kBlock), 0, stream, p);
         hipLaunchKernelGGL((agg_bwd_hub_emit<C>), gs, dim3(kBlock), 0, stream, p);
+    }
+    if (p.stage && p.g_src) {
+        constexpr int per = C::VEC == 1 ? 4 : (C::VEC == 2 ? 2 : 1);
+        const int64_t n_threads = p.n_nodes * ((p.F + C::VEC * per - 1) / (C::VEC * per));
+        hipLaunchKernelGGL((seg_sum_rows<C::VEC>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, stream, p);
     }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;

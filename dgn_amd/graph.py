@@ -96,6 +96,21 @@ class DGNGraph:
         self._c = c
         self._wcache: Dict[tuple, torch.Tensor] = {}
 
+    def ensure_csc(self) -> None:
+        """Transposed view for the atomic-free backward (built on first use, one extra sort per graph)."""
+        if getattr(self, "_csc_ready", False):
+            return
+        E, dev = self.num_edges, self.device
+        order = torch.sort(self.src.long(), stable=True)[1]                 # slots ordered by (source, slot)
+        pos = torch.empty(E, dtype=torch.int64, device=dev)
+        pos[order] = torch.arange(E, device=dev)
+        out_deg = torch.bincount(self.src.long(), minlength=self.num_nodes) if E else torch.zeros(self.num_nodes, dtype=torch.int64, device=dev)
+        ptr = torch.zeros(self.num_nodes + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(out_deg, 0)
+        self.csc_ptr, self.csc_pos = ptr.int().contiguous(), pos.int().contiguous()
+        self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+        self._csc_ready = True
+
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----
     def number_of_nodes(self) -> int:
         return self.num_nodes

@@ -91,6 +91,12 @@ typedef struct DgnGraph {
     const int32_t* chunk_hub;     /* [n_chunks] index into hub_rows                              */
     int32_t hub_threshold;
     int32_t hub_chunk;
+    /* Optional transposed view (NULL = absent), used by dgn_agg_backward to avoid atomics: csc_pos[j] is the
+     * rank of CSR slot j when the slots are ordered by (source node, slot) and csc_ptr[u] the first such rank
+     * of source u.  With it (and a large enough workspace) the backward writes every per-edge gradient row
+     * to its csc position and a second kernel sums each source's contiguous rows: deterministic, no atomics. */
+    const int32_t* csc_ptr;  /* [n_nodes+1] */
+    const int32_t* csc_pos;  /* [n_edges]   */
 } DgnGraph;
 
 typedef struct DgnChannel {
@@ -164,7 +170,10 @@ size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_
 int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                     const float* log_deg, float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
 
-/* Backward of dgn_agg_forward for upstream gradient g_out [n_nodes, ld_gout].                  */
+/* Backward of dgn_agg_forward for upstream gradient g_out [n_nodes, ld_gout].
+ * Workspace: dgn_agg_backward_workspace_bytes(); with `deterministic` != 0 (needs g->csc_*) it includes the
+ * [n_edges, F] staging buffer of the two-phase scatter; a smaller workspace silently selects the atomic path. */
+size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t deterministic);
 int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                      const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                      void* ws, size_t ws_bytes, void* stream);
