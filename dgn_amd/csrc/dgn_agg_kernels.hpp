@@ -292,6 +292,45 @@ __device__ __forceinline__ int agg_op(const AggParams& p, int a) { return (int)(
 __device__ __forceinline__ int agg_ch(const AggParams& p, int a) { return (int)((p.ch_pack >> (3 * a)) & 7u); }
 __device__ __forceinline__ int scaler_kind(const AggParams& p, int s) { return (int)((p.scaler_pack >> (2 * s)) & 3u); }
 
+// ---- aggregator-list policies -------------------------------------------------------------------
+// DynOps reads the packed lists from the kernel arguments (any list).  StaticOps<...> bakes a list into the
+// kernel: the per-row epilogue / coefficient code is then fully unrolled with constant ops, i.e. no decode,
+// no branches (about 3x fewer instructions per row on the molecule configs).  The host uses a StaticOps
+// kernel when the launched list matches one of the hot lists of the reference's configs (dgn_agg_hot.hpp).
+struct DynOps {
+    static constexpr bool kStatic = false;
+    static constexpr int NA = DGN_MAX_AGG;
+    static __device__ __forceinline__ int n_agg(const AggParams& p) { return p.n_agg; }
+    static __device__ __forceinline__ int n_scalers(const AggParams& p) { return p.n_scalers; }
+    static __device__ __forceinline__ int op(const AggParams& p, int a) { return agg_op(p, a); }
+    static __device__ __forceinline__ int ch(const AggParams& p, int a) { return agg_ch(p, a); }
+    static __device__ __forceinline__ int scaler(const AggParams& p, int s) { return scaler_kind(p, s); }
+};
+template <int NA_, uint64_t OPS, uint64_t CHS, int NS_, uint32_t SCS>
+struct StaticOps {
+    static constexpr bool kStatic = true;
+    static constexpr int NA = NA_;
+    static constexpr uint64_t kOps = OPS, kChs = CHS;
+    static constexpr int kNS = NS_;
+    static constexpr uint32_t kScs = SCS;
+    static __device__ __forceinline__ constexpr int n_agg(const AggParams&) { return NA_; }
+    static __device__ __forceinline__ constexpr int n_scalers(const AggParams&) { return NS_; }
+    static __device__ __forceinline__ constexpr int op(const AggParams&, int a) { return (int)((OPS >> (4 * a)) & 15u); }
+    static __device__ __forceinline__ constexpr int ch(const AggParams&, int a) { return (int)((CHS >> (3 * a)) & 7u); }
+    static __device__ __forceinline__ constexpr int scaler(const AggParams&, int s) { return (int)((SCS >> (2 * s)) & 3u); }
+};
+
+// loop over the aggregators: a plain loop for DynOps, fully unrolled for StaticOps
+template <class O, int STEP = 1, class Fn>
+__device__ __forceinline__ void for_each_agg(const AggParams& p, Fn&& fn) {
+    if constexpr (O::kStatic) {
+#pragma unroll
+        for (int a = 0; a < O::NA; a += STEP) fn(a);
+    } else {
+        for (int a = 0; a < O::n_agg(p); a += STEP) fn(a);
+    }
+}
+
 __device__ __forceinline__ float scaler_factor(int kind, float logd, float avg) {
     if (kind == DGN_SCALE_AMPLIFICATION) return logd / avg;
     if (kind == DGN_SCALE_ATTENUATION) return avg / logd;
@@ -414,7 +453,7 @@ __device__ __forceinline__ void agg_value(float (&val)[C::VEC], int op, int c, c
 
 // write one finished row: aggregator values x scalers in the reference concat order.
 // orow already includes the lane's column part; xin / logd were loaded by the caller (early).
-template <class C>
+template <class C, class O = DynOps>
 __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggParams& p, float* orow, int deg,
                                           const float (&xin)[C::VEC], float logd) {
     constexpr int VEC = C::VEC;
@@ -422,8 +461,8 @@ __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggPar
         float z[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) z[i] = 0.f;
-        for (int s = 0; s < p.n_scalers; ++s)
-            for (int a = 0; a < p.n_agg; ++a) stv<VEC>(orow + sa_col(p, s, a), z);
+        for (int s = 0; s < O::n_scalers(p); ++s)
+            for (int a = 0; a < O::n_agg(p); ++a) stv<VEC>(orow + sa_col(p, s, a), z);
         return;
     }
     const float d = (float)deg;
@@ -431,23 +470,23 @@ __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggPar
     row_stats<C, false>(st, acc, d, p);
     float fac[DGN_MAX_SCALERS];
 #pragma unroll
-    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < p.n_scalers ? scaler_factor(scaler_kind(p, s), logd, p.avg_log) : 1.f;
-    for (int a = 0; a < p.n_agg; ++a) {
+    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < O::n_scalers(p) ? scaler_factor(O::scaler(p, s), logd, p.avg_log) : 1.f;
+    for_each_agg<O>(p, [&](int a) {
         float val[VEC];
-        agg_value<C, false>(val, agg_op(p, a), agg_ch(p, a), acc, st, xin);
+        agg_value<C, false>(val, O::op(p, a), O::ch(p, a), acc, st, xin);
 #pragma unroll
         for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
-            if (s < p.n_scalers) {
+            if (s < O::n_scalers(p)) {
                 float o[VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) o[i] = scaler_kind(p, s) == DGN_SCALE_IDENTITY ? val[i] : val[i] * fac[s];
+                for (int i = 0; i < VEC; ++i) o[i] = O::scaler(p, s) == DGN_SCALE_IDENTITY ? val[i] : val[i] * fac[s];
 #ifdef DGN_EXP_NOSTORE
                 if (o[0] == 123.456f)
 #endif
                 stv<VEC>(orow + sa_col(p, s, a), o);
             }
         }
-    }
+    });
 }
 
 // ---- hub workspace I/O ----------------------------------------------------------------------
@@ -507,7 +546,7 @@ __device__ __forceinline__ void load_partial(Acc<C, TRACK>& acc, const AggParams
 
 // ---- forward kernels --------------------------------------------------------------------------
 
-template <class C>
+template <class C, class O = DynOps>
 __global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
     const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
     constexpr int VEC = C::VEC;
@@ -548,7 +587,7 @@ __global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
     if (acc.sum[0] + acc.sw[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
     return;
 #endif
-    if (active) write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+    if (active) write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
 }
 
 __device__ __forceinline__ void slice_bounds(const AggParams& p, int chunk, int& hub, int& row, int& beg, int& end) {
@@ -618,7 +657,7 @@ struct Coef {
 
 // per-row coefficient vectors from the upstream gradient and the (recomputed) accumulators;
 // also returns d x_in for this row.  grow already includes the lane's column part.
-template <class C>
+template <class C, class O = DynOps>
 __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], const Acc<C, true>& acc, const AggParams& p,
                                           const float* grow, int deg, const float (&xin)[C::VEC], float logd) {
     constexpr int VEC = C::VEC;
@@ -644,11 +683,11 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
     row_stats<C, true>(st, acc, d, p);
     float fac[DGN_MAX_SCALERS];
 #pragma unroll
-    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < p.n_scalers ? scaler_factor(scaler_kind(p, s), logd, p.avg_log) : 0.f;
+    for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < O::n_scalers(p) ? scaler_factor(O::scaler(p, s), logd, p.avg_log) : 0.f;
     // one aggregator's share of the coefficients, given its upstream gradient g (scalers already summed in)
     auto apply = [&](int a, const float (&g)[VEC]) {
-        const int op = agg_op(p, a);
-        const int c = agg_ch(p, a);
+        const int op = O::op(p, a);
+        const int c = O::ch(p, a);
         if (op < DGN_AGG_DIR_AV) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -698,30 +737,30 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
     };
     // The upstream-gradient loads of several aggregators are issued together (tiles of 4 aggregators when
     // there is one scaler, 2 otherwise): a one-at-a-time loop would be a chain of n_agg dependent latencies.
-    if (p.n_scalers == 1) {
+    if (O::n_scalers(p) == 1) {
         constexpr int AT = 4;
-        for (int a0 = 0; a0 < p.n_agg; a0 += AT) {
+        for_each_agg<O, AT>(p, [&](int a0) {
             float t[AT][VEC];
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) t[j][i] = 0.f;
-                if (a0 + j < p.n_agg) ldv<VEC>(t[j], grow + sa_col(p, 0, a0 + j));
+                if (a0 + j < O::n_agg(p)) ldv<VEC>(t[j], grow + sa_col(p, 0, a0 + j));
             }
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
-                if (a0 + j < p.n_agg) {
-                    if (scaler_kind(p, 0) != DGN_SCALE_IDENTITY) {
+                if (a0 + j < O::n_agg(p)) {
+                    if (O::scaler(p, 0) != DGN_SCALE_IDENTITY) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) t[j][i] *= fac[0];
                     }
                     apply(a0 + j, t[j]);
                 }
             }
-        }
+        });
     } else {
         constexpr int AT = 2;
-        for (int a0 = 0; a0 < p.n_agg; a0 += AT) {
+        for_each_agg<O, AT>(p, [&](int a0) {
             float t[AT][DGN_MAX_SCALERS][VEC];
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
@@ -729,27 +768,27 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
                 for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) t[j][s][i] = 0.f;
-                    if (a0 + j < p.n_agg && s < p.n_scalers) ldv<VEC>(t[j][s], grow + sa_col(p, s, a0 + j));
+                    if (a0 + j < O::n_agg(p) && s < O::n_scalers(p)) ldv<VEC>(t[j][s], grow + sa_col(p, s, a0 + j));
                 }
             }
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
-                if (a0 + j < p.n_agg) {
+                if (a0 + j < O::n_agg(p)) {
                     float g[VEC];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) g[i] = 0.f;
 #pragma unroll
                     for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
-                        if (s < p.n_scalers) {
+                        if (s < O::n_scalers(p)) {
 #pragma unroll
                             for (int i = 0; i < VEC; ++i)
-                                g[i] += scaler_kind(p, s) == DGN_SCALE_IDENTITY ? t[j][s][i] : t[j][s][i] * fac[s];
+                                g[i] += O::scaler(p, s) == DGN_SCALE_IDENTITY ? t[j][s][i] : t[j][s][i] * fac[s];
                         }
                     }
                     apply(a0 + j, g);
                 }
             }
-        }
+        });
     }
 }
 
@@ -839,7 +878,7 @@ __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f
     }
 }
 
-template <class C>
+template <class C, class O = DynOps>
 __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
     constexpr int VEC = C::VEC;
@@ -881,7 +920,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     float gxin[VEC], rsum[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
-    if (active) make_coef<C>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin, logd);
+    if (active) make_coef<C, O>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin, logd);
     emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
 }
@@ -1014,12 +1053,12 @@ inline int row_waves_per_block(const AggParams& p) {
     return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
 }
 
-template <class C>
+template <class C, class O = DynOps>
 int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     const int wpb = row_waves_per_block(p);
     const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_fwd_rows<C>), grid, dim3(kWave * wpb), 0, stream, p);
+    hipLaunchKernelGGL((agg_fwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         hipLaunchKernelGGL((agg_hub_slices<C, false>), gs, dim3(kBlock), 0, stream, p);
@@ -1030,12 +1069,12 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     return DGN_OK;
 }
 
-template <class C>
+template <class C, class O = DynOps>
 int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     const int wpb = row_waves_per_block(p);
     const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
     dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_bwd_rows<C>), grid, dim3(kWave * wpb), 0, stream, p);
+    hipLaunchKernelGGL((agg_bwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         dim3 gc((unsigned)((p.n_hub + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
@@ -1057,6 +1096,17 @@ template <int VEC, bool BWD>
 int launch_vec(const AggParams& p, unsigned tiles, hipStream_t stream) {
     const bool stats = (p.need & (NEED_SQ | NEED_MAX | NEED_MIN)) != 0;
     const bool av = p.any_av;
+    // hot aggregator lists of the reference's configs: kernels with the list baked in (dgn_agg_hot.hpp)
+    static const bool no_hot = getenv("DGN_NO_HOT") != nullptr;
+#define DGN_HOT(NA, OPS, CHS, NS, SCS, N, S, A)                                                                  \
+    if (!no_hot && p.n_agg == NA && p.op_pack == OPS && p.ch_pack == CHS && p.n_scalers == NS && p.scaler_pack == SCS && \
+        p.agg_total == NA && p.agg_offset == 0 && p.n_ch == N) {                                                 \
+        using O = StaticOps<NA, OPS, CHS, NS, SCS>;                                                              \
+        if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A>, O>(p, tiles, stream);                   \
+        else return launch_forward_cfg<Cfg<VEC, N, S, A>, O>(p, tiles, stream);                                  \
+    }
+#include "dgn_agg_hot.hpp"
+#undef DGN_HOT
 #define DGN_GO(N, S, A)                                                                              \
     if (p.n_ch == N && stats == S && av == A) {                                                      \
         if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A>>(p, tiles, stream);          \
