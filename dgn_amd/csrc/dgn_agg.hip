@@ -52,6 +52,7 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
     if (spec->n_scalers < 1 || spec->n_scalers > DGN_MAX_SCALERS) { set_error("n_scalers=%d outside 1..%d", spec->n_scalers, DGN_MAX_SCALERS); return DGN_ERR_INVALID; }
     if (spec->n_towers < 1 || msg->F < 1 || msg->F % spec->n_towers != 0) { set_error("F=%lld not divisible by n_towers=%d", (long long)msg->F, spec->n_towers); return DGN_ERR_INVALID; }
     if (!msg->x_src && !msg->x_dst && !msg->m_edge) { set_error("message has no term"); return DGN_ERR_INVALID; }
+    if ((int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) * msg->F > INT32_MAX) { set_error("output row wider than 2^31 columns"); return DGN_ERR_INVALID; }
     if (msg->ld_src > INT32_MAX || msg->ld_dst > INT32_MAX || msg->ld_edge > INT32_MAX || msg->ld_in > INT32_MAX) { set_error("row strides must fit in int32"); return DGN_ERR_INVALID; }
     bool need_scale = false;
     for (int s = 0; s < spec->n_scalers; ++s) {

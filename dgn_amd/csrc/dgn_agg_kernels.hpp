@@ -264,22 +264,22 @@ __device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggPa
         b.load(p, base, end);
         const int cnt = min(kWave, end - base);
         // groups of U gathers in flight; the last (partial) group is predicated, NOT a one-at-a-time loop:
-        // molecule rows have 2-3 slots, and a scalar remainder loop would serialise their gather latencies
-        for (int k = 0; k < cnt; k += U) {
-            float m[U][VEC];
+        // molecule rows have 2-3 slots, and a scalar remainder loop would serialise their gather latencies.
+        // ONE exec-mask region for the whole batch (v_readlane ignores exec), not one per load.
+        if (active) {
+            for (int k = 0; k < cnt; k += U) {
+                float m[U][VEC];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k + u < cnt) {
-                    const int s = bcast_i(b.src, k + u);
-                    if (active) load_msg<VEC>(m[u], p, s, base + k + u, f0, xd);
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < cnt) load_msg<VEC>(m[u], p, bcast_i(b.src, k + u), base + k + u, f0, xd);
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k + u < cnt && active) {
-                    float wk[C::NW];
-                    b.weights(wk, k + u);
-                    acc.add(m[u], wk, base + k + u);
+                for (int u = 0; u < U; ++u) {
+                    if (k + u < cnt) {
+                        float wk[C::NW];
+                        b.weights(wk, k + u);
+                        acc.add(m[u], wk, base + k + u);
+                    }
                 }
             }
         }
@@ -340,12 +340,14 @@ __device__ __forceinline__ float scaler_factor(int kind, float logd, float avg) 
 // output column of (scaler s, aggregator a, feature f) in the [T][S][A][Ft] layout, split into a
 // per-lane part (tower block + feature inside the tower, computed once per wave) and a wave-uniform part
 __device__ __forceinline__ int64_t lane_col(const AggParams& p, int f) {
+    if (p.n_towers == 1) return f;          // (uniform) no tower blocks: skip the integer division
     const int t = f / p.Ft;
     const int ft = f - t * p.Ft;
     return (int64_t)t * ((int64_t)p.n_scalers * p.agg_total * p.Ft) + ft;
 }
-__device__ __forceinline__ int64_t sa_col(const AggParams& p, int s, int a) {
-    return ((int64_t)s * p.agg_total + p.agg_offset + a) * p.Ft;
+// 32-bit on purpose (S*A*F < 2^31 is validated on the host): one scalar multiply instead of a 64x64 one
+__device__ __forceinline__ int sa_col(const AggParams& p, int s, int a) {
+    return (s * p.agg_total + p.agg_offset + a) * p.Ft;
 }
 
 // r = sum_j w_j m_j - (sum_j w_j) x  with the reference's two roundings (aggregators.py:52/:59)
@@ -802,12 +804,12 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
         b.load(p, base, end);
         const int my_tpos = (p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
         const int cnt = min(kWave, end - base);
+        if (!active) continue;      // (lanes beyond F only help loading the slot batch)
         for (int kk = 0; kk < cnt; ++kk) {
             const int s = bcast_i(b.src, kk);
             const int tp = bcast_i(my_tpos, kk);
             float wk[C::NW];
             b.weights(wk, kk);
-            if (!active) continue;
             const int pos = base + kk;
             float gm[VEC];
 #pragma unroll
