@@ -38,7 +38,7 @@ class DgnAggSpec(C.Structure):
     _fields_ = [("n_agg", C.c_int32), ("agg_op", C.c_int32 * DGN_MAX_AGG), ("agg_ch", C.c_int32 * DGN_MAX_AGG),
                 ("n_ch", C.c_int32), ("n_scalers", C.c_int32), ("scaler", C.c_int32 * DGN_MAX_SCALERS),
                 ("avg_log", C.c_float), ("eps", C.c_float), ("n_towers", C.c_int32), ("agg_total", C.c_int32),
-                ("agg_offset", C.c_int32)]
+                ("agg_offset", C.c_int32), ("tower_stride", C.c_int64)]
 
 
 class DgnMsg(C.Structure):

@@ -16,7 +16,7 @@ bool aligned(const void* ptr, int bytes) { return (reinterpret_cast<uintptr_t>(p
 int pick_vec(const DgnAggSpec* spec, const DgnMsg* msg, const float* out, int64_t ld_out, const DgnMsgGrad* gr) {
     const int64_t Ft = msg->F / spec->n_towers;
     for (int vec : {4, 2}) {
-        bool ok = (msg->F % vec == 0) && (Ft % vec == 0) && (ld_out % vec == 0) && aligned(out, 4 * vec);
+        bool ok = (msg->F % vec == 0) && (Ft % vec == 0) && (ld_out % vec == 0) && aligned(out, 4 * vec) && (spec->tower_stride % vec == 0);
         // keep more than half of the 64 lanes busy, unless the row is too narrow anyway
         if (msg->F / vec <= 32 && vec > 2) ok = false;
         auto chk = [&](const float* ptr, int64_t ld) {
@@ -91,6 +91,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
     p.n_agg = spec->n_agg; p.agg_total = spec->agg_total > 0 ? spec->agg_total : spec->n_agg;
     p.agg_offset = spec->agg_total > 0 ? spec->agg_offset : 0;
     p.n_ch = spec->n_ch; p.n_scalers = spec->n_scalers; p.n_towers = spec->n_towers;
+    p.tower_stride = spec->tower_stride > 0 ? spec->tower_stride : (int64_t)spec->n_scalers * p.agg_total * p.Ft;
     p.avg_log = spec->avg_log; p.eps = spec->eps;
     uint32_t need = 0;
     for (int a = 0; a < spec->n_agg; ++a) {
@@ -164,7 +165,8 @@ extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const 
     int rc = validate(g, spec, msg, w, log_deg);
     if (rc) return rc;
     if (g->n_nodes == 0) return DGN_OK;
-    const int64_t width = (int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) * msg->F;
+    const int64_t width = (int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) *
+                          (spec->tower_stride > 0 ? msg->F / spec->n_towers : msg->F);
     if (!out || ld_out < width) { set_error("out is null or ld_out too small"); return DGN_ERR_INVALID; }
     if (g->n_hub > 0 && (!ws || ws_bytes < hub_ws_bytes(g, spec, msg->F))) { set_error("workspace too small: need %zu bytes", hub_ws_bytes(g, spec, msg->F)); return DGN_ERR_WORKSPACE; }
     AggParams p;
@@ -184,7 +186,8 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     if (rc) return rc;
     if (!grads) { set_error("null grads"); return DGN_ERR_INVALID; }
     if (g->n_nodes == 0) return DGN_OK;
-    const int64_t width = (int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) * msg->F;
+    const int64_t width = (int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) *
+                          (spec->tower_stride > 0 ? msg->F / spec->n_towers : msg->F);
     if (!g_out || ld_gout < width) { set_error("g_out is null or ld_gout too small"); return DGN_ERR_INVALID; }
     if (g->n_hub > 0 && (!ws || ws_bytes < hub_ws_bytes(g, spec, msg->F))) { set_error("workspace too small: need %zu bytes", hub_ws_bytes(g, spec, msg->F)); return DGN_ERR_WORKSPACE; }
     AggParams p;

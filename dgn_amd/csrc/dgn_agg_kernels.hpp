@@ -73,6 +73,7 @@ struct AggParams {
     int32_t n_ch;
     int32_t n_scalers;
     int32_t n_towers;
+    int64_t tower_stride;  // elements between the column blocks of consecutive towers
     // aggregator / scaler lists packed into scalars (4 bits per op, 3 per channel, 2 per scaler): the
     // epilogue decodes them with scalar ALU ops instead of a chain of dependent kernarg loads
     uint64_t op_pack;
@@ -343,7 +344,7 @@ __device__ __forceinline__ int64_t lane_col(const AggParams& p, int f) {
     if (p.n_towers == 1) return f;          // (uniform) no tower blocks: skip the integer division
     const int t = f / p.Ft;
     const int ft = f - t * p.Ft;
-    return (int64_t)t * ((int64_t)p.n_scalers * p.agg_total * p.Ft) + ft;
+    return (int64_t)t * p.tower_stride + ft;
 }
 // 32-bit on purpose (S*A*F < 2^31 is validated on the host): one scalar multiply instead of a 64x64 one
 __device__ __forceinline__ int sa_col(const AggParams& p, int s, int a) {

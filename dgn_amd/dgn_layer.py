@@ -335,16 +335,16 @@ class DGNLayerTower(nn.Module):
             m_edge = F.linear(graph.to_slot_order(e), torch.cat([l.weight[:, 2 * fi:] for l in lins], dim=0))
         # the sweep runs WITHOUT scalers: they are per-row factors and are folded into posttrans below
         agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
-                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T)      # [N, T, A*fi]
+                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
         posts = [t.posttrans.fully_connected[0].linear for t in self.towers]
         S = self.plan.n_scalers
         N = h.shape[0]
-        K = agg.shape[1] // T
+        K = agg.shape[2]
         w_a = torch.stack([l.weight[:, fi:] for l in posts])                         # [T, fo, S*K]
         w_h = torch.stack([l.weight[:, :fi] for l in posts])                         # [T, fo, fi]
         b_p = torch.stack([l.bias for l in posts])                                   # [T, fo]
         w_a = w_a.view(T, fo, S, K).permute(0, 2, 1, 3).reshape(T, S * fo, K)
-        z = torch.bmm(agg.view(N, T, K).transpose(0, 1), w_a.transpose(1, 2))        # [T, N, S*fo]
+        z = torch.bmm(agg, w_a.transpose(1, 2))                                      # [T, N, S*fo], all contiguous
         if S > 1:
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)       # [N, S]
             y = (z.view(T, N, S, fo) * sc.view(1, N, S, 1)).sum(dim=2)               # [T, N, fo]

@@ -23,8 +23,8 @@ from .spec import EPS, AggPlan
 DETERMINISTIC_BACKWARD = "auto"
 
 
-def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float):
-    key = (n_towers, float(avg_log))
+def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
+    key = (n_towers, float(avg_log), int(tower_stride))
     cache = plan.__dict__.setdefault("_spec_cache", {})
     if key not in cache:
         specs = []
@@ -39,6 +39,7 @@ def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float):
                 s.scaler[i] = k
             s.avg_log, s.eps, s.n_towers = float(avg_log), EPS, n_towers
             s.agg_total, s.agg_offset = plan.n_agg, l.agg_offset
+            s.tower_stride = int(tower_stride)
             specs.append(s)
         cache[key] = specs
     return cache[key]
@@ -68,13 +69,22 @@ def _msg_struct(F, x_src, x_dst, m_edge, x_in):
     return m
 
 
+def _out_layout(t: torch.Tensor):
+    """(tower_stride, row stride) of an output / upstream-gradient tensor: [N, W] node-major (tower blocks inside
+    the row, tower_stride 0 = default) or [T, N, K] tower-major."""
+    if t.dim() == 3:
+        return t.stride(0), t.stride(1)
+    return 0, t.stride(0)
+
+
 def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out):
     """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream."""
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
     F = ref.shape[1]
     stream = torch.cuda.current_stream(ref.device).cuda_stream
-    specs = _spec_structs(plan, n_towers, avg_log)
+    tower_stride, ld_out = _out_layout(out)
+    specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
     msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
     g = graph.c_graph
     for spec, l in zip(specs, plan.launches):
@@ -82,7 +92,7 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
         ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
         wl = w[l.ch_offset:] if (w is not None and l.channels) else None
         rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                 graph.log_deg.data_ptr(), out.data_ptr(), out.stride(0), _ptr(ws), nbytes, stream)
+                                 graph.log_deg.data_ptr(), out.data_ptr(), ld_out, _ptr(ws), nbytes, stream)
         _lib.check(rc, "dgn_agg_forward")
 
 
@@ -100,7 +110,8 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
     msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    specs = _spec_structs(plan, n_towers, avg_log)
+    tower_stride, ld_gout = _out_layout(g_out)
+    specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
     g = graph.c_graph
     first = True
     deterministic = (F % 2 == 0) if DETERMINISTIC_BACKWARD == "auto" else bool(DETERMINISTIC_BACKWARD)
@@ -118,7 +129,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
             tmp = torch.empty_like(g_edge)
             grads.g_edge = tmp.data_ptr()
         rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                  graph.log_deg.data_ptr(), g_out.data_ptr(), g_out.stride(0), C.byref(grads),
+                                  graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, C.byref(grads),
                                   _ptr(ws), nbytes, stream)
         _lib.check(rc, "dgn_agg_backward")
         if tmp is not None:
@@ -130,7 +141,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
 class _DirectionalAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in,
-                xin_is_src: bool):
+                xin_is_src: bool, tower_major: bool = False):
         lib = _lib.load()
         ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
         if ref is None:
@@ -147,7 +158,10 @@ class _DirectionalAggregate(torch.autograd.Function):
             raise ValueError("dx aggregators need x_in (h_in of reduce_func)")
         if ref.device != graph.device:
             raise ValueError(f"features on {ref.device} but graph on {graph.device}")
-        out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
+        if tower_major:
+            out = torch.empty((n_towers, N, plan.out_width(F) // n_towers), dtype=torch.float32, device=ref.device)
+        else:
+            out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
         launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out)
         ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
         ctx.has = (x_src is not None, x_dst is not None, m_edge is not None, x_in is not None and not xin_is_src)
@@ -175,14 +189,15 @@ class _DirectionalAggregate(torch.autograd.Function):
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
         return (None, None, None, None, None, g_src if (need_src or ctx.xin_is_src) else None, g_dst, g_edge,
-                None if ctx.xin_is_src else g_in, None)
+                None if ctx.xin_is_src else g_in, None, None)
 
 
 def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Optional[torch.Tensor] = None,
                           x_dst: Optional[torch.Tensor] = None, m_edge: Optional[torch.Tensor] = None,
                           x_in: Optional[torch.Tensor] = None, eig: Optional[torch.Tensor] = None,
-                          n_towers: int = 1, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out [N, T*S*A*(F/T)]: every aggregator of ``plan`` x every applied scaler over the messages
+                          n_towers: int = 1, weights: Optional[torch.Tensor] = None, tower_major: bool = False) -> torch.Tensor:
+    """out [N, T*S*A*(F/T)] (or, with ``tower_major``, [T, N, S*A*(F/T)] so that the per-tower batched GEMMs that
+    follow read contiguous matrices): every aggregator of ``plan`` x every applied scaler over the messages
     ``m_j = x_src[src_j] + x_dst[i] + m_edge[j]`` (``m_edge`` in CSR slot order, see
     ``DGNGraph.to_slot_order``).  ``x_in`` is ``h_in`` of the reference's reduce_func; if it is the
     same tensor as ``x_src`` (simple layer) both gradients land in one buffer."""
@@ -190,4 +205,4 @@ def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Option
     w = weights if weights is not None else graph.edge_weights(plan, eig)
     xin_is_src = x_in is not None and x_in is x_src
     return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, x_src, x_dst, m_edge,
-                                       None if xin_is_src else x_in, xin_is_src)
+                                       None if xin_is_src else x_in, xin_is_src, tower_major)

@@ -122,6 +122,11 @@ typedef struct DgnAggSpec {
      * aggregators [agg_offset, agg_offset + n_agg) out of agg_total (0 = n_agg, offset 0).       */
     int32_t agg_total;
     int32_t agg_offset;
+    /* Distance (in elements) between the column blocks of consecutive towers; 0 = n_scalers*agg_total*(F/T),
+     * i.e. the towers of a node are contiguous inside its row.  With tower_stride = n_nodes*ld_out and
+     * ld_out = n_scalers*agg_total*(F/T) the output is tower-major [T][N][S*A*F/T]: the batched per-tower GEMMs
+     * that follow then read (and their backward writes) contiguous matrices.  Applies to out and g_out.   */
+    int64_t tower_stride;
 } DgnAggSpec;
 
 /* The message of CSR slot j into node i is  m_j = x_src[src_j] + x_dst[i] + m_edge[j];

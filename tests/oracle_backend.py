@@ -7,7 +7,7 @@ from oracle import dgn_oracle as orc
 
 
 def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m_edge=None, x_in=None, eig=None,
-                                 n_towers=1, weights=None):
+                                 n_towers=1, weights=None, tower_major=False):
     src = graph.src.long()
     dst = torch.repeat_interleave(torch.arange(graph.num_nodes), graph.in_degree)
     msg = 0
@@ -27,4 +27,6 @@ def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m
         N = out.shape[0]
         SA = out.shape[1] // F_
         out = out.view(N, SA, n_towers, F_ // n_towers).permute(0, 2, 1, 3).reshape(N, -1)
+    if tower_major:       # [N, T*K] -> [T, N, K]
+        out = out.view(out.shape[0], n_towers, -1).transpose(0, 1).contiguous()
     return out

@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     # sizes implied by include/dgn_hip.h on LP64
     assert C.sizeof(_lib.DgnChannel) == 16
     assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2
-    assert C.sizeof(_lib.DgnAggSpec) == 4 * (1 + 16 + 16 + 1 + 1 + 4 + 1 + 1 + 1 + 1 + 1)
+    assert C.sizeof(_lib.DgnAggSpec) == 4 * (1 + 16 + 16 + 1 + 1 + 4 + 1 + 1 + 1 + 1 + 1) + 8
     assert C.sizeof(_lib.DgnMsg) == 8 * 9
     assert C.sizeof(_lib.DgnMsgGrad) == 8 * 8
     header = open(os.path.join(ROOT, "include", "dgn_hip.h")).read()
