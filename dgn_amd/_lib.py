@@ -27,7 +27,7 @@ class DgnGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("indptr", C.c_void_p), ("src", C.c_void_p),
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
-                ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p)]
+                ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32)]
 
 
 class DgnChannel(C.Structure):

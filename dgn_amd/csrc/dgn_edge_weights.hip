@@ -119,12 +119,49 @@ __device__ __forceinline__ void range_write(const Stats (&st)[DGN_MAX_CH], const
     }
 }
 
+// Rows of at most kFlatMax slots (every row of a molecule batch) are handled one per THREAD by ew_rows_flat:
+// per-edge weights are a few scalars per slot, so a wave per 2-slot row would be all launch overhead.
+constexpr int kFlatMax = 16;
+
+__global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) {
+    const int64_t row64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row64 >= p.n_nodes) return;
+    const int row = (int)row64;
+    const int beg = p.indptr[row], end = p.indptr[row + 1];
+    const int deg = end - beg;
+    if (deg == 0 || deg > kFlatMax) return;
+#pragma unroll
+    for (int c = 0; c < DGN_MAX_CH; ++c) {
+        if (c >= p.n_ch) break;
+        const int col = p.ch[c].eig_col;
+        const float eps = p.ch[c].eps, alpha = p.ch[c].alpha;
+        const int kind = p.ch[c].kind;
+        float sabs = 0.f, spos = 0.f, sneg = 0.f, mx = -INFINITY;
+        for (int e = beg; e < end; ++e) {
+            const float d = edge_delta(p, row, e, col);
+            sabs += fabsf(d); spos += fmaxf(d, 0.f); sneg += fmaxf(-d, 0.f);
+            mx = fmaxf(mx, alpha * fabsf(d));
+        }
+        float se = 0.f;
+        if (kind == DGN_W_SOFTMAX)
+            for (int e = beg; e < end; ++e) se += expf(alpha * fabsf(edge_delta(p, row, e, col)) - mx);
+        for (int e = beg; e < end; ++e) {
+            const float d = edge_delta(p, row, e, col);
+            float v;
+            if (kind == DGN_W_ABSNORM) v = d / (sabs + eps);
+            else if (kind == DGN_W_BALANCED) v = (fmaxf(d, 0.f) / (spos + eps) + fmaxf(-d, 0.f) / (sneg + eps)) / 2.f;
+            else v = expf(alpha * fabsf(d) - mx) / se;
+            p.w[(int64_t)c * p.ld_w + e] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void ew_rows(const EwParams p) {
     const int64_t row64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row64 >= p.n_nodes) return;
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
-    if (end == beg || end - beg > p.hub_threshold) return;
+    if (end - beg <= kFlatMax || end - beg > p.hub_threshold) return;    // short rows: ew_rows_flat; hubs: slices
     Stats st[DGN_MAX_CH];
     range_stats(st, p, row, beg, end);
     range_write(st, p, row, beg, end);
@@ -232,8 +269,11 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
         p.slice_stats = static_cast<float*>(ws);
         p.hub_stats = reinterpret_cast<float*>(static_cast<char*>(ws) + up((size_t)g->n_chunks * DGN_MAX_CH * 5 * sizeof(float)));
     }
-    const unsigned nb = (unsigned)((p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(ew_rows, dim3(nb), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL(ew_rows_flat, dim3((unsigned)((p.n_nodes + 255) / 256)), dim3(256), 0, stream, p);
+    if (g->max_in_degree == 0 || g->max_in_degree > kFlatMax) {     // skipped when every row is known to be short
+        const unsigned nb = (unsigned)((p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock);
+        hipLaunchKernelGGL(ew_rows, dim3(nb), dim3(kBlock), 0, stream, p);
+    }
     if (p.n_hub > 0) {
         const unsigned ns = (unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
         hipLaunchKernelGGL(ew_hub_slice_stats, dim3(ns), dim3(kBlock), 0, stream, p);

@@ -77,11 +77,13 @@ class DGNGraph:
         self.hub_threshold, self.hub_chunk = int(hub_threshold), int(hub_chunk)
         hub_rows = torch.nonzero(deg > hub_threshold).flatten()
         self.n_hub = int(hub_rows.numel())           # one host sync per graph build
+        self.max_in_degree = int(deg.max().item()) if self.num_nodes else 0
         self._keep = []
         c = _lib.DgnGraph()
         c.n_nodes, c.n_edges = self.num_nodes, self.num_edges
         c.indptr, c.src = self.indptr.data_ptr(), self.src.data_ptr()
         c.hub_threshold, c.hub_chunk = self.hub_threshold, self.hub_chunk
+        c.max_in_degree = self.max_in_degree
         c.n_hub, c.n_chunks = 0, 0
         if self.n_hub:
             n_sl = (deg[hub_rows] + hub_chunk - 1) // hub_chunk

@@ -97,6 +97,8 @@ typedef struct DgnGraph {
      * to its csc position and a second kernel sums each source's contiguous rows: deterministic, no atomics. */
     const int32_t* csc_ptr;  /* [n_nodes+1] */
     const int32_t* csc_pos;  /* [n_edges]   */
+    /* Hint: largest in-degree, 0 = unknown.  Lets launches that only concern long rows be skipped.       */
+    int32_t max_in_degree;
 } DgnGraph;
 
 typedef struct DgnChannel {
