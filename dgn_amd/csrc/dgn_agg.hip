@@ -62,8 +62,10 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
     if (need_scale && !log_deg) { set_error("scalers need log_deg"); return DGN_ERR_INVALID; }
     for (int a = 0; a < spec->n_agg; ++a) {
         const int op = spec->agg_op[a];
-        if (op < DGN_AGG_MEAN || op > DGN_AGG_DIR_DX_NO_ABS) { set_error("unknown aggregator op %d", op); return DGN_ERR_INVALID; }
-        if (op >= DGN_AGG_DIR_AV) {
+        if (op < DGN_AGG_MEAN || op > DGN_AGG_X_IN) { set_error("unknown aggregator op %d", op); return DGN_ERR_INVALID; }
+        if (op == DGN_AGG_X_IN && !msg->x_in) { set_error("the x_in pass-through needs x_in"); return DGN_ERR_INVALID; }
+        if (op == DGN_AGG_X_IN && !(spec->n_scalers == 1 && spec->scaler[0] == DGN_SCALE_IDENTITY)) { set_error("the x_in pass-through requires the single identity scaler (fold the scalers into posttrans)"); return DGN_ERR_INVALID; }
+        if (op >= DGN_AGG_DIR_AV && op <= DGN_AGG_DIR_DX_NO_ABS) {
             if (spec->agg_ch[a] < 0 || spec->agg_ch[a] >= spec->n_ch) { set_error("aggregator %d: channel %d outside 0..%d", a, spec->agg_ch[a], spec->n_ch - 1); return DGN_ERR_INVALID; }
             if (!w) { set_error("directional aggregators need edge weights"); return DGN_ERR_INVALID; }
             if ((op == DGN_AGG_DIR_DX || op == DGN_AGG_DIR_DX_NO_ABS) && !msg->x_in) { set_error("dx aggregators need x_in"); return DGN_ERR_INVALID; }
@@ -97,7 +99,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
     for (int a = 0; a < spec->n_agg; ++a) {
         const int op = spec->agg_op[a], c = spec->agg_ch[a];
         p.op_pack |= (uint64_t)op << (4 * a);
-        p.ch_pack |= (uint64_t)(op >= DGN_AGG_DIR_AV ? c : 0) << (3 * a);
+        p.ch_pack |= (uint64_t)((op >= DGN_AGG_DIR_AV && op <= DGN_AGG_DIR_DX_NO_ABS) ? c : 0) << (3 * a);
         switch (op) {
             case DGN_AGG_MAX: need |= NEED_MAX | NEED_RECOMP; break;
             case DGN_AGG_MIN: need |= NEED_MIN | NEED_RECOMP; break;
@@ -106,6 +108,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
             case DGN_AGG_DIR_WSUM: break;
             case DGN_AGG_DIR_DX: need |= NEED_XIN | NEED_RECOMP; break;
             case DGN_AGG_DIR_DX_NO_ABS: need |= NEED_XIN; break;
+            case DGN_AGG_X_IN: need |= NEED_XIN | NEED_XPASS; break;
         }
     }
     for (int s = 0; s < spec->n_scalers; ++s) p.scaler_pack |= (uint32_t)spec->scaler[s] << (2 * s);

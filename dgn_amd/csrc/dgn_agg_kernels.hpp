@@ -41,7 +41,8 @@ enum : uint32_t {
     NEED_SQ = 2u, NEED_MAX = 4u, NEED_MIN = 8u,
     NEED_XIN = 16u,      // some dx aggregator reads x_in
     NEED_RECOMP = 32u,   // backward must recompute the accumulators
-    NEED_M_EMIT = 64u    // backward emit pass needs the message value (var/std)
+    NEED_M_EMIT = 64u,   // backward emit pass needs the message value (var/std)
+    NEED_XPASS = 128u    // the list contains the x_in pass-through (zero-degree rows still carry its gradient)
 };
 
 struct AggParams {
@@ -439,6 +440,11 @@ __device__ __forceinline__ void agg_value(float (&val)[C::VEC], int op, int c, c
         }
         return;
     }
+    if (op == DGN_AGG_X_IN) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) val[i] = xin[i];
+        return;
+    }
     float wsv[VEC], wav[VEC], swv;
     pick_channel<C, TRACK>(wsv, wav, swv, acc, c);
 #pragma unroll
@@ -460,12 +466,13 @@ template <class C, class O = DynOps>
 __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggParams& p, float* orow, int deg,
                                           const float (&xin)[C::VEC], float logd) {
     constexpr int VEC = C::VEC;
-    if (deg == 0) {
+    if (deg == 0) {      // no messages: zeros (DGL fills such rows from the zero initializer); the x_in block is still x_in
         float z[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) z[i] = 0.f;
         for (int s = 0; s < O::n_scalers(p); ++s)
-            for (int a = 0; a < O::n_agg(p); ++a) stv<VEC>(orow + sa_col(p, s, a), z);
+            for (int a = 0; a < O::n_agg(p); ++a)
+                stv<VEC>(orow + sa_col(p, s, a), (O::op(p, a) == DGN_AGG_X_IN && O::scaler(p, s) == DGN_SCALE_IDENTITY) ? xin : z);
         return;
     }
     const float d = (float)deg;
@@ -691,6 +698,11 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
     auto apply = [&](int a, const float (&g)[VEC]) {
         const int op = O::op(p, a);
         const int c = O::ch(p, a);
+        if (op == DGN_AGG_X_IN) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gxin[i] += g[i];
+            return;
+        }
         if (op < DGN_AGG_DIR_AV) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -893,9 +905,24 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
-    if (deg == 0 || deg > p.hub_threshold) return;
+    if (deg > p.hub_threshold) return;
     const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
     const bool active = f0 < p.F;
+    if (deg == 0) {          // no messages, no gradient -- except through the x_in pass-through block
+        if ((p.need & NEED_XPASS) && active && p.g_in) {
+            const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+            for (int a = 0; a < O::n_agg(p); ++a) {
+                if (O::op(p, a) == DGN_AGG_X_IN) {
+                    float g[VEC];
+                    ldv<VEC>(g, grow + sa_col(p, 0, a));
+                    float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, g[i]);
+                }
+            }
+        }
+        return;
+    }
     float xd[VEC], xin[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }

@@ -22,9 +22,9 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import directional_aggregate
-from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, make_plan, parse_aggregator,
-                   parse_scaler)
+from .ops import directional_aggregate, scale_combine
+from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
+                   parse_aggregator, parse_scaler)
 
 
 class _Named:
@@ -152,6 +152,26 @@ def _fold_scalers(weight, agg, sc):
     return (z.view(N, S, Fo) * sc.unsqueeze(-1)).sum(dim=1)
 
 
+def _identity_slot(applied_scalers):
+    """Index of the identity scaler among the applied ones (None if absent): the h block of posttrans([h || agg])
+    is not scaled, so in the folded form its weights live in the identity scaler's output block."""
+    for i, k in enumerate(applied_scalers):
+        if k == SCALE_IDENTITY:
+            return i
+    return None
+
+
+def _folded_weight(w_agg, w_h, S, id_slot):
+    """[fo, S*K] (scaler-major) and [fo, fi] -> [S*fo, K+fi] acting on [agg | h]: row block s holds W_s, and the
+    h columns are W_h in the identity block, zero elsewhere."""
+    fo = w_agg.shape[0]
+    K = w_agg.shape[1] // S
+    w = w_agg.reshape(fo, S, K).permute(1, 0, 2)                                     # [S, fo, K]
+    hcols = torch.zeros(S, fo, w_h.shape[1], dtype=w_h.dtype, device=w_h.device)
+    hcols = torch.cat([hcols[:id_slot], w_h.unsqueeze(0), hcols[id_slot + 1:]], dim=0)
+    return torch.cat([w, hcols], dim=2).reshape(S * fo, K + w_h.shape[1])
+
+
 def _posttrans_split(posttrans: MLP, h, agg, in_dim):
     """posttrans(cat([h, agg])) without building the concat when posttrans is one Linear."""
     if posttrans.is_single_affine():
@@ -185,14 +205,19 @@ class DGNLayerSimple(nn.Module):
     def forward(self, g, h, e, snorm_n):
         h_in = h
         if self.posttrans.is_single_affine() and self.plan.n_scalers > 1:
+            # scalers folded behind the Linear: sweep without scalers -> one GEMM -> scale-combine (+bias, +snorm)
             graph = as_dgn_graph(g)
             lin = self.posttrans.fully_connected[0].linear
+            S, fo = self.plan.n_scalers, lin.weight.shape[0]
+            agg = self.aggregate(graph, h, self._kplan)
+            w = lin.weight.reshape(fo, S, agg.shape[1]).permute(1, 0, 2).reshape(S * fo, agg.shape[1])
+            z = F.linear(agg, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
-            h = _fold_scalers(lin.weight, self.aggregate(graph, h, self._kplan), sc) + lin.bias
+            h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
         else:
             h = self.posttrans(self.aggregate(g, h))
-        if self.graph_norm:
-            h = h * snorm_n
+            if self.graph_norm:
+                h = h * snorm_n
         if self.batch_norm:
             h = self.batchnorm_h(h)
         h = F.relu(h)
@@ -212,6 +237,7 @@ class DGNLayerComplex(nn.Module):
         self.aggregators, self.scalers = _names(aggregators), _names(scalers)
         self.plan = make_plan(self.aggregators, self.scalers)
         self._kplan = make_plan(self.aggregators, ["identity"])
+        self._kplan_x = make_plan(self.aggregators + [X_IN_NAME], ["identity"])     # + h_in pass-through block
         self.batchnorm_h = nn.BatchNorm1d(out_dim)
         self.pretrans = MLP(in_size=2 * in_dim + (edge_dim if edge_features else 0), hidden_size=in_dim,
                             out_size=in_dim, layers=pretrans_layers, mid_activation="relu", last_activation="none")
@@ -230,16 +256,22 @@ class DGNLayerComplex(nn.Module):
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
-        if self.posttrans.is_single_affine() and self.plan.n_scalers > 1:
+        id_slot = _identity_slot(self.plan.applied_scalers)
+        if self.posttrans.is_single_affine() and self.plan.n_scalers > 1 and id_slot is not None:
+            # sweep without scalers and WITH the h_in pass-through block -> posttrans([h || agg]) is one GEMM ->
+            # scale-combine (+bias, +snorm)
             graph = as_dgn_graph(g)
             lin = self.posttrans.fully_connected[0].linear
+            S, fo = self.plan.n_scalers, lin.weight.shape[0]
+            aggx = self.aggregate(graph, h, e, self._kplan_x)                          # [N, A*F | F]
+            w = _folded_weight(lin.weight[:, self.in_dim:], lin.weight[:, :self.in_dim], S, id_slot)
+            z = F.linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
-            h = (_fold_scalers(lin.weight[:, self.in_dim:], self.aggregate(graph, h, e, self._kplan), sc)
-                 + F.linear(h, lin.weight[:, :self.in_dim], lin.bias))
+            h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
         else:
             h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
-        if self.graph_norm:
-            h = h * snorm_n
+            if self.graph_norm:
+                h = h * snorm_n
         if self.batch_norm:
             h = self.batchnorm_h(h)
         h = F.relu(h)
@@ -308,6 +340,7 @@ class DGNLayerTower(nn.Module):
         self.mixing_network = FCLayer(out_dim, out_dim, activation="LeakyReLU")
         self.plan = self.towers[0].plan
         self._kplan = make_plan(self.plan.aggregators, ["identity"])
+        self._kplan_x = make_plan(list(self.plan.aggregators) + [X_IN_NAME], ["identity"])
         self._avg_log = _avg_log(avg_d)
 
     def _fusable(self) -> bool:
@@ -333,28 +366,34 @@ class DGNLayerTower(nn.Module):
         m_edge = None
         if self.edge_features:
             m_edge = F.linear(graph.to_slot_order(e), torch.cat([l.weight[:, 2 * fi:] for l in lins], dim=0))
-        # the sweep runs WITHOUT scalers: they are per-row factors and are folded into posttrans below
-        agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
-                                    x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
         posts = [t.posttrans.fully_connected[0].linear for t in self.towers]
         S = self.plan.n_scalers
         N = h.shape[0]
-        K = agg.shape[2]
-        w_a = torch.stack([l.weight[:, fi:] for l in posts])                         # [T, fo, S*K]
-        w_h = torch.stack([l.weight[:, :fi] for l in posts])                         # [T, fo, fi]
-        b_p = torch.stack([l.bias for l in posts])                                   # [T, fo]
-        w_a = w_a.view(T, fo, S, K).permute(0, 2, 1, 3).reshape(T, S * fo, K)
-        z = torch.bmm(agg, w_a.transpose(1, 2))                                      # [T, N, S*fo], all contiguous
-        if S > 1:
-            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)       # [N, S]
-            y = (z.view(T, N, S, fo) * sc.view(1, N, S, 1)).sum(dim=2)               # [T, N, fo]
+        b_p = torch.cat([l.bias for l in posts])                                     # [T*fo]
+        id_slot = _identity_slot(self.plan.applied_scalers)
+        row_scale = snorm_n if self.graph_norm else None
+        if id_slot is not None:
+            # The sweep runs WITHOUT scalers (per-row factors, folded behind the GEMM) and WITH the h_in
+            # pass-through block, tower-major: posttrans([h_t || agg_t]) of all towers is ONE batched GEMM on
+            # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
+            aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:],
+                                         m_edge=m_edge, x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)
+            w = torch.stack([_folded_weight(l.weight[:, fi:], l.weight[:, :fi], S, id_slot) for l in posts])   # [T, S*fo, K+fi]
+            z = torch.bmm(aggx, w.transpose(1, 2))                                   # [T, N, S*fo]
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+            y = scale_combine(z, sc, b_p, row_scale)                                 # [N, T*fo]
         else:
-            y = z
-        h_t = x_in.view(N, T, fi).transpose(0, 1)
-        y = y + torch.bmm(h_t, w_h.transpose(1, 2)) + b_p.unsqueeze(1)
-        y = y.transpose(0, 1).reshape(N, T * fo)
-        if self.graph_norm:
-            y = y * snorm_n
+            agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
+                                        x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
+            K = agg.shape[2]
+            w_a = torch.stack([l.weight[:, fi:] for l in posts]).view(T, fo, S, K).permute(0, 2, 1, 3).reshape(T, S * fo, K)
+            w_h = torch.stack([l.weight[:, :fi] for l in posts])                     # [T, fo, fi]
+            z = torch.bmm(agg, w_a.transpose(1, 2))                                  # [T, N, S*fo]
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+            y = scale_combine(z, sc, b_p, None)
+            y = y + torch.bmm(x_in.view(N, T, fi).transpose(0, 1), w_h.transpose(1, 2)).transpose(0, 1).reshape(N, T * fo)
+            if row_scale is not None:
+                y = y * row_scale
         if self.batch_norm:
             bns = [t.batchnorm_h for t in self.towers]
             rm = torch.cat([b.running_mean for b in bns])

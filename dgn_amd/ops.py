@@ -206,3 +206,55 @@ def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Option
     xin_is_src = x_in is not None and x_in is x_src
     return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, x_src, x_dst, m_edge,
                                        None if xin_is_src else x_in, xin_is_src, tower_major)
+
+
+class _ScaleCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, scale, bias, row_scale):
+        lib = _lib.load()
+        if not z.is_cuda:
+            raise _lib.DgnError("scale_combine: CUDA tensors only (dgn_amd has no CPU path)")
+        T, N, W = z.shape
+        S = 1 if scale is None else scale.shape[1]
+        fo = W // S
+        z = z.contiguous()
+        y = torch.empty((N, T * fo), dtype=torch.float32, device=z.device)
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        rc = lib.dgn_scale_combine_forward(N, T, S, fo, z.data_ptr(), _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(),
+                                           y.stride(0), stream)
+        _lib.check(rc, "dgn_scale_combine_forward")
+        ctx.save_for_backward(scale, row_scale)
+        ctx.dims = (T, N, S, fo, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        lib = _lib.load()
+        scale, row_scale = ctx.saved_tensors
+        T, N, S, fo, has_bias = ctx.dims
+        g_y = g_y.contiguous()
+        g_z = torch.empty((T, N, S * fo), dtype=torch.float32, device=g_y.device)
+        stream = torch.cuda.current_stream(g_y.device).cuda_stream
+        rc = lib.dgn_scale_combine_backward(N, T, S, fo, g_y.data_ptr(), g_y.stride(0), _ptr(scale), _ptr(row_scale),
+                                            g_z.data_ptr(), stream)
+        _lib.check(rc, "dgn_scale_combine_backward")
+        g_b = None
+        if has_bias and ctx.needs_input_grad[2]:
+            g_b = (g_y * row_scale.view(-1, 1)).sum(0) if row_scale is not None else g_y.sum(0)
+        return g_z, None, g_b, None
+
+
+def scale_combine(z: torch.Tensor, scale: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                  row_scale: Optional[torch.Tensor]) -> torch.Tensor:
+    """y[n, t*fo+o] = row_scale[n] * (bias[t*fo+o] + sum_s scale[n,s] * z[t, n, s*fo+o]).
+
+    ``z [T, N, S*fo]`` is the output of the (batched) post-aggregation GEMM on the scaler-free sweep output,
+    ``scale [N, S]`` the degree-scaler table (None: single identity), ``row_scale [N]`` the graph-norm factor
+    snorm_n (None: no graph norm).  One streaming kernel instead of mul + sum + add + mul + re-layout."""
+    if scale is not None:
+        scale = scale.contiguous()
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).contiguous()
+    if bias is not None:
+        bias = bias.reshape(-1).contiguous()
+    return _ScaleCombine.apply(z, scale, bias, row_scale)

@@ -17,7 +17,8 @@ from . import _lib
 EPS = 1e-8  # aggregators.py:5
 
 # op codes (include/dgn_hip.h)
-AGG_MEAN, AGG_SUM, AGG_MAX, AGG_MIN, AGG_STD, AGG_VAR, AGG_DIR_AV, AGG_DIR_WSUM, AGG_DIR_DX, AGG_DIR_DX_NO_ABS = range(10)
+AGG_MEAN, AGG_SUM, AGG_MAX, AGG_MIN, AGG_STD, AGG_VAR, AGG_DIR_AV, AGG_DIR_WSUM, AGG_DIR_DX, AGG_DIR_DX_NO_ABS, AGG_X_IN = range(11)
+X_IN_NAME = "__x_in__"     # pseudo-aggregator: copies h_in into the output row (posttrans([h || agg]) becomes one GEMM)
 W_ABSNORM, W_BALANCED, W_SOFTMAX = range(3)
 SCALE_IDENTITY, SCALE_AMPLIFICATION, SCALE_ATTENUATION = range(3)
 
@@ -36,6 +37,8 @@ def parse_aggregator(name: str) -> Tuple[int, Channel | None]:
     """name -> (op, channel or None)."""
     if name in _PLAIN:
         return _PLAIN[name], None
+    if name == X_IN_NAME:
+        return AGG_X_IN, None
     m = _DIR_RE.match(name)
     if m is None:
         raise KeyError(name)
@@ -89,7 +92,7 @@ class AggPlan:
         return self.n_agg * self.n_scalers * F
 
     def needs_x_in(self) -> bool:
-        return any(op in (AGG_DIR_DX, AGG_DIR_DX_NO_ABS) for l in self.launches for op in l.ops)
+        return any(op in (AGG_DIR_DX, AGG_DIR_DX_NO_ABS, AGG_X_IN) for l in self.launches for op in l.ops)
 
 
 def make_plan(aggregators: Sequence[str], scalers: Sequence[str]) -> AggPlan:

@@ -59,7 +59,9 @@ enum {
     DGN_AGG_DIR_AV = 6,      /* aggregators.py:35  sum_j |w_j| m_j            (ABSNORM channel) */
     DGN_AGG_DIR_WSUM = 7,    /* aggregators.py:42  sum_j w_j m_j              (SOFTMAX channel) */
     DGN_AGG_DIR_DX = 8,      /* aggregators.py:48/:62  |sum_j w_j m_j - (sum_j w_j) x_i|        */
-    DGN_AGG_DIR_DX_NO_ABS = 9 /* aggregators.py:55  sum_j w_j m_j - (sum_j w_j) x_i             */
+    DGN_AGG_DIR_DX_NO_ABS = 9, /* aggregators.py:55  sum_j w_j m_j - (sum_j w_j) x_i            */
+    DGN_AGG_X_IN = 10        /* not an aggregator: copies x_in (h_in) into the output row, so that
+                                posttrans([h || agg]) of dgn_layer.py:116-119 is ONE GEMM on the sweep's output */
 };
 
 /* edge-weight channel kinds: how delta_j = eig[src_j,k] - eig[dst,k] becomes a per-edge weight */
@@ -184,6 +186,18 @@ size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spe
 int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                      const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* Degree scalers folded behind the post-aggregation Linear (they are per-row factors):
+ *     y[n, t*f_out + o] = row_scale[n] * (bias[t*f_out + o] + sum_s scale[n, s] * z[t][n][s*f_out + o])
+ * z is tower-major [T][N][S*f_out] (the batched GEMM output), y node-major [N, ld_y].  Replaces the scaler concat
+ * of reduce_func (dgn_layer.py:170-171) + the Linear's bias + the graph-norm multiply `h * snorm_n`
+ * (dgn_layer.py:121-122, :192-193, :270-271).  scale == NULL means S == 1 with factor 1; bias / row_scale may be NULL.
+ * The backward writes g_z (same layout as z) from g_y; the bias gradient is a plain column sum left to the caller. */
+int dgn_scale_combine_forward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* z,
+                              const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
+                              void* stream);
+int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* g_y,
+                               int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, void* stream);
 
 #ifdef __cplusplus
 }

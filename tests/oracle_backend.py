@@ -22,7 +22,11 @@ def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m
     if x_in is None:
         x_in = torch.zeros(graph.num_nodes, F_)
     avg = torch.tensor(float(avg_log))
-    out = orc.aggregate_graph(src, dst, graph.num_nodes, msg, eig, x_in, list(plan.aggregators), list(plan.scalers), avg)
+    names = [a for a in plan.aggregators if a != "__x_in__"]
+    out = orc.aggregate_graph(src, dst, graph.num_nodes, msg, eig, x_in, names, list(plan.scalers), avg)
+    if len(names) != len(plan.aggregators):      # h_in pass-through block (single identity scaler by contract)
+        assert len(plan.scalers) == 1 and list(plan.aggregators)[-1] == "__x_in__"
+        out = torch.cat([out, x_in], dim=1)
     if n_towers > 1:      # [S][A][T][Ft] -> [T][S][A][Ft]
         N = out.shape[0]
         SA = out.shape[1] // F_
@@ -30,3 +34,18 @@ def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m
     if tower_major:       # [N, T*K] -> [T, N, K]
         out = out.view(out.shape[0], n_towers, -1).transpose(0, 1).contiguous()
     return out
+
+
+def oracle_scale_combine(z, scale, bias, row_scale):
+    """torch restatement of dgn_scale_combine_forward (autograd does the backward)."""
+    T, N, W = z.shape
+    S = 1 if scale is None else scale.shape[1]
+    fo = W // S
+    y = z.view(T, N, S, fo)
+    y = (y * scale.view(1, N, S, 1)).sum(2) if scale is not None else y[:, :, 0]
+    y = y.transpose(0, 1).reshape(N, T * fo)
+    if bias is not None:
+        y = y + bias.reshape(1, -1)
+    if row_scale is not None:
+        y = y * row_scale.reshape(-1, 1)
+    return y
