@@ -98,7 +98,7 @@ def load() -> C.CDLL:
                                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dgn_scale_combine_backward.restype = C.c_int
         lib.dgn_scale_combine_backward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if lib.dgn_abi_version() != ABI_VERSION:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib

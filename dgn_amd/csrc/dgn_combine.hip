@@ -45,6 +45,20 @@ __global__ __launch_bounds__(256) void combine_bwd(int64_t n_nodes, int T, int S
     }
 }
 
+// bias gradient: column sums of row_scale[n] * gy[n, :]; a block owns a slab of rows, threads own columns
+// (coalesced row reads), one atomic per (block, column)
+__global__ __launch_bounds__(256) void combine_bias_grad(int64_t n_nodes, int width, const float* __restrict__ gy, int64_t ld_gy,
+                                                         const float* __restrict__ row_scale, float* __restrict__ g_bias,
+                                                         int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, n_nodes);
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float acc = 0.f;
+        for (int64_t n = r0; n < r1; ++n) acc += (row_scale ? row_scale[n] : 1.f) * gy[n * ld_gy + c];
+        unsafeAtomicAdd(g_bias + c, acc);
+    }
+}
+
 unsigned grid_for(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -64,12 +78,17 @@ extern "C" int dgn_scale_combine_forward(int64_t n_nodes, int32_t T, int32_t S, 
 }
 
 extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy,
-                                          const float* scale, const float* row_scale, float* g_z, void* stream) {
+                                          const float* scale, const float* row_scale, float* g_z, float* g_bias, void* stream) {
     if (n_nodes < 0 || T < 1 || S < 1 || fo < 1 || (!scale && S != 1)) { set_error("dgn_scale_combine_backward: bad shape"); return DGN_ERR_INVALID; }
     if (n_nodes == 0) return DGN_OK;
     if (!g_y || !g_z || ld_gy < (int64_t)T * fo) { set_error("dgn_scale_combine_backward: null buffer or ld_gy too small"); return DGN_ERR_INVALID; }
     hipLaunchKernelGGL(combine_bwd, dim3(grid_for((int64_t)T * n_nodes * S * fo)), dim3(256), 0, static_cast<hipStream_t>(stream), n_nodes,
                        T, S, fo, g_y, ld_gy, scale, row_scale, g_z);
+    if (g_bias) {
+        const int rows_per_block = 128;
+        hipLaunchKernelGGL(combine_bias_grad, dim3((unsigned)((n_nodes + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), n_nodes, T * fo, g_y, ld_gy, row_scale, g_bias, rows_per_block);
+    }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

@@ -234,13 +234,11 @@ class _ScaleCombine(torch.autograd.Function):
         T, N, S, fo, has_bias = ctx.dims
         g_y = g_y.contiguous()
         g_z = torch.empty((T, N, S * fo), dtype=torch.float32, device=g_y.device)
+        g_b = torch.zeros(T * fo, dtype=torch.float32, device=g_y.device) if (has_bias and ctx.needs_input_grad[2]) else None
         stream = torch.cuda.current_stream(g_y.device).cuda_stream
         rc = lib.dgn_scale_combine_backward(N, T, S, fo, g_y.data_ptr(), g_y.stride(0), _ptr(scale), _ptr(row_scale),
-                                            g_z.data_ptr(), stream)
+                                            g_z.data_ptr(), _ptr(g_b), stream)
         _lib.check(rc, "dgn_scale_combine_backward")
-        g_b = None
-        if has_bias and ctx.needs_input_grad[2]:
-            g_b = (g_y * row_scale.view(-1, 1)).sum(0) if row_scale is not None else g_y.sum(0)
         return g_z, None, g_b, None
 
 

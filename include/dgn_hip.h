@@ -192,12 +192,14 @@ int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* ms
  * z is tower-major [T][N][S*f_out] (the batched GEMM output), y node-major [N, ld_y].  Replaces the scaler concat
  * of reduce_func (dgn_layer.py:170-171) + the Linear's bias + the graph-norm multiply `h * snorm_n`
  * (dgn_layer.py:121-122, :192-193, :270-271).  scale == NULL means S == 1 with factor 1; bias / row_scale may be NULL.
- * The backward writes g_z (same layout as z) from g_y; the bias gradient is a plain column sum left to the caller. */
+ * The backward writes g_z (same layout as z) from g_y and, if g_bias != NULL, ACCUMULATES the bias gradient
+ * sum_n row_scale[n] * g_y[n, :] into g_bias [T*f_out] (caller zero-initialises; atomic adds).             */
 int dgn_scale_combine_forward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* z,
                               const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
                               void* stream);
 int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* g_y,
-                               int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, void* stream);
+                               int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, float* g_bias,
+                               void* stream);
 
 #ifdef __cplusplus
 }
