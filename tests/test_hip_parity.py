@@ -274,3 +274,45 @@ def test_errors_are_loud():
         directional_aggregate(g, plan, 1.0, x_src=h, x_in=h)
     with pytest.raises(dgn_amd._lib.DgnError):          # CPU tensors are refused, no fallback
         directional_aggregate(g, dgn_amd.make_plan(["mean"], ["identity"]), 1.0, x_src=h.cpu())
+
+
+def test_scale_combine_and_x_in_block_vs_torch():
+    """dgn_scale_combine_* and the h_in pass-through block against their plain-torch restatements (fp32)."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd.ops import directional_aggregate, scale_combine
+    from dgn_amd.spec import X_IN_NAME
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import oracle_scale_combine
+    gen = torch.Generator().manual_seed(4)
+    T_, N, S, fo = 3, 257, 3, 7
+    z = torch.randn(T_, N, S * fo, generator=gen)
+    sc, b, rs = torch.rand(N, S, generator=gen) + 0.5, torch.randn(T_ * fo, generator=gen), torch.rand(N, 1, generator=gen)
+    ct = torch.randn(N, T_ * fo, generator=gen)
+    for use_sc, use_b, use_rs in ((True, True, True), (False, True, False), (True, False, True)):
+        zz = (z if use_sc else z[:, :, :fo].contiguous())
+        zd = zz.to(dev).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True) if use_b else None
+        y = scale_combine(zd, sc.to(dev) if use_sc else None, bd, rs.to(dev) if use_rs else None)
+        zo = zz.clone().requires_grad_(True)
+        bo = b.clone().requires_grad_(True) if use_b else None
+        yo = oracle_scale_combine(zo, sc if use_sc else None, bo, rs if use_rs else None)
+        _close(y, yo, 1e-6, 1e-6)
+        y.backward(ct.to(dev)); yo.backward(ct)
+        _close(zd.grad, zo.grad, 1e-6, 1e-6)
+        if use_b:
+            _close(bd.grad, bo.grad, 1e-5, 1e-5)
+    # pass-through block: [agg | x_in], also on the zero in-degree node, and its gradient
+    src, dst = _random_graph(5, 40, 300)
+    g = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), 40, eig=torch.randn(40, 3, generator=gen).to(dev))
+    plan = dgn_amd.make_plan(["mean", "dir1-dx", X_IN_NAME], ["identity"])
+    plain = dgn_amd.make_plan(["mean", "dir1-dx"], ["identity"])
+    P = torch.randn(40, 6, generator=gen).to(dev).requires_grad_(True)
+    H = torch.randn(40, 6, generator=gen).to(dev).requires_grad_(True)
+    ya = directional_aggregate(g, plan, 1.0, x_src=P, x_in=H)
+    yb = torch.cat([directional_aggregate(g, plain, 1.0, x_src=P, x_in=H), H], dim=1)
+    _close(ya, yb, 0, 0)
+    c2 = torch.randn(40, 18, generator=gen).to(dev)
+    for a, b_ in zip(torch.autograd.grad(ya, [P, H], c2), torch.autograd.grad(yb, [P, H], c2)):
+        _close(a, b_, 1e-5, 1e-6)
