@@ -270,17 +270,34 @@ __device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggPa
         // ONE exec-mask region for the whole batch (v_readlane ignores exec), not one per load.
         if (active) {
             for (int k = 0; k < cnt; k += U) {
+                // two half-groups: a short row (<= U/2 slots) pays U/2 + 1 uniform checks instead of U
+                constexpr int H = U / 2;
+                const bool second = k + H < cnt;
                 float m[U][VEC];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < H; ++u)
                     if (k + u < cnt) load_msg<VEC>(m[u], p, bcast_i(b.src, k + u), base + k + u, f0, xd);
+                if (second) {
+#pragma unroll
+                    for (int u = H; u < U; ++u)
+                        if (k + u < cnt) load_msg<VEC>(m[u], p, bcast_i(b.src, k + u), base + k + u, f0, xd);
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < H; ++u) {
                     if (k + u < cnt) {
                         float wk[C::NW];
                         b.weights(wk, k + u);
                         acc.add(m[u], wk, base + k + u);
+                    }
+                }
+                if (second) {
+#pragma unroll
+                    for (int u = H; u < U; ++u) {
+                        if (k + u < cnt) {
+                            float wk[C::NW];
+                            b.weights(wk, k + u);
+                            acc.add(m[u], wk, base + k + u);
+                        }
                     }
                 }
             }
@@ -342,8 +359,9 @@ __device__ __forceinline__ float scaler_factor(int kind, float logd, float avg) 
 // output column of (scaler s, aggregator a, feature f) in the [T][S][A][Ft] layout, split into a
 // per-lane part (tower block + feature inside the tower, computed once per wave) and a wave-uniform part
 __device__ __forceinline__ int64_t lane_col(const AggParams& p, int f) {
-    if (p.n_towers == 1) return f;          // (uniform) no tower blocks: skip the integer division
-    const int t = f / p.Ft;
+    if (p.n_towers == 1) return f;          // (uniform) no tower blocks
+    int t = 0;                              // f / Ft by compares (a per-lane integer division costs ~35 VALU ops)
+    for (int q = 1; q < p.n_towers; ++q) t += (f >= q * p.Ft) ? 1 : 0;
     const int ft = f - t * p.Ft;
     return (int64_t)t * p.tower_stride + ft;
 }
