@@ -71,7 +71,7 @@ def algorithmic_bytes(N, E, F, A, S, Ku, x, r):
 
 def plan_model(plan):
     ops = [op for l in plan.launches for op in l.ops]
-    x = int(any(op in (8, 9) for op in ops))
+    x = int(any(op in (8, 9, 10) for op in ops))
     r = int(any(op in (2, 3, 4, 5) for op in ops))
     return plan.n_agg, plan.n_scalers, plan.n_channels, x, r
 
@@ -222,7 +222,7 @@ def run_layer_workload(args, wl, rank, world, dev):
     # ---- roofline of the aggregation kernels (same shapes the layer launches) ----
     # the plan the layer actually launches: the degree scalers are folded into posttrans, so the sweep
     # runs with S = 1 (dgn_amd/dgn_layer.py: _fold_scalers) and its algorithmic bytes are counted as such
-    plan = layer._kplan
+    plan = layer._kplan_x if (wl["type_net"] != "simple" and hasattr(layer, "_kplan_x")) else layer._kplan     # (+ h_in pass-through block)
     T = wl["towers"] if wl["type_net"] == "towers" else 1
     A, S, Ku, x, r = plan_model(plan)
     w = graph.edge_weights(plan)
