@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
            "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_backward",
-           "dgn_scale_combine_forward", "dgn_scale_combine_backward")
+           "dgn_scale_combine_forward", "dgn_scale_combine_backward", "dgn_bn_tail_forward", "dgn_bn_tail_backward")
 
 
 class DgnGraph(C.Structure):
@@ -99,6 +99,13 @@ def load() -> C.CDLL:
         lib.dgn_scale_combine_backward.restype = C.c_int
         lib.dgn_scale_combine_backward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dgn_bn_tail_forward.restype = C.c_int
+        lib.dgn_bn_tail_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        lib.dgn_bn_tail_backward.restype = C.c_int
+        lib.dgn_bn_tail_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if lib.dgn_abi_version() != ABI_VERSION:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import directional_aggregate, scale_combine
+from .ops import bn_tail, directional_aggregate, scale_combine
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -219,10 +219,11 @@ class DGNLayerSimple(nn.Module):
             if self.graph_norm:
                 h = h * snorm_n
         if self.batch_norm:
-            h = self.batchnorm_h(h)
-        h = F.relu(h)
-        if self.residual:
-            h = h_in + h
+            h = bn_tail(h, self.batchnorm_h, self.training, relu=True, residual=h_in if self.residual else None)
+        else:
+            h = F.relu(h)
+            if self.residual:
+                h = h_in + h
         return F.dropout(h, self.dropout, training=self.training)
 
 
@@ -273,10 +274,11 @@ class DGNLayerComplex(nn.Module):
             if self.graph_norm:
                 h = h * snorm_n
         if self.batch_norm:
-            h = self.batchnorm_h(h)
-        h = F.relu(h)
-        if self.residual:
-            h = h_in + h
+            h = bn_tail(h, self.batchnorm_h, self.training, relu=True, residual=h_in if self.residual else None)
+        else:
+            h = F.relu(h)
+            if self.residual:
+                h = h_in + h
         return F.dropout(h, self.dropout, training=self.training)
 
 
@@ -395,17 +397,7 @@ class DGNLayerTower(nn.Module):
             if row_scale is not None:
                 y = y * row_scale
         if self.batch_norm:
-            bns = [t.batchnorm_h for t in self.towers]
-            rm = torch.cat([b.running_mean for b in bns])
-            rv = torch.cat([b.running_var for b in bns])
-            y = F.batch_norm(y, rm, rv, torch.cat([b.weight for b in bns]), torch.cat([b.bias for b in bns]),
-                             self.training, bns[0].momentum, bns[0].eps)
-            if self.training:
-                with torch.no_grad():
-                    for i, b in enumerate(bns):
-                        b.running_mean.copy_(rm[i * fo:(i + 1) * fo])
-                        b.running_var.copy_(rv[i * fo:(i + 1) * fo])
-                        b.num_batches_tracked += 1
+            y = bn_tail(y, [t.batchnorm_h for t in self.towers], self.training)
         return F.dropout(y, self.dropout, training=self.training)
 
     def forward(self, g, h, e, snorm_n):

@@ -256,3 +256,78 @@ def scale_combine(z: torch.Tensor, scale: Optional[torch.Tensor], bias: Optional
     if bias is not None:
         bias = bias.reshape(-1).contiguous()
     return _ScaleCombine.apply(z, scale, bias, row_scale)
+
+
+class _BNTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, residual):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.DgnError("bn_tail: CUDA tensors only (dgn_amd has no CPU path)")
+        x = x.contiguous()
+        N, F = x.shape
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        save_mean = torch.empty(F, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(F, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * F, dtype=torch.float64, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.dgn_bn_tail_forward(N, F, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     float(momentum), float(eps), 1 if training else 0, 1 if relu else 0, _ptr(residual), y.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), stream)
+        _lib.check(rc, "dgn_bn_tail_forward")
+        if not training and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
+            raise _lib.DgnError("bn_tail: differentiating through eval-mode BatchNorm is not supported by the fused tail")
+        ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        lib = _lib.load()
+        x, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        g_y = g_y.contiguous()
+        N, F = x.shape
+        g_x = torch.empty_like(x)
+        g_gamma = torch.empty(F, dtype=torch.float32, device=x.device) if gamma is not None else None
+        g_beta = torch.empty(F, dtype=torch.float32, device=x.device) if beta is not None else None
+        ws = torch.empty(2 * F, dtype=torch.float64, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.dgn_bn_tail_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 1 if ctx.relu else 0, g_x.data_ptr(), _ptr(g_gamma), _ptr(g_beta),
+                                      ws.data_ptr(), stream)
+        _lib.check(rc, "dgn_bn_tail_backward")
+        return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
+
+
+def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[relu](BatchNorm1d(x)) [+ residual]`` in one pass family (dgn_layer.py:123-128, :194-199, :272-273).
+
+    ``bns``: one ``nn.BatchNorm1d`` or a list of them covering consecutive column blocks of ``x`` (the towers'
+    per-tower BatchNorm1d modules: BatchNorm is per channel, so T modules of width fo are one BatchNorm of width
+    T*fo).  Running statistics and ``num_batches_tracked`` of every module are updated as torch does."""
+    if not isinstance(bns, (list, tuple)):
+        bns = [bns]
+    b0 = bns[0]
+    simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
+    if not simple or (not training and torch.is_grad_enabled() and x.requires_grad):
+        # configurations the fused kernels do not cover: plain torch modules
+        w = x.shape[1] // len(bns)
+        y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)
+        y = torch.relu(y) if relu else y
+        return y + residual if residual is not None else y
+    cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts))
+    gamma, beta = cat([b.weight for b in bns]), cat([b.bias for b in bns])
+    rm, rv = cat([b.running_mean for b in bns]), cat([b.running_var for b in bns])
+    y = _BNTail.apply(x, gamma, beta, rm, rv, b0.momentum, b0.eps, training, relu, residual)
+    if training:
+        with torch.no_grad():
+            if len(bns) > 1:
+                w = x.shape[1] // len(bns)
+                for i, b in enumerate(bns):
+                    b.running_mean.copy_(rm[i * w:(i + 1) * w])
+                    b.running_var.copy_(rv[i * w:(i + 1) * w])
+            for b in bns:
+                b.num_batches_tracked += 1
+    return y

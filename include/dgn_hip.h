@@ -201,6 +201,22 @@ int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scal
                                int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, float* g_bias,
                                void* stream);
 
+/* Layer tail: BatchNorm1d over the node dimension, optionally followed by ReLU and the residual add
+ *     y = [relu]( (x - mean) * invstd * gamma + beta ) [+ residual]          (dgn_layer.py:123-128, :194-199, :272-273)
+ * training != 0: batch statistics (biased variance), running_mean / running_var updated in place with `momentum`
+ * (running_var with the unbiased variance, like torch.nn.BatchNorm1d); save_mean / save_invstd [F] are written for
+ * the backward.  training == 0: running statistics are used.  ws: 2*F DOUBLES of scratch (8-byte aligned).  All [N, F] tensors share
+ * the row stride ld.                                                                                       */
+int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                        int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
+                        void* stream);
+/* Backward of the training-mode tail: g_x [N, F] (written), g_gamma / g_beta [F] (written); ws: 2*F doubles.
+ * The gradient of `residual` is g_y itself (left to the caller).                                           */
+int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
+                         float* g_gamma, float* g_beta, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,3 +49,13 @@ def oracle_scale_combine(z, scale, bias, row_scale):
     if row_scale is not None:
         y = y * row_scale.reshape(-1, 1)
     return y
+
+
+def oracle_bn_tail(x, bns, training, relu=False, residual=None):
+    """plain-torch restatement of dgn_amd.ops.bn_tail (the nn.BatchNorm1d modules themselves)."""
+    if not isinstance(bns, (list, tuple)):
+        bns = [bns]
+    w = x.shape[1] // len(bns)
+    y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else bns[0](x)
+    y = torch.relu(y) if relu else y
+    return y + residual if residual is not None else y

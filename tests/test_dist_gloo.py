@@ -70,9 +70,10 @@ def _build_layer():
 def _install_oracle_backend():
     import dgn_amd.dgn_layer as dl
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_backend import oracle_directional_aggregate, oracle_scale_combine
+    from oracle_backend import oracle_bn_tail, oracle_directional_aggregate, oracle_scale_combine
     dl.directional_aggregate = oracle_directional_aggregate
     dl.scale_combine = oracle_scale_combine
+    dl.bn_tail = oracle_bn_tail
 
 
 def _loss_backward(layer, g, h, snorm):
@@ -124,7 +125,7 @@ def test_dp_gradients_match_sequential_shards(tmp_path):
     # single process: the same shards one after the other, gradients averaged
     from dgn_amd import dist as ddist
     import dgn_amd.dgn_layer as dl
-    saved = (dl.directional_aggregate, dl.scale_combine)
+    saved = (dl.directional_aggregate, dl.scale_combine, dl.bn_tail)
     try:
         _install_oracle_backend()
         b, offs, edge_gid, epg, h = _make_problem()
@@ -138,7 +139,7 @@ def test_dp_gradients_match_sequential_shards(tmp_path):
             acc = grads if acc is None else {n: acc[n] + grads[n] for n in acc}
         want = {n: v / world for n, v in acc.items()}
     finally:
-        dl.directional_aggregate, dl.scale_combine = saved
+        dl.directional_aggregate, dl.scale_combine, dl.bn_tail = saved
     assert set(got) == set(want)
     for n in want:
         torch.testing.assert_close(got[n], want[n], rtol=1e-5, atol=1e-6, msg=n)
@@ -150,7 +151,7 @@ def test_layer_algebra_matches_reference_on_cpu(golden):
     import numpy as np
     import dgn_amd
     import dgn_amd.dgn_layer as dl
-    saved = (dl.directional_aggregate, dl.scale_combine)
+    saved = (dl.directional_aggregate, dl.scale_combine, dl.bn_tail)
     T = torch.from_numpy
     try:
         _install_oracle_backend()
@@ -171,4 +172,4 @@ def test_layer_algebra_matches_reference_on_cpu(golden):
             y = layer(graph, h, e, T(g["snorm_n"]))
             np.testing.assert_allclose(y.detach().numpy(), g[f"{name}/y"], rtol=2e-5, atol=2e-5, err_msg=name)
     finally:
-        dl.directional_aggregate, dl.scale_combine = saved
+        dl.directional_aggregate, dl.scale_combine, dl.bn_tail = saved

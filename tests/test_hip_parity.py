@@ -316,3 +316,51 @@ def test_scale_combine_and_x_in_block_vs_torch():
     c2 = torch.randn(40, 18, generator=gen).to(dev)
     for a, b_ in zip(torch.autograd.grad(ya, [P, H], c2), torch.autograd.grad(yb, [P, H], c2)):
         _close(a, b_, 1e-5, 1e-6)
+
+
+def test_bn_tail_vs_torch_batchnorm():
+    """Fused layer tail ([relu](BatchNorm1d(x)) [+ residual]) against nn.BatchNorm1d: outputs, all gradients,
+    running statistics and num_batches_tracked, one module and five per-tower modules, train and eval."""
+    dev = _dev()
+    from dgn_amd.ops import bn_tail
+    gen = torch.Generator().manual_seed(6)
+    N, W = 1000, 70
+    x0 = torch.randn(N, W, generator=gen) * 3 + 1.5
+    res0, ct = torch.randn(N, W, generator=gen), torch.randn(N, W, generator=gen)
+    for n_bn, relu, use_res in ((1, True, True), (5, False, False), (1, False, True)):
+        def make():
+            bns = [torch.nn.BatchNorm1d(W // n_bn) for _ in range(n_bn)]
+            g2 = torch.Generator().manual_seed(7)
+            for b in bns:
+                with torch.no_grad():
+                    b.weight.copy_(torch.rand(b.weight.shape, generator=g2) + 0.5)
+                    b.bias.copy_(torch.randn(b.bias.shape, generator=g2))
+            return bns
+        ref, mine = make(), [b.to(dev) for b in make()]
+        xr = x0.clone().requires_grad_(True)
+        rr = res0.clone().requires_grad_(True)
+        w = W // n_bn
+        yr = torch.cat([b(xr[:, i * w:(i + 1) * w]) for i, b in enumerate(ref)], dim=1)
+        yr = torch.relu(yr) if relu else yr
+        yr = yr + rr if use_res else yr
+        yr.backward(ct)
+        xm = x0.to(dev).requires_grad_(True)
+        rm = res0.to(dev).requires_grad_(True)
+        ym = bn_tail(xm, mine if n_bn > 1 else mine[0], True, relu=relu, residual=rm if use_res else None)
+        ym.backward(ct.to(dev))
+        _close(ym, yr, 1e-5, 1e-5)
+        _close(xm.grad, xr.grad, 1e-4, 1e-5)
+        if use_res:
+            _close(rm.grad, rr.grad, 0, 0)
+        for a, b in zip(mine, ref):
+            _close(a.weight.grad, b.weight.grad, 1e-4, 1e-4)
+            _close(a.bias.grad, b.bias.grad, 1e-4, 1e-4)
+            _close(a.running_mean, b.running_mean, 1e-5, 1e-6)
+            _close(a.running_var, b.running_var, 1e-5, 1e-6)
+            assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+        for b in ref + mine:
+            b.eval()
+        with torch.no_grad():
+            ye = torch.cat([b(x0[:, i * w:(i + 1) * w]) for i, b in enumerate(ref)], dim=1)
+            ye = torch.relu(ye) if relu else ye
+            _close(bn_tail(x0.to(dev), mine if n_bn > 1 else mine[0], False, relu=relu), ye, 1e-5, 1e-5)
