@@ -277,8 +277,6 @@ class _BNTail(torch.autograd.Function):
                                      float(momentum), float(eps), 1 if training else 0, 1 if relu else 0, _ptr(residual), y.data_ptr(),
                                      save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), stream)
         _lib.check(rc, "dgn_bn_tail_forward")
-        if not training and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
-            raise _lib.DgnError("bn_tail: differentiating through eval-mode BatchNorm is not supported by the fused tail")
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
         return y
@@ -311,7 +309,8 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
         bns = [bns]
     b0 = bns[0]
     simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
-    if not simple or (not training and torch.is_grad_enabled() and x.requires_grad):
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
+    if not simple or (not training and needs_grad):      # (the fused backward covers training mode only)
         # configurations the fused kernels do not cover: plain torch modules
         w = x.shape[1] // len(bns)
         y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)
