@@ -1,16 +1,20 @@
-"""DGNLayer operator API of the reference on the MI355X aggregation kernels.
+"""DGNLayer operator API of the reference on the MI355X kernels.
 
-Same factory, constructor arguments, ``.model`` attribute, ``forward(g, h, e, snorm_n)``
-and ``state_dict`` keys/shapes as realworld_benchmark/nets/dgn_layer.py:52-352, so the
-benchmark nets (nets/*/dgn_net.py) can construct and call these layers unchanged.
+Same factory, constructor arguments, ``.model`` attribute, ``forward(g, h, e, snorm_n)`` and ``state_dict``
+keys/shapes as realworld_benchmark/nets/dgn_layer.py:52-352, so the benchmark nets (nets/*/dgn_net.py) can
+construct and call these layers unchanged.
 
-What differs is everything between ``g.apply_edges`` and the end of ``reduce_func``:
-one fused CSR sweep (``dgn_amd.ops.directional_aggregate``) instead of DGL's degree
-bucketing.  A 1-layer ``pretrans`` (every shipped config) is affine in
-``[h_src || h_dst || ef]`` and is decomposed as ``P[src] + Q[dst] + R[edge]`` with two
-node-level GEMMs, so no ``[E, 2F]`` concat is ever built; all towers run in ONE sweep
-(they are column blocks of the message) and ``posttrans([h || agg])`` is evaluated as two
-GEMMs without materialising the concat.
+What differs is everything between ``g.apply_edges`` and the layer's output:
+* one fused CSR sweep (``ops.directional_aggregate``) instead of DGL's degree bucketing;
+* a 1-layer ``pretrans`` (every shipped config) is affine in ``[h_src || h_dst || ef]`` and is decomposed as
+  ``P[src] + Q[dst] + R[edge]`` with node-level GEMMs, so no ``[E, 2F]`` concat is ever built;
+* all towers run in ONE sweep (they are column blocks of the message), written tower-major so that the per-tower
+  posttrans is one batched GEMM on contiguous matrices;
+* the degree scalers are per-row factors and are folded behind the post-aggregation Linear; ``[h || agg]`` is
+  produced by the sweep itself (h_in pass-through block); scalers, bias and graph norm are applied by one
+  streaming kernel (``ops.scale_combine``), BatchNorm + ReLU + residual by another (``ops.bn_tail``).
+Configurations outside these fast paths (multi-layer pretrans/posttrans, a scaler list without ``identity``,
+BatchNorm variants the fused tail does not cover) run the same kernels through the generic, unfused route.
 """
 from __future__ import annotations
 
@@ -138,18 +142,6 @@ def _scale_table(graph: DGNGraph, kinds, avg_log: float) -> torch.Tensor:
                 cols.append(torch.where(graph.in_degree > 0, avg_log / logd, torch.zeros_like(logd)))
         cache[key] = torch.stack(cols, dim=1).contiguous()
     return cache[key]
-
-
-def _fold_scalers(weight, agg, sc):
-    """``cat_s(scale_s * agg) @ weight^T`` evaluated as ``sum_s scale_s * (agg @ W_s^T)``: the degree
-    scalers are per-row factors, so they commute with the post-aggregation Linear.  The sweep then
-    writes (and the GEMM reads) ``[N, A*F]`` instead of ``[N, S*A*F]``.
-    weight [Fo, S*K], agg [N, K], sc [N, S] -> [N, Fo]"""
-    N, K = agg.shape
-    Fo, S = weight.shape[0], sc.shape[1]
-    w = weight.reshape(Fo, S, K).permute(1, 0, 2).reshape(S * Fo, K)
-    z = F.linear(agg, w)                                        # [N, S*Fo]
-    return (z.view(N, S, Fo) * sc.unsqueeze(-1)).sum(dim=1)
 
 
 def _identity_slot(applied_scalers):
