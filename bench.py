@@ -98,12 +98,15 @@ def configure_gemm_tuning(mode):
         return
     import torch.cuda.tunable as tn
     tn.enable(True)
-    tn.set_filename(TUNING_FILE)
     if mode == "tune":
+        tn.set_filename(TUNING_FILE)
         tn.tuning_enable(True)
         tn.set_max_tuning_duration(150)
         tn.set_max_tuning_iterations(20)
     else:
+        # replay only.  Whatever TunableOp writes at exit goes to a per-process scratch file, so that concurrent
+        # ranks (torchrun) can never clobber the committed selection file.
+        tn.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dgn_tunableop_{os.getpid()}.csv"))
         tn.tuning_enable(False)
         if os.path.exists(TUNING_FILE):
             tn.read_file(TUNING_FILE)
