@@ -345,25 +345,34 @@ class DGNLayerTower(nn.Module):
         """All towers in one sweep: towers are column blocks of the message."""
         graph = as_dgn_graph(g)
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
-        lins = [t.pretrans.fully_connected[0].linear for t in self.towers]
+        dev = h.device
+        # The per-tower parameters keep the reference's state_dict layout; they are assembled into the fused
+        # operands with a handful of batched tensor ops (stack / one indexed assignment / cat), not per-tower
+        # loops: at batch 128 the layer is launch-bound and every small op costs as much as the sweep itself.
+        w_pre = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in self.towers])    # [T, fi, 2fi(+ed)]
+        b_pre = torch.stack([t.pretrans.fully_connected[0].linear.bias for t in self.towers])      # [T, fi]
+        Fm = T * fi
         if self.divide_input:
-            w_s = torch.block_diag(*[l.weight[:, :fi] for l in lins])             # [T*fi, in]
-            w_d = torch.block_diag(*[l.weight[:, fi:2 * fi] for l in lins])
+            idx = torch.arange(T, device=dev)
+            bd = torch.zeros(2, T, fi, T, fi, dtype=w_pre.dtype, device=dev)                      # block diagonals of W_s, W_d
+            bd[:, idx, :, idx, :] = torch.stack([w_pre[:, :, :fi], w_pre[:, :, fi:2 * fi]], dim=1)
+            w_sd = bd.view(2 * Fm, Fm)
             x_in = h
         else:
-            w_s = torch.cat([l.weight[:, :fi] for l in lins], dim=0)              # every tower reads all of h
-            w_d = torch.cat([l.weight[:, fi:2 * fi] for l in lins], dim=0)
-            x_in = h.repeat(1, T)
-        Fm = T * fi
-        bias = torch.cat([l.bias for l in lins])
-        pq = F.linear(h, torch.cat([w_s, w_d], dim=0), torch.cat([torch.zeros_like(bias), bias]))   # [N, 2*Fm]
+            w_sd = torch.cat([w_pre[:, :, :fi].reshape(Fm, fi), w_pre[:, :, fi:2 * fi].reshape(Fm, fi)], dim=0)
+            x_in = h.repeat(1, T)                                                                  # every tower reads all of h
+        bias_sd = torch.cat([torch.zeros(Fm, dtype=b_pre.dtype, device=dev), b_pre.reshape(Fm)])
+        pq = F.linear(h, w_sd, bias_sd)                                                            # [N, 2*Fm]: P | Q
         m_edge = None
         if self.edge_features:
-            m_edge = F.linear(graph.to_slot_order(e), torch.cat([l.weight[:, 2 * fi:] for l in lins], dim=0))
-        posts = [t.posttrans.fully_connected[0].linear for t in self.towers]
+            m_edge = F.linear(graph.to_slot_order(e), w_pre[:, :, 2 * fi:].reshape(Fm, -1))
+        w_post = torch.stack([t.posttrans.fully_connected[0].linear.weight for t in self.towers])  # [T, fo, fi + S*K]
+        b_p = torch.stack([t.posttrans.fully_connected[0].linear.bias for t in self.towers]).reshape(T * fo)
         S = self.plan.n_scalers
         N = h.shape[0]
-        b_p = torch.cat([l.bias for l in posts])                                     # [T*fo]
+        K = (w_post.shape[2] - fi) // S
+        w_h = w_post[:, :, :fi]                                                                    # [T, fo, fi]
+        w_a = w_post[:, :, fi:].reshape(T, fo, S, K).permute(0, 2, 1, 3)                           # [T, S, fo, K]
         id_slot = _identity_slot(self.plan.applied_scalers)
         row_scale = snorm_n if self.graph_norm else None
         if id_slot is not None:
@@ -372,17 +381,16 @@ class DGNLayerTower(nn.Module):
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:],
                                          m_edge=m_edge, x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)
-            w = torch.stack([_folded_weight(l.weight[:, fi:], l.weight[:, :fi], S, id_slot) for l in posts])   # [T, S*fo, K+fi]
-            z = torch.bmm(aggx, w.transpose(1, 2))                                   # [T, N, S*fo]
+            hcols = torch.zeros(T, S, fo, fi, dtype=w_post.dtype, device=dev)
+            hcols[:, id_slot] = w_h                                                                # h block: identity scaler only
+            w = torch.cat([w_a, hcols], dim=3).reshape(T, S * fo, K + fi)
+            z = torch.bmm(aggx, w.transpose(1, 2))                                                 # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
-            y = scale_combine(z, sc, b_p, row_scale)                                 # [N, T*fo]
+            y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
                                         x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
-            K = agg.shape[2]
-            w_a = torch.stack([l.weight[:, fi:] for l in posts]).view(T, fo, S, K).permute(0, 2, 1, 3).reshape(T, S * fo, K)
-            w_h = torch.stack([l.weight[:, :fi] for l in posts])                     # [T, fo, fi]
-            z = torch.bmm(agg, w_a.transpose(1, 2))                                  # [T, N, S*fo]
+            z = torch.bmm(agg, w_a.reshape(T, S * fo, K).transpose(1, 2))                          # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             y = scale_combine(z, sc, b_p, None)
             y = y + torch.bmm(x_in.view(N, T, fi).transpose(0, 1), w_h.transpose(1, 2)).transpose(0, 1).reshape(N, T * fo)

@@ -322,11 +322,9 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
     y = _BNTail.apply(x, gamma, beta, rm, rv, b0.momentum, b0.eps, training, relu, residual)
     if training:
         with torch.no_grad():
-            if len(bns) > 1:
+            if len(bns) > 1:      # scatter the updated statistics back to the per-tower modules (2 + 1 launches)
                 w = x.shape[1] // len(bns)
-                for i, b in enumerate(bns):
-                    b.running_mean.copy_(rm[i * w:(i + 1) * w])
-                    b.running_var.copy_(rv[i * w:(i + 1) * w])
-            for b in bns:
-                b.num_batches_tracked += 1
+                torch._foreach_copy_([b.running_mean for b in bns], list(rm.split(w)))
+                torch._foreach_copy_([b.running_var for b in bns], list(rv.split(w)))
+            torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
     return y
