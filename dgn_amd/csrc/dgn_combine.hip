@@ -1,67 +1,169 @@
-// Scale-combine epilogue of the post-aggregation Linear (see include/dgn_hip.h, dgn_scale_combine_*):
-// pure streaming kernels, one thread per output element.
+// Scale-combine epilogue of the post-aggregation Linear (see include/dgn_hip.h, dgn_scale_combine_*): streaming
+// kernels between the tower-major GEMM output z / g_z [T][N][S*fo] and the node-major y / g_y [N][T*fo].
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "dgn_common.hpp"
 
 namespace dgn {
 namespace {
 
-// Slab layout (no per-element integer divisions): a workgroup owns kRows rows, a thread owns one output column
-// (and a row phase when the row is narrower than the workgroup), so every row access is coalesced.
-constexpr int kRows = 64;
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;          // rows in flight per thread (forward)
+constexpr int kMaxGroups = 2048;    // workgroups (= bias-gradient partial slots) of the backward
+constexpr int kTileFloats = 8192;   // 32 KB g_y tile budget per workgroup (backward)
+constexpr int kMaxWidth = 4096;     // widest y row accepted (the backward keeps a row tile + a bias row in LDS)
 
-__global__ __launch_bounds__(256) void combine_fwd(int64_t n_nodes, int T, int S, int fo, const float* __restrict__ z,
-                                                   const float* __restrict__ scale, const float* __restrict__ bias,
-                                                   const float* __restrict__ row_scale, float* __restrict__ y, int64_t ld_y) {
+// forward slab height: 64 rows for large inputs, down to 8 when that would leave most of the 256 CUs without a
+// workgroup (a 3 000-row molecule batch)
+int fwd_slab_rows(int64_t n) {
+    int r = 8;
+    while (r < 64 && (n + r - 1) / r > 2048) r *= 2;
+    return r;
+}
+
+// Forward: a workgroup owns a slab of rows, a thread one output column (and a row phase when the row is narrower
+// than the workgroup).  kUnroll rows are loaded (row indices clamped) before any use and only the stores are
+// predicated: with one 4-byte load in flight per thread the kernel ran at 1.9 TB/s, with S * kUnroll at 4.3 TB/s.
+template <int S_>
+__global__ __launch_bounds__(kThreads) void combine_fwd(int64_t n_nodes, int rows_per_block, int T, int S_rt, int fo,
+                                                        const float* __restrict__ z, const float* __restrict__ scale,
+                                                        const float* __restrict__ bias, const float* __restrict__ row_scale,
+                                                        float* __restrict__ y, int64_t ld_y) {
+    const int S = S_ ? S_ : S_rt;
     const int width = T * fo;
-    const int P = max(1, 256 / width);
-    const int64_t r0 = (int64_t)blockIdx.x * kRows, r1 = min(r0 + kRows, n_nodes);
-    for (int c0 = 0; c0 < width; c0 += 256) {
+    const int P = max(1, kThreads / width);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n_nodes);
+    for (int c0 = 0; c0 < width; c0 += kThreads) {
         const int p = (int)threadIdx.x / width, c = c0 + (int)threadIdx.x % width;
         if (p >= P || c >= width) continue;
         const int t = c / fo, o = c - t * fo;
         const float b = bias ? bias[c] : 0.f;
-        for (int64_t n = r0 + p; n < r1; n += P) {
-            const float* zr = z + ((int64_t)t * n_nodes + n) * ((int64_t)S * fo) + o;
-            float acc = b;
-            if (scale) {
-                for (int s = 0; s < S; ++s) acc += scale[n * S + s] * zr[s * fo];
+        const float* zt = z + (int64_t)t * n_nodes * ((int64_t)S * fo) + o;
+        for (int64_t n = r0 + p; n < r1; n += (int64_t)kUnroll * P) {
+            float acc[kUnroll], rs[kUnroll];
+            if constexpr (S_ != 0) {
+                float zv[kUnroll][S_ ? S_ : 1], sv[kUnroll][S_ ? S_ : 1];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int64_t m = min(n + (int64_t)u * P, r1 - 1);
+#pragma unroll
+                    for (int q = 0; q < S_; ++q) {
+                        zv[u][q] = zt[m * ((int64_t)S_ * fo) + q * fo];
+                        sv[u][q] = scale ? scale[m * S_ + q] : 1.f;
+                    }
+                    rs[u] = row_scale ? row_scale[m] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    acc[u] = b;
+#pragma unroll
+                    for (int q = 0; q < S_; ++q) acc[u] += sv[u][q] * zv[u][q];
+                }
             } else {
-                acc += zr[0];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int64_t m = min(n + (int64_t)u * P, r1 - 1);
+                    acc[u] = b;
+                    for (int q = 0; q < S; ++q) acc[u] += scale[m * S + q] * zt[m * ((int64_t)S * fo) + q * fo];
+                    rs[u] = row_scale ? row_scale[m] : 1.f;
+                }
             }
-            if (row_scale) acc *= row_scale[n];
-            y[n * ld_y + c] = acc;
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t m = n + (int64_t)u * P;
+                if (m < r1) y[m * ld_y + c] = acc[u] * rs[u];
+            }
         }
     }
 }
 
-// g_z[t][n][s*fo+o] = row_scale[n] * scale[n,s] * g_y[n, t*fo+o]; threads with s == 0 also accumulate the bias
-// gradient sum_n row_scale[n] * g_y[n, t*fo+o] (one atomic per (block, column))
-__global__ __launch_bounds__(256) void combine_bwd(int64_t n_nodes, int T, int S, int fo, const float* __restrict__ gy,
-                                                   int64_t ld_gy, const float* __restrict__ scale,
-                                                   const float* __restrict__ row_scale, float* __restrict__ gz,
-                                                   float* __restrict__ g_bias) {
-    const int zw = S * fo, width = T * zw;
-    const int P = max(1, 256 / width);
-    const int64_t r0 = (int64_t)blockIdx.x * kRows, r1 = min(r0 + kRows, n_nodes);
-    for (int c0 = 0; c0 < width; c0 += 256) {
-        const int p = (int)threadIdx.x / width, c = c0 + (int)threadIdx.x % width;
-        if (p >= P || c >= width) continue;
-        const int t = c / zw, so = c - t * zw, s = so / fo, o = so - s * fo;
-        float bsum = 0.f;
-        for (int64_t n = r0 + p; n < r1; n += P) {
-            float g = gy[n * ld_gy + t * fo + o];
-            if (row_scale) g *= row_scale[n];
-            if (s == 0) bsum += g;
-            if (scale) g *= scale[n * S + s];
-            gz[((int64_t)t * n_nodes + n) * zw + so] = g;
+// (row, column) cursor over a [rows, w] tile walked linearly with a stride of kThreads elements
+struct Cursor {
+    int r, c, dr, dc, w;
+    __device__ Cursor(int start, int w_) : r(start / w_), c(start - (start / w_) * w_), dr(kThreads / w_), dc(kThreads - (kThreads / w_) * w_), w(w_) {}
+    __device__ void next() {
+        r += dr;
+        c += dc;
+        if (c >= w) { c -= w; ++r; }
+    }
+};
+
+// backward slab height: what the tile budget allows, at most 32 rows
+int bwd_slab_rows(int wy) { return std::max(1, std::min(32, kTileFloats / wy)); }
+
+// Backward: g_z[t][n][s*fo+o] = row_scale[n] * scale[n,s] * g_y[n, t*fo+o].  A workgroup walks slabs b, b + G, ...;
+// each slab of row_scale * g_y is staged in LDS so that the g_z stores of one tower are one contiguous run (a
+// thread-per-column layout wrote 168-byte pieces).  The bias gradient sum_n row_scale[n] * g_y[n, :] is kept per
+// workgroup in LDS and written to the workgroup's own slot of `bias_part` [T*fo][G]; bias_finalize adds the slots.
+// No atomics: 4 300 workgroups adding into 70 addresses serialised at ~22 ns per add (measured 170 us of a 220 us
+// kernel), and the fixed slot order makes the gradient reproducible.
+__global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int rows_per_block, int T, int S, int fo,
+                                                        const float* __restrict__ gy, int64_t ld_gy,
+                                                        const float* __restrict__ scale, const float* __restrict__ row_scale,
+                                                        float* __restrict__ gz, float* __restrict__ bias_part) {
+    extern __shared__ float lds[];
+    const int zw = S * fo, wy = T * fo, G = (int)gridDim.x;
+    float* g_t = lds;                                // [rows][wy]   row_scale * g_y
+    float* s_t = g_t + (size_t)rows_per_block * wy;  // [rows][S]
+    float* b_t = s_t + (size_t)rows_per_block * S;   // [wy]         bias-gradient partial of this workgroup
+    for (int c = threadIdx.x; c < wy; c += kThreads) b_t[c] = 0.f;
+    const int64_t n_slabs = (n_nodes + rows_per_block - 1) / rows_per_block;
+    for (int64_t slab = blockIdx.x; slab < n_slabs; slab += G) {
+        const int64_t r0 = slab * rows_per_block;
+        const int rows = (int)min((int64_t)rows_per_block, n_nodes - r0);
+        __syncthreads();                             // previous slab fully consumed
+        {
+            Cursor k((int)threadIdx.x, wy);
+#pragma unroll 4
+            for (int i = threadIdx.x; i < rows * wy; i += kThreads, k.next()) {
+                float g = gy[(r0 + k.r) * ld_gy + k.c];
+                if (row_scale) g *= row_scale[r0 + k.r];
+                g_t[i] = g;
+            }
         }
-        if (g_bias && s == 0) unsafeAtomicAdd(g_bias + t * fo + o, bsum);
+        for (int i = threadIdx.x; i < rows * S; i += kThreads) s_t[i] = scale ? scale[r0 * S + i] : 1.f;
+        __syncthreads();
+        if (bias_part) {
+            for (int c = threadIdx.x; c < wy; c += kThreads) {
+                float b = b_t[c];
+                for (int r = 0; r < rows; ++r) b += g_t[r * wy + c];
+                b_t[c] = b;
+            }
+        }
+        for (int t = 0; t < T; ++t) {
+            float* dst = gz + ((int64_t)t * n_nodes + r0) * zw;
+            Cursor k((int)threadIdx.x, zw);
+            for (int i = threadIdx.x; i < rows * zw; i += kThreads, k.next()) {
+                const int q = k.c / fo, o = k.c - q * fo;
+                dst[i] = g_t[k.r * wy + t * fo + o] * s_t[k.r * S + q];
+            }
+        }
+    }
+    if (bias_part) {
+        for (int c = threadIdx.x; c < wy; c += kThreads) bias_part[(int64_t)c * G + blockIdx.x] = b_t[c];   // own column: no sync needed
     }
 }
 
-unsigned row_blocks(int64_t n) { return (unsigned)((n + kRows - 1) / kRows); }
+// g_bias[c] += sum of the G slots (one wavefront per column, fixed order)
+__global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const float* __restrict__ bias_part, float* __restrict__ g_bias) {
+    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (c >= wy) return;
+    const int lane = (int)threadIdx.x & 63;
+    float s = 0.f;
+    for (int g = lane; g < G; g += 64) s += bias_part[(int64_t)c * G + g];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) g_bias[c] += s;
+}
+
+int bwd_groups(int64_t n_nodes, int rows) { return (int)std::min<int64_t>((n_nodes + rows - 1) / rows, kMaxGroups); }
+
+int check_shape(const char* fn, int64_t n_nodes, int32_t T, int32_t S, int32_t fo, bool has_scale) {
+    if (n_nodes < 0 || T < 1 || S < 1 || fo < 1 || (!has_scale && S != 1)) { set_error("%s: bad shape", fn); return DGN_ERR_INVALID; }
+    if ((int64_t)T * fo > kMaxWidth) { set_error("%s: n_towers * f_out > 4096 is not supported", fn); return DGN_ERR_INVALID; }
+    return DGN_OK;
+}
 
 }  // namespace
 }  // namespace dgn
@@ -70,22 +172,43 @@ using namespace dgn;
 
 extern "C" int dgn_scale_combine_forward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* z, const float* scale,
                                          const float* bias, const float* row_scale, float* y, int64_t ld_y, void* stream) {
-    if (n_nodes < 0 || T < 1 || S < 1 || fo < 1 || (!scale && S != 1)) { set_error("dgn_scale_combine_forward: bad shape"); return DGN_ERR_INVALID; }
+    if (int rc = check_shape("dgn_scale_combine_forward", n_nodes, T, S, fo, scale != nullptr)) return rc;
     if (n_nodes == 0) return DGN_OK;
     if (!z || !y || ld_y < (int64_t)T * fo) { set_error("dgn_scale_combine_forward: null buffer or ld_y too small"); return DGN_ERR_INVALID; }
-    hipLaunchKernelGGL(combine_fwd, dim3(row_blocks(n_nodes)), dim3(256), 0, static_cast<hipStream_t>(stream), n_nodes, T, S, fo,
-                       z, scale, bias, row_scale, y, ld_y);
+    const int rows = fwd_slab_rows(n_nodes);
+    const dim3 grid((unsigned)((n_nodes + rows - 1) / rows)), block(kThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (S) {
+        case 1: hipLaunchKernelGGL(combine_fwd<1>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
+        case 2: hipLaunchKernelGGL(combine_fwd<2>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
+        case 3: hipLaunchKernelGGL(combine_fwd<3>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
+        default: hipLaunchKernelGGL(combine_fwd<0>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
+    }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
 
+extern "C" size_t dgn_scale_combine_backward_workspace_bytes(int64_t n_nodes, int32_t T, int32_t fo) {
+    if (n_nodes <= 0 || T < 1 || fo < 1 || (int64_t)T * fo > kMaxWidth) return 0;
+    return (size_t)T * fo * bwd_groups(n_nodes, bwd_slab_rows(T * fo)) * sizeof(float);
+}
+
 extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy,
-                                          const float* scale, const float* row_scale, float* g_z, float* g_bias, void* stream) {
-    if (n_nodes < 0 || T < 1 || S < 1 || fo < 1 || (!scale && S != 1)) { set_error("dgn_scale_combine_backward: bad shape"); return DGN_ERR_INVALID; }
+                                          const float* scale, const float* row_scale, float* g_z, float* g_bias, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    if (int rc = check_shape("dgn_scale_combine_backward", n_nodes, T, S, fo, scale != nullptr)) return rc;
     if (n_nodes == 0) return DGN_OK;
     if (!g_y || !g_z || ld_gy < (int64_t)T * fo) { set_error("dgn_scale_combine_backward: null buffer or ld_gy too small"); return DGN_ERR_INVALID; }
-    hipLaunchKernelGGL(combine_bwd, dim3(row_blocks(n_nodes)), dim3(256), 0, static_cast<hipStream_t>(stream), n_nodes, T, S, fo, g_y, ld_gy,
-                       scale, row_scale, g_z, g_bias);
+    if (g_bias && (!ws || ws_bytes < dgn_scale_combine_backward_workspace_bytes(n_nodes, T, fo))) {
+        set_error("dgn_scale_combine_backward: workspace too small (the bias gradient needs dgn_scale_combine_backward_workspace_bytes())");
+        return DGN_ERR_WORKSPACE;
+    }
+    const int wy = T * fo, rows = bwd_slab_rows(wy), G = bwd_groups(n_nodes, rows);
+    const size_t lds = ((size_t)rows * wy + (size_t)rows * S + wy) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = g_bias ? static_cast<float*>(ws) : nullptr;
+    hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part);
+    if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3((wy + 3) / 4), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

@@ -235,9 +235,11 @@ class _ScaleCombine(torch.autograd.Function):
         g_y = g_y.contiguous()
         g_z = torch.empty((T, N, S * fo), dtype=torch.float32, device=g_y.device)
         g_b = torch.zeros(T * fo, dtype=torch.float32, device=g_y.device) if (has_bias and ctx.needs_input_grad[2]) else None
+        ws_bytes = lib.dgn_scale_combine_backward_workspace_bytes(N, T, fo) if g_b is not None else 0
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=g_y.device) if ws_bytes else None
         stream = torch.cuda.current_stream(g_y.device).cuda_stream
         rc = lib.dgn_scale_combine_backward(N, T, S, fo, g_y.data_ptr(), g_y.stride(0), _ptr(scale), _ptr(row_scale),
-                                            g_z.data_ptr(), _ptr(g_b), stream)
+                                            g_z.data_ptr(), _ptr(g_b), _ptr(ws), ws_bytes, stream)
         _lib.check(rc, "dgn_scale_combine_backward")
         return g_z, None, g_b, None
 
@@ -271,11 +273,12 @@ class _BNTail(torch.autograd.Function):
         y = torch.empty_like(x)
         save_mean = torch.empty(F, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty(F, dtype=torch.float32, device=x.device)
-        ws = torch.empty(2 * F, dtype=torch.float64, device=x.device)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F) if training else 0
+        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
         stream = torch.cuda.current_stream(x.device).cuda_stream
         rc = lib.dgn_bn_tail_forward(N, F, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), 1 if training else 0, 1 if relu else 0, _ptr(residual), y.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), stream)
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), _ptr(ws), ws_bytes, stream)
         _lib.check(rc, "dgn_bn_tail_forward")
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
@@ -290,11 +293,12 @@ class _BNTail(torch.autograd.Function):
         g_x = torch.empty_like(x)
         g_gamma = torch.empty(F, dtype=torch.float32, device=x.device) if gamma is not None else None
         g_beta = torch.empty(F, dtype=torch.float32, device=x.device) if beta is not None else None
-        ws = torch.empty(2 * F, dtype=torch.float64, device=x.device)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         rc = lib.dgn_bn_tail_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if ctx.relu else 0, g_x.data_ptr(), _ptr(g_gamma), _ptr(g_beta),
-                                      ws.data_ptr(), stream)
+                                      ws.data_ptr(), ws_bytes, stream)
         _lib.check(rc, "dgn_bn_tail_backward")
         return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
 
@@ -310,7 +314,7 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
     b0 = bns[0]
     simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
-    if not simple or (not training and needs_grad):      # (the fused backward covers training mode only)
+    if not simple or x.shape[1] > 1024 or (not training and needs_grad):   # (fused: training-mode backward, F <= 1024)
         # configurations the fused kernels do not cover: plain torch modules
         w = x.shape[1] // len(bns)
         y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)

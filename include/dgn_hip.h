@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 1
+#define DGN_ABI_VERSION 2
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -192,30 +192,35 @@ int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* ms
  * z is tower-major [T][N][S*f_out] (the batched GEMM output), y node-major [N, ld_y].  Replaces the scaler concat
  * of reduce_func (dgn_layer.py:170-171) + the Linear's bias + the graph-norm multiply `h * snorm_n`
  * (dgn_layer.py:121-122, :192-193, :270-271).  scale == NULL means S == 1 with factor 1; bias / row_scale may be NULL.
- * The backward writes g_z (same layout as z) from g_y and, if g_bias != NULL, ACCUMULATES the bias gradient
- * sum_n row_scale[n] * g_y[n, :] into g_bias [T*f_out] (caller zero-initialises; atomic adds).             */
+ * The backward writes g_z (same layout as z) from g_y and, if g_bias != NULL, ADDS the bias gradient
+ * sum_n row_scale[n] * g_y[n, :] to g_bias [T*f_out] (caller zero-initialises).  The sum is formed from
+ * per-workgroup partials in `ws` (dgn_scale_combine_backward_workspace_bytes(); needed only with g_bias) in a
+ * fixed order -- no atomics, bitwise reproducible.  n_towers * f_out <= 4096.                               */
 int dgn_scale_combine_forward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* z,
                               const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
                               void* stream);
+size_t dgn_scale_combine_backward_workspace_bytes(int64_t n_nodes, int32_t n_towers, int32_t f_out);
 int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* g_y,
                                int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, float* g_bias,
-                               void* stream);
+                               void* ws, size_t ws_bytes, void* stream);
 
 /* Layer tail: BatchNorm1d over the node dimension, optionally followed by ReLU and the residual add
  *     y = [relu]( (x - mean) * invstd * gamma + beta ) [+ residual]          (dgn_layer.py:123-128, :194-199, :272-273)
  * training != 0: batch statistics (biased variance), running_mean / running_var updated in place with `momentum`
  * (running_var with the unbiased variance, like torch.nn.BatchNorm1d); save_mean / save_invstd [F] are written for
- * the backward.  training == 0: running statistics are used.  ws: 2*F DOUBLES of scratch (8-byte aligned).  All [N, F] tensors share
- * the row stride ld.                                                                                       */
+ * the backward.  training == 0: running statistics are used.  1 <= F <= 1024.  All [N, F] tensors share the row
+ * stride ld.  ws: dgn_bn_tail_workspace_bytes() of scratch (8-byte aligned; training / backward only) holding the
+ * per-workgroup fp64 column partials, which are added in a fixed order (no atomics, bitwise reproducible).   */
+size_t dgn_bn_tail_workspace_bytes(int64_t n_rows, int32_t F);
 int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                         int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
-                        void* stream);
-/* Backward of the training-mode tail: g_x [N, F] (written), g_gamma / g_beta [F] (written); ws: 2*F doubles.
+                        size_t ws_bytes, void* stream);
+/* Backward of the training-mode tail: g_x [N, F] (written), g_gamma / g_beta [F] (written; may be NULL).
  * The gradient of `residual` is g_y itself (left to the caller).                                           */
 int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
-                         float* g_gamma, float* g_beta, void* ws, void* stream);
+                         float* g_gamma, float* g_beta, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
