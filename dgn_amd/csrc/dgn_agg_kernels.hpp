@@ -212,14 +212,11 @@ struct Acc {
     }
 };
 
-// message of slot e coming from node s:  x_src[s] + x_dst[row] + m_edge[e]
+// message of slot e coming from node s:  x_src[s] + x_dst[row] + m_edge[e]   (rounded in this order)
 template <int VEC>
 __device__ __forceinline__ void load_msg(float (&m)[VEC], const AggParams& p, int s, int e, int f0, const float (&xd)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) m[i] = xd[i];
-#ifdef DGN_EXP_NOGATHER
-    s = 0;
-#endif
     if (p.x_src) {
         float t[VEC];
         ldv<VEC>(t, p.x_src + (int64_t)s * p.ld_src + f0);
@@ -233,6 +230,25 @@ __device__ __forceinline__ void load_msg(float (&m)[VEC], const AggParams& p, in
         for (int i = 0; i < VEC; ++i) m[i] += t[i];
     }
 }
+
+// The gather loops do NOT use load_msg(): a value consumed in the same (conditional) block as its load makes the
+// compiler put `s_waitcnt vmcnt(0)` right behind every load, i.e. the gathers of a row run one full memory round
+// trip after the other (that is how these kernels ran until round 1's ISA check: 2.5 TB/s of gathers on C5,
+// 0.25 ms for the ZINC-12k forward).  They first ISSUE a group of loads into a register tile and consume it
+// afterwards.  MsgSrc is the gathered part when there is exactly one (x_src rows by source id, or m_edge rows by
+// slot); messages with both parts use half the tile for each.
+template <int VEC>
+struct MsgSrc {
+    const float* base;
+    int ld;
+    bool by_src, both;
+    __device__ __forceinline__ explicit MsgSrc(const AggParams& p)
+        : base(p.x_src ? p.x_src : p.m_edge), ld(p.x_src ? p.ld_src : p.ld_edge), by_src(p.x_src != nullptr),
+          both(p.x_src != nullptr && p.m_edge != nullptr) {}
+    __device__ __forceinline__ void load(float (&t)[VEC], int s, int e, int f0) const {
+        ldv<VEC>(t, base + (int64_t)(by_src ? s : e) * ld + f0);
+    }
+};
 
 // 64 CSR slots (source id + weights), one per lane
 template <int NCH, int NW>
@@ -256,52 +272,87 @@ struct SlotBatch {
     }
 };
 
-// accumulate CSR slots [beg, end) of one destination row
+// accumulate the cnt (<= 64) slots of one loaded slot batch (slots base .. base + cnt - 1); active lanes only.
+// Groups of U gathers in flight; the last (partial) group is predicated, NOT a one-at-a-time loop: molecule
+// rows have 2-3 slots, and a scalar remainder loop would serialise their gather latencies.  Slot k always
+// exists (loop condition), so its load is unconditional: the wait for the slot batch then sits on the common
+// path instead of behind every conditional load.
 template <class C, bool TRACK>
-__device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggParams& p, int beg, int end, int f0,
-                                                 bool active, const float (&xd)[C::VEC]) {
-    constexpr int VEC = C::VEC, U = DGN_UNROLL;
-    for (int base = beg; base < end; base += kWave) {
-        SlotBatch<C::NCH, C::NW> b;
-        b.load(p, base, end);
-        const int cnt = min(kWave, end - base);
-        // groups of U gathers in flight; the last (partial) group is predicated, NOT a one-at-a-time loop:
-        // molecule rows have 2-3 slots, and a scalar remainder loop would serialise their gather latencies.
-        // ONE exec-mask region for the whole batch (v_readlane ignores exec), not one per load.
-        if (active) {
-            for (int k = 0; k < cnt; k += U) {
-                // two half-groups: a short row (<= U/2 slots) pays U/2 + 1 uniform checks instead of U
-                constexpr int H = U / 2;
-                const bool second = k + H < cnt;
-                float m[U][VEC];
+__device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggParams& p, const MsgSrc<C::VEC>& src,
+                                                 const SlotBatch<C::NCH, C::NW>& b, int base, int cnt, int f0,
+                                                 const float (&xd)[C::VEC]) {
+    constexpr int VEC = C::VEC, U = DGN_UNROLL, H = U / 2;
+    float t[U][VEC];
+    auto use = [&](int slot, const float (&m)[VEC]) {
+        float wk[C::NW];
+        b.weights(wk, slot);
+        acc.add(m, wk, base + slot);
+    };
+    if (!src.both) {
+        for (int k = 0; k < cnt; k += U) {
+            // two half-groups: a short row (<= U/2 slots) pays U/2 + 1 uniform checks instead of U
+            const bool second = k + H < cnt;
 #pragma unroll
-                for (int u = 0; u < H; ++u)
-                    if (k + u < cnt) load_msg<VEC>(m[u], p, bcast_i(b.src, k + u), base + k + u, f0, xd);
-                if (second) {
+            for (int u = 0; u < H; ++u)
+                if (u == 0 || k + u < cnt) src.load(t[u], bcast_i(b.src, k + u), base + k + u, f0);
+            if (second) {
 #pragma unroll
-                    for (int u = H; u < U; ++u)
-                        if (k + u < cnt) load_msg<VEC>(m[u], p, bcast_i(b.src, k + u), base + k + u, f0, xd);
+                for (int u = H; u < U; ++u)
+                    if (k + u < cnt) src.load(t[u], bcast_i(b.src, k + u), base + k + u, f0);
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                if (u == 0 || k + u < cnt) {
+                    float m[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) m[i] = xd[i] + t[u][i];
+                    use(k + u, m);
                 }
+            }
+            if (second) {
 #pragma unroll
-                for (int u = 0; u < H; ++u) {
+                for (int u = H; u < U; ++u) {
                     if (k + u < cnt) {
-                        float wk[C::NW];
-                        b.weights(wk, k + u);
-                        acc.add(m[u], wk, base + k + u);
-                    }
-                }
-                if (second) {
+                        float m[VEC];
 #pragma unroll
-                    for (int u = H; u < U; ++u) {
-                        if (k + u < cnt) {
-                            float wk[C::NW];
-                            b.weights(wk, k + u);
-                            acc.add(m[u], wk, base + k + u);
-                        }
+                        for (int i = 0; i < VEC; ++i) m[i] = xd[i] + t[u][i];
+                        use(k + u, m);
                     }
                 }
             }
         }
+    } else {
+        for (int k = 0; k < cnt; k += H) {      // x_src part in t[0..H), m_edge part in t[H..U)
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                if (u == 0 || k + u < cnt) {
+                    ldv<VEC>(t[u], p.x_src + (int64_t)bcast_i(b.src, k + u) * p.ld_src + f0);
+                    ldv<VEC>(t[H + u], p.m_edge + (int64_t)(base + k + u) * p.ld_edge + f0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < H; ++u) {
+                if (u == 0 || k + u < cnt) {
+                    float m[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) m[i] = (xd[i] + t[u][i]) + t[H + u][i];
+                    use(k + u, m);
+                }
+            }
+        }
+    }
+}
+
+// accumulate CSR slots [beg, end) of one destination row
+template <class C, bool TRACK>
+__device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggParams& p, int beg, int end, int f0,
+                                                 bool active, const float (&xd)[C::VEC]) {
+    const MsgSrc<C::VEC> src(p);
+    for (int base = beg; base < end; base += kWave) {
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, base, end);
+        // ONE exec-mask region for the whole batch (v_readlane ignores exec), not one per load
+        if (active) accumulate_batch<C, TRACK>(acc, p, src, b, base, min(kWave, end - base), f0, xd);
     }
 }
 
@@ -574,21 +625,13 @@ __device__ __forceinline__ void load_partial(Acc<C, TRACK>& acc, const AggParams
 
 // ---- forward kernels --------------------------------------------------------------------------
 
-template <class C, class O = DynOps>
-__global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
-    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
+// one destination row, start to finish (row pointers -> slot batches -> gathers -> epilogue)
+template <class C, class O>
+__device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0, bool active) {
     constexpr int VEC = C::VEC;
-    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
-    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
-    if (lb < 0) return;
-    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
-    if (row64 >= p.n_nodes) return;
-    const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
     if (deg > p.hub_threshold) return;  // hub row: slice + combine kernels own it
-    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
-    const bool active = f0 < p.F;
     // everything the epilogue needs is requested before the gather loop, so its latency hides there
     float xd[VEC], xin[VEC];
 #pragma unroll
@@ -598,24 +641,109 @@ __global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
     if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
     Acc<C, false> acc;
     acc.init();
-#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 1      // ablation: launch + kernargs + row pointers + side inputs only
-    if (xd[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
-    return;
-#endif
-#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 2      // + the slot batch (src ids, weights), no gathers
-    {
-        SlotBatch<C::NCH, C::NW> b;
-        b.load(p, beg, end);
-        if (b.src + b.w[0] + xd[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
+    accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
+    if (active) write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+}
+
+template <class C, class O = DynOps>
+__global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
+    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
+    if (row64 >= p.n_nodes) return;
+    const int f0 = (blockIdx.y * kWave + lane_id()) * C::VEC;
+    fwd_one_row<C, O>(p, uniform_i((int)row64), f0, f0 < p.F);
+}
+
+// ---- short-row kernels: kShortRows consecutive destination rows per wavefront -------------------------------
+// A molecule row has 2-3 in-edges: one wave per row is a chain of four dependent memory round trips (row
+// pointers -> slot batch -> gathers -> store acknowledgement) around ~1 000 cycles of work, and with 8 waves per
+// SIMD the chip mostly waits (measured on ZINC-12k: 0.25 ms, of which 0.11 ms remain without the stores and
+// 0.05 ms with neither gathers nor epilogue; a 128-float row takes barely longer than a 64-float one).  Here a
+// wave takes kShortRows rows whose slots -- contiguous in the CSR -- fit ONE slot batch: one row-pointer load, one
+// batch load, all gathers of all rows in flight together, then the rows are finished one after the other from
+// registers while the next row's side inputs are already on their way and the previous row's stores drain.
+// Groups with more than kShortSlots slots (or a hub row) fall back to the row-at-a-time routine, so the kernels
+// are correct on any graph; the host picks them when the average in-degree is small (short_rows()).
+constexpr int kShortRows = 4, kShortSlots = 16;
+
+// side inputs of one row: x_dst (message part), x_in (epilogue), log-degree
+template <int VEC>
+struct RowSide {
+    float xd[VEC], xin[VEC], logd;
+    __device__ __forceinline__ void load(const AggParams& p, int row, int f0, bool active) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
+        logd = p.log_deg ? p.log_deg[row] : 0.f;
+        if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+        if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    }
+};
+
+// group of the wave: first row, number of rows, row pointers (lane l: indptr[row0 + min(l, nrows)])
+struct ShortGroup {
+    int row0, nrows, ipv;
+    __device__ __forceinline__ bool init(const AggParams& p) {
+        const int wpb = blockDim.x >> 6;
+        const int64_t n_groups = (p.n_nodes + kShortRows - 1) / kShortRows;
+        const int64_t n_blocks = (n_groups + wpb - 1) / wpb;
+        const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+        if (lb < 0) return false;
+        const int64_t g = lb * wpb + (threadIdx.x >> 6);
+        if (g >= n_groups) return false;
+        row0 = uniform_i((int)(g * kShortRows));
+        nrows = (int)min((int64_t)kShortRows, p.n_nodes - row0);
+        ipv = p.indptr[row0 + min(lane_id(), nrows)];
+        return true;
+    }
+    __device__ __forceinline__ int ptr(int r) const { return bcast_i(ipv, r); }
+};
+
+template <class C, class O = DynOps>
+__global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
+    constexpr int VEC = C::VEC, U = kShortSlots;
+    ShortGroup grp;
+    if (!grp.init(p)) return;
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    const int beg0 = grp.ptr(0), tot = grp.ptr(grp.nrows) - beg0;
+    if (tot > U || (p.x_src && p.m_edge)) {     // long group, or two gathered parts per message: row at a time
+        for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active);
         return;
     }
-#endif
-    accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
-#if defined(DGN_EXP_STAGE) && DGN_EXP_STAGE == 3      // + gathers and accumulation, no epilogue
-    if (acc.sum[0] + acc.sw[0] + xin[0] + logd == 123.456f && active) p.out[row] = 1.f;
-    return;
-#endif
-    if (active) write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+    RowSide<VEC> next;
+    next.load(p, grp.row0, f0, active);
+    SlotBatch<C::NCH, C::NW> b;
+    b.load(p, beg0, beg0 + tot);
+    const MsgSrc<VEC> src(p);
+    float t[U][VEC];
+    if (active && tot > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u == 0 || u < tot) src.load(t[u], bcast_i(b.src, u), beg0 + u, f0);
+    }
+    for (int r = 0; r < grp.nrows; ++r) {
+        const int row = grp.row0 + r;
+        const RowSide<VEC> cur = next;
+        if (r + 1 < grp.nrows) next.load(p, row + 1, f0, active);
+        const int lo = grp.ptr(r) - beg0, hi = grp.ptr(r + 1) - beg0;
+        if (!active) continue;
+        Acc<C, false> acc;
+        acc.init();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u >= lo && u < hi) {
+                float mm[VEC], wk[C::NW];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) mm[i] = cur.xd[i] + t[u][i];
+                b.weights(wk, u);
+                acc.add(mm, wk, beg0 + u);
+            }
+        }
+        write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), hi - lo, cur.xin, cur.logd);
+    }
 }
 
 __device__ __forceinline__ void slice_bounds(const AggParams& p, int chunk, int& hub, int& row, int& beg, int& end) {
@@ -685,9 +813,11 @@ struct Coef {
 
 // per-row coefficient vectors from the upstream gradient and the (recomputed) accumulators;
 // also returns d x_in for this row.  grow already includes the lane's column part.
-template <class C, class O = DynOps>
-__device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], const Acc<C, true>& acc, const AggParams& p,
-                                          const float* grow, int deg, const float (&xin)[C::VEC], float logd) {
+// `load_g(a, s, g)` delivers the upstream gradient block of (aggregator a, scaler s): from memory, or from a
+// register tile the caller loaded earlier (agg_bwd_rows, static lists).
+template <class C, class O = DynOps, class LoadG>
+__device__ __forceinline__ void make_coef_from(Coef<C>& k, float (&gxin)[C::VEC], const Acc<C, true>& acc, const AggParams& p,
+                                               LoadG&& load_g, int deg, const float (&xin)[C::VEC], float logd) {
     constexpr int VEC = C::VEC;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -778,7 +908,7 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
             for (int j = 0; j < AT; ++j) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) t[j][i] = 0.f;
-                if (a0 + j < O::n_agg(p)) ldv<VEC>(t[j], grow + sa_col(p, 0, a0 + j));
+                if (a0 + j < O::n_agg(p)) load_g(a0 + j, 0, t[j]);
             }
 #pragma unroll
             for (int j = 0; j < AT; ++j) {
@@ -801,7 +931,7 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
                 for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) t[j][s][i] = 0.f;
-                    if (a0 + j < O::n_agg(p) && s < O::n_scalers(p)) ldv<VEC>(t[j][s], grow + sa_col(p, s, a0 + j));
+                    if (a0 + j < O::n_agg(p) && s < O::n_scalers(p)) load_g(a0 + j, s, t[j][s]);
                 }
             }
 #pragma unroll
@@ -825,18 +955,36 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
     }
 }
 
-// emit dm_j for slots [beg, end) of a row; returns the row-sum of dm_j in rsum
+template <class C, class O = DynOps>
+__device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], const Acc<C, true>& acc, const AggParams& p,
+                                          const float* grow, int deg, const float (&xin)[C::VEC], float logd) {
+    make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int s, float (&g)[C::VEC]) { ldv<C::VEC>(g, grow + sa_col(p, s, a)); },
+                         deg, xin, logd);
+}
+
+// emit dm_j for the cnt slots of one loaded slot batch (my_tpos: the lane's csc position, two-phase scatter);
+// adds them to the row-sum rsum.  Active lanes only.
 template <class C, bool NEED_M>
-__device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
-                                           int f0, bool active, const float (&xd)[C::VEC]) {
-    constexpr int VEC = C::VEC;
-    for (int base = beg; base < end; base += kWave) {
-        SlotBatch<C::NCH, C::NW> b;
-        b.load(p, base, end);
-        const int my_tpos = (p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
-        const int cnt = min(kWave, end - base);
-        if (!active) continue;      // (lanes beyond F only help loading the slot batch)
-        for (int kk = 0; kk < cnt; ++kk) {
+__device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
+                                           const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
+                                           const float (&xd)[C::VEC]) {
+    constexpr int VEC = C::VEC, U = DGN_UNROLL;
+    const MsgSrc<VEC> src(p);
+    for (int k0 = 0; k0 < cnt; k0 += U) {
+        // var/std need the message again: the group's gathers are issued together, BEFORE the group's stores (a
+        // load waited for after a store drains the store first: loads and stores share one in-order counter)
+        float t[NEED_M ? U : 1][VEC];
+        if constexpr (NEED_M) {
+            if (!src.both) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u == 0 || k0 + u < cnt) src.load(t[u], bcast_i(b.src, k0 + u), base + k0 + u, f0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + u;
+            if (u != 0 && kk >= cnt) break;
             const int s = bcast_i(b.src, kk);
             const int tp = bcast_i(my_tpos, kk);
             float wk[C::NW];
@@ -847,7 +995,12 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
             for (int i = 0; i < VEC; ++i) gm[i] = k.c0[i];
             if constexpr (NEED_M) {
                 float m[VEC];
-                load_msg<VEC>(m, p, s, pos, f0, xd);
+                if (src.both) {
+                    load_msg<VEC>(m, p, s, pos, f0, xd);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) m[i] = xd[i] + t[u][i];
+                }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) gm[i] = fmaf(k.cv[i], m[i], gm[i]);
             }
@@ -884,6 +1037,18 @@ __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VE
     }
 }
 
+// emit dm_j for slots [beg, end) of a row; returns the row-sum of dm_j in rsum
+template <class C, bool NEED_M>
+__device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
+                                           int f0, bool active, const float (&xd)[C::VEC]) {
+    for (int base = beg; base < end; base += kWave) {
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, base, end);
+        const int my_tpos = (p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
+        if (active) emit_batch<C, NEED_M>(k, rsum, p, b, my_tpos, base, min(kWave, end - base), f0, xd);   // (lanes beyond F only help loading the slot batch)
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
                                               int f0, bool active, const float (&xd)[C::VEC]) {
@@ -894,6 +1059,19 @@ __device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C:
         }
     }
     emit_range<C, false>(k, rsum, p, beg, end, f0, active, xd);
+}
+
+template <class C>
+__device__ __forceinline__ void emit_batch_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
+                                                    const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
+                                                    const float (&xd)[C::VEC]) {
+    if constexpr (C::STATS) {
+        if (p.need & NEED_M_EMIT) {
+            emit_batch<C, true>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
+            return;
+        }
+    }
+    emit_batch<C, false>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
 }
 
 template <int VEC>
@@ -945,10 +1123,58 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
     const float logd = p.log_deg ? p.log_deg[row] : 0.f;
-    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
     Acc<C, true> acc;
     acc.init();
+    Coef<C> k;
+    float gxin[VEC], rsum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
+    if (deg <= kWave && (p.need & NEED_RECOMP)) {
+        // Row in one slot batch (every row of a molecule / kNN graph): ONE batch load serves recompute and emit,
+        // and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static lists),
+        // gathers -- is issued before the first store; the separate passes re-loaded the batch after the
+        // recompute and fetched the gradient after the gather wait (two more dependent round trips per row).
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, beg, end);
+        const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+        if (!active) return;
+        if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+        if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+        constexpr bool PRE = O::kStatic && O::NA <= 8;
+        float gpre[PRE ? O::NA : 1][VEC];
+        const bool pre = PRE && O::n_scalers(p) == 1;
+        if constexpr (PRE) {
+            if (pre) {
+#pragma unroll
+                for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[a], grow + sa_col(p, 0, a));
+            }
+        }
+        const MsgSrc<VEC> src(p);
+        accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
+        if constexpr (PRE) {
+            if (pre) {
+                make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int, float (&g)[VEC]) {
+#pragma unroll
+                    for (int aa = 0; aa < O::NA; ++aa) {
+                        if (aa == a) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) g[i] = gpre[aa][i];
+                        }
+                    }
+                }, deg, xin, logd);
+            } else {
+                make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
+            }
+        } else {
+            make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
+        }
+        emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
+        add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
+        return;
+    }
+    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
     if (p.need & NEED_RECOMP) {
         accumulate_range<C, true>(acc, p, beg, end, f0, active, xd);
     } else if constexpr (C::NCH > 0) {
@@ -964,11 +1190,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 #pragma unroll
         for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(part[c]);
     }
-    Coef<C> k;
-    float gxin[VEC], rsum[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
-    if (active) make_coef<C, O>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin, logd);
+    if (active) make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
 }
@@ -1101,12 +1323,25 @@ inline int row_waves_per_block(const AggParams& p) {
     return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
 }
 
+// kShortRows rows per wave when a group's slots usually fit one gather group (average in-degree <= 3)
+inline bool short_rows(const AggParams& p) {
+    static const char* env = getenv("DGN_SHORT_ROWS");
+    if (env) return atoi(env) != 0;
+    return p.n_edges <= 3 * p.n_nodes;
+}
+
 template <class C, class O = DynOps>
 int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     const int wpb = row_waves_per_block(p);
-    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
-    dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_fwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+    if (short_rows(p)) {
+        const int64_t n_groups = (p.n_nodes + kShortRows - 1) / kShortRows;
+        dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);
+        hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+    } else {
+        const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
+        dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
+        hipLaunchKernelGGL((agg_fwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+    }
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         hipLaunchKernelGGL((agg_hub_slices<C, false>), gs, dim3(kBlock), 0, stream, p);

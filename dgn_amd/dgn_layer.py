@@ -107,7 +107,7 @@ def _slot_dst(graph: DGNGraph) -> torch.Tensor:
 
 
 def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
-    """(x_src, x_dst, m_edge) such that m_j = x_src[src_j] + x_dst[i] + m_edge[j] equals
+    """(x_pair, m_edge) such that m_j = P[src_j] + Q[i] + m_edge[j] with x_pair = P | Q [N, 2*in] equals
     pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80."""
     if pretrans.is_single_affine():
         lin = pretrans.fully_connected[0].linear
@@ -117,12 +117,12 @@ def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
         b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
         pq = F.linear(h, w_sd, b_sd)                       # [N, 2*in]: P | Q
         m_edge = F.linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
-        return pq[:, :in_dim], pq[:, in_dim:], m_edge
+        return pq, m_edge
     # general pretrans (ReLU between layers): materialise the messages, directly in slot order
     z = [h.index_select(0, graph.src.long()), h.index_select(0, _slot_dst(graph))]
     if edge_features:
         z.append(graph.to_slot_order(e))
-    return None, None, pretrans(torch.cat(z, dim=1))
+    return None, pretrans(torch.cat(z, dim=1))
 
 
 def _scale_table(graph: DGNGraph, kinds, avg_log: float) -> torch.Tensor:
@@ -243,8 +243,8 @@ class DGNLayerComplex(nn.Module):
 
     def aggregate(self, g, h, e, plan=None):
         graph = as_dgn_graph(g)
-        x_src, x_dst, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
-        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge,
+        x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge,
                                      x_in=h, eig=g.ndata["eig"])
 
     def forward(self, g, h, e, snorm_n):
@@ -296,8 +296,8 @@ class DGNTower(nn.Module):
     def forward(self, g, h, e, snorm_n):
         graph = as_dgn_graph(g)
         h = h.contiguous()
-        x_src, x_dst, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
-        agg = directional_aggregate(graph, self.plan, self._avg_log, x_src=x_src, x_dst=x_dst, m_edge=m_edge, x_in=h,
+        x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        agg = directional_aggregate(graph, self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge, x_in=h,
                                     eig=g.ndata["eig"])
         h = _posttrans_split(self.posttrans, h, agg, self.in_dim)
         if self.graph_norm:
@@ -379,8 +379,8 @@ class DGNLayerTower(nn.Module):
             # The sweep runs WITHOUT scalers (per-row factors, folded behind the GEMM) and WITH the h_in
             # pass-through block, tower-major: posttrans([h_t || agg_t]) of all towers is ONE batched GEMM on
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
-            aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:],
-                                         m_edge=m_edge, x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)
+            aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
+                                         eig=g.ndata["eig"], n_towers=T, tower_major=True)
             hcols = torch.zeros(T, S, fo, fi, dtype=w_post.dtype, device=dev)
             hcols[:, id_slot] = w_h                                                                # h block: identity scaler only
             w = torch.cat([w_a, hcols], dim=3).reshape(T, S * fo, K + fi)
@@ -388,7 +388,7 @@ class DGNLayerTower(nn.Module):
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
-            agg = directional_aggregate(graph, self._kplan, self._avg_log, x_src=pq[:, :Fm], x_dst=pq[:, Fm:], m_edge=m_edge,
+            agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,
                                         x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
             z = torch.bmm(agg, w_a.reshape(T, S * fo, K).transpose(1, 2))                          # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)

@@ -141,8 +141,11 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
 class _DirectionalAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in,
-                xin_is_src: bool, tower_major: bool = False):
+                xin_is_src: bool, tower_major: bool = False, x_pair=None):
         lib = _lib.load()
+        if x_pair is not None:       # [N, 2F] = x_src | x_dst in one tensor: one gradient tensor comes back
+            half = x_pair.shape[1] // 2
+            x_src, x_dst = x_pair[:, :half], x_pair[:, half:]
         ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
         if ref is None:
             raise ValueError("the message needs at least one of x_src / x_dst / m_edge")
@@ -164,8 +167,11 @@ class _DirectionalAggregate(torch.autograd.Function):
             out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
         launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out)
         ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
-        ctx.has = (x_src is not None, x_dst is not None, m_edge is not None, x_in is not None and not xin_is_src)
-        ctx.save_for_backward(w, x_src, x_dst, m_edge, None if xin_is_src else x_in)
+        ctx.paired = x_pair is not None
+        if ctx.paired:
+            ctx.save_for_backward(w, x_pair, None, m_edge, None if xin_is_src else x_in)
+        else:
+            ctx.save_for_backward(w, x_src, x_dst, m_edge, None if xin_is_src else x_in)
         return out
 
     @staticmethod
@@ -173,13 +179,24 @@ class _DirectionalAggregate(torch.autograd.Function):
         lib = _lib.load()
         graph, plan, F = ctx.graph, ctx.plan, ctx.F
         w, x_src, x_dst, m_edge, x_in = ctx.saved_tensors
+        g_pair = None
+        if ctx.paired:
+            x_pair, half = x_src, x_src.shape[1] // 2
+            x_src, x_dst = x_pair[:, :half], x_pair[:, half:]
         if ctx.xin_is_src:
             x_in = x_src
         g_out = g_out.contiguous()
         need_src, need_dst, need_edge, need_in = ctx.needs_input_grad[5:9]
         dev = g_out.device
-        g_src = torch.zeros_like(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
-        g_dst = torch.zeros_like(x_dst) if (x_dst is not None and need_dst) else None
+        if ctx.paired:
+            # one [N, 2F] gradient for P | Q (views into it go to the kernel): no slice-backward zero-fill + copy + add
+            g_pair = torch.zeros_like(x_pair) if ctx.needs_input_grad[11] else None
+            g_src = g_pair[:, :half] if g_pair is not None else None
+            g_dst = g_pair[:, half:] if g_pair is not None else None
+            need_src = need_dst = False
+        else:
+            g_src = torch.zeros_like(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
+            g_dst = torch.zeros_like(x_dst) if (x_dst is not None and need_dst) else None
         g_edge = torch.empty_like(m_edge) if (m_edge is not None and need_edge) else None
         if ctx.xin_is_src:
             g_in = g_src
@@ -188,21 +205,30 @@ class _DirectionalAggregate(torch.autograd.Function):
         launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in)
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
+        if ctx.paired:
+            return (None, None, None, None, None, None, None, g_edge, None if ctx.xin_is_src else g_in, None, None, g_pair)
         return (None, None, None, None, None, g_src if (need_src or ctx.xin_is_src) else None, g_dst, g_edge,
-                None if ctx.xin_is_src else g_in, None, None)
+                None if ctx.xin_is_src else g_in, None, None, None)
 
 
 def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Optional[torch.Tensor] = None,
                           x_dst: Optional[torch.Tensor] = None, m_edge: Optional[torch.Tensor] = None,
                           x_in: Optional[torch.Tensor] = None, eig: Optional[torch.Tensor] = None,
-                          n_towers: int = 1, weights: Optional[torch.Tensor] = None, tower_major: bool = False) -> torch.Tensor:
+                          n_towers: int = 1, weights: Optional[torch.Tensor] = None, tower_major: bool = False,
+                          x_pair: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out [N, T*S*A*(F/T)] (or, with ``tower_major``, [T, N, S*A*(F/T)] so that the per-tower batched GEMMs that
     follow read contiguous matrices): every aggregator of ``plan`` x every applied scaler over the messages
     ``m_j = x_src[src_j] + x_dst[i] + m_edge[j]`` (``m_edge`` in CSR slot order, see
     ``DGNGraph.to_slot_order``).  ``x_in`` is ``h_in`` of the reference's reduce_func; if it is the
-    same tensor as ``x_src`` (simple layer) both gradients land in one buffer."""
+    same tensor as ``x_src`` (simple layer) both gradients land in one buffer.  ``x_pair [N, 2F]`` gives
+    ``x_src | x_dst`` as the column halves of one tensor (the P|Q GEMM output of the complex/towers layers) and
+    gets ONE gradient tensor back."""
     avg = float(avg_log.item()) if torch.is_tensor(avg_log) else float(avg_log)
     w = weights if weights is not None else graph.edge_weights(plan, eig)
+    if x_pair is not None:
+        if x_src is not None or x_dst is not None:
+            raise ValueError("x_pair replaces x_src and x_dst")
+        return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, None, None, m_edge, x_in, False, tower_major, x_pair)
     xin_is_src = x_in is not None and x_in is x_src
     return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, x_src, x_dst, m_edge,
                                        None if xin_is_src else x_in, xin_is_src, tower_major)

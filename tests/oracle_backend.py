@@ -7,7 +7,10 @@ from oracle import dgn_oracle as orc
 
 
 def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m_edge=None, x_in=None, eig=None,
-                                 n_towers=1, weights=None, tower_major=False):
+                                 n_towers=1, weights=None, tower_major=False, x_pair=None):
+    if x_pair is not None:
+        half = x_pair.shape[1] // 2
+        x_src, x_dst = x_pair[:, :half], x_pair[:, half:]
     src = graph.src.long()
     dst = torch.repeat_interleave(torch.arange(graph.num_nodes), graph.in_degree)
     msg = 0
