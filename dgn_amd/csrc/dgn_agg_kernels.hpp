@@ -665,9 +665,9 @@ __global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
 // wave takes kShortRows rows whose slots -- contiguous in the CSR -- fit ONE slot batch: one row-pointer load, one
 // batch load, all gathers of all rows in flight together, then the rows are finished one after the other from
 // registers while the next row's side inputs are already on their way and the previous row's stores drain.
-// Groups with more than kShortSlots slots (or a hub row) fall back to the row-at-a-time routine, so the kernels
+// Groups with a row of more than kShortDeg slots fall back to the row-at-a-time routine, so the kernels
 // are correct on any graph; the host picks them when the average in-degree is small (short_rows()).
-constexpr int kShortRows = 4, kShortSlots = 16;
+constexpr int kShortRows = 4, kShortDeg = 4;
 
 // side inputs of one row: x_dst (message part), x_in (epilogue), log-degree
 template <int VEC>
@@ -703,46 +703,59 @@ struct ShortGroup {
 
 template <class C, class O = DynOps>
 __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
-    constexpr int VEC = C::VEC, U = kShortSlots;
+    constexpr int VEC = C::VEC, R = kShortRows, J = kShortDeg;
     ShortGroup grp;
     if (!grp.init(p)) return;
     const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
     const bool active = f0 < p.F;
-    const int beg0 = grp.ptr(0), tot = grp.ptr(grp.nrows) - beg0;
-    if (tot > U || (p.x_src && p.m_edge)) {     // long group, or two gathered parts per message: row at a time
+    const int beg0 = grp.ptr(0);
+    // in-degree of each row of the group (0 for rows past the end of the graph)
+    int lo[R], deg[R], max_deg = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        lo[r] = grp.ptr(min(r, grp.nrows)) - beg0;
+        deg[r] = grp.ptr(min(r + 1, grp.nrows)) - beg0 - lo[r];
+        max_deg = max(max_deg, deg[r]);
+    }
+    if (max_deg > J || (p.x_src && p.m_edge)) {   // a longer row, or two gathered parts per message: row at a time
         for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active);
         return;
     }
-    RowSide<VEC> next;
-    next.load(p, grp.row0, f0, active);
-    SlotBatch<C::NCH, C::NW> b;
-    b.load(p, beg0, beg0 + tot);
-    const MsgSrc<VEC> src(p);
-    float t[U][VEC];
-    if (active && tot > 0) {
+    // every load of the group is issued before the first store: a load waited for after a store drains the store
+    // first (loads and stores share one in-order counter on gfx950), so the rows are finished from registers only
+    RowSide<VEC> side[R];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u == 0 || u < tot) src.load(t[u], bcast_i(b.src, u), beg0 + u, f0);
+    for (int r = 0; r < R; ++r)
+        if (r == 0 || r < grp.nrows) side[r].load(p, grp.row0 + r, f0, active);
+    SlotBatch<C::NCH, C::NW> b;
+    b.load(p, beg0, beg0 + lo[R - 1] + deg[R - 1]);
+    if (!active) return;
+    const MsgSrc<VEC> src(p);
+    // tile [row][j-th slot of the row]: the register index is static, the slot (= lane of the batch) is not --
+    // one compare per tile instead of a range check of every slot against every row
+    float t[R][J][VEC];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (j < deg[r]) src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
     }
-    for (int r = 0; r < grp.nrows; ++r) {
-        const int row = grp.row0 + r;
-        const RowSide<VEC> cur = next;
-        if (r + 1 < grp.nrows) next.load(p, row + 1, f0, active);
-        const int lo = grp.ptr(r) - beg0, hi = grp.ptr(r + 1) - beg0;
-        if (!active) continue;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r != 0 && r >= grp.nrows) break;
         Acc<C, false> acc;
         acc.init();
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (u >= lo && u < hi) {
+        for (int j = 0; j < J; ++j) {
+            if (j < deg[r]) {
                 float mm[VEC], wk[C::NW];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) mm[i] = cur.xd[i] + t[u][i];
-                b.weights(wk, u);
-                acc.add(mm, wk, beg0 + u);
+                for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
+                b.weights(wk, lo[r] + j);
+                acc.add(mm, wk, beg0 + lo[r] + j);
             }
         }
-        write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), hi - lo, cur.xin, cur.logd);
+        write_row<C, O>(acc, p, p.out + (int64_t)(grp.row0 + r) * p.ld_out + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
     }
 }
 

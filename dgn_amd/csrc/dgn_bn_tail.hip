@@ -64,12 +64,13 @@ __device__ __forceinline__ void column_partials(int64_t n_rows, int F, double* _
     }
 }
 
-// one wavefront per column: sum of the G slots of both quantities in a fixed order
+// one workgroup per column: sum of the G slots of both quantities in a fixed order (thread-strided partials,
+// wave shuffles, then the four wave sums through LDS); the result is valid in thread 0
 __device__ __forceinline__ void slot_sums(const double* __restrict__ part, int F, int G, int c, double& s0, double& s1) {
-    const int lane = (int)threadIdx.x & 63;
+    __shared__ double red[2][4];
     s0 = 0.0;
     s1 = 0.0;
-    for (int g = lane; g < G; g += 64) {
+    for (int g = threadIdx.x; g < G; g += 256) {
         s0 += part[(int64_t)c * G + g];
         s1 += part[((int64_t)F + c) * G + g];
     }
@@ -77,6 +78,10 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ part, int F
         s0 += __shfl_xor(s0, off);
         s1 += __shfl_xor(s1, off);
     }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
 }
 
 // forward partials: sum x, sum x^2
@@ -93,11 +98,10 @@ __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const flo
 __global__ __launch_bounds__(256) void bn_finalize(int64_t n_rows, int F, int G, const double* __restrict__ part,
                                                    float* running_mean, float* running_var, float momentum, float eps,
                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (c >= F) return;
+    const int c = (int)blockIdx.x;
     double s0, s1;
     slot_sums(part, F, G, c, s0, s1);
-    if ((threadIdx.x & 63) != 0) return;
+    if (threadIdx.x != 0) return;
     const double mu = s0 / (double)n_rows;
     double m2 = s1 - mu * s0;                      // sum (x - mean)^2
     if (m2 < 0.0) m2 = 0.0;
@@ -147,11 +151,10 @@ __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const
 // sums[c] = sum g' (= d beta), sums[F + c] = sum g' xhat (= d gamma)
 __global__ __launch_bounds__(256) void bn_bwd_finalize(int F, int G, const double* __restrict__ part, float* __restrict__ sums,
                                                        float* g_gamma, float* g_beta) {
-    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (c >= F) return;
+    const int c = (int)blockIdx.x;
     double s0, s1;
     slot_sums(part, F, G, c, s0, s1);
-    if ((threadIdx.x & 63) != 0) return;
+    if (threadIdx.x != 0) return;
     sums[c] = (float)s0;
     sums[F + c] = (float)s1;
     if (g_beta) g_beta[c] = (float)s0;
@@ -203,7 +206,7 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
         double* part = static_cast<double*>(ws);
         const int G = stat_groups(n_rows, F);
         hipLaunchKernelGGL(bn_stats, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
-        hipLaunchKernelGGL(bn_finalize, dim3((F + 3) / 4), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
+        hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd);
         hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,
                            (const float*)save_mean, (const float*)save_invstd, (const float*)nullptr, (const float*)nullptr, eps, relu,
@@ -230,7 +233,7 @@ extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y,
     float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
     hipLaunchKernelGGL(bn_bwd_stats, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
-    hipLaunchKernelGGL(bn_bwd_finalize, dim3((F + 3) / 4), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean,
                        save_invstd, relu, (const float*)sums, g_x);
     DGN_HIP_CHECK(hipGetLastError());

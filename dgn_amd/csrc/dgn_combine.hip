@@ -146,15 +146,16 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
     }
 }
 
-// g_bias[c] += sum of the G slots (one wavefront per column, fixed order)
+// g_bias[c] += sum of the G slots (one workgroup per column, fixed order)
 __global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const float* __restrict__ bias_part, float* __restrict__ g_bias) {
-    const int c = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (c >= wy) return;
-    const int lane = (int)threadIdx.x & 63;
+    __shared__ float red[kThreads / 64];
+    const int c = (int)blockIdx.x;
     float s = 0.f;
-    for (int g = lane; g < G; g += 64) s += bias_part[(int64_t)c * G + g];
+    for (int g = threadIdx.x; g < G; g += kThreads) s += bias_part[(int64_t)c * G + g];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) g_bias[c] += s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) g_bias[c] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 int bwd_groups(int64_t n_nodes, int rows) { return (int)std::min<int64_t>((n_nodes + rows - 1) / rows, kMaxGroups); }
@@ -208,7 +209,7 @@ extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S,
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = g_bias ? static_cast<float*>(ws) : nullptr;
     hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part);
-    if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3((wy + 3) / 4), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias);
+    if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3(wy), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
