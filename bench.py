@@ -243,7 +243,8 @@ def run_layer_workload(args, wl, rank, world, dev):
     g_src, g_dst, g_in = torch.zeros(N, F_, device=dev), (torch.zeros(N, F_, device=dev) if xd is not None else None), torch.zeros(N, F_, device=dev)
     reps = 20
     ms_f = event_ms(lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out), reps, dev)
-    ms_b = event_ms(lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in), reps, dev)
+    ms_b = event_ms(lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in,
+                                            accumulate=False), reps, dev)
     ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
     kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK),

@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -51,7 +51,8 @@ class DgnMsg(C.Structure):
 
 class DgnMsgGrad(C.Structure):
     _fields_ = [("g_src", C.c_void_p), ("ld_src", C.c_int64), ("g_dst", C.c_void_p), ("ld_dst", C.c_int64),
-                ("g_edge", C.c_void_p), ("ld_edge", C.c_int64), ("g_in", C.c_void_p), ("ld_in", C.c_int64)]
+                ("g_edge", C.c_void_p), ("ld_edge", C.c_int64), ("g_in", C.c_void_p), ("ld_in", C.c_int64),
+                ("accumulate", C.c_int32)]
 
 
 class DgnError(RuntimeError):

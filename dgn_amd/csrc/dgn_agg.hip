@@ -208,7 +208,22 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
         p.stage = reinterpret_cast<float*>(static_cast<char*>(ws) + hub_ws_bytes(g, spec, msg->F));
         p.csc_ptr = g->csc_ptr; p.csc_pos = g->csc_pos;
     }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // accumulate == 0: the sinks arrive uninitialised.  With the two-phase scatter every row of every sink is
+    // written by exactly one thread (no zero-fill, no read-modify-write); the atomic scatter needs zeroed sinks.
+    p.fresh = grads->accumulate == 0 && p.stage != nullptr;
+    p.seg_add = !p.fresh || p.g_in == p.g_src;
+    if (grads->accumulate == 0 && !p.fresh) {
+        auto zero = [&](float* ptr, int32_t ld) -> hipError_t {
+            const size_t wbytes = (size_t)msg->F * sizeof(float), pitch = (size_t)ld * sizeof(float);
+            if (pitch == wbytes) return hipMemsetAsync(ptr, 0, wbytes * (size_t)g->n_nodes, stream);
+            return hipMemset2DAsync(ptr, pitch, 0, wbytes, (size_t)g->n_nodes, stream);
+        };
+        if (p.g_src) DGN_HIP_CHECK(zero(p.g_src, p.ldg_src));
+        if (p.g_dst) DGN_HIP_CHECK(zero(p.g_dst, p.ldg_dst));
+        if (p.g_in && p.g_in != p.g_src) DGN_HIP_CHECK(zero(p.g_in, p.ldg_in));
+    }
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
-    return launch(vec, p, tiles, static_cast<hipStream_t>(stream_), true);
+    return launch(vec, p, tiles, stream, true);
 }

@@ -97,6 +97,8 @@ struct AggParams {
     float* part_sw;       // [n_chunks][DGN_MAX_CH]
     float* coef;          // [n_hub][n_coef][F]  (backward)
     float* stage;         // [n_edges][F] per-edge gradient rows in csc order (atomic-free backward), or NULL
+    bool fresh;           // backward: g_dst / g_in rows are WRITTEN by the row kernel (buffers arrive uninitialised)
+    bool seg_add;         // backward: seg_sum_rows adds to g_src (accumulate mode, or g_in aliases g_src) instead of writing it
     const int32_t* csc_ptr;
     const int32_t* csc_pos;
     int32_t n_slots;
@@ -1087,18 +1089,28 @@ __device__ __forceinline__ void emit_batch_dispatch(const Coef<C>& k, float (&rs
     emit_batch<C, false>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
 }
 
+// per-row gradients d x_dst (= row sum of dm_j) and d x_in.  `plain`: the caller owns the row (row kernel in
+// fresh mode) and stores; otherwise hardware atomics into initialised buffers (accumulate mode, hub slices).
 template <int VEC>
 __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f0, const float (&rsum)[VEC],
-                                              const float (&gxin)[VEC], bool with_xin) {
+                                              const float (&gxin)[VEC], bool with_xin, bool plain = false) {
     if (p.g_dst) {
         float* dst = p.g_dst + (int64_t)row * p.ldg_dst + f0;
+        if (plain) {
+            stv<VEC>(dst, rsum);
+        } else {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, rsum[i]);
+            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, rsum[i]);
+        }
     }
-    if (with_xin && p.g_in && (p.need & NEED_XIN)) {
+    if (with_xin && p.g_in && (plain || (p.need & NEED_XIN))) {
         float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
+        if (plain) {
+            stv<VEC>(dst, gxin);
+        } else {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gxin[i]);
+            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gxin[i]);
+        }
     }
 }
 
@@ -1114,21 +1126,32 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
-    if (deg > p.hub_threshold) return;
     const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
     const bool active = f0 < p.F;
-    if (deg == 0) {          // no messages, no gradient -- except through the x_in pass-through block
-        if ((p.need & NEED_XPASS) && active && p.g_in) {
+    if (deg > p.hub_threshold || deg == 0) {
+        // hub row: the slice kernels own it (they add with atomics: in fresh mode this kernel zeroes the row first).
+        // Row without messages: no gradient -- except through the x_in pass-through block.
+        if (!active) return;
+        float gx[VEC], zero[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { gx[i] = 0.f; zero[i] = 0.f; }
+        if (deg == 0 && (p.need & NEED_XPASS) && p.g_in) {
             const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
             for (int a = 0; a < O::n_agg(p); ++a) {
                 if (O::op(p, a) == DGN_AGG_X_IN) {
                     float g[VEC];
                     ldv<VEC>(g, grow + sa_col(p, 0, a));
-                    float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, g[i]);
+                    for (int i = 0; i < VEC; ++i) gx[i] += g[i];
                 }
             }
+        }
+        if (p.fresh) {
+            add_row_grads<VEC>(p, row, f0, zero, gx, true, true);
+        } else if (deg == 0 && (p.need & NEED_XPASS) && p.g_in) {
+            float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gx[i]);
         }
         return;
     }
@@ -1183,7 +1206,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
             make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
         }
         emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
-        add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
+        add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
         return;
     }
     if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
@@ -1205,7 +1228,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     }
     if (active) make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
-    if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true);
+    if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
 }
 
 // hub backward, phase 2: merge slice partials, build the row's coefficient vectors, park them
@@ -1282,8 +1305,8 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_hub_emit(const AggParams p) {
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, false);
 }
 
-// second phase of the atomic-free backward: g_src[u] += sum of the staged rows of source u (contiguous in csc
-// order).  Flat mapping: one thread per (node, VEC-chunk), so short out-neighbourhoods do not cost a wave each.
+// second phase of the atomic-free backward: g_src[u] (+)= sum of the staged rows of source u (contiguous in csc
+// order; p.seg_add selects += over =).  Flat mapping: one thread per (node, VEC-chunk), so short out-neighbourhoods do not cost a wave each.
 template <int VEC>
 __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     constexpr int PER = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);    // 4 floats per thread whatever the vector width
@@ -1293,7 +1316,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     const int u = (int)(t / nchunk);
     const int f0 = (int)(t - (int64_t)u * nchunk) * VEC * PER;
     const int beg = p.csc_ptr[u], end = p.csc_ptr[u + 1];
-    if (beg == end) return;
+    if (beg == end && p.seg_add) return;
     float acc[PER][VEC];
 #pragma unroll
     for (int q = 0; q < PER; ++q)
@@ -1315,11 +1338,13 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         if (f0 + q * VEC < p.F) {
-            float cur[VEC];
-            ldv<VEC>(cur, dst + q * VEC);
+            if (p.seg_add) {
+                float cur[VEC];
+                ldv<VEC>(cur, dst + q * VEC);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) cur[i] += acc[q][i];
-            stv<VEC>(dst + q * VEC, cur);
+                for (int i = 0; i < VEC; ++i) acc[q][i] += cur[i];
+            }
+            stv<VEC>(dst + q * VEC, acc[q]);
         }
     }
 }

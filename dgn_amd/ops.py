@@ -97,8 +97,9 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
 
 
 def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, g_out,
-                    g_src, g_dst, g_edge, g_in):
-    """Enqueue dgn_agg_backward; g_src/g_dst/g_in are accumulated into, g_edge is overwritten."""
+                    g_src, g_dst, g_edge, g_in, accumulate: bool = True):
+    """Enqueue dgn_agg_backward.  ``accumulate=False``: the sinks g_src/g_dst/g_in may be uninitialised, the first
+    launch of the plan defines them and later launches add; ``True``: every launch adds.  g_edge is overwritten."""
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
     F = ref.shape[1]
@@ -128,6 +129,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
             # g_edge is overwritten by every launch: accumulate the slices on the host side
             tmp = torch.empty_like(g_edge)
             grads.g_edge = tmp.data_ptr()
+        grads.accumulate = 1 if (accumulate or not first) else 0
         rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
                                   graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, C.byref(grads),
                                   _ptr(ws), nbytes, stream)
@@ -136,6 +138,11 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
             g_edge += tmp
             grads.g_edge = g_edge.data_ptr()
         first = False
+
+
+def _empty_rows(x: torch.Tensor) -> torch.Tensor:
+    """Uninitialised contiguous [N, F] gradient buffer for x (which may be a strided view)."""
+    return torch.empty(x.shape, dtype=x.dtype, device=x.device)
 
 
 class _DirectionalAggregate(torch.autograd.Function):
@@ -190,19 +197,21 @@ class _DirectionalAggregate(torch.autograd.Function):
         dev = g_out.device
         if ctx.paired:
             # one [N, 2F] gradient for P | Q (views into it go to the kernel): no slice-backward zero-fill + copy + add
-            g_pair = torch.zeros_like(x_pair) if ctx.needs_input_grad[11] else None
+            g_pair = torch.empty_like(x_pair) if ctx.needs_input_grad[11] else None
             g_src = g_pair[:, :half] if g_pair is not None else None
             g_dst = g_pair[:, half:] if g_pair is not None else None
             need_src = need_dst = False
         else:
-            g_src = torch.zeros_like(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
-            g_dst = torch.zeros_like(x_dst) if (x_dst is not None and need_dst) else None
+            g_src = _empty_rows(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
+            g_dst = _empty_rows(x_dst) if (x_dst is not None and need_dst) else None
         g_edge = torch.empty_like(m_edge) if (m_edge is not None and need_edge) else None
         if ctx.xin_is_src:
             g_in = g_src
         else:
-            g_in = torch.zeros_like(x_in) if (x_in is not None and need_in and plan.needs_x_in()) else None
-        launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in)
+            g_in = _empty_rows(x_in) if (x_in is not None and need_in and plan.needs_x_in()) else None
+        # the sinks are DEFINED by the call (accumulate = 0): no zero-fill, every row is written exactly once
+        launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in,
+                        accumulate=False)
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
         if ctx.paired:

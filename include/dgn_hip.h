@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 2
+#define DGN_ABI_VERSION 3
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -147,14 +147,19 @@ typedef struct DgnMsg {
     const float* x_in;   int64_t ld_in;    /* [n_nodes, ld_in]                                   */
 } DgnMsg;
 
-/* Gradient sinks of dgn_agg_backward.  g_src / g_dst / g_in are ACCUMULATED with atomic adds into
- * caller-initialised buffers (they may alias each other: the simple layer passes one zeroed
- * buffer for g_src and g_in); g_edge is overwritten.  NULL = not wanted.                        */
+/* Gradient sinks of dgn_agg_backward; NULL = not wanted.  g_edge is always overwritten.  g_src / g_dst / g_in:
+ *   accumulate != 0: the call ADDS into caller-initialised buffers (a plan split into several launches, or a
+ *                    caller summing several graphs' gradients);
+ *   accumulate == 0: the call DEFINES them, the buffers may arrive uninitialised (with the two-phase scatter
+ *                    every row is written exactly once: no zero-fill and no read-modify-write traffic; the
+ *                    atomic scatter zero-fills them itself).
+ * g_in may alias g_src (the simple layer's x_in IS x_src: both gradients land in one buffer).          */
 typedef struct DgnMsgGrad {
     float* g_src;  int64_t ld_src;
     float* g_dst;  int64_t ld_dst;
     float* g_edge; int64_t ld_edge;
     float* g_in;   int64_t ld_in;
+    int32_t accumulate;
 } DgnMsgGrad;
 
 int dgn_abi_version(void);

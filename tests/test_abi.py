@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2 + 8      # (+ max_in_degree, padded)
     assert C.sizeof(_lib.DgnAggSpec) == 4 * (1 + 16 + 16 + 1 + 1 + 4 + 1 + 1 + 1 + 1 + 1) + 8
     assert C.sizeof(_lib.DgnMsg) == 8 * 9
-    assert C.sizeof(_lib.DgnMsgGrad) == 8 * 8
+    assert C.sizeof(_lib.DgnMsgGrad) == 8 * 8 + 8                                # (+ accumulate, padded)
     header = open(os.path.join(ROOT, "include", "dgn_hip.h")).read()
     assert f"#define DGN_MAX_AGG {_lib.DGN_MAX_AGG}" in header
     assert f"#define DGN_MAX_CH {_lib.DGN_MAX_CH}" in header
