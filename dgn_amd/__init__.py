@@ -10,7 +10,8 @@ from .spec import AGGREGATOR_NAMES, SCALER_NAMES, make_plan
 from .ops import directional_aggregate
 from .layers import FCLayer, MLP, get_activation
 from .dgn_layer import (AGGREGATORS, SCALERS, DGNLayer, DGNLayerComplex, DGNLayerSimple, DGNLayerTower, DGNTower)
+from .readout import VirtualNode, max_nodes, mean_nodes, readout, sum_nodes
 
 __all__ = ["DGNGraph", "as_dgn_graph", "compute_edge_weights", "make_plan", "directional_aggregate", "FCLayer", "MLP",
            "get_activation", "AGGREGATORS", "SCALERS", "DGNLayer", "DGNLayerSimple", "DGNLayerComplex", "DGNLayerTower",
-           "DGNTower", "AGGREGATOR_NAMES", "SCALER_NAMES"]
+           "DGNTower", "AGGREGATOR_NAMES", "SCALER_NAMES", "VirtualNode", "sum_nodes", "mean_nodes", "max_nodes", "readout"]

@@ -46,6 +46,7 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
         set_error("n_nodes/n_edges out of the int32 CSR range"); return DGN_ERR_INVALID;
     }
     if (g->n_nodes > 0 && (!g->indptr || (g->n_edges > 0 && !g->src))) { set_error("null CSR arrays"); return DGN_ERR_INVALID; }
+    if (g->n_src < 0 || g->n_src > INT32_MAX - 1) { set_error("n_src out of the int32 range"); return DGN_ERR_INVALID; }
     if (spec->n_agg < 1 || spec->n_agg > DGN_MAX_AGG) { set_error("n_agg=%d outside 1..%d", spec->n_agg, DGN_MAX_AGG); return DGN_ERR_INVALID; }
     if (spec->agg_total != 0 && (spec->agg_offset < 0 || spec->agg_offset + spec->n_agg > spec->agg_total)) { set_error("aggregator slice [%d, %d) outside agg_total=%d", spec->agg_offset, spec->agg_offset + spec->n_agg, spec->agg_total); return DGN_ERR_INVALID; }
     if (spec->n_ch < 0 || spec->n_ch > DGN_MAX_CH) { set_error("n_ch=%d outside 0..%d", spec->n_ch, DGN_MAX_CH); return DGN_ERR_INVALID; }
@@ -81,6 +82,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
                  const float* log_deg) {
     p = AggParams{};
     p.indptr = g->indptr; p.src = g->src; p.n_nodes = g->n_nodes; p.n_edges = g->n_edges;
+    p.n_src = g->n_src > 0 ? g->n_src : g->n_nodes;
     p.n_hub = g->n_hub; p.n_chunks = g->n_hub > 0 ? g->n_chunks : 0;
     p.hub_threshold = g->n_hub > 0 ? g->hub_threshold : INT32_MAX;
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;
@@ -214,14 +216,14 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     p.fresh = grads->accumulate == 0 && p.stage != nullptr;
     p.seg_add = !p.fresh || p.g_in == p.g_src;
     if (grads->accumulate == 0 && !p.fresh) {
-        auto zero = [&](float* ptr, int32_t ld) -> hipError_t {
+        auto zero = [&](float* ptr, int32_t ld, int64_t rows) -> hipError_t {
             const size_t wbytes = (size_t)msg->F * sizeof(float), pitch = (size_t)ld * sizeof(float);
-            if (pitch == wbytes) return hipMemsetAsync(ptr, 0, wbytes * (size_t)g->n_nodes, stream);
-            return hipMemset2DAsync(ptr, pitch, 0, wbytes, (size_t)g->n_nodes, stream);
+            if (pitch == wbytes) return hipMemsetAsync(ptr, 0, wbytes * (size_t)rows, stream);
+            return hipMemset2DAsync(ptr, pitch, 0, wbytes, (size_t)rows, stream);
         };
-        if (p.g_src) DGN_HIP_CHECK(zero(p.g_src, p.ldg_src));
-        if (p.g_dst) DGN_HIP_CHECK(zero(p.g_dst, p.ldg_dst));
-        if (p.g_in && p.g_in != p.g_src) DGN_HIP_CHECK(zero(p.g_in, p.ldg_in));
+        if (p.g_src) DGN_HIP_CHECK(zero(p.g_src, p.ldg_src, p.n_src));
+        if (p.g_dst) DGN_HIP_CHECK(zero(p.g_dst, p.ldg_dst, p.n_nodes));
+        if (p.g_in && p.g_in != p.g_src) DGN_HIP_CHECK(zero(p.g_in, p.ldg_in, p.n_nodes));
     }
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));

@@ -50,6 +50,7 @@ struct AggParams {
     const int32_t* indptr;
     const int32_t* src;
     int64_t n_nodes;
+    int64_t n_src;        // rows of x_src / g_src (== n_nodes unless the CSR is bipartite)
     int64_t n_edges;
     int32_t hub_threshold;
     int32_t hub_chunk;
@@ -1312,7 +1313,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     constexpr int PER = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);    // 4 floats per thread whatever the vector width
     const int nchunk = (p.F + VEC * PER - 1) / (VEC * PER);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.n_nodes * nchunk) return;
+    if (t >= p.n_src * nchunk) return;
     const int u = (int)(t / nchunk);
     const int f0 = (int)(t - (int64_t)u * nchunk) * VEC * PER;
     const int beg = p.csc_ptr[u], end = p.csc_ptr[u + 1];
@@ -1405,7 +1406,7 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
     }
     if (p.stage && p.g_src) {
         constexpr int per = C::VEC == 1 ? 4 : (C::VEC == 2 ? 2 : 1);
-        const int64_t n_threads = p.n_nodes * ((p.F + C::VEC * per - 1) / (C::VEC * per));
+        const int64_t n_threads = p.n_src * ((p.F + C::VEC * per - 1) / (C::VEC * per));
         hipLaunchKernelGGL((seg_sum_rows<C::VEC>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, stream, p);
     }
     DGN_HIP_CHECK(hipGetLastError());

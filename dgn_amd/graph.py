@@ -52,23 +52,25 @@ class DGNGraph:
     @classmethod
     def from_csr(cls, indptr: torch.Tensor, src_csr: torch.Tensor, eid: Optional[torch.Tensor] = None,
                  eig: Optional[torch.Tensor] = None, hub_threshold: int = HUB_THRESHOLD,
-                 hub_chunk: int = HUB_CHUNK) -> "DGNGraph":
-        """Adopt an existing destination-major CSR (no sort)."""
+                 hub_chunk: int = HUB_CHUNK, num_src: Optional[int] = None) -> "DGNGraph":
+        """Adopt an existing destination-major CSR (no sort).  ``num_src``: number of source nodes of a bipartite
+        CSR (rows = e.g. the graphs of a batch, sources = its nodes); default: the same node set."""
         self = cls.__new__(cls)
         n = indptr.numel() - 1
         deg = (indptr[1:] - indptr[:-1]).long()
-        self._init_csr(indptr.long(), src_csr, eid, n, src_csr.numel(), deg, hub_threshold, hub_chunk)
+        self._init_csr(indptr.long(), src_csr, eid, n, src_csr.numel(), deg, hub_threshold, hub_chunk, num_src)
         self.ndata, self.edata = {}, {}
         if eig is not None:
             self.ndata["eig"] = eig
         return self
 
-    def _init_csr(self, indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk):
-        if num_nodes >= 2 ** 31 - 1 or E >= 2 ** 31 - 1:
+    def _init_csr(self, indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk, num_src=None):
+        if num_nodes >= 2 ** 31 - 1 or E >= 2 ** 31 - 1 or (num_src or 0) >= 2 ** 31 - 1:
             raise ValueError("graph exceeds the int32 CSR range")
         device = indptr.device
         self.device = device
         self.num_nodes, self.num_edges = int(num_nodes), int(E)
+        self.num_src = int(num_src) if num_src is not None else int(num_nodes)
         self.indptr = indptr.to(torch.int32).contiguous()
         self.src = src_csr.to(torch.int32).contiguous()
         self.eid = eid  # None = identity (messages already in slot order)
@@ -84,6 +86,7 @@ class DGNGraph:
         c.indptr, c.src = self.indptr.data_ptr(), self.src.data_ptr()
         c.hub_threshold, c.hub_chunk = self.hub_threshold, self.hub_chunk
         c.max_in_degree = self.max_in_degree
+        c.n_src = self.num_src if self.num_src != self.num_nodes else 0
         c.n_hub, c.n_chunks = 0, 0
         if self.n_hub:
             n_sl = (deg[hub_rows] + hub_chunk - 1) // hub_chunk
@@ -106,8 +109,8 @@ class DGNGraph:
         order = torch.sort(self.src.long(), stable=True)[1]                 # slots ordered by (source, slot)
         pos = torch.empty(E, dtype=torch.int64, device=dev)
         pos[order] = torch.arange(E, device=dev)
-        out_deg = torch.bincount(self.src.long(), minlength=self.num_nodes) if E else torch.zeros(self.num_nodes, dtype=torch.int64, device=dev)
-        ptr = torch.zeros(self.num_nodes + 1, dtype=torch.int64, device=dev)
+        out_deg = torch.bincount(self.src.long(), minlength=self.num_src) if E else torch.zeros(self.num_src, dtype=torch.int64, device=dev)
+        ptr = torch.zeros(self.num_src + 1, dtype=torch.int64, device=dev)
         ptr[1:] = torch.cumsum(out_deg, 0)
         self.csc_ptr, self.csc_pos = ptr.int().contiguous(), pos.int().contiguous()
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()

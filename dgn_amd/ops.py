@@ -158,7 +158,7 @@ class _DirectionalAggregate(torch.autograd.Function):
             raise ValueError("the message needs at least one of x_src / x_dst / m_edge")
         F = ref.shape[1]
         N, E = graph.num_nodes, graph.num_edges
-        _check(x_src, "x_src", N, F)
+        _check(x_src, "x_src", graph.num_src, F)
         _check(x_dst, "x_dst", N, F)
         _check(m_edge, "m_edge", E, F)
         if xin_is_src:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 3
+#define DGN_ABI_VERSION 4
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -97,10 +97,15 @@ typedef struct DgnGraph {
      * rank of CSR slot j when the slots are ordered by (source node, slot) and csc_ptr[u] the first such rank
      * of source u.  With it (and a large enough workspace) the backward writes every per-edge gradient row
      * to its csc position and a second kernel sums each source's contiguous rows: deterministic, no atomics. */
-    const int32_t* csc_ptr;  /* [n_nodes+1] */
+    const int32_t* csc_ptr;  /* [n_src+1]   */
     const int32_t* csc_pos;  /* [n_edges]   */
     /* Hint: largest in-degree, 0 = unknown.  Lets launches that only concern long rows be skipped.       */
     int32_t max_in_degree;
+    /* Number of SOURCE nodes when it differs from n_nodes (0 = same): a bipartite CSR whose rows are e.g. the
+     * graphs of a batch and whose sources are its nodes -- the readouts (dgl.mean_nodes / sum_nodes / max_nodes,
+     * nets/.../dgn_net.py:71-86) are this sweep over such a CSR.  x_src / g_src have n_src rows, csc_ptr
+     * n_src + 1 entries; x_dst, x_in, log_deg, out are per destination row.                               */
+    int64_t n_src;
 } DgnGraph;
 
 typedef struct DgnChannel {

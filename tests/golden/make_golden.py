@@ -11,7 +11,9 @@ any import from the reference tree).
 What drives the reference:
 * ``realworld_benchmark/nets/{aggregators,scalers,layers}.py`` import as they are.
 * ``realworld_benchmark/nets/dgn_layer.py`` needs ``dgl.nn.pytorch.glob`` only for
-  ``VirtualNode`` (out of scope): four empty stub modules are registered.
+  ``VirtualNode``; the nets call ``dgl.{sum,mean,max}_nodes``: four stub modules are registered whose
+  ``*_nodes`` functions reduce ``g.ndata[key]`` over the consecutive node blocks ``g.batch_num_nodes`` of a
+  batched graph (DGL's documented meaning; DGL's own implementation is absent -> unpinned like the mailbox order).
 * DGL itself (0.4.2) is not installed.  ``FakeGraph`` below implements the UDF
   protocol the layer relies on (ndata/edata, apply_edges, update_all with degree
   bucketing).  Two DGL-internal behaviours are NOT pinned by the reference and are
@@ -36,9 +38,19 @@ def _install_stubs():
     for name in ("dgl", "dgl.nn", "dgl.nn.pytorch", "dgl.nn.pytorch.glob"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
-    glob = sys.modules["dgl.nn.pytorch.glob"]
-    glob.mean_nodes = lambda *a, **k: None
-    glob.sum_nodes = lambda *a, **k: None
+    def seg(how):
+        def fn(g, feat):
+            x, outs, off = g.ndata[feat], [], 0
+            for n in g.batch_num_nodes:
+                blk = x[off:off + n]
+                outs.append(blk.sum(0) if how == "sum" else (blk.mean(0) if how == "mean" else blk.max(0)[0]))
+                off += n
+            return torch.stack(outs)
+        return fn
+    glob, dgl = sys.modules["dgl.nn.pytorch.glob"], sys.modules["dgl"]
+    for how in ("sum", "mean", "max"):
+        setattr(dgl, how + "_nodes", seg(how))
+    glob.mean_nodes, glob.sum_nodes = dgl.mean_nodes, dgl.sum_nodes
     sys.path.insert(0, os.path.join(REF, "realworld_benchmark"))
     sys.path.insert(1, REF)
 
@@ -445,11 +457,77 @@ def g6_dense(out):
             out[f"{lname}/gp::{pn}"] = gr.numpy()
 
 
+def g8_readouts(out):
+    """Graph-level readouts of nets/molecules_graph_regression/dgn_net.py:71-86 (captured at the input of the
+    net's MLP_layer) and VirtualNode of nets/dgn_layer.py:12-49."""
+    from nets.molecules_graph_regression.dgn_net import DGNNet
+    from nets.dgn_layer import VirtualNode
+    src, dst, N, sizes = make_test_graph(seed=3)
+    out["src"], out["dst"], out["N"], out["sizes"] = src, dst, np.array(N), np.array(sizes)
+    gen = torch.Generator().manual_seed(11)
+    eig = torch.randn(N, 4, generator=gen)
+    atoms = torch.randint(0, 5, (N,), generator=gen)
+    snorm = torch.rand(N, 1, generator=gen) + 0.5
+    out["eig"] = eig.numpy()
+    for mode in ("sum", "max", "mean", "directional", "directional_abs"):
+        torch.manual_seed(1)
+        net = DGNNet(dict(num_atom_type=5, num_bond_type=3, hidden_dim=8, out_dim=8, in_feat_dropout=0.0, dropout=0.0, L=2,
+                          type_net="simple", pos_enc_dim=0, readout=mode, graph_norm=True, batch_norm=True,
+                          aggregators="mean dir1-dx", scalers="identity", avg_d={"log": torch.tensor(1.0)}, residual=True,
+                          edge_feat=False, edge_dim=0, pretrans_layers=1, posttrans_layers=1, device="cpu"))
+        g = FakeGraph(src, dst, N)
+        g.batch_num_nodes = list(sizes)
+        g.ndata["eig"] = eig
+        seen = {}
+        net.MLP_layer.register_forward_pre_hook(lambda m, inp: seen.__setitem__("hg", inp[0]))
+        net(g, atoms, None, snorm, None)
+        h_last, hg = g.ndata["h"], seen["hg"]
+        ct = torch.randn(hg.shape, generator=torch.Generator().manual_seed(2))
+        gh, = torch.autograd.grad(hg, [h_last], ct)
+        out[f"readout/{mode}/h"], out[f"readout/{mode}/hg"] = h_last.detach().numpy(), hg.detach().numpy()
+        out[f"readout/{mode}/cot"], out[f"readout/{mode}/gh"] = ct.numpy(), gh.numpy()
+    G, D = len(sizes), 8
+    case = 0
+    for vn_type in ("mean", "sum", "logsum"):
+        for b_norm, residual in ((False, True), (True, True), (False, False)):
+            torch.manual_seed(20 + case)
+            vn = VirtualNode(dim=D, dropout=0.0, batch_norm=b_norm, bias=True, residual=residual, vn_type=vn_type)
+            with torch.no_grad():
+                for q in vn.parameters():
+                    q.mul_(3.0).add_(0.1 * torch.randn(q.shape, generator=gen))
+            vn.train(True)
+            pre = f"vn/c{case}"
+            out[f"{pre}/cfg"] = np.array([vn_type, str(int(b_norm)), str(int(residual))])
+            for k, v in vn.state_dict().items():
+                out[f"{pre}/sd::{k}"] = v.detach().numpy().copy()
+            h = torch.randn(N, D, generator=gen).requires_grad_(True)
+            vh = torch.randn(G, D, generator=gen).requires_grad_(True)
+            g = FakeGraph(src, dst, N)
+            g.batch_num_nodes = list(sizes)
+            vn_out, h_out = vn(g, h, vh)
+            ct_v = torch.randn(G, D, generator=torch.Generator().manual_seed(3))
+            ct_h = torch.randn(N, D, generator=torch.Generator().manual_seed(4))
+            params = list(vn.parameters())
+            grads = torch.autograd.grad([vn_out, h_out], [h, vh] + params, [ct_v, ct_h])
+            out[f"{pre}/h"], out[f"{pre}/vn_h"] = h.detach().numpy(), vh.detach().numpy()
+            out[f"{pre}/vn_out"], out[f"{pre}/h_out"] = vn_out.detach().numpy(), h_out.detach().numpy()
+            out[f"{pre}/cot_v"], out[f"{pre}/cot_h"] = ct_v.numpy(), ct_h.numpy()
+            out[f"{pre}/gh"], out[f"{pre}/gvn"] = grads[0].numpy(), grads[1].numpy()
+            for (pn, _), gr in zip(vn.named_parameters(), grads[2:]):
+                out[f"{pre}/gp::{pn}"] = gr.numpy()
+            for k, v in vn.state_dict().items():
+                if "running" in k:
+                    out[f"{pre}/after::{k}"] = v.detach().numpy().copy()
+            case += 1
+    out["vn/n_cases"] = np.array(case)
+
+
 def main():
     _install_stubs()
     only = sys.argv[1:]
     for fname, fn in (("g1_aggregators", g1_aggregators), ("g2_scalers", g2_scalers), ("g3_reduce", g3_reduce),
-                      ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases), ("g6_dense", g6_dense)):
+                      ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases), ("g6_dense", g6_dense),
+                      ("g8_readouts", g8_readouts)):
         if only and fname not in only:
             continue
         out = {}
