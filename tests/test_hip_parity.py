@@ -219,6 +219,38 @@ def test_random_graph_vs_oracle(F_, hub):
     assert float(y[N - 1].detach().abs().max()) == 0.0      # zero in-degree row -> zeros
 
 
+@pytest.mark.parametrize("F_", [6, 7])      # even: two-phase scatter, odd: atomic scatter
+@pytest.mark.parametrize("hub", [False, True])
+def test_backward_define_vs_accumulate_mode(F_, hub):
+    """DgnMsgGrad.accumulate: 0 defines the sinks (garbage in, gradient out), 1 adds to what is there."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd.ops import launch_backward
+    N, E = 41, 600
+    src, dst = _random_graph(F_ + 100, N, E)
+    gen = torch.Generator().manual_seed(F_)
+    kw = dict(hub_threshold=16, hub_chunk=7) if hub else {}
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=torch.randn(N, 3, generator=gen).to(dev), **kw)
+    plan = dgn_amd.make_plan(["mean", "max", "std", "dir1-dx", "dir2-av"], ["identity", "amplification"])
+    xs, xd, xin = (torch.randn(N, F_, generator=gen).to(dev) for _ in range(3))
+    w = graph.edge_weights(plan)
+    g_out = torch.randn(N, plan.out_width(F_), generator=gen).to(dev)
+
+    def run(accumulate, fill):
+        sinks = [torch.full((N, F_), fill, device=dev) for _ in range(3)]
+        launch_backward(graph, plan, 1, 0.9, w, xs, xd, None, xin, g_out, sinks[0], sinks[1], None, sinks[2], accumulate=accumulate)
+        return sinks
+
+    fresh = run(False, float("nan"))                 # uninitialised sinks are fine in define mode
+    added = run(True, 1.5)
+    for a, b in zip(fresh, added):
+        assert torch.isfinite(a).all()
+        _close(b - 1.5, a, 1e-5, 1e-5)
+    again = run(False, 7.0)                          # and define mode does not depend on the previous content
+    for a, b in zip(fresh, again):
+        _close(b, a, 1e-6, 1e-6)
+
+
 def test_three_term_message_vs_oracle():
     dev = _dev()
     import dgn_amd
