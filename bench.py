@@ -268,19 +268,31 @@ def run_c5(args, wl, rank, world, dev):
     if args.scale != 1.0:
         kw["num_nodes"] = int(kw["num_nodes"] * args.scale)
         kw["num_edges"] = int(kw["num_edges"] * args.scale)
-    indptr, src, eig = synth.powerlaw_csr(device=dev, seed=rank, **kw)
-    graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    partition = world > 1 and args.c5_mode == "partition"
+    # partition: ALL ranks build the same graph and own a destination range with a balanced edge count (strong
+    # scaling of one graph; the node features stay whole on every rank, the sweep needs no exchange).
+    # replicas: every rank its own graph (weak scaling).
+    indptr, src, eig = synth.powerlaw_csr(device=dev, seed=0 if partition else rank, **kw)
+    r0, r1 = 0, indptr.numel() - 1
+    if partition:
+        r0, r1 = ddist.row_ranges_by_edges(indptr, world)[rank]
+        graph = ddist.shard_rows(indptr, src, r0, r1)
+        graph.ndata["eig"] = eig
+    else:
+        graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    N_all = indptr.numel() - 1
     del indptr
     N, E, F_ = graph.num_nodes, graph.num_edges, wl["hidden"]
     plan = dgn_amd.make_plan(wl["aggregators"].split(), wl["scalers"].split())
     avg_log = float(graph.log_deg.mean().item())
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    X = torch.randn(N, F_, device=dev, generator=gen)
+    gen = torch.Generator(device=dev).manual_seed(0 if partition else rank)
+    X_all = torch.randn(N_all, F_, device=dev, generator=gen)
+    X = X_all[r0:r1]                                   # x_in: the shard's own rows
     out = torch.empty(N, plan.out_width(F_), device=dev)
     w = graph.edge_weights(plan)
 
     def step():
-        launch_forward(graph, plan, 1, avg_log, w, X, None, None, X, out)
+        launch_forward(graph, plan, 1, avg_log, w, X_all, None, None, X, out)
 
     for _ in range(args.warmup):
         step()
@@ -297,7 +309,10 @@ def run_c5(args, wl, rank, world, dev):
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
-    result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N)
+    result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
+                  scaling="strong" if partition else "weak",
+                  parallelism=(f"1 graph, {world} destination-range shards (balanced edges), features replicated, no exchange "
+                               f"inside the sweep") if partition else (f"{world} independent replicas" if world > 1 else "single GPU"))
     if rank == 0:
         A, S, Ku, x, r = plan_model(plan)
         ms_f = event_ms(step, max(3, args.steps), dev)
@@ -320,6 +335,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="c5 only: scale N and E")
+    ap.add_argument("--c5-mode", default="partition", choices=["partition", "replicas"],
+                    help="c5 with --gpus > 1: one graph split by destination ranges (strong scaling) or one graph per rank")
     ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,12 +367,14 @@ def main():
     result, batch = res
     line = dict(metric="dgn_layer_fwd_bwd_edges_per_sec" if wl["type_net"] != "op" else "dgn_aggregation_fwd_edges_per_sec",
                 value=result["value"], unit="edges/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                ms_per_step=result["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                ms_per_step=result["ms_per_step"], higher_is_better=True, scaling=result.get("scaling", "weak"), vs_baseline=None,
+                dtype="f32",
                 data="synthetic",
                 config=dict(workload=args.workload + ": " + wl["desc"], edges_per_gpu=result["edges_per_rank"],
                             nodes_per_gpu=result["nodes_per_rank"], type_net=wl["type_net"], hidden=wl["hidden"],
                             aggregators=wl["aggregators"], scalers=wl["scalers"], towers=wl["towers"],
-                            parallelism=f"dp{world} (graphs sharded, flat-gradient all-reduce)" if world > 1 else "single GPU",
+                            parallelism=result.get("parallelism") or (f"dp{world} (graphs sharded, flat-gradient all-reduce)"
+                                                                      if world > 1 else "single GPU"),
                             step="edge weights + layer forward + backward" if wl["type_net"] != "op" else "aggregation forward"),
                 roofline=result.get("roofline"))
     if world == 1 and not args.no_cpu_baseline and batch is not None:

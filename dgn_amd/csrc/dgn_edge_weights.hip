@@ -23,6 +23,7 @@ struct EwParams {
     const int32_t* indptr;
     const int32_t* src;
     int64_t n_nodes;
+    int64_t row_base;      // global id of row 0 (destination-range shard), 0 otherwise
     int32_t hub_threshold;
     int32_t hub_chunk;
     const int32_t* hub_rows;
@@ -48,7 +49,7 @@ struct Stats {  // per channel
 
 __device__ __forceinline__ float edge_delta(const EwParams& p, int row, int e, int col) {
     if (p.eig_s) return p.eig_s[(int64_t)e * p.ld_eig + col] - p.eig_d[(int64_t)e * p.ld_eig + col];
-    return p.eig[(int64_t)p.src[e] * p.ld_eig + col] - p.eig[(int64_t)row * p.ld_eig + col];
+    return p.eig[(int64_t)p.src[e] * p.ld_eig + col] - p.eig[(p.row_base + row) * p.ld_eig + col];
 }
 
 // statistics of slots [beg, end) of row `row` for every channel (wave-wide results)
@@ -256,7 +257,7 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
     if (g->n_hub > 0 && (!ws || ws_bytes < ws_bytes_for(g))) { set_error("workspace too small: need %zu bytes", ws_bytes_for(g)); return DGN_ERR_WORKSPACE; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     EwParams p{};
-    p.indptr = g->indptr; p.src = g->src; p.n_nodes = g->n_nodes;
+    p.indptr = g->indptr; p.src = g->src; p.n_nodes = g->n_nodes; p.row_base = g->row_base;
     p.n_hub = g->n_hub; p.n_chunks = g->n_hub > 0 ? g->n_chunks : 0;
     p.hub_threshold = g->n_hub > 0 ? g->hub_threshold : INT32_MAX;
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;

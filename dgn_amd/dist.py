@@ -7,14 +7,22 @@ inside the layer: every rank runs the full layer stack on its own graphs, and th
 the gradient average.  The parameter set of a DGN net is ~0.1-0.3 M fp32 values (~1 MB): the
 all-reduce is latency-bound on a ~153 GB/s xGMI link, so one call on one pre-flattened buffer, no
 bucketing, no overlap machinery.
+
+ONE giant graph (BASELINE config 5, the ogbn-scale power-law graph) is split the other way
+(``row_ranges_by_edges`` / ``shard_rows`` / ``all_gather_rows``): every rank owns a contiguous range of destination
+rows with a balanced edge count and keeps the node features whole; the sweep over a shard needs no exchange, the
+layer OUTPUT rows (F wide, after the post-transformation) are all-gathered for the next layer, and the gradient
+of the replicated features is summed with an all-reduce.
 """
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Sequence
+from typing import Iterable, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+from .graph import DGNGraph
 
 
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
@@ -48,6 +56,43 @@ def shard_by_edges(edge_counts: Sequence[int], world: int) -> List[List[int]]:
     for s in shards:
         s.sort()
     return shards
+
+
+def row_ranges_by_edges(indptr: torch.Tensor, world: int) -> List[Tuple[int, int]]:
+    """Cut the destination rows of ONE graph into ``world`` contiguous ranges with balanced edge totals
+    (dst-range CSR shards).  ``indptr`` [N+1] on any device; deterministic."""
+    n = indptr.numel() - 1
+    ip = indptr.long()
+    total = int(ip[-1].item())
+    targets = torch.tensor([(total * r) // world for r in range(1, world)], dtype=torch.long, device=ip.device)
+    cuts = torch.searchsorted(ip, targets, right=False).clamp(0, n).tolist() if world > 1 else []
+    bounds = [0] + cuts + [n]
+    for i in range(1, len(bounds)):              # monotone even when a hub row swallows several targets
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def shard_rows(indptr: torch.Tensor, src: torch.Tensor, r0: int, r1: int, **graph_kw) -> DGNGraph:
+    """Rows [r0, r1) of a destination-major CSR as a bipartite shard: sources keep their global ids (the node
+    features stay whole / replicated, ``x_src`` has N rows), the per-row arrays (``x_in``, ``x_dst``, output) are
+    the shard's, and ``row_base = r0`` tells ``dgn_edge_weights`` where the shard's rows sit in ``eig``."""
+    n = indptr.numel() - 1
+    e0, e1 = int(indptr[r0].item()), int(indptr[r1].item())
+    return DGNGraph.from_csr((indptr[r0:r1 + 1] - indptr[r0]), src[e0:e1], num_src=n, row_base=r0, **graph_kw)
+
+
+def all_gather_rows(local: torch.Tensor, ranges: Sequence[Tuple[int, int]]) -> torch.Tensor:
+    """[rows_r, F] per rank -> [N, F] on every rank (the exchange a multi-layer net needs between two sharded layers:
+    after the post-transformation the rows are F wide, 5.1 GB for 10 M x 128 fp32).  Uneven shards are padded to the
+    largest one for the collective."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    longest = max(b - a for a, b in ranges)
+    pad = local.new_zeros((longest,) + tuple(local.shape[1:]))
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in ranges]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:b - a] for p, (a, b) in zip(parts, ranges)], dim=0)
 
 
 class FlatGradAllReduce:

@@ -52,13 +52,16 @@ class DGNGraph:
     @classmethod
     def from_csr(cls, indptr: torch.Tensor, src_csr: torch.Tensor, eid: Optional[torch.Tensor] = None,
                  eig: Optional[torch.Tensor] = None, hub_threshold: int = HUB_THRESHOLD,
-                 hub_chunk: int = HUB_CHUNK, num_src: Optional[int] = None) -> "DGNGraph":
+                 hub_chunk: int = HUB_CHUNK, num_src: Optional[int] = None, row_base: int = 0) -> "DGNGraph":
         """Adopt an existing destination-major CSR (no sort).  ``num_src``: number of source nodes of a bipartite
-        CSR (rows = e.g. the graphs of a batch, sources = its nodes); default: the same node set."""
+        CSR (rows = e.g. the graphs of a batch, sources = its nodes); default: the same node set.  ``row_base``:
+        global id of row 0 when the CSR is a destination-range shard of a larger graph (``dist.shard_rows``)."""
         self = cls.__new__(cls)
         n = indptr.numel() - 1
         deg = (indptr[1:] - indptr[:-1]).long()
         self._init_csr(indptr.long(), src_csr, eid, n, src_csr.numel(), deg, hub_threshold, hub_chunk, num_src)
+        self.row_base = int(row_base)
+        self._c.row_base = self.row_base
         self.ndata, self.edata = {}, {}
         if eig is not None:
             self.ndata["eig"] = eig
@@ -71,6 +74,7 @@ class DGNGraph:
         self.device = device
         self.num_nodes, self.num_edges = int(num_nodes), int(E)
         self.num_src = int(num_src) if num_src is not None else int(num_nodes)
+        self.row_base = 0
         self.indptr = indptr.to(torch.int32).contiguous()
         self.src = src_csr.to(torch.int32).contiguous()
         self.eid = eid  # None = identity (messages already in slot order)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 4
+#define DGN_ABI_VERSION 5
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -106,6 +106,10 @@ typedef struct DgnGraph {
      * nets/.../dgn_net.py:71-86) are this sweep over such a CSR.  x_src / g_src have n_src rows, csc_ptr
      * n_src + 1 entries; x_dst, x_in, log_deg, out are per destination row.                               */
     int64_t n_src;
+    /* Destination-range shard of a larger graph (one giant graph split across GPUs, dgn_amd/dist.py): row i of
+     * this CSR is node row_base + i of the source node set.  Only dgn_edge_weights uses it (the destination side of
+     * eig is read at row row_base + i); the per-row arrays of the sweep (x_dst, x_in, log_deg, out) are the shard's. */
+    int64_t row_base;
 } DgnGraph;
 
 typedef struct DgnChannel {

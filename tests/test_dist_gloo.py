@@ -173,3 +173,62 @@ def test_layer_algebra_matches_reference_on_cpu(golden):
             np.testing.assert_allclose(y.detach().numpy(), g[f"{name}/y"], rtol=2e-5, atol=2e-5, err_msg=name)
     finally:
         dl.directional_aggregate, dl.scale_combine, dl.bn_tail = saved
+
+
+# ---- one giant graph split by destination ranges ---------------------------------------
+
+def _sharded_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        from dgn_amd import dist as ddist
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_backend import oracle_directional_aggregate
+        import dgn_amd
+        ddist.init_from_env("gloo")
+        gen = torch.Generator().manual_seed(5)
+        N, F_ = 57, 6
+        deg = torch.randint(0, 9, (N,), generator=gen)
+        deg[7] = 60                                           # one long row: the cut must stay monotone around it
+        indptr = torch.zeros(N + 1, dtype=torch.long)
+        indptr[1:] = torch.cumsum(deg, 0)
+        src = torch.randint(0, N, (int(indptr[-1]),), generator=gen)
+        X, eig = torch.randn(N, F_, generator=gen), torch.randn(N, 3, generator=gen)
+        plan = dgn_amd.make_plan(["mean", "max", "dir1-dx", "dir2-av"], ["identity", "amplification"])
+        full = dgn_amd.DGNGraph.from_csr(indptr, src)
+        ref = oracle_directional_aggregate(full, plan, 1.1, x_src=X, x_in=X, eig=eig)
+        ranges = ddist.row_ranges_by_edges(indptr, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == N and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        r0, r1 = ranges[rank]
+        shard = ddist.shard_rows(indptr, src, r0, r1)
+        assert shard.num_nodes == r1 - r0 and shard.num_src == N and shard.row_base == r0
+        assert shard.num_edges == int(indptr[r1] - indptr[r0])
+        # rows of the shard through the oracle: same sources, the shard's destinations shifted back to global ids
+        # (the scalers read the degree per row, so the padding rows around the shard do not matter)
+        emb = torch.zeros(N + 1, dtype=torch.long)
+        emb[r0 + 1:r1 + 1] = shard.indptr.long()[1:]
+        emb[r1 + 1:] = emb[r1]
+        local = oracle_directional_aggregate(dgn_amd.DGNGraph.from_csr(emb, shard.src.long()), plan, 1.1, x_src=X, x_in=X, eig=eig)[r0:r1]
+        gathered = ddist.all_gather_rows(local, ranges)
+        ok = gathered.shape == ref.shape and torch.allclose(gathered, ref, rtol=1e-6, atol=1e-6)
+        q.put((rank, bool(ok), [tuple(r) for r in ranges]))
+        dist.destroy_process_group()
+    except Exception as exc:   # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_row_sharded_single_graph_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, ok, info in res:
+        assert ok, f"rank {rank}: {info}"
+    assert res[0][2] == res[1][2]

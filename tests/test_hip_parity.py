@@ -247,8 +247,8 @@ def test_backward_define_vs_accumulate_mode(F_, hub):
         assert torch.isfinite(a).all()
         _close(b - 1.5, a, 1e-5, 1e-5)
     again = run(False, 7.0)                          # and define mode does not depend on the previous content
-    for a, b in zip(fresh, again):
-        _close(b, a, 1e-6, 1e-6)
+    for a, b in zip(fresh, again):                   # (odd F: atomic scatter, the add order varies run to run)
+        _close(b, a, 1e-5, 1e-5)
 
 
 def test_three_term_message_vs_oracle():
