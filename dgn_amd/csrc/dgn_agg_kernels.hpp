@@ -1323,15 +1323,28 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     for (int q = 0; q < PER; ++q)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
-    for (int k = beg; k < end; ++k) {
-        const float* row = p.stage + (int64_t)k * p.F + f0;
+    // four staged rows are requested before the first add (row index clamped, adds predicated and in csc order):
+    // a load consumed right away would make every out-edge of the node a separate memory round trip
+    constexpr int KU = 4;
+    for (int k0 = beg; k0 < end; k0 += KU) {
+        float r[KU][PER][VEC];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            if (f0 + q * VEC < p.F) {
-                float r[VEC];
-                ldv<VEC>(r, row + q * VEC);
+        for (int j = 0; j < KU; ++j) {
+            const float* row = p.stage + (int64_t)min(k0 + j, end - 1) * p.F + f0;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[q][i] += r[i];
+            for (int q = 0; q < PER; ++q) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r[j][q][i] = 0.f;
+                if (f0 + q * VEC < p.F) ldv<VEC>(r[j][q], row + q * VEC);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KU; ++j) {
+            if (k0 + j < end) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[q][i] += r[j][q][i];
             }
         }
     }
