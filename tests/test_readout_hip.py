@@ -83,3 +83,51 @@ def test_readouts_random_batch_vs_oracle(F_):
         g_ref, = torch.autograd.grad(ref, [hc], ct)
         g_out, = torch.autograd.grad(out, [hd], ct.cuda())
         _close(g_out.cpu().numpy(), g_ref.numpy(), rtol=2e-5, atol=2e-5, msg=mode)
+
+
+class _DGLShaped:
+    """What the reference's nets hand to the layer: a batched DGLGraph 0.4.  Only the surface dgn_amd touches:
+    all_edges(order='eid'), number_of_nodes(), ndata (eig on the CPU, like the reference keeps it), batch_num_nodes."""
+
+    def __init__(self, src, dst, n, eig, sizes):
+        self._src, self._dst, self._n = src, dst, n
+        self.ndata = {"eig": eig}
+        self.edata = {}
+        self.batch_num_nodes = list(sizes)
+
+    def all_edges(self, order="eid"):
+        assert order == "eid"
+        return self._src, self._dst
+
+    def number_of_nodes(self):
+        return self._n
+
+
+def test_drop_in_flow_with_a_dgl_shaped_graph(golden):
+    """INTEGRATION.md route A end to end: the nets' call sequence (layer, g.ndata['h'] = h, readout) with a DGL-shaped
+    batch object and CPU-resident eig/edge lists, against the same layer fed a DGNGraph and against the fixtures."""
+    import dgn_amd
+    from oracle import readout_oracle as ro
+    g4, g8 = golden("g4_layers"), golden("g8_readouts")
+    name = "towers_c2"
+    dev = torch.device("cuda")
+    src, dst, N = torch.from_numpy(g4["src"]), torch.from_numpy(g4["dst"]), int(g4["N"])
+    eig = torch.from_numpy(g4[f"{name}/eig"])                              # stays on the CPU
+    sizes = [17, 23, N - 40]
+    batch = _DGLShaped(src, dst, N, eig, sizes)
+    from test_hip_parity import _build_layer_from_fixture
+    layer, train = _build_layer_from_fixture(g4, name, dev)
+    layer.train(train)
+    h = torch.from_numpy(g4[f"{name}/h"]).to(dev).requires_grad_(True)
+    e = torch.from_numpy(g4[f"{name}/e"]).to(dev)
+    snorm = torch.from_numpy(g4["snorm_n"]).to(dev)
+    y = layer(batch, h, e, snorm)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g4[f"{name}/y"], rtol=2e-5, atol=2e-5)
+    assert getattr(batch, "_dgn_graph", None) is not None                   # converted once, cached on the object
+    batch.ndata["h"] = y
+    hg = dgn_amd.readout(batch, "h", "directional")                        # ndata key, eig taken from the batch object
+    ref = ro.readout(y.detach().cpu(), sizes, "directional", eig)
+    np.testing.assert_allclose(hg.detach().cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    hg.sum().backward()
+    assert h.grad is not None and torch.isfinite(h.grad).all()
+    assert g8 is not None
