@@ -235,14 +235,18 @@ def run_layer_workload(args, wl, rank, world, dev):
     A, S, Ku, x, r = plan_model(plan)
     w = graph.edge_weights(plan)
     hd = h.detach()
+    Fk = F_          # width the kernels are launched with
     if wl["type_net"] == "simple":
+        if F_ % 2:   # the simple layer pads odd widths with one zero column (dgn_layer.py: DGNLayerSimple.forward)
+            hd = torch.nn.functional.pad(hd, (0, 1))
+            Fk = F_ + 1
         xs, xd = hd, None
     else:
         pq = torch.randn(N, 2 * F_, device=dev, generator=gen)
         xs, xd = pq[:, :F_], pq[:, F_:]
-    out = torch.empty(N, plan.out_width(F_), device=dev)
-    g_out = torch.randn(N, plan.out_width(F_), device=dev, generator=gen)
-    g_src, g_dst, g_in = torch.zeros(N, F_, device=dev), (torch.zeros(N, F_, device=dev) if xd is not None else None), torch.zeros(N, F_, device=dev)
+    out = torch.empty(N, plan.out_width(Fk), device=dev)
+    g_out = torch.randn(N, plan.out_width(Fk), device=dev, generator=gen)
+    g_src, g_dst, g_in = torch.zeros(N, Fk, device=dev), (torch.zeros(N, Fk, device=dev) if xd is not None else None), torch.zeros(N, Fk, device=dev)
     reps = 20
     ms_f = event_ms(lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out), reps, dev)
     ms_b = event_ms(lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in,

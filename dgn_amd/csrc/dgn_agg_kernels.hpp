@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     float gxin[VEC], rsum[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
-    if (deg <= kWave && (p.need & NEED_RECOMP)) {
+    if (deg <= kWave) {
         // Row in one slot batch (every row of a molecule / kNN graph): ONE batch load serves recompute and emit,
         // and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static lists),
         // gathers -- is issued before the first store; the separate passes re-loaded the batch after the
@@ -1175,6 +1175,13 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
         SlotBatch<C::NCH, C::NW> b;
         b.load(p, beg, end);
         const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+        const bool recomp = (p.need & NEED_RECOMP) != 0;
+        if constexpr (C::NCH > 0) {
+            if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(b.w[c]);       // (all lanes still here)
+            }
+        }
         if (!active) return;
         if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
         if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
@@ -1188,7 +1195,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
             }
         }
         const MsgSrc<VEC> src(p);
-        accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
+        if (recomp) accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
         if constexpr (PRE) {
             if (pre) {
                 make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int, float (&g)[VEC]) {

@@ -164,6 +164,14 @@ def _folded_weight(w_agg, w_h, S, id_slot):
     return torch.cat([w, hcols], dim=2).reshape(S * fo, K + w_h.shape[1])
 
 
+def _pad_blocks(weight, n_blocks, F0, Fp):
+    """[fo, n_blocks*F0] -> [fo, n_blocks*Fp]: a zero column after every F0-wide block (the padded feature)."""
+    if Fp == F0:
+        return weight
+    fo = weight.shape[0]
+    return F.pad(weight.reshape(fo, n_blocks, F0), (0, Fp - F0)).reshape(fo, n_blocks * Fp)
+
+
 def _posttrans_split(posttrans: MLP, h, agg, in_dim):
     """posttrans(cat([h, agg])) without building the concat when posttrans is one Linear."""
     if posttrans.is_single_affine():
@@ -196,18 +204,35 @@ class DGNLayerSimple(nn.Module):
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
-        if self.posttrans.is_single_affine() and self.plan.n_scalers > 1:
-            # scalers folded behind the Linear: sweep without scalers -> one GEMM -> scale-combine (+bias, +snorm)
+        F0 = h.shape[1]
+        # Odd widths (ZINC simple: 75, CIFAR10: 65) would run the sweep with 4-byte lanes, a second, nearly empty
+        # feature tile and the atomic scatter.  One zero column keeps the 8-byte-lane kernels: the aggregates of a zero
+        # column meet zero weights (the padded columns of W below), so the layer output is unchanged.
+        hp = F.pad(h, (0, 1)) if F0 % 2 else h
+        Fp = hp.shape[1]
+        if self.posttrans.is_single_affine():
             graph = as_dgn_graph(g)
             lin = self.posttrans.fully_connected[0].linear
-            S, fo = self.plan.n_scalers, lin.weight.shape[0]
-            agg = self.aggregate(graph, h, self._kplan)
-            w = lin.weight.reshape(fo, S, agg.shape[1]).permute(1, 0, 2).reshape(S * fo, agg.shape[1])
-            z = F.linear(agg, w)
-            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
-            h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
+            fo = lin.weight.shape[0]
+            A = len(self.aggregators)
+            if self.plan.n_scalers > 1:
+                # scalers folded behind the Linear: sweep without scalers -> one GEMM -> scale-combine (+bias, +snorm)
+                S = self.plan.n_scalers
+                agg = self.aggregate(graph, hp, self._kplan)                                  # [N, A*Fp]
+                w = _pad_blocks(lin.weight, S * A, F0, Fp).reshape(fo, S, A * Fp).permute(1, 0, 2).reshape(S * fo, A * Fp)
+                z = F.linear(agg, w)
+                sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+                h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
+            else:
+                agg = self.aggregate(graph, hp)                                               # [N, A*Fp] (single scaler: not applied)
+                h = F.linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
+                if self.graph_norm:
+                    h = h * snorm_n
         else:
-            h = self.posttrans(self.aggregate(g, h))
+            agg = self.aggregate(g, hp)
+            if Fp != F0:
+                agg = agg.view(agg.shape[0], -1, Fp)[:, :, :F0].reshape(agg.shape[0], -1)
+            h = self.posttrans(agg)
             if self.graph_norm:
                 h = h * snorm_n
         if self.batch_norm:

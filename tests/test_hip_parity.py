@@ -177,6 +177,47 @@ def test_layers_vs_reference(golden):
                 _close(v, g[f"{name}/after::{k}"], 1e-5, 1e-6, msg=f"{name} {k}")
 
 
+@pytest.mark.parametrize("case", [(7, 7, "mean max dir1-dx std", "identity amplification attenuation", 1),
+                                  (7, 5, "mean dir1-dx dir2-dx", "identity", 1),
+                                  (9, 9, "sum min dir1-av", "identity attenuation", 2)])
+def test_simple_layer_odd_width_vs_oracle(golden, case):
+    """odd hidden sizes (ZINC simple 75, CIFAR10 65) run the sweep on a zero-padded even width: values and every
+    gradient must equal the unpadded reference computation"""
+    dev = _dev()
+    import dgn_amd
+    from oracle import dgn_oracle as orc
+    din, dout, aggs, scalers, post = case
+    g = golden("g4_layers")
+    src, dst, N = T(g["src"]), T(g["dst"]), int(g["N"])
+    gen = torch.Generator().manual_seed(din * 10 + dout)
+    h, eig, snorm = torch.randn(N, din, generator=gen), torch.randn(N, 4, generator=gen), torch.rand(N, 1, generator=gen) + 0.5
+    torch.manual_seed(3)
+    layer = dgn_amd.DGNLayer(din, dout, 0.0, True, True, aggs, scalers, {"log": torch.tensor(1.1)}, "simple", True,
+                             posttrans_layers=post).model
+    with torch.no_grad():
+        for q in layer.parameters():
+            q.mul_(4.0).add_(0.05 * torch.randn(q.shape, generator=gen))
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k)
+          for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.1), graph_norm=True, batch_norm=True, residual=True,
+               towers=1, divide_input=True, edge_features=False)
+    ho = h.clone().requires_grad_(True)
+    yo, _ = orc.layer_forward("simple", sd, cfg, src, dst, N, eig, ho, None, snorm, training=True)
+    ct = torch.randn(yo.shape, generator=gen)
+    names = [k for k, v in sd.items() if v.requires_grad]
+    go = torch.autograd.grad(yo, [ho] + [sd[k] for k in names], ct)
+    layer = layer.to(dev).train(True)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, snorm.to(dev))
+    _close(y, yo, 2e-5, 2e-5)
+    params = dict(layer.named_parameters())
+    gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
+    for a, r, k in zip(gd, go, ["h"] + names):
+        scale = max(1.0, float(r.abs().max()))
+        _close(a, r, 1e-4, 2e-5 * scale, msg=k)
+
+
 def _random_graph(seed, N, E, zero_in=True):
     rng = np.random.default_rng(seed)
     dst = rng.integers(0, N - (1 if zero_in else 0), E)      # last node never a destination
