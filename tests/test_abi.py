@@ -110,3 +110,31 @@ def test_no_cpu_fallback():
     with pytest.raises((dgn_amd._lib.DgnError, RuntimeError, AssertionError)):
         g = dgn_amd.DGNGraph(src, src.flip(0), 2, eig=torch.randn(2, 2))
         directional_aggregate(g, dgn_amd.make_plan(["mean"], ["identity"]), 1.0, x_src=torch.randn(2, 4))
+
+
+def test_argument_validation_runs_before_any_device_work(lib):
+    """Maximum sizes and malformed arguments are rejected by the host-side checks with an error code and a message
+    (no kernel is launched, so this runs without a GPU): int32 CSR range, widths over the kernels' limits, nulls."""
+    from dgn_amd import _lib
+    err = lambda: lib.dgn_last_error().decode()
+    g = _lib.DgnGraph()
+    g.n_nodes, g.n_edges = 2 ** 31, 10                      # beyond the int32 CSR range
+    spec, msg = _lib.DgnAggSpec(), _lib.DgnMsg()
+    spec.n_agg, spec.n_scalers, spec.n_towers, spec.eps = 1, 1, 1, 1e-8
+    msg.F, msg.x_src, msg.ld_src = 4, 1, 4                  # (a non-null dummy pointer: never dereferenced)
+    rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), None, 0, None, None, 0, None, 0, None)
+    assert rc == -1 and "int32" in err()
+    g.n_nodes = 10
+    rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), None, 0, None, None, 0, None, 0, None)
+    assert rc == -1 and "null CSR" in err()
+    g.indptr = g.src = 1                                    # (dummies again)
+    spec.n_agg = 99                                         # more aggregators than one launch takes
+    rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), None, 0, None, None, 0, None, 0, None)
+    assert rc == -1 and "n_agg" in err()
+    assert lib.dgn_bn_tail_forward(5, 2000, None, 2000, None, None, None, None, 0.1, 1e-5, 1, 0, None, None, None, None, None, 0, None) == -1
+    assert "F <= 1024" in err()
+    assert lib.dgn_scale_combine_forward(5, 1, 3, 4, None, None, None, None, None, 0, None) == -1      # S = 3 without a scale table
+    assert lib.dgn_scale_combine_backward(5, 600, 1, 8, None, 0, None, None, None, None, None, 0, None) == -1
+    assert "4096" in err()
+    assert lib.dgn_bn_tail_workspace_bytes(0, 8) == 0 and lib.dgn_bn_tail_workspace_bytes(1000, 8) > 0
+    assert lib.dgn_scale_combine_backward_workspace_bytes(1000, 5, 14) > 0
