@@ -205,6 +205,36 @@ def run_layer_workload(args, wl, rank, world, dev):
         if reducer is not None:
             reducer()
 
+    if args.hipgraph:
+        # Launch-bound batches (the reference's batch of 128 molecules: ~80 launches around 0.4 ms of kernels): the whole
+        # step -- edge weights, forward, backward -- is captured ONCE into a HIP graph and replayed.  Only valid for
+        # a fixed batch shape (every kernel argument is frozen), so it is an option, not the headline mode.
+        if reducer is not None:
+            raise SystemExit("--hipgraph is a single-GPU mode (the gradient all-reduce is not captured)")
+        def bare_step():                   # (gradients stay None: the captured backward writes fresh ones per replay)
+            graph._wcache.clear()
+            layer(graph, h, None, snorm).backward(ct)
+
+        def reset():
+            h.grad = None
+            for p in params:
+                p.grad = None
+
+        def warm_step():
+            reset()
+            bare_step()
+
+        from dgn_amd.hipgraph import capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                warm_step()                 # warm-up off the capture: allocator pools, csc view, cached tables
+        torch.cuda.current_stream(dev).wait_stream(side)
+        reset()
+        hip_graph = capture(bare_step, warmup=0)
+        eager_step, step = step, hip_graph.replay
+
     for _ in range(args.warmup):
         step()
     if torch.distributed.is_initialized():
@@ -346,6 +376,8 @@ def main():
     ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="layer workloads, 1 GPU: capture the step (edge weights + forward + backward) in a HIP graph and replay it")
     ap.add_argument("--gemm-tuning", default="file", choices=["off", "file", "tune"],
                     help="PyTorch TunableOp for the dense pre/post-aggregation GEMMs (rocBLAS/hipBLASLt solution choice): "
                          "'file' replays dgn_amd/tunableop_gfx950.csv without tuning, 'tune' tunes and rewrites it")
@@ -381,7 +413,8 @@ def main():
                             aggregators=wl["aggregators"], scalers=wl["scalers"], towers=wl["towers"],
                             parallelism=result.get("parallelism") or (f"dp{world} (graphs sharded, flat-gradient all-reduce)"
                                                                       if world > 1 else "single GPU"),
-                            step="edge weights + layer forward + backward" if wl["type_net"] != "op" else "aggregation forward"),
+                            step=("edge weights + layer forward + backward" + (" (HIP graph replay)" if args.hipgraph else ""))
+                            if wl["type_net"] != "op" else "aggregation forward"),
                 roofline=result.get("roofline"))
     if world == 1 and not args.no_cpu_baseline and batch is not None:
         line["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])))
