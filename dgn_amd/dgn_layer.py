@@ -18,6 +18,8 @@ BatchNorm variants the fused tail does not cover) run the same kernels through t
 """
 from __future__ import annotations
 
+import math
+
 from typing import List, Sequence
 
 import torch
@@ -26,7 +28,7 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import bn_tail, directional_aggregate, scale_combine
+from .ops import bn_tail, bn_tail_fused, bn_tail_supported, directional_aggregate, scale_combine
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -366,63 +368,139 @@ class DGNLayerTower(nn.Module):
         t0 = self.towers[0]
         return t0.pretrans.is_single_affine() and t0.posttrans.is_single_affine()
 
+    # ---- fused operands -----------------------------------------------------------------------------------------
+    # The per-tower parameters keep the reference's state_dict layout.  The operands of the fused layer are
+    # re-arrangements of them (block diagonals, scaler-major permutations, zero blocks):
+    #   w_sd [2Fm, Fm]   P | Q weights, block diagonal with divide_input       bias_sd [2Fm]   0 | pretrans biases
+    #   w_edge [Fm, ed]  edge-feature part of the pretrans weights             b_p [T*fo]      posttrans biases
+    #   w [T, S*fo, K+fi] posttrans weights acting on [agg | h_in] (identity slot), or w_a [T, S*fo, K] and w_h [T, fo, fi]
+    def _param_list(self):
+        out = []
+        for t in self.towers:
+            pre, post = t.pretrans.fully_connected[0].linear, t.posttrans.fully_connected[0].linear
+            out += [pre.weight, pre.bias, post.weight, post.bias, t.batchnorm_h.weight, t.batchnorm_h.bias]
+        return out
+
+    def _linked_bn_stats(self, dev):
+        """(running_mean [T*fo], running_var [T*fo], num_batches_tracked [T]) as single tensors that the per-tower
+        BatchNorm modules VIEW: the tail kernels update the statistics of all towers in place, the state_dict keeps
+        the reference's per-tower keys, and nothing is concatenated or scattered per step.  Re-linked whenever the
+        modules' buffers were replaced (``.to()``, ``deepcopy``, ...)."""
+        bns = [t.batchnorm_h for t in self.towers]
+        fo = self.output_tower
+        link = self.__dict__.get("_bn_link")
+        if link is not None and link[0].device == dev and all(
+                b.running_mean.data_ptr() == link[0].data_ptr() + 4 * i * fo and b.running_var.data_ptr() == link[1].data_ptr() + 4 * i * fo
+                and b.num_batches_tracked.data_ptr() == link[2].data_ptr() + 8 * i for i, b in enumerate(bns)):
+            return link
+        with torch.no_grad():
+            rm = torch.cat([b.running_mean.reshape(-1) for b in bns]).to(dev)
+            rv = torch.cat([b.running_var.reshape(-1) for b in bns]).to(dev)
+            nbt = torch.stack([b.num_batches_tracked.reshape(()) for b in bns]).to(dev)
+            for i, b in enumerate(bns):
+                b.running_mean, b.running_var = rm[i * fo:(i + 1) * fo], rv[i * fo:(i + 1) * fo]
+                b.num_batches_tracked = nbt[i]
+        self.__dict__["_bn_link"] = (rm, rv, nbt)
+        return self.__dict__["_bn_link"]
+
+    def _assemble(self, plist):
+        """Operands from the parameter list with plain tensor ops (stack / indexed assignment / cat): the definition
+        of the layout.  Also run ONCE on tensors of element ids to derive the index map of the fast path."""
+        T, fi, fo = len(self.towers), self.input_tower, self.output_tower
+        w_pre, b_pre = torch.stack(plist[0::6]), torch.stack(plist[1::6])                      # [T, fi, 2fi(+ed)], [T, fi]
+        w_post, b_post = torch.stack(plist[2::6]), torch.stack(plist[3::6])                    # [T, fo, fi + S*K], [T, fo]
+        dev, dt = w_pre.device, w_pre.dtype
+        Fm = T * fi
+        ops = {}
+        if self.divide_input:
+            idx = torch.arange(T, device=dev)
+            bd = torch.zeros(2, T, fi, T, fi, dtype=dt, device=dev)                            # block diagonals of W_s, W_d
+            bd[:, idx, :, idx, :] = torch.stack([w_pre[:, :, :fi], w_pre[:, :, fi:2 * fi]], dim=1)
+            ops["w_sd"] = bd.view(2 * Fm, Fm)
+        else:
+            ops["w_sd"] = torch.cat([w_pre[:, :, :fi].reshape(Fm, fi), w_pre[:, :, fi:2 * fi].reshape(Fm, fi)], dim=0)
+        ops["bias_sd"] = torch.cat([torch.zeros(Fm, dtype=dt, device=dev), b_pre.reshape(Fm)])
+        if self.edge_features:
+            ops["w_edge"] = w_pre[:, :, 2 * fi:].reshape(Fm, -1)
+        ops["b_p"] = b_post.reshape(T * fo)
+        ops["bn_gamma"], ops["bn_beta"] = torch.cat(plist[4::6]), torch.cat(plist[5::6])       # the towers' BatchNorms, channel-concatenated
+        S = self.plan.n_scalers
+        K = (w_post.shape[2] - fi) // S
+        w_h = w_post[:, :, :fi]                                                                # [T, fo, fi]
+        w_a = w_post[:, :, fi:].reshape(T, fo, S, K).permute(0, 2, 1, 3)                       # [T, S, fo, K]
+        id_slot = _identity_slot(self.plan.applied_scalers)
+        if id_slot is not None:
+            hcols = torch.zeros(T, S, fo, fi, dtype=dt, device=dev)
+            hcols[:, id_slot] = w_h                                                            # h block: identity scaler only
+            ops["w"] = torch.cat([w_a, hcols], dim=3).reshape(T, S * fo, K + fi)
+        else:
+            ops["w_a"] = w_a.reshape(T, S * fo, K)
+            ops["w_h"] = w_h.contiguous()
+        return ops
+
+    def _operands(self, dev):
+        """The operands through ONE gather/scatter pair instead of ~15 small kernels (and as many backward nodes): all
+        parameters are concatenated into a flat vector and scattered into one zero-initialised buffer by a precomputed
+        index map; the operands are views of that buffer.  At batch 128 the layer is launch-bound: the assembly cost
+        as much as the sweep itself.  The map is derived by running _assemble on element ids, so the layout has a
+        single definition."""
+        plist = self._param_list()
+        key = (str(dev), tuple(tuple(p.shape) for p in plist))
+        cache = self.__dict__.setdefault("_opmap", {})
+        if key not in cache:
+            with torch.no_grad():
+                sizes = [p.numel() for p in plist]
+                ids = torch.arange(1, sum(sizes) + 1, dtype=torch.float64, device=dev).split(sizes)
+                id_ops = self._assemble([i.view(p.shape) for i, p in zip(ids, plist)])
+                names = list(id_ops)
+                flat_ids = torch.cat([id_ops[k].reshape(-1) for k in names])
+                pos = torch.nonzero(flat_ids).flatten()
+                sel = (flat_ids[pos] - 1).long()
+                cache[key] = (names, [tuple(id_ops[k].shape) for k in names], pos, sel, flat_ids.numel())
+        names, shapes, pos, sel, total = cache[key]
+        flat = torch.cat([p.reshape(-1) for p in plist])
+        fused = flat.new_zeros(total).index_put((pos,), flat.index_select(0, sel))
+        sizes = [math.prod(shp) for shp in shapes]
+        # (split, not slicing: its backward is ONE concatenation instead of a zero-fill + copy + add per operand)
+        return {k: part.view(shp) for k, part, shp in zip(names, fused.split(sizes), shapes)}
+
     def _fused_towers(self, g, h, e, snorm_n):
         """All towers in one sweep: towers are column blocks of the message."""
         graph = as_dgn_graph(g)
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
-        dev = h.device
-        # The per-tower parameters keep the reference's state_dict layout; they are assembled into the fused
-        # operands with a handful of batched tensor ops (stack / one indexed assignment / cat), not per-tower
-        # loops: at batch 128 the layer is launch-bound and every small op costs as much as the sweep itself.
-        w_pre = torch.stack([t.pretrans.fully_connected[0].linear.weight for t in self.towers])    # [T, fi, 2fi(+ed)]
-        b_pre = torch.stack([t.pretrans.fully_connected[0].linear.bias for t in self.towers])      # [T, fi]
-        Fm = T * fi
-        if self.divide_input:
-            idx = torch.arange(T, device=dev)
-            bd = torch.zeros(2, T, fi, T, fi, dtype=w_pre.dtype, device=dev)                      # block diagonals of W_s, W_d
-            bd[:, idx, :, idx, :] = torch.stack([w_pre[:, :, :fi], w_pre[:, :, fi:2 * fi]], dim=1)
-            w_sd = bd.view(2 * Fm, Fm)
-            x_in = h
-        else:
-            w_sd = torch.cat([w_pre[:, :, :fi].reshape(Fm, fi), w_pre[:, :, fi:2 * fi].reshape(Fm, fi)], dim=0)
-            x_in = h.repeat(1, T)                                                                  # every tower reads all of h
-        bias_sd = torch.cat([torch.zeros(Fm, dtype=b_pre.dtype, device=dev), b_pre.reshape(Fm)])
-        pq = F.linear(h, w_sd, bias_sd)                                                            # [N, 2*Fm]: P | Q
-        m_edge = None
-        if self.edge_features:
-            m_edge = F.linear(graph.to_slot_order(e), w_pre[:, :, 2 * fi:].reshape(Fm, -1))
-        w_post = torch.stack([t.posttrans.fully_connected[0].linear.weight for t in self.towers])  # [T, fo, fi + S*K]
-        b_p = torch.stack([t.posttrans.fully_connected[0].linear.bias for t in self.towers]).reshape(T * fo)
+        ops = self._operands(h.device)
+        x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)
+        pq = F.linear(h, ops["w_sd"], ops["bias_sd"])                                              # [N, 2*Fm]: P | Q
+        m_edge = F.linear(graph.to_slot_order(e), ops["w_edge"]) if self.edge_features else None
+        b_p = ops["b_p"]
         S = self.plan.n_scalers
         N = h.shape[0]
-        K = (w_post.shape[2] - fi) // S
-        w_h = w_post[:, :, :fi]                                                                    # [T, fo, fi]
-        w_a = w_post[:, :, fi:].reshape(T, fo, S, K).permute(0, 2, 1, 3)                           # [T, S, fo, K]
-        id_slot = _identity_slot(self.plan.applied_scalers)
         row_scale = snorm_n if self.graph_norm else None
-        if id_slot is not None:
+        if "w" in ops:
             # The sweep runs WITHOUT scalers (per-row factors, folded behind the GEMM) and WITH the h_in
             # pass-through block, tower-major: posttrans([h_t || agg_t]) of all towers is ONE batched GEMM on
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True)
-            hcols = torch.zeros(T, S, fo, fi, dtype=w_post.dtype, device=dev)
-            hcols[:, id_slot] = w_h                                                                # h block: identity scaler only
-            w = torch.cat([w_a, hcols], dim=3).reshape(T, S * fo, K + fi)
-            z = torch.bmm(aggx, w.transpose(1, 2))                                                 # [T, N, S*fo]
+            z = torch.bmm(aggx, ops["w"].transpose(1, 2))                                          # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,
                                         x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
-            z = torch.bmm(agg, w_a.reshape(T, S * fo, K).transpose(1, 2))                          # [T, N, S*fo]
+            z = torch.bmm(agg, ops["w_a"].transpose(1, 2))                                         # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             y = scale_combine(z, sc, b_p, None)
-            y = y + torch.bmm(x_in.view(N, T, fi).transpose(0, 1), w_h.transpose(1, 2)).transpose(0, 1).reshape(N, T * fo)
+            y = y + torch.bmm(x_in.view(N, T, fi).transpose(0, 1), ops["w_h"].transpose(1, 2)).transpose(0, 1).reshape(N, T * fo)
             if row_scale is not None:
                 y = y * row_scale
         if self.batch_norm:
-            y = bn_tail(y, [t.batchnorm_h for t in self.towers], self.training)
+            bns = [t.batchnorm_h for t in self.towers]
+            if bn_tail_supported(bns, y, self.training):
+                rm, rv, nbt = self._linked_bn_stats(y.device)
+                y = bn_tail_fused(y, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps, self.training)
+            else:
+                y = bn_tail(y, bns, self.training)
         return F.dropout(y, self.dropout, training=self.training)
 
     def forward(self, g, h, e, snorm_n):

@@ -338,6 +338,26 @@ class _BNTail(torch.autograd.Function):
         return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
 
 
+def bn_tail_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor,
+                  num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float, training: bool, relu: bool = False,
+                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The tail on ALREADY concatenated per-channel tensors (the towers layer keeps its BatchNorm parameters in the
+    fused operand buffer and its running statistics in one tensor the per-tower modules view): no cat before and no
+    scatter after the kernels.  Running statistics are updated in place."""
+    y = _BNTail.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, residual)
+    if training and num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
+    return y
+
+
+def bn_tail_supported(bns, x: torch.Tensor, training: bool) -> bool:
+    """What the fused tail kernels cover: affine BatchNorm with running statistics, F <= 1024, and -- with gradients -- training mode."""
+    simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
+    return simple and x.shape[1] <= 1024 and (training or not needs_grad)
+
+
 def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[relu](BatchNorm1d(x)) [+ residual]`` in one pass family (dgn_layer.py:123-128, :194-199, :272-273).
 

@@ -62,3 +62,14 @@ def oracle_bn_tail(x, bns, training, relu=False, residual=None):
     y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else bns[0](x)
     y = torch.relu(y) if relu else y
     return y + residual if residual is not None else y
+
+
+def oracle_bn_tail_fused(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu=False,
+                         residual=None):
+    """plain-torch restatement of dgn_amd.ops.bn_tail_fused (F.batch_norm on the concatenated channels)."""
+    y = torch.nn.functional.batch_norm(x, running_mean, running_var, gamma, beta, training, momentum, eps)
+    if training and num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
+    y = torch.relu(y) if relu else y
+    return y + residual if residual is not None else y
