@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -22,7 +22,8 @@ LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
            "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_backward",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
-           "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward")
+           "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
+           "dgn_bias_act_forward", "dgn_bias_act_backward")
 
 
 class DgnGraph(C.Structure):
@@ -114,6 +115,12 @@ def load() -> C.CDLL:
         lib.dgn_bn_tail_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                              C.c_void_p]
+        lib.dgn_bias_act_forward.restype = C.c_int
+        lib.dgn_bias_act_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        lib.dgn_bias_act_backward.restype = C.c_int
+        lib.dgn_bias_act_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         if lib.dgn_abi_version() != ABI_VERSION:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib

@@ -512,10 +512,9 @@ class DGNLayerTower(nn.Module):
                                for n, tower in enumerate(self.towers)], dim=1)
         else:
             h_cat = torch.cat([tower(g, h, e, snorm_n) for tower in self.towers], dim=1)
-        h_out = self.mixing_network(h_cat) if len(self.towers) > 1 else h_cat
-        if self.residual:
-            h_out = h_in + h_out
-        return h_out
+        if len(self.towers) > 1:
+            return self.mixing_network(h_cat, residual=h_in if self.residual else None)       # Linear -> LeakyReLU (+ h_in): one tail kernel
+        return h_in + h_cat if self.residual else h_cat
 
 
 class DGNLayer(nn.Module):

@@ -46,7 +46,30 @@ class FCLayer(nn.Module):
         if self.bias:
             self.linear.bias.data.zero_()
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (not in the reference's signature): added after the whole layer; with a plain Linear ->
+        (Leaky)ReLU layer on the GPU the bias, the activation and this add are one kernel (ops.bias_act)."""
+        act = self._fused_act()
+        if act is not None and (act[0] != "none" or residual is not None) and x.is_cuda and x.dim() == 2 and self.out_size <= 1024:
+            from .ops import bias_act
+            return bias_act(torch.nn.functional.linear(x, self.linear.weight), self.linear.bias, act[0], act[1], residual)
+        h = self._forward_modules(x)
+        return h if residual is None else residual + h
+
+    def _fused_act(self):
+        """(name, slope) if the layer is Linear -> none | ReLU | LeakyReLU with no dropout / batch norm, else None"""
+        if self.dropout is not None or self.b_norm is not None:
+            return None
+        a = self.activation
+        if a is None:
+            return ("none", 0.0)
+        if type(a) is nn.ReLU:
+            return ("relu", 0.0)
+        if type(a) is nn.LeakyReLU:
+            return ("leaky_relu", float(a.negative_slope))
+        return None
+
+    def _forward_modules(self, x):
         h = self.linear(x)
         if self.activation is not None:
             h = self.activation(h)

@@ -338,6 +338,54 @@ class _BNTail(torch.autograd.Function):
         return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
 
 
+_ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, act, slope, residual):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.DgnError("bias_act: CUDA tensors only (dgn_amd has no CPU path)")
+        x = x.contiguous()
+        N, F = x.shape
+        if residual is not None:
+            residual = residual.contiguous()
+        if bias is not None:
+            bias = bias.contiguous()
+        y = torch.empty_like(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.dgn_bias_act_forward(N, F, x.data_ptr(), x.stride(0), _ptr(bias), act, float(slope), _ptr(residual), y.data_ptr(), stream)
+        _lib.check(rc, "dgn_bias_act_forward")
+        ctx.save_for_backward(x, bias)
+        ctx.act, ctx.slope, ctx.has_res = act, float(slope), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        lib = _lib.load()
+        x, bias = ctx.saved_tensors
+        N, F = x.shape
+        g_y = g_y.contiguous()
+        g_x = torch.empty_like(x)
+        g_b = torch.empty(F, dtype=torch.float32, device=x.device) if (bias is not None and ctx.needs_input_grad[1]) else None
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.dgn_bias_act_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(bias), ctx.act, ctx.slope, g_x.data_ptr(),
+                                       _ptr(g_b), ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "dgn_bias_act_backward")
+        return g_x, g_b, None, None, (g_y if ctx.has_res else None)
+
+
+def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: str = "none", slope: float = 0.01,
+             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(x + bias) [+ residual]`` on the bias-free GEMM output ``x [N, F]`` in one pass (the tail of an FCLayer,
+    layers.py:101-112; the towers' mixing network with the layer's residual, dgn_layer.py:319-324); the backward
+    produces ``g_x`` and the bias gradient together.  ``act``: none | relu | leaky_relu.  F <= 1024."""
+    return _BiasAct.apply(x, bias, _ACT_CODES[act], slope, residual)
+
+
 def bn_tail_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor,
                   num_batches_tracked: Optional[torch.Tensor], momentum: float, eps: float, training: bool, relu: bool = False,
                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:

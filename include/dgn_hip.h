@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 5
+#define DGN_ABI_VERSION 6
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -235,6 +235,17 @@ int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, c
 int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
                          float* g_gamma, float* g_beta, void* ws, size_t ws_bytes, void* stream);
+
+/* Tail of an FCLayer (Linear -> activation, nets/layers.py:101-112) on the bias-free GEMM output x [N, F]:
+ *     y = act(x + bias) [+ residual]        act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
+ * -- the towers' mixing network (LeakyReLU) with the layer's residual add (dgn_layer.py:319-324) in one pass.  Backward:
+ * g_x = g_y * act'(x + bias) (written) and g_bias = sum_n g_x[n, :] (written; NULL = not wanted; fp64 per-workgroup
+ * partials in `ws` of dgn_bn_tail_workspace_bytes(n_rows, F) bytes, fixed-order sum); the residual's gradient is g_y.
+ * All [N, F] tensors share the row stride ld; F <= 1024 for the backward.                                           */
+int dgn_bias_act_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* bias, int32_t act, float slope,
+                         const float* residual, float* y, void* stream);
+int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* bias,
+                          int32_t act, float slope, float* g_x, float* g_bias, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -391,6 +391,29 @@ def test_scale_combine_and_x_in_block_vs_torch():
         _close(a, b_, 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("act", ["none", "relu", "leaky_relu"])
+@pytest.mark.parametrize("shape", [(1000, 70), (37, 300), (5, 1), (0, 8)])
+def test_bias_act_vs_torch(act, shape):
+    """bias + activation (+ residual) tail of an FCLayer: values and gradients (incl. the fused bias gradient)"""
+    dev = _dev()
+    from dgn_amd.ops import bias_act
+    N, F_ = shape
+    gen = torch.Generator().manual_seed(N + F_)
+    x, b, res, ct = (torch.randn(N, F_, generator=gen), torch.randn(F_, generator=gen), torch.randn(N, F_, generator=gen),
+                     torch.randn(N, F_, generator=gen))
+    fn = {"none": lambda v: v, "relu": torch.relu, "leaky_relu": lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[act]
+    for use_res in (False, True):
+        ld = [t.clone().to(dev).requires_grad_(True) for t in (x, b, res)]
+        lc = [t.clone().double().requires_grad_(True) for t in (x, b, res)]
+        y = bias_act(ld[0], ld[1], act, 0.01, ld[2] if use_res else None)
+        yc = fn(lc[0] + lc[1]) + (lc[2] if use_res else 0)
+        _close(y, yc.float(), 1e-6, 1e-6)
+        gd = torch.autograd.grad(y, ld[:3] if use_res else ld[:2], ct.to(dev), allow_unused=True)
+        gc = torch.autograd.grad(yc, lc[:3] if use_res else lc[:2], ct.double(), allow_unused=True)
+        for a, r in zip(gd, gc):
+            _close(a, r.float(), 1e-5, 1e-5 * max(1.0, float(r.abs().max()) if r.numel() else 1.0))
+
+
 def test_bn_tail_vs_torch_batchnorm():
     """Fused layer tail ([relu](BatchNorm1d(x)) [+ residual]) against nn.BatchNorm1d: outputs, all gradients,
     running statistics and num_batches_tracked, one module and five per-tower modules, train and eval."""
