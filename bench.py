@@ -128,6 +128,23 @@ def event_ms(fn, reps, dev):
     return a.elapsed_time(b) / reps
 
 
+def event_percentiles(fn, dev, warm=20, reps=100):
+    """SURVEY 8(d) timing protocol: 20 warm-up calls, then `reps` calls each bracketed by its own HIP event pair;
+    (p10, median, p90) in ms.  (Single-call brackets include the inter-launch gap, so they sit slightly above the
+    back-to-back average of event_ms for sub-50 us calls.)"""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize(dev)
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize(dev)
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return dict(p10=t[reps // 10], p50=t[reps // 2], p90=t[(reps * 9) // 10])
+
+
 def build_batch(wl, seed, dev):
     kind, kw = wl["gen"]
     if kind == "molecules":
@@ -283,8 +300,12 @@ def run_layer_workload(args, wl, rank, world, dev):
                                             accumulate=False), reps, dev)
     ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
-    kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK),
-               "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK),
+    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out)
+    bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in, accumulate=False)
+    kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK,
+                                    ms_percentiles=event_percentiles(fwd_call, dev)),
+               "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK,
+                                    ms_percentiles=event_percentiles(bwd_call, dev)),
                "ew_rows": dict(ms=ms_w)}
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
