@@ -132,12 +132,27 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
                 b_t[c] = b;
             }
         }
-        for (int t = 0; t < T; ++t) {
-            float* dst = gz + ((int64_t)t * n_nodes + r0) * zw;
-            Cursor k((int)threadIdx.x, zw);
-            for (int i = threadIdx.x; i < rows * zw; i += kThreads, k.next()) {
-                const int q = k.c / fo, o = k.c - q * fo;
-                dst[i] = g_t[k.r * wy + t * fo + o] * s_t[k.r * S + q];
+        if ((fo & 1) == 0) {
+            // even f_out: pairs (8-byte lanes; a pair never straddles a scaler block, and every offset below is even)
+            const int zw2 = zw >> 1;
+            for (int t = 0; t < T; ++t) {
+                float2* dst = reinterpret_cast<float2*>(gz + ((int64_t)t * n_nodes + r0) * zw);
+                Cursor k((int)threadIdx.x, zw2);
+                for (int i = threadIdx.x; i < rows * zw2; i += kThreads, k.next()) {
+                    const int c = 2 * k.c, q = c / fo, o = c - q * fo;
+                    const float2 g = *reinterpret_cast<const float2*>(g_t + k.r * wy + t * fo + o);
+                    const float sc = s_t[k.r * S + q];
+                    dst[i] = make_float2(g.x * sc, g.y * sc);
+                }
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                float* dst = gz + ((int64_t)t * n_nodes + r0) * zw;
+                Cursor k((int)threadIdx.x, zw);
+                for (int i = threadIdx.x; i < rows * zw; i += kThreads, k.next()) {
+                    const int q = k.c / fo, o = k.c - q * fo;
+                    dst[i] = g_t[k.r * wy + t * fo + o] * s_t[k.r * S + q];
+                }
             }
         }
     }
