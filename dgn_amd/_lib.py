@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -55,6 +55,11 @@ class DgnMsgGrad(C.Structure):
     _fields_ = [("g_src", C.c_void_p), ("ld_src", C.c_int64), ("g_dst", C.c_void_p), ("ld_dst", C.c_int64),
                 ("g_edge", C.c_void_p), ("ld_edge", C.c_int64), ("g_in", C.c_void_p), ("ld_in", C.c_int64),
                 ("accumulate", C.c_int32)]
+
+
+class DgnBnGrad(C.Structure):
+    _fields_ = [("g_out", C.c_void_p), ("y", C.c_void_p), ("ld", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("relu", C.c_int32)]
 
 
 class DgnError(RuntimeError):
@@ -102,7 +107,8 @@ def load() -> C.CDLL:
                                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dgn_scale_combine_backward.restype = C.c_int
         lib.dgn_scale_combine_backward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DgnBnGrad),
+                                                   C.c_void_p]
         lib.dgn_scale_combine_backward_workspace_bytes.restype = C.c_size_t
         lib.dgn_scale_combine_backward_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_bn_tail_workspace_bytes.restype = C.c_size_t
@@ -113,8 +119,8 @@ def load() -> C.CDLL:
                                             C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_bn_tail_backward.restype = C.c_int
         lib.dgn_bn_tail_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                             C.c_void_p]
+                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]
         lib.dgn_bias_act_forward.restype = C.c_int
         lib.dgn_bias_act_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p]

@@ -270,19 +270,20 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
 
 extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
-                                    float* g_gamma, float* g_beta, void* ws, size_t ws_bytes, void* stream_) {
+                                    float* g_gamma, float* g_beta, float* sums_out, void* ws, size_t ws_bytes, void* stream_) {
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F) { set_error("dgn_bn_tail_backward: bad shape (need 1 <= F <= 1024, ld >= F)"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
-    if (!g_y || !x || !g_x || !save_mean || !save_invstd || !ws) { set_error("dgn_bn_tail_backward: null buffer"); return DGN_ERR_INVALID; }
+    if (!g_y || !x || (!g_x && !sums_out) || !save_mean || !save_invstd || !ws) { set_error("dgn_bn_tail_backward: null buffer"); return DGN_ERR_INVALID; }
     if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bn_tail_backward: workspace too small"); return DGN_ERR_WORKSPACE; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     double* part = static_cast<double*>(ws);
-    float* sums = reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
+    float* sums = sums_out ? sums_out : reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
     hipLaunchKernelGGL(bn_bwd_stats, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
-    hipLaunchKernelGGL(bn_bwd_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean,
-                       save_invstd, relu, (const float*)sums, g_x);
+    if (g_x)
+        hipLaunchKernelGGL(bn_bwd_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean,
+                           save_invstd, relu, (const float*)sums, g_x);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

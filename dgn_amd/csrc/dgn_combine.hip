@@ -102,13 +102,26 @@ int bwd_slab_rows(int wy) { return std::max(1, std::min(32, kTileFloats / wy)); 
 __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int rows_per_block, int T, int S, int fo,
                                                         const float* __restrict__ gy, int64_t ld_gy,
                                                         const float* __restrict__ scale, const float* __restrict__ row_scale,
-                                                        float* __restrict__ gz, float* __restrict__ bias_part) {
+                                                        float* __restrict__ gz, float* __restrict__ bias_part, const DgnBnGrad bn,
+                                                        int has_bn) {
     extern __shared__ float lds[];
     const int zw = S * fo, wy = T * fo, G = (int)gridDim.x;
     float* g_t = lds;                                // [rows][wy]   row_scale * g_y
     float* s_t = g_t + (size_t)rows_per_block * wy;  // [rows][S]
     float* b_t = s_t + (size_t)rows_per_block * S;   // [wy]         bias-gradient partial of this workgroup
-    for (int c = threadIdx.x; c < wy; c += kThreads) b_t[c] = 0.f;
+    float* c_t = b_t + wy;                           // [6][wy]      BatchNorm-backward column constants (fused form)
+    for (int c = threadIdx.x; c < wy; c += kThreads) {
+        b_t[c] = 0.f;
+        if (has_bn) {
+            const float inv_n = 1.f / (float)n_nodes;
+            c_t[c] = bn.mean[c];
+            c_t[wy + c] = bn.invstd[c];
+            c_t[2 * wy + c] = bn.gamma ? bn.gamma[c] : 1.f;
+            c_t[3 * wy + c] = bn.beta ? bn.beta[c] : 0.f;
+            c_t[4 * wy + c] = bn.sums[c] * inv_n;
+            c_t[5 * wy + c] = bn.sums[wy + c] * inv_n;
+        }
+    }
     const int64_t n_slabs = (n_nodes + rows_per_block - 1) / rows_per_block;
     for (int64_t slab = blockIdx.x; slab < n_slabs; slab += G) {
         const int64_t r0 = slab * rows_per_block;
@@ -118,7 +131,17 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
             Cursor k((int)threadIdx.x, wy);
 #pragma unroll 4
             for (int i = threadIdx.x; i < rows * wy; i += kThreads, k.next()) {
-                float g = gy[(r0 + k.r) * ld_gy + k.c];
+                float g;
+                if (has_bn) {       // g_y of the combine = BatchNorm backward of the tail's gradient, formed here
+                    const int c = k.c;
+                    const float is = c_t[wy + c], ga = c_t[2 * wy + c];
+                    const float xh = (bn.y[(r0 + k.r) * bn.ld + c] - c_t[c]) * is;
+                    g = bn.g_out[(r0 + k.r) * bn.ld + c];
+                    if (bn.relu && !(xh * ga + c_t[3 * wy + c] > 0.f)) g = 0.f;
+                    g = ga * is * (g - c_t[4 * wy + c] - xh * c_t[5 * wy + c]);
+                } else {
+                    g = gy[(r0 + k.r) * ld_gy + k.c];
+                }
                 if (row_scale) g *= row_scale[r0 + k.r];
                 g_t[i] = g;
             }
@@ -211,19 +234,31 @@ extern "C" size_t dgn_scale_combine_backward_workspace_bytes(int64_t n_nodes, in
 
 extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy,
                                           const float* scale, const float* row_scale, float* g_z, float* g_bias, void* ws,
-                                          size_t ws_bytes, void* stream) {
+                                          size_t ws_bytes, const DgnBnGrad* bn, void* stream) {
     if (int rc = check_shape("dgn_scale_combine_backward", n_nodes, T, S, fo, scale != nullptr)) return rc;
     if (n_nodes == 0) return DGN_OK;
-    if (!g_y || !g_z || ld_gy < (int64_t)T * fo) { set_error("dgn_scale_combine_backward: null buffer or ld_gy too small"); return DGN_ERR_INVALID; }
+    const int wy = T * fo;
+    if (bn) {
+        if (!bn->g_out || !bn->y || !bn->mean || !bn->invstd || !bn->sums || bn->ld < wy || wy > 1024) {
+            set_error("dgn_scale_combine_backward: incomplete DgnBnGrad (or n_towers * f_out > 1024)");
+            return DGN_ERR_INVALID;
+        }
+    } else if (!g_y || ld_gy < wy) {
+        set_error("dgn_scale_combine_backward: null g_y or ld_gy too small");
+        return DGN_ERR_INVALID;
+    }
+    if (!g_z) { set_error("dgn_scale_combine_backward: null g_z"); return DGN_ERR_INVALID; }
     if (g_bias && (!ws || ws_bytes < dgn_scale_combine_backward_workspace_bytes(n_nodes, T, fo))) {
         set_error("dgn_scale_combine_backward: workspace too small (the bias gradient needs dgn_scale_combine_backward_workspace_bytes())");
         return DGN_ERR_WORKSPACE;
     }
-    const int wy = T * fo, rows = bwd_slab_rows(wy), G = bwd_groups(n_nodes, rows);
-    const size_t lds = ((size_t)rows * wy + (size_t)rows * S + wy) * sizeof(float);
+    const int rows = bwd_slab_rows(wy), G = bwd_groups(n_nodes, rows);
+    const size_t lds = ((size_t)rows * wy + (size_t)rows * S + wy + (bn ? 6 * (size_t)wy : 0)) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = g_bias ? static_cast<float*>(ws) : nullptr;
-    hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part);
+    const DgnBnGrad none{};
+    hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part,
+                       bn ? *bn : none, bn ? 1 : 0);
     if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3(wy), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import bn_tail, bn_tail_fused, bn_tail_supported, directional_aggregate, scale_combine
+from .ops import bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, scale_combine
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -166,6 +166,21 @@ def _folded_weight(w_agg, w_h, S, id_slot):
     return torch.cat([w, hcols], dim=2).reshape(S * fo, K + w_h.shape[1])
 
 
+def _combine_and_tail(layer, z, sc, bias, snorm_n, h_in):
+    """scale_combine -> (BatchNorm -> ReLU -> residual) of the simple / complex layers; one autograd node in training."""
+    row_scale = snorm_n if layer.graph_norm else None
+    res = h_in if layer.residual else None
+    bn = layer.batchnorm_h
+    if layer.batch_norm and layer.training and z.shape[2] // (sc.shape[1] if sc is not None else 1) <= 1024 and bn_tail_supported([bn], z, True):
+        return combine_bn_tail(z, sc, bias, row_scale, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                               bn.momentum, bn.eps, relu=True, residual=res)
+    h = scale_combine(z, sc, bias, row_scale)
+    if layer.batch_norm:
+        return bn_tail(h, bn, layer.training, relu=True, residual=res)
+    h = F.relu(h)
+    return h_in + h if layer.residual else h
+
+
 def _pad_blocks(weight, n_blocks, F0, Fp):
     """[fo, n_blocks*F0] -> [fo, n_blocks*Fp]: a zero column after every F0-wide block (the padded feature)."""
     if Fp == F0:
@@ -224,7 +239,8 @@ class DGNLayerSimple(nn.Module):
                 w = _pad_blocks(lin.weight, S * A, F0, Fp).reshape(fo, S, A * Fp).permute(1, 0, 2).reshape(S * fo, A * Fp)
                 z = F.linear(agg, w)
                 sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
-                h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
+                h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)      # (+snorm, BatchNorm, ReLU, residual)
+                return F.dropout(h, self.dropout, training=self.training)
             else:
                 agg = self.aggregate(graph, hp)                                               # [N, A*Fp] (single scaler: not applied)
                 h = F.linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
@@ -287,7 +303,8 @@ class DGNLayerComplex(nn.Module):
             w = _folded_weight(lin.weight[:, self.in_dim:], lin.weight[:, :self.in_dim], S, id_slot)
             z = F.linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
-            h = scale_combine(z.unsqueeze(0), sc, lin.bias, snorm_n if self.graph_norm else None)
+            h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)          # (+snorm, BatchNorm, ReLU, residual)
+            return F.dropout(h, self.dropout, training=self.training)
         else:
             h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
             if self.graph_norm:
@@ -484,6 +501,11 @@ class DGNLayerTower(nn.Module):
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True)
             z = torch.bmm(aggx, ops["w"].transpose(1, 2))                                          # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+            bns = [t.batchnorm_h for t in self.towers]
+            if self.batch_norm and self.training and T * fo <= 1024 and bn_tail_supported(bns, z, True):
+                rm, rv, nbt = self._linked_bn_stats(z.device)                                      # combine + BatchNorm: one autograd node
+                y = combine_bn_tail(z, sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps)
+                return F.dropout(y, self.dropout, training=self.training)
             y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,

@@ -274,7 +274,7 @@ class _ScaleCombine(torch.autograd.Function):
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=g_y.device) if ws_bytes else None
         stream = torch.cuda.current_stream(g_y.device).cuda_stream
         rc = lib.dgn_scale_combine_backward(N, T, S, fo, g_y.data_ptr(), g_y.stride(0), _ptr(scale), _ptr(row_scale),
-                                            g_z.data_ptr(), _ptr(g_b), _ptr(ws), ws_bytes, stream)
+                                            g_z.data_ptr(), _ptr(g_b), _ptr(ws), ws_bytes, None, stream)
         _lib.check(rc, "dgn_scale_combine_backward")
         return g_z, None, g_b, None
 
@@ -333,9 +333,91 @@ class _BNTail(torch.autograd.Function):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         rc = lib.dgn_bn_tail_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if ctx.relu else 0, g_x.data_ptr(), _ptr(g_gamma), _ptr(g_beta),
-                                      ws.data_ptr(), ws_bytes, stream)
+                                      None, ws.data_ptr(), ws_bytes, stream)
         _lib.check(rc, "dgn_bn_tail_backward")
         return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
+
+
+class _CombineBNTail(torch.autograd.Function):
+    """scale_combine followed by the training-mode BatchNorm tail as ONE autograd node: the backward forms the
+    combine's upstream gradient from the tail's inputs on the fly (DgnBnGrad), so the [N, F] gradient between the two
+    steps is never written or re-read."""
+
+    @staticmethod
+    def forward(ctx, z, scale, bias, row_scale, gamma, beta, running_mean, running_var, momentum, eps, relu, residual):
+        lib = _lib.load()
+        if not z.is_cuda:
+            raise _lib.DgnError("combine_bn_tail: CUDA tensors only (dgn_amd has no CPU path)")
+        T, N, W = z.shape
+        S = 1 if scale is None else scale.shape[1]
+        fo = W // S
+        F = T * fo
+        z = z.contiguous()
+        dev = z.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        y = torch.empty((N, F), dtype=torch.float32, device=dev)
+        rc = lib.dgn_scale_combine_forward(N, T, S, fo, z.data_ptr(), _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
+        _lib.check(rc, "dgn_scale_combine_forward")
+        if residual is not None:
+            residual = residual.contiguous()
+        out = torch.empty_like(y)
+        save_mean = torch.empty(F, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(F, dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        rc = lib.dgn_bn_tail_forward(N, F, y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     float(momentum), float(eps), 1, 1 if relu else 0, _ptr(residual), out.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "dgn_bn_tail_forward")
+        ctx.save_for_backward(scale, row_scale, y, gamma, beta, save_mean, save_invstd)
+        ctx.dims = (T, N, S, fo, bias is not None, relu, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        scale, row_scale, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        T, N, S, fo, has_bias, relu, has_res = ctx.dims
+        F = T * fo
+        dev = y.device
+        g_out = g_out.contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        g_gamma = torch.empty(F, dtype=torch.float32, device=dev) if gamma is not None else None
+        g_beta = torch.empty(F, dtype=torch.float32, device=dev) if beta is not None else None
+        sums = torch.empty(2 * F, dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        rc = lib.dgn_bn_tail_backward(N, F, g_out.data_ptr(), y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 1 if relu else 0, None, _ptr(g_gamma), _ptr(g_beta), sums.data_ptr(),
+                                      ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "dgn_bn_tail_backward")
+        bn = _lib.DgnBnGrad(g_out=g_out.data_ptr(), y=y.data_ptr(), ld=y.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
+                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0)
+        g_z = torch.empty((T, N, S * fo), dtype=torch.float32, device=dev)
+        g_b = torch.zeros(F, dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[2]) else None
+        ws2_bytes = lib.dgn_scale_combine_backward_workspace_bytes(N, T, fo) if g_b is not None else 0
+        ws2 = torch.empty(ws2_bytes // 4, dtype=torch.float32, device=dev) if ws2_bytes else None
+        rc = lib.dgn_scale_combine_backward(N, T, S, fo, None, 0, _ptr(scale), _ptr(row_scale), g_z.data_ptr(), _ptr(g_b), _ptr(ws2),
+                                            ws2_bytes, C.byref(bn), stream)
+        _lib.check(rc, "dgn_scale_combine_backward")
+        return g_z, None, g_b, None, g_gamma, g_beta, None, None, None, None, None, (g_out if has_res else None)
+
+
+def combine_bn_tail(z, scale, bias, row_scale, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                    relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[relu](BatchNorm(scale_combine(z, scale, bias, row_scale))) [+ residual]`` in TRAINING mode as one autograd node
+    (see _CombineBNTail); running statistics are updated in place.  Needs n_towers * f_out <= 1024."""
+    if scale is not None:
+        scale = scale.contiguous()
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).contiguous()
+    if bias is not None:
+        bias = bias.reshape(-1).contiguous()
+    out = _CombineBNTail.apply(z, scale, bias, row_scale, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+    if num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
+    return out
 
 
 _ACT_CODES = {"none": 0, "relu": 1, "leaky_relu": 2}

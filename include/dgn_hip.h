@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 6
+#define DGN_ABI_VERSION 7
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -214,9 +214,25 @@ int dgn_scale_combine_forward(int64_t n_nodes, int32_t n_towers, int32_t n_scale
                               const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
                               void* stream);
 size_t dgn_scale_combine_backward_workspace_bytes(int64_t n_nodes, int32_t n_towers, int32_t f_out);
+/* Optional fusion with the BatchNorm tail that follows the combine (dgn_bn_tail_*): when `bn` is given, g_y is not
+ * read; the upstream gradient of the combine is formed on the fly from the tail's inputs,
+ *     g_y = gamma * invstd * (g' - sums[c]/N - xhat * sums[F+c]/N),   g' = g_out masked by the ReLU,  xhat = (y - mean) * invstd
+ * with sums / g_gamma / g_beta from dgn_bn_tail_backward(..., g_x = NULL, sums): the [N, F] gradient between the two
+ * steps is never written or re-read.                                                                        */
+typedef struct DgnBnGrad {
+    const float* g_out;    /* [N, ld] gradient of the tail's output                                          */
+    const float* y;        /* [N, ld] the combine's output = the tail's input                                */
+    int64_t ld;
+    const float* gamma;    /* [F] or NULL                                                                    */
+    const float* beta;     /* [F] or NULL                                                                    */
+    const float* mean;     /* [F] save_mean of the forward                                                   */
+    const float* invstd;   /* [F] save_invstd                                                                */
+    const float* sums;     /* [2F] from dgn_bn_tail_backward                                                 */
+    int32_t relu;
+} DgnBnGrad;
 int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* g_y,
                                int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, float* g_bias,
-                               void* ws, size_t ws_bytes, void* stream);
+                               void* ws, size_t ws_bytes, const DgnBnGrad* bn, void* stream);
 
 /* Layer tail: BatchNorm1d over the node dimension, optionally followed by ReLU and the residual add
  *     y = [relu]( (x - mean) * invstd * gamma + beta ) [+ residual]          (dgn_layer.py:123-128, :194-199, :272-273)
@@ -231,10 +247,11 @@ int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, c
                         int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
                         size_t ws_bytes, void* stream);
 /* Backward of the training-mode tail: g_x [N, F] (written), g_gamma / g_beta [F] (written; may be NULL).
- * The gradient of `residual` is g_y itself (left to the caller).                                           */
+ * The gradient of `residual` is g_y itself (left to the caller).  g_x == NULL skips the apply pass: only the column
+ * sums are produced (`sums` [2F], may be NULL when g_x is given) for dgn_scale_combine_backward's fused form.  */
 int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
-                         float* g_gamma, float* g_beta, void* ws, size_t ws_bytes, void* stream);
+                         float* g_gamma, float* g_beta, float* sums, void* ws, size_t ws_bytes, void* stream);
 
 /* Tail of an FCLayer (Linear -> activation, nets/layers.py:101-112) on the bias-free GEMM output x [N, F]:
  *     y = act(x + bias) [+ residual]        act: 0 none, 1 ReLU, 2 LeakyReLU(slope)

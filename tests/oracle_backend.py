@@ -73,3 +73,10 @@ def oracle_bn_tail_fused(x, gamma, beta, running_mean, running_var, num_batches_
             num_batches_tracked.add_(1)
     y = torch.relu(y) if relu else y
     return y + residual if residual is not None else y
+
+
+def oracle_combine_bn_tail(z, scale, bias, row_scale, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                           relu=False, residual=None):
+    """plain-torch restatement of dgn_amd.ops.combine_bn_tail (training mode)."""
+    y = oracle_scale_combine(z, scale, bias, row_scale)
+    return oracle_bn_tail_fused(y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, True, relu, residual)

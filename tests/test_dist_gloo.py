@@ -70,11 +70,13 @@ def _build_layer():
 def _install_oracle_backend():
     import dgn_amd.dgn_layer as dl
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_backend import oracle_bn_tail, oracle_bn_tail_fused, oracle_directional_aggregate, oracle_scale_combine
+    from oracle_backend import (oracle_bn_tail, oracle_bn_tail_fused, oracle_combine_bn_tail, oracle_directional_aggregate,
+                                oracle_scale_combine)
     dl.directional_aggregate = oracle_directional_aggregate
     dl.scale_combine = oracle_scale_combine
     dl.bn_tail = oracle_bn_tail
     dl.bn_tail_fused = oracle_bn_tail_fused
+    dl.combine_bn_tail = oracle_combine_bn_tail
 
 
 def _loss_backward(layer, g, h, snorm):
