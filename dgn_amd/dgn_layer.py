@@ -171,7 +171,8 @@ def _combine_and_tail(layer, z, sc, bias, snorm_n, h_in):
     row_scale = snorm_n if layer.graph_norm else None
     res = h_in if layer.residual else None
     bn = layer.batchnorm_h
-    if layer.batch_norm and layer.training and z.shape[2] // (sc.shape[1] if sc is not None else 1) <= 1024 and bn_tail_supported([bn], z, True):
+    width = z.shape[0] * (z.shape[2] // (sc.shape[1] if sc is not None else 1))
+    if layer.batch_norm and layer.training and bn_tail_supported([bn], z, True, width):
         return combine_bn_tail(z, sc, bias, row_scale, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                bn.momentum, bn.eps, relu=True, residual=res)
     h = scale_combine(z, sc, bias, row_scale)
@@ -502,7 +503,7 @@ class DGNLayerTower(nn.Module):
             z = torch.bmm(aggx, ops["w"].transpose(1, 2))                                          # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             bns = [t.batchnorm_h for t in self.towers]
-            if self.batch_norm and self.training and T * fo <= 1024 and bn_tail_supported(bns, z, True):
+            if self.batch_norm and self.training and bn_tail_supported(bns, z, True, T * fo):
                 rm, rv, nbt = self._linked_bn_stats(z.device)                                      # combine + BatchNorm: one autograd node
                 y = combine_bn_tail(z, sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps)
                 return F.dropout(y, self.dropout, training=self.training)

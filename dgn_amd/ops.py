@@ -481,11 +481,12 @@ def bn_tail_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, runn
     return y
 
 
-def bn_tail_supported(bns, x: torch.Tensor, training: bool) -> bool:
-    """What the fused tail kernels cover: affine BatchNorm with running statistics, F <= 1024, and -- with gradients -- training mode."""
+def bn_tail_supported(bns, x: torch.Tensor, training: bool, width: Optional[int] = None) -> bool:
+    """What the fused tail kernels cover: affine BatchNorm with running statistics, F <= 1024 (``width``, default
+    ``x.shape[1]``), and -- with gradients -- training mode."""
     simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
-    return simple and x.shape[1] <= 1024 and (training or not needs_grad)
+    return simple and (x.shape[1] if width is None else width) <= 1024 and (training or not needs_grad)
 
 
 def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -19,10 +19,12 @@ h = torch.randn(N, F_, device=dev, requires_grad=True)
 snorm = batch["snorm_n"].to(dev)
 ct = torch.randn(N, F_, device=dev)
 
+params = list(layer.parameters())
+
 def step():
     graph._wcache.clear()
     h.grad = None
-    for p in layer.parameters():
+    for p in params:
         p.grad = None
     layer(graph, h, None, snorm).backward(ct)
 
@@ -36,4 +38,4 @@ print("ms/step", (time.perf_counter() - t0) * 5)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "tottime")).print_stats(34); print(s.getvalue()[:6000])
