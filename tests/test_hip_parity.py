@@ -218,6 +218,38 @@ def test_simple_layer_odd_width_vs_oracle(golden, case):
         _close(a, r, 1e-4, 2e-5 * scale, msg=k)
 
 
+@pytest.mark.parametrize("F_", [300, 131, 6])
+def test_short_row_kernels_wide_and_odd_features_vs_oracle(F_):
+    """molecule batch (4-rows-per-wave forward, single-batch backward) with several feature tiles (F = 300: two
+    16-byte-lane tiles; F = 131: three 4-byte-lane tiles) against the oracle, values and gradients"""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.ops import directional_aggregate
+    from oracle import dgn_oracle as orc
+    b = synth.molecule_batch(24, seed=F_, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    gen = torch.Generator().manual_seed(F_)
+    h, x, eig = torch.randn(N, F_, generator=gen), torch.randn(N, F_, generator=gen), torch.randn(N, 3, generator=gen)
+    aggs, scalers = ["mean", "max", "std", "dir1-dx", "dir2-av"], ["identity", "amplification", "attenuation"]
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    assert graph.num_edges <= 3 * N                      # the host picks the short-row kernels for this graph
+    plan = dgn_amd.make_plan(aggs, scalers)
+    hd, xd = h.to(dev).requires_grad_(True), x.to(dev).requires_grad_(True)
+    y = directional_aggregate(graph, plan, 1.3, x_src=hd, x_in=xd)
+    ho, xo = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yo = orc.aggregate_graph(src, dst, N, ho[src], eig, xo, aggs, scalers, torch.tensor(1.3))
+    ho64, xo64 = h.double().requires_grad_(True), x.double().requires_grad_(True)
+    y64 = orc.aggregate_graph(src, dst, N, ho64[src], eig.double(), xo64, aggs, scalers, torch.tensor(1.3, dtype=torch.float64))
+    _as_good(y, yo, y64, 2e-5, 2e-5)      # (std of two nearly equal messages: sqrt(1e-8 + fp32 cancellation noise), also in the reference)
+    ct = torch.randn(yo.shape, generator=gen)
+    gd = torch.autograd.grad(y, [hd, xd], ct.to(dev))
+    go = torch.autograd.grad(yo, [ho, xo], ct)
+    g64 = torch.autograd.grad(y64, [ho64, xo64], ct.double())
+    for a, r, r64 in zip(gd, go, g64):
+        _as_good(a, r, r64, 1e-4, 2e-5)
+
+
 def _random_graph(seed, N, E, zero_in=True):
     rng = np.random.default_rng(seed)
     dst = rng.integers(0, N - (1 if zero_in else 0), E)      # last node never a destination
