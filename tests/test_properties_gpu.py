@@ -143,3 +143,59 @@ def test_row_sharded_graph_equals_whole_graph():
     torch.testing.assert_close(torch.cat(ys), y.detach(), rtol=0, atol=0)          # same kernels, same order: bit-equal
     torch.testing.assert_close(torch.cat(gi), g_in, rtol=0, atol=0)
     torch.testing.assert_close(gs, g_src, rtol=1e-5, atol=1e-5)                     # partial sums are added in another order
+
+
+def test_headline_config_layer_vs_oracle_on_molecules():
+    """BASELINE configs[1] exactly as bench.py runs it (towers, hidden 70, 5 aggregators x 3 scalers, graph norm, batch
+    norm, residual, training mode) on 256 ZINC-like molecules -- short-row kernels, fused operands, fused tails --
+    against the reference-structured oracle: output, input gradient, every parameter gradient, BN statistics.
+    Gradients are anchored on an fp64 evaluation of the same oracle: a handful of max/min/|.| routings flip between
+    fp32 and fp64 in the REFERENCE computation itself (0.2 absolute on 0.1 % of the entries), so the criterion is
+    "as close to fp64 as the fp32 reference is, or within tolerance of the fp32 reference"."""
+    import dgn_amd
+    from dgn_amd import synth
+    from oracle import dgn_oracle as orc
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(256, seed=41, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    F_ = 70
+    aggs, scalers = "mean max min dir1-av dir1-dx", "identity amplification attenuation"
+    avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, aggs, scalers, {"log": torch.tensor(avg)}, "towers", True, towers=5,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    h, ct = torch.randn(N, F_, generator=gen), torch.randn(N, F_, generator=gen)
+
+    def oracle(dtype):
+        sd = {k: (v.detach().to(dtype).requires_grad_("running" not in k) if v.dtype.is_floating_point else v.clone())
+              for k, v in layer.state_dict().items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+        cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg, dtype=dtype), graph_norm=True, batch_norm=True,
+                   residual=True, towers=5, divide_input=True, edge_features=False)
+        hh = h.to(dtype).requires_grad_(True)
+        y, stats = orc.layer_forward("towers", sd, cfg, src, dst, N, b["eig"].to(dtype), hh, None, b["snorm_n"].to(dtype), training=True)
+        return y, torch.autograd.grad(y, [hh] + [sd[k] for k in names], ct.to(dtype)), names, stats
+
+    y32, g32, names, stats = oracle(torch.float32)
+    y64, g64, _, _ = oracle(torch.float64)
+    layer = layer.to(dev).train()
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=b["eig"].to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, b["snorm_n"].to(dev))
+    params = dict(layer.named_parameters())
+    gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y32.detach().numpy(), rtol=2e-5, atol=2e-5)
+    for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
+        a = a.cpu().double()
+        scale = max(1.0, float(r64.abs().max()))
+        tol = 2e-5 * scale + 2e-4 * r64.abs()
+        ok_ref = (a - r32.double()).abs() <= tol
+        ok_f64 = (a - r64).abs() <= tol + 4 * (r32.double() - r64).abs()
+        assert bool((ok_ref | ok_f64).all()), f"{k}: {int((~(ok_ref | ok_f64)).sum())} entries off"
+        assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale, f"{k}: not close to the fp64 evaluation"
+    for k, v in stats.items():
+        np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
