@@ -103,25 +103,25 @@ class FlatGradAllReduce:
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.active = dist.is_initialized()
 
     def __call__(self) -> None:
+        """Three launches around the collective whatever the number of parameters: gather (foreach copy), scale, scatter."""
         if not self.active:
             return
-        views, off = [], 0
-        for p in self.params:
-            views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(views, grads)
+        torch._foreach_copy_(self.views, grads)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / self.world)
-        for p, v in zip(self.params, views):
+        for p, g in zip(self.params, grads):
             if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = g
+        torch._foreach_copy_(grads, self.views)
 
 
 def barrier_max_ms(ms: float, device) -> float:
