@@ -98,6 +98,7 @@ struct AggParams {
     float* part_sw;       // [n_chunks][DGN_MAX_CH]
     float* coef;          // [n_hub][n_coef][F]  (backward)
     float* stage;         // [n_edges][F] per-edge gradient rows in csc order (atomic-free backward), or NULL
+    int32_t stage_out;    // forward, agg_fwd_short: rows go through the wave's LDS slice (tower-major output, one feature tile)
     bool fresh;           // backward: g_dst / g_in rows are WRITTEN by the row kernel (buffers arrive uninitialised)
     bool seg_add;         // backward: seg_sum_rows adds to g_src (accumulate mode, or g_in aliases g_src) instead of writing it
     const int32_t* csc_ptr;
@@ -565,7 +566,7 @@ __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggPar
 #ifdef DGN_EXP_NOSTORE
                 if (o[0] == 123.456f)
 #endif
-                stv<VEC>(orow + sa_col(p, s, a), o);
+                stv<VEC>(orow + sa_col(p, s, a), o);      // (orow may point into the wave's LDS staging slice, see agg_fwd_short)
             }
         }
     });
@@ -732,33 +733,60 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
         if (r == 0 || r < grp.nrows) side[r].load(p, grp.row0 + r, f0, active);
     SlotBatch<C::NCH, C::NW> b;
     b.load(p, beg0, beg0 + lo[R - 1] + deg[R - 1]);
-    if (!active) return;
+    // Tower-major output: a lane owns one feature pair of ONE tower, so a direct store of an aggregator block is
+    // n_towers pieces of Ft floats (56 bytes on ZINC).  With p.stage_out the wave first lays the row out in its LDS
+    // slice exactly as it lies in memory per tower ([tower][aggregator][Ft]) and then stores every tower's row --
+    // agg_total * Ft contiguous floats (336 bytes) -- with consecutive lanes.  All lanes stay for that second step.
+    extern __shared__ float lds_rows[];
+    const bool staged = p.stage_out != 0;
+    if (!active && !staged) return;
+    const int K = p.agg_total * p.Ft;                                     // floats of one row inside one tower
+    float* slice = lds_rows + (size_t)(threadIdx.x >> 6) * p.n_towers * K;
+    int t_of = 0;                                                        // tower and in-tower feature of this lane
+    if (staged) for (int q = 1; q < p.n_towers; ++q) t_of += (f0 >= q * p.Ft) ? 1 : 0;
+    float* lds_row = slice + t_of * K + (f0 - t_of * p.Ft);
     const MsgSrc<VEC> src(p);
     // tile [row][j-th slot of the row]: the register index is static, the slot (= lane of the batch) is not --
     // one compare per tile instead of a range check of every slot against every row
     float t[R][J][VEC];
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int j = 0; j < J; ++j)
-            if (j < deg[r]) src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
+            for (int j = 0; j < J; ++j)
+                if (j < deg[r]) src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (r != 0 && r >= grp.nrows) break;
-        Acc<C, false> acc;
-        acc.init();
+        float* orow = p.out + (int64_t)(grp.row0 + r) * p.ld_out;
+        if (active) {
+            Acc<C, false> acc;
+            acc.init();
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            if (j < deg[r]) {
-                float mm[VEC], wk[C::NW];
+            for (int j = 0; j < J; ++j) {
+                if (j < deg[r]) {
+                    float mm[VEC], wk[C::NW];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
-                b.weights(wk, lo[r] + j);
-                acc.add(mm, wk, beg0 + lo[r] + j);
+                    for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
+                    b.weights(wk, lo[r] + j);
+                    acc.add(mm, wk, beg0 + lo[r] + j);
+                }
+            }
+            write_row<C, O>(acc, p, staged ? lds_row : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
+        }
+        if (staged) {
+            // (same wave: LDS operations complete in program order, no barrier needed)
+            const int c = lane_id() * VEC;
+            if (c < K) {
+                for (int q = 0; q < p.n_towers; ++q) {
+                    float v[VEC];
+                    ldv<VEC>(v, slice + q * K + c);
+                    stv<VEC>(orow + (int64_t)q * p.tower_stride + c, v);
+                }
             }
         }
-        write_row<C, O>(acc, p, p.out + (int64_t)(grp.row0 + r) * p.ld_out + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
     }
 }
 
@@ -1395,7 +1423,15 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     if (short_rows(p)) {
         const int64_t n_groups = (p.n_nodes + kShortRows - 1) / kShortRows;
         dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);
-        hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+        // LDS-staged stores: tower-major layout, one feature tile, no scalers in the row, a row per tower <= 64 lanes wide
+        AggParams q = p;
+        const int K = p.agg_total * p.Ft;
+        static const bool no_stage = getenv("DGN_NO_STAGE_OUT") != nullptr;
+        const bool sa_in_tower = p.agg_offset == 0 && p.n_agg == p.agg_total;     // the launch writes the whole row of every tower
+        q.stage_out = (!no_stage && p.n_towers > 1 && tiles == 1 && p.n_scalers == 1 && sa_in_tower && K <= kWave * C::VEC &&
+                       (size_t)wpb * p.n_towers * K * sizeof(float) <= 32768) ? 1 : 0;
+        const size_t lds = q.stage_out ? (size_t)wpb * p.n_towers * K * sizeof(float) : 0;
+        hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), lds, stream, q);
     } else {
         const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
         dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
