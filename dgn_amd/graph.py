@@ -81,9 +81,9 @@ class DGNGraph:
         self.in_degree = deg
         self.log_deg = torch.log((deg + 1).double()).float().contiguous()
         self.hub_threshold, self.hub_chunk = int(hub_threshold), int(hub_chunk)
-        hub_rows = torch.nonzero(deg > hub_threshold).flatten()
-        self.n_hub = int(hub_rows.numel())           # one host sync per graph build
-        self.max_in_degree = int(deg.max().item()) if self.num_nodes else 0
+        self.max_in_degree = int(deg.max().item()) if self.num_nodes else 0      # the one host sync of a graph build
+        hub_rows = torch.nonzero(deg > hub_threshold).flatten() if self.max_in_degree > hub_threshold else deg.new_empty(0)
+        self.n_hub = int(hub_rows.numel())           # (a second sync only for graphs that do have hub rows)
         self._keep = []
         c = _lib.DgnGraph()
         c.n_nodes, c.n_edges = self.num_nodes, self.num_edges
