@@ -181,15 +181,47 @@ def cpu_baseline(wl, batch, sample_graphs, reps=5):
         y, _ = orc.layer_forward(wl["type_net"], sd, cfg, src, dst, n, eig, hh, None, snorm, training=True)
         y.backward(ct)
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    def timed(threads, n):
+        torch.set_num_threads(threads)
         step()
-    dt = (time.perf_counter() - t0) / reps
-    return dict(value=src.numel() / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        return (time.perf_counter() - t0) / n
+
+    # the CPU path with all threads torch uses by default AND with one thread; `value` is the faster
+    # of the two (the reference's per-degree-bucket torch ops are small, so more threads do not always help)
+    all_threads = torch.get_num_threads()
+    runs = {all_threads: timed(all_threads, reps)}
+    if all_threads > 1:
+        runs[1] = timed(1, max(2, reps // 2))
+        torch.set_num_threads(all_threads)
+    cores, dt = min(runs.items(), key=lambda kv: kv[1])
+    return dict(value=src.numel() / dt, unit="edges/s", cores=cores, kind="port",
                 sample=f"first {sample_graphs} graphs of the batch ({n} nodes, {src.numel()} edges), layer fwd+bwd, "
-                       f"{reps} timed passes of {dt * 1e3:.1f} ms, torch {torch.__version__} CPU",
-                host_cpus=os.cpu_count())
+                       f"{dt * 1e3:.1f} ms per pass with {cores} thread(s), torch {torch.__version__} CPU",
+                edges_per_s_by_threads={str(k): src.numel() / v for k, v in runs.items()},
+                host_cpus=os.cpu_count(), cpu_model=cpu_model())
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def hbm_triad_GBps(dev, n_bytes=1 << 30, reps=10):
+    """Measured device-memory rate of c = a + s*b over three `n_bytes` fp32 arrays (the box's own
+    stream-triad figure as a second denominator beside the 8 TB/s specification)."""
+    n = n_bytes // 4
+    a, b, c = (torch.empty(n, device=dev).normal_() for _ in range(3))
+    ms = event_ms(lambda: torch.add(a, b, alpha=0.5, out=c), reps, dev)
+    return 3 * n_bytes / ms / 1e6
 
 
 def run_layer_workload(args, wl, rank, world, dev):
@@ -313,8 +345,10 @@ def run_layer_workload(args, wl, rank, world, dev):
     launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "seg_sum_rows"]}[dom]
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
              "agg_bwd_rows": "dgn_agg_backward (agg_bwd_rows + seg_sum_rows)"}[dom]
+    triad = hbm_triad_GBps(dev)
     result["roofline"] = dict(bound="hbm", kernel=label, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
                               frac=kernels[dom]["frac"], traffic=pmc_traffic(args.workload, launches), kernels=kernels,
+                              triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
                               model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r))
     return result, batch
 
@@ -376,7 +410,8 @@ def run_c5(args, wl, rank, world, dev):
         ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=eig), 3, dev)
         bf, _ = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
         result["roofline"] = dict(bound="hbm", kernel="agg_fwd_rows+hub", achieved=bf / ms_f / 1e6, peak=HBM_PEAK / 1e9,
-                                  unit="GB/s", frac=bf / (ms_f * 1e-3) / HBM_PEAK,
+                                  unit="GB/s", frac=bf / (ms_f * 1e-3) / HBM_PEAK, triad_GBps=(triad := hbm_triad_GBps(dev)),
+                                  frac_of_triad=bf / ms_f / 1e6 / triad,
                                   traffic=pmc_traffic("c5", ["agg_fwd_rows", "agg_hub_slices", "agg_fwd_hub_combine"])
                                   if args.scale == 1.0 and not args.aggregators and not args.scalers else None,
                                   kernels={"agg_fwd(all launches)": dict(ms=ms_f, bytes=bf), "edge_weights": dict(ms=ms_w)},
