@@ -28,7 +28,8 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, scale_combine
+from .ops import (bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, node_linear,
+                  scale_combine)
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -117,7 +118,7 @@ def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
         bias = lin.bias
         w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
         b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
-        pq = F.linear(h, w_sd, b_sd)                       # [N, 2*in]: P | Q
+        pq = node_linear(h, w_sd, b_sd)                    # [N, 2*in]: P | Q
         m_edge = F.linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
         return pq, m_edge
     # general pretrans (ReLU between layers): materialise the messages, directly in slot order
@@ -238,7 +239,7 @@ class DGNLayerSimple(nn.Module):
                 S = self.plan.n_scalers
                 agg = self.aggregate(graph, hp, self._kplan)                                  # [N, A*Fp]
                 w = _pad_blocks(lin.weight, S * A, F0, Fp).reshape(fo, S, A * Fp).permute(1, 0, 2).reshape(S * fo, A * Fp)
-                z = F.linear(agg, w)
+                z = node_linear(agg, w)
                 sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
                 h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)      # (+snorm, BatchNorm, ReLU, residual)
                 return F.dropout(h, self.dropout, training=self.training)
@@ -302,7 +303,7 @@ class DGNLayerComplex(nn.Module):
             S, fo = self.plan.n_scalers, lin.weight.shape[0]
             aggx = self.aggregate(graph, h, e, self._kplan_x)                          # [N, A*F | F]
             w = _folded_weight(lin.weight[:, self.in_dim:], lin.weight[:, :self.in_dim], S, id_slot)
-            z = F.linear(aggx, w)
+            z = node_linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)          # (+snorm, BatchNorm, ReLU, residual)
             return F.dropout(h, self.dropout, training=self.training)
@@ -488,7 +489,7 @@ class DGNLayerTower(nn.Module):
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
         ops = self._operands(h.device)
         x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)
-        pq = F.linear(h, ops["w_sd"], ops["bias_sd"])                                              # [N, 2*Fm]: P | Q
+        pq = node_linear(h, ops["w_sd"], ops["bias_sd"])                                            # [N, 2*Fm]: P | Q
         m_edge = F.linear(graph.to_slot_order(e), ops["w_edge"]) if self.edge_features else None
         b_p = ops["b_p"]
         S = self.plan.n_scalers
@@ -500,7 +501,7 @@ class DGNLayerTower(nn.Module):
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True)
-            z = torch.bmm(aggx, ops["w"].transpose(1, 2))                                          # [T, N, S*fo]
+            z = node_linear(aggx, ops["w"])                                                        # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             bns = [t.batchnorm_h for t in self.towers]
             if self.batch_norm and self.training and bn_tail_supported(bns, z, True, T * fo):
@@ -511,7 +512,7 @@ class DGNLayerTower(nn.Module):
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,
                                         x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
-            z = torch.bmm(agg, ops["w_a"].transpose(1, 2))                                         # [T, N, S*fo]
+            z = node_linear(agg, ops["w_a"])                                                       # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             y = scale_combine(z, sc, b_p, None)
             y = y + torch.bmm(x_in.view(N, T, fi).transpose(0, 1), ops["w_h"].transpose(1, 2)).transpose(0, 1).reshape(N, T * fo)

@@ -51,8 +51,8 @@ class FCLayer(nn.Module):
         (Leaky)ReLU layer on the GPU the bias, the activation and this add are one kernel (ops.bias_act)."""
         act = self._fused_act()
         if act is not None and (act[0] != "none" or residual is not None) and x.is_cuda and x.dim() == 2 and self.out_size <= 1024:
-            from .ops import bias_act
-            return bias_act(torch.nn.functional.linear(x, self.linear.weight), self.linear.bias, act[0], act[1], residual)
+            from .ops import bias_act, node_linear
+            return bias_act(node_linear(x, self.linear.weight), self.linear.bias, act[0], act[1], residual)
         h = self._forward_modules(x)
         return h if residual is None else residual + h
 
@@ -70,7 +70,11 @@ class FCLayer(nn.Module):
         return None
 
     def _forward_modules(self, x):
-        h = self.linear(x)
+        if x.is_cuda and x.dim() == 2:
+            from .ops import node_linear
+            h = node_linear(x, self.linear.weight, self.linear.bias)
+        else:
+            h = self.linear(x)
         if self.activation is not None:
             h = self.activation(h)
         if self.dropout is not None:

@@ -7,6 +7,7 @@ GPU only; no CPU path exists in this package.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -518,3 +519,92 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
                 torch._foreach_copy_([b.running_var for b in bns], list(rv.split(w)))
             torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
     return y
+
+
+# ---- tall-skinny Linear (dgn_linear.hip) -------------------------------------------------------------------------------
+
+def _lin_fwd(lib, a, w, w_is_kn, bias, n):
+    """a [T, M, k] dense, w [T, n, k] (or [T, k, n] with w_is_kn) -> [T, M, n]"""
+    T, M, k = a.shape
+    c = torch.empty(T, M, n, dtype=torch.float32, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    rc = lib.dgn_linear_forward(M, k, n, T, a.data_ptr(), k, a.stride(0), w.data_ptr(), w.stride(1), w.stride(0), int(w_is_kn),
+                                _ptr(bias), bias.stride(0) if bias is not None else 0, c.data_ptr(), n, M * n, stream)
+    _lib.check(rc, "dgn_linear_forward")
+    return c
+
+
+class _TsLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.DgnError("linear: CUDA tensors only (dgn_amd has no CPU path)")
+        x, w = x.contiguous(), w.contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return _lin_fwd(lib, x, w, False, bias, w.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        T, M, k = x.shape
+        n = w.shape[1]
+        g = g.contiguous()
+        g_x = _lin_fwd(lib, g, w, True, None, k) if ctx.needs_input_grad[0] else None
+        g_w = g_b = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty_like(w)
+            if want_b and k % 16 != 0:                # the bias gradient rides along as a column of ones
+                g_b = torch.empty(T, n, dtype=torch.float32, device=x.device)
+            ws_bytes = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, T)
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = lib.dgn_linear_wgrad(M, k, n, T, g.data_ptr(), n, g.stride(0), x.data_ptr(), k, x.stride(0), g_w.data_ptr(), k, n * k,
+                                      _ptr(g_b), n, ws.data_ptr(), ws_bytes, stream)
+            _lib.check(rc, "dgn_linear_wgrad")
+        if want_b and g_b is None:
+            g_b = g.sum(dim=1)
+        return g_x, g_w, g_b
+
+
+_LIN_OK = {}
+
+
+def linear_supported(k: int, n: int) -> bool:
+    """Whether ``linear`` takes an [*, k] x [n, k] product: even widths up to 160 (forward, input gradient, and a
+    weight gradient of at most 50 16x16 tiles).  Otherwise use ``F.linear``."""
+    key = (int(k), int(n))
+    if key not in _LIN_OK:
+        lib = _lib.load()
+        _LIN_OK[key] = bool(lib.dgn_linear_supported(key[0], key[1], 1)) and bool(lib.dgn_linear_supported(key[1], key[0], 0))
+    return _LIN_OK[key]
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear(x, weight, bias)`` for node-count-tall operands on the streaming MFMA kernels, exact fp32.
+
+    ``x [M, k]`` with ``weight [n, k]`` (``bias [n]``), or batched over towers: ``x [T, M, k]``, ``weight [T, n, k]``
+    (``bias [T, n]``) = ``torch.bmm(x, weight.transpose(1, 2))``.  Forward, input gradient and weight gradient each are
+    one pass over the rows with the weights resident in LDS (``include/dgn_hip.h: dgn_linear_*``)."""
+    if x.dim() == 2:
+        y = _TsLinear.apply(x.unsqueeze(0), weight.unsqueeze(0), bias.unsqueeze(0) if bias is not None else None)
+        return y.squeeze(0)
+    return _TsLinear.apply(x, weight, bias)
+
+
+def node_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` / batched ``bmm(x, weight^T)`` of the layers' node-count-tall operands: the streaming kernels where
+    they apply (fp32 on the GPU, even widths up to 160), the library GEMM otherwise (wide simple-layer posttrans, CPU
+    glue in the tests)."""
+    k, n = x.shape[-1], weight.shape[-2]
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == weight.dim() and x.dim() in (2, 3)
+            and x.shape[-2] > 0 and os.environ.get("DGN_LIBRARY_GEMM") != "1" and linear_supported(k, n)):
+        return linear(x, weight, bias)
+    if x.dim() == 2:
+        return torch.nn.functional.linear(x, weight, bias)
+    y = torch.bmm(x, weight.transpose(1, 2))
+    return y if bias is None else y + bias.unsqueeze(1)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 7
+#define DGN_ABI_VERSION 8
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -263,6 +263,28 @@ int dgn_bias_act_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, 
                          const float* residual, float* y, void* stream);
 int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* bias,
                           int32_t act, float slope, float* g_x, float* g_bias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- tall-skinny fp32 Linear (dgn_linear.hip) ---------------------------------------------------------------------
+ * The nn.Linear of the reference's pretrans / posttrans MLPs (layers.py:101-112, called from nets/dgn_layer.py:67-75
+ * and :116-119) for matrices with ~1e5..1e6 rows (nodes) and k, n <= 160 columns, batched over towers:
+ *   dgn_linear_forward   c[t] = a[t] . op(w[t]) (+ bias[t])    a: [n_rows, k], c: [n_rows, n], dense rows (lda == k, ldc == n)
+ *                        w_is_kn == 0: w[t] is [n, k] (nn.Linear weight: c = a w^T, the forward)
+ *                        w_is_kn == 1: w[t] is [k, n] (c = a w: the input gradient with a = g_out, w = weight)
+ *   dgn_linear_wgrad     dw[t] = g[t]^T . x[t]                 g: [n_rows, n], x: [n_rows, k], both dense; dw: [n, k]
+ *                        dbias[t] = column sums of g[t] (NULL = not wanted; needs k % 16 != 0: it is computed as the
+ *                        product with an extra column of ones in x's tile padding, at no extra pass)
+ * Exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain); the weight gradient is summed over per-wave partials in a fixed
+ * order (bitwise reproducible).  dgn_linear_supported(k, n) says whether the pair is handled (even, <= 160, and for
+ * the weight gradient at most 50 16x16 tiles); callers use a library GEMM otherwise.  stride_* are element offsets
+ * between batch entries (towers).  `ws` of dgn_linear_wgrad_workspace_bytes(...) bytes holds the partials.           */
+int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad);
+int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* a, int64_t lda, int64_t stride_a,
+                       const float* w, int64_t ldw, int64_t stride_w, int32_t w_is_kn, const float* bias,
+                       int64_t stride_bias, float* c, int64_t ldc, int64_t stride_c, void* stream);
+size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, int32_t batch);
+int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
+                     const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
+                     int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

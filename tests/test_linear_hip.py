@@ -1,0 +1,85 @@
+"""dgn_linear_* (tall-skinny fp32 Linear on the streaming MFMA kernels) against torch on the GPU, anchored on fp64:
+forward, input gradient, weight gradient and bias gradient; ragged row counts (not a multiple of the 16-row strips),
+one row, widths that are / are not multiples of 4 and 16, batched towers, and the dispatcher's library fall-back."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(T, M, k, n, bias, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(T, M, k, device="cuda", generator=g)
+    w = torch.randn(T, n, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(T, n, device="cuda", generator=g) if bias else None
+    gy = torch.randn(T, M, n, device="cuda", generator=g)
+    return x, w, b, gy
+
+
+def _ref64(x, w, b, gy):
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if b is not None else None
+    y = torch.bmm(x64, w64.transpose(1, 2)) + (b64.unsqueeze(1) if b64 is not None else 0)
+    y.backward(gy.double())
+    return y.detach(), x64.grad, w64.grad, (b64.grad if b64 is not None else None)
+
+
+def _close(a, r, tol=1e-5):
+    scale = float(r.abs().max()) + 1e-30
+    assert float((a.double() - r).abs().max()) <= tol * scale, float((a.double() - r).abs().max()) / scale
+
+
+@pytest.mark.parametrize("T,M,k,n,bias", [(1, 1000, 70, 140, True), (5, 777, 84, 42, False), (1, 1, 70, 70, True), (1, 16, 2, 2, True),
+                                          (3, 4097, 16, 160, True), (2, 333, 160, 16, False), (1, 50000, 42, 84, False),
+                                          (1, 15, 64, 64, True), (4, 31, 6, 10, True)])
+def test_linear_matches_fp64(T, M, k, n, bias):
+    from dgn_amd import ops
+    x, w, b, gy = _case(T, M, k, n, bias)
+    assert ops.linear_supported(k, n)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if b is not None else None
+    y = ops.linear(xr, wr, br)
+    y.backward(gy)
+    y64, gx64, gw64, gb64 = _ref64(x, w, b, gy)
+    _close(y, y64)
+    _close(xr.grad, gx64)
+    _close(wr.grad, gw64)
+    if b is not None:
+        _close(br.grad, gb64)
+
+
+def test_linear_2d_equals_torch_and_is_reproducible():
+    import torch.nn.functional as F
+    from dgn_amd import ops
+    x, w, b, gy = _case(1, 12345, 70, 140, True)
+    x, w, b, gy = x[0], w[0], b[0], gy[0]
+    outs = []
+    for _ in range(2):
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.linear(xr, wr, br)
+        y.backward(gy)
+        outs.append((y.detach(), xr.grad, wr.grad, br.grad))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)                       # no atomics anywhere: bitwise reproducible
+    yt = F.linear(x, w, b)
+    assert torch.allclose(outs[0][0], yt, rtol=1e-5, atol=1e-5)
+
+
+def test_non_finite_rows_stay_in_their_rows():
+    """The strip's padding columns alias the next row in LDS: an inf / nan there must not leak into the row before."""
+    from dgn_amd import ops
+    x, w, b, _ = _case(1, 64, 70, 70, True)
+    x[0, 5, 0] = float("inf")
+    x[0, 21, 3] = float("nan")
+    y = ops.linear(x, w, b)[0]
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert bad.nonzero().flatten().tolist() == [5, 21]
+
+
+def test_dispatcher_falls_back_to_the_library():
+    from dgn_amd import ops
+    assert not ops.linear_supported(228, 75) and not ops.linear_supported(70, 71)
+    x, w = torch.randn(100, 228, device="cuda"), torch.randn(75, 228, device="cuda")
+    assert torch.allclose(ops.node_linear(x, w), torch.nn.functional.linear(x, w), rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception):
+        ops.linear(x, w)                                # the kernels refuse unsupported widths loudly
