@@ -24,7 +24,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
-           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
+           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
 
 
 class DgnGraph(C.Structure):
@@ -134,6 +134,10 @@ def load() -> C.CDLL:
         lib.dgn_linear_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                            C.c_void_p]
+        lib.dgn_linear_combine_forward.restype = C.c_int
+        lib.dgn_linear_combine_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                                   C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                   C.c_void_p]
         lib.dgn_linear_wgrad_workspace_bytes.restype = C.c_size_t
         lib.dgn_linear_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
         lib.dgn_linear_wgrad.restype = C.c_int

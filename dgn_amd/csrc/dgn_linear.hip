@@ -38,6 +38,10 @@ struct LinParams {
     float* C; int64_t sC;                            // dense rows: [M][n]
     int groups;                                      // workgroups per batch entry
     int dbg;
+    // scale-combine epilogue (S > 0): y[m][t*fo + o] = rs[m] * (cb[t*fo + o] + sum_s sc[m][s] * c[t][m][s*fo + o]); C is not written
+    int S, fo;
+    const float* sc; const float* rs; const float* cb;
+    float* Y; int64_t ldy;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
@@ -108,6 +112,18 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     int64_t out_strip = -1;
     auto store_out = [&]() {
         if (p.dbg & 1) return;
+        if (p.S > 0) {
+            const int64_t row0 = out_strip * kStrip;
+            const int cnt = (int)min((int64_t)kStrip, p.M - row0) * p.fo;
+            for (int idx = lane; idx < cnt; idx += 64) {
+                const int r = idx / p.fo, o = idx - r * p.fo;
+                const int64_t row = row0 + r;
+                float v = p.cb ? p.cb[t * p.fo + o] : 0.f;
+                for (int s = 0; s < p.S; ++s) v += (p.sc ? p.sc[row * p.S + s] : 1.f) * Cl[r * n + s * p.fo + o];
+                p.Y[row * p.ldy + t * p.fo + o] = p.rs ? v * p.rs[row] : v;
+            }
+            return;
+        }
         const int cnt2 = (int)min((int64_t)kStrip, p.M - out_strip * kStrip) * (n >> 1);
         float* dst = C + out_strip * kStrip * n;
 #pragma unroll
@@ -351,6 +367,32 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
     return ok && (!wgrad || ((n + 15) / 16) * ((k + 15) / 16) <= kMaxWgradTiles);
 }
 
+static int launch_linear(const char* fn, LinParams& p, void* stream) {
+    p.kp = lds_stride(p.k);
+    const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
+    const size_t w_bytes = ((size_t)NT * 16 * p.kp + NT * 16) * 4;
+    const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n) * 4;
+    int waves = linear_threads(NT, KB) / 64;
+    while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
+    const size_t lds = w_bytes + waves * strip_bytes;
+    if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
+    const int per_cu = std::max(1, std::min((int)(kLdsBudget / lds), 32 / waves));
+    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
+    int groups = std::max(1, n_cus() * per_cu / p.T);
+    groups = (int)std::min<int64_t>(groups, (n_strips + waves - 1) / waves);
+    p.groups = groups;
+    { const char* d = getenv("DGN_LIN_DBG"); p.dbg = d ? atoi(d) : 0; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipErrorInvalidValue;
+    switch (NT) {
+#define DGN_CASE(N) case N: e = launch_linear_n<N>(KB, p, waves * 64, lds, st); break;
+        DGN_CASE(1) DGN_CASE(2) DGN_CASE(3) DGN_CASE(4) DGN_CASE(5) DGN_CASE(6) DGN_CASE(7) DGN_CASE(8) DGN_CASE(9) DGN_CASE(10)
+#undef DGN_CASE
+    }
+    DGN_HIP_CHECK(e);
+    return 0;
+}
+
 extern "C" int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* a, int64_t lda,
                                   int64_t stride_a, const float* w, int64_t ldw, int64_t stride_w, int32_t w_is_kn,
                                   const float* bias, int64_t stride_bias, float* c, int64_t ldc, int64_t stride_c,
@@ -364,33 +406,33 @@ extern "C" int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t 
         return -1;
     }
     LinParams p{};
-    p.M = n_rows; p.k = k; p.n = n; p.T = batch; p.kp = lds_stride(k);
+    p.M = n_rows; p.k = k; p.n = n; p.T = batch;
     p.A = a; p.sA = stride_a;
     p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = w_is_kn;
     p.bias = bias; p.sBias = stride_bias;
     p.C = c; p.sC = stride_c;
-    const int NT = (n + 15) / 16, KB = (k + 15) / 16;
-    const size_t w_bytes = ((size_t)NT * 16 * p.kp + NT * 16) * 4;
-    const size_t strip_bytes = ((size_t)strip_floats(k) + kStrip * n) * 4;
-    int waves = linear_threads(NT, KB) / 64;
-    while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
-    const size_t lds = w_bytes + waves * strip_bytes;
-    if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
-    const int per_cu = std::max(1, std::min((int)(kLdsBudget / lds), 32 / waves));
-    const int64_t n_strips = (n_rows + kStrip - 1) / kStrip;
-    int groups = std::max(1, n_cus() * per_cu / batch);
-    groups = (int)std::min<int64_t>(groups, (n_strips + waves - 1) / waves);
-    p.groups = groups;
-    { const char* d = getenv("DGN_LIN_DBG"); p.dbg = d ? atoi(d) : 0; }
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipErrorInvalidValue;
-    switch (NT) {
-#define DGN_CASE(N) case N: e = launch_linear_n<N>(KB, p, waves * 64, lds, st); break;
-        DGN_CASE(1) DGN_CASE(2) DGN_CASE(3) DGN_CASE(4) DGN_CASE(5) DGN_CASE(6) DGN_CASE(7) DGN_CASE(8) DGN_CASE(9) DGN_CASE(10)
-#undef DGN_CASE
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out,
+                                          const float* a, int64_t stride_a, const float* w, int64_t ldw, int64_t stride_w,
+                                          const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
+                                          void* stream) {
+    const char* fn = "dgn_linear_combine_forward";
+    const int n = n_scalers * f_out;
+    if (n_rows < 0 || n_towers < 1 || n_scalers < 1 || f_out < 1 || !dgn_linear_supported(k, n, 0)) {
+        set_error("%s: need even k and n_scalers * f_out in [2, 160] (k=%d n=%d)", fn, k, n);
+        return -1;
     }
-    DGN_HIP_CHECK(e);
-    return 0;
+    if (n_rows == 0) return 0;
+    if (!a || !w || !y || (n_scalers > 1 && !scale)) { set_error("%s: null operand", fn); return -1; }
+    if ((stride_a & 1) || !aligned8(a) || ld_y < (int64_t)n_towers * f_out) { set_error("%s: A entries must be 8-byte aligned, y rows n_towers * f_out wide", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = n_towers;
+    p.A = a; p.sA = stride_a;
+    p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = 0;
+    p.S = n_scalers; p.fo = f_out; p.sc = scale; p.rs = row_scale; p.cb = bias; p.Y = y; p.ldy = ld_y;
+    return launch_linear(fn, p, stream);
 }
 
 static int wgrad_groups(int64_t n_rows, int32_t k, int32_t n, int32_t batch) {

@@ -28,8 +28,8 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
-from .ops import (bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, node_linear,
-                  scale_combine)
+from .ops import (bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, linear_combine_bn_tail,
+                  node_linear, node_linear_supported, scale_combine)
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -501,10 +501,16 @@ class DGNLayerTower(nn.Module):
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True)
-            z = node_linear(aggx, ops["w"])                                                        # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             bns = [t.batchnorm_h for t in self.towers]
-            if self.batch_norm and self.training and bn_tail_supported(bns, z, True, T * fo):
+            fused_tail = self.batch_norm and self.training and bn_tail_supported(bns, aggx, True, T * fo)
+            if fused_tail and node_linear_supported(aggx, ops["w"]):
+                rm, rv, nbt = self._linked_bn_stats(aggx.device)                                   # posttrans + combine + BatchNorm: one autograd node
+                y = linear_combine_bn_tail(aggx, ops["w"], sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt,
+                                           bns[0].momentum, bns[0].eps)
+                return F.dropout(y, self.dropout, training=self.training)
+            z = node_linear(aggx, ops["w"])                                                        # [T, N, S*fo]
+            if fused_tail:
                 rm, rv, nbt = self._linked_bn_stats(z.device)                                      # combine + BatchNorm: one autograd node
                 y = combine_bn_tail(z, sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps)
                 return F.dropout(y, self.dropout, training=self.training)

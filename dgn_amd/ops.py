@@ -557,16 +557,8 @@ class _TsLinear(torch.autograd.Function):
         g_w = g_b = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            g_w = torch.empty_like(w)
-            if want_b and k % 16 != 0:                # the bias gradient rides along as a column of ones
-                g_b = torch.empty(T, n, dtype=torch.float32, device=x.device)
-            ws_bytes = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, T)
-            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-            rc = lib.dgn_linear_wgrad(M, k, n, T, g.data_ptr(), n, g.stride(0), x.data_ptr(), k, x.stride(0), g_w.data_ptr(), k, n * k,
-                                      _ptr(g_b), n, ws.data_ptr(), ws_bytes, stream)
-            _lib.check(rc, "dgn_linear_wgrad")
-        if want_b and g_b is None:
+            g_w, g_b = _lin_wgrad(lib, g, x, want_b)
+        elif want_b:
             g_b = g.sum(dim=1)
         return g_x, g_w, g_b
 
@@ -596,15 +588,107 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _TsLinear.apply(x, weight, bias)
 
 
+def node_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Whether ``node_linear`` runs this product on the streaming kernels (fp32 on the GPU, even widths up to 160)."""
+    return bool(x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == weight.dim() and x.dim() in (2, 3)
+                and x.shape[-2] > 0 and os.environ.get("DGN_LIBRARY_GEMM") != "1" and linear_supported(x.shape[-1], weight.shape[-2]))
+
+
 def node_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` / batched ``bmm(x, weight^T)`` of the layers' node-count-tall operands: the streaming kernels where
-    they apply (fp32 on the GPU, even widths up to 160), the library GEMM otherwise (wide simple-layer posttrans, CPU
-    glue in the tests)."""
-    k, n = x.shape[-1], weight.shape[-2]
-    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == weight.dim() and x.dim() in (2, 3)
-            and x.shape[-2] > 0 and os.environ.get("DGN_LIBRARY_GEMM") != "1" and linear_supported(k, n)):
+    they apply, the library GEMM otherwise (wide simple-layer posttrans, CPU glue in the tests)."""
+    if node_linear_supported(x, weight):
         return linear(x, weight, bias)
     if x.dim() == 2:
         return torch.nn.functional.linear(x, weight, bias)
     y = torch.bmm(x, weight.transpose(1, 2))
     return y if bias is None else y + bias.unsqueeze(1)
+
+
+def _lin_wgrad(lib, g, x, want_bias):
+    """g [T, M, n], x [T, M, k] dense -> (dW [T, n, k], dbias [T, n] | None)"""
+    T, M, n = g.shape
+    k = x.shape[2]
+    g_w = torch.empty(T, n, k, dtype=torch.float32, device=x.device)
+    g_b = torch.empty(T, n, dtype=torch.float32, device=x.device) if (want_bias and k % 16 != 0) else None
+    ws_bytes = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, T)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.dgn_linear_wgrad(M, k, n, T, g.data_ptr(), n, g.stride(0), x.data_ptr(), k, x.stride(0), g_w.data_ptr(), k, n * k,
+                              _ptr(g_b), n, ws.data_ptr(), ws_bytes, stream)
+    _lib.check(rc, "dgn_linear_wgrad")
+    if want_bias and g_b is None:
+        g_b = g.sum(dim=1)
+    return g_w, g_b
+
+
+class _LinCombineBNTail(torch.autograd.Function):
+    """The towers' posttrans Linear, the scale-combine and the training-mode BatchNorm tail as ONE autograd node: the
+    forward never writes the [T, N, S*fo] product (dgn_linear_combine_forward), the backward forms its gradient from
+    the tail's inputs (see _CombineBNTail) and runs the input / weight gradients on the streaming kernels."""
+
+    @staticmethod
+    def forward(ctx, aggx, w, scale, bias, row_scale, gamma, beta, running_mean, running_var, momentum, eps, relu, residual):
+        lib = _lib.load()
+        if not aggx.is_cuda:
+            raise _lib.DgnError("linear_combine_bn_tail: CUDA tensors only (dgn_amd has no CPU path)")
+        aggx, w = aggx.contiguous(), w.contiguous()
+        T, N, k = aggx.shape
+        S = 1 if scale is None else scale.shape[1]
+        fo = w.shape[1] // S
+        F = T * fo
+        dev = aggx.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        y = torch.empty((N, F), dtype=torch.float32, device=dev)
+        rc = lib.dgn_linear_combine_forward(N, k, T, S, fo, aggx.data_ptr(), aggx.stride(0), w.data_ptr(), w.stride(1), w.stride(0),
+                                            _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
+        _lib.check(rc, "dgn_linear_combine_forward")
+        if residual is not None:
+            residual = residual.contiguous()
+        out = torch.empty_like(y)
+        save_mean = torch.empty(F, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(F, dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        rc = lib.dgn_bn_tail_forward(N, F, y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                     float(momentum), float(eps), 1, 1 if relu else 0, _ptr(residual), out.data_ptr(),
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "dgn_bn_tail_forward")
+        ctx.save_for_backward(scale, row_scale, y, gamma, beta, save_mean, save_invstd, aggx, w)
+        ctx.dims = (T, N, S, fo, bias is not None, relu, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        aggx, w = ctx.saved_tensors[7:]
+        ctx_like = type("Ctx", (), {})()
+        ctx_like.saved_tensors = ctx.saved_tensors[:7]
+        ctx_like.dims = ctx.dims
+        ctx_like.needs_input_grad = (True, False, ctx.needs_input_grad[3])
+        g_z, _, g_b, _, g_gamma, g_beta, _, _, _, _, _, g_res = _CombineBNTail.backward(ctx_like, g_out)
+        g_aggx = _lin_fwd(lib, g_z, w, True, None, aggx.shape[2]) if ctx.needs_input_grad[0] else None
+        g_w = _lin_wgrad(lib, g_z, aggx, False)[0] if ctx.needs_input_grad[1] else None
+        return g_aggx, g_w, None, g_b, None, g_gamma, g_beta, None, None, None, None, None, g_res
+
+
+def linear_combine_supported(k: int, n: int) -> bool:
+    return linear_supported(k, n)
+
+
+def linear_combine_bn_tail(aggx, w, scale, bias, row_scale, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                           eps, relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[relu](BatchNorm(scale_combine(bmm(aggx, w^T), scale, bias, row_scale))) [+ residual]`` in TRAINING mode as one
+    autograd node; ``aggx [T, N, k]`` (the sweep's tower-major output), ``w [T, S*fo, k]``.  Running statistics are
+    updated in place.  Needs ``linear_supported(k, S*fo)`` and ``T*fo <= 1024``."""
+    if scale is not None:
+        scale = scale.contiguous()
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).contiguous()
+    if bias is not None:
+        bias = bias.reshape(-1).contiguous()
+    out = _LinCombineBNTail.apply(aggx, w, scale, bias, row_scale, gamma, beta, running_mean, running_var, momentum, eps, relu, residual)
+    if num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
+    return out

@@ -281,6 +281,14 @@ int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad);
 int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* a, int64_t lda, int64_t stride_a,
                        const float* w, int64_t ldw, int64_t stride_w, int32_t w_is_kn, const float* bias,
                        int64_t stride_bias, float* c, int64_t ldc, int64_t stride_c, void* stream);
+/* The towers' posttrans Linear with the scale-combine epilogue of dgn_scale_combine_forward in the same pass (the
+ * [T, N, S*f_out] product never reaches memory):
+ *   y[m, t*f_out + o] = row_scale[m] * (bias[t*f_out + o] + sum_s scale[m, s] * (a[t] w[t]^T)[m, s*f_out + o])
+ * a: [T][n_rows][k] dense (stride_a between towers), w[t]: [S*f_out, k]; scale [n_rows, S] (NULL only if S == 1),
+ * bias [T*f_out] / row_scale [n_rows] may be NULL.  Same width limits as dgn_linear_forward with n = S*f_out.        */
+int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* a,
+                               int64_t stride_a, const float* w, int64_t ldw, int64_t stride_w, const float* scale,
+                               const float* bias, const float* row_scale, float* y, int64_t ld_y, void* stream);
 size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, int32_t batch);
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,

@@ -83,3 +83,32 @@ def test_dispatcher_falls_back_to_the_library():
     assert torch.allclose(ops.node_linear(x, w), torch.nn.functional.linear(x, w), rtol=1e-5, atol=1e-5)
     with pytest.raises(Exception):
         ops.linear(x, w)                                # the kernels refuse unsupported widths loudly
+
+
+@pytest.mark.parametrize("T,N,k,S,fo,with_scale_rows", [(5, 3001, 84, 3, 14, True), (2, 100, 20, 1, 6, False), (3, 17, 36, 2, 8, True)])
+def test_linear_combine_bn_tail_equals_the_unfused_nodes(T, N, k, S, fo, with_scale_rows):
+    """posttrans + scale-combine + BatchNorm tail as one node (the product never written) == bmm -> combine_bn_tail."""
+    from dgn_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    aggx = torch.randn(T, N, k, device="cuda", generator=g)
+    w = torch.randn(T, S * fo, k, device="cuda", generator=g) / k ** 0.5
+    sc = (torch.rand(N, S, device="cuda", generator=g) + 0.5) if S > 1 else None
+    bias = torch.randn(T * fo, device="cuda", generator=g)
+    rs = (torch.rand(N, device="cuda", generator=g) + 0.5) if with_scale_rows else None
+    gamma, beta = torch.rand(T * fo, device="cuda", generator=g) + 0.5, torch.randn(T * fo, device="cuda", generator=g)
+    ct = torch.randn(N, T * fo, device="cuda", generator=g)
+    res = []
+    for fused in (True, False):
+        a, ww, b = aggx.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(T * fo, device="cuda"), torch.ones(T * fo, device="cuda")
+        if fused:
+            y = ops.linear_combine_bn_tail(a, ww, sc, b, rs, ga, be, rm, rv, None, 0.1, 1e-5)
+        else:
+            y = ops.combine_bn_tail(torch.bmm(a, ww.transpose(1, 2)), sc, b, rs, ga, be, rm, rv, None, 0.1, 1e-5)
+        y.backward(ct)
+        res.append((y.detach(), a.grad, ww.grad, b.grad, ga.grad, be.grad, rm, rv))
+    for name, x, r in zip("y g_aggx g_w g_bias g_gamma g_beta running_mean running_var".split(), *res):
+        # (the bias feeds a BatchNorm: its exact gradient is zero, both paths return rounding noise of the column sums)
+        scale = float(ct.abs().sum(0).max()) if name == "g_bias" else float(r.abs().max()) + 1e-30
+        assert float((x - r).abs().max()) <= 2e-5 * scale, (name, float((x - r).abs().max()) / scale)
