@@ -25,6 +25,7 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kStrip = 16;          // rows per strip = one MFMA tile edge
 constexpr int kMaxTiles = 10;       // k, n <= 160
 constexpr int kLdsBudget = 160 * 1024;
+constexpr int kFacFloats = 2 * kStrip * 4;
 constexpr int kMaxWgradTiles = 50;  // accumulator tiles (4 registers each) one wave can hold for the weight gradient
 
 __host__ __device__ inline int lds_stride(int k) { return ((k + 15) / 16) * 16 + 4; }   // == 4 mod 8: spreads rows over banks
@@ -45,7 +46,7 @@ struct LinParams {
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_threads(int NT, int KB) { return 8 * NT + 4 * KB + 40 <= 116 ? 1024 : 512; }
+constexpr int linear_threads(int NT, int KB) { return 8 * NT + 4 * KB + 52 <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
 // A strip is 16 * k consecutive floats of A (rows are dense: lda == k), copied as float2 number j * 64 + lane.
@@ -69,7 +70,7 @@ __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], 
         if (j * 64 + lane < kStrip * (k >> 1)) reinterpret_cast<float2*>(Xl)[j * 64 + lane] = pre[j];
 }
 
-template <int NT, int KB>
+template <int NT, int KB, bool COMBINE>
 __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p) {
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
@@ -79,17 +80,30 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     const int kp = p.kp, k = p.k, n = p.n;
     float* Wl = lds;                                 // [NT*16][kp], zero beyond (n, k)
     float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
-    float* Xl = Bl + NT * 16 + wave * (strip_floats(k) + kStrip * n);   // this wave's strip, as it lies in memory
+    float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
+    float* Xl = Cb + NT * 16 + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
+    float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
 
     const float* A = p.A + (int64_t)t * p.sA;
     float* C = p.C + (int64_t)t * p.sC;
     const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
     const int64_t first = (int64_t)grp * n_waves + wave, step = (int64_t)p.groups * n_waves;
     float2 pre[NL];
-    if (first < n_strips) load_strip<NL>(pre, A, p.M, k, first, lane);       // in flight while the weights are set up
+    f4 fac = f4{1.f, 1.f, 1.f, 1.f};                 // the combine epilogue's row factors travel with the strip's prefetch
+    // (branch-free: a conditional load would make the compiler wait for everything in flight where the branches join)
+    const int S1 = COMBINE ? p.S : 1;
+    auto load_fac = [&](int64_t strip) {
+        if constexpr (!COMBINE) return;
+        const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
+        const float* scp = p.sc ? p.sc + row * S1 : A;
+        const float* rsp = p.rs ? p.rs + row : A;
+        const float f0 = scp[0], f1 = scp[min(1, S1 - 1)], f2 = scp[min(2, S1 - 1)], f3 = *rsp;
+        fac = f4{p.sc ? f0 : 1.f, p.sc ? f1 : 1.f, p.sc ? f2 : 1.f, p.rs ? f3 : 1.f};
+    };
+    if (first < n_strips) { load_strip<NL>(pre, A, p.M, k, first, lane); load_fac(first); }      // in flight while the weights are set up
 
-    for (int i = tid; i < NT * 16 * kp + NT * 16; i += blockDim.x) lds[i] = 0.f;
+    for (int i = tid; i < NT * 16 * kp + 2 * NT * 16; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
     const float* Wg = p.W + (int64_t)t * p.sW;
     for (int i = tid; i < n * k; i += blockDim.x) {
@@ -98,6 +112,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
         Wl[r * kp + c] = p.w_kn ? Wg[(int64_t)c * p.ldw + r] : Wg[(int64_t)r * p.ldw + c];
     }
     if (p.bias) for (int i = tid; i < n; i += blockDim.x) Bl[i] = p.bias[(int64_t)t * p.sBias + i];
+    if (COMBINE && p.cb) for (int i = tid; i < p.fo; i += blockDim.x) Cb[i] = p.cb[t * p.fo + i];
     __syncthreads();
 
     const int m = lane & 15, g = lane >> 4;
@@ -110,17 +125,19 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     // They wait in LDS, from where the strip's 16 * n floats leave as one contiguous run (C's rows are dense)
     // (8-byte pieces with gaps, straight from the accumulators, ran at half the store rate).
     int64_t out_strip = -1;
+    int it = 0, out_it = 0;
     auto store_out = [&]() {
         if (p.dbg & 1) return;
-        if (p.S > 0) {
+        if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
             const int cnt = (int)min((int64_t)kStrip, p.M - row0) * p.fo;
+            const float* F = Fl + (out_it & 1) * (kStrip * 4);
             for (int idx = lane; idx < cnt; idx += 64) {
                 const int r = idx / p.fo, o = idx - r * p.fo;
-                const int64_t row = row0 + r;
-                float v = p.cb ? p.cb[t * p.fo + o] : 0.f;
-                for (int s = 0; s < p.S; ++s) v += (p.sc ? p.sc[row * p.S + s] : 1.f) * Cl[r * n + s * p.fo + o];
-                p.Y[row * p.ldy + t * p.fo + o] = p.rs ? v * p.rs[row] : v;
+                const f4 f = *reinterpret_cast<const f4*>(F + 4 * r);
+                float v = Cb[o];
+                for (int s = 0; s < p.S; ++s) v += f[s] * Cl[r * n + s * p.fo + o];
+                p.Y[(row0 + r) * p.ldy + t * p.fo + o] = v * f[3];
             }
             return;
         }
@@ -132,8 +149,9 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
         store_strip<NL>(Xl, pre, k, lane);
+        if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
-        if (strip + step < n_strips && !(p.dbg & 4)) load_strip<NL>(pre, A, p.M, k, strip + step, lane);
+        if (strip + step < n_strips && !(p.dbg & 4)) { load_strip<NL>(pre, A, p.M, k, strip + step, lane); load_fac(strip + step); }
 
         f4 acc[NT];
 #pragma unroll
@@ -167,6 +185,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
             if (col + 3 < n) *reinterpret_cast<float2*>(c + 16 * q + 2) = make_float2(acc[q][2], acc[q][3]);
         }
         out_strip = strip;
+        out_it = it++;
     }
     if (out_strip >= 0) store_out();
 }
@@ -298,17 +317,21 @@ __global__ __launch_bounds__(256) void ts_wgrad_finalize(int T, int n, int k, in
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-template <int NT, int KB>
-hipError_t launch_linear_nk(const LinParams& p, int threads, size_t lds, hipStream_t st) {
+template <int NT, int KB, bool COMBINE>
+hipError_t launch_linear_nkc(const LinParams& p, int threads, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB, COMBINE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((ts_linear<NT, KB>), dim3(p.T * p.groups), dim3(threads), lds, st, p);
+    hipLaunchKernelGGL((ts_linear<NT, KB, COMBINE>), dim3(p.T * p.groups), dim3(threads), lds, st, p);
     return hipGetLastError();
+}
+template <int NT, int KB>
+hipError_t launch_linear_nk(const LinParams& p, int threads, size_t lds, hipStream_t st) {
+    return p.S > 0 ? launch_linear_nkc<NT, KB, true>(p, threads, lds, st) : launch_linear_nkc<NT, KB, false>(p, threads, lds, st);
 }
 template <int NT, int KT>
 hipError_t launch_wgrad_nk(const WgParams& p, size_t lds, hipStream_t st) {
@@ -370,8 +393,8 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
 static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
-    const size_t w_bytes = ((size_t)NT * 16 * p.kp + NT * 16) * 4;
-    const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n) * 4;
+    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16) * 4;
+    const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB) / 64;
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
     const size_t lds = w_bytes + waves * strip_bytes;
@@ -420,8 +443,8 @@ extern "C" int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_t
                                           void* stream) {
     const char* fn = "dgn_linear_combine_forward";
     const int n = n_scalers * f_out;
-    if (n_rows < 0 || n_towers < 1 || n_scalers < 1 || f_out < 1 || !dgn_linear_supported(k, n, 0)) {
-        set_error("%s: need even k and n_scalers * f_out in [2, 160] (k=%d n=%d)", fn, k, n);
+    if (n_rows < 0 || n_towers < 1 || n_scalers < 1 || n_scalers > 3 || f_out < 1 || !dgn_linear_supported(k, n, 0)) {
+        set_error("%s: need even k and n_scalers * f_out in [2, 160], at most 3 scalers (k=%d n=%d)", fn, k, n);
         return -1;
     }
     if (n_rows == 0) return 0;
