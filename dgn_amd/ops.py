@@ -588,10 +588,18 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _TsLinear.apply(x, weight, bias)
 
 
+# Below this many rows a product goes to the library GEMM: the streaming kernels spend ~10 us staging the weights in LDS,
+# which only pays off once there are enough 16-row strips to stream (a 128-molecule batch has ~3 000 rows: 9 products
+# of a captured towers step cost 0.26 ms on these kernels, 0.20 ms on the library's).
+LINEAR_MIN_ROWS = int(os.environ.get("DGN_LINEAR_MIN_ROWS", "8192"))
+
+
 def node_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Whether ``node_linear`` runs this product on the streaming kernels (fp32 on the GPU, even widths up to 160)."""
+    """Whether ``node_linear`` runs this product on the streaming kernels (fp32 on the GPU, even widths up to 160, at least
+    ``LINEAR_MIN_ROWS`` rows)."""
     return bool(x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == weight.dim() and x.dim() in (2, 3)
-                and x.shape[-2] > 0 and os.environ.get("DGN_LIBRARY_GEMM") != "1" and linear_supported(x.shape[-1], weight.shape[-2]))
+                and x.shape[-2] >= LINEAR_MIN_ROWS and os.environ.get("DGN_LIBRARY_GEMM") != "1"
+                and linear_supported(x.shape[-1], weight.shape[-2]))
 
 
 def node_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

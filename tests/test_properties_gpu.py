@@ -145,8 +145,11 @@ def test_row_sharded_graph_equals_whole_graph():
     torch.testing.assert_close(gs, g_src, rtol=1e-5, atol=1e-5)                     # partial sums are added in another order
 
 
-def test_headline_config_layer_vs_oracle_on_molecules():
-    """BASELINE configs[1] exactly as bench.py runs it (towers, hidden 70, 5 aggregators x 3 scalers, graph norm, batch
+@pytest.mark.parametrize("linear_min_rows", [0, 1 << 40], ids=["streaming-linear", "library-gemm"])
+def test_headline_config_layer_vs_oracle_on_molecules(monkeypatch, linear_min_rows):
+    """(Both routes of the dense products: the streaming dgn_linear_* kernels incl. the fused posttrans + combine +
+    BatchNorm node, which full-size batches take, and the library GEMMs small batches take.)
+    BASELINE configs[1] exactly as bench.py runs it (towers, hidden 70, 5 aggregators x 3 scalers, graph norm, batch
     norm, residual, training mode) on 256 ZINC-like molecules -- short-row kernels, fused operands, fused tails --
     against the reference-structured oracle: output, input gradient, every parameter gradient, BN statistics.
     Gradients are anchored on an fp64 evaluation of the same oracle: a handful of max/min/|.| routings flip between
@@ -155,6 +158,7 @@ def test_headline_config_layer_vs_oracle_on_molecules():
     import dgn_amd
     from dgn_amd import synth
     from oracle import dgn_oracle as orc
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", linear_min_rows)
     dev = torch.device("cuda")
     b = synth.molecule_batch(256, seed=41, laplacian_eig=False)
     src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
