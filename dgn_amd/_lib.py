@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -24,7 +24,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
-           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
+           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
 
 
 class DgnGraph(C.Structure):
@@ -138,6 +138,13 @@ def load() -> C.CDLL:
         lib.dgn_linear_combine_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                    C.c_void_p]
+        lib.dgn_linear_combine_backward_input.restype = C.c_int
+        lib.dgn_linear_combine_backward_input.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dgn_linear_combine_backward_weight.restype = C.c_int
+        lib.dgn_linear_combine_backward_weight.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                           C.c_size_t, C.c_void_p]
         lib.dgn_linear_wgrad_workspace_bytes.restype = C.c_size_t
         lib.dgn_linear_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32]
         lib.dgn_linear_wgrad.restype = C.c_int

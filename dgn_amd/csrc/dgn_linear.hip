@@ -26,9 +26,15 @@ constexpr int kStrip = 16;          // rows per strip = one MFMA tile edge
 constexpr int kMaxTiles = 10;       // k, n <= 160
 constexpr int kLdsBudget = 160 * 1024;
 constexpr int kFacFloats = 2 * kStrip * 4;
-constexpr int kMaxWgradTiles = 50;  // accumulator tiles (4 registers each) one wave can hold for the weight gradient
+constexpr int kMaxWgradTiles = 45;  // accumulator tiles (4 registers each) one wave can hold for the weight gradient
 
 __host__ __device__ inline int lds_stride(int k) { return ((k + 15) / 16) * 16 + 4; }   // == 4 mod 8: spreads rows over banks
+
+struct ExpandSrc {
+    const float* gy; int64_t sT;                     // [T][M][fo] dense rows, sT between towers
+    const float* sc;                                 // [M][S] or null
+    int S, fo;
+};
 
 struct LinParams {
     int64_t M;
@@ -39,6 +45,7 @@ struct LinParams {
     float* C; int64_t sC;                            // dense rows: [M][n]
     int groups;                                      // workgroups per batch entry
     int dbg;
+    ExpandSrc ex;                                    // kExpand: A is formed from ex (A, sA unused)
     // scale-combine epilogue (S > 0): y[m][t*fo + o] = rs[m] * (cb[t*fo + o] + sum_s sc[m][s] * c[t][m][s*fo + o]); C is not written
     int S, fo;
     const float* sc; const float* rs; const float* cb;
@@ -70,8 +77,48 @@ __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], 
         if (j * 64 + lane < kStrip * (k >> 1)) reinterpret_cast<float2*>(Xl)[j * 64 + lane] = pre[j];
 }
 
-template <int NT, int KB, bool COMBINE>
+
+// "Expanded" strips: the operand is not in memory but G[t][m][s*fo + o] = scale[m][s] * gy[t][m][o] -- the gradient of the
+// posttrans product behind the scale-combine -- formed while the strip is staged.  gy is tower-major, so a strip's 16 * fo
+// floats are one contiguous run; they and the rows' scale factors travel as the prefetch.  NL covers the expanded width:
+// loads past the run repeat its last element (one cache line).
+template <int NL>
+__device__ __forceinline__ void load_expand(float2 (&pre)[NL], f4& fac, const ExpandSrc& e, int t, int64_t M, int64_t strip, int lane) {
+    const int64_t row0 = strip * kStrip;
+    const float2* base = reinterpret_cast<const float2*>(e.gy + t * e.sT + row0 * e.fo);        // wave-uniform; 16 * fo contiguous floats
+    const int last = (int)min((int64_t)kStrip, M - row0) * (e.fo >> 1) - 1;
+#pragma unroll
+    for (int j = 0; j < (NL + 1) / 2; ++j) pre[j] = base[min(j * 64 + lane, last)];     // S >= 2: the run is at most half the expanded width
+    const int64_t row = min(row0 + (lane & 15), M - 1);
+    const float* scp = e.sc ? e.sc + row * e.S : e.gy;       // (branch-free: see ts_linear)
+    const float f0 = scp[0], f1 = scp[min(1, e.S - 1)], f2 = scp[min(2, e.S - 1)];
+    fac = f4{e.sc ? f0 : 1.f, e.sc ? f1 : 1.f, e.sc ? f2 : 1.f, 0.f};
+}
+// Xl: [16][S*fo]; Fl: 16 x f4 scratch of this wave.  Rows >= rows_valid become zero.
+template <int NL>
+__device__ __forceinline__ void store_expand(float* Xl, float* Fl, const float2 (&pre)[NL], const f4& fac, const ExpandSrc& e,
+                                             int rows_valid, int lane) {
+    if (lane < 16) *reinterpret_cast<f4*>(Fl + 4 * lane) = fac;
+    const int fo2 = e.fo >> 1, width = e.S * e.fo;
+#pragma unroll
+    for (int j = 0; j < (NL + 1) / 2; ++j) {
+        const int idx = j * 64 + lane, r = idx / fo2, o2 = idx - r * fo2;
+        if (idx < kStrip * fo2) {
+            const f4 f = *reinterpret_cast<const f4*>(Fl + 4 * r);
+            const float2 v = r < rows_valid ? pre[j] : make_float2(0.f, 0.f);
+            float* d = Xl + r * width + 2 * o2;
+            *reinterpret_cast<float2*>(d) = make_float2(v.x * f[0], v.y * f[0]);
+            if (e.S > 1) *reinterpret_cast<float2*>(d + e.fo) = make_float2(v.x * f[1], v.y * f[1]);
+            if (e.S > 2) *reinterpret_cast<float2*>(d + 2 * e.fo) = make_float2(v.x * f[2], v.y * f[2]);
+        }
+    }
+}
+
+enum { kPlain = 0, kCombine = 1, kExpand = 2 };        // ts_linear variants
+
+template <int NT, int KB, int MODE>
 __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p) {
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -101,7 +148,11 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
         const float f0 = scp[0], f1 = scp[min(1, S1 - 1)], f2 = scp[min(2, S1 - 1)], f3 = *rsp;
         fac = f4{p.sc ? f0 : 1.f, p.sc ? f1 : 1.f, p.sc ? f2 : 1.f, p.rs ? f3 : 1.f};
     };
-    if (first < n_strips) { load_strip<NL>(pre, A, p.M, k, first, lane); load_fac(first); }      // in flight while the weights are set up
+    auto fetch = [&](int64_t strip) {
+        if constexpr (EXPAND) load_expand<NL>(pre, fac, p.ex, t, p.M, strip, lane);
+        else { load_strip<NL>(pre, A, p.M, k, strip, lane); load_fac(strip); }
+    };
+    if (first < n_strips) fetch(first);              // in flight while the weights are set up
 
     for (int i = tid; i < NT * 16 * kp + 2 * NT * 16; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
@@ -148,10 +199,11 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
             if (j * 64 + lane < cnt2) reinterpret_cast<float2*>(dst)[j * 64 + lane] = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
-        store_strip<NL>(Xl, pre, k, lane);
+        if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
+        else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
-        if (strip + step < n_strips && !(p.dbg & 4)) { load_strip<NL>(pre, A, p.M, k, strip + step, lane); load_fac(strip + step); }
+        if (strip + step < n_strips && !(p.dbg & 4)) fetch(strip + step);
 
         f4 acc[NT];
 #pragma unroll
@@ -199,21 +251,23 @@ struct WgParams {
     float* part;                                     // [T][slots][NT*16][KT*16]
     int groups;
     int ones;                                        // append a column of ones to X (k % 16 != 0)
+    ExpandSrc ex;                                    // EXPAND: G is formed from ex (G, sG unused)
 };
 
 // One wave = one partial sum of the whole [n, k] gradient over its strips (NT x KT accumulator tiles); four waves
 // per workgroup, one per SIMD.  MFMA: D[n][k] += G[m][n] * X[m][k] with the strip's rows as the reduction index
 // (m = 4*(lane/16) + s for the s-th instruction).  Columns past n / k of a strip row alias the next row: they only
 // reach accumulator entries that are never read.
-template <int NT, int KT>
+template <int NT, int KT, bool EXPAND>
 __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
     extern __shared__ float lds[];
     constexpr int NLG = 2 * NT, NLX = 2 * KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int t = blockIdx.x % p.T, grp = blockIdx.x / p.T;
     const int n = p.n, k = p.k;
-    float* Gl = lds + wave * (strip_floats(n) + strip_floats(k));
+    float* Gl = lds + wave * (strip_floats(n) + strip_floats(k) + 64);
     float* Xl = Gl + strip_floats(n);
+    float* Fl = Xl + strip_floats(k);                // 16 x f4 scale factors (EXPAND)
     for (int i = lane; i < strip_floats(n) + strip_floats(k); i += 64) Gl[i] = 0.f;
 
     const float* G = p.G + (int64_t)t * p.sG;
@@ -222,6 +276,11 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
     const int64_t first = (int64_t)grp * n_waves + wave, step = (int64_t)p.groups * n_waves;
 
     float2 pg[NLG], px[NLX];
+    f4 fac = f4{1.f, 1.f, 1.f, 0.f};
+    auto fetch_g = [&](int64_t strip) {
+        if constexpr (EXPAND) load_expand<NLG>(pg, fac, p.ex, t, p.M, strip, lane);
+        else load_strip<NLG>(pg, G, p.M, n, strip, lane);
+    };
     f4 acc[NT][KT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -230,20 +289,24 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
 
     const int i16 = lane & 15, mq = lane >> 4;
     if (first < n_strips) {
-        load_strip<NLG>(pg, G, p.M, n, first, lane);
+        fetch_g(first);
         load_strip<NLX>(px, X, p.M, k, first, lane);
     }
     for (int64_t strip = first; strip < n_strips; strip += step) {
         const int rows = (int)min((int64_t)kStrip, p.M - strip * kStrip);
-        if (rows < kStrip) {                         // rows past the end contribute zero
+        if constexpr (EXPAND) {
+            store_expand<NLG>(Gl, Fl, pg, fac, p.ex, rows, lane);
+        } else {
+            if (rows < kStrip) {                     // rows past the end contribute zero
 #pragma unroll
-            for (int j = 0; j < NLG; ++j)
-                if (j * 64 + lane >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
+                for (int j = 0; j < NLG; ++j)
+                    if (j * 64 + lane >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
+            }
+            store_strip<NLG>(Gl, pg, n, lane);
         }
-        store_strip<NLG>(Gl, pg, n, lane);
         store_strip<NLX>(Xl, px, k, lane);
         if (strip + step < n_strips) {
-            load_strip<NLG>(pg, G, p.M, n, strip + step, lane);
+            fetch_g(strip + step);
             load_strip<NLX>(px, X, p.M, k, strip + step, lane);
         }
 #pragma unroll
@@ -317,7 +380,7 @@ __global__ __launch_bounds__(256) void ts_wgrad_finalize(int T, int n, int k, in
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-template <int NT, int KB, bool COMBINE>
+template <int NT, int KB, int COMBINE>
 hipError_t launch_linear_nkc(const LinParams& p, int threads, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
@@ -331,21 +394,25 @@ hipError_t launch_linear_nkc(const LinParams& p, int threads, size_t lds, hipStr
 }
 template <int NT, int KB>
 hipError_t launch_linear_nk(const LinParams& p, int threads, size_t lds, hipStream_t st) {
-    return p.S > 0 ? launch_linear_nkc<NT, KB, true>(p, threads, lds, st) : launch_linear_nkc<NT, KB, false>(p, threads, lds, st);
+    if (p.ex.gy) return launch_linear_nkc<NT, KB, kExpand>(p, threads, lds, st);
+    return p.S > 0 ? launch_linear_nkc<NT, KB, kCombine>(p, threads, lds, st) : launch_linear_nkc<NT, KB, kPlain>(p, threads, lds, st);
 }
-template <int NT, int KT>
-hipError_t launch_wgrad_nk(const WgParams& p, size_t lds, hipStream_t st) {
-    if constexpr (NT * KT > kMaxWgradTiles) return hipErrorInvalidValue; else {
+template <int NT, int KT, bool EXPAND>
+hipError_t launch_wgrad_nke(const WgParams& p, size_t lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_wgrad<NT, KT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_wgrad<NT, KT, EXPAND>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((ts_wgrad<NT, KT>), dim3(p.T * p.groups), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((ts_wgrad<NT, KT, EXPAND>), dim3(p.T * p.groups), dim3(256), lds, st, p);
     return hipGetLastError();
-    }
+}
+template <int NT, int KT>
+hipError_t launch_wgrad_nk(const WgParams& p, size_t lds, hipStream_t st) {
+    if constexpr (NT * KT > kMaxWgradTiles) return hipErrorInvalidValue;
+    else return p.ex.gy ? launch_wgrad_nke<NT, KT, true>(p, lds, st) : launch_wgrad_nke<NT, KT, false>(p, lds, st);
 }
 
 template <int NT>
@@ -471,38 +538,17 @@ extern "C" size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, in
     return (size_t)batch * wgrad_groups(n_rows, k, n, batch) * NT * 16 * KT * 16 * sizeof(float);
 }
 
-extern "C" int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg,
-                                int64_t stride_g, const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw,
-                                int64_t stride_dw, float* dbias, int64_t stride_dbias, void* ws, size_t ws_bytes,
-                                void* stream) {
-    const char* fn = "dgn_linear_wgrad";
-    if (dbias && k % 16 == 0) { set_error("%s: the bias gradient rides in X's padding column (k %% 16 != 0)", fn); return -1; }
-    if (n_rows < 0 || batch < 1 || !dgn_linear_supported(k, n, 1)) { set_error("%s: need even k, n in [2, 160] and at most 50 tiles (k=%d n=%d)", fn, k, n); return -1; }
-    if (!dw) { set_error("%s: null output", fn); return -1; }
+static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, int64_t stride_dw, float* dbias, int64_t stride_dbias,
+                        void* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (n_rows == 0) {
-        for (int t = 0; t < batch; ++t) {
-            DGN_HIP_CHECK(hipMemset2DAsync(dw + t * stride_dw, lddw * 4, 0, (size_t)k * 4, (size_t)n, st));
-            if (dbias) DGN_HIP_CHECK(hipMemsetAsync(dbias + t * stride_dbias, 0, (size_t)n * 4, st));
-        }
-        return 0;
-    }
-    if (!g || !x) { set_error("%s: null operand", fn); return -1; }
-    if (ldg != n || ldx != k || (stride_g & 1) || (stride_x & 1) || !aligned8(g) || !aligned8(x)) {
-        set_error("%s: G and X must have dense rows (ldg == n, ldx == k) and 8-byte aligned batch entries", fn);
-        return -1;
-    }
-    const size_t need = dgn_linear_wgrad_workspace_bytes(n_rows, k, n, batch);
+    const int n = p.n, k = p.k, batch = p.T;
+    const size_t need = dgn_linear_wgrad_workspace_bytes(p.M, k, n, batch);
     if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return -1; }
-    WgParams p{};
-    p.M = n_rows; p.n = n; p.k = k; p.T = batch;
-    p.G = g; p.sG = stride_g;
-    p.X = x; p.sX = stride_x;
     p.part = static_cast<float*>(ws);
-    p.groups = wgrad_groups(n_rows, k, n, batch);
+    p.groups = wgrad_groups(p.M, k, n, batch);
     p.ones = dbias != nullptr;
     const int NT = (n + 15) / 16, KT = (k + 15) / 16;
-    const size_t lds = std::max((size_t)4 * (strip_floats(n) + strip_floats(k)), (size_t)NT * 16 * KT * 16) * 4;
+    const size_t lds = std::max((size_t)4 * (strip_floats(n) + strip_floats(k) + 64), (size_t)NT * 16 * KT * 16) * 4;
     hipError_t e = hipErrorInvalidValue;
     switch (NT) {
 #define DGN_CASE(N) case N: e = launch_wgrad_n<N>(KT, p, lds, st); break;
@@ -515,4 +561,84 @@ extern "C" int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t ba
                        NT * 16, KT * 16, p.part, dw, lddw, stride_dw, dbias, stride_dbias);
     DGN_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+static int zero_wgrad(float* dw, int64_t lddw, int64_t stride_dw, float* dbias, int64_t stride_dbias, int k, int n, int batch,
+                      hipStream_t st) {
+    for (int t = 0; t < batch; ++t) {
+        DGN_HIP_CHECK(hipMemset2DAsync(dw + t * stride_dw, lddw * 4, 0, (size_t)k * 4, (size_t)n, st));
+        if (dbias) DGN_HIP_CHECK(hipMemsetAsync(dbias + t * stride_dbias, 0, (size_t)n * 4, st));
+    }
+    return 0;
+}
+
+extern "C" int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg,
+                                int64_t stride_g, const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw,
+                                int64_t stride_dw, float* dbias, int64_t stride_dbias, void* ws, size_t ws_bytes,
+                                void* stream) {
+    const char* fn = "dgn_linear_wgrad";
+    if (dbias && k % 16 == 0) { set_error("%s: the bias gradient rides in X's padding column (k %% 16 != 0)", fn); return -1; }
+    if (n_rows < 0 || batch < 1 || !dgn_linear_supported(k, n, 1)) { set_error("%s: need even k, n in [2, 160] and at most 45 tiles (k=%d n=%d)", fn, k, n); return -1; }
+    if (!dw) { set_error("%s: null output", fn); return -1; }
+    if (n_rows == 0) return zero_wgrad(dw, lddw, stride_dw, dbias, stride_dbias, k, n, batch, static_cast<hipStream_t>(stream));
+    if (!g || !x) { set_error("%s: null operand", fn); return -1; }
+    if (ldg != n || ldx != k || (stride_g & 1) || (stride_x & 1) || !aligned8(g) || !aligned8(x)) {
+        set_error("%s: G and X must have dense rows (ldg == n, ldx == k) and 8-byte aligned batch entries", fn);
+        return -1;
+    }
+    WgParams p{};
+    p.M = n_rows; p.n = n; p.k = k; p.T = batch;
+    p.G = g; p.sG = stride_g;
+    p.X = x; p.sX = stride_x;
+    return launch_wgrad(fn, p, dw, lddw, stride_dw, dbias, stride_dbias, ws, ws_bytes, stream);
+}
+
+static bool expand_ok(const char* fn, int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* gy,
+                      int64_t stride_gy, const float* scale) {
+    if (n_rows < 0 || n_towers < 1 || n_scalers < 1 || n_scalers > 3 || f_out < 2 || (f_out & 1)) {
+        set_error("%s: need 1..3 scalers and an even f_out", fn);
+        return false;
+    }
+    if (n_rows > 0 && (!gy || (n_scalers > 1 && !scale) || (stride_gy & 1) || !aligned8(gy))) {
+        set_error("%s: gy must be [n_towers][n_rows][f_out] with 8-byte aligned towers; scale is required for more than one scaler", fn);
+        return false;
+    }
+    return true;
+}
+
+extern "C" int dgn_linear_combine_backward_input(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k,
+                                                 const float* gy, int64_t stride_gy, const float* scale, const float* w, int64_t ldw,
+                                                 int64_t stride_w, float* g_a, int64_t stride_ga, void* stream) {
+    const char* fn = "dgn_linear_combine_backward_input";
+    const int red = n_scalers * f_out;               // reduction width = rows of w[t]
+    if (!expand_ok(fn, n_rows, n_towers, n_scalers, f_out, gy, stride_gy, scale)) return -1;
+    if (!dgn_linear_supported(red, k, 0)) { set_error("%s: need even widths in [2, 160] (S*f_out=%d k=%d)", fn, red, k); return -1; }
+    if (n_rows == 0) return 0;
+    if (!w || !g_a || (stride_ga & 1) || !aligned8(g_a)) { set_error("%s: null or misaligned operand", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = red; p.n = k; p.T = n_towers;
+    p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = 1;
+    p.C = g_a; p.sC = stride_ga;
+    if (n_scalers == 1) { p.A = gy; p.sA = stride_gy; }      // nothing to expand: gy is the operand
+    else { p.ex.gy = gy; p.ex.sT = stride_gy; p.ex.sc = scale; p.ex.S = n_scalers; p.ex.fo = f_out; }
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_combine_backward_weight(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k,
+                                                  const float* gy, int64_t stride_gy, const float* scale, const float* a,
+                                                  int64_t stride_a, float* dw, int64_t lddw, int64_t stride_dw, void* ws,
+                                                  size_t ws_bytes, void* stream) {
+    const char* fn = "dgn_linear_combine_backward_weight";
+    const int n = n_scalers * f_out;
+    if (!expand_ok(fn, n_rows, n_towers, n_scalers, f_out, gy, stride_gy, scale)) return -1;
+    if (!dgn_linear_supported(k, n, 1)) { set_error("%s: need even widths in [2, 160] and at most 45 tiles (k=%d S*f_out=%d)", fn, k, n); return -1; }
+    if (!dw) { set_error("%s: null output", fn); return -1; }
+    if (n_rows == 0) return zero_wgrad(dw, lddw, stride_dw, nullptr, 0, k, n, n_towers, static_cast<hipStream_t>(stream));
+    if (!a || (stride_a & 1) || !aligned8(a)) { set_error("%s: null or misaligned operand", fn); return -1; }
+    WgParams p{};
+    p.M = n_rows; p.n = n; p.k = k; p.T = n_towers;
+    p.X = a; p.sX = stride_a;
+    if (n_scalers == 1) { p.G = gy; p.sG = stride_gy; }
+    else { p.ex.gy = gy; p.ex.sT = stride_gy; p.ex.sc = scale; p.ex.S = n_scalers; p.ex.fo = f_out; }
+    return launch_wgrad(fn, p, dw, lddw, stride_dw, nullptr, 0, ws, ws_bytes, stream);
 }

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
 from .ops import (bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, linear_combine_bn_tail,
-                  node_linear, node_linear_supported, scale_combine)
+                  linear_combine_supported, node_linear, scale_combine)
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -504,7 +504,7 @@ class DGNLayerTower(nn.Module):
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             bns = [t.batchnorm_h for t in self.towers]
             fused_tail = self.batch_norm and self.training and bn_tail_supported(bns, aggx, True, T * fo)
-            if fused_tail and node_linear_supported(aggx, ops["w"]):
+            if fused_tail and linear_combine_supported(aggx, ops["w"], S):
                 rm, rv, nbt = self._linked_bn_stats(aggx.device)                                   # posttrans + combine + BatchNorm: one autograd node
                 y = linear_combine_bn_tail(aggx, ops["w"], sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt,
                                            bns[0].momentum, bns[0].eps)

@@ -568,7 +568,7 @@ _LIN_OK = {}
 
 def linear_supported(k: int, n: int) -> bool:
     """Whether ``linear`` takes an [*, k] x [n, k] product: even widths up to 160 (forward, input gradient, and a
-    weight gradient of at most 50 16x16 tiles).  Otherwise use ``F.linear``."""
+    weight gradient of at most 45 16x16 tiles).  Otherwise use ``F.linear``."""
     key = (int(k), int(n))
     if key not in _LIN_OK:
         lib = _lib.load()
@@ -669,19 +669,52 @@ class _LinCombineBNTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        aggx, w = ctx.saved_tensors[7:]
-        ctx_like = type("Ctx", (), {})()
-        ctx_like.saved_tensors = ctx.saved_tensors[:7]
-        ctx_like.dims = ctx.dims
-        ctx_like.needs_input_grad = (True, False, ctx.needs_input_grad[3])
-        g_z, _, g_b, _, g_gamma, g_beta, _, _, _, _, _, g_res = _CombineBNTail.backward(ctx_like, g_out)
-        g_aggx = _lin_fwd(lib, g_z, w, True, None, aggx.shape[2]) if ctx.needs_input_grad[0] else None
-        g_w = _lin_wgrad(lib, g_z, aggx, False)[0] if ctx.needs_input_grad[1] else None
-        return g_aggx, g_w, None, g_b, None, g_gamma, g_beta, None, None, None, None, None, g_res
+        scale, row_scale, y, gamma, beta, save_mean, save_invstd, aggx, w = ctx.saved_tensors
+        T, N, S, fo, has_bias, relu, has_res = ctx.dims
+        F, k = T * fo, aggx.shape[2]
+        dev = y.device
+        g_out = g_out.contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        g_gamma = torch.empty(F, dtype=torch.float32, device=dev) if gamma is not None else None
+        g_beta = torch.empty(F, dtype=torch.float32, device=dev) if beta is not None else None
+        sums = torch.empty(2 * F, dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
+        ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        rc = lib.dgn_bn_tail_backward(N, F, g_out.data_ptr(), y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 1 if relu else 0, None, _ptr(g_gamma), _ptr(g_beta), sums.data_ptr(),
+                                      ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc, "dgn_bn_tail_backward")
+        bn = _lib.DgnBnGrad(g_out=g_out.data_ptr(), y=y.data_ptr(), ld=y.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
+                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0)
+        # g_yr = row_scale * (BatchNorm backward of g_out), tower-major [T, N, fo]: the combine backward run with ONE scaler and
+        # no scale table; the per-scaler expansion happens inside the two products below
+        g_yr = torch.empty((T, N, fo), dtype=torch.float32, device=dev)
+        g_b = torch.zeros(F, dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[3]) else None
+        ws2_bytes = lib.dgn_scale_combine_backward_workspace_bytes(N, T, fo) if g_b is not None else 0
+        ws2 = torch.empty(ws2_bytes // 4, dtype=torch.float32, device=dev) if ws2_bytes else None
+        rc = lib.dgn_scale_combine_backward(N, T, 1, fo, None, 0, None, _ptr(row_scale), g_yr.data_ptr(), _ptr(g_b), _ptr(ws2),
+                                            ws2_bytes, C.byref(bn), stream)
+        _lib.check(rc, "dgn_scale_combine_backward")
+        g_aggx = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_aggx = torch.empty_like(aggx)
+            rc = lib.dgn_linear_combine_backward_input(N, T, S, fo, k, g_yr.data_ptr(), g_yr.stride(0), _ptr(scale), w.data_ptr(), w.stride(1),
+                                                       w.stride(0), g_aggx.data_ptr(), g_aggx.stride(0), stream)
+            _lib.check(rc, "dgn_linear_combine_backward_input")
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty_like(w)
+            ws3_bytes = lib.dgn_linear_wgrad_workspace_bytes(N, k, S * fo, T)
+            ws3 = torch.empty(max(ws3_bytes // 4, 1), dtype=torch.float32, device=dev)
+            rc = lib.dgn_linear_combine_backward_weight(N, T, S, fo, k, g_yr.data_ptr(), g_yr.stride(0), _ptr(scale), aggx.data_ptr(), aggx.stride(0),
+                                                        g_w.data_ptr(), k, S * fo * k, ws3.data_ptr(), ws3_bytes, stream)
+            _lib.check(rc, "dgn_linear_combine_backward_weight")
+        return g_aggx, g_w, None, g_b, None, g_gamma, g_beta, None, None, None, None, None, (g_out if has_res else None)
 
 
-def linear_combine_supported(k: int, n: int) -> bool:
-    return linear_supported(k, n)
+def linear_combine_supported(aggx: torch.Tensor, w: torch.Tensor, n_scalers: int) -> bool:
+    """Whether ``linear_combine_bn_tail`` takes this posttrans product: the streaming kernels apply, at most 3 scalers,
+    an even per-tower output width."""
+    return node_linear_supported(aggx, w) and 1 <= n_scalers <= 3 and w.shape[-2] % n_scalers == 0 and (w.shape[-2] // n_scalers) % 2 == 0
 
 
 def linear_combine_bn_tail(aggx, w, scale, bias, row_scale, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,

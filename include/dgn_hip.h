@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 8
+#define DGN_ABI_VERSION 9
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -275,7 +275,7 @@ int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y, const flo
  *                        product with an extra column of ones in x's tile padding, at no extra pass)
  * Exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain); the weight gradient is summed over per-wave partials in a fixed
  * order (bitwise reproducible).  dgn_linear_supported(k, n) says whether the pair is handled (even, <= 160, and for
- * the weight gradient at most 50 16x16 tiles); callers use a library GEMM otherwise.  stride_* are element offsets
+ * the weight gradient at most 45 16x16 tiles); callers use a library GEMM otherwise.  stride_* are element offsets
  * between batch entries (towers).  `ws` of dgn_linear_wgrad_workspace_bytes(...) bytes holds the partials.           */
 int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad);
 int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* a, int64_t lda, int64_t stride_a,
@@ -289,6 +289,20 @@ int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, cons
 int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* a,
                                int64_t stride_a, const float* w, int64_t ldw, int64_t stride_w, const float* scale,
                                const float* bias, const float* row_scale, float* y, int64_t ld_y, void* stream);
+/* Backward of dgn_linear_combine_forward without the [T, N, S*f_out] gradient in memory.  With
+ *   G[t][m][s*f_out + o] = scale[m, s] * gy[t][m][o]
+ * (gy [T][n_rows][f_out], stride_gy between towers = row_scale * the gradient of the combine's output in tower-major form,
+ * i.e. what dgn_scale_combine_backward writes when called with ONE scaler and no scale table) the two products are formed
+ * while the strips are staged:
+ *   dgn_linear_combine_backward_input    g_a[t] = G[t] . w[t]        [n_rows, k]   (w[t]: [S*f_out, k])
+ *   dgn_linear_combine_backward_weight   dw[t]  = G[t]^T . a[t]      [S*f_out, k]  (ws as for dgn_linear_wgrad with n = S*f_out)
+ * f_out even, at most 3 scalers, widths as for dgn_linear_forward / dgn_linear_wgrad.                                */
+int dgn_linear_combine_backward_input(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
+                                      int64_t stride_gy, const float* scale, const float* w, int64_t ldw, int64_t stride_w, float* g_a,
+                                      int64_t stride_ga, void* stream);
+int dgn_linear_combine_backward_weight(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
+                                       int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
+                                       int64_t stride_dw, void* ws, size_t ws_bytes, void* stream);
 size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, int32_t batch);
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
