@@ -13,7 +13,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "dgn_common.hpp"
 
@@ -44,7 +43,6 @@ struct LinParams {
     const float* bias; int64_t sBias;
     float* C; int64_t sC;                            // dense rows: [M][n]
     int groups;                                      // workgroups per batch entry
-    int dbg;
     ExpandSrc ex;                                    // kExpand: A is formed from ex (A, sA unused)
     // scale-combine epilogue (S > 0): y[m][t*fo + o] = rs[m] * (cb[t*fo + o] + sum_s sc[m][s] * c[t][m][s*fo + o]); C is not written
     int S, fo;
@@ -178,7 +176,6 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     int64_t out_strip = -1;
     int it = 0, out_it = 0;
     auto store_out = [&]() {
-        if (p.dbg & 1) return;
         if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
             const int cnt = (int)min((int64_t)kStrip, p.M - row0) * p.fo;
@@ -203,13 +200,13 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
-        if (strip + step < n_strips && !(p.dbg & 4)) fetch(strip + step);
+        if (strip + step < n_strips) fetch(strip + step);
 
         f4 acc[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] = *reinterpret_cast<const f4*>(Bl + 16 * q + 4 * g);
 #pragma unroll 1
-        for (int b = 0; b < ((p.dbg & 2) ? 0 : KB); ++b) {
+        for (int b = 0; b < KB; ++b) {               // 16-k blocks: lane group g takes k = 16b + 4g + s in the s-th MFMA
             f4 xv;
             if (k4) {
                 xv = *reinterpret_cast<const f4*>(xrow + 16 * b);
@@ -471,7 +468,6 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     int groups = std::max(1, n_cus() * per_cu / p.T);
     groups = (int)std::min<int64_t>(groups, (n_strips + waves - 1) / waves);
     p.groups = groups;
-    { const char* d = getenv("DGN_LIN_DBG"); p.dbg = d ? atoi(d) : 0; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipErrorInvalidValue;
     switch (NT) {
