@@ -1,0 +1,458 @@
+// Tall-skinny fp32 Linear for the layer's pre/post-aggregation transforms (see include/dgn_hip.h, dgn_linear_*):
+//   forward / input gradient   C[t] = A[t] . W[t]^T (+ bias)     A: [M, k] with M = number of nodes, k, n <= 160
+//   weight gradient            dW[t] = G[t]^T . X[t]             reduction over the M rows
+// The reference does these with nn.Linear inside its pretrans/posttrans MLPs (layers.py:101-112 via
+// nets/dgn_layer.py:67-75,116-119).  On ZINC-sized batches M is ~3e5 while k and n are 42..140: a library GEMM
+// spends its time in per-tile prologues of a 5-iteration K loop, and picks a different (often 3x slower) kernel for
+// every new M.  Here the whole weight matrix sits in LDS for the life of a persistent workgroup and the rows stream
+// through: every wave owns 16-row strips, copies a strip global -> registers -> its private LDS slice with
+// contiguous 8-byte lanes (the next strip's loads are in flight while the current one is multiplied), and feeds
+// v_mfma_f32_16x16x4_f32 (exact fp32) from LDS.  The product is formed transposed (D[n][m]) so that a lane ends up
+// with four consecutive output columns of one row: 16-byte stores.  The reduction index is visited in the order
+// k = 16b + 4*(lane/16) + s, which lets a lane fetch its four operands of a 16-k block with one ds_read_b128.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "dgn_common.hpp"
+
+namespace dgn {
+namespace lin {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kStrip = 16;          // rows per strip = one MFMA tile edge
+constexpr int kMaxTiles = 10;       // k, n <= 160
+constexpr int kLdsBudget = 160 * 1024;
+constexpr int kFacFloats = 2 * kStrip * 4;
+constexpr int kMaxWgradTiles = 45;  // accumulator tiles (4 registers each) one wave can hold for the weight gradient
+
+__host__ __device__ inline int lds_stride(int k) { return ((k + 15) / 16) * 16 + 4; }   // == 4 mod 8: spreads rows over banks
+
+struct ExpandSrc {
+    const float* gy; int64_t sT;                     // [T][M][fo] dense rows, sT between towers
+    const float* sc;                                 // [M][S] or null
+    int S, fo;
+};
+
+struct LinParams {
+    int64_t M;
+    int k, n, T, kp;
+    const float* A; int64_t sA;                      // dense rows: [M][k]
+    const float* W; int64_t ldw, sW; int w_kn;      // 0: W[n][k] (C = A W^T)   1: W[k][n] (C = A W)
+    const float* bias; int64_t sBias;
+    float* C; int64_t sC;                            // dense rows: [M][n]
+    int groups;                                      // workgroups per batch entry
+    ExpandSrc ex;                                    // kExpand: A is formed from ex (A, sA unused)
+    // scale-combine epilogue (S > 0): y[m][t*fo + o] = rs[m] * (cb[t*fo + o] + sum_s sc[m][s] * c[t][m][s*fo + o]); C is not written
+    int S, fo;
+    const float* sc; const float* rs; const float* cb;
+    float* Y; int64_t ldy;
+};
+
+// registers a lane needs: accumulators + one block of W operands + the prefetched strip
+constexpr int linear_threads(int NT, int KB) { return 8 * NT + 4 * KB + 52 <= 116 ? 1024 : 512; }
+__host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
+
+// A strip is 16 * k consecutive floats of A (rows are dense: lda == k), copied as float2 number j * 64 + lane.
+template <int NL>
+__device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane) {
+    const int64_t row0 = strip * kStrip;
+    const float2* base = reinterpret_cast<const float2*>(A + row0 * k);          // wave-uniform
+    const int n2 = (int)min((int64_t)kStrip, M - row0) * (k >> 1);               // float2's that exist
+    if (n2 == kStrip * (k >> 1) && NL * 64 <= n2) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) pre[j] = base[j * 64 + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) pre[j] = base[min(j * 64 + lane, n2 - 1)];
+    }
+}
+template <int NL>
+__device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], int k, int lane) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+        if (j * 64 + lane < kStrip * (k >> 1)) reinterpret_cast<float2*>(Xl)[j * 64 + lane] = pre[j];
+}
+
+
+// "Expanded" strips: the operand is not in memory but G[t][m][s*fo + o] = scale[m][s] * gy[t][m][o] -- the gradient of the
+// posttrans product behind the scale-combine -- formed while the strip is staged.  gy is tower-major, so a strip's 16 * fo
+// floats are one contiguous run; they and the rows' scale factors travel as the prefetch.  NL covers the expanded width:
+// loads past the run repeat its last element (one cache line).
+template <int NL>
+__device__ __forceinline__ void load_expand(float2 (&pre)[NL], f4& fac, const ExpandSrc& e, int t, int64_t M, int64_t strip, int lane) {
+    const int64_t row0 = strip * kStrip;
+    const float2* base = reinterpret_cast<const float2*>(e.gy + t * e.sT + row0 * e.fo);        // wave-uniform; 16 * fo contiguous floats
+    const int last = (int)min((int64_t)kStrip, M - row0) * (e.fo >> 1) - 1;
+#pragma unroll
+    for (int j = 0; j < (NL + 1) / 2; ++j) pre[j] = base[min(j * 64 + lane, last)];     // S >= 2: the run is at most half the expanded width
+    const int64_t row = min(row0 + (lane & 15), M - 1);
+    const float* scp = e.sc ? e.sc + row * e.S : e.gy;       // (branch-free: see ts_linear)
+    const float f0 = scp[0], f1 = scp[min(1, e.S - 1)], f2 = scp[min(2, e.S - 1)];
+    fac = f4{e.sc ? f0 : 1.f, e.sc ? f1 : 1.f, e.sc ? f2 : 1.f, 0.f};
+}
+// Xl: [16][S*fo]; Fl: 16 x f4 scratch of this wave.  Rows >= rows_valid become zero.
+template <int NL>
+__device__ __forceinline__ void store_expand(float* Xl, float* Fl, const float2 (&pre)[NL], const f4& fac, const ExpandSrc& e,
+                                             int rows_valid, int lane) {
+    if (lane < 16) *reinterpret_cast<f4*>(Fl + 4 * lane) = fac;
+    const int fo2 = e.fo >> 1, width = e.S * e.fo;
+#pragma unroll
+    for (int j = 0; j < (NL + 1) / 2; ++j) {
+        const int idx = j * 64 + lane, r = idx / fo2, o2 = idx - r * fo2;
+        if (idx < kStrip * fo2) {
+            const f4 f = *reinterpret_cast<const f4*>(Fl + 4 * r);
+            const float2 v = r < rows_valid ? pre[j] : make_float2(0.f, 0.f);
+            float* d = Xl + r * width + 2 * o2;
+            *reinterpret_cast<float2*>(d) = make_float2(v.x * f[0], v.y * f[0]);
+            if (e.S > 1) *reinterpret_cast<float2*>(d + e.fo) = make_float2(v.x * f[1], v.y * f[1]);
+            if (e.S > 2) *reinterpret_cast<float2*>(d + 2 * e.fo) = make_float2(v.x * f[2], v.y * f[2]);
+        }
+    }
+}
+
+enum { kPlain = 0, kCombine = 1, kExpand = 2 };        // ts_linear variants
+
+template <int NT, int KB, int MODE>
+__global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p) {
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand;
+    extern __shared__ float lds[];
+    constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
+    constexpr int NLC = 2 * NT;                      // the same for a strip of C
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int t = blockIdx.x % p.T, grp = blockIdx.x / p.T;
+    const int kp = p.kp, k = p.k, n = p.n;
+    float* Wl = lds;                                 // [NT*16][kp], zero beyond (n, k)
+    float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
+    float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
+    float* Xl = Cb + NT * 16 + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
+    float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
+    float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
+
+    const float* A = p.A + (int64_t)t * p.sA;
+    float* C = p.C + (int64_t)t * p.sC;
+    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
+    const int64_t first = (int64_t)grp * n_waves + wave, step = (int64_t)p.groups * n_waves;
+    float2 pre[NL];
+    f4 fac = f4{1.f, 1.f, 1.f, 1.f};                 // the combine epilogue's row factors travel with the strip's prefetch
+    // (branch-free: a conditional load would make the compiler wait for everything in flight where the branches join)
+    const int S1 = COMBINE ? p.S : 1;
+    auto load_fac = [&](int64_t strip) {
+        if constexpr (!COMBINE) return;
+        const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
+        const float* scp = p.sc ? p.sc + row * S1 : A;
+        const float* rsp = p.rs ? p.rs + row : A;
+        const float f0 = scp[0], f1 = scp[min(1, S1 - 1)], f2 = scp[min(2, S1 - 1)], f3 = *rsp;
+        fac = f4{p.sc ? f0 : 1.f, p.sc ? f1 : 1.f, p.sc ? f2 : 1.f, p.rs ? f3 : 1.f};
+    };
+    auto fetch = [&](int64_t strip) {
+        if constexpr (EXPAND) load_expand<NL>(pre, fac, p.ex, t, p.M, strip, lane);
+        else { load_strip<NL>(pre, A, p.M, k, strip, lane); load_fac(strip); }
+    };
+    if (first < n_strips) fetch(first);              // in flight while the weights are set up
+
+    for (int i = tid; i < NT * 16 * kp + 2 * NT * 16; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    const float* Wg = p.W + (int64_t)t * p.sW;
+    for (int i = tid; i < n * k; i += blockDim.x) {
+        int r, c;                                    // r: output column, c: reduction index
+        if (p.w_kn) { c = i / n; r = i - c * n; } else { r = i / k; c = i - r * k; }
+        Wl[r * kp + c] = p.w_kn ? Wg[(int64_t)c * p.ldw + r] : Wg[(int64_t)r * p.ldw + c];
+    }
+    if (p.bias) for (int i = tid; i < n; i += blockDim.x) Bl[i] = p.bias[(int64_t)t * p.sBias + i];
+    if (COMBINE && p.cb) for (int i = tid; i < p.fo; i += blockDim.x) Cb[i] = p.cb[t * p.fo + i];
+    __syncthreads();
+
+    const int m = lane & 15, g = lane >> 4;
+    const float* xrow = Xl + m * k + 4 * g;
+    const float* wrow = Wl + m * kp + 4 * g;
+    const bool k4 = (k & 3) == 0;
+    // lane (m, g) holds C[row0 + m][16q + 4g .. + 3].  A strip's results are stored one iteration late, right before the
+    // loads of the strip after next are issued: loads and stores retire through one in-order counter, so a wave that
+    // stored at the end of an iteration would sit out the store acknowledgement (~2.5 us) before touching its prefetch.
+    // They wait in LDS, from where the strip's 16 * n floats leave as one contiguous run (C's rows are dense)
+    // (8-byte pieces with gaps, straight from the accumulators, ran at half the store rate).
+    int64_t out_strip = -1;
+    int it = 0, out_it = 0;
+    auto store_out = [&]() {
+        if constexpr (COMBINE) {
+            const int64_t row0 = out_strip * kStrip;
+            const int cnt = (int)min((int64_t)kStrip, p.M - row0) * p.fo;
+            const float* F = Fl + (out_it & 1) * (kStrip * 4);
+            for (int idx = lane; idx < cnt; idx += 64) {
+                const int r = idx / p.fo, o = idx - r * p.fo;
+                const f4 f = *reinterpret_cast<const f4*>(F + 4 * r);
+                float v = Cb[o];
+                for (int s = 0; s < p.S; ++s) v += f[s] * Cl[r * n + s * p.fo + o];
+                p.Y[(row0 + r) * p.ldy + t * p.fo + o] = v * f[3];
+            }
+            return;
+        }
+        const int cnt2 = (int)min((int64_t)kStrip, p.M - out_strip * kStrip) * (n >> 1);
+        float* dst = C + out_strip * kStrip * n;
+#pragma unroll
+        for (int j = 0; j < NLC; ++j)
+            if (j * 64 + lane < cnt2) reinterpret_cast<float2*>(dst)[j * 64 + lane] = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+    };
+    for (int64_t strip = first; strip < n_strips; strip += step) {
+        if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
+        else store_strip<NL>(Xl, pre, k, lane);
+        if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
+        if (out_strip >= 0) store_out();
+        if (strip + step < n_strips) fetch(strip + step);
+
+        f4 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = *reinterpret_cast<const f4*>(Bl + 16 * q + 4 * g);
+#pragma unroll 1
+        for (int b = 0; b < KB; ++b) {               // 16-k blocks: lane group g takes k = 16b + 4g + s in the s-th MFMA
+            f4 xv;
+            if (k4) {
+                xv = *reinterpret_cast<const f4*>(xrow + 16 * b);
+            } else {
+                const float2 lo = *reinterpret_cast<const float2*>(xrow + 16 * b), hi = *reinterpret_cast<const float2*>(xrow + 16 * b + 2);
+                xv = f4{lo.x, lo.y, hi.x, hi.y};
+            }
+            if (b == KB - 1) {                       // columns past k belong to the next row: W is zero there, but 0 * inf is not
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xv[s] = 16 * b + 4 * g + s < k ? xv[s] : 0.f;
+            }
+            f4 wv[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) wv[q] = *reinterpret_cast<const f4*>(wrow + 16 * q * kp + 16 * b);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)              // s outer: consecutive MFMAs on one accumulator would wait for each other
+#pragma unroll
+                for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], xv[s], acc[q], 0, 0, 0);
+        }
+        float* c = Cl + m * n + 4 * g;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int col = 16 * q + 4 * g;
+            if (col + 1 < n) *reinterpret_cast<float2*>(c + 16 * q) = make_float2(acc[q][0], acc[q][1]);
+            if (col + 3 < n) *reinterpret_cast<float2*>(c + 16 * q + 2) = make_float2(acc[q][2], acc[q][3]);
+        }
+        out_strip = strip;
+        out_it = it++;
+    }
+    if (out_strip >= 0) store_out();
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------
+struct WgParams {
+    int64_t M;
+    int n, k, T;
+    const float* G; int64_t sG;                      // dense rows: [M][n]
+    const float* X; int64_t sX;                      // [M][k]
+    float* part;                                     // [T][slots][NT*16][KT*16]
+    int groups;
+    int ones;                                        // append a column of ones to X (k % 16 != 0)
+    ExpandSrc ex;                                    // EXPAND: G is formed from ex (G, sG unused)
+};
+
+// One wave = one partial sum of the whole [n, k] gradient over its strips (NT x KT accumulator tiles); four waves
+// per workgroup, one per SIMD.  MFMA: D[n][k] += G[m][n] * X[m][k] with the strip's rows as the reduction index
+// (m = 4*(lane/16) + s for the s-th instruction).  Columns past n / k of a strip row alias the next row: they only
+// reach accumulator entries that are never read.
+template <int NT, int KT, bool EXPAND>
+__global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
+    extern __shared__ float lds[];
+    constexpr int NLG = 2 * NT, NLX = 2 * KT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int t = blockIdx.x % p.T, grp = blockIdx.x / p.T;
+    const int n = p.n, k = p.k;
+    float* Gl = lds + wave * (strip_floats(n) + strip_floats(k) + 64);
+    float* Xl = Gl + strip_floats(n);
+    float* Fl = Xl + strip_floats(k);                // 16 x f4 scale factors (EXPAND)
+    for (int i = lane; i < strip_floats(n) + strip_floats(k); i += 64) Gl[i] = 0.f;
+
+    const float* G = p.G + (int64_t)t * p.sG;
+    const float* X = p.X + (int64_t)t * p.sX;
+    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
+    const int64_t first = (int64_t)grp * n_waves + wave, step = (int64_t)p.groups * n_waves;
+
+    float2 pg[NLG], px[NLX];
+    f4 fac = f4{1.f, 1.f, 1.f, 0.f};
+    auto fetch_g = [&](int64_t strip) {
+        if constexpr (EXPAND) load_expand<NLG>(pg, fac, p.ex, t, p.M, strip, lane);
+        else load_strip<NLG>(pg, G, p.M, n, strip, lane);
+    };
+    f4 acc[NT][KT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int i16 = lane & 15, mq = lane >> 4;
+    if (first < n_strips) {
+        fetch_g(first);
+        load_strip<NLX>(px, X, p.M, k, first, lane);
+    }
+    for (int64_t strip = first; strip < n_strips; strip += step) {
+        const int rows = (int)min((int64_t)kStrip, p.M - strip * kStrip);
+        if constexpr (EXPAND) {
+            store_expand<NLG>(Gl, Fl, pg, fac, p.ex, rows, lane);
+        } else {
+            if (rows < kStrip) {                     // rows past the end contribute zero
+#pragma unroll
+                for (int j = 0; j < NLG; ++j)
+                    if (j * 64 + lane >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
+            }
+            store_strip<NLG>(Gl, pg, n, lane);
+        }
+        store_strip<NLX>(Xl, px, k, lane);
+        if (strip + step < n_strips) {
+            fetch_g(strip + step);
+            load_strip<NLX>(px, X, p.M, k, strip + step, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float gv[NT], xv[KT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) gv[a] = Gl[(4 * mq + s) * n + 16 * a + i16];
+#pragma unroll
+            for (int b = 0; b < KT; ++b) xv[b] = Xl[(4 * mq + s) * k + 16 * b + i16];
+            if (p.ones && 16 * (KT - 1) + i16 == k) xv[KT - 1] = 1.f;      // column k of X := 1, so dW[:, k] = sum_m G[m, :] (the bias gradient)
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < KT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[a], xv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // lane holds D[n = 16a + 4*mq + r][k = 16b + i16]: the workgroup's waves add up in LDS in wave order, one slot
+    // per workgroup goes to memory
+    __syncthreads();
+    float* red = lds;                                // [NT*16][KT*16], reuses the strips
+    for (int w = 0; w < n_waves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + (16 * a + 4 * mq + r) * (KT * 16) + 16 * b + i16;
+                        *d = w == 0 ? acc[a][b][r] : *d + acc[a][b][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = p.part + ((int64_t)t * p.groups + grp) * (NT * 16) * (KT * 16);
+    for (int i = tid; i < NT * 16 * KT * 16 / 4; i += blockDim.x) reinterpret_cast<f4*>(out)[i] = reinterpret_cast<const f4*>(red)[i];
+}
+
+// dW[t][n][k] = sum over the workgroup slots in a fixed order (bitwise reproducible): a block covers 64 consecutive
+// elements, its four waves take every fourth slot, LDS joins them
+static __global__ __launch_bounds__(256) void ts_wgrad_finalize(int T, int n, int k, int slots, int npad, int kpad,
+                                                         const float* __restrict__ part, float* __restrict__ dW,
+                                                         int64_t lddw, int64_t sdW, float* __restrict__ dbias, int64_t sdb) {
+    __shared__ float red[4][64];
+    const int kk = dbias ? k + 1 : k;                // with the ones column: k + 1 columns per row, the last one is the bias gradient
+    const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sg = threadIdx.x >> 6;
+    const bool live = e < (int64_t)T * n * kk;
+    int t = 0, r = 0, c = 0;
+    float s0 = 0.f, s1 = 0.f;
+    if (live) {
+        t = (int)(e / ((int64_t)n * kk));
+        const int rem = (int)(e - (int64_t)t * n * kk);
+        r = rem / kk;
+        c = rem - r * kk;
+        const float* src = part + (int64_t)t * slots * npad * kpad + (int64_t)r * kpad + c;
+        int q = sg;
+        for (; q + 4 < slots; q += 8) {
+            s0 += src[(int64_t)q * npad * kpad];
+            s1 += src[(int64_t)(q + 4) * npad * kpad];
+        }
+        if (q < slots) s0 += src[(int64_t)q * npad * kpad];
+    }
+    red[sg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (live && sg == 0) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (c < k) dW[(int64_t)t * sdW + (int64_t)r * lddw + c] = v;
+        else dbias[(int64_t)t * sdb + r] = v;
+    }
+}
+
+// ---- dispatch -------------------------------------------------------------------------------------------------
+// ---- dispatch: one translation unit per kernel family (dgn_linear*.hip), each instantiating its (NT, KB) grid --------
+template <int NT, int KB, int MODE>
+hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ts_linear<NT, KB, MODE>), dim3(p.T * p.groups), dim3(threads), lds, st, p);
+    return hipGetLastError();
+}
+template <int NT, int KT, bool EXPAND>
+hipError_t launch_wgrad_nke(const WgParams& p, size_t lds, hipStream_t st) {
+    if constexpr (NT * KT > kMaxWgradTiles) {
+        return hipErrorInvalidValue;
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_wgrad<NT, KT, EXPAND>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL((ts_wgrad<NT, KT, EXPAND>), dim3(p.T * p.groups), dim3(256), lds, st, p);
+        return hipGetLastError();
+    }
+}
+
+#define DGN_LIN_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+
+template <int NT, int MODE>
+hipError_t launch_linear_n(int kb, const LinParams& p, int threads, size_t lds, hipStream_t st) {
+    switch (kb) {
+#define DGN_CASE(K) case K: return launch_linear_nkm<NT, K, MODE>(p, threads, lds, st);
+        DGN_LIN_CASES(DGN_CASE)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+template <int MODE>
+hipError_t launch_linear_grid(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st) {
+    switch (nt) {
+#define DGN_CASE(N) case N: return launch_linear_n<N, MODE>(kb, p, threads, lds, st);
+        DGN_LIN_CASES(DGN_CASE)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+template <int NT, bool EXPAND>
+hipError_t launch_wgrad_n(int kt, const WgParams& p, size_t lds, hipStream_t st) {
+    switch (kt) {
+#define DGN_CASE(K) case K: return launch_wgrad_nke<NT, K, EXPAND>(p, lds, st);
+        DGN_LIN_CASES(DGN_CASE)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+template <bool EXPAND>
+hipError_t launch_wgrad_grid(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st) {
+    switch (nt) {
+#define DGN_CASE(N) case N: return launch_wgrad_n<N, EXPAND>(kt, p, lds, st);
+        DGN_LIN_CASES(DGN_CASE)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// defined in dgn_linear.hip (plain), dgn_linear_combine.hip, dgn_linear_expand.hip, dgn_linear_wgrad.hip
+hipError_t launch_linear_plain(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_combine(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
+hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
+
+}  // namespace lin
+}  // namespace dgn
