@@ -138,3 +138,25 @@ def test_argument_validation_runs_before_any_device_work(lib):
     assert "4096" in err()
     assert lib.dgn_bn_tail_workspace_bytes(0, 8) == 0 and lib.dgn_bn_tail_workspace_bytes(1000, 8) > 0
     assert lib.dgn_scale_combine_backward_workspace_bytes(1000, 5, 14) > 0
+
+
+def test_linear_entry_points_validate_before_any_device_work(lib):
+    """dgn_linear_*: width limits, dense-row and alignment requirements, workspace size -- all host-side checks."""
+    err = lambda: lib.dgn_last_error().decode()
+    assert lib.dgn_linear_supported(70, 140, 0) == 1 and lib.dgn_linear_supported(70, 140, 1) == 1
+    assert lib.dgn_linear_supported(71, 140, 0) == 0 and lib.dgn_linear_supported(70, 162, 0) == 0      # odd / too wide
+    assert lib.dgn_linear_supported(160, 160, 0) == 1 and lib.dgn_linear_supported(160, 160, 1) == 0    # 100 tiles > 45
+    a = 1 << 12                                                                                        # dummy aligned pointer, never dereferenced
+    assert lib.dgn_linear_forward(10, 71, 140, 1, a, 71, 0, a, 71, 0, 0, None, 0, a, 140, 0, None) == -1 and "even" in err()
+    assert lib.dgn_linear_forward(10, 70, 140, 1, a, 72, 0, a, 70, 0, 0, None, 0, a, 140, 0, None) == -1 and "dense rows" in err()
+    assert lib.dgn_linear_forward(10, 70, 140, 1, a + 4, 70, 0, a, 70, 0, 0, None, 0, a, 140, 0, None) == -1
+    assert lib.dgn_linear_forward(10, 70, 140, 1, None, 70, 0, a, 70, 0, 0, None, 0, a, 140, 0, None) == -1 and "null" in err()
+    assert lib.dgn_linear_forward(0, 70, 140, 1, None, 70, 0, None, 70, 0, 0, None, 0, None, 140, 0, None) == 0      # no rows: nothing to do
+    need = lib.dgn_linear_wgrad_workspace_bytes(1000, 70, 140, 1)
+    assert need > 0 and lib.dgn_linear_wgrad_workspace_bytes(1000, 70, 141, 1) == 0
+    assert lib.dgn_linear_wgrad(1000, 70, 140, 1, a, 140, 0, a, 70, 0, a, 70, 0, None, 0, a, need - 1, None) == -1 and "workspace" in err()
+    assert lib.dgn_linear_wgrad(1000, 64, 140, 1, a, 140, 0, a, 64, 0, a, 64, 0, a, 0, a, need, None) == -1 and "bias gradient" in err()
+    assert lib.dgn_linear_combine_forward(10, 84, 5, 4, 14, a, 0, a, 84, 0, a, None, None, a, 70, None) == -1 and "3 scalers" in err()
+    assert lib.dgn_linear_combine_forward(10, 84, 5, 3, 14, a, 0, a, 84, 0, None, None, None, a, 70, None) == -1       # 3 scalers need the table
+    assert lib.dgn_linear_combine_backward_input(10, 5, 3, 13, 84, a, 0, a, a, 84, 0, a, 0, None) == -1 and "even f_out" in err()
+    assert lib.dgn_linear_combine_backward_weight(10, 5, 3, 14, 84, a, 0, a, a, 0, a, 84, 0, None, 0, None) == -1 and "workspace" in err()
