@@ -6,8 +6,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("type_net,F_", [("towers", 20), ("simple", 7), ("complex", 8)])
-def test_captured_step_equals_eager_step(type_net, F_):
+@pytest.mark.parametrize("type_net,F_,min_rows", [("towers", 20, None), ("towers", 20, 0), ("simple", 7, None), ("complex", 8, 0)])
+def test_captured_step_equals_eager_step(monkeypatch, type_net, F_, min_rows):
+    if min_rows is not None:        # small test graphs take the library GEMMs by default: also capture the streaming Linear kernels
+        import dgn_amd.ops
+        monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", min_rows)
     import dgn_amd
     from dgn_amd import synth
     from dgn_amd.hipgraph import capture
