@@ -133,10 +133,15 @@ def _build_layer_from_fixture(g, name, dev):
     return layer.to(dev), bool(int(meta[12]))
 
 
-def test_layers_vs_reference(golden):
+@pytest.mark.parametrize("linear_min_rows", [None, 0], ids=["default-routes", "streaming-linear"])
+def test_layers_vs_reference(golden, monkeypatch, linear_min_rows):
+    """(second run: every dense product whose widths allow it goes through the streaming dgn_linear_* kernels, which the
+    small fixture graphs would not reach on their own)"""
     dev = _dev()
     import dgn_amd
     from oracle import dgn_oracle as orc
+    if linear_min_rows is not None:
+        monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", linear_min_rows)
     g = golden("g4_layers")
     src, dst, N = T(g["src"]).to(dev), T(g["dst"]).to(dev), int(g["N"])
     snorm = T(g["snorm_n"]).to(dev)
