@@ -394,10 +394,18 @@ class DGNLayerTower(nn.Module):
     #   w_edge [Fm, ed]  edge-feature part of the pretrans weights             b_p [T*fo]      posttrans biases
     #   w [T, S*fo, K+fi] posttrans weights acting on [agg | h_in] (identity slot), or w_a [T, S*fo, K] and w_h [T, fo, fi]
     def _param_list(self):
+        """The towers' parameters in assembly order.  Cached (module attribute look-ups are ~1 us each and there are a
+        hundred of them per call: at batch 128 the step is host-bound); re-read when a Parameter object was replaced."""
+        cached = self.__dict__.get("_plist")
+        t0, t1 = self.towers[0], self.towers[-1]
+        if (cached is not None and cached[0] is t0.pretrans.fully_connected[0].linear.weight
+                and cached[-1] is t1.batchnorm_h.bias and cached[-4] is t1.posttrans.fully_connected[0].linear.weight):
+            return cached
         out = []
         for t in self.towers:
             pre, post = t.pretrans.fully_connected[0].linear, t.posttrans.fully_connected[0].linear
             out += [pre.weight, pre.bias, post.weight, post.bias, t.batchnorm_h.weight, t.batchnorm_h.bias]
+        self.__dict__["_plist"] = out
         return out
 
     def _linked_bn_stats(self, dev):
@@ -464,7 +472,7 @@ class DGNLayerTower(nn.Module):
         as much as the sweep itself.  The map is derived by running _assemble on element ids, so the layout has a
         single definition."""
         plist = self._param_list()
-        key = (str(dev), tuple(tuple(p.shape) for p in plist))
+        key = (dev, id(plist), plist[0].shape, plist[2].shape)
         cache = self.__dict__.setdefault("_opmap", {})
         if key not in cache:
             with torch.no_grad():
@@ -475,11 +483,11 @@ class DGNLayerTower(nn.Module):
                 flat_ids = torch.cat([id_ops[k].reshape(-1) for k in names])
                 pos = torch.nonzero(flat_ids).flatten()
                 sel = (flat_ids[pos] - 1).long()
-                cache[key] = (names, [tuple(id_ops[k].shape) for k in names], pos, sel, flat_ids.numel())
-        names, shapes, pos, sel, total = cache[key]
+                shapes = [tuple(id_ops[k].shape) for k in names]
+                cache[key] = (names, shapes, pos, sel, flat_ids.numel(), [math.prod(shp) for shp in shapes])
+        names, shapes, pos, sel, total, sizes = cache[key]
         flat = torch.cat([p.reshape(-1) for p in plist])
         fused = flat.new_zeros(total).index_put((pos,), flat.index_select(0, sel))
-        sizes = [math.prod(shp) for shp in shapes]
         # (split, not slicing: its backward is ONE concatenation instead of a zero-fill + copy + add per operand)
         return {k: part.view(shp) for k, part, shp in zip(names, fused.split(sizes), shapes)}
 
