@@ -6,7 +6,7 @@
 // spends its time in per-tile prologues of a 5-iteration K loop, and picks a different (often 3x slower) kernel for
 // every new M.  Here the whole weight matrix sits in LDS for the life of a persistent workgroup and the rows stream
 // through: every wave owns 16-row strips, copies a strip global -> registers -> its private LDS slice with
-// contiguous 8-byte lanes (the next strip's loads are in flight while the current one is multiplied), and feeds
+// contiguous 16-byte lanes (the next strip's loads are in flight while the current one is multiplied), and feeds
 // v_mfma_f32_16x16x4_f32 (exact fp32) from LDS.  The product is formed transposed (D[n][m]) so that a lane ends up
 // with four consecutive output columns of one row: 16-byte stores.  The reduction index is visited in the order
 // k = 16b + 4*(lane/16) + s, which lets a lane fetch its four operands of a 16-k block with one ds_read_b128.
@@ -55,25 +55,34 @@ struct LinParams {
 constexpr int linear_threads(int NT, int KB) { return 8 * NT + 4 * KB + 52 <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
-// A strip is 16 * k consecutive floats of A (rows are dense: lda == k), copied as float2 number j * 64 + lane.
+// A strip is 16 * k consecutive floats of A (rows are dense: lda == k) starting at a multiple of 64 bytes: it is copied with
+// 16-byte lanes, float4 number q = jq * 64 + lane living in pre[2 jq], pre[2 jq + 1] (NL = 2 KB is even).  The batch's last,
+// partial strip is read in 8-byte pieces with clamped indices instead (a 16-byte lane could reach past the tensor).
+__device__ __forceinline__ int strip_idx2(int j, int lane) { return 2 * ((j >> 1) * 64 + lane) + (j & 1); }   // float2 number held by pre[j]
 template <int NL>
 __device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane) {
     const int64_t row0 = strip * kStrip;
-    const float2* base = reinterpret_cast<const float2*>(A + row0 * k);          // wave-uniform
+    const float* base = A + row0 * k;                                             // wave-uniform
     const int n2 = (int)min((int64_t)kStrip, M - row0) * (k >> 1);               // float2's that exist
-    if (n2 == kStrip * (k >> 1) && NL * 64 <= n2) {
+    if (n2 == kStrip * (k >> 1)) {
+        const int last4 = (kStrip / 4) * k - 1;                                    // 16 k floats = 4 k float4
 #pragma unroll
-        for (int j = 0; j < NL; ++j) pre[j] = base[j * 64 + lane];
+        for (int jq = 0; jq < NL / 2; ++jq) {
+            const float4 v = reinterpret_cast<const float4*>(base)[min(jq * 64 + lane, last4)];
+            pre[2 * jq] = make_float2(v.x, v.y);
+            pre[2 * jq + 1] = make_float2(v.z, v.w);
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < NL; ++j) pre[j] = base[min(j * 64 + lane, n2 - 1)];
+        for (int j = 0; j < NL; ++j) pre[j] = reinterpret_cast<const float2*>(base)[min(strip_idx2(j, lane), n2 - 1)];
     }
 }
 template <int NL>
 __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], int k, int lane) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j)
-        if (j * 64 + lane < kStrip * (k >> 1)) reinterpret_cast<float2*>(Xl)[j * 64 + lane] = pre[j];
+    for (int jq = 0; jq < NL / 2; ++jq)
+        if (jq * 64 + lane < (kStrip / 4) * k)
+            reinterpret_cast<float4*>(Xl)[jq * 64 + lane] = make_float4(pre[2 * jq].x, pre[2 * jq].y, pre[2 * jq + 1].x, pre[2 * jq + 1].y);
 }
 
 
@@ -192,9 +201,15 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
         }
         const int cnt2 = (int)min((int64_t)kStrip, p.M - out_strip * kStrip) * (n >> 1);
         float* dst = C + out_strip * kStrip * n;
+        if (cnt2 == kStrip * (n >> 1)) {             // a full strip: 16 n floats from a 64-byte aligned address, 16-byte lanes
 #pragma unroll
-        for (int j = 0; j < NLC; ++j)
-            if (j * 64 + lane < cnt2) reinterpret_cast<float2*>(dst)[j * 64 + lane] = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+            for (int jq = 0; jq < NLC / 2; ++jq)
+                if (jq * 64 + lane < (kStrip / 4) * n) reinterpret_cast<float4*>(dst)[jq * 64 + lane] = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLC; ++j)
+                if (j * 64 + lane < cnt2) reinterpret_cast<float2*>(dst)[j * 64 + lane] = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+        }
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
         if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
             if (rows < kStrip) {                     // rows past the end contribute zero
 #pragma unroll
                 for (int j = 0; j < NLG; ++j)
-                    if (j * 64 + lane >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
+                    if (strip_idx2(j, lane) >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
             }
             store_strip<NLG>(Gl, pg, n, lane);
         }
