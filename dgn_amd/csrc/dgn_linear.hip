@@ -92,6 +92,7 @@ extern "C" int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_t
     }
     if (n_rows == 0) return 0;
     if (!a || !w || !y || (n_scalers > 1 && !scale)) { set_error("%s: null operand", fn); return -1; }
+    if ((f_out & 1) || (ld_y & 1) || !aligned8(y)) { set_error("%s: f_out and ld_y must be even, y 8-byte aligned", fn); return -1; }
     if ((stride_a & 1) || !aligned8(a) || ld_y < (int64_t)n_towers * f_out) { set_error("%s: A entries must be 8-byte aligned, y rows n_towers * f_out wide", fn); return -1; }
     LinParams p{};
     p.M = n_rows; p.k = k; p.n = n; p.T = n_towers;

@@ -188,14 +188,19 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     auto store_out = [&]() {
         if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
-            const int cnt = (int)min((int64_t)kStrip, p.M - row0) * p.fo;
+            const int fo2 = p.fo >> 1;                // (f_out is even: pairs of output columns, 8-byte stores)
+            const int cnt = (int)min((int64_t)kStrip, p.M - row0) * fo2;
             const float* F = Fl + (out_it & 1) * (kStrip * 4);
             for (int idx = lane; idx < cnt; idx += 64) {
-                const int r = idx / p.fo, o = idx - r * p.fo;
+                const int r = idx / fo2, o = 2 * (idx - r * fo2);
                 const f4 f = *reinterpret_cast<const f4*>(F + 4 * r);
-                float v = Cb[o];
-                for (int s = 0; s < p.S; ++s) v += f[s] * Cl[r * n + s * p.fo + o];
-                p.Y[(row0 + r) * p.ldy + t * p.fo + o] = v * f[3];
+                float2 v = *reinterpret_cast<const float2*>(Cb + o);
+                for (int s = 0; s < p.S; ++s) {
+                    const float2 z = *reinterpret_cast<const float2*>(Cl + r * n + s * p.fo + o);
+                    v.x += f[s] * z.x;
+                    v.y += f[s] * z.y;
+                }
+                *reinterpret_cast<float2*>(p.Y + (row0 + r) * p.ldy + t * p.fo + o) = make_float2(v.x * f[3], v.y * f[3]);
             }
             return;
         }
