@@ -64,6 +64,56 @@ __device__ __forceinline__ void column_partials(int64_t n_rows, int F, double* _
     }
 }
 
+// The same with a thread per column PAIR (even F, rows 8-byte aligned): 8-byte lanes, 256 / (F/2) row phases.  fn fills
+// v0[2], v1[2] for columns c, c + 1 of row n.
+struct NoPost {
+    __device__ __forceinline__ void operator()(int64_t, int, const float (&)[2]) const {}
+};
+// (post(n, c, v0) runs after ALL loads of the unrolled group: a store between the loads would be waited for with them)
+template <class Fn, class Post = NoPost>
+__device__ __forceinline__ void column_partials_pairs(int64_t n_rows, int F, double* __restrict__ part, Fn&& fn, Post&& post = Post()) {
+    __shared__ double red[4][256];
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int F2 = F >> 1;
+    const int P = max(1, 256 / F2);
+    const int64_t stride = (int64_t)G * P;
+    for (int c0 = 0; c0 < F2; c0 += 256) {         // (one iteration unless F > 512)
+        const int p = (int)threadIdx.x / F2, c2 = c0 + (int)threadIdx.x % F2;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (p < P && c2 < F2) {
+            for (int64_t n = (int64_t)b * P + p; n < n_rows; n += kUnroll * stride) {
+                float v0[kUnroll][2], v1[kUnroll][2];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) fn(min(n + u * stride, n_rows - 1), 2 * c2, v0[u], v1[u]);
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    if (n + u * stride < n_rows) {
+                        post(n + u * stride, 2 * c2, v0[u]);
+                        a[0] += (double)v0[u][0];
+                        a[1] += (double)v0[u][1];
+                        a[2] += (double)v1[u][0];
+                        a[3] += (double)v1[u][1];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = a[q];
+        __syncthreads();
+        if (p == 0 && c2 < F2) {
+            for (int q = 1; q < P; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] += red[i][threadIdx.x + q * F2];
+            const int c = 2 * c2;
+            part[(int64_t)c * G + b] = a[0];
+            part[(int64_t)(c + 1) * G + b] = a[1];
+            part[((int64_t)F + c) * G + b] = a[2];
+            part[((int64_t)F + c + 1) * G + b] = a[3];
+        }
+        __syncthreads();
+    }
+}
+
 // one workgroup per column: sum of the G slots of both quantities in a fixed order (thread-strided partials,
 // wave shuffles, then the four wave sums through LDS); the result is valid in thread 0
 __device__ __forceinline__ void slot_sums(const double* __restrict__ part, int F, int G, int c, double& s0, double& s1) {
@@ -96,13 +146,22 @@ __device__ __forceinline__ void flat_loop(int64_t total, int F, Load&& load, Sto
 }
 
 // forward partials: sum x, sum x^2
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const float* __restrict__ x, int64_t ld,
                                                 double* __restrict__ part) {
-    column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) {
-        const float v = x[n * ld + c];
-        v0 = v;
-        v1 = v * v;
-    });
+    if constexpr (PAIRS) {
+        column_partials_pairs(n_rows, F, part, [&](int64_t n, int c, float (&v0)[2], float (&v1)[2]) {
+            const float2 v = *reinterpret_cast<const float2*>(x + n * ld + c);
+            v0[0] = v.x; v0[1] = v.y;
+            v1[0] = v.x * v.x; v1[1] = v.y * v.y;
+        });
+    } else {
+        column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) {
+            const float v = x[n * ld + c];
+            v0 = v;
+            v1 = v * v;
+        });
+    }
 }
 
 // mean / invstd per column, running statistics (unbiased variance, like torch)
@@ -143,17 +202,26 @@ __global__ __launch_bounds__(256) void bn_apply(int64_t n_rows, int F, const flo
 }
 
 // backward partials: sum g', sum g' * xhat      (g' = g masked by the ReLU)
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
                                                     int64_t ld, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                     double* __restrict__ part) {
-    column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) {
-        const float xh = (x[n * ld + c] - mean[c]) * invstd[c];
-        float g = gy[n * ld + c];
+    auto one = [&](float xv, float g, int c, float& v0, float& v1) {
+        const float xh = (xv - mean[c]) * invstd[c];
         if (relu && !(xh * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f) > 0.f)) g = 0.f;
         v0 = g;
         v1 = g * xh;
-    });
+    };
+    if constexpr (PAIRS) {
+        column_partials_pairs(n_rows, F, part, [&](int64_t n, int c, float (&v0)[2], float (&v1)[2]) {
+            const float2 xv = *reinterpret_cast<const float2*>(x + n * ld + c), g = *reinterpret_cast<const float2*>(gy + n * ld + c);
+            one(xv.x, g.x, c, v0[0], v1[0]);
+            one(xv.y, g.y, c + 1, v0[1], v1[1]);
+        });
+    } else {
+        column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) { one(x[n * ld + c], gy[n * ld + c], c, v0, v1); });
+    }
 }
 
 // sums[c] = sum g' (= d beta), sums[F + c] = sum g' xhat (= d gamma)
@@ -206,16 +274,43 @@ __global__ __launch_bounds__(256) void bias_act_fwd(int64_t n_rows, int F, const
     }, [&](int64_t n, int c, float v) { y[n * ld + c] = v; });
 }
 
+// The same on dense rows of even width (ld == F): flat 8-byte lanes, a pair never straddles a row.
+__global__ __launch_bounds__(256) void bias_act_fwd_pairs(int64_t n_pairs, int F, const float2* __restrict__ x,
+                                                          const float* __restrict__ bias, int act, float slope,
+                                                          const float2* __restrict__ residual, float2* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((2 * i) % F);
+        const float2 xv = x[i];
+        float2 v = make_float2(act_fwd(xv.x + (bias ? bias[c] : 0.f), act, slope), act_fwd(xv.y + (bias ? bias[c + 1] : 0.f), act, slope));
+        if (residual) {
+            const float2 r = residual[i];
+            v.x += r.x;
+            v.y += r.y;
+        }
+        y[i] = v;
+    }
+}
+
 // g_x = g_y * act'(x + bias), and the partials of the bias gradient sum_n g_x[n, c] (second quantity unused)
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void bias_act_bwd(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
                                                     int64_t ld, const float* __restrict__ bias, int act, float slope,
                                                     float* __restrict__ gx, double* __restrict__ part) {
-    column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) {
-        const float g = gy[n * ld + c] * act_grad(x[n * ld + c] + (bias ? bias[c] : 0.f), act, slope);
-        gx[n * ld + c] = g;        // (rows clamped at the tail are rewritten with the same value)
-        v0 = g;
-        v1 = 0.f;
-    });
+    if constexpr (PAIRS) {
+        column_partials_pairs(n_rows, F, part, [&](int64_t n, int c, float (&v0)[2], float (&v1)[2]) {
+            const float2 g = *reinterpret_cast<const float2*>(gy + n * ld + c), xv = *reinterpret_cast<const float2*>(x + n * ld + c);
+            v0[0] = g.x * act_grad(xv.x + (bias ? bias[c] : 0.f), act, slope);
+            v0[1] = g.y * act_grad(xv.y + (bias ? bias[c + 1] : 0.f), act, slope);
+            v1[0] = v1[1] = 0.f;
+        }, [&](int64_t n, int c, const float (&v0)[2]) { *reinterpret_cast<float2*>(gx + n * ld + c) = make_float2(v0[0], v0[1]); });
+    } else {
+        column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) {
+            const float g = gy[n * ld + c] * act_grad(x[n * ld + c] + (bias ? bias[c] : 0.f), act, slope);
+            gx[n * ld + c] = g;        // (rows clamped at the tail are rewritten with the same value)
+            v0 = g;
+            v1 = 0.f;
+        });
+    }
 }
 
 __global__ __launch_bounds__(256) void bias_act_finalize(int F, int G, const double* __restrict__ part, float* __restrict__ g_bias) {
@@ -223,6 +318,12 @@ __global__ __launch_bounds__(256) void bias_act_finalize(int F, int G, const dou
     double s0, s1;
     slot_sums(part, F, G, c, s0, s1);
     if (threadIdx.x == 0) g_bias[c] = (float)s0;
+}
+
+// thread-per-column-pair kernels: even width and row stride, 8-byte aligned bases
+bool pairs_ok(int F, int64_t ld, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+    return (F & 1) == 0 && (ld & 1) == 0 && al8(a) && al8(b) && al8(c);
 }
 
 unsigned flat_grid(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32); }
@@ -252,7 +353,8 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
         if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bn_tail_forward: workspace too small"); return DGN_ERR_WORKSPACE; }
         double* part = static_cast<double*>(ws);
         const int G = stat_groups(n_rows, F);
-        hipLaunchKernelGGL(bn_stats, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
+        if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
+        else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd);
         hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,
@@ -279,7 +381,8 @@ extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y,
     double* part = static_cast<double*>(ws);
     float* sums = sums_out ? sums_out : reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
-    hipLaunchKernelGGL(bn_bwd_stats, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
+    if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
+    else hipLaunchKernelGGL(bn_bwd_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
     if (g_x)
         hipLaunchKernelGGL(bn_bwd_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean,
@@ -293,8 +396,16 @@ extern "C" int dgn_bias_act_forward(int64_t n_rows, int32_t F, const float* x, i
     if (n_rows < 0 || F < 1 || ld < F || act < 0 || act > 2) { set_error("dgn_bias_act_forward: bad shape or activation"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
     if (!x || !y) { set_error("dgn_bias_act_forward: null buffer"); return DGN_ERR_INVALID; }
-    hipLaunchKernelGGL(bias_act_fwd, dim3(flat_grid(n_rows * F)), dim3(256), 0, static_cast<hipStream_t>(stream), n_rows, F, x, ld, bias, act,
-                       slope, residual, y);
+    auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+    if (ld == F && (F & 1) == 0 && al8(x) && al8(y) && al8(residual)) {
+        const int64_t n_pairs = n_rows * F / 2;
+        hipLaunchKernelGGL(bias_act_fwd_pairs, dim3(flat_grid(n_pairs)), dim3(256), 0, static_cast<hipStream_t>(stream), n_pairs, F,
+                           reinterpret_cast<const float2*>(x), bias, act, slope, reinterpret_cast<const float2*>(residual),
+                           reinterpret_cast<float2*>(y));
+    } else {
+        hipLaunchKernelGGL(bias_act_fwd, dim3(flat_grid(n_rows * F)), dim3(256), 0, static_cast<hipStream_t>(stream), n_rows, F, x, ld, bias,
+                           act, slope, residual, y);
+    }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
@@ -311,7 +422,8 @@ extern "C" int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y
     if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bias_act_backward: workspace too small (dgn_bn_tail_workspace_bytes)"); return DGN_ERR_WORKSPACE; }
     double* part = static_cast<double*>(ws);
     const int G = stat_groups(n_rows, F);
-    hipLaunchKernelGGL(bias_act_bwd, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, bias, act, slope, g_x, part);
+    if (pairs_ok(F, ld, x, g_y, g_x)) hipLaunchKernelGGL(bias_act_bwd<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, bias, act, slope, g_x, part);
+    else hipLaunchKernelGGL(bias_act_bwd<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, bias, act, slope, g_x, part);
     if (g_bias) hipLaunchKernelGGL(bias_act_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, g_bias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
