@@ -129,7 +129,7 @@ static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, in
     const hipError_t e = p.ex.gy ? launch_wgrad_expand(NT, KT, p, lds, st) : launch_wgrad_plain(NT, KT, p, lds, st);
     DGN_HIP_CHECK(e);
     const int64_t total = (int64_t)batch * n * (dbias ? k + 1 : k);
-    hipLaunchKernelGGL(ts_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, batch, n, k, p.groups,
+    hipLaunchKernelGGL(ts_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(64 * kFinWaves), 0, st, batch, n, k, p.groups,
                        NT * 16, KT * 16, p.part, dw, lddw, stride_dw, dbias, stride_dbias);
     DGN_HIP_CHECK(hipGetLastError());
     return 0;

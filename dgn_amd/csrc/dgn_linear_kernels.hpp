@@ -364,14 +364,15 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
 }
 
 // dW[t][n][k] = sum over the workgroup slots in a fixed order (bitwise reproducible): a block covers 64 consecutive
-// elements, its four waves take every fourth slot, LDS joins them
-static __global__ __launch_bounds__(256) void ts_wgrad_finalize(int T, int n, int k, int slots, int npad, int kpad,
+// elements, its sixteen waves take every sixteenth slot (all loads of a lane in flight together), LDS joins them
+constexpr int kFinWaves = 16;
+static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T, int n, int k, int slots, int npad, int kpad,
                                                          const float* __restrict__ part, float* __restrict__ dW,
                                                          int64_t lddw, int64_t sdW, float* __restrict__ dbias, int64_t sdb) {
-    __shared__ float red[4][64];
+    __shared__ float red[kFinWaves][64];
     const int kk = dbias ? k + 1 : k;                // with the ones column: k + 1 columns per row, the last one is the bias gradient
-    const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     const bool live = e < (int64_t)T * n * kk;
     int t = 0, r = 0, c = 0;
     float s0 = 0.f, s1 = 0.f;
@@ -382,16 +383,18 @@ static __global__ __launch_bounds__(256) void ts_wgrad_finalize(int T, int n, in
         c = rem - r * kk;
         const float* src = part + (int64_t)t * slots * npad * kpad + (int64_t)r * kpad + c;
         int q = sg;
-        for (; q + 4 < slots; q += 8) {
+        for (; q + kFinWaves < slots; q += 2 * kFinWaves) {
             s0 += src[(int64_t)q * npad * kpad];
-            s1 += src[(int64_t)(q + 4) * npad * kpad];
+            s1 += src[(int64_t)(q + kFinWaves) * npad * kpad];
         }
         if (q < slots) s0 += src[(int64_t)q * npad * kpad];
     }
-    red[sg][threadIdx.x & 63] = s0 + s1;
+    red[sg][lane] = s0 + s1;
     __syncthreads();
     if (live && sg == 0) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kFinWaves; ++w) v += red[w][lane];
         if (c < k) dW[(int64_t)t * sdW + (int64_t)r * lddw + c] = v;
         else dbias[(int64_t)t * sdb + r] = v;
     }
