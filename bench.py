@@ -323,8 +323,12 @@ def run_layer_workload(args, wl, rank, world, dev):
     else:
         pq = torch.randn(N, 2 * F_, device=dev, generator=gen)
         xs, xd = pq[:, :F_], pq[:, F_:]
-    out = torch.empty(N, plan.out_width(Fk), device=dev)
-    g_out = torch.randn(N, plan.out_width(Fk), device=dev, generator=gen)
+    if T > 1:    # the towers layer runs the sweep tower-major ([T, N, A*F/T], dgn_layer.py: _fused_towers): time that layout
+        out = torch.empty(T, N, plan.out_width(Fk) // T, device=dev)
+        g_out = torch.randn(T, N, plan.out_width(Fk) // T, device=dev, generator=gen)
+    else:
+        out = torch.empty(N, plan.out_width(Fk), device=dev)
+        g_out = torch.randn(N, plan.out_width(Fk), device=dev, generator=gen)
     g_src, g_dst, g_in = torch.zeros(N, Fk, device=dev), (torch.zeros(N, Fk, device=dev) if xd is not None else None), torch.zeros(N, Fk, device=dev)
     reps = 20
     ms_f = event_ms(lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out), reps, dev)
