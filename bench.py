@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """DGN-layer forward+backward throughput on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2_b128|c1|c3|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2_b128|c1|c3|c4|c5] [--scaling weak|strong]
+
+With --gpus N > 1 and no launcher environment (RANK unset) the script re-executes itself under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` -- one rank per GPU over
+RCCL -- and refuses to run if fewer than N devices are visible.
 
 A "step" is one pass of the hot path over one batch of synthetic input: per-edge directional weights
 from eig, one DGN layer forward, one backward (fixed random cotangent), and -- for N > 1 -- the flat
 gradient all-reduce.  Inputs (graph CSR, features, eig) are resident in HBM before the timed region.
 The default workload is BASELINE.json configs[1]: ZINC-12k (all 12 000 molecules as one batch),
 DGN towers (5 towers, hidden 70, mean/max/min/dir1-av/dir1-dx, 3 PNA scalers).  For N > 1 every rank
-processes its own 12k-molecule batch (weak scaling), one rank per GPU over RCCL.
+processes its own 12k-molecule batch (weak scaling: seed 41 + rank), or -- ``--scaling strong`` -- its edge-balanced
+shard of ONE global batch (``dist.shard_by_edges``; SURVEY 8(e): ogbg-molhiv batch 2048 split over the ranks).
+The default single-GPU run also appends short sub-results for the other BASELINE configs (``extra``: c1, c3, c4,
+c2_b128, c5), each with its own roofline, so that one driver-run line carries every number DESIGN.md quotes.
 
 Besides the contract keys the line carries
   roofline      the dominant aggregation kernel's algorithmic bytes / its measured launch duration
@@ -21,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -74,6 +83,10 @@ def plan_model(plan):
     x = int(any(op in (8, 9, 10) for op in ops))
     r = int(any(op in (2, 3, 4, 5) for op in ops))
     return plan.n_agg, plan.n_scalers, plan.n_channels, x, r
+
+
+TRAFFIC_SOURCE = ("committed rocprofv3 --pmc passes of the same command (profiles/pmc_traffic.json, builder-run); "
+                  "not re-measured in this run")
 
 
 def pmc_traffic(tag, kernels):
@@ -145,7 +158,8 @@ def event_percentiles(fn, dev, warm=20, reps=100):
     return dict(p10=t[reps // 10], p50=t[reps // 2], p90=t[(reps * 9) // 10])
 
 
-def build_batch(wl, seed, dev):
+def build_batch(wl, seed, dev, shard=None):
+    """``shard = (rank, world)``: keep this rank's edge-balanced share of the batch's graphs (strong scaling)."""
     kind, kw = wl["gen"]
     if kind == "molecules":
         b = synth.molecule_batch(seed=seed, **kw)
@@ -153,6 +167,10 @@ def build_batch(wl, seed, dev):
         b = synth.knn_batch(seed=seed, **kw)
     else:
         raise ValueError(kind)
+    if shard is not None:
+        rank, world = shard
+        mine = ddist.shard_by_edges(synth.edges_per_graph(b).tolist(), world)[rank]
+        b = synth.subset_batch(b, mine)
     graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), b["num_nodes"], eig=b["eig"].to(dev))
     return b, graph
 
@@ -224,11 +242,16 @@ def hbm_triad_GBps(dev, n_bytes=1 << 30, reps=10):
     return 3 * n_bytes / ms / 1e6
 
 
-def run_layer_workload(args, wl, rank, world, dev):
-    # every rank draws the SAME synthetic batch (generator seed 41, BASELINE config seed) so that all ranks run
-    # identical shapes (weak scaling, and the committed GEMM solution file applies to every rank); node features
-    # and cotangents are rank-specific, so the all-reduced gradients are not
-    batch, graph = build_batch(wl, 41, dev)
+def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
+    """One layer workload: timed steps (contract timing) + the roofline of its aggregation kernels on rank 0."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    tag = tag or args.workload
+    # weak scaling: every rank draws its OWN batch (generator seed 41 + rank; 41 = BASELINE config seed), so shapes differ
+    # slightly between ranks as they do in a real data-parallel epoch; strong scaling: ONE global batch (seed 41 on every
+    # rank), every rank keeps its edge-balanced share of the graphs.  Node features / cotangents are rank-specific.
+    strong = world > 1 and args.scaling == "strong"
+    batch, graph = build_batch(wl, 41 if strong else 41 + rank, dev, shard=(rank, world) if strong else None)
     F_ = wl["hidden"]
     N, E = graph.num_nodes, graph.num_edges
     torch.manual_seed(0)
@@ -284,25 +307,26 @@ def run_layer_workload(args, wl, rank, world, dev):
         hip_graph = capture(bare_step, warmup=0)
         eager_step, step = step, hip_graph.replay
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
-    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    ms = (time.perf_counter() - t0) * 1e3 / steps
     ms = ddist.barrier_max_ms(ms, dev)
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
     total_edges = float(e_total.item())
 
-    result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N)
+    result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
+                  scaling="strong" if strong else "weak")
     if rank != 0:
         return result
 
@@ -338,11 +362,13 @@ def run_layer_workload(args, wl, rank, world, dev):
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
     fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out)
     bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in, accumulate=False)
+    pct = (lambda fn: event_percentiles(fn, dev)) if args.percentiles else (lambda fn: None)
+    bw = E * (4 + 8 * Ku + 4 * Ku) + N * 4        # edge weights: src id, both eig endpoints per channel, weight out; row pointer
     kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK,
-                                    ms_percentiles=event_percentiles(fwd_call, dev)),
+                                    ms_percentiles=pct(fwd_call)),
                "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK,
-                                    ms_percentiles=event_percentiles(bwd_call, dev)),
-               "ew_rows": dict(ms=ms_w)}
+                                    ms_percentiles=pct(bwd_call)),
+               "ew_rows": dict(ms=ms_w, bytes=bw, GBps=bw / ms_w / 1e6, frac=bw / (ms_w * 1e-3) / HBM_PEAK)}
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
     # rows) or agg_fwd_rows; backward = agg_bwd_rows + seg_sum_rows (second phase of the atomic-free scatter)
@@ -350,15 +376,26 @@ def run_layer_workload(args, wl, rank, world, dev):
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
              "agg_bwd_rows": "dgn_agg_backward (agg_bwd_rows + seg_sum_rows)"}[dom]
     triad = hbm_triad_GBps(dev)
+    # The launched list carries the h_in pass-through block of the complex / towers layers as one more "aggregator"
+    # (A = survey's A + 1: the sweep really writes that block).  The same launch priced with SURVEY 8(d)'s own A:
+    A_survey = A - int(any(op == 10 for l in plan.launches for op in l.ops))
+    bf_s, bb_s = algorithmic_bytes(N, E, F_, A_survey, S, Ku, x, r)
+    dom_ms = kernels[dom]["ms"]
+    frac_survey = (bb_s if dom == "agg_bwd_rows" else bf_s) / (dom_ms * 1e-3) / HBM_PEAK
+    traffic = pmc_traffic(tag, launches)
     result["roofline"] = dict(bound="hbm", kernel=label, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
-                              frac=kernels[dom]["frac"], traffic=pmc_traffic(args.workload, launches), kernels=kernels,
-                              triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
-                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r))
+                              frac=kernels[dom]["frac"], traffic=traffic, traffic_source=TRAFFIC_SOURCE if traffic else None,
+                              kernels=kernels, triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
+                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r),
+                              frac_with_survey_A=dict(A=A_survey, frac=frac_survey,
+                                                      note="same launch priced without the h_in pass-through block"))
     return result, batch
 
 
-def run_c5(args, wl, rank, world, dev):
+def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
     """Single forward pass of the fused aggregation on the power-law graph (HBM-roofline run)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     kw = dict(wl["gen"][1])
     if args.scale != 1.0:
         kw["num_nodes"] = int(kw["num_nodes"] * args.scale)
@@ -389,18 +426,18 @@ def run_c5(args, wl, rank, world, dev):
     def step():
         launch_forward(graph, plan, 1, avg_log, w, X_all, None, None, X, out)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
-    ms = ddist.barrier_max_ms((time.perf_counter() - t0) * 1e3 / args.steps, dev)
+    ms = ddist.barrier_max_ms((time.perf_counter() - t0) * 1e3 / steps, dev)
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
@@ -410,7 +447,7 @@ def run_c5(args, wl, rank, world, dev):
                                f"inside the sweep") if partition else (f"{world} independent replicas" if world > 1 else "single GPU"))
     if rank == 0:
         A, S, Ku, x, r = plan_model(plan)
-        ms_f = event_ms(step, max(3, args.steps), dev)
+        ms_f = event_ms(step, max(3, steps), dev)
         ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=eig), 3, dev)
         bf, _ = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
         result["roofline"] = dict(bound="hbm", kernel="agg_fwd_rows+hub", achieved=bf / ms_f / 1e6, peak=HBM_PEAK / 1e9,
@@ -418,10 +455,74 @@ def run_c5(args, wl, rank, world, dev):
                                   frac_of_triad=bf / ms_f / 1e6 / triad,
                                   traffic=pmc_traffic("c5", ["agg_fwd_rows", "agg_hub_slices", "agg_fwd_hub_combine"])
                                   if args.scale == 1.0 and not args.aggregators and not args.scalers else None,
-                                  kernels={"agg_fwd(all launches)": dict(ms=ms_f, bytes=bf), "edge_weights": dict(ms=ms_w)},
+                                  traffic_source=TRAFFIC_SOURCE,
+                                  kernels={"agg_fwd(all launches)": dict(ms=ms_f, bytes=bf),
+                                           "edge_weights": dict(ms=ms_w, bytes=(bw := E * (4 + 12 * Ku) + N * 4), GBps=bw / ms_w / 1e6,
+                                                                frac=bw / (ms_w * 1e-3) / HBM_PEAK)},
                                   model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, n_hub=graph.n_hub,
                                              n_slices=graph.n_chunks, max_degree=int(graph.in_degree.max().item())))
     return result, None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks_if_needed(args):
+    """``--gpus N`` without a launcher environment: re-execute under torch.distributed.run, one rank per GPU.  Never
+    degrades silently: fewer visible devices than requested ranks is an error."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {n_dev} GPU(s) are visible; refusing to run "
+                         f"fewer ranks under that label")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def compact(result):
+    """A sub-result of the default run: timing, throughput and the roofline of its dominant aggregation call."""
+    r = result.get("roofline") or {}
+    out = dict(ms_per_step=result["ms_per_step"], value=result["value"], unit="edges/s", edges=result["edges_per_rank"],
+               nodes=result["nodes_per_rank"])
+    if r:
+        out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                 "frac_of_triad", "model", "frac_with_survey_A") if k in r}
+        out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac")}
+                                      for k, v in (r.get("kernels") or {}).items()}
+    return out
+
+
+def run_extras(args, dev):
+    """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
+    extra = {}
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2_b128", 20, 5), ("c5", 3, 1)]
+    for name, steps, warmup in plan:
+        wl = dict(WORKLOADS[name])
+        t0 = time.perf_counter()
+        try:
+            runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
+            res, batch = runner(args, wl, 0, 1, dev, steps=steps, warmup=warmup, tag=name)
+            extra[name] = compact(res)
+            extra[name]["config"] = wl["desc"]
+            extra[name]["steps"], extra[name]["warmup"] = steps, warmup
+            if name == "c1" and not args.no_cpu_baseline:
+                # BASELINE configs[0] is quoted on the reference's CPU path: the same bounded CPU sample for it
+                extra[name]["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])), reps=3)
+        except Exception as exc:          # an extra must never take the headline down with it -- but it is reported
+            extra[name] = dict(error=f"{type(exc).__name__}: {exc}")
+        extra[name]["wall_s"] = time.perf_counter() - t0
+        del wl
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+    return extra
 
 
 def main():
@@ -430,12 +531,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="layer workloads with --gpus > 1: 'weak' = every rank its own batch (default), 'strong' = one global "
+                         "batch, graphs sharded over the ranks by edge count")
     ap.add_argument("--scale", type=float, default=1.0, help="c5 only: scale N and E")
     ap.add_argument("--c5-mode", default="partition", choices=["partition", "replicas"],
                     help="c5 with --gpus > 1: one graph split by destination ranges (strong scaling) or one graph per rank")
     ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-results of the other configs in the default run")
+    ap.add_argument("--percentiles", action="store_true", help="per-launch p10/p50/p90 of the aggregation calls (SURVEY 8(d) protocol)")
     ap.add_argument("--hipgraph", action="store_true",
                     help="layer workloads, 1 GPU: capture the step (edge weights + forward + backward) in a HIP graph and replay it")
     ap.add_argument("--gemm-tuning", default="file", choices=["off", "file", "tune"],
@@ -443,12 +549,16 @@ def main():
                          "'file' replays dgn_amd/tunableop_gfx950.csv without tuning, 'tune' tunes and rewrites it")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "weak"
 
+    spawn_ranks_if_needed(args)
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)} ranks")
     configure_gemm_tuning(args.gemm_tuning)
     rank, world, local = ddist.init_from_env("nccl")
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     wl = dict(WORKLOADS[args.workload])
@@ -463,6 +573,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
     result, batch = res
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
     line = dict(metric="dgn_layer_fwd_bwd_edges_per_sec" if wl["type_net"] != "op" else "dgn_aggregation_fwd_edges_per_sec",
                 value=result["value"], unit="edges/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=result["ms_per_step"], higher_is_better=True, scaling=result.get("scaling", "weak"), vs_baseline=None,
@@ -471,15 +582,21 @@ def main():
                 config=dict(workload=args.workload + ": " + wl["desc"], edges_per_gpu=result["edges_per_rank"],
                             nodes_per_gpu=result["nodes_per_rank"], type_net=wl["type_net"], hidden=wl["hidden"],
                             aggregators=wl["aggregators"], scalers=wl["scalers"], towers=wl["towers"],
-                            parallelism=result.get("parallelism") or (f"dp{world} (graphs sharded, flat-gradient all-reduce)"
-                                                                      if world > 1 else "single GPU"),
-                            step=("edge weights + layer forward + backward" + (" (HIP graph replay)" if args.hipgraph else ""))
+                            parallelism=result.get("parallelism") or (
+                                f"dp{world}: {'one global batch, graphs sharded by edge count' if result.get('scaling') == 'strong' else 'one batch per rank'}"
+                                f", flat-gradient all-reduce ({backend} = RCCL, {world} ranks)" if world > 1 else "single GPU"),
+                            step=("edge weights + layer forward + backward" + (" + gradient all-reduce" if world > 1 else "")
+                                  + (" (HIP graph replay)" if args.hipgraph else ""))
                             if wl["type_net"] != "op" else "aggregation forward"),
                 roofline=result.get("roofline"))
     if world == 1 and not args.no_cpu_baseline and batch is not None:
         line["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])))
     else:
         line["cpu_baseline"] = None
+    if world == 1 and args.workload == "c2" and not args.no_extras and not args.hipgraph and not args.aggregators and not args.scalers:
+        del res, result, batch
+        torch.cuda.empty_cache()
+        line["extra"] = run_extras(args, dev)
     print(json.dumps(line))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -217,9 +217,12 @@ class DGNLayerSimple(nn.Module):
         if in_dim != out_dim:
             self.residual = False
 
-    def aggregate(self, g, h, plan=None):
-        graph = as_dgn_graph(g)
-        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=h, x_in=h, eig=g.ndata["eig"])
+    def aggregate(self, g, h, plan=None, eig=None):
+        """``eig``: the caller's CURRENT ``g.ndata['eig']`` (read before any conversion of ``g``: a cached conversion
+        must never supply a stale eig when the train loop reassigns it per batch)."""
+        eig = g.ndata["eig"] if eig is None else eig
+        graph = as_dgn_graph(g, h.device)
+        return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=h, x_in=h, eig=eig)
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
@@ -229,27 +232,28 @@ class DGNLayerSimple(nn.Module):
         # column meet zero weights (the padded columns of W below), so the layer output is unchanged.
         hp = F.pad(h, (0, 1)) if F0 % 2 else h
         Fp = hp.shape[1]
+        eig = g.ndata["eig"]
         if self.posttrans.is_single_affine():
-            graph = as_dgn_graph(g)
+            graph = as_dgn_graph(g, h.device)
             lin = self.posttrans.fully_connected[0].linear
             fo = lin.weight.shape[0]
             A = len(self.aggregators)
             if self.plan.n_scalers > 1:
                 # scalers folded behind the Linear: sweep without scalers -> one GEMM -> scale-combine (+bias, +snorm)
                 S = self.plan.n_scalers
-                agg = self.aggregate(graph, hp, self._kplan)                                  # [N, A*Fp]
+                agg = self.aggregate(graph, hp, self._kplan, eig)                             # [N, A*Fp]
                 w = _pad_blocks(lin.weight, S * A, F0, Fp).reshape(fo, S, A * Fp).permute(1, 0, 2).reshape(S * fo, A * Fp)
                 z = node_linear(agg, w)
                 sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
                 h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)      # (+snorm, BatchNorm, ReLU, residual)
                 return F.dropout(h, self.dropout, training=self.training)
             else:
-                agg = self.aggregate(graph, hp)                                               # [N, A*Fp] (single scaler: not applied)
+                agg = self.aggregate(graph, hp, None, eig)                                    # [N, A*Fp] (single scaler: not applied)
                 h = F.linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
                 if self.graph_norm:
                     h = h * snorm_n
         else:
-            agg = self.aggregate(g, hp)
+            agg = self.aggregate(g, hp, None, eig)
             if Fp != F0:
                 agg = agg.view(agg.shape[0], -1, Fp)[:, :, :F0].reshape(agg.shape[0], -1)
             h = self.posttrans(agg)
@@ -286,29 +290,31 @@ class DGNLayerComplex(nn.Module):
         if in_dim != out_dim:
             self.residual = False
 
-    def aggregate(self, g, h, e, plan=None):
-        graph = as_dgn_graph(g)
+    def aggregate(self, g, h, e, plan=None, eig=None):
+        eig = g.ndata["eig"] if eig is None else eig           # (the caller's current eig, see DGNLayerSimple.aggregate)
+        graph = as_dgn_graph(g, h.device)
         x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
         return directional_aggregate(graph, plan or self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge,
-                                     x_in=h, eig=g.ndata["eig"])
+                                     x_in=h, eig=eig)
 
     def forward(self, g, h, e, snorm_n):
         h_in = h
+        eig = g.ndata["eig"]
         id_slot = _identity_slot(self.plan.applied_scalers)
         if self.posttrans.is_single_affine() and self.plan.n_scalers > 1 and id_slot is not None:
             # sweep without scalers and WITH the h_in pass-through block -> posttrans([h || agg]) is one GEMM ->
             # scale-combine (+bias, +snorm)
-            graph = as_dgn_graph(g)
+            graph = as_dgn_graph(g, h.device)
             lin = self.posttrans.fully_connected[0].linear
             S, fo = self.plan.n_scalers, lin.weight.shape[0]
-            aggx = self.aggregate(graph, h, e, self._kplan_x)                          # [N, A*F | F]
+            aggx = self.aggregate(graph, h, e, self._kplan_x, eig)                     # [N, A*F | F]
             w = _folded_weight(lin.weight[:, self.in_dim:], lin.weight[:, :self.in_dim], S, id_slot)
             z = node_linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)          # (+snorm, BatchNorm, ReLU, residual)
             return F.dropout(h, self.dropout, training=self.training)
         else:
-            h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e), self.in_dim)
+            h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e, None, eig), self.in_dim)
             if self.graph_norm:
                 h = h * snorm_n
         if self.batch_norm:
@@ -340,7 +346,7 @@ class DGNTower(nn.Module):
         self._avg_log = _avg_log(avg_d)
 
     def forward(self, g, h, e, snorm_n):
-        graph = as_dgn_graph(g)
+        graph = as_dgn_graph(g, h.device)
         h = h.contiguous()
         x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
         agg = directional_aggregate(graph, self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge, x_in=h,
@@ -493,7 +499,7 @@ class DGNLayerTower(nn.Module):
 
     def _fused_towers(self, g, h, e, snorm_n):
         """All towers in one sweep: towers are column blocks of the message."""
-        graph = as_dgn_graph(g)
+        graph = as_dgn_graph(g, h.device)
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
         ops = self._operands(h.device)
         x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)

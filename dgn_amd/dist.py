@@ -81,18 +81,40 @@ def shard_rows(indptr: torch.Tensor, src: torch.Tensor, r0: int, r1: int, **grap
     return DGNGraph.from_csr((indptr[r0:r1 + 1] - indptr[r0]), src[e0:e1], num_src=n, row_base=r0, **graph_kw)
 
 
+class _AllGatherRows(torch.autograd.Function):
+    """Row all-gather with its adjoint: the gradient of a rank's own rows is the SUM over ranks of the gradients of
+    those rows of the gathered tensor (every rank consumed them), i.e. all-reduce + slice (= reduce-scatter; the
+    all-reduce form also runs on gloo and with uneven shards)."""
+
+    @staticmethod
+    def forward(ctx, local, ranges, rank):
+        longest = max(b - a for a, b in ranges)
+        pad = local.new_zeros((longest,) + tuple(local.shape[1:]))
+        pad[:local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in ranges]
+        dist.all_gather(parts, pad)
+        ctx.ranges, ctx.rank = ranges, rank
+        return torch.cat([p[:b - a] for p, (a, b) in zip(parts, ranges)], dim=0)
+
+    @staticmethod
+    def backward(ctx, g_full):
+        g_full = g_full.contiguous().clone()
+        dist.all_reduce(g_full, op=dist.ReduceOp.SUM)
+        a0 = ctx.ranges[0][0]
+        a, b = ctx.ranges[ctx.rank]
+        return g_full[a - a0:b - a0], None, None
+
+
 def all_gather_rows(local: torch.Tensor, ranges: Sequence[Tuple[int, int]]) -> torch.Tensor:
     """[rows_r, F] per rank -> [N, F] on every rank (the exchange a multi-layer net needs between two sharded layers:
     after the post-transformation the rows are F wide, 5.1 GB for 10 M x 128 fp32).  Uneven shards are padded to the
-    largest one for the collective."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    largest one for the collective.  Differentiable: the backward sums the gathered tensor's gradient over the ranks
+    and hands every rank the rows it owns.  Without an initialised process group it is the identity."""
+    if not dist.is_initialized():
         return local
-    longest = max(b - a for a, b in ranges)
-    pad = local.new_zeros((longest,) + tuple(local.shape[1:]))
-    pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in ranges]
-    dist.all_gather(parts, pad)
-    return torch.cat([p[:b - a] for p, (a, b) in zip(parts, ranges)], dim=0)
+    if len(ranges) != dist.get_world_size():
+        raise ValueError(f"{len(ranges)} row ranges for {dist.get_world_size()} ranks")
+    return _AllGatherRows.apply(local, [tuple(r) for r in ranges], dist.get_rank())
 
 
 class FlatGradAllReduce:

@@ -136,23 +136,36 @@ class DGNGraph:
         return per_edge if self.eid is None else per_edge.index_select(0, self.eid)
 
     # ---- per-edge directional weights (cached per eig tensor version) ----
+    def _normalised_eig(self, eig: torch.Tensor) -> torch.Tensor:
+        """``eig`` on this graph's device as contiguous fp32 -- converted ONCE per (source tensor, version): the
+        reference keeps eig on the CPU (dgn_layer.py:157-159) and the nets hand the same tensor to every layer, so the
+        H2D copy / cast must not be repeated per layer.  The source tensor is held by the cache entry (identity check,
+        not an address), so a freed-and-reused allocation can never alias an entry."""
+        ent = getattr(self, "_eig_norm", None)
+        if ent is not None and ent[0] is eig and ent[1] == eig._version:
+            return ent[2]
+        e = eig
+        if e.device != self.device:
+            e = e.to(self.device)
+        if e.dtype != torch.float32 or e.dim() != 2 or e.stride(-1) != 1:
+            e = e.float().contiguous()
+        self._eig_norm = (eig, eig._version, e)
+        return e
+
     def edge_weights(self, plan: AggPlan, eig: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         if plan.n_channels == 0:
             return None
-        eig = self.ndata["eig"] if eig is None else eig
-        if eig.device != self.device:
-            eig = eig.to(self.device)       # the reference keeps eig on the CPU (dgn_layer.py:157-159)
-        if eig.dtype != torch.float32 or eig.stride(-1) != 1:
-            eig = eig.float().contiguous()
-        key = (eig.data_ptr(), eig._version, tuple(eig.shape), plan.channels)
-        w = self._wcache.get(key)
-        if w is None:
+        eig = self._normalised_eig(self.ndata["eig"] if eig is None else eig)
+        # the entry keeps a strong reference to the tensor it was computed from: while the entry lives, that tensor's
+        # storage cannot be freed and handed to another eig, so (id, version) identifies the VALUES
+        key = (id(eig), eig._version, tuple(eig.shape), plan.channels)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] is not eig:
             w = compute_edge_weights(self, plan.channels, eig=eig)
-            if len(self._wcache) > 8:
+            if len(self._wcache) >= 8:
                 self._wcache.clear()
-            self._wcache[key] = w
-            self._keep_eig = eig
-        return w
+            self._wcache[key] = ent = (eig, w)
+        return ent[1]
 
 
 def _channel_array(channels: Tuple[Channel, ...]):
@@ -186,19 +199,24 @@ def compute_edge_weights(graph: DGNGraph, channels: Tuple[Channel, ...], eig: Op
     return w
 
 
-def as_dgn_graph(g) -> DGNGraph:
+def as_dgn_graph(g, device: Optional[torch.device] = None) -> DGNGraph:
     """Accept a DGNGraph, or anything DGL-shaped (``edges()``/``all_edges()``, ``number_of_nodes()``,
-    ``ndata['eig']``): the converted batch is cached on the object."""
+    ``ndata['eig']``): the converted batch is cached on the object, per device.  ``device``: where the features
+    live (the layers pass ``h.device``); default: the current CUDA device.  The cached conversion always carries the
+    caller's CURRENT ``g.ndata['eig']`` (the reference's train loops reassign it per batch for the sign-flip /
+    rotation augmentations, train_molecules_graph_regression.py:29-33)."""
     if isinstance(g, DGNGraph):
         return g
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     cached = getattr(g, "_dgn_graph", None)
-    if cached is not None:
+    if cached is not None and cached.device == dev:
+        cached.ndata["eig"] = g.ndata["eig"]
         return cached
     edges = g.all_edges(order="eid") if hasattr(g, "all_edges") else g.edges()
     src, dst = edges[0], edges[1]
-    eig = g.ndata["eig"]
-    dev = torch.device("cuda", torch.cuda.current_device())
-    out = DGNGraph(src.to(dev), dst.to(dev), g.number_of_nodes(), eig=eig.to(dev))
+    out = DGNGraph(src.to(dev), dst.to(dev), g.number_of_nodes(), eig=g.ndata["eig"])
     try:
         g._dgn_graph = out
     except Exception:

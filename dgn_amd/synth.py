@@ -69,6 +69,31 @@ def molecule_batch(n_graphs: int, seed: int = 41, n_lo: int = 9, n_hi: int = 37,
                 sizes=sizes_t, eig=torch.from_numpy(np.concatenate(eigs)), snorm_n=snorm)
 
 
+def subset_batch(b: Dict[str, torch.Tensor], graph_ids) -> Dict[str, torch.Tensor]:
+    """The sub-batch holding the given graphs of ``b`` (in the given order, nodes relabelled consecutively): what a
+    data-parallel rank keeps of a global batch (``dist.shard_by_edges``)."""
+    sizes = b["sizes"].long()
+    offs = torch.zeros(sizes.numel() + 1, dtype=torch.long)
+    offs[1:] = torch.cumsum(sizes, 0)
+    gids = torch.as_tensor(list(graph_ids), dtype=torch.long)
+    keep_sizes = sizes[gids]
+    new_offs = torch.zeros(gids.numel() + 1, dtype=torch.long)
+    new_offs[1:] = torch.cumsum(keep_sizes, 0)
+    n_new = int(new_offs[-1])
+    # old node id of every kept node, and the inverse map (-1 = dropped)
+    nodes = torch.repeat_interleave(offs[gids] - new_offs[:-1], keep_sizes) + torch.arange(n_new)
+    new_id = torch.full((int(offs[-1]),), -1, dtype=torch.long)
+    new_id[nodes] = torch.arange(n_new)
+    keep = new_id[b["dst"]] >= 0                      # edges never cross graphs
+    return dict(src=new_id[b["src"][keep]], dst=new_id[b["dst"][keep]], num_nodes=n_new, sizes=keep_sizes,
+                eig=b["eig"][nodes], snorm_n=b["snorm_n"][nodes])
+
+
+def edges_per_graph(b: Dict[str, torch.Tensor]) -> torch.Tensor:
+    gid = torch.repeat_interleave(torch.arange(b["sizes"].numel()), b["sizes"].long())
+    return torch.bincount(gid[b["dst"]], minlength=b["sizes"].numel())
+
+
 def knn_batch(n_graphs: int = 128, seed: int = 41, n_lo: int = 85, n_hi: int = 150, k: int = 8) -> Dict[str, torch.Tensor]:
     """CIFAR10-superpixel-like graphs: 2-D points, every node sends an edge to its k nearest
     (data/superpixels.py:139-145), so in-degree varies and can be 0; eig = [0, x, y] (coord_eig mode,

@@ -212,8 +212,14 @@ def _sharded_worker(rank, world, port, q):
         emb[r0 + 1:r1 + 1] = shard.indptr.long()[1:]
         emb[r1 + 1:] = emb[r1]
         local = oracle_directional_aggregate(dgn_amd.DGNGraph.from_csr(emb, shard.src.long()), plan, 1.1, x_src=X, x_in=X, eig=eig)[r0:r1]
+        local = local.detach().requires_grad_(True)
         gathered = ddist.all_gather_rows(local, ranges)
         ok = gathered.shape == ref.shape and torch.allclose(gathered, ref, rtol=1e-6, atol=1e-6)
+        # the gather is differentiable: rank r weighs the gathered rows with (r + 1) * Cw, so the gradient of a rank's own
+        # rows is the SUM over ranks = (1 + 2 + ... + world) * Cw[r0:r1]
+        Cw = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))
+        (gathered * ((rank + 1) * Cw)).sum().backward()
+        ok = ok and torch.allclose(local.grad, (world * (world + 1) / 2) * Cw[r0:r1], rtol=1e-6, atol=1e-6)
         q.put((rank, bool(ok), [tuple(r) for r in ranges]))
         dist.destroy_process_group()
     except Exception as exc:   # pragma: no cover

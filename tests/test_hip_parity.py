@@ -76,8 +76,31 @@ def test_mailbox_aggregators_vs_reference(golden, fixture):
         for name in names:
             y, gh, gx = _run_mailbox(name, h, es, ed, x, ct, dev)
             if loose and name in ("std", "var"):
-                # catastrophic cancellation (mean(m^2)-mean(m)^2 at |m|~1e3): only the scale is defined
-                assert float(y.detach().abs().max()) < 1.0
+                # catastrophic cancellation (mean(m^2) - mean(m)^2 of five IDENTICAL messages at |m| ~ 1e3): the fp32
+                # result is rounding noise in the reference too, so the check is anchored on an fp64 evaluation
+                # (aggregators.py:20-28 in double) with the standard forward-error bound of the expression,
+                # |fl(var) - var| <= (d + 3) u (mean(m^2) + mean(m)^2), u = 2^-24, element by element; std = sqrt(var + eps)
+                # inherits sqrt(bound).  Gradients: as close to fp64 as the reference's own fp32 result (x4).
+                h64 = h.double().requires_grad_(True)
+                d = h.shape[1]
+                m1, m2 = h64.mean(1), (h64 * h64).mean(1)
+                var64 = torch.relu(m2 - m1 * m1)
+                y64 = var64 if name == "var" else torch.sqrt(var64 + 1e-8)
+                bound = (d + 3) * 2.0 ** -24 * (m2 + m1 * m1).detach()
+                err = (y.detach().cpu().double() - y64.detach()).abs()
+                lim = bound if name == "var" else torch.sqrt(bound + 1e-8)
+                assert bool((err <= lim + 1e-6).all()), f"{c} {name}: {float((err - lim).max()):.3e} over the fp32 error bound"
+                # Gradients: exactly 0 in exact arithmetic (identical messages).  In fp32 the relu gate [rawvar > 0] opens on
+                # rounding noise, and then  d var / d m_j = ct (2/d) (m_j - fl(mean)),  |m_j - fl(mean)| <= (d + 1) u |m|;
+                # for std that is divided by 2 std with std >= sqrt(u) |m| whenever the gate is open (one quantum of m^2).
+                (gh64,) = torch.autograd.grad(y64, h64, ct.double())
+                assert float(gh64.abs().max()) <= 1e-9
+                u, cta, ma = 2.0 ** -24, ct.double().abs().unsqueeze(1), h.double().abs()
+                lim_var = cta * (2.0 / d) * (d + 1) * u * ma + 1e-6
+                lim_g = lim_var if name == "var" else cta * 2.0 * (d + 1) / d * 2.0 ** -12 + 1e-6
+                errg = gh.detach().cpu().double().abs()
+                assert bool((errg <= lim_g).all()), f"{c} {name} gh: {float((errg - lim_g).max()):.3e} over the bound"
+                assert float(gx.abs().max()) == 0.0
                 continue
             _close(y, g[f"{c}/{name}/y"], msg=f"{c} {name} y")
             _close(gh, g[f"{c}/{name}/gh"], msg=f"{c} {name} gh")
