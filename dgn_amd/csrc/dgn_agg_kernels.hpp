@@ -105,6 +105,21 @@ struct AggParams {
     const int32_t* csc_pos;
     int32_t n_slots;
     int32_t n_coef;
+    // window-local scatter (agg_bwd_window): row windows of the graph build, see DgnGraph.win_ptr
+    const int32_t* win_ptr;   // [n_win + 1] first row of every window, NULL = row kernels
+    int64_t n_win;
+    int32_t win_rows;         // most rows a window has
+    int32_t win_ecap;         // csc entries of a window that live in LDS (the others go through `stage`)
+    const int32_t* rem_ptr;   // [n_src + 1]  csc entries that go through `stage`, per source (NULL: there are none)
+    const int32_t* rem_idx;   // their csc positions
+};
+
+// LDS views of agg_bwd_window: the window's csc entries [c0, c1) and the rows' d x_dst / d x_in
+struct WinCtx {
+    float* ent;
+    float* rb_dst;
+    float* rb_in;
+    int c0, c1, lrow;
 };
 
 // accumulator slot ids in the hub workspace
@@ -1020,10 +1035,10 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
 
 // emit dm_j for the cnt slots of one loaded slot batch (my_tpos: the lane's csc position, two-phase scatter);
 // adds them to the row-sum rsum.  Active lanes only.
-template <class C, bool NEED_M>
+template <class C, bool NEED_M, bool WIN = false>
 __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                            const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
-                                           const float (&xd)[C::VEC]) {
+                                           const float (&xd)[C::VEC], const WinCtx& wc = WinCtx{}) {
     constexpr int VEC = C::VEC, U = DGN_UNROLL;
     const MsgSrc<VEC> src(p);
     for (int k0 = 0; k0 < cnt; k0 += U) {
@@ -1078,7 +1093,15 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
                 }
                 rsum[i] += gm[i];
             }
-            if (p.g_src) {
+            bool parked = false;
+            if constexpr (WIN) {
+                // the source lives in this workgroup's window: the row waits in LDS for the window's own reduction
+                if (tp >= wc.c0 && tp < wc.c1) {
+                    stv<VEC>(wc.ent + (tp - wc.c0) * p.F + f0, gm);
+                    parked = true;
+                }
+            }
+            if (p.g_src && !parked) {
                 if (p.stage) {
                     // atomic-free path: park the row at its csc position; seg_sum_rows adds each source's rows
                     stv<VEC>(p.stage + (int64_t)tp * p.F + f0, gm);
@@ -1117,17 +1140,17 @@ __device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C:
     emit_range<C, false>(k, rsum, p, beg, end, f0, active, xd);
 }
 
-template <class C>
+template <class C, bool WIN = false>
 __device__ __forceinline__ void emit_batch_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                                     const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
-                                                    const float (&xd)[C::VEC]) {
+                                                    const float (&xd)[C::VEC], const WinCtx& wc = WinCtx{}) {
     if constexpr (C::STATS) {
         if (p.need & NEED_M_EMIT) {
-            emit_batch<C, true>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
+            emit_batch<C, true, WIN>(k, rsum, p, b, my_tpos, base, cnt, f0, xd, wc);
             return;
         }
     }
-    emit_batch<C, false>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
+    emit_batch<C, false, WIN>(k, rsum, p, b, my_tpos, base, cnt, f0, xd, wc);
 }
 
 // per-row gradients d x_dst (= row sum of dm_j) and d x_in.  `plain`: the caller owns the row (row kernel in
@@ -1152,6 +1175,78 @@ __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f
 #pragma unroll
             for (int i = 0; i < VEC; ++i) unsafeAtomicAdd(dst + i, gxin[i]);
         }
+    }
+}
+
+// Backward of one row whose slots fit ONE slot batch (every row of a molecule / kNN graph): one batch load serves
+// recompute and emit, and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static
+// lists), gathers -- is issued before the first store; separate passes would re-load the batch after the recompute and
+// fetch the gradient after the gather wait (two more dependent round trips per row).
+// WIN (agg_bwd_window): per-edge rows whose source lives in the workgroup's window and the row's own d x_dst / d x_in
+// go to LDS (wc) instead of memory.
+template <class C, class O, bool WIN>
+__device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, int beg, int end, int f0, bool active,
+                                                  const WinCtx& wc) {
+    constexpr int VEC = C::VEC;
+    const int deg = end - beg;
+    float xd[VEC], xin[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
+    const float logd = p.log_deg ? p.log_deg[row] : 0.f;
+    const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+    Acc<C, true> acc;
+    acc.init();
+    Coef<C> k;
+    float gxin[VEC], rsum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
+    SlotBatch<C::NCH, C::NW> b;
+    b.load(p, beg, end);
+    const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+    const bool recomp = (p.need & NEED_RECOMP) != 0;
+    if constexpr (C::NCH > 0) {
+        if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(b.w[c]);       // (all lanes still here)
+        }
+    }
+    if (!active) return;
+    if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    constexpr bool PRE = O::kStatic && O::NA <= 8;
+    float gpre[PRE ? O::NA : 1][VEC];
+    const bool pre = PRE && O::n_scalers(p) == 1;
+    if constexpr (PRE) {
+        if (pre) {
+#pragma unroll
+            for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[a], grow + sa_col(p, 0, a));
+        }
+    }
+    const MsgSrc<VEC> src(p);
+    if (recomp) accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
+    if constexpr (PRE) {
+        if (pre) {
+            make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int, float (&g)[VEC]) {
+#pragma unroll
+                for (int aa = 0; aa < O::NA; ++aa) {
+                    if (aa == a) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) g[i] = gpre[aa][i];
+                    }
+                }
+            }, deg, xin, logd);
+        } else {
+            make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
+        }
+    } else {
+        make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
+    }
+    emit_batch_dispatch<C, WIN>(k, rsum, p, b, my_tpos, beg, deg, f0, xd, wc);
+    if constexpr (WIN) {
+        if (p.g_dst) stv<VEC>(wc.rb_dst + wc.lrow * p.F + f0, rsum);
+        if (p.g_in) stv<VEC>(wc.rb_in + wc.lrow * p.F + f0, gxin);
+    } else {
+        add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
     }
 }
 
@@ -1208,53 +1303,7 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     if (deg <= kWave) {
-        // Row in one slot batch (every row of a molecule / kNN graph): ONE batch load serves recompute and emit,
-        // and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static lists),
-        // gathers -- is issued before the first store; the separate passes re-loaded the batch after the
-        // recompute and fetched the gradient after the gather wait (two more dependent round trips per row).
-        SlotBatch<C::NCH, C::NW> b;
-        b.load(p, beg, end);
-        const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
-        const bool recomp = (p.need & NEED_RECOMP) != 0;
-        if constexpr (C::NCH > 0) {
-            if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
-#pragma unroll
-                for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(b.w[c]);       // (all lanes still here)
-            }
-        }
-        if (!active) return;
-        if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-        if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
-        constexpr bool PRE = O::kStatic && O::NA <= 8;
-        float gpre[PRE ? O::NA : 1][VEC];
-        const bool pre = PRE && O::n_scalers(p) == 1;
-        if constexpr (PRE) {
-            if (pre) {
-#pragma unroll
-                for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[a], grow + sa_col(p, 0, a));
-            }
-        }
-        const MsgSrc<VEC> src(p);
-        if (recomp) accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
-        if constexpr (PRE) {
-            if (pre) {
-                make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int, float (&g)[VEC]) {
-#pragma unroll
-                    for (int aa = 0; aa < O::NA; ++aa) {
-                        if (aa == a) {
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) g[i] = gpre[aa][i];
-                        }
-                    }
-                }, deg, xin, logd);
-            } else {
-                make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
-            }
-        } else {
-            make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
-        }
-        emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
-        add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
+        bwd_row_one_batch<C, O, false>(p, row, beg, end, f0, active, WinCtx{});
         return;
     }
     if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);

@@ -203,8 +203,13 @@ def test_c5_full_graph_sampled_rows_and_properties():
     w_sh = shard.edge_weights(plan, eig)
     out_sh = torch.empty(r1 - r0, W, device=dev)
     launch_forward(shard, plan, 1, avg, w_sh, X, None, None, X[r0:r1], out_sh)
-    rel = float((out_sh - ref_rows).abs().max() / ref_rows.abs().max().clamp_min(1.0))
-    assert rel < 2e-5, rel                                                      # slices merge in slot order: only the association differs
+    # slices merge in slot order: only the association of the fp32 sums differs.  One wave adding the d ~ 1e6 messages of
+    # the largest hub one after the other carries ~ sqrt(d) u relative rounding noise (the sliced path is the MORE accurate
+    # one), so that row gets a bound that grows with sqrt(d); every other row of the range must agree to 2e-5.
+    d_loc = deg[r0:r1].float()
+    per_row = (out_sh - ref_rows).abs().amax(1) / ref_rows.abs().amax(1).clamp_min(1.0)
+    lim = torch.clamp(2.0 ** -23 * torch.sqrt(d_loc) * 4.0, min=2e-5)
+    assert bool((per_row <= lim).all()), (float((per_row / lim).max()), int(torch.argmax(per_row / lim)) + r0)
     del out_sh, ref_rows, shard, w_sh
     # linearity of the linear aggregators (mean, sum) under every scaler, on the sampled rows
     gotY = fwd(Y)[sample_d].cpu()
