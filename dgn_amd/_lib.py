@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -32,7 +32,9 @@ class DgnGraph(C.Structure):
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
                 ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
-                ("n_src", C.c_int64), ("row_base", C.c_int64)]
+                ("n_src", C.c_int64), ("row_base", C.c_int64), ("win_ptr", C.c_void_p), ("n_win", C.c_int64),
+                ("win_rows", C.c_int32), ("win_ecap", C.c_int32), ("rem_ptr", C.c_void_p), ("rem_idx", C.c_void_p),
+                ("n_remote", C.c_int64)]
 
 
 class DgnChannel(C.Structure):

@@ -118,7 +118,67 @@ class DGNGraph:
         ptr[1:] = torch.cumsum(out_deg, 0)
         self.csc_ptr, self.csc_pos = ptr.int().contiguous(), pos.int().contiguous()
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+        self._build_windows(order, ptr)
         self._csc_ready = True
+
+    # ---- row windows of the window-local backward scatter (include/dgn_hip.h: DgnGraph.win_ptr) ----
+    WIN_BIN = 16        # rows per bin; a window spans at most 3 bins - 1 rows
+    WIN_ECAP = 96       # csc entries of a window kept in LDS
+
+    def _build_windows(self, order: torch.Tensor, csc_ptr: torch.Tensor) -> None:
+        """Cut the rows into windows of at most ``3 * WIN_BIN - 1`` rows, preferring CLOSED cuts -- places no edge
+        crosses, i.e. the boundaries between the graphs of a batch -- so that (almost) every per-edge gradient row of a
+        batch of small graphs is reduced inside its window's LDS.  Every bin of WIN_BIN rows contributes at most one cut
+        (its last closed one; a forced one at its end when it and the bin before have none), so the number of windows is
+        static and the whole build is a handful of device ops: no host loop over the graphs.  Square graphs whose rows all
+        fit one slot batch only (the kernel's domain)."""
+        N, E, dev = self.num_nodes, self.num_edges, self.device
+        self.n_remote, self.win_ptr = 0, None
+        if self.num_src != N or self.n_hub or E == 0 or not (0 < self.max_in_degree <= 64) or N < 2:
+            return
+        R0 = self.WIN_BIN
+        rows = torch.arange(N, device=dev)
+        src = self.src.long()
+        dst = torch.repeat_interleave(rows, self.in_degree)                       # destination of every CSR slot
+        lo_e, hi_e = torch.minimum(src, dst), torch.maximum(src, dst)
+        # a cut after row r is closed iff no edge has one end <= r and the other > r: count the edges spanning it
+        span = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        span.index_add_(0, lo_e, torch.ones_like(lo_e))
+        span.index_add_(0, hi_e, -torch.ones_like(hi_e))
+        closed = torch.cumsum(span[:N], 0) == 0                                    # [N]: cut after row r crosses nothing
+        nb = (N + R0 - 1) // R0
+        last_closed = torch.full((nb,), -1, dtype=torch.int64, device=dev)
+        last_closed.scatter_reduce_(0, rows // R0, torch.where(closed, rows, torch.full_like(rows, -1)), "amax")
+        has = last_closed >= 0
+        prev_has = torch.cat([has.new_ones(1), has[:-1]])
+        bin_end = torch.clamp((torch.arange(nb, device=dev) + 1) * R0 - 1, max=N - 1)
+        cut = torch.where(has, last_closed, torch.where(~prev_has, bin_end, torch.full_like(bin_end, -1)))
+        cut[-1] = N - 1
+        win_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+        win_ptr[1:] = torch.cummax(cut + 1, 0)[0]
+        # which csc entries stay in LDS: source and destination in the same window, position within the window's first
+        # WIN_ECAP csc entries.  The others ("remote") go through the staging buffer; listed per source.
+        win_of_row = torch.bucketize(rows, win_ptr[1:], right=True)               # window b holds rows [ptr[b], ptr[b+1])
+        e_src, e_dst = src[order], dst[order]                                      # csc entry k: source, destination
+        k = torch.arange(E, device=dev)
+        w_src = win_of_row[e_src]
+        local = (w_src == win_of_row[e_dst]) & (k - csc_ptr[win_ptr[w_src]] < self.WIN_ECAP)
+        rem_idx = torch.nonzero(~local).flatten()                                  # (the build's host sync for this view)
+        self.n_remote = int(rem_idx.numel())
+        self.local_fraction = 1.0 - self.n_remote / E
+        if self.local_fraction < 0.5:          # e.g. k-NN graphs with unordered points: the windows catch little
+            self.n_remote = 0
+            return
+        self.win_ptr = win_ptr.int().contiguous()
+        c = self._c
+        c.win_ptr, c.n_win, c.win_rows, c.win_ecap = self.win_ptr.data_ptr(), nb, 3 * R0 - 1, self.WIN_ECAP
+        c.n_remote = self.n_remote
+        if self.n_remote:
+            rem_cnt = torch.bincount(e_src[rem_idx], minlength=N)
+            rem_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+            rem_ptr[1:] = torch.cumsum(rem_cnt, 0)
+            self.rem_ptr, self.rem_idx = rem_ptr.int().contiguous(), rem_idx.int().contiguous()
+            c.rem_ptr, c.rem_idx = self.rem_ptr.data_ptr(), self.rem_idx.data_ptr()
 
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----
     def number_of_nodes(self) -> int:
@@ -130,6 +190,14 @@ class DGNGraph:
     @property
     def c_graph(self) -> _lib.DgnGraph:
         return self._c
+
+    @property
+    def c_graph_no_windows(self) -> _lib.DgnGraph:
+        """The same graph description without the row windows (the backward then stages every per-edge row globally)."""
+        c = _lib.DgnGraph()
+        C.memmove(C.byref(c), C.byref(self._c), C.sizeof(_lib.DgnGraph))
+        c.win_ptr, c.n_win, c.rem_ptr, c.rem_idx, c.n_remote = None, 0, None, None, 0
+        return c
 
     def to_slot_order(self, per_edge: torch.Tensor) -> torch.Tensor:
         """[E, ...] in original edge-id order -> CSR slot order (differentiable)."""

@@ -23,6 +23,11 @@ from .spec import EPS, AggPlan
 # e.g. hidden 75: 4-byte staging rows make the two-phase path 40 % slower than atomics).
 DETERMINISTIC_BACKWARD = "auto"
 
+# Window-local scatter of the two-phase backward (agg_bwd_window: the per-edge gradient rows of a batch of small graphs are
+# reduced in LDS by the workgroup that owns their window of rows, include/dgn_hip.h: DgnGraph.win_ptr).  False: always the
+# global [E, F] staging buffer + seg_sum_rows (tests compare the two).
+WINDOW_BACKWARD = True
+
 
 def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
     key = (n_towers, float(avg_log), int(tower_stride))
@@ -120,7 +125,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     deterministic = deterministic and g_src is not None
     if deterministic:
         graph.ensure_csc()
-        g = graph.c_graph
+        g = graph.c_graph if WINDOW_BACKWARD else graph.c_graph_no_windows
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 9
+#define DGN_ABI_VERSION 10
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -110,6 +110,20 @@ typedef struct DgnGraph {
      * this CSR is node row_base + i of the source node set.  Only dgn_edge_weights uses it (the destination side of
      * eig is read at row row_base + i); the per-row arrays of the sweep (x_dst, x_in, log_deg, out) are the shard's. */
     int64_t row_base;
+    /* Optional row windows for the backward's window-local scatter (NULL = absent; needs csc_ptr / csc_pos, a square,
+     * hub-free graph whose rows all fit one slot batch).  Window b = rows [win_ptr[b], win_ptr[b+1]) (may be empty), at most
+     * win_rows rows; batched small graphs are block diagonal, so the build puts the cuts where no edge crosses whenever such
+     * a place is nearby.  A per-edge gradient row whose source AND destination lie in the same window, and whose csc position
+     * is among the first win_ecap of the window's csc range, is reduced in LDS by the workgroup that owns the window; all
+     * other csc entries ("remote": rem_ptr[u] .. rem_ptr[u+1] index rem_idx, csc positions in ascending order, per source u)
+     * go through the workspace's staging buffer.  n_remote == 0 with rem_ptr == NULL: there are none.                  */
+    const int32_t* win_ptr;  /* [n_win+1] */
+    int64_t n_win;
+    int32_t win_rows;
+    int32_t win_ecap;
+    const int32_t* rem_ptr;  /* [n_nodes+1] */
+    const int32_t* rem_idx;  /* [n_remote]  */
+    int64_t n_remote;
 } DgnGraph;
 
 typedef struct DgnChannel {

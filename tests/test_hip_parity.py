@@ -520,3 +520,84 @@ def test_bn_tail_vs_torch_batchnorm():
             ye = torch.cat([b(x0[:, i * w:(i + 1) * w]) for i, b in enumerate(ref)], dim=1)
             ye = torch.relu(ye) if relu else ye
             _close(bn_tail(x0.to(dev), mine if n_bn > 1 else mine[0], False, relu=relu), ye, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("case", ["pair", "simple", "three_term", "cut_molecules", "one_graph"])
+def test_window_backward_equals_staged_backward(monkeypatch, case):
+    """agg_bwd_window (per-edge gradient rows reduced in the LDS of the workgroup that owns their window of rows) against the
+    global two-phase scatter it replaces, on molecule batches: all sinks, run-to-run bitwise equality, the remote path
+    (edges that cross a window, windows with more csc entries than the LDS holds), and against the oracle."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.ops import directional_aggregate
+    from oracle import dgn_oracle as orc
+    if case == "one_graph":
+        # ONE connected graph (a 300-node chain with chords i -- i+3): no closed cut anywhere, so every window ends at a
+        # forced cut and the edges across it take the remote path
+        i = torch.arange(299)
+        j = torch.arange(297)
+        u, v = torch.cat([i, j]), torch.cat([i + 1, j + 3])
+        b = dict(src=torch.cat([u, v]), dst=torch.cat([v, u]), num_nodes=300)
+    else:
+        b = synth.molecule_batch(40, seed=11, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    F_ = 12 if case != "simple" else 70
+    gen = torch.Generator().manual_seed(4)
+    eig = torch.randn(N, 4, generator=gen)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    if case == "cut_molecules":
+        monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_ECAP", 40)             # fewer LDS entries than a window's csc range
+    graph.ensure_csc()
+    assert graph.win_ptr is not None
+    if case in ("one_graph", "cut_molecules"):
+        assert graph.n_remote > 0
+    aggs, scalers = ["mean", "max", "min", "std", "dir1-av", "dir1-dx", "dir2-dx-no-abs"], ["identity", "attenuation"]
+    plan = dgn_amd.make_plan(aggs, scalers)
+    P, Q, X = (torch.randn(N, F_, generator=gen) for _ in range(3))
+    R = torch.randn(src.numel(), F_, generator=gen)
+    ct = torch.randn(N, plan.out_width(F_), generator=gen)
+
+    def run(window):
+        monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", window)
+        if case == "simple":
+            h = X.to(dev).requires_grad_(True)
+            y = directional_aggregate(graph, plan, 1.1, x_src=h, x_in=h)
+            return y, torch.autograd.grad(y, [h], ct.to(dev))
+        pq = torch.cat([P, Q], 1).to(dev).requires_grad_(True)
+        x = X.to(dev).requires_grad_(True)
+        leaves = [pq, x]
+        m_edge = None
+        if case == "three_term":
+            r = R.to(dev).requires_grad_(True)
+            leaves.append(r)
+            m_edge = graph.to_slot_order(r)
+        y = directional_aggregate(graph, plan, 1.1, x_pair=pq, m_edge=m_edge, x_in=x)
+        return y, torch.autograd.grad(y, leaves, ct.to(dev))
+
+    y_w, g_w = run(True)
+    y_w2, g_w2 = run(True)
+    y_s, g_s = run(False)
+    for a, b2, c in zip(g_w, g_w2, g_s):
+        assert torch.equal(a, b2)                                         # fixed summation order: bitwise reproducible
+        _close(a, c, 1e-5, 1e-5)                                          # vs the global staging path (other association)
+    # and against the oracle
+    if case == "simple":
+        lo = [X.clone().requires_grad_(True)]
+        msg, xin = lo[0][src], lo[0]
+    else:
+        lo = [P.clone().requires_grad_(True), Q.clone().requires_grad_(True), X.clone().requires_grad_(True)]
+        msg, xin = lo[0][src] + lo[1][dst], lo[2]
+        if case == "three_term":
+            lo.append(R.clone().requires_grad_(True))
+            msg = msg + lo[3]
+    yo = orc.aggregate_graph(src, dst, N, msg, eig, xin, aggs, scalers, torch.tensor(1.1))
+    go = torch.autograd.grad(yo, lo, ct)
+    _close(y_w, yo, 2e-5, 2e-5)
+    if case == "simple":
+        _close(g_w[0], go[0], 1e-4, 1e-4)
+    else:
+        _close(g_w[0], torch.cat([go[0], go[1]], 1), 1e-4, 1e-4)
+        _close(g_w[1], go[2], 1e-4, 1e-4)
+        if case == "three_term":
+            _close(g_w[2], go[3], 1e-4, 1e-4)
