@@ -32,7 +32,7 @@ class DgnGraph(C.Structure):
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
                 ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
-                ("n_src", C.c_int64), ("row_base", C.c_int64), ("win_ptr", C.c_void_p), ("n_win", C.c_int64),
+                ("n_src", C.c_int64), ("row_base", C.c_int64), ("win_ptr", C.c_void_p), ("win_info", C.c_void_p), ("n_win", C.c_int64),
                 ("win_rows", C.c_int32), ("win_ecap", C.c_int32), ("rem_ptr", C.c_void_p), ("rem_idx", C.c_void_p),
                 ("n_remote", C.c_int64)]
 

@@ -107,6 +107,7 @@ struct AggParams {
     int32_t n_coef;
     // window-local scatter (agg_bwd_window): row windows of the graph build, see DgnGraph.win_ptr
     const int32_t* win_ptr;   // [n_win + 1] first row of every window, NULL = row kernels
+    const int32_t* win_info;  // [n_win][8]: first row, rows, first slot, end slot, first csc entry, end csc entry, 0, 0
     int64_t n_win;
     int32_t win_rows;         // most rows a window has
     int32_t win_ecap;         // csc entries of a window that live in LDS (the others go through `stage`)
@@ -120,7 +121,12 @@ struct WinCtx {
     float* rb_dst;
     float* rb_in;
     int c0, c1, lrow;
+    const int* s_src;     // the window's slot arrays in LDS (NULL: the window has more slots than the copy holds)
+    const int* s_tp;
+    const float* s_w;
+    int e0;
 };
+constexpr int kWinSlotCap = 192;     // slots (in-edges) of a window whose src / weights / csc positions are copied to LDS
 
 // accumulator slot ids in the hub workspace
 constexpr int SLOT_SUM = 0, SLOT_SQ = 1, SLOT_MAX = 2, SLOT_MIN = 3, SLOT_AMAX = 4, SLOT_AMIN = 5, SLOT_W0 = 6;
@@ -282,6 +288,17 @@ struct SlotBatch {
         for (int c = 0; c < NW; ++c) w[c] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) w[c] = in ? p.w[(int64_t)c * p.ld_w + e] : 0.f;
+    }
+    // the same batch from a workgroup's LDS copy of the window's slot arrays (agg_bwd_window): s_src / s_w[c * ld] hold the
+    // window's slots e0 .. ; off = base - e0
+    __device__ __forceinline__ void load_lds(const int* s_src, const float* s_w, int ld, int off, int cnt) {
+        const int l = lane_id();
+        const bool in = l < cnt;
+        src = in ? s_src[off + l] : 0;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) w[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) w[c] = in ? s_w[c * ld + off + l] : 0.f;
     }
     __device__ __forceinline__ void weights(float (&wk)[NW], int k) const {
 #pragma unroll
@@ -1201,8 +1218,19 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     SlotBatch<C::NCH, C::NW> b;
-    b.load(p, beg, end);
-    const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+    int my_tpos = 0;
+    bool from_lds = false;
+    if constexpr (WIN) {
+        if (wc.s_src) {          // the slot arrays are already in LDS: the gathers below are this row's FIRST memory round trip
+            b.load_lds(wc.s_src, wc.s_w, kWinSlotCap, beg - wc.e0, deg);
+            my_tpos = lane_id() < deg ? wc.s_tp[beg - wc.e0 + lane_id()] : 0;
+            from_lds = true;
+        }
+    }
+    if (!from_lds) {
+        b.load(p, beg, end);
+        my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+    }
     const bool recomp = (p.need & NEED_RECOMP) != 0;
     if constexpr (C::NCH > 0) {
         if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
@@ -1477,31 +1505,51 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
 // staging buffer as before and are added by seg_sum_rows<VEC, true>.
 constexpr int kWinWaves = 8;
 
+// LDS carve-up of agg_bwd_window (floats): [ip | cp | s_src | s_tp] ints, then s_w, ent, rb_dst, rb_in
+__host__ __device__ inline int win_int_words(int win_rows) { return ((2 * (win_rows + 1) + 2 * kWinSlotCap + 3) & ~3); }
+
 template <class C, class O = DynOps>
 __global__ __launch_bounds__(kWave * kWinWaves) void agg_bwd_window(const AggParams p) {
     constexpr int VEC = C::VEC;
     extern __shared__ float lds_win[];
     const int64_t lb = xcd_remap(blockIdx.x, p.n_win);
     if (lb < 0) return;
-    const int r0 = p.win_ptr[lb], nrows = p.win_ptr[lb + 1] - r0;
+    // one record per window: first row, rows, slot range, csc range -- everything the workgroup needs to ask for its inputs
+    const int* wi = p.win_info + lb * 8;
+    const int r0 = wi[0], nrows = wi[1], e0 = wi[2], e1 = wi[3], c0 = wi[4];
     if (nrows <= 0) return;                                              // (bins that hold no cut: empty windows)
+    const int c1 = min(wi[5], c0 + p.win_ecap);
     const int F = p.F, tid = threadIdx.x;
-    int* cp = reinterpret_cast<int*>(lds_win);                            // csc_ptr of the window's rows
-    float* ent = lds_win + ((p.win_rows + 1 + 3) & ~3);
+    int* ip = reinterpret_cast<int*>(lds_win);                            // indptr of the window's rows
+    int* cp = ip + p.win_rows + 1;                                        // csc_ptr of the window's rows
+    int* s_src = cp + p.win_rows + 1;
+    int* s_tp = s_src + kWinSlotCap;
+    float* s_w = lds_win + win_int_words(p.win_rows);
+    float* ent = s_w + C::NCH * kWinSlotCap;
     float* rb_dst = ent + p.win_ecap * F;
     float* rb_in = rb_dst + (p.g_dst ? p.win_rows * F : 0);
-    for (int i = tid; i <= nrows; i += blockDim.x) cp[i] = p.csc_ptr[r0 + i];
-    __syncthreads();
-    const int c0 = cp[0], c1 = min(cp[nrows], c0 + p.win_ecap);
+    const bool slots_in_lds = e1 - e0 <= kWinSlotCap;
+    for (int i = tid; i <= nrows; i += blockDim.x) {
+        ip[i] = p.indptr[r0 + i];
+        cp[i] = p.csc_ptr[r0 + i];
+    }
+    if (slots_in_lds) {
+        for (int i = tid; i < e1 - e0; i += blockDim.x) {
+            s_src[i] = p.src[e0 + i];
+            s_tp[i] = p.csc_pos[e0 + i];
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) s_w[c * kWinSlotCap + i] = p.w[(int64_t)c * p.ld_w + e0 + i];
+        }
+    }
     for (int i = tid; i < (c1 - c0) * F; i += blockDim.x) ent[i] = 0.f;   // entries whose destination is elsewhere stay zero
     __syncthreads();
     const int f0 = lane_id() * VEC;
     const bool active = f0 < F;
-    WinCtx wc{ent, rb_dst, rb_in, c0, c1, 0};
+    WinCtx wc{ent, rb_dst, rb_in, c0, c1, 0, slots_in_lds ? s_src : nullptr, s_tp, s_w, e0};
     for (int lr = tid >> 6; lr < nrows; lr += kWinWaves) {
         const int row = uniform_i(r0 + lr);
         wc.lrow = lr;
-        const int beg = p.indptr[row], end = p.indptr[row + 1];
+        const int beg = uniform_i(ip[lr]), end = uniform_i(ip[lr + 1]);
         if (end == beg) {
             // row without messages: no gradient -- except through the x_in pass-through block
             if (active) {
@@ -1553,7 +1601,7 @@ __global__ __launch_bounds__(kWave * kWinWaves) void agg_bwd_window(const AggPar
 
 inline size_t window_lds_bytes(const AggParams& p) {
     const int nbuf = (p.g_dst ? 1 : 0) + (p.g_in ? 1 : 0);
-    return ((size_t)((p.win_rows + 1 + 3) & ~3) + (size_t)(p.win_ecap + nbuf * p.win_rows) * p.F) * sizeof(float);
+    return ((size_t)win_int_words(p.win_rows) + (size_t)p.n_ch * kWinSlotCap + (size_t)(p.win_ecap + nbuf * p.win_rows) * p.F) * sizeof(float);
 }
 
 // ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------

@@ -170,8 +170,13 @@ class DGNGraph:
             self.n_remote = 0
             return
         self.win_ptr = win_ptr.int().contiguous()
+        ip64 = self.indptr.long()
+        zero = torch.zeros(nb, dtype=torch.int64, device=dev)
+        self.win_info = torch.stack([win_ptr[:-1], win_ptr[1:] - win_ptr[:-1], ip64[win_ptr[:-1]], ip64[win_ptr[1:]],
+                                     csc_ptr[win_ptr[:-1]], csc_ptr[win_ptr[1:]], zero, zero], dim=1).int().contiguous()
         c = self._c
         c.win_ptr, c.n_win, c.win_rows, c.win_ecap = self.win_ptr.data_ptr(), nb, 3 * R0 - 1, self.WIN_ECAP
+        c.win_info = self.win_info.data_ptr()
         c.n_remote = self.n_remote
         if self.n_remote:
             rem_cnt = torch.bincount(e_src[rem_idx], minlength=N)
@@ -196,7 +201,7 @@ class DGNGraph:
         """The same graph description without the row windows (the backward then stages every per-edge row globally)."""
         c = _lib.DgnGraph()
         C.memmove(C.byref(c), C.byref(self._c), C.sizeof(_lib.DgnGraph))
-        c.win_ptr, c.n_win, c.rem_ptr, c.rem_idx, c.n_remote = None, 0, None, None, 0
+        c.win_ptr, c.win_info, c.n_win, c.rem_ptr, c.rem_idx, c.n_remote = None, None, 0, None, None, 0
         return c
 
     def to_slot_order(self, per_edge: torch.Tensor) -> torch.Tensor:

@@ -25,8 +25,11 @@ DETERMINISTIC_BACKWARD = "auto"
 
 # Window-local scatter of the two-phase backward (agg_bwd_window: the per-edge gradient rows of a batch of small graphs are
 # reduced in LDS by the workgroup that owns their window of rows, include/dgn_hip.h: DgnGraph.win_ptr).  False: always the
-# global [E, F] staging buffer + seg_sum_rows (tests compare the two).
-WINDOW_BACKWARD = True
+# global [E, F] staging buffer + seg_sum_rows (tests compare the two).  "auto": where it measured faster on ZINC-12k
+# (profiles/r02_window_backward.txt) -- layers whose message is x_src alone (simple layers: one LDS row buffer, three workgroups
+# per CU: 0.207 -> 0.184 ms); P|Q messages (two row buffers next to 96 VGPRs: two workgroups per CU) measured 0.349 -> 0.375 ms and
+# keep the global staging path.  "all": wherever the kernel applies.
+WINDOW_BACKWARD = "auto"
 
 
 def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
@@ -125,7 +128,8 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     deterministic = deterministic and g_src is not None
     if deterministic:
         graph.ensure_csc()
-        g = graph.c_graph if WINDOW_BACKWARD else graph.c_graph_no_windows
+        use_windows = bool(WINDOW_BACKWARD) and (WINDOW_BACKWARD == "all" or g_dst is None)
+        g = graph.c_graph if use_windows else graph.c_graph_no_windows
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None

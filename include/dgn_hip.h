@@ -118,6 +118,8 @@ typedef struct DgnGraph {
      * other csc entries ("remote": rem_ptr[u] .. rem_ptr[u+1] index rem_idx, csc positions in ascending order, per source u)
      * go through the workspace's staging buffer.  n_remote == 0 with rem_ptr == NULL: there are none.                  */
     const int32_t* win_ptr;  /* [n_win+1] */
+    const int32_t* win_info; /* [n_win][8]: win_ptr[b], rows, indptr at both ends, csc_ptr at both ends, 0, 0 (one record the
+                                 workgroup of window b reads instead of three dependent look-ups)                           */
     int64_t n_win;
     int32_t win_rows;
     int32_t win_ecap;
