@@ -51,6 +51,9 @@ WORKLOADS = {
                     "mean max min dir1-av dir1-dx x identity amplification attenuation",
                gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
+    "c2e": dict(desc="ZINC-12k towers as c2 WITH edge features (edge_dim 10: pretrans on [h_src || h_dst || ef])",
+                gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
+                aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5, edge_dim=10),
     "c2_b128": dict(desc="ZINC batch of 128 molecules, DGN towers (as c2)",
                     gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                     aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
@@ -256,13 +259,15 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     N, E = graph.num_nodes, graph.num_edges
     torch.manual_seed(0)
     avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
+    edge_dim = wl.get("edge_dim", 0)
     layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
-                             wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev)
+                             wl["type_net"], True, towers=wl["towers"], edge_features=edge_dim > 0, edge_dim=edge_dim).model.to(dev)
     layer.train()
     gen = torch.Generator(device=dev).manual_seed(rank)
     h = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
     ct = torch.randn(N, F_, device=dev, generator=gen)
     snorm = batch["snorm_n"].to(dev)
+    ef = torch.randn(E, edge_dim, device=dev, generator=gen).requires_grad_(True) if edge_dim else None
     reducer = ddist.FlatGradAllReduce(layer.parameters()) if torch.distributed.is_initialized() else None
 
     params = list(layer.parameters())      # (what an optimizer holds; walking the module tree costs 0.1 ms per step)
@@ -270,9 +275,11 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     def step():
         graph._wcache.clear()              # per-edge weights are recomputed every step (eig flips per batch)
         h.grad = None
+        if ef is not None:
+            ef.grad = None
         for p in params:
             p.grad = None
-        y = layer(graph, h, None, snorm)
+        y = layer(graph, h, ef, snorm)
         y.backward(ct)
         if reducer is not None:
             reducer()
@@ -285,7 +292,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
             raise SystemExit("--hipgraph is a single-GPU mode (the gradient all-reduce is not captured)")
         def bare_step():                   # (gradients stay None: the captured backward writes fresh ones per replay)
             graph._wcache.clear()
-            layer(graph, h, None, snorm).backward(ct)
+            layer(graph, h, ef, snorm).backward(ct)
 
         def reset():
             h.grad = None
@@ -355,13 +362,19 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
         g_out = torch.randn(N, plan.out_width(Fk), device=dev, generator=gen)
     g_src, g_dst, g_in = torch.zeros(N, Fk, device=dev), (torch.zeros(N, Fk, device=dev) if xd is not None else None), torch.zeros(N, Fk, device=dev)
     reps = 20
-    ms_f = event_ms(lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out), reps, dev)
-    ms_b = event_ms(lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in,
-                                            accumulate=False), reps, dev)
+    # with edge features the message has a third, per-edge term R = ef W_e^T [E, F] in slot order (materialised by a streaming
+    # Linear): the sweep reads it (+4F per edge, forward and -- with max/min/std -- backward) and the backward writes d R
+    me = torch.randn(E, F_, device=dev, generator=gen) if edge_dim else None
+    g_me = torch.empty(E, F_, device=dev) if edge_dim else None
+    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out)
+    bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False)
+    ms_f = event_ms(fwd_call, reps, dev)
+    ms_b = event_ms(bwd_call, reps, dev)
     ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
-    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, None, hd, out)
-    bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, None, hd, g_out, g_src, g_dst, None, g_in, accumulate=False)
+    if edge_dim:
+        bf += 4 * F_ * E
+        bb += 4 * F_ * E * (1 + r)
     pct = (lambda fn: event_percentiles(fn, dev)) if args.percentiles else (lambda fn: None)
     bw = E * (4 + 8 * Ku + 4 * Ku) + N * 4        # edge weights: src id, both eig endpoints per channel, weight out; row pointer
     kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK,
@@ -413,6 +426,19 @@ def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
     else:
         graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
     N_all = indptr.numel() - 1
+    eig_info = None
+    if args.c5_eig == "lobpcg" and not partition:
+        # real Laplacian eigenvectors instead of random columns: k lowest eigenpairs of D - (A + A^T)/2 by
+        # LOBPCG on the sweep's own products; column 0 of eig is the trivial one, dir1..3 read columns 1..3
+        from dgn_amd.eig import lobpcg_eigvecs
+        torch.cuda.synchronize(dev)
+        t_e = time.perf_counter()
+        eig, lam, its, res = lobpcg_eigvecs(graph, eig.shape[1], iters=args.c5_eig_iters, tol=1e-3,
+                                            generator=torch.Generator(device=dev).manual_seed(0))
+        torch.cuda.synchronize(dev)
+        eig_info = dict(method="LOBPCG on the sweep's sum-aggregator products", seconds=time.perf_counter() - t_e, iterations=its,
+                        eigenvalues=[float(v) for v in lam], residual_norms=[float(v) for v in res])
+        graph.ndata["eig"] = eig
     del indptr
     N, E, F_ = graph.num_nodes, graph.num_edges, wl["hidden"]
     plan = dgn_amd.make_plan(wl["aggregators"].split(), wl["scalers"].split())
@@ -442,7 +468,7 @@ def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
     result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
-                  scaling="strong" if partition else "weak",
+                  eig=eig_info or "random columns", scaling="strong" if partition else "weak",
                   parallelism=(f"1 graph, {world} destination-range shards (balanced edges), features replicated, no exchange "
                                f"inside the sweep") if partition else (f"{world} independent replicas" if world > 1 else "single GPU"))
     if rank == 0:
@@ -492,6 +518,8 @@ def compact(result):
     r = result.get("roofline") or {}
     out = dict(ms_per_step=result["ms_per_step"], value=result["value"], unit="edges/s", edges=result["edges_per_rank"],
                nodes=result["nodes_per_rank"])
+    if "eig" in result:
+        out["eig"] = result["eig"]
     if r:
         out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "frac_of_triad", "model", "frac_with_survey_A") if k in r}
@@ -503,7 +531,7 @@ def compact(result):
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2_b128", 20, 5), ("c5", 3, 1)]
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2_b128", 20, 5), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()
@@ -537,6 +565,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="c5 only: scale N and E")
     ap.add_argument("--c5-mode", default="partition", choices=["partition", "replicas"],
                     help="c5 with --gpus > 1: one graph split by destination ranges (strong scaling) or one graph per rank")
+    ap.add_argument("--c5-eig", default="random", choices=["random", "lobpcg"],
+                    help="c5: eig columns are random numbers (the sweep's cost does not depend on the values) or the graph's lowest "
+                         "Laplacian eigenvectors computed by dgn_amd.eig.lobpcg_eigvecs")
+    ap.add_argument("--c5-eig-iters", type=int, default=40)
     ap.add_argument("--aggregators", default=None, help="override the workload's aggregator string (experiments)")
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

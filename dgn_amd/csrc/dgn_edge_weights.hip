@@ -36,6 +36,8 @@ struct EwParams {
     const float* eig_d;    // [E, ld]
     int64_t ld_eig;
     int32_t n_ch;
+    int32_t vw;            // vector width (floats) of the eig row loads: 4, 2 or 1
+    int32_t n_need;        // floats of a row prefix the channels read (largest column + 1, capped at kEigRegs)
     DgnChannel ch[DGN_MAX_CH];
     float* w;
     int64_t ld_w;
@@ -47,14 +49,95 @@ struct Stats {  // per channel
     float sabs, spos, sneg, mx, se;
 };
 
-__device__ __forceinline__ float edge_delta(const EwParams& p, int row, int e, int col) {
-    if (p.eig_s) return p.eig_s[(int64_t)e * p.ld_eig + col] - p.eig_d[(int64_t)e * p.ld_eig + col];
-    return p.eig[(int64_t)p.src[e] * p.ld_eig + col] - p.eig[(p.row_base + row) * p.ld_eig + col];
+// ---- eig access ---------------------------------------------------------------------------------------------------
+// An edge needs eig[src, col_c] for every channel c.  The columns of one node are adjacent (eig is [N, K] row major, K = 4..7),
+// so the row prefix up to the largest column used is fetched with ONE (K = 4: 16-byte) vector load per endpoint and the
+// channels pick their column from registers -- instead of one dependent 4-byte gather per channel and pass (round 1: 6 gathers
+// per edge on C5's three channels, 0.41 TB/s).  `vw` = widest vector the row stride / base alignment allow (host-chosen);
+// columns >= kEigRegs fall back to scalar loads.
+constexpr int kEigRegs = 8;
+
+__device__ __forceinline__ void load_eig_prefix(float (&v)[kEigRegs], const float* rowp, int n_need, int vw) {
+#pragma unroll
+    for (int i = 0; i < kEigRegs; ++i) v[i] = 0.f;
+    if (vw == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(rowp);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        if (n_need > 4) {
+            const float4 b = *reinterpret_cast<const float4*>(rowp + 4);
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+    } else if (vw == 2) {
+#pragma unroll
+        for (int i = 0; i < kEigRegs / 2; ++i) {
+            if (2 * i < n_need) {
+                const float2 a = *reinterpret_cast<const float2*>(rowp + 2 * i);
+                v[2 * i] = a.x; v[2 * i + 1] = a.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kEigRegs; ++i)
+            if (i < n_need) v[i] = rowp[i];
+    }
+}
+__device__ __forceinline__ float pick_col(const float (&v)[kEigRegs], int col) {
+    float r = 0.f;                      // compare chain: a dynamic register index would go to scratch
+#pragma unroll
+    for (int i = 0; i < kEigRegs; ++i) r = (i == col) ? v[i] : r;
+    return r;
+}
+
+// destination side of a row (node mode): wave-uniform scalars
+struct RowEig {
+    float d[DGN_MAX_CH];
+    __device__ __forceinline__ void load(const EwParams& p, int row) {
+#pragma unroll
+        for (int c = 0; c < DGN_MAX_CH; ++c) d[c] = (c < p.n_ch && p.eig) ? p.eig[(p.row_base + row) * p.ld_eig + p.ch[c].eig_col] : 0.f;
+    }
+};
+
+// delta_c of slot e for every channel
+__device__ __forceinline__ void edge_deltas(float (&dl)[DGN_MAX_CH], const EwParams& p, const RowEig& re, int e) {
+    float vs[kEigRegs];
+    if (p.eig_s) {      // slot mode: both endpoints per slot
+        float vd[kEigRegs];
+        load_eig_prefix(vs, p.eig_s + (int64_t)e * p.ld_eig, p.n_need, p.vw);
+        load_eig_prefix(vd, p.eig_d + (int64_t)e * p.ld_eig, p.n_need, p.vw);
+#pragma unroll
+        for (int c = 0; c < DGN_MAX_CH; ++c) {
+            dl[c] = 0.f;
+            if (c < p.n_ch) {
+                const int col = p.ch[c].eig_col;
+                dl[c] = col < kEigRegs ? pick_col(vs, col) - pick_col(vd, col)
+                                       : p.eig_s[(int64_t)e * p.ld_eig + col] - p.eig_d[(int64_t)e * p.ld_eig + col];
+            }
+        }
+        return;
+    }
+    const float* rowp = p.eig + (int64_t)p.src[e] * p.ld_eig;
+    load_eig_prefix(vs, rowp, p.n_need, p.vw);
+#pragma unroll
+    for (int c = 0; c < DGN_MAX_CH; ++c) {
+        dl[c] = 0.f;
+        if (c < p.n_ch) {
+            const int col = p.ch[c].eig_col;
+            dl[c] = (col < kEigRegs ? pick_col(vs, col) : rowp[col]) - re.d[c];
+        }
+    }
+}
+
+__device__ __forceinline__ float weight_of(const DgnChannel& ch, const Stats& st, float d) {
+    if (ch.kind == DGN_W_ABSNORM) return d / (st.sabs + ch.eps);
+    if (ch.kind == DGN_W_BALANCED) return (fmaxf(d, 0.f) / (st.spos + ch.eps) + fmaxf(-d, 0.f) / (st.sneg + ch.eps)) / 2.f;
+    return expf(ch.alpha * fabsf(d) - st.mx) / st.se;
 }
 
 // statistics of slots [beg, end) of row `row` for every channel (wave-wide results)
 __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwParams& p, int row, int beg, int end) {
     const int lane = lane_id();
+    RowEig re;
+    re.load(p, row);
     bool any_softmax = false;
 #pragma unroll
     for (int c = 0; c < DGN_MAX_CH; ++c) {
@@ -62,10 +145,12 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
         if (c < p.n_ch && p.ch[c].kind == DGN_W_SOFTMAX) any_softmax = true;
     }
     for (int e = beg + lane; e < end; e += kWave) {
+        float dl[DGN_MAX_CH];
+        edge_deltas(dl, p, re, e);
 #pragma unroll
         for (int c = 0; c < DGN_MAX_CH; ++c) {
             if (c < p.n_ch) {
-                const float d = edge_delta(p, row, e, p.ch[c].eig_col);
+                const float d = dl[c];
                 st[c].sabs += fabsf(d);
                 st[c].spos += fmaxf(d, 0.f);
                 st[c].sneg += fmaxf(-d, 0.f);
@@ -84,13 +169,11 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
     }
     if (any_softmax) {
         for (int e = beg + lane; e < end; e += kWave) {
+            float dl[DGN_MAX_CH];
+            edge_deltas(dl, p, re, e);
 #pragma unroll
-            for (int c = 0; c < DGN_MAX_CH; ++c) {
-                if (c < p.n_ch && p.ch[c].kind == DGN_W_SOFTMAX) {
-                    const float d = edge_delta(p, row, e, p.ch[c].eig_col);
-                    st[c].se += expf(p.ch[c].alpha * fabsf(d) - st[c].mx);
-                }
-            }
+            for (int c = 0; c < DGN_MAX_CH; ++c)
+                if (c < p.n_ch && p.ch[c].kind == DGN_W_SOFTMAX) st[c].se += expf(p.ch[c].alpha * fabsf(dl[c]) - st[c].mx);
         }
 #pragma unroll
         for (int c = 0; c < DGN_MAX_CH; ++c)
@@ -100,29 +183,26 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
 
 __device__ __forceinline__ void range_write(const Stats (&st)[DGN_MAX_CH], const EwParams& p, int row, int beg, int end) {
     const int lane = lane_id();
+    RowEig re;
+    re.load(p, row);
     for (int e = beg + lane; e < end; e += kWave) {
+        float dl[DGN_MAX_CH];
+        edge_deltas(dl, p, re, e);
 #pragma unroll
-        for (int c = 0; c < DGN_MAX_CH; ++c) {
-            if (c < p.n_ch) {
-                const float d = edge_delta(p, row, e, p.ch[c].eig_col);
-                const float eps = p.ch[c].eps;
-                float v;
-                if (p.ch[c].kind == DGN_W_ABSNORM) {
-                    v = d / (st[c].sabs + eps);
-                } else if (p.ch[c].kind == DGN_W_BALANCED) {
-                    v = (fmaxf(d, 0.f) / (st[c].spos + eps) + fmaxf(-d, 0.f) / (st[c].sneg + eps)) / 2.f;
-                } else {
-                    v = expf(p.ch[c].alpha * fabsf(d) - st[c].mx) / st[c].se;
-                }
-                p.w[(int64_t)c * p.ld_w + e] = v;
-            }
-        }
+        for (int c = 0; c < DGN_MAX_CH; ++c)
+            if (c < p.n_ch) p.w[(int64_t)c * p.ld_w + e] = weight_of(p.ch[c], st[c], dl[c]);
     }
 }
 
-// Rows of at most kFlatMax slots (every row of a molecule batch) are handled one per THREAD by ew_rows_flat:
-// per-edge weights are a few scalars per slot, so a wave per 2-slot row would be all launch overhead.
-constexpr int kFlatMax = 16;
+// Three row classes, one kernel each (a kernel skips the rows of the other classes; the host skips a kernel when the graph's
+// largest in-degree says its class is empty):
+//   deg <= kFlatMax (4: every row of a molecule batch)   one THREAD per row, all deltas in registers (ew_rows_flat)
+//   deg <= kGroup  (16)                                   16 lanes per row, four rows per wave (ew_rows_g16)
+//   longer                                                one wave per row (ew_rows); hub rows: slices
+// Every class gathers eig ONCE per edge (the deltas wait in registers between the statistics and the write) except wave rows
+// longer than 64 slots.
+constexpr int kFlatMax = 4;
+constexpr int kGroup = 16;
 
 __global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) {
     const int64_t row64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,29 +211,77 @@ __global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) {
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
     if (deg == 0 || deg > kFlatMax) return;
+    RowEig re;
+    re.load(p, row);
+    float dl[kFlatMax][DGN_MAX_CH];
+#pragma unroll
+    for (int j = 0; j < kFlatMax; ++j) {           // all gathers issued before the first use
+#pragma unroll
+        for (int c = 0; c < DGN_MAX_CH; ++c) dl[j][c] = 0.f;
+        if (j < deg) edge_deltas(dl[j], p, re, beg + j);
+    }
 #pragma unroll
     for (int c = 0; c < DGN_MAX_CH; ++c) {
         if (c >= p.n_ch) break;
-        const int col = p.ch[c].eig_col;
-        const float eps = p.ch[c].eps, alpha = p.ch[c].alpha;
-        const int kind = p.ch[c].kind;
-        float sabs = 0.f, spos = 0.f, sneg = 0.f, mx = -INFINITY;
-        for (int e = beg; e < end; ++e) {
-            const float d = edge_delta(p, row, e, col);
-            sabs += fabsf(d); spos += fmaxf(d, 0.f); sneg += fmaxf(-d, 0.f);
-            mx = fmaxf(mx, alpha * fabsf(d));
+        Stats st{0.f, 0.f, 0.f, -INFINITY, 0.f};
+#pragma unroll
+        for (int j = 0; j < kFlatMax; ++j) {       // slot order, as the reference's sum over the mailbox dimension
+            if (j < deg) {
+                const float d = dl[j][c];
+                st.sabs += fabsf(d); st.spos += fmaxf(d, 0.f); st.sneg += fmaxf(-d, 0.f);
+                st.mx = fmaxf(st.mx, p.ch[c].alpha * fabsf(d));
+            }
         }
-        float se = 0.f;
-        if (kind == DGN_W_SOFTMAX)
-            for (int e = beg; e < end; ++e) se += expf(alpha * fabsf(edge_delta(p, row, e, col)) - mx);
-        for (int e = beg; e < end; ++e) {
-            const float d = edge_delta(p, row, e, col);
-            float v;
-            if (kind == DGN_W_ABSNORM) v = d / (sabs + eps);
-            else if (kind == DGN_W_BALANCED) v = (fmaxf(d, 0.f) / (spos + eps) + fmaxf(-d, 0.f) / (sneg + eps)) / 2.f;
-            else v = expf(alpha * fabsf(d) - mx) / se;
-            p.w[(int64_t)c * p.ld_w + e] = v;
+        if (p.ch[c].kind == DGN_W_SOFTMAX) {
+#pragma unroll
+            for (int j = 0; j < kFlatMax; ++j)
+                if (j < deg) st.se += expf(p.ch[c].alpha * fabsf(dl[j][c]) - st.mx);
         }
+#pragma unroll
+        for (int j = 0; j < kFlatMax; ++j)
+            if (j < deg) p.w[(int64_t)c * p.ld_w + beg + j] = weight_of(p.ch[c], st, dl[j][c]);
+    }
+}
+
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = kGroup / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kGroup);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = kGroup / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kGroup));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ew_rows_g16(const EwParams p) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row64 = t / kGroup;
+    const int l = (int)(t % kGroup);
+    // (no early return before the shuffles: lanes of rows past the end / of other classes stay and contribute nothing)
+    const bool row_ok = row64 < p.n_nodes;
+    const int row = row_ok ? (int)row64 : 0;
+    const int beg = row_ok ? p.indptr[row] : 0, end = row_ok ? p.indptr[row + 1] : 0;
+    const int deg = end - beg;
+    const bool mine = row_ok && deg > kFlatMax && deg <= kGroup;
+    const bool in = mine && l < deg;
+    RowEig re;
+    re.load(p, row);
+    float dl[DGN_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < DGN_MAX_CH; ++c) dl[c] = 0.f;
+    if (in) edge_deltas(dl, p, re, beg + l);
+#pragma unroll
+    for (int c = 0; c < DGN_MAX_CH; ++c) {
+        if (c >= p.n_ch) break;
+        const float d = dl[c];
+        Stats st{0.f, 0.f, 0.f, -INFINITY, 0.f};
+        st.sabs = group_sum(fabsf(d));
+        st.spos = group_sum(fmaxf(d, 0.f));
+        st.sneg = group_sum(fmaxf(-d, 0.f));
+        st.mx = group_max(in ? p.ch[c].alpha * fabsf(d) : -INFINITY);
+        if (p.ch[c].kind == DGN_W_SOFTMAX) st.se = group_sum(in ? expf(p.ch[c].alpha * fabsf(d) - st.mx) : 0.f);
+        if (in) p.w[(int64_t)c * p.ld_w + beg + l] = weight_of(p.ch[c], st, d);
     }
 }
 
@@ -162,7 +290,38 @@ __global__ __launch_bounds__(kBlock) void ew_rows(const EwParams p) {
     if (row64 >= p.n_nodes) return;
     const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
-    if (end - beg <= kFlatMax || end - beg > p.hub_threshold) return;    // short rows: ew_rows_flat; hubs: slices
+    const int deg = end - beg;
+    if (deg <= kGroup || deg > p.hub_threshold) return;    // short rows: ew_rows_flat / ew_rows_g16; hubs: slices
+    if (deg <= kWave) {
+        // the row is one slot per lane: ONE gather per edge, the deltas stay in registers between statistics and write
+        const int lane = lane_id();
+        const bool in = lane < deg;
+        RowEig re;
+        re.load(p, row);
+        float dl[DGN_MAX_CH];
+#pragma unroll
+        for (int c = 0; c < DGN_MAX_CH; ++c) dl[c] = 0.f;
+        if (in) edge_deltas(dl, p, re, beg + lane);
+        Stats st[DGN_MAX_CH];
+#pragma unroll
+        for (int c = 0; c < DGN_MAX_CH; ++c) {
+            st[c] = Stats{0.f, 0.f, 0.f, -INFINITY, 0.f};
+            if (c < p.n_ch) {
+                const float d = dl[c];            // (0 on idle lanes: adds nothing; alpha * 0 must not win the max)
+                st[c].sabs = wave_sum(fabsf(d));
+                st[c].spos = wave_sum(fmaxf(d, 0.f));
+                st[c].sneg = wave_sum(fmaxf(-d, 0.f));
+                st[c].mx = wave_max(in ? p.ch[c].alpha * fabsf(d) : -INFINITY);
+                if (p.ch[c].kind == DGN_W_SOFTMAX) st[c].se = wave_sum(in ? expf(p.ch[c].alpha * fabsf(d) - st[c].mx) : 0.f);
+            }
+        }
+        if (in) {
+#pragma unroll
+            for (int c = 0; c < DGN_MAX_CH; ++c)
+                if (c < p.n_ch) p.w[(int64_t)c * p.ld_w + beg + lane] = weight_of(p.ch[c], st[c], dl[c]);
+        }
+        return;
+    }
     Stats st[DGN_MAX_CH];
     range_stats(st, p, row, beg, end);
     range_write(st, p, row, beg, end);
@@ -263,7 +422,17 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;
     if (eig_s_edge && eig_d_edge) { p.eig_s = eig_s_edge; p.eig_d = eig_d_edge; } else { p.eig = eig; }
     p.ld_eig = ld_eig; p.n_ch = n_ch;
-    for (int c = 0; c < n_ch; ++c) p.ch[c] = ch[c];
+    int max_col = 0;
+    for (int c = 0; c < n_ch; ++c) { p.ch[c] = ch[c]; max_col = ch[c].eig_col > max_col ? ch[c].eig_col : max_col; }
+    p.n_need = max_col + 1 < 8 ? max_col + 1 : 8;
+    {   // widest vector load every row start and the needed prefix allow (a vector never reaches past its row's last column
+        // rounded up to the vector width, so ld_eig must be a multiple of it)
+        auto ok = [&](int v) {
+            auto al = [&](const float* q) { return !q || (reinterpret_cast<uintptr_t>(q) % (4 * v)) == 0; };
+            return ld_eig % v == 0 && al(eig) && al(eig_s_edge) && al(eig_d_edge);
+        };
+        p.vw = ok(4) ? 4 : (ok(2) ? 2 : 1);
+    }
     p.w = w; p.ld_w = ld_w;
     if (g->n_hub > 0) {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -271,7 +440,9 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
         p.hub_stats = reinterpret_cast<float*>(static_cast<char*>(ws) + up((size_t)g->n_chunks * DGN_MAX_CH * 5 * sizeof(float)));
     }
     hipLaunchKernelGGL(ew_rows_flat, dim3((unsigned)((p.n_nodes + 255) / 256)), dim3(256), 0, stream, p);
-    if (g->max_in_degree == 0 || g->max_in_degree > kFlatMax) {     // skipped when every row is known to be short
+    if (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)        // (skipped when every row is known to be shorter)
+        hipLaunchKernelGGL(ew_rows_g16, dim3((unsigned)((p.n_nodes * kGroup + 255) / 256)), dim3(256), 0, stream, p);
+    if (g->max_in_degree == 0 || g->max_in_degree > kGroup) {
         const unsigned nb = (unsigned)((p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock);
         hipLaunchKernelGGL(ew_rows, dim3(nb), dim3(kBlock), 0, stream, p);
     }

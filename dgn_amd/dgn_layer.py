@@ -119,7 +119,9 @@ def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
         w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
         b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
         pq = node_linear(h, w_sd, b_sd)                    # [N, 2*in]: P | Q
-        m_edge = F.linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
+        # edge term R = ef W_e^T in CSR slot order: the permuted copy is edge_dim floats per edge (40 B), the product runs on
+        # the streaming Linear kernels (k = edge_dim), not on a library GEMM
+        m_edge = node_linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
         return pq, m_edge
     # general pretrans (ReLU between layers): materialise the messages, directly in slot order
     z = [h.index_select(0, graph.src.long()), h.index_select(0, _slot_dst(graph))]
@@ -504,7 +506,7 @@ class DGNLayerTower(nn.Module):
         ops = self._operands(h.device)
         x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)
         pq = node_linear(h, ops["w_sd"], ops["bias_sd"])                                            # [N, 2*Fm]: P | Q
-        m_edge = F.linear(graph.to_slot_order(e), ops["w_edge"]) if self.edge_features else None
+        m_edge = node_linear(graph.to_slot_order(e), ops["w_edge"]) if self.edge_features else None          # R = ef W_e^T, slot order
         b_p = ops["b_p"]
         S = self.plan.n_scalers
         N = h.shape[0]

@@ -124,6 +124,7 @@ class DGNGraph:
     # ---- row windows of the window-local backward scatter (include/dgn_hip.h: DgnGraph.win_ptr) ----
     WIN_BIN = 16        # rows per bin; a window spans at most 3 bins - 1 rows
     WIN_ECAP = 96       # csc entries of a window kept in LDS
+    WIN_MIN_EDGES = 32768   # below this the backward is launch-bound and the ~20 device ops of the window build cost more than they save
 
     def _build_windows(self, order: torch.Tensor, csc_ptr: torch.Tensor) -> None:
         """Cut the rows into windows of at most ``3 * WIN_BIN - 1`` rows, preferring CLOSED cuts -- places no edge
@@ -134,7 +135,7 @@ class DGNGraph:
         fit one slot batch only (the kernel's domain)."""
         N, E, dev = self.num_nodes, self.num_edges, self.device
         self.n_remote, self.win_ptr = 0, None
-        if self.num_src != N or self.n_hub or E == 0 or not (0 < self.max_in_degree <= 64) or N < 2:
+        if self.num_src != N or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
             return
         R0 = self.WIN_BIN
         rows = torch.arange(N, device=dev)

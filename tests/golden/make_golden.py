@@ -522,12 +522,78 @@ def g8_readouts(out):
     out["vn/n_cases"] = np.array(case)
 
 
+def g9_laplacian(out):
+    """Laplacian construction + eigenvector bookkeeping of ``MoleculeDGL.get_eig`` (data/molecules.py:100-116), UNMODIFIED,
+    driven by a fake graph that supplies the three DGL methods it calls.  ``scipy.sparse.linalg.eigs`` is ARPACK with
+    tol=5e-1 and a random start vector -- irreproducible by construction -- so the solver call is intercepted: the matrix L
+    the reference built is RECORDED (that pins the construction: in-degree clipping, the three normalisations, A's
+    orientation) and an exact dense solve is handed back, which the reference then sorts / truncates / casts itself
+    (that pins column order, the ``pos_enc_dim`` cut and the fp32 cast).  Unpinned (DGL 0.4.2 absent): the orientation of
+    ``adjacency_matrix_scipy`` (rows = destinations, DGL's documented default) -- irrelevant for the symmetric graphs here."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    dgl = sys.modules["dgl"]
+    dgl.backend = types.SimpleNamespace(asnumpy=lambda t: t.numpy() if torch.is_tensor(t) else np.asarray(t))
+    dgl.DGLGraph = object
+    import data.molecules as M
+
+    class G:
+        def __init__(self, src, dst, n):
+            self.src, self.dst, self.n, self.ndata = np.asarray(src), np.asarray(dst), n, {}
+
+        def number_of_nodes(self):
+            return self.n
+
+        def in_degrees(self):
+            return torch.from_numpy(np.bincount(self.dst, minlength=self.n))
+
+        def adjacency_matrix_scipy(self, return_edge_ids=False):
+            return sp.coo_matrix((np.ones(len(self.src)), (self.dst, self.src)), shape=(self.n, self.n)).tocsr()
+
+    recorded = []
+    real_eigs = spl.eigs
+
+    def fake_eigs(L, k, which="SR", tol=0):
+        dense = np.asarray(L.todense())
+        recorded.append(dense)
+        w, v = np.linalg.eig(dense)
+        idx = np.argsort(w.real)[:k]
+        # (hand the pairs back in a scrambled order: the reference's own argsort must restore increasing order)
+        idx = idx[::-1]
+        return w[idx], v[:, idx]
+
+    rng = np.random.default_rng(9)
+    graphs = []
+    for n in (9, 14, 23, 37):
+        und = [(int(rng.integers(0, v)), v) for v in range(1, n)]
+        for _ in range(3):
+            a, b = sorted(int(x) for x in rng.integers(0, n, 2))
+            if a != b and (a, b) not in und:
+                und.append((a, b))
+        und = np.asarray(und)
+        graphs.append((np.concatenate([und[:, 0], und[:, 1]]), np.concatenate([und[:, 1], und[:, 0]]), n))
+    out["n_graphs"] = np.array(len(graphs))
+    out["pos_enc_dim"] = np.array(6)
+    M.sp.linalg.eigs = fake_eigs
+    try:
+        for norm in ("none", "sym", "walk"):
+            ds = types.SimpleNamespace(graph_lists=[G(*g) for g in graphs])
+            recorded.clear()
+            M.MoleculeDGL.get_eig(ds, pos_enc_dim=6, norm=norm)
+            for i, (g, fg) in enumerate(zip(graphs, ds.graph_lists)):
+                out[f"g{i}/src"], out[f"g{i}/dst"], out[f"g{i}/n"] = g[0], g[1], np.array(g[2])
+                out[f"g{i}/{norm}/L"] = recorded[i]
+                out[f"g{i}/{norm}/eig"] = fg.ndata["eig"].numpy()
+    finally:
+        M.sp.linalg.eigs = real_eigs
+
+
 def main():
     _install_stubs()
     only = sys.argv[1:]
     for fname, fn in (("g1_aggregators", g1_aggregators), ("g2_scalers", g2_scalers), ("g3_reduce", g3_reduce),
                       ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases), ("g6_dense", g6_dense),
-                      ("g8_readouts", g8_readouts)):
+                      ("g8_readouts", g8_readouts), ("g9_laplacian", g9_laplacian)):
         if only and fname not in only:
             continue
         out = {}

@@ -546,6 +546,7 @@ def test_window_backward_equals_staged_backward(monkeypatch, case):
     gen = torch.Generator().manual_seed(4)
     eig = torch.randn(N, 4, generator=gen)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_MIN_EDGES", 0)             # (small test graphs: build the windows anyway)
     if case == "cut_molecules":
         monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_ECAP", 40)             # fewer LDS entries than a window's csc range
     graph.ensure_csc()
