@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -24,6 +24,8 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
+           "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
+           "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
 
 
@@ -63,6 +65,22 @@ class DgnMsgGrad(C.Structure):
 class DgnBnGrad(C.Structure):
     _fields_ = [("g_out", C.c_void_p), ("y", C.c_void_p), ("ld", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("relu", C.c_int32)]
+
+
+class DgnTowersLayer(C.Structure):
+    _fields_ = [("graph", C.POINTER(DgnGraph)), ("spec", C.POINTER(DgnAggSpec)), ("w", C.c_void_p), ("ld_w", C.c_int64),
+                ("log_deg", C.c_void_p), ("n_towers", C.c_int32), ("f_in", C.c_int32), ("f_out", C.c_int32), ("n_scalers", C.c_int32),
+                ("residual", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("slope", C.c_float),
+                ("h", C.c_void_p), ("snorm", C.c_void_p), ("scale", C.c_void_p), ("w_sd", C.c_void_p), ("bias_sd", C.c_void_p),
+                ("w_post", C.c_void_p), ("b_post", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
+                ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+class DgnTowersGrads(C.Structure):
+    _fields_ = [("g_out", C.c_void_p), ("g_h", C.c_void_p), ("g_w_sd", C.c_void_p), ("g_bias_sd", C.c_void_p), ("g_w_post", C.c_void_p),
+                ("g_b_post", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p), ("g_w_mix", C.c_void_p), ("g_b_mix", C.c_void_p)]
 
 
 class DgnError(RuntimeError):
@@ -153,6 +171,15 @@ def load() -> C.CDLL:
         lib.dgn_linear_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
+        lib.dgn_towers_layer_supported.restype = C.c_int
+        lib.dgn_towers_layer_supported.argtypes = [C.c_int32] * 5
+        for name in ("dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_backward_workspace_bytes"):
+            getattr(lib, name).restype = C.c_size_t
+            getattr(lib, name).argtypes = [C.POINTER(DgnTowersLayer)]
+        lib.dgn_towers_layer_forward.restype = C.c_int
+        lib.dgn_towers_layer_forward.argtypes = [C.POINTER(DgnTowersLayer), C.c_void_p]
+        lib.dgn_towers_layer_backward.restype = C.c_int
+        lib.dgn_towers_layer_backward.argtypes = [C.POINTER(DgnTowersLayer), C.POINTER(DgnTowersGrads), C.c_void_p]
         if lib.dgn_abi_version() != ABI_VERSION:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib

@@ -1,0 +1,215 @@
+// Whole-layer entry points of the towers DGN layer (include/dgn_hip.h: dgn_towers_layer_*): every kernel of one
+// DGNLayerTower.forward -- P|Q pretrans Linear, the aggregation sweep, posttrans + scale-combine, BatchNorm tail, mixing
+// Linear, bias + LeakyReLU + residual -- and of its backward is enqueued by ONE call, on the caller's stream, with no host
+// synchronisation.  At the reference's batch size (128 molecules, configs/molecules_graph_regression_DGN_ZINC.json) the layer is
+// host-bound when every kernel is its own Python / autograd node (~48 launches, 1.2-1.4 ms around 0.2 ms of GPU work); here the
+// host side of a step is two calls.  No new device code: the calls below are the library's own entry points.
+// Reference: realworld_benchmark/nets/dgn_layer.py:254-325 (DGNTower.forward x towers, mixing network, residual).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "dgn_common.hpp"
+
+namespace dgn {
+namespace {
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// g_h = [g_res] + g_a + g_b   (the three contributions to d h: residual, h_in of the sweep, the P|Q input gradient)
+__global__ __launch_bounds__(256) void add3_rows(int64_t n4, const float4* __restrict__ res, const float4* __restrict__ a,
+                                                 const float4* __restrict__ b, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = a[i];
+    const float4 w = b[i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    if (res) {
+        const float4 r = res[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    out[i] = v;
+}
+__global__ __launch_bounds__(256) void add3_tail(int64_t first, int64_t n, const float* __restrict__ res, const float* __restrict__ a,
+                                                 const float* __restrict__ b, float* __restrict__ out) {
+    const int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = a[i] + b[i] + (res ? res[i] : 0.f);
+}
+
+struct Dims {
+    int64_t N;
+    int T, fi, fo, S, Fm, Fo, K;
+};
+
+bool dims_of(const DgnTowersLayer* L, Dims& d, const char* fn) {
+    if (!L || !L->graph || !L->spec) { set_error("%s: null layer / graph / spec", fn); return false; }
+    d.N = L->graph->n_nodes; d.T = L->n_towers; d.fi = L->f_in; d.fo = L->f_out; d.S = L->n_scalers;
+    if (d.T < 1 || d.fi < 1 || d.fo < 1 || d.S < 1 || d.S > 3) { set_error("%s: bad tower / scaler counts", fn); return false; }
+    d.Fm = d.T * d.fi; d.Fo = d.T * d.fo;
+    const int a_total = L->spec->agg_total > 0 ? L->spec->agg_total : L->spec->n_agg;
+    d.K = a_total * d.fi;
+    if (L->spec->n_towers != d.T || L->spec->n_scalers != 1) { set_error("%s: the sweep spec must carry the towers and ONE (identity) scaler", fn); return false; }
+    if (!dgn_linear_supported(d.Fm, 2 * d.Fm, 1) || !dgn_linear_supported(2 * d.Fm, d.Fm, 0) || !dgn_linear_supported(d.K, d.S * d.fo, 1) ||
+        !dgn_linear_supported(d.S * d.fo, d.K, 0) || !dgn_linear_supported(d.Fo, d.Fo, 1) || (d.Fm % 16) == 0 || (d.fo & 1) || d.Fo > 1024) {
+        set_error("%s: widths outside the streaming Linear kernels (in %d, towers %d x (%d -> %d), %d scalers)", fn, d.Fm, d.T, d.fi, d.fo, d.S);
+        return false;
+    }
+    return true;
+}
+
+DgnMsg sweep_msg(const DgnTowersLayer* L, const Dims& d) {
+    DgnMsg m{};
+    m.F = d.Fm;
+    m.x_src = L->pq; m.ld_src = 2 * d.Fm;
+    m.x_dst = L->pq + d.Fm; m.ld_dst = 2 * d.Fm;
+    m.x_in = L->h; m.ld_in = d.Fm;
+    return m;
+}
+
+}  // namespace
+}  // namespace dgn
+
+using namespace dgn;
+
+#define DGN_TRY(call)          \
+    do {                       \
+        const int _rc = (call); \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+extern "C" int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total) {
+    const int Fm = n_towers * f_in, Fo = n_towers * f_out, K = n_agg_total * f_in;
+    return n_towers >= 1 && n_scalers >= 1 && n_scalers <= 3 && dgn_linear_supported(Fm, 2 * Fm, 1) && dgn_linear_supported(2 * Fm, Fm, 0) &&
+           dgn_linear_supported(K, n_scalers * f_out, 1) && dgn_linear_supported(n_scalers * f_out, K, 0) && dgn_linear_supported(Fo, Fo, 1) &&
+           (Fm % 16) != 0 && (f_out & 1) == 0 && Fo <= 1024;
+}
+
+extern "C" size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_towers_layer_forward_workspace_bytes")) return 0;
+    return up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo)) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fm));
+}
+
+extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
+    const char* fn = "dgn_towers_layer_forward";
+    Dims d;
+    if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
+    if (d.N == 0) return DGN_OK;
+    if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || !L->y1 || !L->z || !L->out || !L->save_mean ||
+        !L->save_invstd || (d.S > 1 && !L->scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
+    const size_t bn_ws = up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
+    if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
+    char* ws = static_cast<char*>(L->ws);
+    // P | Q = h [W_s | W_d]^T + [0 | b]                                                     (dgn_layer.py:226-231, decomposed)
+    DGN_TRY(dgn_linear_forward(d.N, d.Fm, 2 * d.Fm, 1, L->h, d.Fm, 0, L->w_sd, d.Fm, 0, 0, L->bias_sd, 0, L->pq, 2 * d.Fm, 0, stream));
+    // all towers' aggregators (+ the h_in block) in one sweep, tower-major                   (:237-249, :261-264)
+    const DgnMsg msg = sweep_msg(L, d);
+    const size_t agg_ws = L->ws_bytes - bn_ws;
+    DGN_TRY(dgn_agg_forward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, ws + bn_ws, agg_ws, stream));
+    // posttrans([h || agg]) with the folded scalers, bias and graph norm                     (:266-271)
+    DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
+                                       L->b_post, L->snorm, L->y0, d.Fo, stream));
+    // the towers' BatchNorm (training statistics)                                            (:272-273)
+    DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
+                                nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, stream));
+    // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
+    DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
+    DGN_TRY(dgn_bias_act_forward(d.N, d.Fo, L->z, d.Fo, L->b_mix, 2, L->slope, L->residual ? L->h : nullptr, L->out, stream));
+    return DGN_OK;
+}
+
+namespace {
+struct BwdScratch {
+    size_t g_z, g_y1, sums, g_yr, g_aggx, g_pq, g_in, g_hpq, bn_ws, comb_ws, wg_mix, wg_post, wg_sd, agg_ws, total;
+};
+BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
+    BwdScratch s{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += up256(bytes); return at; };
+    const size_t NF = (size_t)d.N * d.Fo * 4;
+    s.g_z = take(NF); s.g_y1 = take(NF); s.sums = take((size_t)2 * d.Fo * 4);
+    s.g_yr = take(NF);
+    s.g_aggx = take((size_t)d.T * d.N * d.K * 4);
+    s.g_pq = take((size_t)d.N * 2 * d.Fm * 4); s.g_in = take((size_t)d.N * d.Fm * 4); s.g_hpq = take((size_t)d.N * d.Fm * 4);
+    s.bn_ws = take(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
+    s.comb_ws = take(dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo));
+    s.wg_mix = take(dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1));
+    s.wg_post = take(dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T));
+    s.wg_sd = take(dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1));
+    s.agg_ws = take(dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1));
+    s.total = off;
+    return s;
+}
+}  // namespace
+
+extern "C" size_t dgn_towers_layer_backward_workspace_bytes(const DgnTowersLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_towers_layer_backward_workspace_bytes")) return 0;
+    return bwd_scratch(L, d).total;
+}
+
+extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTowersGrads* G, void* stream) {
+    const char* fn = "dgn_towers_layer_backward";
+    Dims d;
+    if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
+    if (!G) { set_error("%s: null grads", fn); return DGN_ERR_INVALID; }
+    if (d.N == 0) return DGN_OK;
+    if (!G->g_out || !G->g_h || !G->g_w_sd || !G->g_bias_sd || !G->g_w_post || !G->g_b_post || !G->g_gamma || !G->g_beta || !G->g_w_mix ||
+        !G->g_b_mix) { set_error("%s: null gradient buffer", fn); return DGN_ERR_INVALID; }
+    const BwdScratch s = bwd_scratch(L, d);
+    if (!L->ws || L->ws_bytes < s.total) { set_error("%s: workspace too small (%zu < %zu)", fn, L->ws_bytes, s.total); return DGN_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(L->ws);
+    auto f = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    float *g_z = f(s.g_z), *g_y1 = f(s.g_y1), *sums = f(s.sums), *g_yr = f(s.g_yr), *g_aggx = f(s.g_aggx), *g_pq = f(s.g_pq),
+          *g_in = f(s.g_in), *g_hpq = f(s.g_hpq);
+    // bias + LeakyReLU (+ residual: its gradient is g_out itself, added at the end)
+    DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
+                                  dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
+    // mixing Linear: input and weight gradients
+    DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->w_mix, d.Fo, 0, 1, nullptr, 0, g_y1, d.Fo, 0, stream));
+    DGN_TRY(dgn_linear_wgrad(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->y1, d.Fo, 0, G->g_w_mix, d.Fo, 0, nullptr, 0, ws + s.wg_mix,
+                             dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
+    DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
+                                 G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
+    DgnBnGrad bn{};
+    bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
+    bn.sums = sums; bn.relu = 0;
+    DGN_HIP_CHECK(hipMemsetAsync(G->g_b_post, 0, (size_t)d.Fo * 4, st));
+    DGN_TRY(dgn_scale_combine_backward(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
+                                       dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream));
+    // posttrans: the scaler expansion happens inside the two products
+    DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
+                                              g_aggx, d.N * d.K, stream));
+    DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
+                                               (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
+                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
+    // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
+    const DgnMsg msg = sweep_msg(L, d);
+    DgnMsgGrad gr{};
+    gr.g_src = g_pq; gr.ld_src = 2 * d.Fm;
+    gr.g_dst = g_pq + d.Fm; gr.ld_dst = 2 * d.Fm;
+    gr.g_in = g_in; gr.ld_in = d.Fm;
+    gr.accumulate = 0;
+    DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, &gr, ws + s.agg_ws,
+                             dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
+    // P|Q Linear: input gradient, weight + bias gradient (the bias rides in the weight-gradient pass)
+    DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
+    DGN_TRY(dgn_linear_wgrad(d.N, d.Fm, 2 * d.Fm, 1, g_pq, 2 * d.Fm, 0, L->h, d.Fm, 0, G->g_w_sd, d.Fm, 0, G->g_bias_sd, 0, ws + s.wg_sd,
+                             dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1), stream));
+    // d h = [residual] + d h_in + (d P|Q) W_sd
+    const int64_t n = d.N * d.Fm, n4 = n / 4;
+    const bool al = ((reinterpret_cast<uintptr_t>(G->g_h) | reinterpret_cast<uintptr_t>(G->g_out)) & 15) == 0;
+    const float* res = L->residual ? G->g_out : nullptr;
+    if (al && n4 > 0) {
+        hipLaunchKernelGGL(add3_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, reinterpret_cast<const float4*>(res),
+                           reinterpret_cast<const float4*>(g_in), reinterpret_cast<const float4*>(g_hpq), reinterpret_cast<float4*>(G->g_h));
+        if (n > 4 * n4) hipLaunchKernelGGL(add3_tail, dim3(1), dim3(256), 0, st, 4 * n4, n, res, g_in, g_hpq, G->g_h);
+    } else {
+        hipLaunchKernelGGL(add3_tail, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int64_t)0, n, res, g_in, g_hpq, G->g_h);
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}

@@ -28,8 +28,9 @@ import torch.nn.functional as F
 
 from .graph import DGNGraph, as_dgn_graph
 from .layers import MLP, FCLayer
+from . import ops as _ops
 from .ops import (bn_tail, bn_tail_fused, bn_tail_supported, combine_bn_tail, directional_aggregate, linear_combine_bn_tail,
-                  linear_combine_supported, node_linear, scale_combine)
+                  linear_combine_supported, node_linear, scale_combine, towers_layer, towers_layer_supported)
 from .spec import (AGGREGATOR_NAMES, SCALE_AMPLIFICATION, SCALE_IDENTITY, SCALER_NAMES, X_IN_NAME, make_plan,
                    parse_aggregator, parse_scaler)
 
@@ -549,8 +550,37 @@ class DGNLayerTower(nn.Module):
                 y = bn_tail(y, bns, self.training)
         return F.dropout(y, self.dropout, training=self.training)
 
+    def _whole_layer(self, g, h, snorm_n):
+        """The layer through dgn_towers_layer_forward / _backward (one C call per direction), or None when the configuration
+        is outside that entry point's domain: training-mode BatchNorm, mixing network Linear -> LeakyReLU, no edge features,
+        no dropout, identity among the scalers, widths the streaming Linear kernels take."""
+        T, fi, fo = len(self.towers), self.input_tower, self.output_tower
+        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and T > 1 and self.divide_input
+                and not self.edge_features and self.dropout == 0 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+                and _identity_slot(self.plan.applied_scalers) is not None and self._fusable()
+                and towers_layer_supported(T, fi, fo, self.plan.n_scalers, self._kplan_x.n_agg)):
+            return None
+        act = self.mixing_network._fused_act()
+        bns = [t.batchnorm_h for t in self.towers]
+        if act is None or act[0] != "leaky_relu" or self.mixing_network.linear.bias is None or not bn_tail_supported(bns, h, True, T * fo):
+            return None
+        eig = g.ndata["eig"]
+        graph = as_dgn_graph(g, h.device)
+        ops = self._operands(h.device)
+        S = self.plan.n_scalers
+        sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+        rm, rv, nbt = self._linked_bn_stats(h.device)
+        w_edge = graph.edge_weights(self._kplan_x, eig)
+        mix = self.mixing_network.linear
+        return towers_layer(graph, self._kplan_x, self._avg_log, w_edge, h, snorm_n if self.graph_norm else None, sc, rm, rv, nbt,
+                            ops["w_sd"], ops["bias_sd"], ops["w"], ops["b_p"], ops["bn_gamma"], ops["bn_beta"], mix.weight, mix.bias,
+                            T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1])
+
     def forward(self, g, h, e, snorm_n):
         h_in = h
+        y = self._whole_layer(g, h, snorm_n)
+        if y is not None:
+            return y
         if self._fusable():
             h_cat = self._fused_towers(g, h, e, snorm_n)
         elif self.divide_input:

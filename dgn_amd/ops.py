@@ -742,3 +742,133 @@ def linear_combine_bn_tail(aggx, w, scale, bias, row_scale, gamma, beta, running
         with torch.no_grad():
             num_batches_tracked.add_(1)
     return out
+
+
+# ---- the whole towers layer as ONE autograd node over two C calls (dgn_towers.hip) --------------------------------------------
+
+# True: DGNLayerTower runs its fused configuration (single-affine pretrans / posttrans, divide_input, scalers folded, training-mode
+# BatchNorm, mixing network, no edge features, no dropout) through dgn_towers_layer_forward / _backward: every kernel of the
+# layer is enqueued by one call per direction.  At the reference's batch size the layer is host-bound otherwise (~48 launches,
+# each its own Python / autograd node).  False: the per-kernel route (same kernels, same results).
+WHOLE_LAYER = os.environ.get("DGN_WHOLE_LAYER", "1") != "0"
+
+_TOWERS_OK = {}
+
+
+def towers_layer_supported(n_towers: int, f_in: int, f_out: int, n_scalers: int, n_agg_total: int) -> bool:
+    key = (n_towers, f_in, f_out, n_scalers, n_agg_total)
+    if key not in _TOWERS_OK:
+        _TOWERS_OK[key] = bool(_lib.load().dgn_towers_layer_supported(*key))
+    return _TOWERS_OK[key]
+
+
+def _carve(sizes, device):
+    """one allocation, views of the given element counts (each view starts 256-byte aligned)"""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) & ~63
+    buf = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    return buf, [buf[o:o + n] for o, n in zip(offs, sizes)]
+
+
+class _TowersLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var,
+                w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix):
+        lib = _lib.load()
+        T, fi, fo, S, residual, momentum, eps, slope = cfg
+        if not h.is_cuda:
+            raise _lib.DgnError("towers_layer: CUDA tensors only (dgn_amd has no CPU path)")
+        N, Fm, Fo = h.shape[0], T * fi, T * fo
+        K = plan.n_agg * fi
+        dev = h.device
+        h, w_sd, bias_sd, w_post, b_post = h.contiguous(), w_sd.contiguous(), bias_sd.contiguous(), w_post.contiguous(), b_post.contiguous()
+        gamma, beta, w_mix, b_mix = gamma.contiguous(), beta.contiguous(), w_mix.contiguous(), b_mix.contiguous()
+        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, N * Fo, N * Fo, Fo, Fo], dev)
+        out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
+        spec = _spec_structs(plan, T, avg_log, N * K)[0]
+        L = _lib.DgnTowersLayer()
+        cg = graph.c_graph_no_windows        # (P|Q messages keep the global staging path in the backward, see WINDOW_BACKWARD)
+        L.graph, L.spec = C.pointer(cg), C.pointer(spec)
+        L.w, L.ld_w, L.log_deg = _ptr(w_edge), (w_edge.stride(0) if w_edge is not None else 0), graph.log_deg.data_ptr()
+        L.n_towers, L.f_in, L.f_out, L.n_scalers, L.residual = T, fi, fo, S, int(residual)
+        L.momentum, L.eps, L.slope = float(momentum), float(eps), float(slope)
+        L.h, L.snorm, L.scale = h.data_ptr(), _ptr(snorm), _ptr(scale)
+        L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
+        L.bn_gamma, L.bn_beta, L.running_mean, L.running_var = gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()
+        L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), y1.data_ptr(), z.data_ptr()
+        L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
+        nbytes = lib.dgn_towers_layer_forward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_towers_layer_forward(C.byref(L), stream), "dgn_towers_layer_forward")
+        ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf)
+        ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf = ctx.saved_tensors
+        graph, plan = ctx.graph, ctx.plan
+        T, fi, fo, S, residual, momentum, eps, slope = ctx.cfg
+        N, Fm, Fo = h.shape[0], T * fi, T * fo
+        K = plan.n_agg * fi
+        dev = h.device
+        sizes = [N * 2 * Fm, T * N * K, N * Fo, N * Fo, N * Fo, Fo, Fo]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) & ~63
+        pq, aggx, y0, y1, z, mean, invstd = (saved_buf[o:o + n] for o, n in zip(offs, sizes))
+        g_out = g_out.contiguous()
+        graph.ensure_csc()
+        spec = _spec_structs(plan, T, ctx.avg_log, N * K)[0]
+        L = _lib.DgnTowersLayer()
+        cg = graph.c_graph_no_windows
+        L.graph, L.spec = C.pointer(cg), C.pointer(spec)
+        L.w, L.ld_w, L.log_deg = _ptr(w_edge), (w_edge.stride(0) if w_edge is not None else 0), graph.log_deg.data_ptr()
+        L.n_towers, L.f_in, L.f_out, L.n_scalers, L.residual = T, fi, fo, S, int(residual)
+        L.momentum, L.eps, L.slope = float(momentum), float(eps), float(slope)
+        L.h, L.snorm, L.scale = h.data_ptr(), _ptr(snorm), _ptr(scale)
+        L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
+        L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
+        L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), y1.data_ptr(), z.data_ptr()
+        L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
+        nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        g_h = torch.empty((N, Fm), dtype=torch.float32, device=dev)
+        _, (g_w_sd, g_bias_sd, g_w_post, g_b_post, g_gamma, g_beta, g_w_mix, g_b_mix) = _carve(
+            [2 * Fm * Fm, 2 * Fm, T * S * fo * K, Fo, Fo, Fo, Fo * Fo, Fo], dev)
+        G = _lib.DgnTowersGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_w_sd=g_w_sd.data_ptr(), g_bias_sd=g_bias_sd.data_ptr(),
+                                g_w_post=g_w_post.data_ptr(), g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(),
+                                g_beta=g_beta.data_ptr(), g_w_mix=g_w_mix.data_ptr(), g_b_mix=g_b_mix.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_towers_layer_backward(C.byref(L), C.byref(G), stream), "dgn_towers_layer_backward")
+        return (None, None, None, None, None, g_h, None, None, None, None, g_w_sd.view(2 * Fm, Fm), g_bias_sd, g_w_post.view(T, S * fo, K),
+                g_b_post, g_gamma, g_beta, g_w_mix.view(Fo, Fo), g_b_mix)
+
+
+def towers_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm, scale, running_mean, running_var, num_batches_tracked,
+                 w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, n_towers: int, f_in: int, f_out: int, residual: bool,
+                 momentum: float, eps: float, slope: float) -> torch.Tensor:
+    """``DGNLayerTower.forward`` (nets/dgn_layer.py:309-325) of the fused configuration as one autograd node: see
+    ``include/dgn_hip.h: DgnTowersLayer`` for the operand layouts (those of ``DGNLayerTower._assemble``) and the sequence of
+    kernels.  Training mode; the BatchNorm running statistics and ``num_batches_tracked`` are updated in place."""
+    S = 1 if scale is None else scale.shape[1]
+    if snorm is not None:
+        snorm = snorm.reshape(-1).contiguous()
+    if scale is not None:
+        scale = scale.contiguous()
+    cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope))
+    out = _TowersLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, running_mean, running_var,
+                             w_sd, bias_sd, w_post.contiguous(), b_post, gamma, beta, w_mix, b_mix)
+    if num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
+    return out

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 10
+#define DGN_ABI_VERSION 11
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -323,6 +323,52 @@ size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, in
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
                      int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- whole towers layer in one call (dgn_towers.hip) ------------------------------------------------------------------
+ * DGNLayerTower.forward of the reference (nets/dgn_layer.py:309-325 over DGNTower.forward :254-276) for the fused form the
+ * host side already uses (dgn_amd/dgn_layer.py::_fused_towers): single-affine pretrans / posttrans, divide_input, scalers
+ * folded behind posttrans, training-mode BatchNorm, mixing network + residual, no edge features, no dropout:
+ *     pq   = h [W_s | W_d]^T + [0 | b]                    dgn_linear_forward
+ *     aggx = sweep(pq, h)  tower-major [T][N][K]           dgn_agg_forward        (spec: the towers, ONE identity scaler,
+ *                                                                                  aggregators incl. the h_in block)
+ *     y0   = snorm * (b_post + sum_s scale_s * (aggx W_s^T))   dgn_linear_combine_forward
+ *     y1   = BatchNorm(y0)                                  dgn_bn_tail_forward (training; running stats updated in place)
+ *     z    = y1 W_mix^T ;  out = LeakyReLU(z + b_mix) [+ h]  dgn_linear_forward, dgn_bias_act_forward
+ * One call enqueues all of it on `stream`; dgn_towers_layer_backward enqueues the whole backward.  pq, aggx, y0, y1, z,
+ * save_mean, save_invstd are written by the forward and read by the backward (caller-owned: the autograd-saved tensors).
+ * Shapes: h [N, T*f_in]; w_sd [2 T f_in, T f_in]; w_post [T][S*f_out][K], K = agg_total * f_in; w_mix [T f_out, T f_out].
+ * dgn_towers_layer_supported() says whether the widths fit the streaming Linear kernels.                            */
+typedef struct DgnTowersLayer {
+    const DgnGraph* graph;
+    const DgnAggSpec* spec;
+    const float* w;            /* edge weights [n_ch][ld_w] (dgn_edge_weights), or NULL                     */
+    int64_t ld_w;
+    const float* log_deg;
+    int32_t n_towers, f_in, f_out, n_scalers;
+    int32_t residual;          /* add h to the output (in_dim == out_dim and the layer's residual flag)     */
+    float momentum, eps, slope;
+    const float* h;            /* [N, T*f_in]                                                               */
+    const float* snorm;        /* [N] graph-norm factor or NULL                                             */
+    const float* scale;        /* [N, S] degree-scaler table (NULL iff S == 1)                              */
+    const float* w_sd;  const float* bias_sd;
+    const float* w_post; const float* b_post;
+    const float* bn_gamma; const float* bn_beta;
+    float* running_mean; float* running_var;
+    const float* w_mix; const float* b_mix;
+    float* pq; float* aggx; float* y0; float* save_mean; float* save_invstd; float* y1; float* z;
+    float* out;                /* [N, T*f_out]  (forward only)                                              */
+    void* ws; size_t ws_bytes; /* scratch: dgn_towers_layer_{forward,backward}_workspace_bytes()            */
+} DgnTowersLayer;
+typedef struct DgnTowersGrads {
+    const float* g_out;        /* [N, T*f_out]                                                              */
+    float* g_h;                /* [N, T*f_in]   written                                                     */
+    float* g_w_sd; float* g_bias_sd; float* g_w_post; float* g_b_post; float* g_gamma; float* g_beta; float* g_w_mix; float* g_b_mix;
+} DgnTowersGrads;
+int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total);
+size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
+int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);
+size_t dgn_towers_layer_backward_workspace_bytes(const DgnTowersLayer* layer);
+int dgn_towers_layer_backward(const DgnTowersLayer* layer, const DgnTowersGrads* grads, void* stream);
 
 #ifdef __cplusplus
 }

@@ -610,3 +610,53 @@ def test_window_backward_equals_staged_backward(monkeypatch, case):
         _as_good(g_w[1], go[2], g64[2], 1e-4, 1e-4, "g_x")
         if case == "three_term":
             _as_good(g_w[2], go[3], g64[3], 1e-4, 1e-4, "g_edge")
+
+
+@pytest.mark.parametrize("residual,graph_norm,scalers", [(True, True, "identity amplification attenuation"), (False, False, "identity attenuation"),
+                                                         (True, True, "identity")])
+def test_whole_layer_call_equals_per_kernel_route(monkeypatch, residual, graph_norm, scalers):
+    """dgn_towers_layer_forward / _backward (one C call per direction) against the same layer run kernel by kernel through
+    the per-op autograd nodes: output, every gradient, BatchNorm running statistics."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)                 # both routes on the streaming Linear kernels
+    b = synth.molecule_batch(200, seed=21, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    F_ = 70
+    torch.manual_seed(2)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, graph_norm, True, "mean max min dir1-av dir1-dx", scalers, {"log": torch.tensor(1.2)}, "towers",
+                             residual, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=gen))
+    h0 = torch.randn(N, F_, device=dev, generator=gen)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    res = {}
+    for whole in (True, False):
+        monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER", whole)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        used = []
+        if whole:
+            orig = dgn_amd.dgn_layer.towers_layer
+            monkeypatch.setattr(dgn_amd.dgn_layer, "towers_layer", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        if whole:
+            assert used, "the whole-layer entry point was not taken"
+            monkeypatch.setattr(dgn_amd.dgn_layer, "towers_layer", orig)
+        res[whole] = (y.detach(), h.grad, {k: v.grad for k, v in lay.named_parameters()}, {k: v.clone() for k, v in lay.state_dict().items() if "running" in k or "num_batches" in k})
+    (ya, ga, pa, sa), (yb, gb, pb, sb) = res[True], res[False]
+    _close(ya, yb, 1e-6, 1e-6)
+    _close(ga, gb, 1e-5, 1e-5)
+    assert set(pa) == set(pb)
+    for k in pa:
+        assert pa[k] is not None and pb[k] is not None, k
+        _close(pa[k], pb[k], 1e-5, 1e-5 * max(1.0, float(pb[k].abs().max())), msg=k)
+    for k in sa:
+        _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
