@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -24,6 +24,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
+           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_windows",
            "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
@@ -171,6 +172,15 @@ def load() -> C.CDLL:
         lib.dgn_linear_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
+        lib.dgn_graph_build_workspace_bytes.restype = C.c_size_t
+        lib.dgn_graph_build_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
+        lib.dgn_graph_build.restype = C.c_int
+        lib.dgn_graph_build.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_graph_build_csc.restype = C.c_int
+        lib.dgn_graph_build_csc.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_graph_build_windows.restype = C.c_int
+        lib.dgn_graph_build_windows.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + \
+                                              [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_towers_layer_supported.restype = C.c_int
         lib.dgn_towers_layer_supported.argtypes = [C.c_int32] * 5
         for name in ("dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_backward_workspace_bytes"):

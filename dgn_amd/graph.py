@@ -24,6 +24,9 @@ from .spec import EPS, AggPlan, Channel
 
 HUB_THRESHOLD = 2048
 HUB_CHUNK = 1024
+# True: a graph given as CUDA edge lists is prepared by dgn_graph_build* (a handful of kernels behind one C call each);
+# False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
+NATIVE_BUILD = True
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -37,13 +40,16 @@ class DGNGraph:
             raise ValueError("src/dst must be 1-D tensors of equal length")
         device = src.device
         E = src.numel()
-        dst64 = dst.long()
-        # stable sort by destination keeps ascending edge id inside every row (DGL mailbox order)
-        _, perm = torch.sort(dst64, stable=True)
-        deg = torch.bincount(dst64, minlength=num_nodes)
-        indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
-        indptr[1:] = torch.cumsum(deg, 0)
-        self._init_csr(indptr, src.long()[perm], perm, num_nodes, E, deg, hub_threshold, hub_chunk)
+        if src.is_cuda and NATIVE_BUILD:
+            self._build_native(src, dst, int(num_nodes), hub_threshold, hub_chunk)
+        else:
+            dst64 = dst.long()
+            # stable sort by destination keeps ascending edge id inside every row (DGL mailbox order)
+            _, perm = torch.sort(dst64, stable=True)
+            deg = torch.bincount(dst64, minlength=num_nodes)
+            indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
+            indptr[1:] = torch.cumsum(deg, 0)
+            self._init_csr(indptr, src.long()[perm], perm, num_nodes, E, deg, hub_threshold, hub_chunk)
         self.ndata: Dict[str, torch.Tensor] = {}
         self.edata: Dict[str, torch.Tensor] = {}
         if eig is not None:
@@ -67,7 +73,32 @@ class DGNGraph:
             self.ndata["eig"] = eig
         return self
 
-    def _init_csr(self, indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk, num_src=None):
+    def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
+        """CSR by destination through dgn_graph_build: one C call, one read-back of (max in-degree, hub rows)."""
+        lib = _lib.load()
+        dev, E = src.device, src.numel()
+        if num_nodes >= 2 ** 31 - 1 or E >= 2 ** 31 - 1:
+            raise ValueError("graph exceeds the int32 CSR range")
+        src64, dst64 = src.long().contiguous(), dst.long().contiguous()
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        indptr, src_csr, dst_csr = i32(num_nodes + 1), i32(E), i32(E)
+        eid = torch.empty(E, dtype=torch.int64, device=dev)
+        log_deg = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        deg = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+        stats = i32(4)
+        nbytes = lib.dgn_graph_build_workspace_bytes(num_nodes, E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_graph_build(num_nodes, E, _ptr(src64), _ptr(dst64), indptr.data_ptr(), _ptr(src_csr), _ptr(dst_csr), _ptr(eid),
+                                       log_deg.data_ptr(), deg.data_ptr(), stats.data_ptr(), int(hub_threshold), ws.data_ptr(), nbytes,
+                                       stream), "dgn_graph_build")
+        self.dst_csr, self._stats = dst_csr, stats
+        max_deg, n_hub = stats[:2].tolist()                                      # the one host sync of a graph build
+        self._init_csr(indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk, log_deg=log_deg, max_in_degree=max_deg,
+                       n_hub_hint=n_hub)
+
+    def _init_csr(self, indptr, src_csr, eid, num_nodes, E, deg, hub_threshold, hub_chunk, num_src=None, log_deg=None,
+                  max_in_degree=None, n_hub_hint=None):
         if num_nodes >= 2 ** 31 - 1 or E >= 2 ** 31 - 1 or (num_src or 0) >= 2 ** 31 - 1:
             raise ValueError("graph exceeds the int32 CSR range")
         device = indptr.device
@@ -79,10 +110,13 @@ class DGNGraph:
         self.src = src_csr.to(torch.int32).contiguous()
         self.eid = eid  # None = identity (messages already in slot order)
         self.in_degree = deg
-        self.log_deg = torch.log((deg + 1).double()).float().contiguous()
+        self.log_deg = log_deg if log_deg is not None else torch.log((deg + 1).double()).float().contiguous()
         self.hub_threshold, self.hub_chunk = int(hub_threshold), int(hub_chunk)
-        self.max_in_degree = int(deg.max().item()) if self.num_nodes else 0      # the one host sync of a graph build
-        hub_rows = torch.nonzero(deg > hub_threshold).flatten() if self.max_in_degree > hub_threshold else deg.new_empty(0)
+        if max_in_degree is None:
+            max_in_degree = int(deg.max().item()) if self.num_nodes else 0       # the one host sync of a graph build
+        self.max_in_degree = int(max_in_degree)
+        has_hubs = self.max_in_degree > hub_threshold if n_hub_hint is None else n_hub_hint > 0
+        hub_rows = torch.nonzero(deg > hub_threshold).flatten() if has_hubs else deg.new_empty(0)
         self.n_hub = int(hub_rows.numel())           # (a second sync only for graphs that do have hub rows)
         self._keep = []
         c = _lib.DgnGraph()
@@ -110,6 +144,10 @@ class DGNGraph:
         if getattr(self, "_csc_ready", False):
             return
         E, dev = self.num_edges, self.device
+        if self.src.is_cuda and NATIVE_BUILD and self.num_src == self.num_nodes and E > 0:
+            self._csc_native()
+            self._csc_ready = True
+            return
         order = torch.sort(self.src.long(), stable=True)[1]                 # slots ordered by (source, slot)
         pos = torch.empty(E, dtype=torch.int64, device=dev)
         pos[order] = torch.arange(E, device=dev)
@@ -120,6 +158,45 @@ class DGNGraph:
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
         self._build_windows(order, ptr)
         self._csc_ready = True
+
+    def _csc_native(self) -> None:
+        """Transposed view + row windows through dgn_graph_build_csc / _windows (two C calls, one read-back)."""
+        lib = _lib.load()
+        N, E, dev = self.num_nodes, self.num_edges, self.device
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.csc_ptr, self.csc_pos, order = i32(N + 1), i32(E), i32(E)
+        _lib.check(lib.dgn_graph_build_csc(N, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), order.data_ptr(),
+                                           ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
+        self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+        self.n_remote, self.win_ptr = 0, None
+        if self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
+            return
+        dst_csr = getattr(self, "dst_csr", None)
+        if dst_csr is None:        # (graph adopted from a CSR: destination of every slot from the row pointers)
+            dst_csr = self.dst_csr = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32), self.in_degree)
+        R0 = self.WIN_BIN
+        nb = (N + R0 - 1) // R0
+        win_ptr, win_info, rem_ptr, rem_idx = i32(nb + 1), i32(nb * 8), i32(N + 1), i32(E)
+        stats = getattr(self, "_stats", None)
+        if stats is None:
+            stats = self._stats = i32(4)
+        _lib.check(lib.dgn_graph_build_windows(N, E, self.indptr.data_ptr(), self.src.data_ptr(), dst_csr.data_ptr(), self.csc_ptr.data_ptr(),
+                                               order.data_ptr(), R0, self.WIN_ECAP, win_ptr.data_ptr(), win_info.data_ptr(), rem_ptr.data_ptr(),
+                                               rem_idx.data_ptr(), stats.data_ptr(), ws.data_ptr(), nbytes, stream), "dgn_graph_build_windows")
+        n_remote = int(stats[2].item())                                          # (host sync of this view)
+        self.local_fraction = 1.0 - n_remote / E
+        if self.local_fraction < 0.5:          # e.g. k-NN graphs with unordered points: the windows catch little
+            return
+        self.n_remote, self.win_ptr, self.win_info = n_remote, win_ptr, win_info.view(nb, 8)
+        c = self._c
+        c.win_ptr, c.win_info, c.n_win, c.win_rows, c.win_ecap = win_ptr.data_ptr(), win_info.data_ptr(), nb, 3 * R0 - 1, self.WIN_ECAP
+        c.n_remote = n_remote
+        if n_remote:
+            self.rem_ptr, self.rem_idx = rem_ptr, rem_idx
+            c.rem_ptr, c.rem_idx = rem_ptr.data_ptr(), rem_idx.data_ptr()
 
     # ---- row windows of the window-local backward scatter (include/dgn_hip.h: DgnGraph.win_ptr) ----
     WIN_BIN = 16        # rows per bin; a window spans at most 3 bins - 1 rows

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 11
+#define DGN_ABI_VERSION 12
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -323,6 +323,30 @@ size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, in
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
                      int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- graph batch preparation on the device (dgn_graph_build.hip) ------------------------------------------------------
+ * The edge list of a (batched) graph in edge-id order -> the DgnGraph arrays, by a handful of kernels on `stream`, no host
+ * synchronisation inside.  Replaces what DGL does per update_all call (degree bucketing, nets/dgn_layer.py:115,186,264) and
+ * the ~40 torch ops of the Python build; `dgl.batch` (data/molecules.py:229) is where a caller would invoke it.
+ *   dgn_graph_build          indptr [N+1], src_csr / dst_csr [E] (source / destination of every CSR slot; slots of a row in
+ *                            ascending edge id), eid [E] (slot -> edge id), log_deg [N], in_degree [N] (int64, may be NULL),
+ *                            stats[0] = largest in-degree, stats[1] = rows with more than hub_threshold in-edges
+ *   dgn_graph_build_csc      csc_ptr [N+1], csc_pos [E], csc_order [E] (rank -> slot) of DgnGraph's transposed view
+ *   dgn_graph_build_windows  win_ptr [nb+1], win_info [nb][8] with nb = ceil(N / bin_rows) windows of at most 3*bin_rows-1 rows
+ *                            (cuts where no edge crosses when a bin has such a place), rem_ptr [N+1], rem_idx [<= E];
+ *                            stats[2] = stats[3] = number of remote csc entries
+ * src / dst are int64 (what torch / DGL hand over); all outputs are caller-allocated device arrays; stats is int32[4] on the
+ * device (the caller reads it when it needs the numbers); ws: dgn_graph_build_workspace_bytes() bytes for every call.    */
+size_t dgn_graph_build_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int dgn_graph_build(int64_t n_nodes, int64_t n_edges, const int64_t* src, const int64_t* dst, int32_t* indptr, int32_t* src_csr,
+                    int32_t* dst_csr, int64_t* eid, float* log_deg, int64_t* in_degree, int32_t* stats, int32_t hub_threshold,
+                    void* ws, size_t ws_bytes, void* stream);
+int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, int32_t* csc_ptr, int32_t* csc_pos,
+                        int32_t* csc_order, void* ws, size_t ws_bytes, void* stream);
+int dgn_graph_build_windows(int64_t n_nodes, int64_t n_edges, const int32_t* indptr, const int32_t* src_csr, const int32_t* dst_csr,
+                            const int32_t* csc_ptr, const int32_t* csc_order, int32_t bin_rows, int32_t ecap, int32_t* win_ptr,
+                            int32_t* win_info, int32_t* rem_ptr, int32_t* rem_idx, int32_t* stats, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* ---- whole towers layer in one call (dgn_towers.hip) ------------------------------------------------------------------
  * DGNLayerTower.forward of the reference (nets/dgn_layer.py:309-325 over DGNTower.forward :254-276) for the fused form the
