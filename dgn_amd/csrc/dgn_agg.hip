@@ -147,6 +147,15 @@ int launch(int vec, const AggParams& p, unsigned tiles, hipStream_t stream, bool
 }
 
 }  // namespace
+
+// shared with dgn_fused.hip
+int agg_validate_and_fill(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                          const float* log_deg) {
+    const int rc = validate(g, spec, msg, w, log_deg);
+    if (rc) return rc;
+    fill_params(p, g, spec, msg, w, ld_w, log_deg);
+    return DGN_OK;
+}
 }  // namespace dgn
 
 using namespace dgn;

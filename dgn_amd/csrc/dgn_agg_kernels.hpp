@@ -663,7 +663,7 @@ __device__ __forceinline__ void load_partial(Acc<C, TRACK>& acc, const AggParams
 
 // one destination row, start to finish (row pointers -> slot batches -> gathers -> epilogue)
 template <class C, class O>
-__device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0, bool active) {
+__device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0, bool active, float* orow_override = nullptr) {
     constexpr int VEC = C::VEC;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
@@ -678,7 +678,7 @@ __device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0,
     Acc<C, false> acc;
     acc.init();
     accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
-    if (active) write_row<C, O>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+    if (active) write_row<C, O>(acc, p, orow_override ? orow_override : p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
 }
 
 template <class C, class O = DynOps>
@@ -734,8 +734,73 @@ struct ShortGroup {
         ipv = p.indptr[row0 + min(lane_id(), nrows)];
         return true;
     }
+    // explicit group (the fused layer kernel walks its own row ranges)
+    __device__ __forceinline__ bool init_at(const AggParams& p, int64_t first_row) {
+        if (first_row >= p.n_nodes) return false;
+        row0 = uniform_i((int)first_row);
+        nrows = (int)min((int64_t)kShortRows, p.n_nodes - row0);
+        ipv = p.indptr[row0 + min(lane_id(), nrows)];
+        return true;
+    }
     __device__ __forceinline__ int ptr(int r) const { return bcast_i(ipv, r); }
 };
+
+// kShortRows rows of one wave with every row LEFT in LDS: row r of the group goes to lds_rows + r * row_stride, laid out per
+// tower as it would lie in a tower-major output ([tower][aggregator][Ft], tower blocks K floats apart).  The sweep half of the
+// fused layer kernel (layer_fwd_fused); one feature tile, no scalers in the row.
+template <class C, class O>
+__device__ __forceinline__ void short_group_to_lds(const AggParams& p, const ShortGroup& grp, int f0, bool active, float* lds_rows,
+                                                   int row_stride) {
+    constexpr int VEC = C::VEC, R = kShortRows, J = kShortDeg;
+    const int K = p.agg_total * p.Ft;
+    int t_of = 0;
+    for (int q = 1; q < p.n_towers; ++q) t_of += (f0 >= q * p.Ft) ? 1 : 0;
+    const int lane_off = t_of * K + (f0 - t_of * p.Ft);
+    const int beg0 = grp.ptr(0);
+    int lo[R], deg[R], max_deg = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        lo[r] = grp.ptr(min(r, grp.nrows)) - beg0;
+        deg[r] = grp.ptr(min(r + 1, grp.nrows)) - beg0 - lo[r];
+        max_deg = max(max_deg, deg[r]);
+    }
+    if (max_deg > J || (p.x_src && p.m_edge)) {   // a longer row, or two gathered parts per message: row at a time
+        for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active, lds_rows + r * row_stride + lane_off);
+        return;
+    }
+    RowSide<VEC> side[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r == 0 || r < grp.nrows) side[r].load(p, grp.row0 + r, f0, active);
+    SlotBatch<C::NCH, C::NW> b;
+    b.load(p, beg0, beg0 + lo[R - 1] + deg[R - 1]);
+    if (!active) return;
+    const MsgSrc<VEC> src(p);
+    float t[R][J][VEC];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (j < deg[r]) src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r != 0 && r >= grp.nrows) break;
+        Acc<C, false> acc;
+        acc.init();
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            if (j < deg[r]) {
+                float mm[VEC], wk[C::NW];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
+                b.weights(wk, lo[r] + j);
+                acc.add(mm, wk, beg0 + lo[r] + j);
+            }
+        }
+        write_row<C, O>(acc, p, lds_rows + r * row_stride + lane_off, deg[r], side[r].xin, side[r].logd);
+    }
+}
 
 template <class C, class O = DynOps>
 __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {

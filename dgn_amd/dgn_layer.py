@@ -516,9 +516,24 @@ class DGNLayerTower(nn.Module):
             # The sweep runs WITHOUT scalers (per-row factors, folded behind the GEMM) and WITH the h_in
             # pass-through block, tower-major: posttrans([h_t || agg_t]) of all towers is ONE batched GEMM on
             # contiguous matrices, then one scale-combine kernel (+bias, +snorm) writes [N, T*fo].
+            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+            needs_grad = torch.is_grad_enabled() and (h.requires_grad or any(q.requires_grad for q in self.parameters()))
+            if (_ops.FUSED_FORWARD and not needs_grad and m_edge is None and h.is_cuda and self.divide_input
+                    and _ops.fused_sweep_posttrans_supported(graph, self._kplan_x, T, x_in.shape[1], S, fo)):
+                # inference: sweep + posttrans + scale-combine in ONE kernel, the aggregate rows stay in LDS
+                w_edge = graph.edge_weights(self._kplan_x, g.ndata["eig"])
+                y = _ops.fused_sweep_posttrans_forward(graph, self._kplan_x, T, self._avg_log, w_edge, pq, x_in.contiguous(), ops["w"], sc, b_p,
+                                                       row_scale)
+                if self.batch_norm:
+                    bns = [t.batchnorm_h for t in self.towers]
+                    if bn_tail_supported(bns, y, self.training):
+                        rm, rv, nbt = self._linked_bn_stats(y.device)
+                        y = bn_tail_fused(y, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps, self.training)
+                    else:
+                        y = bn_tail(y, bns, self.training)
+                return F.dropout(y, self.dropout, training=self.training)
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True)
-            sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
             bns = [t.batchnorm_h for t in self.towers]
             fused_tail = self.batch_norm and self.training and bn_tail_supported(bns, aggx, True, T * fo)
             if fused_tail and linear_combine_supported(aggx, ops["w"], S):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 12
+#define DGN_ABI_VERSION 13
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -323,6 +323,21 @@ size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, in
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
                      int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the posttrans product inside the sweep (dgn_fused.hip) -----------------------------------------------------------
+ * dgn_agg_forward + dgn_linear_combine_forward as ONE kernel: the aggregate rows ([T][A][F/T] per node: 1 680 bytes on the
+ * ZINC towers config, 0.46 GB per pass) stay in LDS, are multiplied there by the posttrans weights (w[t]: [S*f_out, K],
+ * K = agg_total * F/T, exact fp32 MFMA) and leave as
+ *     y[i, t*f_out + o] = row_scale[i] * (bias[t*f_out + o] + sum_s scale[i, s] * (agg[t][i] w[t]^T)[s*f_out + o])
+ * -- reduce_func's row feeding posttrans (nets/dgn_layer.py:237-249 -> :266-271) without the [N, A*F] tensor in between.
+ * Domain (dgn_layer_fused_supported): spec with ONE identity scaler (scalers folded behind posttrans) and an aggregator list of
+ * the reference's configs, even F <= 128 and F/T, K <= 96 (a multiple of 4), n_towers * ceil(S*f_out / 16) <= 16, graphs without
+ * hub rows whose rows fit one slot batch (batched molecules / superpixel graphs), no bipartite CSR.                   */
+int dgn_layer_fused_supported(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t n_scalers, int32_t f_out);
+int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                            const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers,
+                            int32_t f_out, const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
+                            void* stream);
 
 /* ---- graph batch preparation on the device (dgn_graph_build.hip) ------------------------------------------------------
  * The edge list of a (batched) graph in edge-id order -> the DgnGraph arrays, by a handful of kernels on `stream`, no host

@@ -660,3 +660,48 @@ def test_whole_layer_call_equals_per_kernel_route(monkeypatch, residual, graph_n
         _close(pa[k], pb[k], 1e-5, 1e-5 * max(1.0, float(pb[k].abs().max())), msg=k)
     for k in sa:
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
+
+
+@pytest.mark.parametrize("n_graphs,scalers", [(300, "identity amplification attenuation"), (7, "identity attenuation"), (40, "identity")])
+def test_fused_forward_equals_separate_kernels(monkeypatch, n_graphs, scalers):
+    """layer_fwd_fused (the posttrans product inside the sweep: aggregate rows in LDS -> MFMA -> scale-combine) against the
+    sweep + streaming Linear + combine kernels it replaces on the no-grad path, and against the oracle's layer."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    from oracle import dgn_oracle as orc
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    b = synth.molecule_batch(n_graphs, seed=31, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=b["eig"].to(dev))
+    F_ = 70
+    aggs = "mean max min dir1-av dir1-dx"
+    torch.manual_seed(4)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, aggs, scalers, {"log": torch.tensor(1.15)}, "towers", True, towers=5,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+        for t in layer.towers:
+            t.batchnorm_h.running_mean.normal_(generator=gen)
+            t.batchnorm_h.running_var.uniform_(0.5, 1.5, generator=gen)
+    h = torch.randn(N, F_, generator=gen)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.15), graph_norm=True, batch_norm=True, residual=True, towers=5,
+               divide_input=True, edge_features=False)
+    with torch.no_grad():
+        yo, _ = orc.layer_forward("towers", sd, cfg, src, dst, N, b["eig"], h, None, b["snorm_n"], training=False)
+    layer = layer.to(dev).eval()
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(dgn_amd.ops, "FUSED_FORWARD", fused)
+        taken = []
+        orig = dgn_amd.ops.fused_sweep_posttrans_forward
+        monkeypatch.setattr(dgn_amd.ops, "fused_sweep_posttrans_forward", lambda *a, **k: (taken.append(1), orig(*a, **k))[1])
+        with torch.no_grad():
+            outs[fused] = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+        monkeypatch.setattr(dgn_amd.ops, "fused_sweep_posttrans_forward", orig)
+        assert bool(taken) == fused
+    assert torch.equal(outs[True], outs[False])                     # same arithmetic in the same order: bit-identical
+    _close(outs[True], yo, 2e-5, 2e-5)
