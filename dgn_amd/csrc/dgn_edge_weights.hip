@@ -133,7 +133,10 @@ __device__ __forceinline__ float weight_of(const DgnChannel& ch, const Stats& st
     return expf(ch.alpha * fabsf(d) - st.mx) / st.se;
 }
 
-// statistics of slots [beg, end) of row `row` for every channel (wave-wide results)
+// statistics of slots [beg, end) of row `row` for every channel (wave-wide results).  The gathered deltas are PARKED in the
+// output planes (w[c][e] := delta): the softmax pass and range_write read them back -- sequential, coalesced 4-byte reads of
+// what the same lane wrote -- instead of gathering eig a second time (rows longer than one slot batch and hub slices: 39 % of
+// C5's edges).
 __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwParams& p, int row, int beg, int end) {
     const int lane = lane_id();
     RowEig re;
@@ -151,6 +154,7 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
         for (int c = 0; c < DGN_MAX_CH; ++c) {
             if (c < p.n_ch) {
                 const float d = dl[c];
+                p.w[(int64_t)c * p.ld_w + e] = d;
                 st[c].sabs += fabsf(d);
                 st[c].spos += fmaxf(d, 0.f);
                 st[c].sneg += fmaxf(-d, 0.f);
@@ -169,11 +173,10 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
     }
     if (any_softmax) {
         for (int e = beg + lane; e < end; e += kWave) {
-            float dl[DGN_MAX_CH];
-            edge_deltas(dl, p, re, e);
 #pragma unroll
             for (int c = 0; c < DGN_MAX_CH; ++c)
-                if (c < p.n_ch && p.ch[c].kind == DGN_W_SOFTMAX) st[c].se += expf(p.ch[c].alpha * fabsf(dl[c]) - st[c].mx);
+                if (c < p.n_ch && p.ch[c].kind == DGN_W_SOFTMAX)
+                    st[c].se += expf(p.ch[c].alpha * fabsf(p.w[(int64_t)c * p.ld_w + e]) - st[c].mx);
         }
 #pragma unroll
         for (int c = 0; c < DGN_MAX_CH; ++c)
@@ -181,16 +184,17 @@ __device__ __forceinline__ void range_stats(Stats (&st)[DGN_MAX_CH], const EwPar
     }
 }
 
+// weights from the parked deltas, in place (same lane -> slot mapping as range_stats)
 __device__ __forceinline__ void range_write(const Stats (&st)[DGN_MAX_CH], const EwParams& p, int row, int beg, int end) {
     const int lane = lane_id();
-    RowEig re;
-    re.load(p, row);
     for (int e = beg + lane; e < end; e += kWave) {
-        float dl[DGN_MAX_CH];
-        edge_deltas(dl, p, re, e);
 #pragma unroll
-        for (int c = 0; c < DGN_MAX_CH; ++c)
-            if (c < p.n_ch) p.w[(int64_t)c * p.ld_w + e] = weight_of(p.ch[c], st[c], dl[c]);
+        for (int c = 0; c < DGN_MAX_CH; ++c) {
+            if (c < p.n_ch) {
+                float* q = p.w + (int64_t)c * p.ld_w + e;
+                *q = weight_of(p.ch[c], st[c], *q);
+            }
+        }
     }
 }
 
@@ -254,44 +258,75 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void ew_rows_g16(const EwParams p) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row64 = t / kGroup;
-    const int l = (int)(t % kGroup);
-    // (no early return before the shuffles: lanes of rows past the end / of other classes stay and contribute nothing)
-    const bool row_ok = row64 < p.n_nodes;
-    const int row = row_ok ? (int)row64 : 0;
-    const int beg = row_ok ? p.indptr[row] : 0, end = row_ok ? p.indptr[row + 1] : 0;
-    const int deg = end - beg;
-    const bool mine = row_ok && deg > kFlatMax && deg <= kGroup;
-    const bool in = mine && l < deg;
-    RowEig re;
-    re.load(p, row);
-    float dl[DGN_MAX_CH];
+// Row classes by ballot: a one-wave workgroup looks at 64 consecutive rows (one coalesced read of their degrees), lists the ones
+// of its class in LDS and works through that list -- four rows at a time here (16 lanes each), one row at a time in ew_rows.
+// On a power-law graph most rows belong to another class: launching a wave (or 16 lanes) per ROW made the dispatcher the cost of
+// these kernels (10 M one-wave workgroups = 2.2 ms at ~4.6 workgroups/ns), and several waves per workgroup tie a finished wave's
+// slot to the longest row of the group (measured: 2.4 -> 4.0 ms).
+// (R = candidate rows per wave: 64 on large graphs; 4 / 1 -- the plain 16-lanes-per-row / wave-per-row mapping -- on small
+// batches, where a wave walking through 20 rows one after the other would serialise their gather latencies: CIFAR10-like batch
+// 0.018 ms with R = 1 / 4, 0.037 ms with R = 64)
+template <int R>
+__device__ __forceinline__ int class_rows(const EwParams& p, int64_t base, int lo, int hi, int* list, int& my_beg, int& my_deg) {
+    const int lane = lane_id();
+    const int64_t r = base + lane;
+    my_beg = 0;
+    my_deg = 0;
+    if (lane < R && r < p.n_nodes) {
+        my_beg = p.indptr[r];
+        my_deg = p.indptr[r + 1] - my_beg;
+    }
+    const bool mine = my_deg > lo && my_deg <= hi;
+    const uint64_t mask = __ballot(mine);
+    if (mine) list[__popcll(mask & ((1ull << lane) - 1))] = lane;
+    return __popcll(mask);
+}
+
+template <int R>
+__global__ __launch_bounds__(kWave) void ew_rows_g16(const EwParams p) {
+    __shared__ int list[kWave];
+    const int64_t base = (int64_t)blockIdx.x * R;
+    int my_beg, my_deg;
+    const int count = class_rows<R>(p, base, kFlatMax, kGroup, list, my_beg, my_deg);
+    const int lane = lane_id(), grp = lane / kGroup, l = lane % kGroup;
+    for (int it = 0; it * (kWave / kGroup) < count; ++it) {
+        const int idx = it * (kWave / kGroup) + grp;
+        const bool have = idx < count;
+        const int rl = have ? list[idx] : 0;                      // (LDS written by this wave: program order suffices)
+        const int row = (int)(base + rl);
+        const int beg = __shfl(my_beg, rl, kWave), deg = __shfl(my_deg, rl, kWave);
+        const bool in = have && l < deg;
+        RowEig re;
+        re.load(p, have ? row : 0);
+        float dl[DGN_MAX_CH];
 #pragma unroll
-    for (int c = 0; c < DGN_MAX_CH; ++c) dl[c] = 0.f;
-    if (in) edge_deltas(dl, p, re, beg + l);
+        for (int c = 0; c < DGN_MAX_CH; ++c) dl[c] = 0.f;
+        if (in) edge_deltas(dl, p, re, beg + l);
 #pragma unroll
-    for (int c = 0; c < DGN_MAX_CH; ++c) {
-        if (c >= p.n_ch) break;
-        const float d = dl[c];
-        Stats st{0.f, 0.f, 0.f, -INFINITY, 0.f};
-        st.sabs = group_sum(fabsf(d));
-        st.spos = group_sum(fmaxf(d, 0.f));
-        st.sneg = group_sum(fmaxf(-d, 0.f));
-        st.mx = group_max(in ? p.ch[c].alpha * fabsf(d) : -INFINITY);
-        if (p.ch[c].kind == DGN_W_SOFTMAX) st.se = group_sum(in ? expf(p.ch[c].alpha * fabsf(d) - st.mx) : 0.f);
-        if (in) p.w[(int64_t)c * p.ld_w + beg + l] = weight_of(p.ch[c], st, d);
+        for (int c = 0; c < DGN_MAX_CH; ++c) {
+            if (c >= p.n_ch) break;
+            const float d = dl[c];
+            Stats st{0.f, 0.f, 0.f, -INFINITY, 0.f};
+            st.sabs = group_sum(fabsf(d));
+            st.spos = group_sum(fmaxf(d, 0.f));
+            st.sneg = group_sum(fmaxf(-d, 0.f));
+            st.mx = group_max(in ? p.ch[c].alpha * fabsf(d) : -INFINITY);
+            if (p.ch[c].kind == DGN_W_SOFTMAX) st.se = group_sum(in ? expf(p.ch[c].alpha * fabsf(d) - st.mx) : 0.f);
+            if (in) p.w[(int64_t)c * p.ld_w + beg + l] = weight_of(p.ch[c], st, d);
+        }
     }
 }
 
-__global__ __launch_bounds__(kBlock) void ew_rows(const EwParams p) {
-    const int64_t row64 = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (row64 >= p.n_nodes) return;
-    const int row = uniform_i((int)row64);
-    const int beg = p.indptr[row], end = p.indptr[row + 1];
-    const int deg = end - beg;
-    if (deg <= kGroup || deg > p.hub_threshold) return;    // short rows: ew_rows_flat / ew_rows_g16; hubs: slices
+template <int R>
+__global__ __launch_bounds__(kWave) void ew_rows(const EwParams p) {
+    __shared__ int list[kWave];
+    const int64_t base = (int64_t)blockIdx.x * R;
+    int my_beg, my_deg;
+    const int count = class_rows<R>(p, base, kGroup, p.hub_threshold, list, my_beg, my_deg);
+    for (int it = 0; it < count; ++it) {
+    const int rl = list[it];
+    const int row = uniform_i((int)(base + rl));
+    const int beg = bcast_i(my_beg, rl), deg = bcast_i(my_deg, rl), end = beg + deg;
     if (deg <= kWave) {
         // the row is one slot per lane: ONE gather per edge, the deltas stay in registers between statistics and write
         const int lane = lane_id();
@@ -320,11 +355,12 @@ __global__ __launch_bounds__(kBlock) void ew_rows(const EwParams p) {
             for (int c = 0; c < DGN_MAX_CH; ++c)
                 if (c < p.n_ch) p.w[(int64_t)c * p.ld_w + beg + lane] = weight_of(p.ch[c], st[c], dl[c]);
         }
-        return;
+        continue;
     }
     Stats st[DGN_MAX_CH];
     range_stats(st, p, row, beg, end);
     range_write(st, p, row, beg, end);
+    }
 }
 
 __device__ __forceinline__ void slice_bounds(const EwParams& p, int chunk, int& hub, int& row, int& beg, int& end) {
@@ -353,22 +389,33 @@ __global__ __launch_bounds__(kBlock) void ew_hub_slice_stats(const EwParams p) {
     }
 }
 
-// one thread per (hub row, channel): merge the slice statistics in slot order
-__global__ void ew_hub_combine(const EwParams p) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.n_hub * DGN_MAX_CH) return;
-    const int hub = (int)(t / DGN_MAX_CH), c = (int)(t % DGN_MAX_CH);
-    float sabs = 0.f, spos = 0.f, sneg = 0.f, mx = -INFINITY, se = 0.f;
-    for (int k = p.hub_chunk_ptr[hub]; k < p.hub_chunk_ptr[hub + 1]; ++k) {
-        const float* s = p.slice_stats + ((int64_t)k * DGN_MAX_CH + c) * 5;
-        sabs += s[0]; spos += s[1]; sneg += s[2];
-        const float m2 = s[3], e2 = s[4];
-        const float M = fmaxf(mx, m2);
-        if (M > -INFINITY) se = se * expf(mx - M) + e2 * expf(m2 - M);
-        mx = M;
+// one wave per hub row: lanes stride over the row's slices (a 2.4 M-edge row has 2 400 of them), wave reductions join them;
+// the softmax partial sums are rescaled to the row's maximum
+__global__ __launch_bounds__(kWave) void ew_hub_combine(const EwParams p) {
+    const int hub = blockIdx.x;
+    if (hub >= p.n_hub) return;
+    const int lane = lane_id();
+    const int k0 = p.hub_chunk_ptr[hub], k1 = p.hub_chunk_ptr[hub + 1];
+#pragma unroll
+    for (int c = 0; c < DGN_MAX_CH; ++c) {
+        float sabs = 0.f, spos = 0.f, sneg = 0.f, mx = -INFINITY;
+        for (int k = k0 + lane; k < k1; k += kWave) {
+            const float* s = p.slice_stats + ((int64_t)k * DGN_MAX_CH + c) * 5;
+            sabs += s[0]; spos += s[1]; sneg += s[2];
+            mx = fmaxf(mx, s[3]);
+        }
+        sabs = wave_sum(sabs); spos = wave_sum(spos); sneg = wave_sum(sneg); mx = wave_max(mx);
+        float se = 0.f;
+        for (int k = k0 + lane; k < k1; k += kWave) {
+            const float* s = p.slice_stats + ((int64_t)k * DGN_MAX_CH + c) * 5;
+            if (s[3] > -INFINITY) se += s[4] * expf(s[3] - mx);
+        }
+        se = wave_sum(se);
+        if (lane == 0) {
+            float* o = p.hub_stats + ((int64_t)hub * DGN_MAX_CH + c) * 5;
+            o[0] = sabs; o[1] = spos; o[2] = sneg; o[3] = mx; o[4] = se;
+        }
     }
-    float* o = p.hub_stats + ((int64_t)hub * DGN_MAX_CH + c) * 5;
-    o[0] = sabs; o[1] = spos; o[2] = sneg; o[3] = mx; o[4] = se;
 }
 
 __global__ __launch_bounds__(kBlock) void ew_hub_slice_write(const EwParams p) {
@@ -439,18 +486,21 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
         p.slice_stats = static_cast<float*>(ws);
         p.hub_stats = reinterpret_cast<float*>(static_cast<char*>(ws) + up((size_t)g->n_chunks * DGN_MAX_CH * 5 * sizeof(float)));
     }
+    const bool big = p.n_nodes >= (1 << 20);       // row classes by ballot (64 candidate rows per wave) vs a wave / 16 lanes per row
     hipLaunchKernelGGL(ew_rows_flat, dim3((unsigned)((p.n_nodes + 255) / 256)), dim3(256), 0, stream, p);
     if (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)        // (skipped when every row is known to be shorter)
-        hipLaunchKernelGGL(ew_rows_g16, dim3((unsigned)((p.n_nodes * kGroup + 255) / 256)), dim3(256), 0, stream, p);
+    {
+        if (big) hipLaunchKernelGGL(ew_rows_g16<kWave>, dim3((unsigned)((p.n_nodes + kWave - 1) / kWave)), dim3(kWave), 0, stream, p);
+        else hipLaunchKernelGGL(ew_rows_g16<kWave / kGroup>, dim3((unsigned)((p.n_nodes + 3) / 4)), dim3(kWave), 0, stream, p);
+    }
     if (g->max_in_degree == 0 || g->max_in_degree > kGroup) {
-        const unsigned nb = (unsigned)((p.n_nodes + kWavesPerBlock - 1) / kWavesPerBlock);
-        hipLaunchKernelGGL(ew_rows, dim3(nb), dim3(kBlock), 0, stream, p);
+        if (big) hipLaunchKernelGGL(ew_rows<kWave>, dim3((unsigned)((p.n_nodes + kWave - 1) / kWave)), dim3(kWave), 0, stream, p);
+        else hipLaunchKernelGGL(ew_rows<1>, dim3((unsigned)p.n_nodes), dim3(kWave), 0, stream, p);
     }
     if (p.n_hub > 0) {
         const unsigned ns = (unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);
         hipLaunchKernelGGL(ew_hub_slice_stats, dim3(ns), dim3(kBlock), 0, stream, p);
-        const unsigned nc = (unsigned)((p.n_hub * DGN_MAX_CH + 255) / 256);
-        hipLaunchKernelGGL(ew_hub_combine, dim3(nc), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(ew_hub_combine, dim3((unsigned)p.n_hub), dim3(kWave), 0, stream, p);
         hipLaunchKernelGGL(ew_hub_slice_write, dim3(ns), dim3(kBlock), 0, stream, p);
     }
     DGN_HIP_CHECK(hipGetLastError());
