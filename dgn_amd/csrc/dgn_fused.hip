@@ -31,7 +31,8 @@ int launch_fwd(const FusedParams& p, size_t lds, hipStream_t st) {
                                           160 * 1024));
         attr = true;
     }
-    const unsigned grid = (unsigned)std::min<int64_t>(p.n_iters, n_cus());
+    const int per_cu = std::max(1, (int)(160 * 1024 / lds));                       // workgroups of one CU alternate between sweep and MFMA phases
+    const unsigned grid = (unsigned)std::min<int64_t>(p.n_iters, (int64_t)n_cus() * per_cu);
     hipLaunchKernelGGL((layer_fwd_fused<C, O>), dim3(grid), dim3(kWave * kFusedWaves), lds, st, p);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
@@ -78,7 +79,7 @@ extern "C" int dgn_layer_fused_supported(const DgnGraph* g, const DgnAggSpec* sp
     const int Ft = (int)(F / spec->n_towers);
     const int a_total = spec->agg_total > 0 ? spec->agg_total : spec->n_agg;
     const int K = a_total * Ft, n = n_scalers * f_out, nq = (n + 15) / 16;
-    if ((Ft & 1) || K > 16 * kFusedKB || (K & 3) || n_scalers < 1 || n_scalers > 3 || f_out < 2 || (f_out & 1) || spec->n_towers * nq > kFusedWaves) return 0;
+    if ((Ft & 1) || K > 16 * kFusedKB || (K & 3) || n_scalers < 1 || n_scalers > 3 || f_out < 2 || (f_out & 1) || spec->n_towers * nq > kFusedWaves * kFusedUnits) return 0;
     if (spec->n_scalers != 1 || spec->scaler[0] != DGN_SCALE_IDENTITY || (spec->agg_total > 0 && (spec->agg_offset != 0 || spec->n_agg != spec->agg_total))) return 0;
     if (g->n_hub > 0 || g->n_src > 0 || g->max_in_degree <= 0 || g->max_in_degree > kWave) return 0;
     AggParams a{};
@@ -116,6 +117,7 @@ extern "C" int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec
     p.S = n_scalers; p.fo = f_out; p.nq = (n_scalers * f_out + 15) / 16;
     p.Y = y; p.ldy = ld_y;
     p.n_iters = (g->n_nodes + kFusedRows - 1) / kFusedRows;
+    { static const char* e = getenv("DGN_FUSED_DBG"); p.dbg = e ? atoi(e) : 0; }
     const size_t lds = fused_lds_floats(p.a, p.nq) * sizeof(float);
     return dispatch_fwd(p, lds, static_cast<hipStream_t>(stream));
 }

@@ -16,8 +16,12 @@ namespace dgn {
 
 using f4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kFusedRows = 64;       // destination rows per iteration = 16 waves x kShortRows
-constexpr int kFusedWaves = 16;
+#ifndef DGN_FUSED_WAVES
+#define DGN_FUSED_WAVES 16
+#endif
+constexpr int kFusedWaves = DGN_FUSED_WAVES;                 // 8: two workgroups per CU alternate between their sweep and MFMA phases
+constexpr int kFusedRows = kFusedWaves * kShortRows;         // destination rows per iteration
+constexpr int kFusedUnits = 16 / kFusedWaves;                // (tower, n-tile) weight tiles per wave: 16 units in all
 constexpr int kFusedKB = 6;          // 16-k blocks a wave keeps of its weight tile: K <= 96
 
 struct FusedParams {
@@ -32,6 +36,7 @@ struct FusedParams {
     // wgrad twin (layer_wgrad_fused): G = gy expanded by the scalers, dW partial slots
     const float* gy; int64_t s_gy;    // [T][N][fo]
     float* part;                      // [T][slots][nq*16][kFusedKB*16]
+    int dbg;                          // experiments (DGN_FUSED_DBG): 1 = sweep only, 2 = product + combine only
 };
 
 __host__ __device__ inline int fused_tk(const AggParams& a) { return a.n_towers * a.agg_total * a.Ft; }
@@ -47,16 +52,24 @@ __global__ __launch_bounds__(kWave * kFusedWaves) void layer_fwd_fused(const Fus
     const AggParams& a = p.a;
     const int T = a.n_towers, K = a.agg_total * a.Ft, TK = T * K, NQ = p.nq, ZW = T * NQ * 16;
     float* AX = lds_f;                                   // [64][T][K]
-    float* FAC = AX + kFusedRows * max(TK, ZW);          // [64][4]: scale_0..2, row_scale  (the products [64][T][NQ*16] reuse AX)
+    float* FAC = AX + kFusedRows * max(TK, ZW);          // [rows][4]: scale_0..2, row_scale  (the products [rows][T][NQ*16] reuse AX)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    // this wave's weight tile: unit u = (tower, n-tile); lane (i16, g) keeps W[t][16q + i16][16b + 4g + s]
-    const bool has_unit = wave < T * NQ;
-    const int t_u = has_unit ? wave / NQ : 0, q_u = has_unit ? wave - t_u * NQ : 0;
-    const int n_u = 16 * q_u + i16;
-    const bool w_live = has_unit && n_u < p.S * p.fo;
-    const float* wrow = p.W + (int64_t)t_u * p.sW + (int64_t)(w_live ? n_u : 0) * p.ldw + 4 * g;
+    // this wave's weight tiles: unit u = wave + j * kFusedWaves = (tower, n-tile); lane (i16, g) keeps W[t][16q + i16][16b + 4g + s]
+    int t_u[kFusedUnits], q_u[kFusedUnits];
+    bool has_unit[kFusedUnits], w_live[kFusedUnits];
+    const float* wrow[kFusedUnits];
     const bool w16 = (p.ldw & 3) == 0 && (p.sW & 3) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < kFusedUnits; ++j) {
+        const int u = wave + j * kFusedWaves;
+        has_unit[j] = u < T * NQ;
+        t_u[j] = has_unit[j] ? u / NQ : 0;
+        q_u[j] = has_unit[j] ? u - t_u[j] * NQ : 0;
+        const int n_u = 16 * q_u[j] + i16;
+        w_live[j] = has_unit[j] && n_u < p.S * p.fo;
+        wrow[j] = p.W + (int64_t)t_u[j] * p.sW + (int64_t)(w_live[j] ? n_u : 0) * p.ldw + 4 * g;
+    }
     const int f0 = lane * VEC;
     const bool active = f0 < a.F;
     const int fo2 = p.fo >> 1;
@@ -77,55 +90,75 @@ __global__ __launch_bounds__(kWave * kFusedWaves) void layer_fwd_fused(const Fus
             *reinterpret_cast<f4*>(FAC + 4 * tid) = f;
         }
         ShortGroup grp;
-        if (grp.init_at(a, row_base + (int64_t)wave * kShortRows))
+        if (p.dbg != 2 && grp.init_at(a, row_base + (int64_t)wave * kShortRows))
             short_group_to_lds<C, O>(a, grp, f0, active, AX + (wave * kShortRows) * TK, TK);
-        // The wave's 16 x K weight tile (70 KB for all units together: L2 resident) is fetched per iteration, AFTER the sweep:
-        // kept in registers across the sweep it pushed every configuration past 128 VGPRs.  Lane (i16, g): W[t][16q+i16][16b+4g+s].
-        float wreg[kFusedKB][4];
-#pragma unroll
-        for (int b = 0; b < kFusedKB; ++b) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wreg[b][s] = 0.f;
-            if (w_live && 16 * b + 4 * g < K) {
-                if (w16) {
-                    const f4 v = *reinterpret_cast<const f4*>(wrow + 16 * b);      // (K % 4 == 0: the four k's are all inside the row)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) wreg[b][s] = v[s];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) wreg[b][s] = wrow[16 * b + s];
-                }
-            }
-        }
-        __syncthreads();
-        // all four strips back to back (four independent accumulators keep the MFMA pipe busy); the products then take the
-        // place of the aggregate rows, which are dead once every wave is through
-        f4 acc[kFusedRows / 16];
-        if (has_unit) {
-#pragma unroll
-            for (int strip = 0; strip < kFusedRows / 16; ++strip) acc[strip] = f4{0.f, 0.f, 0.f, 0.f};
+        if (p.dbg == 1) { __syncthreads(); continue; }
+        // The 16 x K weight tile of a unit (70 KB for all units together: L2 resident) is fetched per iteration, AFTER the sweep
+        // (kept in registers across the sweep it pushed every configuration past 128 VGPRs) and, for the first unit, BEFORE the
+        // barrier, so that its latency overlaps the other waves' last rows.
+        auto load_w = [&](float (&wreg)[kFusedKB][4], int j) {
 #pragma unroll
             for (int b = 0; b < kFusedKB; ++b) {
-                if (16 * b < K) {
-                    f4 xv[kFusedRows / 16];
 #pragma unroll
-                    for (int strip = 0; strip < kFusedRows / 16; ++strip)
-                        xv[strip] = *reinterpret_cast<const f4*>(AX + (strip * 16 + i16) * TK + t_u * K + 4 * g + 16 * b);
+                for (int s2 = 0; s2 < 4; ++s2) wreg[b][s2] = 0.f;
+                if (w_live[j] && 16 * b + 4 * g < K) {
+                    if (w16) {
+                        const f4 v = *reinterpret_cast<const f4*>(wrow[j] + 16 * b);      // (K % 4 == 0: the four k's are all inside the row)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const bool live = 16 * b + 4 * g + s < K;      // (past K: another row's data, and 0 * inf is not 0)
+                        for (int s2 = 0; s2 < 4; ++s2) wreg[b][s2] = v[s2];
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) wreg[b][s2] = wrow[j][16 * b + s2];
+                    }
+                }
+            }
+        };
+        float wreg0[kFusedKB][4];
+        load_w(wreg0, 0);
+        __syncthreads();
+        // all strips back to back (independent accumulators keep the MFMA pipe busy); the products then take the place of the
+        // aggregate rows, which are dead once every wave is through
+        f4 acc[kFusedUnits][kFusedRows / 16];
+#pragma unroll
+        for (int j = 0; j < kFusedUnits; ++j) {
+            float wreg[kFusedKB][4];
+            if (j == 0) {
+#pragma unroll
+                for (int b = 0; b < kFusedKB; ++b)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) wreg[b][s2] = wreg0[b][s2];
+            } else {
+                load_w(wreg, j);
+            }
+#pragma unroll
+            for (int strip = 0; strip < kFusedRows / 16; ++strip) acc[j][strip] = f4{0.f, 0.f, 0.f, 0.f};
+            if (has_unit[j]) {
+#pragma unroll
+                for (int b = 0; b < kFusedKB; ++b) {
+                    if (16 * b < K) {
+                        f4 xv[kFusedRows / 16];
 #pragma unroll
                         for (int strip = 0; strip < kFusedRows / 16; ++strip)
-                            acc[strip] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b][s], live ? xv[strip][s] : 0.f, acc[strip], 0, 0, 0);
+                            xv[strip] = *reinterpret_cast<const f4*>(AX + (strip * 16 + i16) * TK + t_u[j] * K + 4 * g + 16 * b);
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) {
+                            const bool live = 16 * b + 4 * g + s2 < K;      // (past K: another row's data, and 0 * inf is not 0)
+#pragma unroll
+                            for (int strip = 0; strip < kFusedRows / 16; ++strip)
+                                acc[j][strip] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b][s2], live ? xv[strip][s2] : 0.f, acc[j][strip], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
         __syncthreads();                                  // AX is dead: Z (64 rows) goes over it
-        if (has_unit) {
 #pragma unroll
-            for (int strip = 0; strip < kFusedRows / 16; ++strip)      // lane (m = i16, g) holds z[m][16 q + 4 g .. + 3]
-                *reinterpret_cast<f4*>(AX + (strip * 16 + i16) * ZW + t_u * NQ * 16 + 16 * q_u + 4 * g) = acc[strip];
+        for (int j = 0; j < kFusedUnits; ++j) {
+            if (has_unit[j]) {
+#pragma unroll
+                for (int strip = 0; strip < kFusedRows / 16; ++strip)      // lane (m = i16, g) holds z[m][16 q + 4 g .. + 3]
+                    *reinterpret_cast<f4*>(AX + (strip * 16 + i16) * ZW + t_u[j] * NQ * 16 + 16 * q_u[j] + 4 * g) = acc[j][strip];
+            }
         }
         __syncthreads();
         // y[m][t*fo + o] = rs * (cb + sum_s sc_s * z[s*fo + o]): a thread per (row, tower, output pair)
