@@ -576,9 +576,10 @@ def main():
     ap.add_argument("--percentiles", action="store_true", help="per-launch p10/p50/p90 of the aggregation calls (SURVEY 8(d) protocol)")
     ap.add_argument("--hipgraph", action="store_true",
                     help="layer workloads, 1 GPU: capture the step (edge weights + forward + backward) in a HIP graph and replay it")
-    ap.add_argument("--gemm-tuning", default="file", choices=["off", "file", "tune"],
-                    help="PyTorch TunableOp for the dense pre/post-aggregation GEMMs (rocBLAS/hipBLASLt solution choice): "
-                         "'file' replays dgn_amd/tunableop_gfx950.csv without tuning, 'tune' tunes and rewrites it")
+    ap.add_argument("--gemm-tuning", default="off", choices=["off", "file", "tune"],
+                    help="PyTorch TunableOp for whatever library GEMMs remain (small batches below the kernels' row thresholds): 'off' "
+                         "(default: every Linear of the benched layers runs on this library's own kernels), 'file' replays "
+                         "dgn_amd/tunableop_gfx950.csv, 'tune' tunes and rewrites it")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
     args = ap.parse_args()
     if args.scaling is None:

@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -25,6 +25,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
            "dgn_layer_fused_supported", "dgn_layer_fused_forward",
+           "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
            "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_windows",
            "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
@@ -173,6 +174,16 @@ def load() -> C.CDLL:
         lib.dgn_linear_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
+        lib.dgn_gemm_supported.restype = C.c_int
+        lib.dgn_gemm_supported.argtypes = [C.c_int32, C.c_int32]
+        lib.dgn_gemm_forward.restype = C.c_int
+        lib.dgn_gemm_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dgn_gemm_wgrad_workspace_bytes.restype = C.c_size_t
+        lib.dgn_gemm_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        lib.dgn_gemm_wgrad.restype = C.c_int
+        lib.dgn_gemm_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_supported.restype = C.c_int
         lib.dgn_layer_fused_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_layer_fused_forward.restype = C.c_int

@@ -1,0 +1,128 @@
+// Host side of the wide tall-skinny GEMMs (include/dgn_hip.h: dgn_gemm_*), kernels in dgn_gemm_kernels.hpp.
+#include "dgn_gemm_kernels.hpp"
+
+#include <algorithm>
+
+namespace dgn {
+namespace gemm {
+namespace {
+
+int n_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+template <int NT>
+hipError_t launch_gemm_nt(const GemmParams& p, dim3 grid, hipStream_t st, int wkn) {
+    if (wkn) hipLaunchKernelGGL((ts_gemm<NT, 1>), grid, dim3(kWave * kWaves), 0, st, p);
+    else hipLaunchKernelGGL((ts_gemm<NT, 0>), grid, dim3(kWave * kWaves), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(int nt, const GemmParams& p, dim3 grid, hipStream_t st, int wkn) {
+    switch (nt) {
+#define DGN_CASE(N) case N: return launch_gemm_nt<N>(p, grid, st, wkn);
+        DGN_CASE(1) DGN_CASE(2) DGN_CASE(3) DGN_CASE(4) DGN_CASE(5) DGN_CASE(6) DGN_CASE(7) DGN_CASE(8)
+        DGN_CASE(9) DGN_CASE(10) DGN_CASE(11) DGN_CASE(12) DGN_CASE(13) DGN_CASE(14) DGN_CASE(15) DGN_CASE(16)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int KT>
+hipError_t launch_wgrad_kt(const WgradParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_gemm_wgrad<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ts_gemm_wgrad<KT>), grid, dim3(kWave * kWgWaves), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad(int kt, const WgradParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (kt) {
+#define DGN_CASE(K) case K: return launch_wgrad_kt<K>(p, grid, lds, st);
+        DGN_CASE(1) DGN_CASE(2) DGN_CASE(3) DGN_CASE(4) DGN_CASE(5) DGN_CASE(6) DGN_CASE(7) DGN_CASE(8) DGN_CASE(9) DGN_CASE(10) DGN_CASE(11)
+        DGN_CASE(12) DGN_CASE(13) DGN_CASE(14) DGN_CASE(15) DGN_CASE(16) DGN_CASE(17) DGN_CASE(18) DGN_CASE(19) DGN_CASE(20) DGN_CASE(21) DGN_CASE(22)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+struct WgPlan { int k_slices, k_slice, kt, nt, slots; size_t lds; };
+WgPlan wgrad_plan(int64_t M, int k, int n) {
+    WgPlan w{};
+    w.nt = (n + 15) / 16;
+    w.k_slices = (k + 16 * kMaxKT - 1) / (16 * kMaxKT);
+    const int per = (k + w.k_slices - 1) / w.k_slices;
+    w.kt = (per + 15) / 16;
+    w.k_slice = w.kt * 16;
+    w.k_slices = (k + w.k_slice - 1) / w.k_slice;
+    const int64_t n_strips = (M + 15) / 16;
+    w.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus(), n_strips));
+    w.lds = (size_t)2 * 16 * ((w.nt * 16 + 4) + (w.kt * 16 + 4)) * sizeof(float);
+    return w;
+}
+
+}  // namespace
+}  // namespace gemm
+}  // namespace dgn
+
+using namespace dgn;
+using namespace dgn::gemm;
+
+extern "C" int dgn_gemm_supported(int32_t k, int32_t n) { return k >= 1 && n >= 1 && k <= 4096 && n <= 4096; }
+
+extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
+                                int32_t w_is_kn, const float* bias, float* c, int64_t ldc, void* stream) {
+    const char* fn = "dgn_gemm_forward";
+    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 1..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
+    if (n_rows == 0) return DGN_OK;
+    if (!a || !w || !c || lda < k || ldc < n || ldw < (w_is_kn ? n : k)) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
+    GemmParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.bias = bias; p.C = c; p.ldc = ldc;
+    const int slices = (n + 16 * kMaxNT - 1) / (16 * kMaxNT);
+    const int nt = ((n + slices - 1) / slices + 15) / 16;
+    p.n_slice = nt * 16;
+    const int gy = (n + p.n_slice - 1) / p.n_slice;
+    const int64_t n_blocks = (n_rows + 16 * kWaves - 1) / (16 * kWaves);
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(n_blocks, (int64_t)n_cus() * 2 / gy + 1));
+    DGN_HIP_CHECK(launch_gemm(nt, p, dim3(gx, gy), static_cast<hipStream_t>(stream), w_is_kn));
+    return DGN_OK;
+}
+
+extern "C" size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n) {
+    if (n_rows <= 0 || !dgn_gemm_supported(k, n) || n > 16 * kWgWaves) return 0;
+    const WgPlan w = wgrad_plan(n_rows, k, n);
+    return (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float);
+}
+
+extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw,
+                              int64_t lddw, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "dgn_gemm_wgrad";
+    if (n_rows < 0 || !dgn_gemm_supported(k, n) || n > 16 * kWgWaves) { set_error("%s: need n <= %d (k=%d n=%d)", fn, 16 * kWgWaves, k, n); return DGN_ERR_INVALID; }
+    if (!dw || lddw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_rows == 0) { DGN_HIP_CHECK(hipMemset2DAsync(dw, lddw * 4, 0, (size_t)k * 4, (size_t)n, st)); return DGN_OK; }
+    if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
+    const WgPlan w = wgrad_plan(n_rows, k, n);
+    const size_t need = dgn_gemm_wgrad_workspace_bytes(n_rows, k, n);
+    if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
+    WgradParams p{};
+    p.M = n_rows; p.n = n; p.k = k; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
+    p.k_slice = w.k_slice; p.slots = w.slots;
+    DGN_HIP_CHECK(launch_wgrad(w.kt, p, dim3(w.slots, w.k_slices), w.lds, st));
+    const int64_t total = (int64_t)n * k;
+    hipLaunchKernelGGL(ts_gemm_wgrad_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, k, w.k_slice, w.slots, w.nt * 16,
+                       w.kt * 16, p.part, dw, lddw);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}

@@ -1,0 +1,249 @@
+// Wide tall-skinny fp32 GEMMs for the layers whose post-aggregation Linear does not fit dgn_linear_kernels.hpp's "whole weight
+// matrix in LDS" scheme: the simple / complex layers' posttrans (reference nets/dgn_layer.py:148,187-190 and :69,116-119 via
+// nets/layers.py:101-112): A [M, k] with M = number of nodes (1e4 .. 1e6), k = aggregators x features = 152 .. 420 after scaler
+// folding, n = scalers x f_out = 65 .. 225 (and the transposed shapes of the input gradient).  The library GEMM the round-1 layers
+// called for these runs at 40-45 TFLOP/s on such shapes and only with a shape-keyed TunableOp selection (a training run with
+// varying node counts never hits it); these kernels are shape independent.
+//   ts_gemm<NT, WKN>     C[M, n-slice] = A . W^T (+ bias)  (WKN: W given as [k, n]: the input gradient)
+//                        512 threads = 8 waves x 16 rows; each wave keeps its 16 x (NT*16) output tile in NT accumulators and walks k
+//                        in 16-wide chunks: A straight from memory in the MFMA lane layout (16 bytes per lane, unaligned-safe), the
+//                        W chunk staged in LDS by the whole workgroup, double buffered.  Exact fp32: v_mfma_f32_16x16x4_f32.
+//   ts_gemm_wgrad<KT>    dW[n, k-slice] = G^T . X over the rows: 16 waves, wave a owns n-tile a and KT k-tiles; 16-row strips of
+//                        G and X staged in LDS (double buffered), per-workgroup partials, fixed-order finalize (bitwise reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dgn_common.hpp"
+
+namespace dgn {
+namespace gemm {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte vector at 4-byte alignment (odd row strides)
+
+constexpr int kWaves = 8;            // ts_gemm: rows per workgroup pass = 16 * kWaves
+constexpr int kKS = 20;              // LDS row stride of a 16-k weight chunk (floats): 80 bytes, spreads the rows over the banks
+constexpr int kMaxNT = 16;           // n-slice of at most 256 columns per workgroup column (128: measured 5-15 % slower)
+
+struct GemmParams {
+    int64_t M;
+    int k, n;                        // full reduction width, full output width
+    const float* A; int64_t lda;
+    const float* W; int64_t ldw;     // WKN == 0: [n, k];  WKN == 1: [k, n]
+    const float* bias;               // [n] or NULL
+    float* C; int64_t ldc;
+    int n_slice;                     // columns per blockIdx.y (a multiple of 16)
+};
+
+template <int NT, int WKN>
+__global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
+    __shared__ float Wc[2][NT * 16 * kKS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * p.n_slice;                    // first output column of this workgroup column
+    const int n_here = min(NT * 16, p.n - n0);
+    const int KB = (p.k + 15) >> 4;
+    const int64_t n_blocks = (p.M + 16 * kWaves - 1) / (16 * kWaves);
+
+    // stage chunk kc of the weights into Wc[buf]: element (r, c) = W(n0 + r, 16 kc + c), zero outside
+    auto stage = [&](int kc, int buf) {
+        float* dst = Wc[buf];
+        const int k0 = 16 * kc;
+        if (WKN == 0) {
+            for (int it = tid; it < NT * 16 * 4; it += blockDim.x) {
+                const int r = it >> 2, c4 = (it & 3) * 4;
+                f4 v = f4{0.f, 0.f, 0.f, 0.f};
+                if (r < n_here) {
+                    const float* src = p.W + (int64_t)(n0 + r) * p.ldw + k0 + c4;
+                    if (k0 + c4 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (k0 + c4 + j < p.k) v[j] = src[j];
+                    }
+                }
+                *reinterpret_cast<f4*>(dst + r * kKS + c4) = v;
+            }
+        } else {
+            for (int it = tid; it < 16 * NT * 4; it += blockDim.x) {
+                const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
+                f4 v = f4{0.f, 0.f, 0.f, 0.f};
+                if (k0 + c < p.k && r4 < n_here) {
+                    const float* src = p.W + (int64_t)(k0 + c) * p.ldw + n0 + r4;
+                    if (r4 + 3 < n_here) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (r4 + j < n_here) v[j] = src[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(r4 + j) * kKS + c] = v[j];
+            }
+        }
+    };
+    // this lane's four A values of chunk kc: A[row][16 kc + 4 g .. + 3]
+    auto load_a = [&](const float* arow, int kc) {
+        const int k0 = 16 * kc + 4 * g;
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(arow + k0);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k0 + j < p.k) v[j] = arow[k0 + j];
+        }
+        return v;
+    };
+
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t row = blk * (16 * kWaves) + wave * 16 + i16;
+        const float* arow = p.A + min(row, p.M - 1) * p.lda;
+        f4 acc[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * q + 4 * g + r;
+                acc[q][r] = (p.bias && col < n_here) ? p.bias[n0 + col] : 0.f;
+            }
+        }
+        __syncthreads();                                       // (the previous row block is done with both buffers)
+        stage(0, 0);
+        f4 xv = load_a(arow, 0);
+        __syncthreads();
+        for (int kc = 0; kc < KB; ++kc) {
+            const f4 xn = kc + 1 < KB ? load_a(arow, kc + 1) : f4{0.f, 0.f, 0.f, 0.f};      // next chunk's A in flight during the MFMAs
+            if (kc + 1 < KB) stage(kc + 1, (kc + 1) & 1);
+            const float* wl = Wc[kc & 1] + i16 * kKS + 4 * g;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const f4 wv = *reinterpret_cast<const f4*>(wl + 16 * q * kKS);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[q], 0, 0, 0);
+            }
+            xv = xn;
+            __syncthreads();                                   // chunk kc+1 is staged; everyone is done reading chunk kc
+        }
+        if (row < p.M) {
+            float* crow = p.C + row * p.ldc + n0;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int col = 16 * q + 4 * g;
+                if (col + 3 < n_here) *reinterpret_cast<f4u*>(crow + col) = acc[q];
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (col + r < n_here) crow[col + r] = acc[q][r];
+                }
+            }
+        }
+    }
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------------------------------
+constexpr int kWgWaves = 16;
+constexpr int kMaxKT = 22;           // k-tiles one wave accumulates (88 registers): k-slice of at most 352 columns
+
+struct WgradParams {
+    int64_t M;
+    int n, k;                        // n <= 16 * kWgWaves
+    const float* G; int64_t ldg;     // [M, n]
+    const float* X; int64_t ldx;     // [M, k]
+    float* part;                     // [k-slices][slots][NT*16][KT*16] per-workgroup partials
+    int k_slice;                     // columns of X per blockIdx.y (a multiple of 16, <= 16 * kMaxKT)
+    int slots;
+};
+
+template <int KT>
+__global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradParams p) {
+    extern __shared__ float lds_g[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int NTn = (p.n + 15) >> 4;
+    const int k0 = blockIdx.y * p.k_slice, k_here = min(KT * 16, p.k - k0);
+    const int gs = NTn * 16 + 4, xs = KT * 16 + 4;              // LDS row strides (== 4 mod 8... spreads the rows over the banks)
+    const int half = 16 * (gs + xs);                              // floats of one (G strip, X strip) buffer
+    auto Gbuf = [&](int b) { return lds_g + b * half; };         // (pointer arithmetic, not a pointer table: a dynamically indexed
+    auto Xbuf = [&](int b) { return lds_g + b * half + 16 * gs; };   //  array of pointers would live in scratch memory)
+    const int64_t n_strips = (p.M + 15) / 16;
+    // a 16-row strip of G (all n columns) and of X (this k slice) -> LDS, zero beyond the matrices
+    auto stage = [&](int64_t strip, int buf) {
+        const int64_t r0 = strip * 16;
+        const int gq = NTn * 4, xq = KT * 4;                     // float4's per staged row
+        for (int it = tid; it < 16 * (gq + xq); it += blockDim.x) {
+            const int r = it / (gq + xq), c = it - r * (gq + xq);
+            const int64_t row = r0 + r;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (c < gq) {
+                const int col = 4 * c;
+                if (row < p.M && col < p.n) {
+                    const float* src = p.G + row * p.ldg + col;
+                    if (col + 3 < p.n) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < p.n) v[j] = src[j];
+                    }
+                }
+                *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + col) = v;
+            } else {
+                const int col = 4 * (c - gq);
+                if (row < p.M && col < k_here) {
+                    const float* src = p.X + row * p.ldx + k0 + col;
+                    if (col + 3 < k_here) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < k_here) v[j] = src[j];
+                    }
+                }
+                *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + col) = v;
+            }
+        }
+    };
+    f4 acc[KT];
+#pragma unroll
+    for (int b = 0; b < KT; ++b) acc[b] = f4{0.f, 0.f, 0.f, 0.f};
+    const bool has_tile = wave < NTn;
+    int64_t strip = blockIdx.x;
+    int buf = 0;
+    if (strip < n_strips) stage(strip, 0);
+    __syncthreads();
+    for (; strip < n_strips; strip += gridDim.x, buf ^= 1) {
+        if (strip + gridDim.x < n_strips) stage(strip + gridDim.x, buf ^ 1);
+        if (has_tile) {
+            // D[n][k] += G[m][n] X[m][k], the strip's rows are the reduction index: m = 4 s + g in the s-th instruction
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float gv = Gbuf(buf)[(4 * s + g) * gs + 16 * wave + i16];
+                const float* xr = Xbuf(buf) + (4 * s + g) * xs + i16;
+#pragma unroll
+                for (int b = 0; b < KT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, xr[16 * b], acc[b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // lane holds D[n = 16 wave + 4 g + r][k = 16 b + i16]
+    if (has_tile) {
+        float* out = p.part + ((int64_t)blockIdx.y * p.slots + blockIdx.x) * (NTn * 16) * (KT * 16);
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * wave + 4 * g + r) * (KT * 16) + 16 * b + i16] = acc[b][r];
+    }
+}
+
+// dW[n][k] = sum over the workgroup slots, in slot order (bitwise reproducible); thread per element, 4 slots in flight
+static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int k, int k_slice, int slots, int npad, int kpad,
+                                                                      const float* __restrict__ part, float* __restrict__ dW, int64_t lddw) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n * k) return;
+    const int r = (int)(e / k), c = (int)(e - (int64_t)r * k);
+    const int sl = c / k_slice, cc = c - sl * k_slice;
+    const float* src = part + (int64_t)sl * slots * npad * kpad + (int64_t)r * kpad + cc;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = 0;
+    for (; q + 3 < slots; q += 4) {
+        s0 += src[(int64_t)q * npad * kpad];
+        s1 += src[(int64_t)(q + 1) * npad * kpad];
+        s2 += src[(int64_t)(q + 2) * npad * kpad];
+        s3 += src[(int64_t)(q + 3) * npad * kpad];
+    }
+    for (; q < slots; ++q) s0 += src[(int64_t)q * npad * kpad];
+    dW[(int64_t)r * lddw + c] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace gemm
+}  // namespace dgn

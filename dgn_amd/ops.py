@@ -611,11 +611,74 @@ def node_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
                 and linear_supported(x.shape[-1], weight.shape[-2]))
 
 
+class _WideLinear(torch.autograd.Function):
+    """``F.linear(x, w, b)`` on the wide GEMM kernels (dgn_gemm_*): forward, input gradient and weight gradient each one kernel
+    family of this library (no library GEMM, no shape-keyed tuning)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.DgnError("wide_linear: CUDA tensors only (dgn_amd has no CPU path)")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        w = w.contiguous()
+        M, k = x.shape
+        n = w.shape[0]
+        c = torch.empty((M, n), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = lib.dgn_gemm_forward(M, k, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), 0, _ptr(bias.contiguous() if bias is not None else None),
+                                  c.data_ptr(), n, stream)
+        _lib.check(rc, "dgn_gemm_forward")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        M, k = x.shape
+        n = w.shape[0]
+        g = g.contiguous()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty((M, k), dtype=torch.float32, device=x.device)
+            wt = w.t().contiguous()          # [k, n] as the "weight" of g_x = g . wt^T: the row-major staging path (5-10 % faster than w_is_kn)
+            _lib.check(lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, wt.data_ptr(), n, 0, None, g_x.data_ptr(), k, stream), "dgn_gemm_forward (input gradient)")
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty((n, k), dtype=torch.float32, device=x.device)
+            nbytes = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), x.stride(0), g_w.data_ptr(), k, ws.data_ptr(), nbytes, stream), "dgn_gemm_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = g.sum(dim=0)
+        return g_x, g_w, g_b
+
+
+# Wide products (k or n beyond the streaming kernels' 160 columns, or odd widths) go to the dgn_gemm_* kernels from this many rows on.
+WIDE_MIN_ROWS = int(os.environ.get("DGN_WIDE_MIN_ROWS", "4096"))
+
+
+def wide_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return bool(x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and weight.dim() == 2
+                and x.shape[0] >= WIDE_MIN_ROWS and weight.shape[0] <= 256 and os.environ.get("DGN_LIBRARY_GEMM") != "1"
+                and x.shape[1] <= 4096)
+
+
+def wide_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _WideLinear.apply(x, weight, bias)
+
+
 def node_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` / batched ``bmm(x, weight^T)`` of the layers' node-count-tall operands: the streaming kernels where
-    they apply, the library GEMM otherwise (wide simple-layer posttrans, CPU glue in the tests)."""
+    they apply (even widths up to 160), the wide GEMM kernels for the simple / complex layers' posttrans shapes, the library
+    GEMM only for small batches and CPU glue in the tests."""
     if node_linear_supported(x, weight):
         return linear(x, weight, bias)
+    if wide_linear_supported(x, weight):
+        return wide_linear(x, weight, bias)
     if x.dim() == 2:
         return torch.nn.functional.linear(x, weight, bias)
     y = torch.bmm(x, weight.transpose(1, 2))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 13
+#define DGN_ABI_VERSION 14
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -323,6 +323,21 @@ size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, in
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
                      int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- wide tall-skinny fp32 GEMMs (dgn_gemm.hip) -----------------------------------------------------------------------
+ * The same nn.Linear (layers.py:101-112) for the widths the simple / complex layers' posttrans has after scaler folding
+ * (nets/dgn_layer.py:148,187-190 and :69,116-119): k = aggregators x features up to a few hundred, n = scalers x f_out, any
+ * parity (hidden 75 / 65), any row stride >= the row.  Exact fp32 MFMA, shape independent (no library solution selection).
+ *   dgn_gemm_forward   c = a . op(w) (+ bias)      a [n_rows, k], c [n_rows, n]; w_is_kn == 0: w [n, k] (forward),
+ *                                                   w_is_kn == 1: w [k, n] (input gradient: a = g_out, w = weight)
+ *   dgn_gemm_wgrad     dw [n, k] = g^T . x           g [n_rows, n], x [n_rows, k]; n <= 256; per-workgroup partials in ws
+ *                                                   (dgn_gemm_wgrad_workspace_bytes), fixed-order sum: bitwise reproducible */
+int dgn_gemm_supported(int32_t k, int32_t n);
+int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw, int32_t w_is_kn,
+                     const float* bias, float* c, int64_t ldc, void* stream);
+size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n);
+int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw,
+                   int64_t lddw, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the posttrans product inside the sweep (dgn_fused.hip) -----------------------------------------------------------
  * dgn_agg_forward + dgn_linear_combine_forward as ONE kernel: the aggregate rows ([T][A][F/T] per node: 1 680 bytes on the

@@ -112,3 +112,62 @@ def test_linear_combine_bn_tail_equals_the_unfused_nodes(T, N, k, S, fo, with_sc
         # (the bias feeds a BatchNorm: its exact gradient is zero, both paths return rounding noise of the column sums)
         scale = float(ct.abs().sum(0).max()) if name == "g_bias" else float(r.abs().max()) + 1e-30
         assert float((x - r).abs().max()) <= 2e-5 * scale, (name, float((x - r).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("M,k,n", [(5000, 152, 225), (4097, 350, 210), (129, 198, 65), (1, 7, 3), (300, 420, 300), (2500, 75, 75), (640, 16, 16)])
+def test_wide_gemm_vs_fp64(M, k, n):
+    """dgn_gemm_* (the simple / complex layers' posttrans shapes: odd widths, k and n beyond the streaming kernels): forward with
+    bias, input gradient (both weight layouts), weight gradient against an fp64 evaluation; strided input rows; bitwise repeatability."""
+    import ctypes as C
+    from dgn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + k + n)
+    xbig = torch.randn(M, k + 3, device=dev, generator=gen)
+    x = xbig[:, 1:k + 1]                                        # row stride k + 3, 4-byte aligned rows
+    w = torch.randn(n, k, device=dev, generator=gen) / k ** 0.5
+    b = torch.randn(n, device=dev, generator=gen)
+    g = torch.randn(M, n, device=dev, generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    c = torch.full((M, n), float("nan"), device=dev)
+    _lib.check(lib.dgn_gemm_forward(M, k, n, x.data_ptr(), x.stride(0), w.data_ptr(), k, 0, b.data_ptr(), c.data_ptr(), n, st), "fwd")
+    ref = x.double() @ w.double().T + b.double()
+    tol = lambda r: 2e-6 * float(r.abs().max()) + 1e-6
+    assert float((c.double() - ref).abs().max()) <= tol(ref)
+    gx1 = torch.full((M, k), float("nan"), device=dev)
+    gx2 = torch.full((M, k), float("nan"), device=dev)
+    wt = w.t().contiguous()
+    _lib.check(lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, w.data_ptr(), k, 1, None, gx1.data_ptr(), k, st), "dgrad kn")
+    _lib.check(lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, wt.data_ptr(), n, 0, None, gx2.data_ptr(), k, st), "dgrad t")
+    rgx = g.double() @ w.double()
+    assert float((gx1.double() - rgx).abs().max()) <= tol(rgx) and float((gx2.double() - rgx).abs().max()) <= tol(rgx)
+    if n <= 256:
+        nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        outs = []
+        for _ in range(2):
+            gw = torch.full((n, k), float("nan"), device=dev)
+            _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), x.stride(0), gw.data_ptr(), k, ws.data_ptr(), nb, st), "wgrad")
+            outs.append(gw)
+        rgw = g.double().T @ x.double()
+        assert float((outs[0].double() - rgw).abs().max()) <= 2e-6 * float(rgw.abs().max()) * max(1.0, (M / 4096) ** 0.5) + 1e-6
+        assert torch.equal(outs[0], outs[1])                    # fixed summation order
+    else:
+        assert lib.dgn_gemm_wgrad_workspace_bytes(M, k, n) == 0
+
+
+def test_wide_linear_autograd_matches_library(monkeypatch):
+    from dgn_amd import ops
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    M, k, n = 6000, 152, 225
+    x0, w0, b0 = torch.randn(M, k, device=dev, generator=gen), torch.randn(n, k, device=dev, generator=gen) / 12, torch.randn(n, device=dev, generator=gen)
+    ct = torch.randn(M, n, device=dev, generator=gen)
+    res = []
+    for f in (ops.node_linear, torch.nn.functional.linear):
+        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+        assert f is not ops.node_linear or ops.wide_linear_supported(x, w)
+        y = f(x, w, b)
+        res.append((y, *torch.autograd.grad(y, [x, w, b], ct)))
+    for a, r in zip(*res):
+        torch.testing.assert_close(a, r, rtol=2e-5, atol=2e-5 * float(r.abs().max()))
