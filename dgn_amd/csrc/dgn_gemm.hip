@@ -51,7 +51,7 @@ hipError_t launch_wgrad(int kt, const WgradParams& p, dim3 grid, size_t lds, hip
     switch (kt) {
 #define DGN_CASE(K) case K: return launch_wgrad_kt<K>(p, grid, lds, st);
         DGN_CASE(1) DGN_CASE(2) DGN_CASE(3) DGN_CASE(4) DGN_CASE(5) DGN_CASE(6) DGN_CASE(7) DGN_CASE(8) DGN_CASE(9) DGN_CASE(10) DGN_CASE(11)
-        DGN_CASE(12) DGN_CASE(13) DGN_CASE(14) DGN_CASE(15) DGN_CASE(16) DGN_CASE(17) DGN_CASE(18) DGN_CASE(19) DGN_CASE(20) DGN_CASE(21) DGN_CASE(22)
+        DGN_CASE(12) DGN_CASE(13) DGN_CASE(14) DGN_CASE(15) DGN_CASE(16)
 #undef DGN_CASE
     }
     return hipErrorInvalidValue;

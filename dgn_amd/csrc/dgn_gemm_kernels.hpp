@@ -44,38 +44,56 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
     const int KB = (p.k + 15) >> 4;
     const int64_t n_blocks = (p.M + 16 * kWaves - 1) / (16 * kWaves);
 
-    // stage chunk kc of the weights into Wc[buf]: element (r, c) = W(n0 + r, 16 kc + c), zero outside
-    auto stage = [&](int kc, int buf) {
-        float* dst = Wc[buf];
+    // chunk kc of the weights, element (r, c) = W(n0 + r, 16 kc + c), zero outside: FETCHED into registers (global -> VGPR, issued
+    // before the chunk's MFMAs) and COMMITTED to Wc[buf] after them -- a load consumed by its LDS store right away would make the
+    // wave sit out the L2 latency in front of every chunk's MFMAs
+    constexpr int kItems = (NT * 16 * 4 + kWave * kWaves - 1) / (kWave * kWaves);      // float4's per thread and chunk
+    auto fetch = [&](f4 (&reg)[kItems], int kc) {
         const int k0 = 16 * kc;
-        if (WKN == 0) {
-            for (int it = tid; it < NT * 16 * 4; it += blockDim.x) {
-                const int r = it >> 2, c4 = (it & 3) * 4;
-                f4 v = f4{0.f, 0.f, 0.f, 0.f};
-                if (r < n_here) {
-                    const float* src = p.W + (int64_t)(n0 + r) * p.ldw + k0 + c4;
-                    if (k0 + c4 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
-                    else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (k0 + c4 + j < p.k) v[j] = src[j];
+        for (int j = 0; j < kItems; ++j) {
+            const int it = tid + j * kWave * kWaves;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (it < NT * 16 * 4) {
+                if (WKN == 0) {
+                    const int r = it >> 2, c4 = (it & 3) * 4;
+                    if (r < n_here) {
+                        const float* src = p.W + (int64_t)(n0 + r) * p.ldw + k0 + c4;
+                        if (k0 + c4 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (k0 + c4 + e < p.k) v[e] = src[e];
+                        }
+                    }
+                } else {
+                    const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
+                    if (k0 + c < p.k && r4 < n_here) {
+                        const float* src = p.W + (int64_t)(k0 + c) * p.ldw + n0 + r4;
+                        if (r4 + 3 < n_here) v = *reinterpret_cast<const f4u*>(src);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (r4 + e < n_here) v[e] = src[e];
+                        }
                     }
                 }
-                *reinterpret_cast<f4*>(dst + r * kKS + c4) = v;
             }
-        } else {
-            for (int it = tid; it < 16 * NT * 4; it += blockDim.x) {
-                const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
-                f4 v = f4{0.f, 0.f, 0.f, 0.f};
-                if (k0 + c < p.k && r4 < n_here) {
-                    const float* src = p.W + (int64_t)(k0 + c) * p.ldw + n0 + r4;
-                    if (r4 + 3 < n_here) v = *reinterpret_cast<const f4u*>(src);
-                    else {
+            reg[j] = v;
+        }
+    };
+    auto commit = [&](const f4 (&reg)[kItems], int buf) {
+        float* dst = Wc[buf];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (r4 + j < n_here) v[j] = src[j];
-                    }
+        for (int j = 0; j < kItems; ++j) {
+            const int it = tid + j * kWave * kWaves;
+            if (it < NT * 16 * 4) {
+                if (WKN == 0) {
+                    const int r = it >> 2, c4 = (it & 3) * 4;
+                    *reinterpret_cast<f4*>(dst + r * kKS + c4) = reg[j];
+                } else {
+                    const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[(r4 + e) * kKS + c] = reg[j][e];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dst[(r4 + j) * kKS + c] = v[j];
             }
         }
     };
@@ -104,12 +122,14 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
             }
         }
         __syncthreads();                                       // (the previous row block is done with both buffers)
-        stage(0, 0);
+        f4 wreg[kItems];
+        fetch(wreg, 0);
+        commit(wreg, 0);
         f4 xv = load_a(arow, 0);
         __syncthreads();
         for (int kc = 0; kc < KB; ++kc) {
-            const f4 xn = kc + 1 < KB ? load_a(arow, kc + 1) : f4{0.f, 0.f, 0.f, 0.f};      // next chunk's A in flight during the MFMAs
-            if (kc + 1 < KB) stage(kc + 1, (kc + 1) & 1);
+            const f4 xn = kc + 1 < KB ? load_a(arow, kc + 1) : f4{0.f, 0.f, 0.f, 0.f};      // next chunk's A and W in flight during the MFMAs
+            if (kc + 1 < KB) fetch(wreg, kc + 1);
             const float* wl = Wc[kc & 1] + i16 * kKS + 4 * g;
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
@@ -118,6 +138,7 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
                 for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[q], 0, 0, 0);
             }
             xv = xn;
+            if (kc + 1 < KB) commit(wreg, (kc + 1) & 1);
             __syncthreads();                                   // chunk kc+1 is staged; everyone is done reading chunk kc
         }
         if (row < p.M) {
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------------
 constexpr int kWgWaves = 16;
-constexpr int kMaxKT = 22;           // k-tiles one wave accumulates (88 registers): k-slice of at most 352 columns
+constexpr int kMaxKT = 16;           // k-tiles one wave accumulates (64 registers): k-slice of at most 256 columns
 
 struct WgradParams {
     int64_t M;
@@ -160,36 +181,52 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
     auto Gbuf = [&](int b) { return lds_g + b * half; };         // (pointer arithmetic, not a pointer table: a dynamically indexed
     auto Xbuf = [&](int b) { return lds_g + b * half + 16 * gs; };   //  array of pointers would live in scratch memory)
     const int64_t n_strips = (p.M + 15) / 16;
-    // a 16-row strip of G (all n columns) and of X (this k slice) -> LDS, zero beyond the matrices
-    auto stage = [&](int64_t strip, int buf) {
+    // a 16-row strip of G (all n columns) and of X (this k slice), zero beyond the matrices: fetched into registers before the
+    // current strip's MFMAs, committed to the other LDS buffer after them (see ts_gemm)
+    constexpr int kMaxItems = (16 * (kWgWaves * 4 + KT * 4) + kWave * kWgWaves - 1) / (kWave * kWgWaves);
+    const int gq = NTn * 4, xq = KT * 4;                         // float4's per staged row
+    auto fetch = [&](f4 (&reg)[kMaxItems], int64_t strip) {
         const int64_t r0 = strip * 16;
-        const int gq = NTn * 4, xq = KT * 4;                     // float4's per staged row
-        for (int it = tid; it < 16 * (gq + xq); it += blockDim.x) {
-            const int r = it / (gq + xq), c = it - r * (gq + xq);
-            const int64_t row = r0 + r;
+#pragma unroll
+        for (int j = 0; j < kMaxItems; ++j) {
+            const int it = tid + j * kWave * kWgWaves;
             f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (c < gq) {
-                const int col = 4 * c;
-                if (row < p.M && col < p.n) {
-                    const float* src = p.G + row * p.ldg + col;
-                    if (col + 3 < p.n) v = *reinterpret_cast<const f4u*>(src);
-                    else {
+            if (it < 16 * (gq + xq)) {
+                const int r = it / (gq + xq), c = it - r * (gq + xq);
+                const int64_t row = r0 + r;
+                if (c < gq) {
+                    const int col = 4 * c;
+                    if (row < p.M && col < p.n) {
+                        const float* src = p.G + row * p.ldg + col;
+                        if (col + 3 < p.n) v = *reinterpret_cast<const f4u*>(src);
+                        else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (col + j < p.n) v[j] = src[j];
+                            for (int e = 0; e < 4; ++e) if (col + e < p.n) v[e] = src[e];
+                        }
+                    }
+                } else {
+                    const int col = 4 * (c - gq);
+                    if (row < p.M && col < k_here) {
+                        const float* src = p.X + row * p.ldx + k0 + col;
+                        if (col + 3 < k_here) v = *reinterpret_cast<const f4u*>(src);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (col + e < k_here) v[e] = src[e];
+                        }
                     }
                 }
-                *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + col) = v;
-            } else {
-                const int col = 4 * (c - gq);
-                if (row < p.M && col < k_here) {
-                    const float* src = p.X + row * p.ldx + k0 + col;
-                    if (col + 3 < k_here) v = *reinterpret_cast<const f4u*>(src);
-                    else {
+            }
+            reg[j] = v;
+        }
+    };
+    auto commit = [&](const f4 (&reg)[kMaxItems], int buf) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (col + j < k_here) v[j] = src[j];
-                    }
-                }
-                *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + col) = v;
+        for (int j = 0; j < kMaxItems; ++j) {
+            const int it = tid + j * kWave * kWgWaves;
+            if (it < 16 * (gq + xq)) {
+                const int r = it / (gq + xq), c = it - r * (gq + xq);
+                if (c < gq) *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + 4 * c) = reg[j];
+                else *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + 4 * (c - gq)) = reg[j];
             }
         }
     };
@@ -199,10 +236,15 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
     const bool has_tile = wave < NTn;
     int64_t strip = blockIdx.x;
     int buf = 0;
-    if (strip < n_strips) stage(strip, 0);
+    f4 sreg[kMaxItems];
+    if (strip < n_strips) {
+        fetch(sreg, strip);
+        commit(sreg, 0);
+    }
     __syncthreads();
     for (; strip < n_strips; strip += gridDim.x, buf ^= 1) {
-        if (strip + gridDim.x < n_strips) stage(strip + gridDim.x, buf ^ 1);
+        const bool more = strip + gridDim.x < n_strips;
+        if (more) fetch(sreg, strip + gridDim.x);
         if (has_tile) {
             // D[n][k] += G[m][n] X[m][k], the strip's rows are the reduction index: m = 4 s + g in the s-th instruction
 #pragma unroll
@@ -213,6 +255,7 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
                 for (int b = 0; b < KT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, xr[16 * b], acc[b], 0, 0, 0);
             }
         }
+        if (more) commit(sreg, buf ^ 1);
         __syncthreads();
     }
     // lane holds D[n = 16 wave + 4 g + r][k = 16 b + i16]

@@ -198,7 +198,7 @@ def _posttrans_split(posttrans: MLP, h, agg, in_dim):
     """posttrans(cat([h, agg])) without building the concat when posttrans is one Linear."""
     if posttrans.is_single_affine():
         lin = posttrans.fully_connected[0].linear
-        return F.linear(agg, lin.weight[:, in_dim:]) + F.linear(h, lin.weight[:, :in_dim], lin.bias)
+        return node_linear(agg, lin.weight[:, in_dim:]) + node_linear(h, lin.weight[:, :in_dim], lin.bias)
     return posttrans(torch.cat([h, agg], dim=1))
 
 
@@ -252,7 +252,7 @@ class DGNLayerSimple(nn.Module):
                 return F.dropout(h, self.dropout, training=self.training)
             else:
                 agg = self.aggregate(graph, hp, None, eig)                                    # [N, A*Fp] (single scaler: not applied)
-                h = F.linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
+                h = node_linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
                 if self.graph_norm:
                     h = h * snorm_n
         else:
