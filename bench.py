@@ -528,6 +528,43 @@ def compact(result):
     return out
 
 
+def run_inference(args, dev, steps=20, warmup=5):
+    """Forward-only (no-grad, eval-mode) pass of the headline layer: the path on which sweep + posttrans + scale-combine run as ONE
+    kernel (layer_fwd_fused) and the [N, A*F] aggregate rows never reach memory; timed with that kernel and with the separate ones."""
+    from dgn_amd import ops
+    wl = dict(WORKLOADS["c2"])
+    batch, graph = build_batch(wl, 41, dev)
+    F_, N, E = wl["hidden"], graph.num_nodes, graph.num_edges
+    torch.manual_seed(0)
+    avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)}, "towers", True,
+                             towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev).eval()
+    h = torch.randn(N, F_, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    snorm = batch["snorm_n"].to(dev)
+    out = {}
+    saved = ops.FUSED_FORWARD
+    try:
+        for tag, flag in (("fused_kernel", True), ("separate_kernels", False)):
+            ops.FUSED_FORWARD = flag
+            with torch.no_grad():
+                def step():
+                    graph._wcache.clear()
+                    return layer(graph, h, None, snorm)
+                for _ in range(warmup):
+                    step()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) * 1e3 / steps
+            out[tag] = dict(ms_per_step=ms, value=E / (ms * 1e-3), unit="edges/s")
+    finally:
+        ops.FUSED_FORWARD = saved
+    out["config"] = "c2 layer, eval mode, torch.no_grad(): edge weights + forward only"
+    return out
+
+
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
@@ -550,6 +587,10 @@ def run_extras(args, dev):
         del wl
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()
+    try:
+        extra["c2_inference"] = run_inference(args, dev)
+    except Exception as exc:
+        extra["c2_inference"] = dict(error=f"{type(exc).__name__}: {exc}")
     return extra
 
 
