@@ -131,11 +131,19 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
             const f4 xn = kc + 1 < KB ? load_a(arow, kc + 1) : f4{0.f, 0.f, 0.f, 0.f};      // next chunk's A and W in flight during the MFMAs
             if (kc + 1 < KB) fetch(wreg, kc + 1);
             const float* wl = Wc[kc & 1] + i16 * kKS + 4 * g;
+            // groups of four n-tiles, s outer: consecutive MFMAs go to different accumulators (back-to-back MFMAs on one accumulator
+            // wait for each other), and only four weight operands are live at a time
 #pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                const f4 wv = *reinterpret_cast<const f4*>(wl + 16 * q * kKS);
+            for (int q0 = 0; q0 < NT; q0 += 4) {
+                f4 wv[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[q], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    if (q0 + j < NT) wv[j] = *reinterpret_cast<const f4*>(wl + 16 * (q0 + j) * kKS);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q0 + j < NT) acc[q0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][s], xv[s], acc[q0 + j], 0, 0, 0);
             }
             xv = xn;
             if (kc + 1 < KB) commit(wreg, (kc + 1) & 1);
