@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -27,7 +27,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_layer_fused_supported", "dgn_layer_fused_forward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
            "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_windows",
-           "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
+           "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
 
@@ -199,6 +199,8 @@ def load() -> C.CDLL:
         lib.dgn_graph_build_windows.restype = C.c_int
         lib.dgn_graph_build_windows.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + \
                                               [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_assemble_params.restype = C.c_int
+        lib.dgn_assemble_params.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dgn_towers_layer_supported.restype = C.c_int
         lib.dgn_towers_layer_supported.argtypes = [C.c_int32] * 5
         for name in ("dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_backward_workspace_bytes"):

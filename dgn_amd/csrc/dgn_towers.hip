@@ -37,6 +37,16 @@ __global__ __launch_bounds__(256) void add3_tail(int64_t first, int64_t n, const
     out[i] = a[i] + b[i] + (res ? res[i] : 0.f);
 }
 
+// fused operand buffer of the layer from its per-tower parameters: element i comes from parameter map_param[i] at offset map_off[i]
+// (or is zero: the off-diagonal blocks of the block-diagonal P|Q weights, the h columns of the non-identity scaler blocks)
+__global__ __launch_bounds__(256) void assemble_params(int64_t n, const int64_t* __restrict__ ptrs, const int32_t* __restrict__ map_param,
+                                                       const int32_t* __restrict__ map_off, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int q = map_param[i];
+    out[i] = q < 0 ? 0.f : reinterpret_cast<const float*>(ptrs[q])[map_off[i]];
+}
+
 struct Dims {
     int64_t N;
     int T, fi, fo, S, Fm, Fo, K;
@@ -210,6 +220,16 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     } else {
         hipLaunchKernelGGL(add3_tail, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int64_t)0, n, res, g_in, g_hpq, G->g_h);
     }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" int dgn_assemble_params(int64_t n_out, const int64_t* param_ptrs, const int32_t* map_param, const int32_t* map_off, float* out,
+                                   void* stream) {
+    if (n_out < 0 || (n_out > 0 && (!param_ptrs || !map_param || !map_off || !out))) { set_error("dgn_assemble_params: null argument"); return DGN_ERR_INVALID; }
+    if (n_out == 0) return DGN_OK;
+    hipLaunchKernelGGL(assemble_params, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n_out, param_ptrs,
+                       map_param, map_off, out);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

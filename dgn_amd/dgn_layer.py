@@ -493,10 +493,28 @@ class DGNLayerTower(nn.Module):
                 pos = torch.nonzero(flat_ids).flatten()
                 sel = (flat_ids[pos] - 1).long()
                 shapes = [tuple(id_ops[k].shape) for k in names]
-                cache[key] = (names, shapes, pos, sel, flat_ids.numel(), [math.prod(shp) for shp in shapes])
-        names, shapes, pos, sel, total, sizes = cache[key]
-        flat = torch.cat([p.reshape(-1) for p in plist])
-        fused = flat.new_zeros(total).index_put((pos,), flat.index_select(0, sel))
+                native = None
+                n_flat = sum(sizes)
+                if dev.type == "cuda" and sel.numel() == n_flat and all(p.dtype == torch.float32 and p.is_contiguous() for p in plist):
+                    # every parameter element lands exactly once: the assembly is ONE gather kernel over a table of the
+                    # parameters' addresses (ops.assemble_operands), its backward one index_select
+                    starts = torch.zeros(len(sizes) + 1, dtype=torch.long, device=dev)
+                    starts[1:] = torch.cumsum(torch.tensor(sizes, device=dev), 0)
+                    gid = (flat_ids - 1).long()                                            # -1 where the operand is a structural zero
+                    which = torch.bucketize(gid.clamp(min=0), starts[1:], right=True)
+                    map_param = torch.where(gid >= 0, which, torch.full_like(which, -1)).int()
+                    map_off = torch.where(gid >= 0, gid - starts[which], torch.zeros_like(gid)).int()
+                    inv = torch.empty(n_flat, dtype=torch.long, device=dev)
+                    inv[sel] = pos
+                    native = dict(ptr_table=torch.zeros(len(plist), dtype=torch.int64, device=dev), ptr_host=None, map_param=map_param,
+                                  map_off=map_off, inv=inv, total=flat_ids.numel(), sizes=sizes, shapes=[tuple(p.shape) for p in plist])
+                cache[key] = (names, shapes, pos, sel, flat_ids.numel(), [math.prod(shp) for shp in shapes], native)
+        names, shapes, pos, sel, total, sizes, native = cache[key]
+        if native is not None and all(p.is_cuda and p.is_contiguous() for p in plist):
+            fused = _ops.assemble_operands(native, plist)
+        else:
+            flat = torch.cat([p.reshape(-1) for p in plist])
+            fused = flat.new_zeros(total).index_put((pos,), flat.index_select(0, sel))
         # (split, not slicing: its backward is ONE concatenation instead of a zero-fill + copy + add per operand)
         return {k: part.view(shp) for k, part, shp in zip(names, fused.split(sizes), shapes)}
 

@@ -976,3 +976,35 @@ def fused_sweep_posttrans_forward(graph: DGNGraph, plan: AggPlan, n_towers: int,
                                      _ptr(scale.contiguous() if scale is not None else None), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
     _lib.check(rc, "dgn_layer_fused_forward")
     return y
+
+
+class _AssembleOperands(torch.autograd.Function):
+    """The towers layer's fused operand buffer from its ~30 per-tower parameters in ONE launch (dgn_assemble_params), instead of
+    cat + index_select + zeros + index_put (and, backward, their four nodes plus a cat-backward of 30 slices): at batch 128 the
+    parameter plumbing was a third of the step's host time.  ``maps``: (ptr_table [P] int64 on the device + the host list it mirrors,
+    map_param, map_off [total] int32, inv [n_flat] int64, sizes, shapes) built once per layer."""
+
+    @staticmethod
+    def forward(ctx, maps, *params):
+        lib = _lib.load()
+        ptrs = [p.data_ptr() for p in params]
+        if ptrs != maps["ptr_host"]:                      # (parameters are updated in place: this changes on .to() / load only)
+            maps["ptr_table"].copy_(torch.tensor(ptrs, dtype=torch.int64), non_blocking=False)
+            maps["ptr_host"] = ptrs
+        dev = params[0].device
+        out = torch.empty(maps["total"], dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_assemble_params(maps["total"], maps["ptr_table"].data_ptr(), maps["map_param"].data_ptr(), maps["map_off"].data_ptr(),
+                                           out.data_ptr(), stream), "dgn_assemble_params")
+        ctx.maps = maps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        maps = ctx.maps
+        g_flat = g.contiguous().index_select(0, maps["inv"])
+        return (None,) + tuple(part.view(shp) for part, shp in zip(g_flat.split(maps["sizes"]), maps["shapes"]))
+
+
+def assemble_operands(maps, params) -> torch.Tensor:
+    return _AssembleOperands.apply(maps, *params)

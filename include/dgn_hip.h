@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 14
+#define DGN_ABI_VERSION 15
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -418,6 +418,10 @@ typedef struct DgnTowersGrads {
     float* g_h;                /* [N, T*f_in]   written                                                     */
     float* g_w_sd; float* g_bias_sd; float* g_w_post; float* g_b_post; float* g_gamma; float* g_beta; float* g_w_mix; float* g_b_mix;
 } DgnTowersGrads;
+/* The fused operand buffer from the per-tower parameters (the reference's state_dict layout, nets/dgn_layer.py:205-276 x towers) in ONE
+ * launch: out[i] = ((const float*)param_ptrs[map_param[i]])[map_off[i]], or 0 where map_param[i] < 0.  param_ptrs is a DEVICE array of
+ * device addresses (int64), the maps are device int32 arrays built once per layer (dgn_amd/dgn_layer.py::_operands).          */
+int dgn_assemble_params(int64_t n_out, const int64_t* param_ptrs, const int32_t* map_param, const int32_t* map_off, float* out, void* stream);
 int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total);
 size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);
