@@ -568,7 +568,7 @@ def run_inference(args, dev, steps=20, warmup=5):
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2_b128", 20, 5), ("c5", 3, 1)]
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()
