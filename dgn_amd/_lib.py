@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -67,7 +67,7 @@ class DgnMsgGrad(C.Structure):
 
 class DgnBnGrad(C.Structure):
     _fields_ = [("g_out", C.c_void_p), ("y", C.c_void_p), ("ld", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("relu", C.c_int32)]
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("relu", C.c_int32), ("n_valid", C.c_void_p)]
 
 
 class DgnTowersLayer(C.Structure):
@@ -78,7 +78,7 @@ class DgnTowersLayer(C.Structure):
                 ("w_post", C.c_void_p), ("b_post", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
-                ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p)]
 
 
 class DgnTowersGrads(C.Structure):
@@ -140,11 +140,11 @@ def load() -> C.CDLL:
         lib.dgn_bn_tail_forward.restype = C.c_int
         lib.dgn_bn_tail_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_size_t, C.c_void_p]
+                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.dgn_bn_tail_backward.restype = C.c_int
         lib.dgn_bn_tail_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_size_t, C.c_void_p]
+                                             C.c_size_t, C.c_void_p, C.c_void_p]
         lib.dgn_bias_act_forward.restype = C.c_int
         lib.dgn_bias_act_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p]

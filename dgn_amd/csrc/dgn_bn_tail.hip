@@ -146,9 +146,11 @@ __device__ __forceinline__ void flat_loop(int64_t total, int F, Load&& load, Sto
 }
 
 // forward partials: sum x, sum x^2
+// (n_valid != NULL: only the first *n_valid rows are the batch -- the rest is padding of a fixed-capacity batch, DgnBnGrad.n_valid)
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const float* __restrict__ x, int64_t ld,
-                                                double* __restrict__ part) {
+                                                double* __restrict__ part, const int64_t* __restrict__ n_valid) {
+    if (n_valid) n_rows = min(n_rows, *n_valid);
     if constexpr (PAIRS) {
         column_partials_pairs(n_rows, F, part, [&](int64_t n, int c, float (&v0)[2], float (&v1)[2]) {
             const float2 v = *reinterpret_cast<const float2*>(x + n * ld + c);
@@ -167,7 +169,9 @@ __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const flo
 // mean / invstd per column, running statistics (unbiased variance, like torch)
 __global__ __launch_bounds__(256) void bn_finalize(int64_t n_rows, int F, int G, const double* __restrict__ part,
                                                    float* running_mean, float* running_var, float momentum, float eps,
-                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                   const int64_t* __restrict__ n_valid) {
+    if (n_valid) n_rows = min(n_rows, *n_valid);
     const int c = (int)blockIdx.x;
     double s0, s1;
     slot_sums(part, F, G, c, s0, s1);
@@ -206,7 +210,8 @@ template <bool PAIRS>
 __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
                                                     int64_t ld, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, const int64_t* __restrict__ n_valid) {
+    if (n_valid) n_rows = min(n_rows, *n_valid);
     auto one = [&](float xv, float g, int c, float& v0, float& v1) {
         const float xh = (xv - mean[c]) * invstd[c];
         if (relu && !(xh * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f) > 0.f)) g = 0.f;
@@ -240,14 +245,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize(int F, int G, const doubl
 __global__ __launch_bounds__(256) void bn_bwd_apply(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
                                                     int64_t ld, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                    const float* __restrict__ sums, float* __restrict__ gx) {
-    const float inv_n = 1.f / (float)n_rows;
+                                                    const float* __restrict__ sums, float* __restrict__ gx, const int64_t* __restrict__ n_valid) {
+    const int64_t nv = n_valid ? min(n_rows, *n_valid) : n_rows;
+    const float inv_n = 1.f / (float)nv;
     flat_loop(n_rows * F, F, [&](int64_t n, int c) {
         const float is = invstd[c], ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
         const float xh = (x[n * ld + c] - mean[c]) * is;
         float g = gy[n * ld + c];
         if (relu && !(xh * ga + be > 0.f)) g = 0.f;
-        return ga * is * (g - sums[c] * inv_n - xh * sums[F + c] * inv_n);
+        return n < nv ? ga * is * (g - sums[c] * inv_n - xh * sums[F + c] * inv_n) : 0.f;
     }, [&](int64_t n, int c, float v) { gx[n * ld + c] = v; });
 }
 
@@ -343,7 +349,7 @@ extern "C" size_t dgn_bn_tail_workspace_bytes(int64_t n_rows, int32_t F) {
 extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                                    int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
-                                   size_t ws_bytes, void* stream_) {
+                                   size_t ws_bytes, const int64_t* n_valid, void* stream_) {
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F) { set_error("dgn_bn_tail_forward: bad shape (need 1 <= F <= 1024, ld >= F)"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
     if (!x || !y) { set_error("dgn_bn_tail_forward: null buffer"); return DGN_ERR_INVALID; }
@@ -353,10 +359,10 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
         if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bn_tail_forward: workspace too small"); return DGN_ERR_WORKSPACE; }
         double* part = static_cast<double*>(ws);
         const int G = stat_groups(n_rows, F);
-        if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
-        else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part);
+        if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
+        else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
-                           running_var, momentum, eps, save_mean, save_invstd);
+                           running_var, momentum, eps, save_mean, save_invstd, n_valid);
         hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,
                            (const float*)save_mean, (const float*)save_invstd, (const float*)nullptr, (const float*)nullptr, eps, relu,
                            residual, y);
@@ -372,7 +378,8 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
 
 extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
-                                    float* g_gamma, float* g_beta, float* sums_out, void* ws, size_t ws_bytes, void* stream_) {
+                                    float* g_gamma, float* g_beta, float* sums_out, void* ws, size_t ws_bytes, const int64_t* n_valid,
+                                    void* stream_) {
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F) { set_error("dgn_bn_tail_backward: bad shape (need 1 <= F <= 1024, ld >= F)"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
     if (!g_y || !x || (!g_x && !sums_out) || !save_mean || !save_invstd || !ws) { set_error("dgn_bn_tail_backward: null buffer"); return DGN_ERR_INVALID; }
@@ -381,12 +388,12 @@ extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y,
     double* part = static_cast<double*>(ws);
     float* sums = sums_out ? sums_out : reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
-    if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
-    else hipLaunchKernelGGL(bn_bwd_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part);
+    if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
+    else hipLaunchKernelGGL(bn_bwd_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
     if (g_x)
         hipLaunchKernelGGL(bn_bwd_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean,
-                           save_invstd, relu, (const float*)sums, g_x);
+                           save_invstd, relu, (const float*)sums, g_x, n_valid);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

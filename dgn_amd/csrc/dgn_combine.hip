@@ -110,10 +110,13 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
     float* s_t = g_t + (size_t)rows_per_block * wy;  // [rows][S]
     float* b_t = s_t + (size_t)rows_per_block * S;   // [wy]         bias-gradient partial of this workgroup
     float* c_t = b_t + wy;                           // [6][wy]      BatchNorm-backward column constants (fused form)
+    // rows >= n_valid (DgnBnGrad.n_valid: padding rows of a batch held at a fixed capacity) took no part in the batch statistics and
+    // get a zero gradient
+    const int64_t n_valid = (has_bn && bn.n_valid) ? *bn.n_valid : n_nodes;
     for (int c = threadIdx.x; c < wy; c += kThreads) {
         b_t[c] = 0.f;
         if (has_bn) {
-            const float inv_n = 1.f / (float)n_nodes;
+            const float inv_n = 1.f / (float)n_valid;
             c_t[c] = bn.mean[c];
             c_t[wy + c] = bn.invstd[c];
             c_t[2 * wy + c] = bn.gamma ? bn.gamma[c] : 1.f;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
                     g = bn.g_out[(r0 + k.r) * bn.ld + c];
                     if (bn.relu && !(xh * ga + c_t[3 * wy + c] > 0.f)) g = 0.f;
                     g = ga * is * (g - c_t[4 * wy + c] - xh * c_t[5 * wy + c]);
+                    if (r0 + k.r >= n_valid) g = 0.f;
                 } else {
                     g = gy[(r0 + k.r) * ld_gy + k.c];
                 }

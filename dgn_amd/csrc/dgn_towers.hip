@@ -122,7 +122,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
     DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
-                                nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, stream));
+                                nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
     DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
     DGN_TRY(dgn_bias_act_forward(d.N, d.Fo, L->z, d.Fo, L->b_mix, 2, L->slope, L->residual ? L->h : nullptr, L->out, stream));
@@ -183,10 +183,10 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                              dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
     DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
-                                 G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
+                                 G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));
     DgnBnGrad bn{};
     bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
-    bn.sums = sums; bn.relu = 0;
+    bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;
     DGN_HIP_CHECK(hipMemsetAsync(G->g_b_post, 0, (size_t)d.Fo * 4, st));
     DGN_TRY(dgn_scale_combine_backward(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
                                        dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream));

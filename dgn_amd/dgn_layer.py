@@ -228,6 +228,11 @@ class DGNLayerSimple(nn.Module):
         return directional_aggregate(graph, plan or self.plan, self._avg_log, x_src=h, x_in=h, eig=eig)
 
     def forward(self, g, h, e, snorm_n):
+        # (a batch padded to a fixed row capacity carries its valid-row count as a device scalar: BatchNorm must know, ops.padded_rows)
+        with _ops.padded_rows(getattr(g, "n_valid", None)):
+            return self._forward(g, h, e, snorm_n)
+
+    def _forward(self, g, h, e, snorm_n):
         h_in = h
         F0 = h.shape[1]
         # Odd widths (ZINC simple: 75, CIFAR10: 65) would run the sweep with 4-byte lanes, a second, nearly empty
@@ -301,6 +306,11 @@ class DGNLayerComplex(nn.Module):
                                      x_in=h, eig=eig)
 
     def forward(self, g, h, e, snorm_n):
+        # (a batch padded to a fixed row capacity carries its valid-row count as a device scalar: BatchNorm must know, ops.padded_rows)
+        with _ops.padded_rows(getattr(g, "n_valid", None)):
+            return self._forward(g, h, e, snorm_n)
+
+    def _forward(self, g, h, e, snorm_n):
         h_in = h
         eig = g.ndata["eig"]
         id_slot = _identity_slot(self.plan.applied_scalers)
@@ -610,6 +620,11 @@ class DGNLayerTower(nn.Module):
                             T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1])
 
     def forward(self, g, h, e, snorm_n):
+        # (a batch padded to a fixed row capacity carries its valid-row count as a device scalar: BatchNorm must know, ops.padded_rows)
+        with _ops.padded_rows(getattr(g, "n_valid", None)):
+            return self._forward(g, h, e, snorm_n)
+
+    def _forward(self, g, h, e, snorm_n):
         h_in = h
         y = self._whole_layer(g, h, snorm_n)
         if y is not None:

@@ -73,6 +73,73 @@ class DGNGraph:
             self.ndata["eig"] = eig
         return self
 
+    # ---- a batch held at a fixed capacity (shape-bucketed HIP-graph replay) --------------------------------------------------
+    @classmethod
+    def padded(cls, n_cap: int, e_cap: int, device, eig_dim: int = 0) -> "DGNGraph":
+        """An EMPTY graph with static device arrays for up to ``n_cap`` nodes and ``e_cap`` edges; ``rebuild`` fills it with a
+        batch.  Every array keeps its address and its capacity shape for the life of the object, the C-side description says
+        ``n_nodes = n_cap``, ``n_edges = e_cap`` (rows beyond the batch are isolated, slots beyond its edges are never pointed
+        at), and ``n_valid`` (a device int64 scalar) tells BatchNorm how many rows are real: a HIP graph captured on this object
+        is valid for every batch that fits.  Molecule-like batches only (no hub rows)."""
+        self = cls.__new__(cls)
+        dev = torch.device(device)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        self._pad = dict(n_cap=int(n_cap), e_cap=int(e_cap))
+        indptr, src_csr = i32(n_cap + 1), i32(e_cap)
+        self.dst_csr = i32(e_cap)
+        eid = torch.zeros(e_cap, dtype=torch.int64, device=dev)
+        deg = torch.zeros(n_cap, dtype=torch.int64, device=dev)
+        log_deg = torch.zeros(n_cap, dtype=torch.float32, device=dev)
+        self._stats = i32(4)
+        self._init_csr(indptr, src_csr, eid, n_cap, e_cap, deg, HUB_THRESHOLD, HUB_CHUNK, log_deg=log_deg, max_in_degree=0, n_hub_hint=0)
+        self.n_valid = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.csc_ptr, self.csc_pos, self._csc_order = i32(n_cap + 1), i32(e_cap), i32(e_cap)
+        self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+        self._csc_ready, self.n_remote, self.win_ptr = True, 0, None
+        lib = _lib.load()
+        self._pad["ws_bytes"] = lib.dgn_graph_build_workspace_bytes(n_cap, e_cap)
+        self._pad["ws"] = torch.empty(self._pad["ws_bytes"], dtype=torch.uint8, device=dev)
+        self.ndata, self.edata = {}, {}
+        if eig_dim:
+            self.ndata["eig"] = torch.zeros(n_cap, eig_dim, dtype=torch.float32, device=dev)
+        self.batch_nodes = self.batch_edges = 0
+        return self
+
+    def rebuild(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None) -> None:
+        """Load a batch into a ``padded`` graph, in place (dgn_graph_build + dgn_graph_build_csc into the static arrays, one
+        read-back of the largest in-degree).  Cached per-graph tables (edge weights, scaler tables) are dropped: a step function
+        captured on this object must recompute them INSIDE the captured region (they then replay with every batch)."""
+        lib = _lib.load()
+        pad = self._pad
+        E, N = src.numel(), int(num_nodes)
+        if N > pad["n_cap"] or E > pad["e_cap"]:
+            raise ValueError(f"batch ({N} nodes, {E} edges) exceeds the capacity ({pad['n_cap']}, {pad['e_cap']})")
+        dev = self.device
+        src64, dst64 = src.to(dev).long().contiguous(), dst.to(dev).long().contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        n_cap = pad["n_cap"]
+        _lib.check(lib.dgn_graph_build(n_cap, E, _ptr(src64), _ptr(dst64), self.indptr.data_ptr(), self.src.data_ptr(), self.dst_csr.data_ptr(),
+                                       self.eid.data_ptr(), self.log_deg.data_ptr(), self.in_degree.data_ptr(), self._stats.data_ptr(),
+                                       int(self.hub_threshold), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build")
+        _lib.check(lib.dgn_graph_build_csc(n_cap, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(),
+                                           self._csc_order.data_ptr(), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build_csc")
+        self.n_valid.fill_(N)
+        if eig is not None:
+            buf = self.ndata["eig"]
+            buf[:N].copy_(eig, non_blocking=True)
+            buf[N:].zero_()
+        max_deg, n_hub = self._stats[:2].tolist()                                  # the one host sync of a load
+        if n_hub:
+            raise _lib.DgnError("padded graphs take batches without hub rows (in-degree <= hub_threshold) only")
+        self.max_in_degree, self.batch_nodes, self.batch_edges = int(max_deg), N, E
+        self.invalidate_caches()
+
+    def invalidate_caches(self) -> None:
+        """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
+        self._wcache.clear()
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm"):
+            self.__dict__.pop(k, None)
+
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
         """CSR by destination through dgn_graph_build: one C call, one read-back of (max in-degree, hub rows)."""
         lib = _lib.load()

@@ -32,6 +32,29 @@ DETERMINISTIC_BACKWARD = "auto"
 WINDOW_BACKWARD = "auto"
 
 
+# ---- padded batches -------------------------------------------------------------------------------------------------------------
+# A batch held at a fixed row capacity (shape-bucketed HIP-graph replay: dgn_amd/hipgraph.py::PaddedBatch) carries a DEVICE scalar
+# ``n_valid``: rows >= n_valid are padding (zero features, no edges).  The sweep, the Linears and the elementwise kernels treat them
+# as ordinary isolated rows; only BatchNorm must know (statistics over the valid rows, zero gradient for the others).  The layers
+# announce the scalar for the duration of their forward; every BatchNorm node picks it up and keeps it for its backward.
+_N_VALID = None
+
+
+class padded_rows:
+    def __init__(self, n_valid):
+        self.n_valid = n_valid
+
+    def __enter__(self):
+        global _N_VALID
+        self.prev, _N_VALID = _N_VALID, self.n_valid
+        return self
+
+    def __exit__(self, *exc):
+        global _N_VALID
+        _N_VALID = self.prev
+        return False
+
+
 def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
     key = (n_towers, float(avg_log), int(tower_stride))
     cache = plan.__dict__.setdefault("_spec_cache", {})
@@ -321,9 +344,10 @@ class _BNTail(torch.autograd.Function):
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F) if training else 0
         ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        ctx.n_valid = _N_VALID
         rc = lib.dgn_bn_tail_forward(N, F, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), 1 if training else 0, 1 if relu else 0, _ptr(residual), y.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), _ptr(ws), ws_bytes, stream)
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), _ptr(ws), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_forward")
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.has_res = relu, residual is not None
@@ -343,7 +367,7 @@ class _BNTail(torch.autograd.Function):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         rc = lib.dgn_bn_tail_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if ctx.relu else 0, g_x.data_ptr(), _ptr(g_gamma), _ptr(g_beta),
-                                      None, ws.data_ptr(), ws_bytes, stream)
+                                      None, ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_backward")
         return g_x, g_gamma, g_beta, None, None, None, None, None, None, (g_y if ctx.has_res else None)
 
@@ -375,9 +399,10 @@ class _CombineBNTail(torch.autograd.Function):
         save_invstd = torch.empty(F, dtype=torch.float32, device=dev)
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        ctx.n_valid = _N_VALID
         rc = lib.dgn_bn_tail_forward(N, F, y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), 1, 1 if relu else 0, _ptr(residual), out.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_forward")
         ctx.save_for_backward(scale, row_scale, y, gamma, beta, save_mean, save_invstd)
         ctx.dims = (T, N, S, fo, bias is not None, relu, residual is not None)
@@ -399,10 +424,11 @@ class _CombineBNTail(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
         rc = lib.dgn_bn_tail_backward(N, F, g_out.data_ptr(), y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if relu else 0, None, _ptr(g_gamma), _ptr(g_beta), sums.data_ptr(),
-                                      ws.data_ptr(), ws_bytes, stream)
+                                      ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_backward")
         bn = _lib.DgnBnGrad(g_out=g_out.data_ptr(), y=y.data_ptr(), ld=y.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
-                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0)
+                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0,
+                            n_valid=_ptr(ctx.n_valid))
         g_z = torch.empty((T, N, S * fo), dtype=torch.float32, device=dev)
         g_b = torch.zeros(F, dtype=torch.float32, device=dev) if (has_bias and ctx.needs_input_grad[2]) else None
         ws2_bytes = lib.dgn_scale_combine_backward_workspace_bytes(N, T, fo) if g_b is not None else 0
@@ -730,9 +756,10 @@ class _LinCombineBNTail(torch.autograd.Function):
         save_invstd = torch.empty(F, dtype=torch.float32, device=dev)
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
+        ctx.n_valid = _N_VALID
         rc = lib.dgn_bn_tail_forward(N, F, y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), 1, 1 if relu else 0, _ptr(residual), out.data_ptr(),
-                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+                                     save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_forward")
         ctx.save_for_backward(scale, row_scale, y, gamma, beta, save_mean, save_invstd, aggx, w)
         ctx.dims = (T, N, S, fo, bias is not None, relu, residual is not None)
@@ -754,10 +781,11 @@ class _LinCombineBNTail(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=dev)
         rc = lib.dgn_bn_tail_backward(N, F, g_out.data_ptr(), y.data_ptr(), y.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if relu else 0, None, _ptr(g_gamma), _ptr(g_beta), sums.data_ptr(),
-                                      ws.data_ptr(), ws_bytes, stream)
+                                      ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
         _lib.check(rc, "dgn_bn_tail_backward")
         bn = _lib.DgnBnGrad(g_out=g_out.data_ptr(), y=y.data_ptr(), ld=y.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
-                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0)
+                            mean=save_mean.data_ptr(), invstd=save_invstd.data_ptr(), sums=sums.data_ptr(), relu=1 if relu else 0,
+                            n_valid=_ptr(ctx.n_valid))
         # g_yr = row_scale * (BatchNorm backward of g_out), tower-major [T, N, fo]: the combine backward run with ONE scaler and
         # no scale table; the per-scaler expansion happens inside the two products below
         g_yr = torch.empty((T, N, fo), dtype=torch.float32, device=dev)
@@ -866,6 +894,8 @@ class _TowersLayer(torch.autograd.Function):
         nbytes = lib.dgn_towers_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        ctx.n_valid = _N_VALID
+        L.n_valid = _ptr(ctx.n_valid)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(lib.dgn_towers_layer_forward(C.byref(L), stream), "dgn_towers_layer_forward")
         ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf)
@@ -905,6 +935,7 @@ class _TowersLayer(torch.autograd.Function):
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        L.n_valid = _ptr(ctx.n_valid)
         g_h = torch.empty((N, Fm), dtype=torch.float32, device=dev)
         _, (g_w_sd, g_bias_sd, g_w_post, g_b_post, g_gamma, g_beta, g_w_mix, g_b_mix) = _carve(
             [2 * Fm * Fm, 2 * Fm, T * S * fo * K, Fo, Fo, Fo, Fo * Fo, Fo], dev)

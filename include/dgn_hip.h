@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 15
+#define DGN_ABI_VERSION 16
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -245,6 +245,8 @@ typedef struct DgnBnGrad {
     const float* invstd;   /* [F] save_invstd                                                                */
     const float* sums;     /* [2F] from dgn_bn_tail_backward                                                 */
     int32_t relu;
+    const int64_t* n_valid; /* DEVICE scalar or NULL: only rows < *n_valid are the batch; the rest is padding of a batch held at a
+                               fixed capacity (shape-bucketed HIP-graph replay): excluded from the statistics, zero gradient  */
 } DgnBnGrad;
 int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* g_y,
                                int64_t ld_gy, const float* scale, const float* row_scale, float* g_z, float* g_bias,
@@ -254,20 +256,22 @@ int dgn_scale_combine_backward(int64_t n_nodes, int32_t n_towers, int32_t n_scal
  *     y = [relu]( (x - mean) * invstd * gamma + beta ) [+ residual]          (dgn_layer.py:123-128, :194-199, :272-273)
  * training != 0: batch statistics (biased variance), running_mean / running_var updated in place with `momentum`
  * (running_var with the unbiased variance, like torch.nn.BatchNorm1d); save_mean / save_invstd [F] are written for
- * the backward.  training == 0: running statistics are used.  1 <= F <= 1024.  All [N, F] tensors share the row
+ * the backward.  training == 0: running statistics are used.  n_valid (DEVICE int64 scalar or NULL): rows >= *n_valid are
+ * padding -- they take no part in the statistics (count = *n_valid) and get a zero input gradient in the backward -- so that a
+ * batch can be held at a fixed row capacity (shape-bucketed HIP-graph replay).  1 <= F <= 1024.  All [N, F] tensors share the row
  * stride ld.  ws: dgn_bn_tail_workspace_bytes() of scratch (8-byte aligned; training / backward only) holding the
  * per-workgroup fp64 column partials, which are added in a fixed order (no atomics, bitwise reproducible).   */
 size_t dgn_bn_tail_workspace_bytes(int64_t n_rows, int32_t F);
 int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                         int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
-                        size_t ws_bytes, void* stream);
+                        size_t ws_bytes, const int64_t* n_valid, void* stream);
 /* Backward of the training-mode tail: g_x [N, F] (written), g_gamma / g_beta [F] (written; may be NULL).
  * The gradient of `residual` is g_y itself (left to the caller).  g_x == NULL skips the apply pass: only the column
  * sums are produced (`sums` [2F], may be NULL when g_x is given) for dgn_scale_combine_backward's fused form.  */
 int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int32_t relu, float* g_x,
-                         float* g_gamma, float* g_beta, float* sums, void* ws, size_t ws_bytes, void* stream);
+                         float* g_gamma, float* g_beta, float* sums, void* ws, size_t ws_bytes, const int64_t* n_valid, void* stream);
 
 /* Tail of an FCLayer (Linear -> activation, nets/layers.py:101-112) on the bias-free GEMM output x [N, F]:
  *     y = act(x + bias) [+ residual]        act: 0 none, 1 ReLU, 2 LeakyReLU(slope)
@@ -412,6 +416,7 @@ typedef struct DgnTowersLayer {
     float* pq; float* aggx; float* y0; float* save_mean; float* save_invstd; float* y1; float* z;
     float* out;                /* [N, T*f_out]  (forward only)                                              */
     void* ws; size_t ws_bytes; /* scratch: dgn_towers_layer_{forward,backward}_workspace_bytes()            */
+    const int64_t* n_valid;    /* DEVICE scalar or NULL: rows >= *n_valid are padding (see dgn_bn_tail_forward)         */
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */

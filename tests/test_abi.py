@@ -131,7 +131,7 @@ def test_argument_validation_runs_before_any_device_work(lib):
     spec.n_agg = 99                                         # more aggregators than one launch takes
     rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), None, 0, None, None, 0, None, 0, None)
     assert rc == -1 and "n_agg" in err()
-    assert lib.dgn_bn_tail_forward(5, 2000, None, 2000, None, None, None, None, 0.1, 1e-5, 1, 0, None, None, None, None, None, 0, None) == -1
+    assert lib.dgn_bn_tail_forward(5, 2000, None, 2000, None, None, None, None, 0.1, 1e-5, 1, 0, None, None, None, None, None, 0, None, None) == -1
     assert "F <= 1024" in err()
     assert lib.dgn_scale_combine_forward(5, 1, 3, 4, None, None, None, None, None, 0, None) == -1      # S = 3 without a scale table
     assert lib.dgn_scale_combine_backward(5, 600, 1, 8, None, 0, None, None, None, None, None, 0, None, None) == -1

@@ -1,0 +1,104 @@
+"""Batches held at a fixed capacity (DGNGraph.padded / hipgraph.PaddedBatch): the padded layer step -- eager and as ONE captured HIP
+graph replayed for batches of different sizes -- against the ordinary step on the exact-size graph: outputs of the real rows, input
+and parameter gradients, BatchNorm running statistics."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches():
+    from dgn_amd import synth
+    return [synth.molecule_batch(n, seed=s, laplacian_eig=False) for n, s in ((60, 1), (75, 2), (48, 3), (70, 4))]
+
+
+def _reference_step(layer, b, h, ct, dev):
+    import dgn_amd
+    N = int(b["num_nodes"])
+    g = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    hh = h.clone().requires_grad_(True)
+    y = layer(g, hh, None, b["snorm_n"].to(dev))
+    y.backward(ct)
+    return y.detach(), hh.grad, {k: v.grad.clone() for k, v in layer.named_parameters()}
+
+
+@pytest.mark.parametrize("type_net", ["towers", "simple"])
+def test_padded_step_equals_exact_step(type_net):
+    import dgn_amd
+    from dgn_amd.hipgraph import PaddedBatch, capture
+    dev = torch.device("cuda")
+    bs = _batches()
+    F_ = 70 if type_net == "towers" else 20
+    n_cap = int(max(int(b["num_nodes"]) for b in bs) * 1.1) + 7
+    e_cap = int(max(b["src"].numel() for b in bs) * 1.1) + 5
+    torch.manual_seed(0)
+    proto = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation",
+                             {"log": torch.tensor(1.1)}, type_net, True, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    with torch.no_grad():
+        for p in proto.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=gen))
+    hs = [torch.randn(int(b["num_nodes"]), F_, device=dev, generator=gen) for b in bs]
+    cts = [torch.randn(int(b["num_nodes"]), F_, device=dev, generator=gen) for b in bs]
+
+    ref_layer = copy.deepcopy(proto).train()
+    refs = []
+    for b, h, ct in zip(bs, hs, cts):
+        for p in ref_layer.parameters():
+            p.grad = None
+        refs.append(_reference_step(ref_layer, b, h, ct, dev))
+    ref_stats = {k: v.clone() for k, v in ref_layer.state_dict().items() if "running" in k or "num_batches" in k}
+
+    for mode in ("eager", "captured"):
+        layer = copy.deepcopy(proto).train()
+        pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=bs[0]["eig"].shape[1])
+        h_buf = pb.add_node_tensor("h", F_, requires_grad=True)
+        sn_buf = pb.add_node_tensor("snorm", 1)
+        ct_buf = pb.add_node_tensor("ct", F_)
+        out = {}
+
+        def step():
+            pb.graph.invalidate_caches()
+            y = layer(pb.graph, h_buf, None, sn_buf)
+            y.backward(ct_buf)
+            out["y"] = y.detach()
+
+        def load(i):
+            b = bs[i]
+            pb.load(b["src"].to(dev), b["dst"].to(dev), int(b["num_nodes"]), b["eig"].to(dev),
+                    node=dict(h=hs[i], snorm=b["snorm_n"].to(dev), ct=cts[i]))
+
+        graph = None
+        if mode == "captured":
+            load(0)
+            # warm-up steps would advance the running statistics: snapshot / restore around the capture
+            snap = copy.deepcopy(layer.state_dict())
+            h_buf.grad = None
+            for p in layer.parameters():
+                p.grad = None
+            graph = capture(step, warmup=2)
+            layer.load_state_dict(snap)
+        for i, b in enumerate(bs):
+            N = int(b["num_nodes"])
+            load(i)
+            if graph is None:
+                h_buf.grad = None
+                for p in layer.parameters():
+                    p.grad = None
+                step()
+            else:
+                graph.replay()
+            torch.cuda.synchronize()
+            y_ref, gh_ref, gp_ref = refs[i]
+            np.testing.assert_allclose(out["y"][:N].cpu().numpy(), y_ref.cpu().numpy(), rtol=2e-5, atol=2e-5, err_msg=f"{mode} batch {i} y")
+            np.testing.assert_allclose(h_buf.grad[:N].cpu().numpy(), gh_ref.cpu().numpy(), rtol=1e-4, atol=2e-5, err_msg=f"{mode} batch {i} gh")
+            for k, p in layer.named_parameters():
+                r = gp_ref[k]
+                np.testing.assert_allclose(p.grad.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(r.abs().max())),
+                                           err_msg=f"{mode} batch {i} grad {k}")
+        for k, v in layer.state_dict().items():
+            if "running" in k:
+                np.testing.assert_allclose(v.cpu().numpy(), ref_stats[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=f"{mode} {k}")
