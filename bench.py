@@ -565,6 +565,70 @@ def run_inference(args, dev, steps=20, warmup=5):
     return out
 
 
+def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8):
+    """The reference's operating point -- batches of 128 molecules whose node / edge counts differ from step to step -- on ONE
+    captured HIP graph: the batch lives in static buffers at a fixed capacity (hipgraph.PaddedBatch), BatchNorm reads the number of
+    real rows from the device.  A timed step = graph preparation of the NEXT batch in place (dgn_graph_build + _csc, one read-back)
+    + copies of its features / eig / graph norm / cotangent into the static buffers + one graph launch (edge weights, forward,
+    backward).  The batches are on the device beforehand (as after a data loader's H2D copy)."""
+    from dgn_amd.hipgraph import PaddedBatch, bucket_capacity, capture
+    wl = dict(WORKLOADS["c2_b128"])
+    F_ = wl["hidden"]
+    raw = [synth.molecule_batch(seed=41 + i, **wl["gen"][1]) for i in range(n_batches)]
+    n_cap, e_cap = bucket_capacity(max(int(b["num_nodes"]) for b in raw), max(b["src"].numel() for b in raw))
+    gen = torch.Generator(device=dev).manual_seed(0)
+    data = []
+    for b in raw:
+        N = int(b["num_nodes"])
+        data.append(dict(src=b["src"].to(dev), dst=b["dst"].to(dev), N=N, eig=b["eig"].to(dev), snorm=b["snorm_n"].to(dev),
+                         h=torch.randn(N, F_, device=dev, generator=gen), ct=torch.randn(N, F_, device=dev, generator=gen)))
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(1.0)}, wl["type_net"], True,
+                             towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev).train()
+    pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=raw[0]["eig"].shape[1])
+    h_buf, sn_buf, ct_buf = pb.add_node_tensor("h", F_, requires_grad=True), pb.add_node_tensor("snorm", 1), pb.add_node_tensor("ct", F_)
+    params = list(layer.parameters())
+
+    def load(i):
+        d = data[i % n_batches]
+        pb.load(d["src"], d["dst"], d["N"], d["eig"], node=dict(h=d["h"], snorm=d["snorm"], ct=d["ct"]))
+
+    def bare_step():
+        pb.graph.invalidate_caches()              # edge weights and scaler tables are recomputed inside the captured region
+        layer(pb.graph, h_buf, None, sn_buf).backward(ct_buf)
+
+    def reset():
+        h_buf.grad = None
+        for p in params:
+            p.grad = None
+
+    load(0)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            reset()
+            bare_step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    reset()
+    graph = capture(bare_step, warmup=0)
+    for s_ in range(warmup):
+        load(s_)
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        load(s_)
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    edges = sum(d["src"].numel() for d in data) / n_batches
+    return dict(ms_per_step=ms, value=edges / (ms * 1e-3), unit="edges/s", steps=steps, warmup=warmup,
+                capacity=dict(nodes=n_cap, edges=e_cap), batches=[dict(nodes=d["N"], edges=int(d["src"].numel())) for d in data],
+                config=f"{n_batches} different batches of 128 molecules cycled through ONE captured HIP graph (padded to the capacity); a step = "
+                       "in-place graph preparation + input copies + graph launch (edge weights + layer forward + backward)")
+
+
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
@@ -591,6 +655,10 @@ def run_extras(args, dev):
         extra["c2_inference"] = run_inference(args, dev)
     except Exception as exc:
         extra["c2_inference"] = dict(error=f"{type(exc).__name__}: {exc}")
+    try:
+        extra["c2_b128_bucketed"] = run_bucketed(args, dev)
+    except Exception as exc:
+        extra["c2_b128_bucketed"] = dict(error=f"{type(exc).__name__}: {exc}")
     return extra
 
 

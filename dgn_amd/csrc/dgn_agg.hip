@@ -225,14 +225,10 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     p.fresh = grads->accumulate == 0 && p.stage != nullptr;
     p.seg_add = !p.fresh || p.g_in == p.g_src;
     if (grads->accumulate == 0 && !p.fresh) {
-        auto zero = [&](float* ptr, int32_t ld, int64_t rows) -> hipError_t {
-            const size_t wbytes = (size_t)msg->F * sizeof(float), pitch = (size_t)ld * sizeof(float);
-            if (pitch == wbytes) return hipMemsetAsync(ptr, 0, wbytes * (size_t)rows, stream);
-            return hipMemset2DAsync(ptr, pitch, 0, wbytes, (size_t)rows, stream);
-        };
-        if (p.g_src) DGN_HIP_CHECK(zero(p.g_src, p.ldg_src, p.n_src));
-        if (p.g_dst) DGN_HIP_CHECK(zero(p.g_dst, p.ldg_dst, p.n_nodes));
-        if (p.g_in && p.g_in != p.g_src) DGN_HIP_CHECK(zero(p.g_in, p.ldg_in, p.n_nodes));
+        auto zero = [&](float* ptr, int32_t ld, int64_t rows) -> int { return zero_rows_async(ptr, rows, msg->F, ld, stream); };
+        if (p.g_src && zero(p.g_src, p.ldg_src, p.n_src)) return DGN_ERR_HIP;
+        if (p.g_dst && zero(p.g_dst, p.ldg_dst, p.n_nodes)) return DGN_ERR_HIP;
+        if (p.g_in && p.g_in != p.g_src && zero(p.g_in, p.ldg_in, p.n_nodes)) return DGN_ERR_HIP;
     }
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));

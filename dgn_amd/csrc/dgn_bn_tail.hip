@@ -422,7 +422,7 @@ extern "C" int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F || act < 0 || act > 2) { set_error("dgn_bias_act_backward: bad shape (need 1 <= F <= 1024) or activation"); return DGN_ERR_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_rows == 0) {
-        if (g_bias) DGN_HIP_CHECK(hipMemsetAsync(g_bias, 0, (size_t)F * sizeof(float), stream));
+        if (g_bias && zero_rows_async(g_bias, 1, F, F, stream)) return DGN_ERR_HIP;
         return DGN_OK;
     }
     if (!g_y || !x || !g_x || !ws) { set_error("dgn_bias_act_backward: null buffer"); return DGN_ERR_INVALID; }

@@ -17,6 +17,7 @@ constexpr int kXcds = 8;                         // MI355X: 8 XCDs, block b is d
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+int zero_rows_async(float* p, int64_t rows, int64_t width, int64_t ld, hipStream_t stream);   // capture-safe zero fill (dgn_abi.hip)
 
 #define DGN_HIP_CHECK(expr)                                         \
     do {                                                            \

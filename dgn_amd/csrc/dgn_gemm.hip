@@ -111,7 +111,7 @@ extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float*
     if (n_rows < 0 || !dgn_gemm_supported(k, n) || n > 16 * kWgWaves) { set_error("%s: need n <= %d (k=%d n=%d)", fn, 16 * kWgWaves, k, n); return DGN_ERR_INVALID; }
     if (!dw || lddw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (n_rows == 0) { DGN_HIP_CHECK(hipMemset2DAsync(dw, lddw * 4, 0, (size_t)k * 4, (size_t)n, st)); return DGN_OK; }
+    if (n_rows == 0) return zero_rows_async(dw, n, k, lddw, st);
     if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     const WgPlan w = wgrad_plan(n_rows, k, n);
     const size_t need = dgn_gemm_wgrad_workspace_bytes(n_rows, k, n);

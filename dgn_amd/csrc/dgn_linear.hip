@@ -138,8 +138,8 @@ static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, in
 static int zero_wgrad(float* dw, int64_t lddw, int64_t stride_dw, float* dbias, int64_t stride_dbias, int k, int n, int batch,
                       hipStream_t st) {
     for (int t = 0; t < batch; ++t) {
-        DGN_HIP_CHECK(hipMemset2DAsync(dw + t * stride_dw, lddw * 4, 0, (size_t)k * 4, (size_t)n, st));
-        if (dbias) DGN_HIP_CHECK(hipMemsetAsync(dbias + t * stride_dbias, 0, (size_t)n * 4, st));
+        if (zero_rows_async(dw + t * stride_dw, n, k, lddw, st)) return DGN_ERR_HIP;
+        if (dbias && zero_rows_async(dbias + t * stride_dbias, 1, n, n, st)) return DGN_ERR_HIP;
     }
     return 0;
 }

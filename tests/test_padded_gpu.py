@@ -76,10 +76,22 @@ def test_padded_step_equals_exact_step(type_net):
             load(0)
             # warm-up steps would advance the running statistics: snapshot / restore around the capture
             snap = copy.deepcopy(layer.state_dict())
-            h_buf.grad = None
-            for p in layer.parameters():
-                p.grad = None
-            graph = capture(step, warmup=2)
+
+            def reset():
+                h_buf.grad = None
+                for p in layer.parameters():
+                    p.grad = None
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    reset()
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            reset()                                    # gradients None at capture: every replay then DEFINES them
+            out.clear()
+            graph = capture(step, warmup=0)
             layer.load_state_dict(snap)
         for i, b in enumerate(bs):
             N = int(b["num_nodes"])
