@@ -54,6 +54,11 @@ WORKLOADS = {
     "c2e": dict(desc="ZINC-12k towers as c2 WITH edge features (edge_dim 10: pretrans on [h_src || h_dst || ef])",
                 gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                 aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5, edge_dim=10),
+    "c2et": dict(desc="ZINC-12k towers as c2e, the edge features given as an embedding lookup (4 bond types x edge_dim 10, "
+                      "dgn_net.py:53,75): EdgeTypeFeatures -> a 4 x 70 table in the sweep instead of an [E, 70] term",
+                 gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
+                 aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5, edge_dim=10,
+                 edge_types=4),
     "c2_b128": dict(desc="ZINC batch of 128 molecules, DGN towers (as c2)",
                     gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                     aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
@@ -268,6 +273,11 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     ct = torch.randn(N, F_, device=dev, generator=gen)
     snorm = batch["snorm_n"].to(dev)
     ef = torch.randn(E, edge_dim, device=dev, generator=gen).requires_grad_(True) if edge_dim else None
+    n_types = wl.get("edge_types", 0)
+    ef_leaf = ef
+    if n_types:     # the same features as (embedding table, bond type per edge)
+        ef_leaf = torch.randn(n_types, edge_dim, device=dev, generator=gen).requires_grad_(True)
+        ef = dgn_amd.EdgeTypeFeatures(ef_leaf, torch.randint(0, n_types, (E,), device=dev, generator=gen))
     reducer = ddist.FlatGradAllReduce(layer.parameters()) if torch.distributed.is_initialized() else None
 
     params = list(layer.parameters())      # (what an optimizer holds; walking the module tree costs 0.1 ms per step)
@@ -275,8 +285,8 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     def step():
         graph._wcache.clear()              # per-edge weights are recomputed every step (eig flips per batch)
         h.grad = None
-        if ef is not None:
-            ef.grad = None
+        if ef_leaf is not None:
+            ef_leaf.grad = None
         for p in params:
             p.grad = None
         y = layer(graph, h, ef, snorm)
@@ -364,15 +374,21 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     reps = 20
     # with edge features the message has a third, per-edge term R = ef W_e^T [E, F] in slot order (materialised by a streaming
     # Linear): the sweep reads it (+4F per edge, forward and -- with max/min/std -- backward) and the backward writes d R
-    me = torch.randn(E, F_, device=dev, generator=gen) if edge_dim else None
-    g_me = torch.empty(E, F_, device=dev) if edge_dim else None
-    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out)
-    bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False)
+    # (EdgeTypeFeatures: the term is a [K, F] table + 4 bytes of type per edge; d table = the staged rows summed by type)
+    me = torch.randn(n_types if n_types else E, F_, device=dev, generator=gen) if edge_dim else None
+    g_me = torch.empty_like(me) if edge_dim else None
+    et = graph.to_slot_order(ef.types).to(torch.int32).contiguous() if n_types else None
+    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et)
+    bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False,
+                                       edge_type=et)
     ms_f = event_ms(fwd_call, reps, dev)
     ms_b = event_ms(bwd_call, reps, dev)
     ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
-    if edge_dim:
+    if n_types:
+        bf += 4 * E
+        bb += 4 * E + 4 * E + 4 * F_ * E       # types (sweep, reduction), the reduction's read of the staged rows
+    elif edge_dim:
         bf += 4 * F_ * E
         bb += 4 * F_ * E * (1 + r)
     pct = (lambda fn: event_percentiles(fn, dev)) if args.percentiles else (lambda fn: None)
@@ -632,7 +648,7 @@ def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8):
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()

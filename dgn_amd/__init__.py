@@ -9,11 +9,11 @@ from .graph import DGNGraph, as_dgn_graph, compute_edge_weights
 from .spec import AGGREGATOR_NAMES, SCALER_NAMES, make_plan
 from .ops import directional_aggregate
 from .layers import FCLayer, MLP, get_activation
-from .dgn_layer import (AGGREGATORS, SCALERS, DGNLayer, DGNLayerComplex, DGNLayerSimple, DGNLayerTower, DGNTower)
+from .dgn_layer import (AGGREGATORS, SCALERS, DGNLayer, DGNLayerComplex, DGNLayerSimple, DGNLayerTower, DGNTower, EdgeTypeFeatures)
 from .readout import VirtualNode, max_nodes, mean_nodes, readout, sum_nodes
 from .eig import laplacian_eigvecs
 
 __all__ = ["DGNGraph", "as_dgn_graph", "compute_edge_weights", "make_plan", "directional_aggregate", "FCLayer", "MLP",
            "get_activation", "AGGREGATORS", "SCALERS", "DGNLayer", "DGNLayerSimple", "DGNLayerComplex", "DGNLayerTower",
-           "DGNTower", "AGGREGATOR_NAMES", "SCALER_NAMES", "VirtualNode", "sum_nodes", "mean_nodes", "max_nodes", "readout",
+           "DGNTower", "EdgeTypeFeatures", "AGGREGATOR_NAMES", "SCALER_NAMES", "VirtualNode", "sum_nodes", "mean_nodes", "max_nodes", "readout",
            "laplacian_eigvecs"]

@@ -14,13 +14,13 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_backward",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
@@ -56,7 +56,7 @@ class DgnAggSpec(C.Structure):
 class DgnMsg(C.Structure):
     _fields_ = [("F", C.c_int64), ("x_src", C.c_void_p), ("ld_src", C.c_int64), ("x_dst", C.c_void_p),
                 ("ld_dst", C.c_int64), ("m_edge", C.c_void_p), ("ld_edge", C.c_int64), ("x_in", C.c_void_p),
-                ("ld_in", C.c_int64)]
+                ("ld_in", C.c_int64), ("edge_type", C.c_void_p), ("n_edge_types", C.c_int32)]
 
 
 class DgnMsgGrad(C.Structure):
@@ -118,6 +118,8 @@ def load() -> C.CDLL:
         lib.dgn_agg_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64]
         lib.dgn_agg_backward_workspace_bytes.restype = C.c_size_t
         lib.dgn_agg_backward_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32]
+        lib.dgn_agg_edge_table_workspace_bytes.restype = C.c_size_t
+        lib.dgn_agg_edge_table_workspace_bytes.argtypes = [C.c_int64, C.c_int32]
         lib.dgn_agg_forward.restype = C.c_int
         lib.dgn_agg_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,

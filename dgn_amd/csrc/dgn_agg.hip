@@ -53,6 +53,10 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
     if (spec->n_scalers < 1 || spec->n_scalers > DGN_MAX_SCALERS) { set_error("n_scalers=%d outside 1..%d", spec->n_scalers, DGN_MAX_SCALERS); return DGN_ERR_INVALID; }
     if (spec->n_towers < 1 || msg->F < 1 || msg->F % spec->n_towers != 0) { set_error("F=%lld not divisible by n_towers=%d", (long long)msg->F, spec->n_towers); return DGN_ERR_INVALID; }
     if (!msg->x_src && !msg->x_dst && !msg->m_edge) { set_error("message has no term"); return DGN_ERR_INVALID; }
+    if (msg->edge_type) {
+        if (!msg->m_edge || !msg->x_src) { set_error("edge_type needs the table (m_edge) and x_src"); return DGN_ERR_INVALID; }
+        if (msg->n_edge_types < 1 || (int64_t)msg->n_edge_types * msg->F > DGN_MAX_EDGE_TABLE) { set_error("edge-type table of %d x %lld floats outside 1..%d", msg->n_edge_types, (long long)msg->F, DGN_MAX_EDGE_TABLE); return DGN_ERR_INVALID; }
+    }
     if ((int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) * msg->F > INT32_MAX) { set_error("output row wider than 2^31 columns"); return DGN_ERR_INVALID; }
     if (msg->ld_src > INT32_MAX || msg->ld_dst > INT32_MAX || msg->ld_edge > INT32_MAX || msg->ld_in > INT32_MAX) { set_error("row strides must fit in int32"); return DGN_ERR_INVALID; }
     bool need_scale = false;
@@ -90,6 +94,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
     p.x_src = msg->x_src; p.ld_src = (int32_t)msg->ld_src;
     p.x_dst = msg->x_dst; p.ld_dst = (int32_t)msg->ld_dst;
     p.m_edge = msg->m_edge; p.ld_edge = (int32_t)msg->ld_edge;
+    p.edge_type = msg->edge_type; p.n_edge_types = msg->edge_type ? msg->n_edge_types : 0;
     p.x_in = msg->x_in; p.ld_in = (int32_t)msg->ld_in;
     p.w = w; p.ld_w = (int32_t)ld_w; p.log_deg = log_deg;
     p.n_agg = spec->n_agg; p.agg_total = spec->agg_total > 0 ? spec->agg_total : spec->n_agg;
@@ -138,6 +143,69 @@ void carve_ws(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, void* ws)
     p.coef = reinterpret_cast<float*>(base + up(part) + up(sw));
 }
 
+// ---- gradient of the edge-type table: rows of the staged per-edge gradients summed by type -------------------------------
+// (the sweep parked d m_j of slot j at stage[csc_pos[j]]; d table[k] = sum of the rows whose slot has type k).  Two passes, fixed
+// slot ranges per wave and a fixed summation order: deterministic.
+constexpr int kTabBlocks = 512;
+constexpr int kTabGroup = 8;         // staged rows in flight per wave
+
+__global__ __launch_bounds__(1024) void edge_table_grad_partial(const float* __restrict__ stage, const int32_t* __restrict__ csc_pos,
+                                                               const int32_t* __restrict__ edge_type, int64_t n_edges, int F, int K,
+                                                               float* __restrict__ part) {
+    extern __shared__ float tab_acc[];                        // [waves][K][F]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6, KF = K * F;
+    float* mine = tab_acc + wave * KF;
+    for (int i = lane; i < KF; i += kWave) mine[i] = 0.f;
+    const int64_t nw = (int64_t)gridDim.x * waves, gw = (int64_t)blockIdx.x * waves + wave;
+    const int64_t per = (n_edges + nw - 1) / nw, j0 = gw * per, j1 = min(n_edges, j0 + per);
+    for (int64_t base = j0; base < j1; base += kWave) {
+        const int cnt = (int)min((int64_t)kWave, j1 - base);
+        const int my_pos = lane < cnt ? csc_pos[base + lane] : 0, my_k = lane < cnt ? edge_type[base + lane] : 0;
+        for (int q = 0; q < cnt; q += kTabGroup) {
+            for (int f = 2 * lane; f < F; f += 2 * kWave) {
+                float2 v[kTabGroup];
+#pragma unroll
+                for (int u = 0; u < kTabGroup; ++u)
+                    if (u == 0 || q + u < cnt) v[u] = *reinterpret_cast<const float2*>(stage + (int64_t)bcast_i(my_pos, q + u) * F + f);
+#pragma unroll
+                for (int u = 0; u < kTabGroup; ++u) {
+                    if (u == 0 || q + u < cnt) {
+                        float* a = mine + bcast_i(my_k, q + u) * F + f;      // (one wave, LDS operations in program order)
+                        a[0] += v[u].x;
+                        a[1] += v[u].y;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KF; i += blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < waves; ++w) a += tab_acc[w * KF + i];
+        part[(int64_t)blockIdx.x * KF + i] = a;
+    }
+}
+
+// 16 table entries per workgroup, 16 threads per entry: each adds every 16th partial (fixed order), then the 16 are added in order
+__global__ __launch_bounds__(256) void edge_table_grad_final(const float* __restrict__ part, int blocks, int F, int K, float* __restrict__ g_tab, int64_t ld) {
+    __shared__ float red[16][17];
+    const int li = threadIdx.x & 15, lb = threadIdx.x >> 4, i = blockIdx.x * 16 + li, KF = K * F;
+    float a = 0.f;
+    if (i < KF)
+        for (int b = lb; b < blocks; b += 16) a += part[(int64_t)b * KF + i];
+    red[lb][li] = a;
+    __syncthreads();
+    if (lb == 0 && i < KF) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][li];
+        const int k = i / F;
+        g_tab[(int64_t)k * ld + (i - k * F)] = t;
+    }
+}
+
+size_t edge_table_ws_bytes(int64_t F, int32_t K) { return (((size_t)kTabBlocks * K * F * sizeof(float)) + 255) & ~(size_t)255; }
+
 int launch(int vec, const AggParams& p, unsigned tiles, hipStream_t stream, bool backward) {
     switch (vec) {
         case 4: return launch_agg_v4(p, tiles, stream, backward);
@@ -166,6 +234,10 @@ extern "C" size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* s
 }
 
 size_t stage_bytes(const DgnGraph* g, int64_t F) { return ((size_t)g->n_edges * F * sizeof(float) + 255) & ~(size_t)255; }
+
+extern "C" size_t dgn_agg_edge_table_workspace_bytes(int64_t F, int32_t n_edge_types) {
+    return (F > 0 && n_edge_types > 0) ? edge_table_ws_bytes(F, n_edge_types) : 0;
+}
 
 extern "C" size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t deterministic) {
     if (!g || !spec) return 0;
@@ -219,6 +291,15 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
         p.stage = reinterpret_cast<float*>(static_cast<char*>(ws) + hub_ws_bytes(g, spec, msg->F));
         p.csc_ptr = g->csc_ptr; p.csc_pos = g->csc_pos;
     }
+    float* tab_part = nullptr;
+    if (msg->edge_type) {
+        // the table's gradient is a reduction of the staged rows by type (after the sweep): the sweep itself writes no g_edge
+        const size_t need = hub_ws_bytes(g, spec, msg->F) + stage_bytes(g, msg->F) + edge_table_ws_bytes(msg->F, msg->n_edge_types);
+        if (!p.stage || ws_bytes < need) { set_error("edge-type table: the backward needs the two-phase scatter (g_src, g->csc_*) and a workspace of %zu bytes", need); return DGN_ERR_WORKSPACE; }
+        if (msg->F % 2 != 0) { set_error("edge-type table: F must be even"); return DGN_ERR_INVALID; }
+        tab_part = reinterpret_cast<float*>(static_cast<char*>(ws) + hub_ws_bytes(g, spec, msg->F) + stage_bytes(g, msg->F));
+        p.g_edge = nullptr;
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     // accumulate == 0: the sinks arrive uninitialised.  With the two-phase scatter every row of every sink is
     // written by exactly one thread (no zero-fill, no read-modify-write); the atomic scatter needs zeroed sinks.
@@ -236,11 +317,20 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     // tile of >= 8-byte lanes, and an LDS footprint that leaves room for two workgroups per CU
     // (whether it PAYS is the caller's policy -- a caller that does not want it passes a DgnGraph without win_ptr)
     static const bool no_window = getenv("DGN_NO_WINDOW") != nullptr;
-    if (!no_window && p.fresh && p.g_src && g->win_ptr && g->win_info && g->n_win > 0 && g->n_hub == 0 && g->n_src == 0 && g->max_in_degree > 0 &&
+    if (!no_window && !msg->edge_type && p.fresh && p.g_src && g->win_ptr && g->win_info && g->n_win > 0 && g->n_hub == 0 && g->n_src == 0 && g->max_in_degree > 0 &&
         g->max_in_degree <= kWave && tiles == 1 && vec >= 2 && (g->n_remote == 0 || (g->rem_ptr && g->rem_idx))) {
         p.win_ptr = g->win_ptr; p.win_info = g->win_info; p.n_win = g->n_win; p.win_rows = g->win_rows; p.win_ecap = g->win_ecap;
         if (g->n_remote > 0) { p.rem_ptr = g->rem_ptr; p.rem_idx = g->rem_idx; }
         if (window_lds_bytes(p) > 80 * 1024) { p.win_ptr = nullptr; p.rem_ptr = nullptr; p.rem_idx = nullptr; }
     }
-    return launch(vec, p, tiles, stream, true);
+    rc = launch(vec, p, tiles, stream, true);
+    if (rc || !msg->edge_type || !grads->g_edge) return rc;
+    const int K = msg->n_edge_types, KF = K * (int)msg->F;
+    const int waves = std::max(1, std::min(16, 16384 / KF));                 // per-wave accumulator tables: at most 64 KB of LDS
+    hipLaunchKernelGGL(edge_table_grad_partial, dim3(kTabBlocks), dim3(kWave * waves), (size_t)waves * KF * sizeof(float), stream,
+                       p.stage, p.csc_pos, msg->edge_type, p.n_edges, (int)msg->F, K, tab_part);
+    hipLaunchKernelGGL(edge_table_grad_final, dim3((KF + 15) / 16), dim3(256), 0, stream, tab_part, kTabBlocks, (int)msg->F, K,
+                       grads->g_edge, grads->ld_edge);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
 }

@@ -65,6 +65,9 @@ struct AggParams {
     const float* x_src;  int32_t ld_src;
     const float* x_dst;  int32_t ld_dst;
     const float* m_edge; int32_t ld_edge;
+    const int32_t* edge_type;  // per CSR slot: m_edge is a [n_edge_types, ld_edge] TABLE and slot j adds row edge_type[j] (NULL: row j)
+    int32_t n_edge_types;
+    int32_t tab_off;           // agg_fwd_short: the table's copy starts this many floats into the dynamic LDS
     const float* x_in;   int32_t ld_in;
     const float* w;      int32_t ld_w;
     const float* log_deg;
@@ -279,11 +282,13 @@ struct MsgSrc {
 template <int NCH, int NW>
 struct SlotBatch {
     int src;
+    int et;        // row of the slot's m_edge term: the slot itself, or its edge type (table mode)
     float w[NW];
     __device__ __forceinline__ void load(const AggParams& p, int base, int end) {
         const int e = base + lane_id();
         const bool in = e < end;
         src = in ? p.src[e] : 0;
+        et = p.edge_type ? (in ? p.edge_type[e] : 0) : e;
 #pragma unroll
         for (int c = 0; c < NW; ++c) w[c] = 0.f;
 #pragma unroll
@@ -291,10 +296,11 @@ struct SlotBatch {
     }
     // the same batch from a workgroup's LDS copy of the window's slot arrays (agg_bwd_window): s_src / s_w[c * ld] hold the
     // window's slots e0 .. ; off = base - e0
-    __device__ __forceinline__ void load_lds(const int* s_src, const float* s_w, int ld, int off, int cnt) {
+    __device__ __forceinline__ void load_lds(const int* s_src, const float* s_w, int ld, int off, int cnt, int slot0) {
         const int l = lane_id();
         const bool in = l < cnt;
         src = in ? s_src[off + l] : 0;
+        et = slot0 + l;                                          // (the host keeps the window kernel out of table mode)
 #pragma unroll
         for (int c = 0; c < NW; ++c) w[c] = 0.f;
 #pragma unroll
@@ -363,7 +369,7 @@ __device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggPa
             for (int u = 0; u < H; ++u) {
                 if (u == 0 || k + u < cnt) {
                     ldv<VEC>(t[u], p.x_src + (int64_t)bcast_i(b.src, k + u) * p.ld_src + f0);
-                    ldv<VEC>(t[H + u], p.m_edge + (int64_t)(base + k + u) * p.ld_edge + f0);
+                    ldv<VEC>(t[H + u], p.m_edge + (int64_t)bcast_i(b.et, k + u) * p.ld_edge + f0);
                 }
             }
 #pragma unroll
@@ -805,6 +811,18 @@ __device__ __forceinline__ void short_group_to_lds(const AggParams& p, const Sho
 template <class C, class O = DynOps>
 __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     constexpr int VEC = C::VEC, R = kShortRows, J = kShortDeg;
+    extern __shared__ float lds_rows[];
+    // table mode of the m_edge term (one row per edge TYPE): every workgroup keeps the table in LDS, a slot's term is an LDS read
+    const float* tab = nullptr;
+    if (p.edge_type) {
+        float* dst = lds_rows + p.tab_off;
+        for (int i = threadIdx.x; i < p.n_edge_types * p.F; i += blockDim.x) {
+            const int k = i / p.F;
+            dst[i] = p.m_edge[(int64_t)k * p.ld_edge + (i - k * p.F)];
+        }
+        __syncthreads();
+        tab = dst;
+    }
     ShortGroup grp;
     if (!grp.init(p)) return;
     const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
@@ -818,7 +836,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
         deg[r] = grp.ptr(min(r + 1, grp.nrows)) - beg0 - lo[r];
         max_deg = max(max_deg, deg[r]);
     }
-    if (max_deg > J || (p.x_src && p.m_edge)) {   // a longer row, or two gathered parts per message: row at a time
+    if (max_deg > J || (p.x_src && p.m_edge && !tab)) {   // a longer row, or two gathered parts per message: row at a time
         for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active);
         return;
     }
@@ -834,7 +852,6 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     // n_towers pieces of Ft floats (56 bytes on ZINC).  With p.stage_out the wave first lays the row out in its LDS
     // slice exactly as it lies in memory per tower ([tower][aggregator][Ft]) and then stores every tower's row --
     // agg_total * Ft contiguous floats (336 bytes) -- with consecutive lanes.  All lanes stay for that second step.
-    extern __shared__ float lds_rows[];
     const bool staged = p.stage_out != 0;
     if (!active && !staged) return;
     const int K = p.agg_total * p.Ft;                                     // floats of one row inside one tower
@@ -869,6 +886,11 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                     float mm[VEC], wk[C::NW];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
+                    if (tab) {
+                        const float* tr = tab + bcast_i(b.et, lo[r] + j) * p.F + f0;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) mm[i] += tr[i];
+                    }
                     b.weights(wk, lo[r] + j);
                     acc.add(mm, wk, beg0 + lo[r] + j);
                 }
@@ -1126,12 +1148,20 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
     for (int k0 = 0; k0 < cnt; k0 += U) {
         // var/std need the message again: the group's gathers are issued together, BEFORE the group's stores (a
         // load waited for after a store drains the store first: loads and stores share one in-order counter)
-        float t[NEED_M ? U : 1][VEC];
+        float t[NEED_M ? U : 1][VEC], t2[NEED_M ? U : 1][VEC];
         if constexpr (NEED_M) {
             if (!src.both) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (u == 0 || k0 + u < cnt) src.load(t[u], bcast_i(b.src, k0 + u), base + k0 + u, f0);
+            } else {                                   // both gathered parts of the group's messages: x_src rows, m_edge rows
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u == 0 || k0 + u < cnt) {
+                        ldv<VEC>(t[u], p.x_src + (int64_t)bcast_i(b.src, k0 + u) * p.ld_src + f0);
+                        ldv<VEC>(t2[u], p.m_edge + (int64_t)bcast_i(b.et, k0 + u) * p.ld_edge + f0);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1149,7 +1179,8 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
             if constexpr (NEED_M) {
                 float m[VEC];
                 if (src.both) {
-                    load_msg<VEC>(m, p, s, pos, f0, xd);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) m[i] = (xd[i] + t[u][i]) + t2[u][i];
                 } else {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) m[i] = xd[i] + t[u][i];
@@ -1287,7 +1318,7 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     bool from_lds = false;
     if constexpr (WIN) {
         if (wc.s_src) {          // the slot arrays are already in LDS: the gathers below are this row's FIRST memory round trip
-            b.load_lds(wc.s_src, wc.s_w, kWinSlotCap, beg - wc.e0, deg);
+            b.load_lds(wc.s_src, wc.s_w, kWinSlotCap, beg - wc.e0, deg, beg);
             my_tpos = lane_id() < deg ? wc.s_tp[beg - wc.e0 + lane_id()] : 0;
             from_lds = true;
         }
@@ -1701,7 +1732,11 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
         const bool sa_in_tower = p.agg_offset == 0 && p.n_agg == p.agg_total;     // the launch writes the whole row of every tower
         q.stage_out = (!no_stage && p.n_towers > 1 && tiles == 1 && p.n_scalers == 1 && sa_in_tower && K <= kWave * C::VEC &&
                        (size_t)wpb * p.n_towers * K * sizeof(float) <= 32768) ? 1 : 0;
-        const size_t lds = q.stage_out ? (size_t)wpb * p.n_towers * K * sizeof(float) : 0;
+        size_t lds = q.stage_out ? (size_t)wpb * p.n_towers * K * sizeof(float) : 0;
+        if (p.edge_type) {
+            q.tab_off = (int32_t)(lds / sizeof(float));
+            lds += (size_t)p.n_edge_types * p.F * sizeof(float);
+        }
         hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), lds, stream, q);
     } else {
         const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;

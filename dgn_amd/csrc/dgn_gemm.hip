@@ -20,8 +20,16 @@ int n_cus() {
 
 template <int NT>
 hipError_t launch_gemm_nt(const GemmParams& p, dim3 grid, hipStream_t st, int wkn) {
-    if (wkn) hipLaunchKernelGGL((ts_gemm<NT, 1>), grid, dim3(kWave * kWaves), 0, st, p);
-    else hipLaunchKernelGGL((ts_gemm<NT, 0>), grid, dim3(kWave * kWaves), 0, st, p);
+    const size_t lds = (size_t)2 * NT * 16 * kKS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_gemm<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_gemm<NT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (wkn) hipLaunchKernelGGL((ts_gemm<NT, 1>), grid, dim3(kWave * kWaves), lds, st, p);
+    else hipLaunchKernelGGL((ts_gemm<NT, 0>), grid, dim3(kWave * kWaves), lds, st, p);
     return hipGetLastError();
 }
 

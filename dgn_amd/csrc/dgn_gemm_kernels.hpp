@@ -22,7 +22,11 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte vector at 4-byte alignment (odd row strides)
 
 constexpr int kWaves = 8;            // ts_gemm: rows per workgroup pass = 16 * kWaves
-constexpr int kKS = 20;              // LDS row stride of a 16-k weight chunk (floats): 80 bytes, spreads the rows over the banks
+#ifndef DGN_GEMM_KC
+#define DGN_GEMM_KC 16     // 32 (half the barriers) measured 5-15 % slower: more registers, one workgroup per CU either way
+#endif
+constexpr int kKC = DGN_GEMM_KC;              // reduction columns per LDS chunk (one barrier per chunk)
+constexpr int kKS = kKC + 4;         // LDS row stride of a weight chunk (floats): spreads the rows over the banks
 constexpr int kMaxNT = 16;           // n-slice of at most 256 columns per workgroup column (128: measured 5-15 % slower)
 
 struct GemmParams {
@@ -35,28 +39,35 @@ struct GemmParams {
     int n_slice;                     // columns per blockIdx.y (a multiple of 16)
 };
 
+#ifdef DGN_GEMM_WPE
+#define DGN_GEMM_ATTR __attribute__((amdgpu_waves_per_eu(DGN_GEMM_WPE, DGN_GEMM_WPE)))
+#else
+#define DGN_GEMM_ATTR
+#endif
 template <int NT, int WKN>
-__global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
-    __shared__ float Wc[2][NT * 16 * kKS];
+__global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const GemmParams p) {
+    extern __shared__ float Wc_dyn[];
+    constexpr int kBuf = NT * 16 * kKS;                        // floats per weight-chunk buffer (two of them)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * p.n_slice;                    // first output column of this workgroup column
     const int n_here = min(NT * 16, p.n - n0);
-    const int KB = (p.k + 15) >> 4;
+    const int KB = (p.k + kKC - 1) / kKC;
     const int64_t n_blocks = (p.M + 16 * kWaves - 1) / (16 * kWaves);
 
     // chunk kc of the weights, element (r, c) = W(n0 + r, 16 kc + c), zero outside: FETCHED into registers (global -> VGPR, issued
     // before the chunk's MFMAs) and COMMITTED to Wc[buf] after them -- a load consumed by its LDS store right away would make the
     // wave sit out the L2 latency in front of every chunk's MFMAs
-    constexpr int kItems = (NT * 16 * 4 + kWave * kWaves - 1) / (kWave * kWaves);      // float4's per thread and chunk
+    constexpr int kC4 = kKC / 4;                                                        // float4's per weight row and chunk
+    constexpr int kItems = (NT * 16 * kC4 + kWave * kWaves - 1) / (kWave * kWaves);      // float4's per thread and chunk
     auto fetch = [&](f4 (&reg)[kItems], int kc) {
-        const int k0 = 16 * kc;
+        const int k0 = kKC * kc;
 #pragma unroll
         for (int j = 0; j < kItems; ++j) {
             const int it = tid + j * kWave * kWaves;
             f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (it < NT * 16 * 4) {
+            if (it < NT * 16 * kC4) {
                 if (WKN == 0) {
-                    const int r = it >> 2, c4 = (it & 3) * 4;
+                    const int r = it / kC4, c4 = (it % kC4) * 4;
                     if (r < n_here) {
                         const float* src = p.W + (int64_t)(n0 + r) * p.ldw + k0 + c4;
                         if (k0 + c4 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
@@ -81,13 +92,13 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
         }
     };
     auto commit = [&](const f4 (&reg)[kItems], int buf) {
-        float* dst = Wc[buf];
+        float* dst = Wc_dyn + buf * kBuf;
 #pragma unroll
         for (int j = 0; j < kItems; ++j) {
             const int it = tid + j * kWave * kWaves;
-            if (it < NT * 16 * 4) {
+            if (it < NT * 16 * kC4) {
                 if (WKN == 0) {
-                    const int r = it >> 2, c4 = (it & 3) * 4;
+                    const int r = it / kC4, c4 = (it % kC4) * 4;
                     *reinterpret_cast<f4*>(dst + r * kKS + c4) = reg[j];
                 } else {
                     const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
@@ -98,15 +109,22 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
         }
     };
     // this lane's four A values of chunk kc: A[row][16 kc + 4 g .. + 3]
+    constexpr int SB = kKC / 16;                                // 16-column sub-blocks (one MFMA k-group each) per chunk
+    struct AChunk { f4 v[SB]; };
     auto load_a = [&](const float* arow, int kc) {
-        const int k0 = 16 * kc + 4 * g;
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(arow + k0);
-        else {
+        AChunk a;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (k0 + j < p.k) v[j] = arow[k0 + j];
+        for (int sb = 0; sb < SB; ++sb) {
+            const int k0 = kKC * kc + 16 * sb + 4 * g;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(arow + k0);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k0 + j < p.k) v[j] = arow[k0 + j];
+            }
+            a.v[sb] = v;
         }
-        return v;
+        return a;
     };
 
     for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -125,12 +143,14 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
         f4 wreg[kItems];
         fetch(wreg, 0);
         commit(wreg, 0);
-        f4 xv = load_a(arow, 0);
+        AChunk xv = load_a(arow, 0);
         __syncthreads();
         for (int kc = 0; kc < KB; ++kc) {
-            const f4 xn = kc + 1 < KB ? load_a(arow, kc + 1) : f4{0.f, 0.f, 0.f, 0.f};      // next chunk's A and W in flight during the MFMAs
-            if (kc + 1 < KB) fetch(wreg, kc + 1);
-            const float* wl = Wc[kc & 1] + i16 * kKS + 4 * g;
+            AChunk xn = xv;
+            if (kc + 1 < KB) { xn = load_a(arow, kc + 1); fetch(wreg, kc + 1); }              // next chunk's A and W in flight during the MFMAs
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+            const float* wl = Wc_dyn + (kc & 1) * kBuf + i16 * kKS + 16 * sb + 4 * g;
             // groups of four n-tiles, s outer: consecutive MFMAs go to different accumulators (back-to-back MFMAs on one accumulator
             // wait for each other), and only four weight operands are live at a time
 #pragma unroll
@@ -143,7 +163,8 @@ __global__ __launch_bounds__(kWave * kWaves) void ts_gemm(const GemmParams p) {
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (q0 + j < NT) acc[q0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][s], xv[s], acc[q0 + j], 0, 0, 0);
+                        if (q0 + j < NT) acc[q0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][s], xv.v[sb][s], acc[q0 + j], 0, 0, 0);
+            }
             }
             xv = xn;
             if (kc + 1 < KB) commit(wreg, (kc + 1) & 1);

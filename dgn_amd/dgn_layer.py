@@ -110,9 +110,42 @@ def _slot_dst(graph: DGNGraph) -> torch.Tensor:
     return graph._dst_slots
 
 
+class EdgeTypeFeatures:
+    """Edge features that are an embedding lookup -- ``e = embedding_e(bond_type)`` in the reference's nets
+    (nets/molecules_graph_regression/dgn_net.py:53,75) -- handed to the layers as (table, types) instead of the gathered [E, edge_dim]
+    tensor: ``table`` [K, edge_dim] (e.g. ``embedding_e.weight``), ``types`` [E] integer edge types in the graph's edge order.  A layer
+    whose pretrans is one affine map then adds row ``types[j]`` of the K x F table ``table W_e^T`` inside the sweep (the table lives in
+    LDS): no [E, F] edge term is written or read, and the table's gradient is a reduction of the per-edge gradient rows the backward
+    stages anyway.  Layers that cannot use the table (other pretrans depths, tables over ops.MAX_EDGE_TABLE floats) gather it."""
+
+    def __init__(self, table: torch.Tensor, types: torch.Tensor):
+        if table.dim() != 2 or types.dim() != 1:
+            raise ValueError("EdgeTypeFeatures: table [K, edge_dim], types [E]")
+        self.table, self.types = table, types
+
+    def dense(self) -> torch.Tensor:
+        return self.table.index_select(0, self.types.long())
+
+    def slot_types(self, graph: DGNGraph) -> torch.Tensor:
+        return graph.to_slot_order(self.types).to(torch.int32).contiguous()
+
+
+def _edge_term(graph: DGNGraph, e, w_edge):
+    """(m_edge, edge_type) of the pretrans Linear's edge-feature block: the [E, F] rows ef W_e^T in CSR slot order, or -- for
+    EdgeTypeFeatures -- the [K, F] table and the slots' types."""
+    if isinstance(e, EdgeTypeFeatures):
+        Fm = w_edge.shape[0]
+        det = (Fm % 2 == 0) if _ops.DETERMINISTIC_BACKWARD == "auto" else bool(_ops.DETERMINISTIC_BACKWARD)
+        if e.table.shape[0] * Fm <= _ops.MAX_EDGE_TABLE and det:
+            return F.linear(e.table, w_edge), e.slot_types(graph)
+        e = e.dense()
+    # the permuted copy is edge_dim floats per edge (40 B), the product runs on the streaming Linear kernels (k = edge_dim)
+    return node_linear(graph.to_slot_order(e), w_edge), None
+
+
 def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
-    """(x_pair, m_edge) such that m_j = P[src_j] + Q[i] + m_edge[j] with x_pair = P | Q [N, 2*in] equals
-    pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80."""
+    """(x_pair, m_edge, edge_type) such that m_j = P[src_j] + Q[i] + m_edge[j] (or + m_edge[edge_type[j]]) with
+    x_pair = P | Q [N, 2*in] equals pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80."""
     if pretrans.is_single_affine():
         lin = pretrans.fully_connected[0].linear
         W = lin.weight                                     # [in, 2*in (+edge_dim)]
@@ -120,15 +153,13 @@ def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
         w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
         b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
         pq = node_linear(h, w_sd, b_sd)                    # [N, 2*in]: P | Q
-        # edge term R = ef W_e^T in CSR slot order: the permuted copy is edge_dim floats per edge (40 B), the product runs on
-        # the streaming Linear kernels (k = edge_dim), not on a library GEMM
-        m_edge = node_linear(graph.to_slot_order(e), W[:, 2 * in_dim:]) if edge_features else None
-        return pq, m_edge
+        m_edge, edge_type = _edge_term(graph, e, W[:, 2 * in_dim:]) if edge_features else (None, None)
+        return pq, m_edge, edge_type
     # general pretrans (ReLU between layers): materialise the messages, directly in slot order
     z = [h.index_select(0, graph.src.long()), h.index_select(0, _slot_dst(graph))]
     if edge_features:
-        z.append(graph.to_slot_order(e))
-    return None, pretrans(torch.cat(z, dim=1))
+        z.append(graph.to_slot_order(e.dense() if isinstance(e, EdgeTypeFeatures) else e))
+    return None, pretrans(torch.cat(z, dim=1)), None
 
 
 def _scale_table(graph: DGNGraph, kinds, avg_log: float) -> torch.Tensor:
@@ -301,9 +332,9 @@ class DGNLayerComplex(nn.Module):
     def aggregate(self, g, h, e, plan=None, eig=None):
         eig = g.ndata["eig"] if eig is None else eig           # (the caller's current eig, see DGNLayerSimple.aggregate)
         graph = as_dgn_graph(g, h.device)
-        x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        x_pair, m_edge, edge_type = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
         return directional_aggregate(graph, plan or self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge,
-                                     x_in=h, eig=eig)
+                                     x_in=h, eig=eig, edge_type=edge_type)
 
     def forward(self, g, h, e, snorm_n):
         # (a batch padded to a fixed row capacity carries its valid-row count as a device scalar: BatchNorm must know, ops.padded_rows)
@@ -361,9 +392,9 @@ class DGNTower(nn.Module):
     def forward(self, g, h, e, snorm_n):
         graph = as_dgn_graph(g, h.device)
         h = h.contiguous()
-        x_pair, m_edge = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        x_pair, m_edge, edge_type = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
         agg = directional_aggregate(graph, self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge, x_in=h,
-                                    eig=g.ndata["eig"])
+                                    eig=g.ndata["eig"], edge_type=edge_type)
         h = _posttrans_split(self.posttrans, h, agg, self.in_dim)
         if self.graph_norm:
             h = h * snorm_n
@@ -535,7 +566,7 @@ class DGNLayerTower(nn.Module):
         ops = self._operands(h.device)
         x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)
         pq = node_linear(h, ops["w_sd"], ops["bias_sd"])                                            # [N, 2*Fm]: P | Q
-        m_edge = node_linear(graph.to_slot_order(e), ops["w_edge"]) if self.edge_features else None          # R = ef W_e^T, slot order
+        m_edge, edge_type = _edge_term(graph, e, ops["w_edge"]) if self.edge_features else (None, None)      # R = ef W_e^T, slot order
         b_p = ops["b_p"]
         S = self.plan.n_scalers
         N = h.shape[0]
@@ -561,7 +592,7 @@ class DGNLayerTower(nn.Module):
                         y = bn_tail(y, bns, self.training)
                 return F.dropout(y, self.dropout, training=self.training)
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
-                                         eig=g.ndata["eig"], n_towers=T, tower_major=True)
+                                         eig=g.ndata["eig"], n_towers=T, tower_major=True, edge_type=edge_type)
             bns = [t.batchnorm_h for t in self.towers]
             fused_tail = self.batch_norm and self.training and bn_tail_supported(bns, aggx, True, T * fo)
             if fused_tail and linear_combine_supported(aggx, ops["w"], S):
@@ -577,7 +608,7 @@ class DGNLayerTower(nn.Module):
             y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,
-                                        x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True)   # [T, N, A*fi]
+                                        x_in=x_in, eig=g.ndata["eig"], n_towers=T, tower_major=True, edge_type=edge_type)   # [T, N, A*fi]
             z = node_linear(agg, ops["w_a"])                                                       # [T, N, S*fo]
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             y = scale_combine(z, sc, b_p, None)

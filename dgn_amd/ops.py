@@ -91,13 +91,18 @@ def _ld(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else (t.stride(0) if t.shape[0] > 1 else t.shape[1])
 
 
-def _msg_struct(F, x_src, x_dst, m_edge, x_in):
+MAX_EDGE_TABLE = 8192      # include/dgn_hip.h: DGN_MAX_EDGE_TABLE (floats of an edge-type table)
+
+
+def _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type=None):
     m = _lib.DgnMsg()
     m.F = F
     m.x_src, m.ld_src = _ptr(x_src), _ld(x_src)
     m.x_dst, m.ld_dst = _ptr(x_dst), _ld(x_dst)
     m.m_edge, m.ld_edge = _ptr(m_edge), _ld(m_edge)
     m.x_in, m.ld_in = _ptr(x_in), _ld(x_in)
+    if edge_type is not None:
+        m.edge_type, m.n_edge_types = edge_type.data_ptr(), m_edge.shape[0]
     return m
 
 
@@ -109,15 +114,16 @@ def _out_layout(t: torch.Tensor):
     return 0, t.stride(0)
 
 
-def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out):
-    """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream."""
+def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out, edge_type=None):
+    """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream.  ``edge_type`` (int32 [E], CSR slot
+    order): ``m_edge`` is a [K, F] table and slot j adds row ``edge_type[j]``."""
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
     F = ref.shape[1]
     stream = torch.cuda.current_stream(ref.device).cuda_stream
     tower_stride, ld_out = _out_layout(out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
-    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
     g = graph.c_graph
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
@@ -129,7 +135,7 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
 
 
 def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, g_out,
-                    g_src, g_dst, g_edge, g_in, accumulate: bool = True):
+                    g_src, g_dst, g_edge, g_in, accumulate: bool = True, edge_type=None):
     """Enqueue dgn_agg_backward.  ``accumulate=False``: the sinks g_src/g_dst/g_in may be uninitialised, the first
     launch of the plan defines them and later launches add; ``True``: every launch adds.  g_edge is overwritten."""
     lib = _lib.load()
@@ -141,7 +147,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     grads.g_dst, grads.ld_dst = _ptr(g_dst), _ld(g_dst)
     grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
     grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
-    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
     stream = torch.cuda.current_stream(dev).cuda_stream
     tower_stride, ld_gout = _out_layout(g_out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
@@ -149,12 +155,16 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     first = True
     deterministic = (F % 2 == 0) if DETERMINISTIC_BACKWARD == "auto" else bool(DETERMINISTIC_BACKWARD)
     deterministic = deterministic and g_src is not None
+    if edge_type is not None and not deterministic:
+        raise _lib.DgnError("edge-type table: the backward needs the two-phase scatter (even F, a gradient for x_src)")
     if deterministic:
         graph.ensure_csc()
         use_windows = bool(WINDOW_BACKWARD) and (WINDOW_BACKWARD == "all" or g_dst is None)
         g = graph.c_graph if use_windows else graph.c_graph_no_windows
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
+        if edge_type is not None:
+            nbytes += lib.dgn_agg_edge_table_workspace_bytes(F, m_edge.shape[0])
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
         wl = w[l.ch_offset:] if (w is not None and l.channels) else None
         tmp = None
@@ -181,7 +191,7 @@ def _empty_rows(x: torch.Tensor) -> torch.Tensor:
 class _DirectionalAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in,
-                xin_is_src: bool, tower_major: bool = False, x_pair=None):
+                xin_is_src: bool, tower_major: bool = False, x_pair=None, edge_type=None):
         lib = _lib.load()
         if x_pair is not None:       # [N, 2F] = x_src | x_dst in one tensor: one gradient tensor comes back
             half = x_pair.shape[1] // 2
@@ -193,7 +203,16 @@ class _DirectionalAggregate(torch.autograd.Function):
         N, E = graph.num_nodes, graph.num_edges
         _check(x_src, "x_src", graph.num_src, F)
         _check(x_dst, "x_dst", N, F)
-        _check(m_edge, "m_edge", E, F)
+        if edge_type is not None:
+            if m_edge is None or x_src is None:
+                raise ValueError("edge_type needs the table (m_edge [K, F]) and x_src")
+            if edge_type.dtype != torch.int32 or edge_type.shape != (E,) or not edge_type.is_contiguous() or not edge_type.is_cuda:
+                raise ValueError(f"edge_type: expected a contiguous CUDA int32 [{E}] in CSR slot order")
+            if m_edge.shape[0] * F > MAX_EDGE_TABLE:
+                raise ValueError(f"edge-type table of {m_edge.shape[0]} x {F} floats > {MAX_EDGE_TABLE}: pass the gathered rows instead")
+            _check(m_edge, "m_edge (edge-type table)", m_edge.shape[0], F)
+        else:
+            _check(m_edge, "m_edge", E, F)
         if xin_is_src:
             x_in = x_src
         _check(x_in, "x_in", N, F)
@@ -205,7 +224,8 @@ class _DirectionalAggregate(torch.autograd.Function):
             out = torch.empty((n_towers, N, plan.out_width(F) // n_towers), dtype=torch.float32, device=ref.device)
         else:
             out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
-        launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out)
+        launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out, edge_type)
+        ctx.edge_type = edge_type
         ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
         ctx.paired = x_pair is not None
         if ctx.paired:
@@ -243,37 +263,40 @@ class _DirectionalAggregate(torch.autograd.Function):
         else:
             g_in = _empty_rows(x_in) if (x_in is not None and need_in and plan.needs_x_in()) else None
         # the sinks are DEFINED by the call (accumulate = 0): no zero-fill, every row is written exactly once
+        if ctx.edge_type is not None and g_src is None:
+            g_src = _empty_rows(x_src)               # (the table's gradient is a reduction of the staged per-edge rows)
         launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in,
-                        accumulate=False)
+                        accumulate=False, edge_type=ctx.edge_type)
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
         if ctx.paired:
-            return (None, None, None, None, None, None, None, g_edge, None if ctx.xin_is_src else g_in, None, None, g_pair)
+            return (None, None, None, None, None, None, None, g_edge, None if ctx.xin_is_src else g_in, None, None, g_pair, None)
         return (None, None, None, None, None, g_src if (need_src or ctx.xin_is_src) else None, g_dst, g_edge,
-                None if ctx.xin_is_src else g_in, None, None, None)
+                None if ctx.xin_is_src else g_in, None, None, None, None)
 
 
 def directional_aggregate(graph: DGNGraph, plan: AggPlan, avg_log, x_src: Optional[torch.Tensor] = None,
                           x_dst: Optional[torch.Tensor] = None, m_edge: Optional[torch.Tensor] = None,
                           x_in: Optional[torch.Tensor] = None, eig: Optional[torch.Tensor] = None,
                           n_towers: int = 1, weights: Optional[torch.Tensor] = None, tower_major: bool = False,
-                          x_pair: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          x_pair: Optional[torch.Tensor] = None, edge_type: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out [N, T*S*A*(F/T)] (or, with ``tower_major``, [T, N, S*A*(F/T)] so that the per-tower batched GEMMs that
     follow read contiguous matrices): every aggregator of ``plan`` x every applied scaler over the messages
     ``m_j = x_src[src_j] + x_dst[i] + m_edge[j]`` (``m_edge`` in CSR slot order, see
     ``DGNGraph.to_slot_order``).  ``x_in`` is ``h_in`` of the reference's reduce_func; if it is the
     same tensor as ``x_src`` (simple layer) both gradients land in one buffer.  ``x_pair [N, 2F]`` gives
     ``x_src | x_dst`` as the column halves of one tensor (the P|Q GEMM output of the complex/towers layers) and
-    gets ONE gradient tensor back."""
+    gets ONE gradient tensor back.  ``edge_type`` (int32 [E], CSR slot order): ``m_edge`` is a table [K, F] and slot j adds row
+    ``edge_type[j]`` (edge features that are an embedding lookup: no [E, F] tensor is ever formed; the table gets its gradient)."""
     avg = float(avg_log.item()) if torch.is_tensor(avg_log) else float(avg_log)
     w = weights if weights is not None else graph.edge_weights(plan, eig)
     if x_pair is not None:
         if x_src is not None or x_dst is not None:
             raise ValueError("x_pair replaces x_src and x_dst")
-        return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, None, None, m_edge, x_in, False, tower_major, x_pair)
+        return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, None, None, m_edge, x_in, False, tower_major, x_pair, edge_type)
     xin_is_src = x_in is not None and x_in is x_src
     return _DirectionalAggregate.apply(graph, plan, n_towers, avg, w, x_src, x_dst, m_edge,
-                                       None if xin_is_src else x_in, xin_is_src, tower_major)
+                                       None if xin_is_src else x_in, xin_is_src, tower_major, None, edge_type)
 
 
 class _ScaleCombine(torch.autograd.Function):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 16
+#define DGN_ABI_VERSION 17
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -170,7 +170,15 @@ typedef struct DgnMsg {
     const float* x_dst;  int64_t ld_dst;   /* [n_nodes, ld_dst]                                  */
     const float* m_edge; int64_t ld_edge;  /* [n_edges, ld_edge], CSR slot order                 */
     const float* x_in;   int64_t ld_in;    /* [n_nodes, ld_in]                                   */
+    /* Edge-TYPE table (optional; needs x_src): with edge_type != NULL, m_edge is a table [n_edge_types, ld_edge] and slot j
+     * adds row edge_type[j] (values in 0 .. n_edge_types-1, CSR slot order) -- the edge-feature term of the pretrans Linear when
+     * the edge features are an embedding lookup (nets/molecules_graph_regression/dgn_net.py:53,75: e = embedding_e(bond type);
+     * dgn_layer.py:159-160: pretrans(cat[h_src, h_dst, e])): the caller passes table = embedding W_e^T instead of materialising
+     * [n_edges, F].  n_edge_types * F <= DGN_MAX_EDGE_TABLE floats.  The backward then needs the two-phase scatter (g->csc_*
+     * and a workspace that includes dgn_agg_edge_table_workspace_bytes()); DgnMsgGrad.g_edge is the TABLE's gradient.       */
+    const int32_t* edge_type; int32_t n_edge_types;
 } DgnMsg;
+#define DGN_MAX_EDGE_TABLE 8192
 
 /* Gradient sinks of dgn_agg_backward; NULL = not wanted.  g_edge is always overwritten.  g_src / g_dst / g_in:
  *   accumulate != 0: the call ADDS into caller-initialised buffers (a plan split into several launches, or a
@@ -213,6 +221,8 @@ int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg
  * Workspace: dgn_agg_backward_workspace_bytes(); with `deterministic` != 0 (needs g->csc_*) it includes the
  * [n_edges, F] staging buffer of the two-phase scatter; a smaller workspace silently selects the atomic path. */
 size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t deterministic);
+/* extra workspace bytes of dgn_agg_backward when DgnMsg.edge_type is set (appended to the deterministic workspace) */
+size_t dgn_agg_edge_table_workspace_bytes(int64_t F, int32_t n_edge_types);
 int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                      const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                      void* ws, size_t ws_bytes, void* stream);

@@ -7,7 +7,7 @@ from oracle import dgn_oracle as orc
 
 
 def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m_edge=None, x_in=None, eig=None,
-                                 n_towers=1, weights=None, tower_major=False, x_pair=None):
+                                 n_towers=1, weights=None, tower_major=False, x_pair=None, edge_type=None):
     if x_pair is not None:
         half = x_pair.shape[1] // 2
         x_src, x_dst = x_pair[:, :half], x_pair[:, half:]
@@ -19,7 +19,7 @@ def oracle_directional_aggregate(graph, plan, avg_log, x_src=None, x_dst=None, m
     if x_dst is not None:
         msg = msg + x_dst[dst]
     if m_edge is not None:
-        msg = msg + m_edge
+        msg = msg + (m_edge if edge_type is None else m_edge[edge_type.long()])
     eig = graph.ndata["eig"] if eig is None else eig
     F_ = msg.shape[1]
     if x_in is None:

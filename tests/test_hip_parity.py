@@ -377,6 +377,114 @@ def test_three_term_message_vs_oracle():
         _close(a, b, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize("case", ["molecules", "molecules_towers", "long_rows", "hub", "split_plan"])
+def test_edge_type_table_equals_gathered_rows_and_oracle(case):
+    """m_edge as a [K, F] table + per-slot types (DgnMsg.edge_type) against (1) the same call with the gathered [E, F] rows --
+    forward and the node gradients bit-equal, the table's gradient = the rows' gradient summed by type -- and (2) the oracle."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.ops import directional_aggregate
+    from oracle import dgn_oracle as orc
+    gen = torch.Generator().manual_seed(11)
+    K, n_towers, kw = 5, 1, {}
+    aggs, scalers = ["mean", "max", "std", "dir1-dx", "dir1-av"], ["identity", "amplification"]
+    if case.startswith("molecules"):
+        b = synth.molecule_batch(60, seed=3, laplacian_eig=False)
+        src, dst, N, F_ = b["src"], b["dst"], int(b["num_nodes"]), 70
+        eig = b["eig"]
+        if case == "molecules_towers":
+            n_towers, scalers = 5, ["identity"]
+    else:
+        N, E, F_ = 41, 600, 12
+        src, dst = _random_graph(5, N, E)
+        eig = torch.randn(N, 4, generator=gen)
+        if case == "hub":
+            kw = dict(hub_threshold=16, hub_chunk=7)
+        if case == "split_plan":
+            aggs = ALL_AGGS
+    E = src.numel()
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev), **kw)
+    assert (graph.n_hub > 0) == (case == "hub")
+    plan = dgn_amd.make_plan(aggs, scalers)
+    P, Q, x = (torch.randn(N, F_, generator=gen) for _ in range(3))
+    table = torch.randn(K, F_, generator=gen)
+    types = torch.randint(0, K, (E,), generator=gen)
+    types_slot = graph.to_slot_order(types.to(dev)).to(torch.int32).contiguous()
+    tower_major = n_towers > 1
+
+    def run(table_mode):
+        leaves = [t.to(dev).requires_grad_(True) for t in (P, Q, table, x)]
+        pq = torch.cat([leaves[0], leaves[1]], dim=1)
+        if table_mode:
+            y = directional_aggregate(graph, plan, 0.9, x_pair=pq, m_edge=leaves[2], x_in=leaves[3], edge_type=types_slot,
+                                      n_towers=n_towers, tower_major=tower_major)
+        else:
+            rows = leaves[2].index_select(0, types_slot.long())                       # [E, F] in slot order
+            y = directional_aggregate(graph, plan, 0.9, x_pair=pq, m_edge=rows, x_in=leaves[3], n_towers=n_towers, tower_major=tower_major)
+        ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        return y.detach(), torch.autograd.grad(y, leaves, ct), ct
+
+    y_t, g_t, ct = run(True)
+    y_d, g_d, _ = run(False)
+    assert torch.equal(y_t, y_d)
+    for i in (0, 1, 3):
+        if case == "hub":                                   # (hub slices add their row gradients with atomics: order varies run to run)
+            _close(g_t[i], g_d[i], 1e-5, 1e-5 * float(g_d[i].abs().max()))
+        else:
+            assert torch.equal(g_t[i], g_d[i])
+    _close(g_t[2], g_d[2], 1e-4, 1e-4 * float(g_d[2].abs().max()))
+    if n_towers == 1:
+        refs = []
+        for dt in (torch.float32, torch.float64):
+            lo = [t.clone().to(dt).requires_grad_(True) for t in (P, Q, table, x)]
+            yo = orc.aggregate_graph(src, dst, N, lo[0][src] + lo[1][dst] + lo[2][types], eig.to(dt), lo[3], aggs, scalers, torch.tensor(0.9, dtype=dt))
+            refs.append((yo.detach(), torch.autograd.grad(yo, lo, ct.cpu().to(dt))))
+        _as_good(y_t, refs[0][0], refs[1][0], 1e-4, 1e-4)                     # (std of near-constant rows: see _as_good)
+        for a, b32, b64 in zip(g_t, refs[0][1], refs[1][1]):
+            _as_good(a, b32, b64, 2e-4, 2e-4)
+
+
+def test_edge_type_features_layer_equals_embedding_lookup():
+    """DGNLayer (towers and complex) fed EdgeTypeFeatures(table, types) vs the same layer fed the gathered embedding rows
+    (what dgn_net.py:75 hands the reference layer): same output, same parameter / input gradients, and a gradient for the table."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    b = synth.molecule_batch(50, seed=4, laplacian_eig=False)
+    N, E = int(b["num_nodes"]), b["src"].numel()
+    gen = torch.Generator().manual_seed(2)
+    types = torch.randint(0, 4, (E,), generator=gen).to(dev)
+    for type_net, towers in (("towers", 5), ("complex", 1)):
+        torch.manual_seed(0)
+        layer = dgn_amd.DGNLayer(70, 70, 0.0, True, True, "mean max std dir1-dx dir1-av", "identity amplification", {"log": torch.tensor(1.2)},
+                                 type_net, True, towers=towers, divide_input=True, edge_features=True, edge_dim=10).model.to(dev).train()
+        graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+        h0 = torch.randn(N, 70, generator=gen).to(dev)
+        emb0 = torch.randn(4, 10, generator=gen).to(dev)
+        snorm = b["snorm_n"].to(dev)
+        ct = torch.randn(N, 70, generator=gen).to(dev)
+        outs = []
+        for mode in ("table", "rows"):
+            h, emb = h0.clone().requires_grad_(True), emb0.clone().requires_grad_(True)
+            e = dgn_amd.EdgeTypeFeatures(emb, types) if mode == "table" else emb.index_select(0, types)
+            for p_ in layer.parameters():
+                p_.grad = None
+            for m in layer.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            y = layer(graph, h, e, snorm)
+            y.backward(ct)
+            outs.append((y.detach(), h.grad, emb.grad, [p_.grad.clone() for p_ in layer.parameters() if p_.grad is not None]))
+        (y1, gh1, ge1, gp1), (y2, gh2, ge2, gp2) = outs
+        _close(y1, y2, 1e-5, 1e-5)
+        _close(gh1, gh2, 1e-4, 1e-5)
+        _close(ge1, ge2, 1e-4, 1e-4 * float(ge2.abs().max()))
+        assert len(gp1) == len(gp2)
+        for a, b_ in zip(gp1, gp2):
+            _close(a, b_, 1e-4, 1e-4 * max(1e-3, float(b_.abs().max())))
+
+
 def test_empty_and_edgeless_graphs():
     dev = _dev()
     import dgn_amd
