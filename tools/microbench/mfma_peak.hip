@@ -1,0 +1,45 @@
+// Sustained rate of v_mfma_f32_16x16x4_f32 (the exact-fp32 MFMA every Linear kernel of this library uses) with nothing else going on:
+// W waves per SIMD, each issuing ACC independent accumulator chains.  Prints TFLOP/s and the implied cycles per MFMA at 2.4 GHz.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+using f4 = __attribute__((ext_vector_type(4))) float;
+template <int ACC>
+__global__ __launch_bounds__(1024) void spin(float* out, int iters) {
+    f4 acc[ACC];
+#pragma unroll
+    for (int q = 0; q < ACC; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + blockIdx.x * 1e-6f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q = 0; q < ACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < ACC; ++q) r += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (r == 12345.678f) out[0] = r;
+}
+template <int ACC>
+void run(int waves_per_simd, int iters) {
+    float* out; hipMalloc(&out, 4);
+    const int threads = 64 * 4 * waves_per_simd > 1024 ? 1024 : 64 * 4 * waves_per_simd;
+    const int blocks = 256 * (64 * 4 * waves_per_simd / threads);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(spin<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(spin<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double mfmas = (double)blocks * (threads / 64) * iters * 4.0 * ACC;
+    const double tf = mfmas * 2048 / (ms * 1e-3) / 1e12;
+    printf("ACC=%d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s  (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", ACC, waves_per_simd, ms, tf,
+           1024.0 * 2.4e9 * ms * 1e-3 / mfmas);
+    hipFree(out);
+}
+int main() {
+    for (int w : {1, 2, 4}) { run<3>(w, 20000); run<9>(w, 8000); }
+    run<9>(4, 200000);      // ~0.3 s: sustained
+    return 0;
+}
