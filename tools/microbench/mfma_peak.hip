@@ -4,6 +4,27 @@
 #include <cstdio>
 #include <cstdlib>
 using f4 = __attribute__((ext_vector_type(4))) float;
+// the same with operands that change every iteration and differ per lane (random mantissas, exponents near 1): data-dependent power
+template <int ACC>
+__global__ __launch_bounds__(1024) void spin_data(float* out, int iters) {
+    f4 acc[ACC];
+#pragma unroll
+    for (int q = 0; q < ACC; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    unsigned h = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h = h * 1664525u + 1013904223u;
+            const float a = __uint_as_float(0x3f800000u | (h >> 9)) - 1.5f, b = __uint_as_float(0x3f800000u | ((h * 2246822519u) >> 9)) - 1.5f;
+#pragma unroll
+            for (int q = 0; q < ACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+        }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < ACC; ++q) r += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (r == 12345.678f) out[0] = r;
+}
 template <int ACC>
 __global__ __launch_bounds__(1024) void spin(float* out, int iters) {
     f4 acc[ACC];
@@ -22,24 +43,31 @@ __global__ __launch_bounds__(1024) void spin(float* out, int iters) {
     if (r == 12345.678f) out[0] = r;
 }
 template <int ACC>
-void run(int waves_per_simd, int iters) {
+void run(int waves_per_simd, int iters, bool data = false) {
     float* out; hipMalloc(&out, 4);
     const int threads = 64 * 4 * waves_per_simd > 1024 ? 1024 : 64 * 4 * waves_per_simd;
     const int blocks = 256 * (64 * 4 * waves_per_simd / threads);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(spin<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    auto launch = [&]() {
+        if (data) hipLaunchKernelGGL(spin_data<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+        else hipLaunchKernelGGL(spin<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    };
+    launch();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(spin<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    for (int r = 0; r < 5; ++r) launch();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     const double mfmas = (double)blocks * (threads / 64) * iters * 4.0 * ACC;
     const double tf = mfmas * 2048 / (ms * 1e-3) / 1e12;
-    printf("ACC=%d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s  (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", ACC, waves_per_simd, ms, tf,
+    printf("%s ACC=%d waves/SIMD=%d: %.3f ms  %.1f TFLOP/s  (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", data ? "random operands  " : "constant operands", ACC, waves_per_simd, ms, tf,
            1024.0 * 2.4e9 * ms * 1e-3 / mfmas);
     hipFree(out);
 }
 int main() {
     for (int w : {1, 2, 4}) { run<3>(w, 20000); run<9>(w, 8000); }
     run<9>(4, 200000);      // ~0.3 s: sustained
+    run<9>(2, 8000, true);
+    run<9>(4, 8000, true);
+    run<9>(4, 200000, true);
     return 0;
 }
