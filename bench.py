@@ -400,10 +400,11 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
                "ew_rows": dict(ms=ms_w, bytes=bw, GBps=bw / ms_w / 1e6, frac=bw / (ms_w * 1e-3) / HBM_PEAK)}
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
-    # rows) or agg_fwd_rows; backward = agg_bwd_rows + seg_sum_rows (second phase of the atomic-free scatter)
-    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "seg_sum_rows"]}[dom]
+    # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
+    # atomic-free scatter)
+    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "agg_bwd_window", "seg_sum_rows"]}[dom]
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
-             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_rows + seg_sum_rows)"}[dom]
+             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_short | agg_bwd_rows, + seg_sum_rows)"}[dom]
     triad = hbm_triad_GBps(dev)
     # The launched list carries the h_in pass-through block of the complex / towers layers as one more "aggregator"
     # (A = survey's A + 1: the sweep really writes that block).  The same launch priced with SURVEY 8(d)'s own A:

@@ -1374,20 +1374,12 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     }
 }
 
-template <class C, class O = DynOps>
-__global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
-    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
+// the backward of ONE destination row, any in-degree (what a wave of agg_bwd_rows does)
+template <class C, class O>
+__device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0, bool active) {
     constexpr int VEC = C::VEC;
-    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
-    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
-    if (lb < 0) return;
-    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
-    if (row64 >= p.n_nodes) return;
-    const int row = uniform_i((int)row64);
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
-    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
-    const bool active = f0 < p.F;
     if (deg > p.hub_threshold || deg == 0) {
         // hub row: the slice kernels own it (they add with atomics: in fresh mode this kernel zeroes the row first).
         // Row without messages: no gradient -- except through the x_in pass-through block.
@@ -1450,6 +1442,168 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
     if (active) make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
+}
+
+template <class C, class O = DynOps>
+__global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
+    const int wpb = blockDim.x >> 6;   // 1 (long rows: a finished row frees its slot at once) or 4 (short rows: dispatch-rate bound)
+    constexpr int VEC = C::VEC;
+    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t row64 = lb * wpb + (threadIdx.x >> 6);
+    if (row64 >= p.n_nodes) return;
+    const int row = uniform_i((int)row64);
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    bwd_any_row<C, O>(p, row, f0, f0 < p.F);
+}
+
+// RB consecutive rows per wave when every one of them has 1..kShortDeg in-edges (molecule batches): ONE row-pointer load and ONE
+// slot batch serve the group, and the upstream-gradient blocks, side rows and source gathers of ALL its rows are in flight together
+// before the first row is worked on.  agg_bwd_rows keeps one row per wave in flight: three dependent round trips (row pointer ->
+// slot batch -> gathers) per row at four waves per SIMD, which is what bounds it on such graphs.  Same
+// arithmetic in the same order as bwd_row_one_batch: bit-identical gradients.  Groups with a longer / empty / hub row, partial
+// groups, and launches outside the fast case (dynamic lists, several scalers, accumulate mode, an m_edge term, the atomic scatter)
+// take the per-row routine.
+template <class C, class O, int RB>
+__global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
+    constexpr int VEC = C::VEC, J = kShortDeg;
+    const int wpb = blockDim.x >> 6;
+    const int64_t n_groups = (p.n_nodes + RB - 1) / RB;
+    const int64_t n_blocks = (n_groups + wpb - 1) / wpb;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t g64 = lb * wpb + (threadIdx.x >> 6);
+    if (g64 >= n_groups) return;
+    const int row0 = uniform_i((int)(g64 * RB));
+    const int nrows = (int)min((int64_t)RB, p.n_nodes - row0);
+    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
+    const bool active = f0 < p.F;
+    constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
+    constexpr bool PRE = O::kStatic && NG <= 8;
+    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.m_edge && !p.g_edge;
+    const bool recomp = (p.need & NEED_RECOMP) != 0;     // (otherwise only sum_j w_jc is needed: no gathers at all)
+    int lo[RB], deg[RB], beg0 = 0;
+    if (fast) {
+        const int ipv = p.indptr[row0 + min(lane_id(), RB)];
+        beg0 = bcast_i(ipv, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            lo[r] = bcast_i(ipv, r) - beg0;
+            deg[r] = bcast_i(ipv, r + 1) - beg0 - lo[r];
+            fast = fast && deg[r] >= 1 && deg[r] <= J;
+        }
+    }
+    if (!fast) {
+        for (int r = 0; r < nrows; ++r) bwd_any_row<C, O>(p, row0 + r, f0, active);
+        return;
+    }
+    if constexpr (PRE) {
+        const int total = lo[RB - 1] + deg[RB - 1];
+        SlotBatch<C::NCH, C::NW> b;
+        b.load(p, beg0, beg0 + total);
+        const int my_tpos = lane_id() < total ? p.csc_pos[beg0 + lane_id()] : 0;
+        if (!active) return;
+        // every load of the group, issued before anything is consumed
+        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[RB][NG][VEC], t[RB][J][VEC];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = row0 + r;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { xd[r][i] = 0.f; xin[r][i] = 0.f; }
+            logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
+            if (p.x_dst) ldv<VEC>(xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0);
+            if (p.need & NEED_XIN) ldv<VEC>(xin[r], p.x_in + (int64_t)row * p.ld_in + f0);
+            const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+#pragma unroll
+            for (int sc = 0; sc < O::kNS; ++sc)
+#pragma unroll
+                for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[r][sc * O::NA + a], grow + sa_col(p, sc, a));
+        }
+        if (recomp) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+                    if (j < deg[r]) ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+            }
+        }
+        const bool need_m = C::STATS && (p.need & NEED_M_EMIT) != 0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            Acc<C, true> acc;
+            acc.init();
+            if (recomp) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    if (j < deg[r]) {
+                        float mm[VEC], wk[C::NW];
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) mm[i] = xd[r][i] + t[r][j][i];
+                        b.weights(wk, lo[r] + j);
+                        acc.add(mm, wk, beg0 + lo[r] + j);
+                    }
+                }
+            } else {
+                // sum_j w_jc in the order of wave_sum over a batch that holds this row alone: (w0 + w2) + (w1 + w3)
+                static_assert(J == 4, "the summation tree below is wave_sum's for four slots");
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) {
+                    float wj[J];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) wj[j] = j < deg[r] ? bcast_f(b.w[c], lo[r] + j) : 0.f;
+                    acc.sw[c] = (wj[0] + wj[2]) + (wj[1] + wj[3]);
+                }
+            }
+            Coef<C> k;
+            float gxin[VEC], rsum[VEC];
+            make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int sc, float (&g)[VEC]) {
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    if (q == sc * O::NA + a) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) g[i] = gpre[r][q][i];
+                    }
+                }
+            }, deg[r], xin[r], logd[r]);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (j < deg[r]) {
+                    const int l = lo[r] + j, pos = beg0 + l;
+                    float wk[C::NW], gm[VEC];
+                    b.weights(wk, l);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gm[i] = k.c0[i];
+                    if (need_m) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gm[i] = fmaf(k.cv[i], xd[r][i] + t[r][j][i], gm[i]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C::NCH; ++c) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gm[i] = fmaf(wk[c], k.cs[c][i], gm[i]);
+                        if constexpr (C::AV) {
+                            const float a = fabsf(wk[c]);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) gm[i] = fmaf(a, k.ca[c][i], gm[i]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        if constexpr (C::STATS) {
+                            if (k.amax[i] == pos) gm[i] += k.gmax[i];
+                            if (k.amin[i] == pos) gm[i] += k.gmin[i];
+                        }
+                        rsum[i] += gm[i];
+                    }
+                    stv<VEC>(p.stage + (int64_t)bcast_i(my_tpos, l) * p.F + f0, gm);
+                }
+            }
+            add_row_grads<VEC>(p, row0 + r, f0, rsum, gxin, true, true);
+        }
+    }
 }
 
 // hub backward, phase 2: merge slice partials, build the row's coefficient vectors, park them
@@ -1712,6 +1866,8 @@ inline int row_waves_per_block(const AggParams& p) {
     return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
 }
 
+constexpr int kBwdShortRows = 4;     // rows per wave of agg_bwd_short (2 and 4 are instantiated; DGN_BWD_ROWS_PER_WAVE=1 selects agg_bwd_rows)
+
 // kShortRows rows per wave when a group's slots usually fit one gather group (average in-degree <= 3)
 inline bool short_rows(const AggParams& p) {
     static const char* env = getenv("DGN_SHORT_ROWS");
@@ -1775,9 +1931,18 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
         }
     }
     const int wpb = row_waves_per_block(p);
-    const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
-    dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
-    hipLaunchKernelGGL((agg_bwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+    const char* rb_env = getenv("DGN_BWD_ROWS_PER_WAVE");     // (read per launch: the tests switch it)
+    const int rb = rb_env ? atoi(rb_env) : kBwdShortRows;
+    if (O::kStatic && short_rows(p) && p.stage && p.fresh && rb > 1) {       // molecule-like batches, static lists: rows in groups per wave
+        const int64_t n_groups = (p.n_nodes + rb - 1) / rb;
+        dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);
+        if (rb >= 4) hipLaunchKernelGGL((agg_bwd_short<C, O, 4>), grid, dim3(kWave * wpb), 0, stream, p);
+        else hipLaunchKernelGGL((agg_bwd_short<C, O, 2>), grid, dim3(kWave * wpb), 0, stream, p);
+    } else {
+        const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
+        dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
+        hipLaunchKernelGGL((agg_bwd_rows<C, O>), grid, dim3(kWave * wpb), 0, stream, p);
+    }
     if (p.n_hub > 0) {
         dim3 gs((unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock), tiles);
         dim3 gc((unsigned)((p.n_hub + kWavesPerBlock - 1) / kWavesPerBlock), tiles);

@@ -239,7 +239,7 @@ class DGNGraph:
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
         self.n_remote, self.win_ptr = 0, None
-        if self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
+        if not self.BUILD_WINDOWS or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
             return
         dst_csr = getattr(self, "dst_csr", None)
         if dst_csr is None:        # (graph adopted from a CSR: destination of every slot from the row pointers)
@@ -268,6 +268,9 @@ class DGNGraph:
     # ---- row windows of the window-local backward scatter (include/dgn_hip.h: DgnGraph.win_ptr) ----
     WIN_BIN = 16        # rows per bin; a window spans at most 3 bins - 1 rows
     WIN_ECAP = 96       # csc entries of a window kept in LDS
+    # Row windows for agg_bwd_window are only built on request: since the grouped row kernel (agg_bwd_short: four rows per wave) the
+    # window-local scatter is the slower backward on every measured batch (ZINC-12k simple layer 0.180 vs 0.136 ms), see ops.WINDOW_BACKWARD
+    BUILD_WINDOWS = False
     WIN_MIN_EDGES = 32768   # below this the backward is launch-bound and the ~20 device ops of the window build cost more than they save
 
     def _build_windows(self, order: torch.Tensor, csc_ptr: torch.Tensor) -> None:
@@ -279,7 +282,7 @@ class DGNGraph:
         fit one slot batch only (the kernel's domain)."""
         N, E, dev = self.num_nodes, self.num_edges, self.device
         self.n_remote, self.win_ptr = 0, None
-        if self.num_src != N or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
+        if not self.BUILD_WINDOWS or self.num_src != N or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
             return
         R0 = self.WIN_BIN
         rows = torch.arange(N, device=dev)

@@ -24,12 +24,12 @@ from .spec import EPS, AggPlan
 DETERMINISTIC_BACKWARD = "auto"
 
 # Window-local scatter of the two-phase backward (agg_bwd_window: the per-edge gradient rows of a batch of small graphs are
-# reduced in LDS by the workgroup that owns their window of rows, include/dgn_hip.h: DgnGraph.win_ptr).  False: always the
-# global [E, F] staging buffer + seg_sum_rows (tests compare the two).  "auto": where it measured faster on ZINC-12k
-# (profiles/r02_window_backward.txt) -- layers whose message is x_src alone (simple layers: one LDS row buffer, three workgroups
-# per CU: 0.207 -> 0.184 ms); P|Q messages (two row buffers next to 96 VGPRs: two workgroups per CU) measured 0.349 -> 0.375 ms and
-# keep the global staging path.  "all": wherever the kernel applies.
-WINDOW_BACKWARD = "auto"
+# reduced in LDS by the workgroup that owns their window of rows, include/dgn_hip.h: DgnGraph.win_ptr).  False (default): the
+# global [E, F] staging buffer + seg_sum_rows, fed by the grouped row kernel agg_bwd_short -- which overtook the window kernel on
+# every measured batch (ZINC-12k simple layer: windows 0.180 ms, grouped rows 0.136 ms; towers layer 0.375 vs 0.257 ms).  "all":
+# wherever the window kernel applies (needs DGNGraph.BUILD_WINDOWS = True before the graph's csc view is built; the tests compare
+# the two).  "auto": as "all" for layers whose message is x_src alone.
+WINDOW_BACKWARD = False
 
 
 # ---- padded batches -------------------------------------------------------------------------------------------------------------

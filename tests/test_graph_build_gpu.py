@@ -27,6 +27,7 @@ def test_native_build_equals_torch_build(monkeypatch, case):
     import dgn_amd.graph as G
     name, src, dst, N, kw = case
     dev = torch.device("cuda")
+    monkeypatch.setattr(G.DGNGraph, "BUILD_WINDOWS", True)
     monkeypatch.setattr(G.DGNGraph, "WIN_MIN_EDGES", 0)
     built = {}
     for native in (True, False):

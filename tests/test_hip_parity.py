@@ -630,6 +630,61 @@ def test_bn_tail_vs_torch_batchnorm():
             _close(bn_tail(x0.to(dev), mine if n_bn > 1 else mine[0], False, relu=relu), ye, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("rows_per_wave", ["2", "4"])
+@pytest.mark.parametrize("case", ["towers", "pair_std", "simple"])
+def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, case):
+    """agg_bwd_short (2 / 4 rows of a molecule batch per wave, every load of the group in flight at once) against agg_bwd_rows
+    (DGN_BWD_ROWS_PER_WAVE=1): bit-identical gradients, on static aggregator lists (the fast case) and with a ragged tail of rows;
+    isolated atoms (zero in-degree) and a long row in the batch exercise the per-row fallback inside the grouped kernel."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.ops import directional_aggregate
+    b = synth.molecule_batch(90, seed=17, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    # two isolated nodes and one node with 9 in-edges appended
+    hub = N + 2
+    extra_src = torch.arange(0, 9)
+    src = torch.cat([src, extra_src])
+    dst = torch.cat([dst, torch.full((9,), hub)])
+    N = N + 3
+    gen = torch.Generator().manual_seed(8)
+    eig = torch.randn(N, 4, generator=gen)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
+    if case == "towers":          # the headline list: static operators, tower-major, h_in pass-through block
+        F_, T, aggs, scalers = 70, 5, ["mean", "max", "min", "dir1-av", "dir1-dx"], ["identity"]
+        from dgn_amd.dgn_layer import X_IN_NAME
+        plan = dgn_amd.make_plan(aggs + [X_IN_NAME], scalers)
+    elif case == "pair_std":
+        F_, T, aggs, scalers = 12, 1, ["mean", "max", "std", "dir1-dx"], ["identity"]
+        plan = dgn_amd.make_plan(aggs, scalers)
+    else:
+        F_, T, aggs, scalers = 76, 1, ["mean", "dir1-dx-no-abs"], ["identity", "amplification", "attenuation"]
+        plan = dgn_amd.make_plan(aggs, scalers)
+    X = torch.randn(N, F_, generator=gen)
+    PQ = torch.randn(N, 2 * F_, generator=gen)
+
+    def run(rb):
+        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        x = X.to(dev).requires_grad_(True)
+        if case == "simple":
+            y = directional_aggregate(graph, plan, 1.1, x_src=x, x_in=x)
+            leaves = [x]
+        else:
+            pq = PQ.to(dev).requires_grad_(True)
+            y = directional_aggregate(graph, plan, 1.1, x_pair=pq, x_in=x, n_towers=T, tower_major=T > 1)
+            leaves = [pq, x]
+        ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+        return torch.autograd.grad(y, leaves, ct)
+
+    ref = run("1")
+    got = run(rows_per_wave)
+    for a, r in zip(got, ref):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, r)
+
+
 @pytest.mark.parametrize("case", ["pair", "simple", "three_term", "cut_molecules", "one_graph"])
 def test_window_backward_equals_staged_backward(monkeypatch, case):
     """agg_bwd_window (per-edge gradient rows reduced in the LDS of the workgroup that owns their window of rows) against the
@@ -654,6 +709,7 @@ def test_window_backward_equals_staged_backward(monkeypatch, case):
     gen = torch.Generator().manual_seed(4)
     eig = torch.randn(N, 4, generator=gen)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    monkeypatch.setattr(dgn_amd.DGNGraph, "BUILD_WINDOWS", True)
     monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_MIN_EDGES", 0)             # (small test graphs: build the windows anyway)
     if case == "cut_molecules":
         monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_ECAP", 40)             # fewer LDS entries than a window's csc range
