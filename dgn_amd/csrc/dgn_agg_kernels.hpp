@@ -1465,7 +1465,8 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 // arithmetic in the same order as bwd_row_one_batch: bit-identical gradients.  Groups with a longer / empty / hub row, partial
 // groups, and launches outside the fast case (dynamic lists, several scalers, accumulate mode, an m_edge term, the atomic scatter)
 // take the per-row routine.
-template <class C, class O, int RB>
+// EDGE: the message has an edge-TYPE table term (DgnMsg.edge_type): a second tile of (L1-resident) table rows.
+template <class C, class O, int RB, bool EDGE = false>
 __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
     constexpr int VEC = C::VEC, J = kShortDeg;
     const int wpb = blockDim.x >> 6;
@@ -1481,7 +1482,7 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
     const bool active = f0 < p.F;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
     constexpr bool PRE = O::kStatic && NG <= 8;
-    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.m_edge && !p.g_edge;
+    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.g_edge && (EDGE ? (p.m_edge && p.edge_type) : !p.m_edge);
     const bool recomp = (p.need & NEED_RECOMP) != 0;     // (otherwise only sum_j w_jc is needed: no gathers at all)
     int lo[RB], deg[RB], beg0 = 0;
     if (fast) {
@@ -1505,7 +1506,7 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
         const int my_tpos = lane_id() < total ? p.csc_pos[beg0 + lane_id()] : 0;
         if (!active) return;
         // every load of the group, issued before anything is consumed
-        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[RB][NG][VEC], t[RB][J][VEC];
+        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[RB][NG][VEC], t[RB][J][VEC], t2[EDGE ? RB : 1][EDGE ? J : 1][VEC];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int row = row0 + r;
@@ -1524,8 +1525,12 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
 #pragma unroll
-                for (int j = 0; j < J; ++j)
-                    if (j < deg[r]) ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                for (int j = 0; j < J; ++j) {
+                    if (j < deg[r]) {
+                        ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                        if constexpr (EDGE) ldv<VEC>(t2[r][j], p.m_edge + (int64_t)bcast_i(b.et, lo[r] + j) * p.ld_edge + f0);
+                    }
+                }
             }
         }
         const bool need_m = C::STATS && (p.need & NEED_M_EMIT) != 0;
@@ -1539,7 +1544,10 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
                     if (j < deg[r]) {
                         float mm[VEC], wk[C::NW];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) mm[i] = xd[r][i] + t[r][j][i];
+                        for (int i = 0; i < VEC; ++i) {
+                            mm[i] = xd[r][i] + t[r][j][i];
+                            if constexpr (EDGE) mm[i] += t2[r][j][i];
+                        }
                         b.weights(wk, lo[r] + j);
                         acc.add(mm, wk, beg0 + lo[r] + j);
                     }
@@ -1578,7 +1586,11 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
                     for (int i = 0; i < VEC; ++i) gm[i] = k.c0[i];
                     if (need_m) {
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) gm[i] = fmaf(k.cv[i], xd[r][i] + t[r][j][i], gm[i]);
+                        for (int i = 0; i < VEC; ++i) {
+                            float mv = xd[r][i] + t[r][j][i];
+                            if constexpr (EDGE) mv += t2[r][j][i];
+                            gm[i] = fmaf(k.cv[i], mv, gm[i]);
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < C::NCH; ++c) {
@@ -1866,7 +1878,7 @@ inline int row_waves_per_block(const AggParams& p) {
     return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
 }
 
-constexpr int kBwdShortRows = 4;     // rows per wave of agg_bwd_short (2 and 4 are instantiated; DGN_BWD_ROWS_PER_WAVE=1 selects agg_bwd_rows)
+constexpr int kBwdShortRows = 4;     // rows per wave of agg_bwd_short (two rows measured 0.293 ms on c2, four 0.26; DGN_BWD_ROWS_PER_WAVE=1 selects agg_bwd_rows)
 
 // kShortRows rows per wave when a group's slots usually fit one gather group (average in-degree <= 3)
 inline bool short_rows(const AggParams& p) {
@@ -1932,12 +1944,12 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
     }
     const int wpb = row_waves_per_block(p);
     const char* rb_env = getenv("DGN_BWD_ROWS_PER_WAVE");     // (read per launch: the tests switch it)
-    const int rb = rb_env ? atoi(rb_env) : kBwdShortRows;
+    const int rb = (rb_env && atoi(rb_env) <= 1) ? 1 : kBwdShortRows;
     if (O::kStatic && short_rows(p) && p.stage && p.fresh && rb > 1) {       // molecule-like batches, static lists: rows in groups per wave
         const int64_t n_groups = (p.n_nodes + rb - 1) / rb;
         dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);
-        if (rb >= 4) hipLaunchKernelGGL((agg_bwd_short<C, O, 4>), grid, dim3(kWave * wpb), 0, stream, p);
-        else hipLaunchKernelGGL((agg_bwd_short<C, O, 2>), grid, dim3(kWave * wpb), 0, stream, p);
+        if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true>), grid, dim3(kWave * wpb), 0, stream, p);
+        else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false>), grid, dim3(kWave * wpb), 0, stream, p);
     } else {
         const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
         dim3 grid((unsigned)xcd_grid(n_blocks), tiles);

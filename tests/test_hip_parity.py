@@ -630,8 +630,8 @@ def test_bn_tail_vs_torch_batchnorm():
             _close(bn_tail(x0.to(dev), mine if n_bn > 1 else mine[0], False, relu=relu), ye, 1e-5, 1e-5)
 
 
-@pytest.mark.parametrize("rows_per_wave", ["2", "4"])
-@pytest.mark.parametrize("case", ["towers", "pair_std", "simple"])
+@pytest.mark.parametrize("rows_per_wave", ["4"])
+@pytest.mark.parametrize("case", ["towers", "pair_std", "simple", "edge_table"])
 def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, case):
     """agg_bwd_short (2 / 4 rows of a molecule batch per wave, every load of the group in flight at once) against agg_bwd_rows
     (DGN_BWD_ROWS_PER_WAVE=1): bit-identical gradients, on static aggregator lists (the fast case) and with a ragged tail of rows;
@@ -659,9 +659,15 @@ def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, ca
     elif case == "pair_std":
         F_, T, aggs, scalers = 12, 1, ["mean", "max", "std", "dir1-dx"], ["identity"]
         plan = dgn_amd.make_plan(aggs, scalers)
+    elif case == "edge_table":     # P|Q + a 5-type edge table (DgnMsg.edge_type): the EDGE instantiation
+        F_, T, aggs, scalers = 70, 5, ["mean", "max", "min", "dir1-av", "dir1-dx"], ["identity"]     # (a static list: the grouped path)
+        from dgn_amd.dgn_layer import X_IN_NAME
+        plan = dgn_amd.make_plan(aggs + [X_IN_NAME], scalers)
     else:
         F_, T, aggs, scalers = 76, 1, ["mean", "dir1-dx-no-abs"], ["identity", "amplification", "attenuation"]
         plan = dgn_amd.make_plan(aggs, scalers)
+    table = torch.randn(5, F_, generator=gen)
+    types_slot = graph.to_slot_order(torch.randint(0, 5, (src.numel(),), generator=gen).to(dev)).to(torch.int32).contiguous()
     X = torch.randn(N, F_, generator=gen)
     PQ = torch.randn(N, 2 * F_, generator=gen)
 
@@ -673,8 +679,13 @@ def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, ca
             leaves = [x]
         else:
             pq = PQ.to(dev).requires_grad_(True)
-            y = directional_aggregate(graph, plan, 1.1, x_pair=pq, x_in=x, n_towers=T, tower_major=T > 1)
             leaves = [pq, x]
+            kw_e = {}
+            if case == "edge_table":
+                tb = table.to(dev).requires_grad_(True)
+                leaves.append(tb)
+                kw_e = dict(m_edge=tb, edge_type=types_slot)
+            y = directional_aggregate(graph, plan, 1.1, x_pair=pq, x_in=x, n_towers=T, tower_major=T > 1, **kw_e)
         ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
         return torch.autograd.grad(y, leaves, ct)
 
