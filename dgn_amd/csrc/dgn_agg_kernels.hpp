@@ -1482,7 +1482,8 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
     const bool active = f0 < p.F;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
     constexpr bool PRE = O::kStatic && NG <= 8;
-    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.g_edge && (EDGE ? (p.m_edge && p.edge_type) : !p.m_edge);
+    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.g_edge && (EDGE ? (p.m_edge && p.edge_type) : !p.m_edge) &&
+                !(p.need & NEED_M_EMIT);      // (no static list carries std / var: their emit term stays with the per-row routine)
     const bool recomp = (p.need & NEED_RECOMP) != 0;     // (otherwise only sum_j w_jc is needed: no gathers at all)
     int lo[RB], deg[RB], beg0 = 0;
     if (fast) {
@@ -1533,7 +1534,6 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
                 }
             }
         }
-        const bool need_m = C::STATS && (p.need & NEED_M_EMIT) != 0;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             Acc<C, true> acc;
@@ -1584,14 +1584,6 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
                     b.weights(wk, l);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gm[i] = k.c0[i];
-                    if (need_m) {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            float mv = xd[r][i] + t[r][j][i];
-                            if constexpr (EDGE) mv += t2[r][j][i];
-                            gm[i] = fmaf(k.cv[i], mv, gm[i]);
-                        }
-                    }
 #pragma unroll
                     for (int c = 0; c < C::NCH; ++c) {
 #pragma unroll
