@@ -1,0 +1,116 @@
+"""Seeded sweeps over shapes for the round-2 kernels: grouped-row backward (agg_bwd_short) against the row-per-wave kernel bit for bit,
+edge-type table against gathered rows, both against the oracle; ragged tails, tiny batches, rows with 0 / 1 / 4 / many in-edges."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HOT_LISTS = [  # (aggregators, scalers, needs P|Q): the baked-in lists of csrc/dgn_agg_hot.hpp that molecule configs use
+    (["mean", "max", "min", "dir1-av", "dir1-dx"], ["identity"], True),
+    (["mean", "max", "min", "dir1-dx", "dir1-av"], ["identity"], True),
+    (["mean", "dir1-dx-no-abs"], ["identity"], False),
+    (["mean", "dir1-dx", "dir1-av"], ["identity"], False),
+    (["mean", "dir1-dx"], ["identity"], False),
+    (["mean"], ["identity"], False),
+]
+
+
+def _batch(rng, n_graphs, extra):
+    """molecule-like batch + `extra` special nodes: isolated ones and one with many in-edges"""
+    from dgn_amd import synth
+    b = synth.molecule_batch(n_graphs, seed=int(rng.integers(1 << 30)), laplacian_eig=False, n_lo=2, n_hi=12)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    if extra:
+        k = int(rng.integers(5, 12))
+        src = torch.cat([src, torch.from_numpy(rng.integers(0, N, k))])
+        dst = torch.cat([dst, torch.full((k,), N + 1)])
+        N += 3
+    return src, dst, N
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_grouped_backward_sweep(monkeypatch, seed):
+    import dgn_amd
+    from dgn_amd.dgn_layer import X_IN_NAME
+    from dgn_amd.ops import directional_aggregate
+    from oracle import dgn_oracle as orc
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(100 + seed)
+    aggs, scalers, pq_msg = HOT_LISTS[seed % len(HOT_LISTS)]
+    T = [1, 5, 2][seed % 3] if pq_msg else 1
+    F_ = int(rng.choice([2, 10, 70, 126])) * T if T > 1 else int(rng.choice([2, 6, 70, 76, 130]))
+    src, dst, N = _batch(rng, int(rng.choice([1, 2, 3, 17, 64])), extra=seed % 2 == 0)
+    gen = torch.Generator().manual_seed(seed)
+    eig = torch.randn(N, 3, generator=gen)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
+    x_block = pq_msg and seed % 4 < 2
+    plan = dgn_amd.make_plan(aggs + ([X_IN_NAME] if x_block else []), scalers)
+    X, PQ = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen)
+
+    def run(rb):
+        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        x = X.to(dev).requires_grad_(True)
+        if pq_msg:
+            pq = PQ.to(dev).requires_grad_(True)
+            y = directional_aggregate(graph, plan, 1.3, x_pair=pq, x_in=x, n_towers=T, tower_major=T > 1)
+            leaves = [pq, x]
+        else:
+            y = directional_aggregate(graph, plan, 1.3, x_src=x, x_in=x)
+            leaves = [x]
+        ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+        return y.detach(), torch.autograd.grad(y, leaves, ct), ct
+
+    y1, g1, ct = run("1")
+    y4, g4, _ = run("4")
+    assert torch.equal(y1, y4)
+    for a, b in zip(g4, g1):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    if T == 1 and not x_block:                                   # oracle (fp64) on the same inputs
+        lo = [t.double().requires_grad_(True) for t in ((PQ, X) if pq_msg else (X,))]
+        msg = (lo[0][:, :F_][src] + lo[0][:, F_:][dst]) if pq_msg else lo[0][src]
+        yo = orc.aggregate_graph(src, dst, N, msg, eig.double(), lo[-1], aggs, scalers, torch.tensor(1.3).double())
+        np.testing.assert_allclose(y4.cpu().numpy(), yo.detach().float().numpy(), rtol=2e-4, atol=2e-4)
+        for a, b in zip(g4, torch.autograd.grad(yo, lo, ct.cpu().double())):
+            np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_edge_table_sweep(monkeypatch, seed):
+    import dgn_amd
+    from dgn_amd.dgn_layer import X_IN_NAME
+    from dgn_amd.ops import directional_aggregate
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(500 + seed)
+    aggs, scalers, _ = HOT_LISTS[seed % 2] if seed % 3 else (["mean", "max", "std", "dir1-dx"], ["identity", "attenuation"], True)
+    T = [1, 5][seed % 2]
+    F_ = int(rng.choice([2, 14, 24])) * T
+    K = int(rng.choice([1, 2, 4, 9]))
+    src, dst, N = _batch(rng, int(rng.choice([1, 5, 40])), extra=seed % 2 == 1)
+    E = src.numel()
+    gen = torch.Generator().manual_seed(seed)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=torch.randn(N, 3, generator=gen).to(dev))
+    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
+    plan = dgn_amd.make_plan(aggs + ([X_IN_NAME] if len(scalers) == 1 else []), scalers)
+    X, PQ, table = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen), torch.randn(K, F_, generator=gen)
+    types_slot = graph.to_slot_order(torch.randint(0, K, (E,), generator=gen).to(dev)).to(torch.int32).contiguous()
+
+    def run(table_mode, rb="4"):
+        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        x, pq, tb = X.to(dev).requires_grad_(True), PQ.to(dev).requires_grad_(True), table.to(dev).requires_grad_(True)
+        if table_mode:
+            y = directional_aggregate(graph, plan, 0.8, x_pair=pq, m_edge=tb, x_in=x, edge_type=types_slot, n_towers=T, tower_major=T > 1)
+        else:
+            y = directional_aggregate(graph, plan, 0.8, x_pair=pq, m_edge=tb.index_select(0, types_slot.long()), x_in=x, n_towers=T, tower_major=T > 1)
+        ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+        return y.detach(), torch.autograd.grad(y, [pq, x, tb], ct)
+
+    yt, gt = run(True)
+    yd, gd = run(False)
+    y1, g1 = run(True, "1")
+    assert torch.equal(yt, yd) and torch.equal(yt, y1)
+    for i in (0, 1):
+        assert torch.equal(gt[i], gd[i]) and torch.equal(gt[i], g1[i])
+    assert torch.equal(gt[2], g1[2])                                                    # same staged rows, same reduction
+    np.testing.assert_allclose(gt[2].cpu().numpy(), gd[2].cpu().numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(gd[2].abs().max())))
