@@ -522,6 +522,48 @@ def g8_readouts(out):
     out["vn/n_cases"] = np.array(case)
 
 
+def g10_net(out):
+    """The whole graph-regression net of nets/molecules_graph_regression/dgn_net.py (embeddings, L towers layers with and
+    without bond features, readout, MLPReadout, L1 loss): scores, loss, and every parameter gradient, in training mode."""
+    from nets.molecules_graph_regression.dgn_net import DGNNet
+    src, dst, N, sizes = make_test_graph(seed=5)
+    out["src"], out["dst"], out["N"], out["sizes"] = src, dst, np.array(N), np.array(sizes)
+    gen = torch.Generator().manual_seed(21)
+    eig = torch.randn(N, 4, generator=gen)
+    atoms = torch.randint(0, 6, (N,), generator=gen)
+    bonds = torch.randint(0, 4, (len(src),), generator=gen)
+    snorm = torch.rand(N, 1, generator=gen) + 0.5
+    targets = torch.randn(len(sizes), 1, generator=gen)
+    out["eig"], out["atoms"], out["bonds"], out["snorm"], out["targets"] = eig.numpy(), atoms.numpy(), bonds.numpy(), snorm.numpy(), targets.numpy()
+    cases = [("towers_edge", "towers", True, "mean"), ("towers", "towers", False, "directional"), ("simple", "simple", False, "sum")]
+    out["cases"] = np.array([c[0] for c in cases])
+    for name, type_net, edge_feat, mode in cases:
+        torch.manual_seed(7)
+        params = dict(num_atom_type=6, num_bond_type=4, hidden_dim=20, out_dim=20, in_feat_dropout=0.0, dropout=0.0, L=3,
+                      type_net=type_net, pos_enc_dim=0, readout=mode, graph_norm=True, batch_norm=True,
+                      aggregators="mean max dir1-av dir1-dx", scalers="identity amplification", avg_d={"log": torch.tensor(1.1)},
+                      residual=True, edge_feat=edge_feat, edge_dim=6 if edge_feat else 0, pretrans_layers=1, posttrans_layers=1, device="cpu")
+        net = DGNNet(params)
+        net.train(True)
+        for k, v in net.state_dict().items():
+            out[f"{name}/sd::{k}"] = v.detach().numpy().copy()
+        g = FakeGraph(src, dst, N)
+        g.batch_num_nodes = list(sizes)
+        g.ndata["eig"] = eig
+        scores = net(g, atoms, bonds if edge_feat else None, snorm, None)
+        loss = net.loss(scores, targets)
+        names = [k for k, q in net.named_parameters()]
+        grads = torch.autograd.grad(loss, [q for _, q in net.named_parameters()], allow_unused=True)
+        out[f"{name}/cfg"] = np.array([type_net, str(int(edge_feat)), mode])
+        out[f"{name}/scores"], out[f"{name}/loss"] = scores.detach().numpy(), loss.detach().numpy()
+        for k, gr in zip(names, grads):
+            if gr is not None:
+                out[f"{name}/gp::{k}"] = gr.numpy()
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                out[f"{name}/after::{k}"] = v.detach().numpy().copy()
+
+
 def g9_laplacian(out):
     """Laplacian construction + eigenvector bookkeeping of ``MoleculeDGL.get_eig`` (data/molecules.py:100-116), UNMODIFIED,
     driven by a fake graph that supplies the three DGL methods it calls.  ``scipy.sparse.linalg.eigs`` is ARPACK with
@@ -593,7 +635,7 @@ def main():
     only = sys.argv[1:]
     for fname, fn in (("g1_aggregators", g1_aggregators), ("g2_scalers", g2_scalers), ("g3_reduce", g3_reduce),
                       ("g4_layers", g4_layers), ("g5_edge_cases", g5_edge_cases), ("g6_dense", g6_dense),
-                      ("g8_readouts", g8_readouts), ("g9_laplacian", g9_laplacian)):
+                      ("g8_readouts", g8_readouts), ("g9_laplacian", g9_laplacian), ("g10_net", g10_net)):
         if only and fname not in only:
             continue
         out = {}
