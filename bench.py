@@ -646,6 +646,54 @@ def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8):
                        "in-place graph preparation + input copies + graph launch (edge weights + layer forward + backward)")
 
 
+def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=False):
+    """The graph-regression NET around the layer (dgn_amd.nets.DGNNet = nets/molecules_graph_regression/dgn_net.py: atom embedding, four
+    towers layers, mean readout, MLPReadout, L1 loss; configs/molecules_graph_regression_DGN_ZINC.json: L = 4, batch 128, no bond
+    features) at the reference's ZINC batch size.  One training step = graph preparation of the batch + edge weights + forward + loss +
+    backward + Adam update; eager (no graph capture)."""
+    from dgn_amd.nets import DGNNet
+    raw = [synth.molecule_batch(n_graphs=n_graphs, seed=41 + i, extra_bonds=3.9, eig_dim=6) for i in range(4)]
+    avg_log = float(torch.log(torch.bincount(raw[0]["dst"], minlength=int(raw[0]["num_nodes"])).float() + 1).mean())
+    net = DGNNet(dict(num_atom_type=28, num_bond_type=4, hidden_dim=70, out_dim=70, in_feat_dropout=0.0, dropout=0.0, L=layers, type_net="towers",
+                      pos_enc_dim=0, readout="mean", graph_norm=True, batch_norm=True, aggregators="mean max min dir1-av dir1-dx",
+                      scalers="identity amplification attenuation", avg_d={"log": torch.tensor(avg_log)}, residual=True, edge_feat=edge_feat, edge_dim=10 if edge_feat else 0,
+                      pretrans_layers=1, posttrans_layers=1, device=str(dev))).to(dev).train()
+    try:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)      # one multi-tensor kernel instead of a launch per parameter
+    except Exception:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(0)
+    batches = []
+    for b in raw:
+        N, E = int(b["num_nodes"]), b["src"].numel()
+        batches.append(dict(src=b["src"].to(dev), dst=b["dst"].to(dev), N=N, eig=b["eig"].to(dev), sizes=[int(x) for x in b["sizes"]],
+                            atoms=torch.randint(0, 28, (N,), generator=gen).to(dev), bonds=torch.randint(0, 4, (E,), generator=gen).to(dev),
+                            snorm=b["snorm_n"].to(dev), y=torch.randn(len(b["sizes"]), 1, generator=gen).to(dev)))
+
+    def step(i):
+        b = batches[i % len(batches)]
+        g = dgn_amd.DGNGraph(b["src"], b["dst"], b["N"], eig=b["eig"])          # per-batch graph preparation is part of the step
+        g.batch_num_nodes = b["sizes"]
+        opt.zero_grad(set_to_none=True)
+        loss = net.loss(net(g, b["atoms"], b["bonds"] if edge_feat else None, b["snorm"], None), b["y"])
+        loss.backward()
+        opt.step()
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    edges = sum(b["src"].numel() for b in batches) / len(batches)
+    return dict(ms_per_step=ms, value=layers * edges / (ms * 1e-3), unit="layer-edges/s", steps=steps, warmup=warmup, layers=layers, graphs=n_graphs,
+                edge_feat=edge_feat,
+                config="ZINC-like batch of 128 molecules through dgn_amd.nets.DGNNet (4 towers layers, mean readout, MLP, L1 loss, fused Adam), "
+                       "eager, graph preparation included")
+
+
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
@@ -672,6 +720,10 @@ def run_extras(args, dev):
         extra["c2_inference"] = run_inference(args, dev)
     except Exception as exc:
         extra["c2_inference"] = dict(error=f"{type(exc).__name__}: {exc}")
+    try:
+        extra["zinc_net_b128"] = run_net(args, dev)
+    except Exception as exc:
+        extra["zinc_net_b128"] = dict(error=f"{type(exc).__name__}: {exc}")
     try:
         extra["c2_b128_bucketed"] = run_bucketed(args, dev)
     except Exception as exc:
