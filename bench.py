@@ -686,9 +686,40 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
     for i in range(steps):
         step(i)
     torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / max(steps, 1) * 1e3
     edges = sum(b["src"].numel() for b in batches) / len(batches)
-    return dict(ms_per_step=ms, value=layers * edges / (ms * 1e-3), unit="layer-edges/s", steps=steps, warmup=warmup, layers=layers, graphs=n_graphs,
+    captured = None
+    if getattr(args, "net_capture", True) and not edge_feat:
+        # the same training step as ONE captured HIP graph over capacity-padded static buffers (hipgraph.CapturedNetStep); a step =
+        # load of the next batch (graph rebuilt in place, input copies) + one graph launch
+        try:
+            from dgn_amd.hipgraph import CapturedNetStep, bucket_capacity
+            n_cap, e_cap = bucket_capacity(max(b["N"] for b in batches), max(b["src"].numel() for b in batches))
+            cs = CapturedNetStep(net, n_cap, e_cap, g_cap=n_graphs + 1, eig_dim=batches[0]["eig"].shape[1], lr=1e-3)
+            load = lambda b: cs.load(b["src"], b["dst"], b["N"], b["eig"], b["atoms"], b["snorm"], b["sizes"], b["y"])
+            load(batches[0])
+            cs.capture(warmup=3)
+            for i in range(10):
+                load(batches[i % len(batches)])
+                cs.step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                load(batches[i % len(batches)])
+                cs.step()
+            torch.cuda.synchronize(dev)
+            ms_c = (time.perf_counter() - t0) / steps * 1e3
+            t0 = time.perf_counter()
+            for i in range(steps):
+                cs.step()
+            torch.cuda.synchronize(dev)
+            ms_r = (time.perf_counter() - t0) / steps * 1e3
+            captured = dict(ms_per_step=ms_c, value=layers * edges / (ms_c * 1e-3), replay_only_ms=ms_r, capacity=dict(nodes=n_cap, edges=e_cap),
+                            config="the same step as one captured HIP graph (forward, masked L1 loss, backward, capturable Adam) over padded static "
+                                   "buffers; a step = in-place graph preparation + input copies + one graph launch; replay_only_ms = the launch alone")
+        except Exception as exc:
+            captured = dict(error=f"{type(exc).__name__}: {exc}")
+    return dict(captured=captured, ms_per_step=ms, value=layers * edges / (ms * 1e-3), unit="layer-edges/s", steps=steps, warmup=warmup, layers=layers, graphs=n_graphs,
                 edge_feat=edge_feat,
                 config="ZINC-like batch of 128 molecules through dgn_amd.nets.DGNNet (4 towers layers, mean readout, MLP, L1 loss, fused Adam), "
                        "eager, graph preparation included")

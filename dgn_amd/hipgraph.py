@@ -29,15 +29,25 @@ def capture(step: Callable[[], None], warmup: int = 3) -> torch.cuda.CUDAGraph:
     the graph's private pool on every replay instead of accumulating).  Do not keep autograd-attached outputs of
     EARLIER steps alive across the capture (keep ``y.detach()``): releasing such a graph inside the capture region
     crashes ``capture_end`` on this ROCm / PyTorch."""
+    import gc
+    gc.collect()                      # autograd graphs of earlier eager steps that only a reference cycle keeps alive (e.g. a graph
+    torch.cuda.synchronize()          # object whose ndata holds the features computed ON it) must not be released inside the capture
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(warmup):
             step()
     torch.cuda.current_stream().wait_stream(side)
+    gc.collect()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
+    was_enabled = gc.isenabled()
+    gc.disable()                      # (no collection in the middle of the capture region either)
+    try:
+        with torch.cuda.graph(graph):
+            step()
+    finally:
+        if was_enabled:
+            gc.enable()
     return graph
 
 
@@ -86,3 +96,121 @@ def bucket_capacity(num_nodes: int, num_edges: int, granularity: int = 256, head
     distinct pair; batches of a data loader with a fixed number of graphs fall into very few buckets)."""
     up = lambda v: int(-(-int(v * headroom) // granularity) * granularity)
     return up(num_nodes), up(num_edges)
+
+
+def rewrap_parameters(module: torch.nn.Module) -> None:
+    """Replace every Parameter of ``module`` by a NEW Parameter object on the same storage.  A parameter that took part in an eager
+    autograd pass on the DEFAULT stream keeps a gradient-accumulation node bound to that stream for the life of the Parameter object,
+    and a later capture of a backward pass through it crashes in ``capture_end`` (ROCm 7 / PyTorch 2.10: measured, tools-free repro
+    in tests/test_net_gpu.py).  New Parameter objects start clean; values, ``state_dict`` and storage are untouched, but optimizers and
+    other holders of the OLD Parameter objects must be re-created.  The layers' parameter-list caches are dropped too."""
+    for m in module.modules():
+        for k, q in list(m._parameters.items()):
+            if q is not None:
+                m._parameters[k] = torch.nn.Parameter(q.detach(), requires_grad=q.requires_grad)
+        m.__dict__.pop("_plist", None)
+        m.__dict__.pop("_opmap", None)
+
+
+class CapturedNetStep:
+    """One captured HIP graph for the whole training step of a net around the layers (``dgn_amd.nets.DGNNet``: embedding, L layers,
+    readout, MLP, L1 loss, backward, Adam) at a fixed capacity: ``load(batch)`` writes the batch into static buffers (graph rebuilt in
+    place, atoms / graph norm / targets / the readout's graph -> nodes CSR copied), ``step()`` is one graph launch.
+
+    At the reference's batch size (128 molecules) the eager step is host-bound (~5 ms for ~1 ms of GPU work: per-parameter autograd and
+    optimizer bookkeeping for the ~120 per-tower tensors of the reference's ``state_dict`` layout); the replay is GPU-bound.
+
+    Padding: node rows beyond the batch are isolated (``PaddedBatch``); graph rows beyond the batch are empty, and ALL padding nodes
+    belong to the last graph row, whose loss term is masked -- every slot of the readout CSR stays referenced, so its backward defines
+    (zero) gradients for the padding rows.  The loss is the mean absolute error over the real graphs (``nets.DGNNet.loss``).
+
+    Unless an ``optimizer`` is passed in, the net's Parameter objects are re-created on construction (``rewrap_parameters``: eager
+    training steps on the default stream before a capture are otherwise fatal) and a capturable Adam is built on the new ones."""
+
+    def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None):
+        from .graph import DGNGraph
+        dev = torch.device(device if device is not None else next(net.parameters()).device)
+        self.net, self.device, self.g_cap = net, dev, int(g_cap)
+        self.pb = PaddedBatch(n_cap, e_cap, dev, eig_dim)
+        self.atoms = torch.zeros(n_cap, dtype=torch.int64, device=dev)
+        self.snorm = self.pb.add_node_tensor("snorm", 1)
+        self.targets = torch.zeros(g_cap, 1, device=dev)
+        self.gmask = torch.zeros(g_cap, 1, device=dev)
+        self.n_graphs = torch.ones(1, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self._h_sizes = torch.zeros(g_cap, dtype=torch.int64).pin_memory()
+        self._d_sizes = torch.zeros(g_cap, dtype=torch.int64, device=dev)
+        self._g_ids = torch.arange(g_cap, device=dev).unsqueeze(1)
+        # the readout's CSR: rows = graphs (the last one collects the padding nodes), slots = nodes in order
+        indptr = torch.zeros(g_cap + 1, dtype=torch.int64, device=dev)
+        indptr[-1] = n_cap
+        rg = DGNGraph.from_csr(indptr, torch.arange(n_cap, dtype=torch.int32, device=dev), num_src=n_cap)
+        i32 = lambda n: torch.arange(n, dtype=torch.int32, device=dev)
+        rg.csc_ptr, rg.csc_pos = i32(n_cap + 1), i32(n_cap)                 # node j sits in slot j of exactly one row
+        rg._c.csc_ptr, rg._c.csc_pos = rg.csc_ptr.data_ptr(), rg.csc_pos.data_ptr()
+        rg._csc_ready, rg.n_remote, rg.win_ptr = True, 0, None
+        rg.sizes = rg.in_degree
+        self.rg = rg
+        self.pb.graph._dgn_readout = rg
+        if optimizer is None:
+            rewrap_parameters(net)
+            try:                   # one multi-tensor kernel for all ~120 parameter tensors (the per-tensor form is ~1 ms of tiny kernels per step)
+                optimizer = torch.optim.Adam(net.parameters(), lr=lr, capturable=True, fused=True)
+            except Exception:
+                optimizer = torch.optim.Adam(net.parameters(), lr=lr, capturable=True)
+        self.opt = optimizer
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+
+    @torch.no_grad()
+    def load(self, src, dst, num_nodes: int, eig, atoms, snorm, sizes, targets) -> None:
+        """sizes: nodes per graph (host list or tensor), targets [n_graphs, 1]."""
+        n_cap, g_cap, dev = self.pb.n_cap, self.g_cap, self.device
+        sizes = torch.as_tensor(sizes, dtype=torch.int64)
+        G = sizes.numel()
+        if G >= g_cap:
+            raise ValueError(f"{G} graphs need a capacity of at least {G + 1} graph rows (the last row collects the padding)")
+        if n_cap - int(num_nodes) > 2048:
+            raise ValueError("more than 2048 padding nodes: pick a smaller capacity bucket (the padding row must not be a hub row)")
+        self.pb.load(src, dst, num_nodes, eig, node={"snorm": snorm})
+        self.atoms[:num_nodes].copy_(atoms, non_blocking=True)
+        self.atoms[num_nodes:].zero_()
+        # graph sizes -> the readout CSR, on the device: ONE copy from a pinned staging buffer (a pageable host tensor copied
+        # "non_blocking" right in front of a graph launch stalled the launch by ~20 ms on this runtime), everything else device ops
+        h = self._h_sizes
+        h.zero_()
+        h[:G] = sizes
+        h[g_cap - 1] = n_cap - int(num_nodes)                    # the padding row
+        self._d_sizes.copy_(h, non_blocking=True)
+        rg = self.rg
+        rg.indptr[1:].copy_(torch.cumsum(self._d_sizes, 0))
+        rg.in_degree.copy_(self._d_sizes)
+        rg.log_deg.copy_(torch.log((self._d_sizes + 1).double()))
+        self.targets.zero_()
+        self.targets[:G].copy_(targets, non_blocking=True)
+        self.gmask.copy_((self._g_ids < G).to(self.gmask.dtype))
+        self.n_graphs.fill_(float(G))
+
+    def _step(self) -> None:
+        self.opt.zero_grad(set_to_none=True)
+        self.pb.graph.invalidate_caches()
+        scores = self.net(self.pb.graph, self.atoms, None, self.snorm, None)
+        loss = ((scores - self.targets).abs() * self.gmask).sum() / self.n_graphs
+        loss.backward()
+        self.opt.step()
+        self.loss.copy_(loss.detach().reshape(()))
+        # nothing attached to this step's autograd graph may outlive the step (the net parks the node features on the graph object:
+        # released inside the NEXT capture region it would crash capture_end, see capture())
+        self.pb.graph.ndata.pop("h", None)
+        del scores, loss
+
+    def capture(self, warmup: int = 3) -> None:
+        """Capture the step on the batch currently loaded (the warm-up steps DO update the parameters)."""
+        self.graph = capture(self._step, warmup=warmup)
+
+    def step(self) -> torch.Tensor:
+        """One training step on the loaded batch; returns the (device) loss of that step."""
+        if self.graph is None:
+            self._step()
+        else:
+            self.graph.replay()
+        return self.loss
