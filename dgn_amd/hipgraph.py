@@ -142,9 +142,13 @@ class CapturedNetStep:
         self._d_sizes = torch.zeros(g_cap, dtype=torch.int64, device=dev)
         self._g_ids = torch.arange(g_cap, device=dev).unsqueeze(1)
         # the readout's CSR: rows = graphs (the last one collects the padding nodes), slots = nodes in order
-        indptr = torch.zeros(g_cap + 1, dtype=torch.int64, device=dev)
-        indptr[-1] = n_cap
+        # (built from an even split: no row may look like a hub row -- more than 2048 slots -- at construction, the hub description of
+        #  a DGNGraph is static)
+        indptr = (torch.arange(g_cap + 1, dtype=torch.int64, device=dev) * n_cap) // g_cap
+        if int((indptr[1:] - indptr[:-1]).max()) > 2048:
+            raise ValueError("capacity of more than 2048 nodes per graph row")
         rg = DGNGraph.from_csr(indptr, torch.arange(n_cap, dtype=torch.int32, device=dev), num_src=n_cap)
+        assert rg.n_hub == 0
         i32 = lambda n: torch.arange(n, dtype=torch.int32, device=dev)
         rg.csc_ptr, rg.csc_pos = i32(n_cap + 1), i32(n_cap)                 # node j sits in slot j of exactly one row
         rg._c.csc_ptr, rg._c.csc_pos = rg.csc_ptr.data_ptr(), rg.csc_pos.data_ptr()
