@@ -124,7 +124,9 @@ class CapturedNetStep:
     belong to the last graph row, whose loss term is masked -- every slot of the readout CSR stays referenced, so its backward defines
     (zero) gradients for the padding rows.  The loss is the mean absolute error over the real graphs (``nets.DGNNet.loss``).
 
-    Unless an ``optimizer`` is passed in, the net's Parameter objects are re-created on construction (``rewrap_parameters``: eager
+    An ``optimizer`` passed in must be capturable (``capturable=True`` for Adam-type optimizers; plain SGD is) and must have been built
+    on parameters that never took part in a default-stream autograd pass (``rewrap_parameters`` first).  Unless an ``optimizer`` is
+    passed in, the net's Parameter objects are re-created on construction (``rewrap_parameters``: eager
     training steps on the default stream before a capture are otherwise fatal) and a capturable Adam is built on the new ones."""
 
     def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None):
