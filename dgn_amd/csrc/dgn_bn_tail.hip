@@ -352,7 +352,7 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
                                    size_t ws_bytes, const int64_t* n_valid, void* stream_) {
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F) { set_error("dgn_bn_tail_forward: bad shape (need 1 <= F <= 1024, ld >= F)"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
-    if (!x || !y) { set_error("dgn_bn_tail_forward: null buffer"); return DGN_ERR_INVALID; }
+    if (!x || (!y && !training)) { set_error("dgn_bn_tail_forward: null buffer"); return DGN_ERR_INVALID; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (training) {
         if (!ws || !save_mean || !save_invstd) { set_error("dgn_bn_tail_forward: training needs ws, save_mean, save_invstd"); return DGN_ERR_INVALID; }
@@ -363,9 +363,10 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
         else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd, n_valid);
-        hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,
-                           (const float*)save_mean, (const float*)save_invstd, (const float*)nullptr, (const float*)nullptr, eps, relu,
-                           residual, y);
+        // y == NULL: statistics only (the consumer normalises on the fly: dgn_linear_forward_bn / dgn_linear_wgrad_bn)
+        if (y) hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,
+                                  (const float*)save_mean, (const float*)save_invstd, (const float*)nullptr, (const float*)nullptr, eps, relu,
+                                  residual, y);
     } else {
         if (!running_mean || !running_var) { set_error("dgn_bn_tail_forward: eval mode needs running statistics"); return DGN_ERR_INVALID; }
         hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta,

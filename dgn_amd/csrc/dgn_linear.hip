@@ -40,9 +40,10 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
 static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
-    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16) * 4;
+    const bool bn = p.bn_mean != nullptr;
+    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : 0)) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
-    int waves = linear_threads(NT, KB) / 64;
+    int waves = linear_threads(NT, KB, bn) / 64;
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
     const size_t lds = w_bytes + waves * strip_bytes;
     if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
@@ -54,6 +55,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const hipError_t e = p.ex.gy ? launch_linear_expand(NT, KB, p, waves * 64, lds, st)
                        : p.S > 0 ? launch_linear_combine(NT, KB, p, waves * 64, lds, st)
+                       : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
                                  : launch_linear_plain(NT, KB, p, waves * 64, lds, st);
     DGN_HIP_CHECK(e);
     return 0;
@@ -77,6 +79,23 @@ extern "C" int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t 
     p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = w_is_kn;
     p.bias = bias; p.sBias = stride_bias;
     p.C = c; p.sC = stride_c;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_forward_bn(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, int32_t w_is_kn,
+                                     const float* bias, float* c, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                     const float* bn_beta, void* stream) {
+    const char* fn = "dgn_linear_forward_bn";
+    if (n_rows < 0 || !dgn_linear_supported(k, n, 0)) { set_error("%s: need even k, n in [2, 160] (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!a || !w || !c || !bn_mean || !bn_invstd) { set_error("%s: null operand", fn); return -1; }
+    if (!aligned8(a) || !aligned8(c)) { set_error("%s: A and C must be 8-byte aligned (dense rows)", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = a; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
+    p.bias = bias;
+    p.C = c;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
     return launch_linear(fn, p, stream);
 }
 
@@ -125,7 +144,11 @@ static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, in
     p.groups = wgrad_groups(p.M, k, n, batch);
     p.ones = dbias != nullptr;
     const int NT = (n + 15) / 16, KT = (k + 15) / 16;
-    const size_t lds = std::max((size_t)4 * (strip_floats(n) + strip_floats(k) + 64), (size_t)NT * 16 * KT * 16) * 4;
+    size_t lds = std::max((size_t)4 * (strip_floats(n) + strip_floats(k) + 64), (size_t)NT * 16 * KT * 16) * 4;
+    if (p.bn_mean) {
+        p.bn_off = (int)(lds / 4);
+        lds += (size_t)4 * KT * 16 * 4;
+    }
     const hipError_t e = p.ex.gy ? launch_wgrad_expand(NT, KT, p, lds, st) : launch_wgrad_plain(NT, KT, p, lds, st);
     DGN_HIP_CHECK(e);
     const int64_t total = (int64_t)batch * n * (dbias ? k + 1 : k);
@@ -163,6 +186,22 @@ extern "C" int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t ba
     p.G = g; p.sG = stride_g;
     p.X = x; p.sX = stride_x;
     return launch_wgrad(fn, p, dw, lddw, stride_dw, dbias, stride_dbias, ws, ws_bytes, stream);
+}
+
+extern "C" int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* x, float* dw, int64_t lddw, float* dbias,
+                                   const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    const char* fn = "dgn_linear_wgrad_bn";
+    if (dbias && k % 16 == 0) { set_error("%s: the bias gradient rides in X's padding column (k %% 16 != 0)", fn); return -1; }
+    if (n_rows < 0 || !dgn_linear_supported(k, n, 1)) { set_error("%s: need even k, n in [2, 160] and at most 45 tiles (k=%d n=%d)", fn, k, n); return -1; }
+    if (!dw) { set_error("%s: null output", fn); return -1; }
+    if (n_rows == 0) return zero_wgrad(dw, lddw, 0, dbias, 0, k, n, 1, static_cast<hipStream_t>(stream));
+    if (!g || !x || !bn_mean || !bn_invstd || !aligned8(g) || !aligned8(x)) { set_error("%s: null or misaligned operand", fn); return -1; }
+    WgParams p{};
+    p.M = n_rows; p.n = n; p.k = k; p.T = 1;
+    p.G = g; p.X = x;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    return launch_wgrad(fn, p, dw, lddw, 0, dbias, 0, ws, ws_bytes, stream);
 }
 
 static bool expand_ok(const char* fn, int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* gy,

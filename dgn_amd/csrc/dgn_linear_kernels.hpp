@@ -49,10 +49,13 @@ struct LinParams {
     int S, fo;
     const float* sc; const float* rs; const float* cb;
     float* Y; int64_t ldy;
+    // kBnPlain: the operand is BatchNorm(A) formed while the strip is staged: ((a - mean[c]) * invstd[c]) * gamma[c] + beta[c], the
+    // arithmetic of bn_apply (dgn_bn_tail.hip) in the same order; gamma / beta may be NULL (1 / 0)
+    const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_threads(int NT, int KB) { return 8 * NT + 4 * KB + 52 <= 116 ? 1024 : 512; }
+constexpr int linear_threads(int NT, int KB, bool bn = false) { return 8 * NT + 4 * KB + 52 + (bn ? 12 : 0) <= 116 ? 1024 : 512; }    // (bn: the kBnPlain staging holds a few more values)
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
 // A strip is 16 * k consecutive floats of A (rows are dense: lda == k) starting at a multiple of 64 bytes: it is copied with
@@ -122,11 +125,29 @@ __device__ __forceinline__ void store_expand(float* Xl, float* Fl, const float2 
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2 };        // ts_linear variants
+// store_strip with the BatchNorm transform of the operand (tables in LDS: Bn[0..3][kp16] = mean, invstd, gamma, beta).  pre[j] holds
+// float2 number strip_idx2(j, lane) of the strip, i.e. columns (2 * idx2) % k and the next one (k is even: a pair never straddles a row)
+template <int NL>
+__device__ __forceinline__ void store_strip_bn(float* Xl, const float2 (&pre)[NL], int k, int lane, const float* Bn, int kp16) {
+    auto tf = [&](float v, int c) { return (v - Bn[c]) * Bn[kp16 + c] * Bn[2 * kp16 + c] + Bn[3 * kp16 + c]; };
+    int c = (4 * lane) % k;                                  // column of the lane's first element in piece jq = 0
+    const int dc = 256 % k;
+#pragma unroll
+    for (int jq = 0; jq < NL / 2; ++jq) {
+        if (jq * 64 + lane < (kStrip / 4) * k) {
+            const int c2 = c + 2 >= k ? c + 2 - k : c + 2;
+            reinterpret_cast<float4*>(Xl)[jq * 64 + lane] = make_float4(tf(pre[2 * jq].x, c), tf(pre[2 * jq].y, c + 1), tf(pre[2 * jq + 1].x, c2), tf(pre[2 * jq + 1].y, c2 + 1));
+        }
+        c += dc;
+        if (c >= k) c -= k;
+    }
+}
+
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
-__global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p) {
-    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand;
+__global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(LinParams p) {
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -136,7 +157,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     float* Wl = lds;                                 // [NT*16][kp], zero beyond (n, k)
     float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
     float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
-    float* Xl = Cb + NT * 16 + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
+    float* Bn = Cb + NT * 16;                        // kBnPlain: [4][KB*16] mean, invstd, gamma, beta of the operand's columns
+    float* Xl = Bn + (BNP ? 4 * KB * 16 : 0) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
     float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
 
@@ -172,6 +194,15 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     }
     if (p.bias) for (int i = tid; i < n; i += blockDim.x) Bl[i] = p.bias[(int64_t)t * p.sBias + i];
     if (COMBINE && p.cb) for (int i = tid; i < p.fo; i += blockDim.x) Cb[i] = p.cb[t * p.fo + i];
+    if constexpr (BNP) {
+        for (int i = tid; i < KB * 16; i += blockDim.x) {
+            const bool in = i < k;
+            Bn[i] = in ? p.bn_mean[i] : 0.f;
+            Bn[KB * 16 + i] = in ? p.bn_invstd[i] : 0.f;
+            Bn[2 * KB * 16 + i] = (in && p.bn_gamma) ? p.bn_gamma[i] : 1.f;
+            Bn[3 * KB * 16 + i] = (in && p.bn_beta) ? p.bn_beta[i] : 0.f;
+        }
+    }
     __syncthreads();
 
     const int m = lane & 15, g = lane >> 4;
@@ -218,6 +249,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB)) void ts_linear(LinParams p)
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
         if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
+        else if constexpr (BNP) store_strip_bn<NL>(Xl, pre, k, lane, Bn, KB * 16);
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
@@ -269,6 +301,8 @@ struct WgParams {
     float* part;                                     // [T][slots][NT*16][KT*16]
     int groups;
     int ones;                                        // append a column of ones to X (k % 16 != 0)
+    // X := BatchNorm(X) formed while the strip is staged (bn_apply's arithmetic, see LinParams); tables live bn_off floats into the LDS
+    const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_off;
     ExpandSrc ex;                                    // EXPAND: G is formed from ex (G, sG unused)
 };
 
@@ -287,6 +321,19 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
     float* Xl = Gl + strip_floats(n);
     float* Fl = Xl + strip_floats(k);                // 16 x f4 scale factors (EXPAND)
     for (int i = lane; i < strip_floats(n) + strip_floats(k); i += 64) Gl[i] = 0.f;
+    const float* BnW = nullptr;
+    if (!EXPAND && p.bn_mean) {                      // (uniform)
+        float* tab = lds + p.bn_off;
+        for (int i = tid; i < KT * 16; i += blockDim.x) {
+            const bool in = i < k;
+            tab[i] = in ? p.bn_mean[i] : 0.f;
+            tab[KT * 16 + i] = in ? p.bn_invstd[i] : 0.f;
+            tab[2 * KT * 16 + i] = (in && p.bn_gamma) ? p.bn_gamma[i] : 1.f;
+            tab[3 * KT * 16 + i] = (in && p.bn_beta) ? p.bn_beta[i] : 0.f;
+        }
+        __syncthreads();
+        BnW = tab;
+    }
 
     const float* G = p.G + (int64_t)t * p.sG;
     const float* X = p.X + (int64_t)t * p.sX;
@@ -322,7 +369,8 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
             }
             store_strip<NLG>(Gl, pg, n, lane);
         }
-        store_strip<NLX>(Xl, px, k, lane);
+        if (BnW) store_strip_bn<NLX>(Xl, px, k, lane, BnW, KT * 16);
+        else store_strip<NLX>(Xl, px, k, lane);
         if (strip + step < n_strips) {
             fetch_g(strip + step);
             load_strip<NLX>(px, X, p.M, k, strip + step, lane);
@@ -474,6 +522,7 @@ hipError_t launch_wgrad_grid(int nt, int kt, const WgParams& p, size_t lds, hipS
 hipError_t launch_linear_plain(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_combine(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 

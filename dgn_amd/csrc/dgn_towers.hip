@@ -106,7 +106,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     Dims d;
     if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
     if (d.N == 0) return DGN_OK;
-    if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || !L->y1 || !L->z || !L->out || !L->save_mean ||
+    if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || !L->z || !L->out || !L->save_mean ||
         !L->save_invstd || (d.S > 1 && !L->scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
     const size_t bn_ws = up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
     if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
@@ -121,10 +121,13 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
+    // (y1 == NULL: statistics only -- the mixing Linear normalises y0 while it stages its strips, the normalised tensor is never written)
     DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
                                 nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
-    DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
+    if (L->y1) DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
+    else DGN_TRY(dgn_linear_forward_bn(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, 0, nullptr, L->z, L->save_mean, L->save_invstd, L->bn_gamma,
+                                       L->bn_beta, stream));
     DGN_TRY(dgn_bias_act_forward(d.N, d.Fo, L->z, d.Fo, L->b_mix, 2, L->slope, L->residual ? L->h : nullptr, L->out, stream));
     return DGN_OK;
 }
@@ -179,8 +182,10 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                                   dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
     // mixing Linear: input and weight gradients
     DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->w_mix, d.Fo, 0, 1, nullptr, 0, g_y1, d.Fo, 0, stream));
-    DGN_TRY(dgn_linear_wgrad(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->y1, d.Fo, 0, G->g_w_mix, d.Fo, 0, nullptr, 0, ws + s.wg_mix,
-                             dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    if (L->y1) DGN_TRY(dgn_linear_wgrad(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->y1, d.Fo, 0, G->g_w_mix, d.Fo, 0, nullptr, 0, ws + s.wg_mix,
+                                        dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    else DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, nullptr, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
+                                     ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
     DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
                                  G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));

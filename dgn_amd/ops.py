@@ -865,6 +865,7 @@ def linear_combine_bn_tail(aggx, w, scale, bias, row_scale, gamma, beta, running
 # layer is enqueued by one call per direction.  At the reference's batch size the layer is host-bound otherwise (~48 launches,
 # each its own Python / autograd node).  False: the per-kernel route (same kernels, same results).
 WHOLE_LAYER = os.environ.get("DGN_WHOLE_LAYER", "1") != "0"
+FUSE_BN_MIXING = os.environ.get("DGN_FUSE_BN", "1") != "0"      # whole-layer path: BatchNorm apply inside the mixing Linear's operand staging
 
 _TOWERS_OK = {}
 
@@ -899,7 +900,11 @@ class _TowersLayer(torch.autograd.Function):
         dev = h.device
         h, w_sd, bias_sd, w_post, b_post = h.contiguous(), w_sd.contiguous(), bias_sd.contiguous(), w_post.contiguous(), b_post.contiguous()
         gamma, beta, w_mix, b_mix = gamma.contiguous(), beta.contiguous(), w_mix.contiguous(), b_mix.contiguous()
-        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, N * Fo, N * Fo, Fo, Fo], dev)
+        # y1 = BatchNorm(y0) is not materialised (FUSE_BN_MIXING): the mixing Linear and its weight gradient normalise y0 while they
+        # stage their strips (dgn_linear_forward_bn / dgn_linear_wgrad_bn) -- one pass and N * Fo saved floats per layer less
+        n_y1 = 0 if FUSE_BN_MIXING else N * Fo
+        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, n_y1, N * Fo, Fo, Fo], dev)
+        ctx.n_y1 = n_y1
         out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
         spec = _spec_structs(plan, T, avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
@@ -912,7 +917,7 @@ class _TowersLayer(torch.autograd.Function):
         L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
         L.bn_gamma, L.bn_beta, L.running_mean, L.running_var = gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()
         L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
-        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), y1.data_ptr(), z.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None), z.data_ptr()
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
         nbytes = lib.dgn_towers_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -934,7 +939,7 @@ class _TowersLayer(torch.autograd.Function):
         N, Fm, Fo = h.shape[0], T * fi, T * fo
         K = plan.n_agg * fi
         dev = h.device
-        sizes = [N * 2 * Fm, T * N * K, N * Fo, N * Fo, N * Fo, Fo, Fo]
+        sizes = [N * 2 * Fm, T * N * K, N * Fo, ctx.n_y1, N * Fo, Fo, Fo]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -953,7 +958,7 @@ class _TowersLayer(torch.autograd.Function):
         L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
         L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
         L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
-        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), y1.data_ptr(), z.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if ctx.n_y1 else None), z.data_ptr()
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)

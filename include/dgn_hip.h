@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 17
+#define DGN_ABI_VERSION 18
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -311,6 +311,16 @@ int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad);
 int dgn_linear_forward(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* a, int64_t lda, int64_t stride_a,
                        const float* w, int64_t ldw, int64_t stride_w, int32_t w_is_kn, const float* bias,
                        int64_t stride_bias, float* c, int64_t ldc, int64_t stride_c, void* stream);
+/* The same two products with the operand a (resp. x) replaced by its BatchNorm -- ((v - mean[c]) * invstd[c]) * gamma[c] + beta[c], the
+ * arithmetic of dgn_bn_tail_forward's apply pass in the same order, formed while the strips are staged: the normalised tensor is
+ * never written (the towers layer: y1 = BatchNorm(y0) feeds the mixing Linear, nets/dgn_layer.py:272-273 -> :319).  batch = 1, dense
+ * rows; gamma / beta may be NULL.  dgn_bn_tail_forward(..., y = NULL, ...) computes the statistics alone.                      */
+int dgn_linear_forward_bn(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, int32_t w_is_kn,
+                          const float* bias, float* c, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                          const float* bn_beta, void* stream);
+int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* x, float* dw, int64_t lddw, float* dbias,
+                        const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, void* ws,
+                        size_t ws_bytes, void* stream);
 /* The towers' posttrans Linear with the scale-combine epilogue of dgn_scale_combine_forward in the same pass (the
  * [T, N, S*f_out] product never reaches memory):
  *   y[m, t*f_out + o] = row_scale[m] * (bias[t*f_out + o] + sum_s scale[m, s] * (a[t] w[t]^T)[m, s*f_out + o])

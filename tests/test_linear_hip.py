@@ -171,3 +171,53 @@ def test_wide_linear_autograd_matches_library(monkeypatch):
         res.append((y, *torch.autograd.grad(y, [x, w, b], ct)))
     for a, r in zip(*res):
         torch.testing.assert_close(a, r, rtol=2e-5, atol=2e-5 * float(r.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4099, 70, 70), (275, 70, 70), (16, 84, 42), (1000, 140, 70), (5, 6, 2)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_linear_with_batchnorm_prologue_is_bitwise_bn_apply_then_linear(shape, affine):
+    """dgn_linear_forward_bn / dgn_linear_wgrad_bn (the operand normalised while its strips are staged) against dgn_bn_tail_forward's
+    apply pass followed by dgn_linear_forward / dgn_linear_wgrad: bit-identical products and bias gradient."""
+    import ctypes as C
+    from dgn_amd import _lib
+    lib = _lib.load()
+    M, k, n = shape
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + k)
+    x = torch.randn(M, k, device=dev, generator=gen) * 2 + 0.5
+    w = torch.randn(n, k, device=dev, generator=gen)
+    b = torch.randn(n, device=dev, generator=gen)
+    g = torch.randn(M, n, device=dev, generator=gen)
+    gamma = (torch.rand(k, device=dev, generator=gen) + 0.5) if affine else None
+    beta = torch.randn(k, device=dev, generator=gen) if affine else None
+    rm, rv = torch.zeros(k, device=dev), torch.ones(k, device=dev)
+    mean, invstd = torch.empty(k, device=dev), torch.empty(k, device=dev)
+    y1 = torch.empty_like(x)
+    nb = lib.dgn_bn_tail_workspace_bytes(M, k)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()
+    _lib.check(lib.dgn_bn_tail_forward(M, k, x.data_ptr(), k, P(gamma), P(beta), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, 0, None, y1.data_ptr(),
+                                       mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nb, None, st), "bn")
+    # statistics-only call gives the same statistics
+    mean2, invstd2 = torch.empty_like(mean), torch.empty_like(invstd)
+    _lib.check(lib.dgn_bn_tail_forward(M, k, x.data_ptr(), k, P(gamma), P(beta), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, 0, None, None,
+                                       mean2.data_ptr(), invstd2.data_ptr(), ws.data_ptr(), nb, None, st), "bn stats")
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2)
+    c_ref, c_fus = torch.empty(M, n, device=dev), torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward(M, k, n, 1, y1.data_ptr(), k, 0, w.data_ptr(), k, 0, 0, b.data_ptr(), 0, c_ref.data_ptr(), n, 0, st), "lin")
+    _lib.check(lib.dgn_linear_forward_bn(M, k, n, x.data_ptr(), w.data_ptr(), k, 0, b.data_ptr(), c_fus.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                         P(gamma), P(beta), st), "lin bn")
+    assert torch.equal(c_ref, c_fus)
+    if lib.dgn_linear_supported(k, n, 1):
+        nbw = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, 1)
+        wsw = torch.empty(max(nbw, 1), dtype=torch.uint8, device=dev)
+        dw_ref, dw_fus = torch.empty(n, k, device=dev), torch.empty(n, k, device=dev)
+        db_ref, db_fus = (torch.empty(n, device=dev), torch.empty(n, device=dev)) if k % 16 else (None, None)
+        _lib.check(lib.dgn_linear_wgrad(M, k, n, 1, g.data_ptr(), n, 0, y1.data_ptr(), k, 0, dw_ref.data_ptr(), k, 0, P(db_ref), 0, wsw.data_ptr(), nbw, st), "wg")
+        _lib.check(lib.dgn_linear_wgrad_bn(M, k, n, g.data_ptr(), x.data_ptr(), dw_fus.data_ptr(), k, P(db_fus), mean.data_ptr(), invstd.data_ptr(),
+                                           P(gamma), P(beta), wsw.data_ptr(), nbw, st), "wg bn")
+        assert torch.equal(dw_ref, dw_fus)
+        if db_ref is not None:
+            assert torch.equal(db_ref, db_fus)
