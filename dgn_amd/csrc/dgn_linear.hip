@@ -40,10 +40,11 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
 static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
-    const bool bn = p.bn_mean != nullptr;
-    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : 0)) * 4;
+    const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr;
+    const int mode = bn ? kBnPlain : (actm ? kActPlain : kPlain);
+    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
-    int waves = linear_threads(NT, KB, bn) / 64;
+    int waves = linear_threads(NT, KB, mode) / 64;
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
     const size_t lds = w_bytes + waves * strip_bytes;
     if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
@@ -56,6 +57,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     const hipError_t e = p.ex.gy ? launch_linear_expand(NT, KB, p, waves * 64, lds, st)
                        : p.S > 0 ? launch_linear_combine(NT, KB, p, waves * 64, lds, st)
                        : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
+                       : actm    ? launch_linear_act(NT, KB, p, waves * 64, lds, st)
                                  : launch_linear_plain(NT, KB, p, waves * 64, lds, st);
     DGN_HIP_CHECK(e);
     return 0;
@@ -96,6 +98,25 @@ extern "C" int dgn_linear_forward_bn(int64_t n_rows, int32_t k, int32_t n, const
     p.bias = bias;
     p.C = c;
     p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_act_supported(int32_t k, int32_t n) {
+    return dgn_linear_supported(k, n, 0) && linear_act_shape_ok((n + 15) / 16, (k + 15) / 16);
+}
+
+extern "C" int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
+                                      float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream) {
+    const char* fn = "dgn_linear_forward_act";
+    if (n_rows < 0 || !dgn_linear_act_supported(k, n)) { set_error("%s: need even k, n in [2, 160] (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!g || !z || !w || !c) { set_error("%s: null operand", fn); return -1; }
+    if (!aligned8(g) || !aligned8(z) || !aligned8(c) || (gz_out && (reinterpret_cast<uintptr_t>(gz_out) & 15))) { set_error("%s: operands must be 8-byte aligned (dense rows), gz_out 16-byte aligned", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = g; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
+    p.C = c;
+    p.act_z = z; p.act_bias = act_bias; p.act_kind = act; p.act_slope = slope; p.gz_out = gz_out;
     return launch_linear(fn, p, stream);
 }
 

@@ -52,10 +52,14 @@ struct LinParams {
     // kBnPlain: the operand is BatchNorm(A) formed while the strip is staged: ((a - mean[c]) * invstd[c]) * gamma[c] + beta[c], the
     // arithmetic of bn_apply (dgn_bn_tail.hip) in the same order; gamma / beta may be NULL (1 / 0)
     const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;
+    // kActPlain: the operand is a * act'(z + bias[c]) -- the gradient through bias + activation (dgn_bias_act_backward's arithmetic) --
+    // formed while the strip is staged from a and z (both [M, k] dense); gz_out (may be NULL) receives the formed operand
+    const float* act_z; const float* act_bias; int act_kind; float act_slope; float* gz_out;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_threads(int NT, int KB, bool bn = false) { return 8 * NT + 4 * KB + 52 + (bn ? 12 : 0) <= 116 ? 1024 : 512; }    // (bn: the kBnPlain staging holds a few more values)
+constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : 0); }    // kBnPlain: column state; kActPlain: a second prefetched strip
+constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
 // A strip is 16 * k consecutive floats of A (rows are dense: lda == k) starting at a multiple of 64 bytes: it is copied with
@@ -143,11 +147,42 @@ __device__ __forceinline__ void store_strip_bn(float* Xl, const float2 (&pre)[NL
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3 };        // ts_linear variants
+// store_strip for kActPlain: v = a * act'(z + bias[c]) (act: 1 ReLU, 2 LeakyReLU(slope), else identity), also written to gz (the strip's
+// place in the side output, NULL = not wanted; n2 = float2's of the strip that exist)
+__device__ __forceinline__ float act_grad_lin(float v, int act, float slope) {
+    if (act == 1) return v > 0.f ? 1.f : 0.f;
+    if (act == 2) return v > 0.f ? 1.f : slope;
+    return 1.f;
+}
+template <int NL>
+__device__ __forceinline__ void store_strip_act(float* Xl, const float2 (&pre)[NL], const float2 (&prez)[NL], int k, int lane, const float* Ba,
+                                                int act, float slope, float* gz, int n2) {
+    auto tf = [&](float a, float z, int c) { return a * act_grad_lin(z + Ba[c], act, slope); };
+    int c = (4 * lane) % k;
+    const int dc = 256 % k;
+#pragma unroll
+    for (int jq = 0; jq < NL / 2; ++jq) {
+        const int q = jq * 64 + lane;
+        if (q < (kStrip / 4) * k) {
+            const int c2 = c + 2 >= k ? c + 2 - k : c + 2;
+            const float4 v = make_float4(tf(pre[2 * jq].x, prez[2 * jq].x, c), tf(pre[2 * jq].y, prez[2 * jq].y, c + 1),
+                                         tf(pre[2 * jq + 1].x, prez[2 * jq + 1].x, c2), tf(pre[2 * jq + 1].y, prez[2 * jq + 1].y, c2 + 1));
+            reinterpret_cast<float4*>(Xl)[q] = v;
+            if (gz) {
+                if (2 * q + 1 < n2) reinterpret_cast<float4*>(gz)[q] = v;
+                else if (2 * q < n2) reinterpret_cast<float2*>(gz)[2 * q] = make_float2(v.x, v.y);
+            }
+        }
+        c += dc;
+        if (c >= k) c -= k;
+    }
+}
+
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
-__global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(LinParams p) {
-    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain;
+__global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain, ACT = MODE == kActPlain;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -158,7 +193,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(L
     float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
     float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
     float* Bn = Cb + NT * 16;                        // kBnPlain: [4][KB*16] mean, invstd, gamma, beta of the operand's columns
-    float* Xl = Bn + (BNP ? 4 * KB * 16 : 0) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
+    float* Xl = Bn + (BNP ? 4 * KB * 16 : (ACT ? KB * 16 : 0)) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
     float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
 
@@ -178,9 +213,11 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(L
         const float f0 = scp[0], f1 = scp[min(1, S1 - 1)], f2 = scp[min(2, S1 - 1)], f3 = *rsp;
         fac = f4{p.sc ? f0 : 1.f, p.sc ? f1 : 1.f, p.sc ? f2 : 1.f, p.rs ? f3 : 1.f};
     };
+    float2 prez[ACT ? NL : 1];
     auto fetch = [&](int64_t strip) {
         if constexpr (EXPAND) load_expand<NL>(pre, fac, p.ex, t, p.M, strip, lane);
         else { load_strip<NL>(pre, A, p.M, k, strip, lane); load_fac(strip); }
+        if constexpr (ACT) load_strip<NL>(prez, p.act_z, p.M, k, strip, lane);
     };
     if (first < n_strips) fetch(first);              // in flight while the weights are set up
 
@@ -194,6 +231,9 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(L
     }
     if (p.bias) for (int i = tid; i < n; i += blockDim.x) Bl[i] = p.bias[(int64_t)t * p.sBias + i];
     if (COMBINE && p.cb) for (int i = tid; i < p.fo; i += blockDim.x) Cb[i] = p.cb[t * p.fo + i];
+    if constexpr (ACT) {
+        for (int i = tid; i < KB * 16; i += blockDim.x) Bn[i] = (i < k && p.act_bias) ? p.act_bias[i] : 0.f;
+    }
     if constexpr (BNP) {
         for (int i = tid; i < KB * 16; i += blockDim.x) {
             const bool in = i < k;
@@ -250,6 +290,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE == 3)) void ts_linear(L
     for (int64_t strip = first; strip < n_strips; strip += step) {
         if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
         else if constexpr (BNP) store_strip_bn<NL>(Xl, pre, k, lane, Bn, KB * 16);
+        else if constexpr (ACT) store_strip_act<NL>(Xl, pre, prez, k, lane, Bn, p.act_kind, p.act_slope,
+                                                    p.gz_out ? p.gz_out + strip * kStrip * k : nullptr, (int)min((int64_t)kStrip, p.M - strip * kStrip) * (k >> 1));
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
@@ -450,8 +492,14 @@ static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
 // ---- dispatch: one translation unit per kernel family (dgn_linear*.hip), each instantiating its (NT, KB) grid --------
+// kActPlain holds two prefetched strips: the widest tile shapes would not fit the registers and are not instantiated
+constexpr bool linear_act_shape_ok(int NT, int KB) { return 4 * NT + 8 * KB <= 104; }
+
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
+    if constexpr (MODE == kActPlain && !linear_act_shape_ok(NT, KB)) {
+        return hipErrorInvalidValue;
+    } else {
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB, MODE>),
@@ -461,6 +509,7 @@ hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStr
     }
     hipLaunchKernelGGL((ts_linear<NT, KB, MODE>), dim3(p.T * p.groups), dim3(threads), lds, st, p);
     return hipGetLastError();
+    }
 }
 template <int NT, int KT, bool EXPAND>
 hipError_t launch_wgrad_nke(const WgParams& p, size_t lds, hipStream_t st) {
@@ -523,6 +572,7 @@ hipError_t launch_linear_plain(int nt, int kb, const LinParams& p, int threads, 
 hipError_t launch_linear_combine(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_act(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 

@@ -177,15 +177,24 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     auto f = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     float *g_z = f(s.g_z), *g_y1 = f(s.g_y1), *sums = f(s.sums), *g_yr = f(s.g_yr), *g_aggx = f(s.g_aggx), *g_pq = f(s.g_pq),
           *g_in = f(s.g_in), *g_hpq = f(s.g_hpq);
-    // bias + LeakyReLU (+ residual: its gradient is g_out itself, added at the end)
-    DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
-                                  dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
-    // mixing Linear: input and weight gradients
-    DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->w_mix, d.Fo, 0, 1, nullptr, 0, g_y1, d.Fo, 0, stream));
-    if (L->y1) DGN_TRY(dgn_linear_wgrad(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->y1, d.Fo, 0, G->g_w_mix, d.Fo, 0, nullptr, 0, ws + s.wg_mix,
-                                        dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
-    else DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, nullptr, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
-                                     ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    // bias + LeakyReLU (+ residual: its gradient is g_out itself, added at the end) and the mixing Linear's input gradient in ONE pass:
+    // g_z = g_out * act'(z + b_mix) is formed while the strips are staged and leaves as a side output for the weight gradient, whose
+    // ones-column delivers the bias gradient (the separate path: dgn_bias_act_backward, then the two products)
+    const bool fused_act = L->y1 == nullptr && d.Fo % 16 != 0 && (reinterpret_cast<uintptr_t>(g_z) & 15) == 0 && dgn_linear_act_supported(d.Fo, d.Fo);
+    if (fused_act) {
+        DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
+        DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
+                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    } else {
+        DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
+                                      dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
+        // mixing Linear: input and weight gradients
+        DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->w_mix, d.Fo, 0, 1, nullptr, 0, g_y1, d.Fo, 0, stream));
+        if (L->y1) DGN_TRY(dgn_linear_wgrad(d.N, d.Fo, d.Fo, 1, g_z, d.Fo, 0, L->y1, d.Fo, 0, G->g_w_mix, d.Fo, 0, nullptr, 0, ws + s.wg_mix,
+                                            dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+        else DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, nullptr, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
+                                         ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+    }
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
     DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
                                  G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));

@@ -321,6 +321,13 @@ int dgn_linear_forward_bn(int64_t n_rows, int32_t k, int32_t n, const float* a, 
 int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* x, float* dw, int64_t lddw, float* dbias,
                         const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, void* ws,
                         size_t ws_bytes, void* stream);
+/* c = (g * act'(z + act_bias)) . op(w): the gradient through bias + activation (dgn_bias_act_backward's arithmetic) formed while the
+ * strips of g and z ([n_rows, k] dense) are staged, then the Linear's input-gradient product; gz_out (may be NULL) receives the formed
+ * operand (the Linear's weight gradient needs it: dgn_linear_wgrad / _bn, whose dbias output is then the bias gradient).
+ * Replaces dgn_bias_act_backward + dgn_linear_forward(w_is_kn = 1) for LeakyReLU(Linear(.)) (mixing network, nets/dgn_layer.py:319). */
+int dgn_linear_act_supported(int32_t k, int32_t n);      /* (the widest tile shapes are not: two prefetched strips per wave) */
+int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
+                           float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);
 /* The towers' posttrans Linear with the scale-combine epilogue of dgn_scale_combine_forward in the same pass (the
  * [T, N, S*f_out] product never reaches memory):
  *   y[m, t*f_out + o] = row_scale[m] * (bias[t*f_out + o] + sum_s scale[m, s] * (a[t] w[t]^T)[m, s*f_out + o])

@@ -221,3 +221,33 @@ def test_linear_with_batchnorm_prologue_is_bitwise_bn_apply_then_linear(shape, a
         assert torch.equal(dw_ref, dw_fus)
         if db_ref is not None:
             assert torch.equal(db_ref, db_fus)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4099, 70, 70), (275, 70, 70), (19, 84, 42), (1000, 140, 70), (3, 6, 2)])
+@pytest.mark.parametrize("act", [2, 1, 0])
+def test_linear_with_activation_gradient_prologue_is_bitwise(shape, act):
+    """dgn_linear_forward_act (g * act'(z + b) formed while the strips are staged, side output included) against
+    dgn_bias_act_backward followed by dgn_linear_forward: bit-identical operand and product."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    M, k, n = shape
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + 7 * k + act)
+    g, z = torch.randn(M, k, device=dev, generator=gen), torch.randn(M, k, device=dev, generator=gen)
+    b = torch.randn(k, device=dev, generator=gen)
+    w = torch.randn(k, n, device=dev, generator=gen)                                   # [k, n]: c = g_z . w  (w_is_kn = 1)
+    st = torch.cuda.current_stream().cuda_stream
+    gz_ref, gb = torch.empty_like(g), torch.empty(k, device=dev)
+    nb = lib.dgn_bn_tail_workspace_bytes(M, k)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dgn_bias_act_backward(M, k, g.data_ptr(), z.data_ptr(), k, b.data_ptr(), act, 0.01, gz_ref.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, st), "bab")
+    c_ref = torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward(M, k, n, 1, gz_ref.data_ptr(), k, 0, w.data_ptr(), n, 0, 1, None, 0, c_ref.data_ptr(), n, 0, st), "lin")
+    c_fus, gz_fus = torch.empty(M, n, device=dev), torch.full((M, k), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_act(M, k, n, g.data_ptr(), z.data_ptr(), b.data_ptr(), act, 0.01, w.data_ptr(), n, 1, c_fus.data_ptr(), gz_fus.data_ptr(), st), "lin act")
+    assert torch.equal(gz_ref, gz_fus)
+    assert torch.equal(c_ref, c_fus)
+    c_no = torch.empty(M, n, device=dev)                                                # without the side output
+    _lib.check(lib.dgn_linear_forward_act(M, k, n, g.data_ptr(), z.data_ptr(), b.data_ptr(), act, 0.01, w.data_ptr(), n, 1, c_no.data_ptr(), None, st), "lin act")
+    assert torch.equal(c_ref, c_no)
