@@ -40,8 +40,8 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
 static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
-    const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr;
-    const int mode = bn ? kBnPlain : (actm ? kActPlain : kPlain);
+    const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr, addm = p.add1 != nullptr;
+    const int mode = bn ? kBnPlain : (actm ? kActPlain : (addm ? kAddPlain : kPlain));
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
@@ -58,6 +58,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
                        : p.S > 0 ? launch_linear_combine(NT, KB, p, waves * 64, lds, st)
                        : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
                        : actm    ? launch_linear_act(NT, KB, p, waves * 64, lds, st)
+                       : addm    ? launch_linear_add(NT, KB, p, waves * 64, lds, st)
                                  : launch_linear_plain(NT, KB, p, waves * 64, lds, st);
     DGN_HIP_CHECK(e);
     return 0;
@@ -98,6 +99,26 @@ extern "C" int dgn_linear_forward_bn(int64_t n_rows, int32_t k, int32_t n, const
     p.bias = bias;
     p.C = c;
     p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_add_supported(int32_t k, int32_t n) {
+    return dgn_linear_supported(k, n, 0) && linear_add_shape_ok((n + 15) / 16, (k + 15) / 16);
+}
+
+extern "C" int dgn_linear_forward_add(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, int32_t w_is_kn,
+                                      const float* add1, const float* add2, float* c, void* stream) {
+    const char* fn = "dgn_linear_forward_add";
+    if (n_rows < 0 || !dgn_linear_add_supported(k, n)) { set_error("%s: widths outside the supported set (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!a || !w || !c || !add1) { set_error("%s: null operand", fn); return -1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!aligned8(a) || !al16(c) || !al16(add1) || (add2 && !al16(add2))) { set_error("%s: a must be 8-byte, c / add1 / add2 16-byte aligned (dense rows)", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = a; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
+    p.C = c;
+    p.add1 = add1; p.add2 = add2;
     return launch_linear(fn, p, stream);
 }
 

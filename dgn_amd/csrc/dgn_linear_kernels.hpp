@@ -55,10 +55,13 @@ struct LinParams {
     // kActPlain: the operand is a * act'(z + bias[c]) -- the gradient through bias + activation (dgn_bias_act_backward's arithmetic) --
     // formed while the strip is staged from a and z (both [M, k] dense); gz_out (may be NULL) receives the formed operand
     const float* act_z; const float* act_bias; int act_kind; float act_slope; float* gz_out;
+    // kAddPlain: C = (add1 + A op(W)) + add2 -- two more [M, n] dense operands added in the epilogue (add2 may be NULL), the sum of
+    // gradient contributions that otherwise costs its own pass
+    const float* add1; const float* add2;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : 0); }    // kBnPlain: column state; kActPlain: a second prefetched strip
+constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 5 ? 64 : 0)); }    // kBnPlain: column state; kActPlain: a second prefetched strip
 constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
@@ -178,11 +181,11 @@ __device__ __forceinline__ void store_strip_act(float* Xl, const float2 (&pre)[N
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4 };        // ts_linear variants
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
 __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
-    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain, ACT = MODE == kActPlain;
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain, ACT = MODE == kActPlain, ADD = MODE == kAddPlain;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     // (8-byte pieces with gaps, straight from the accumulators, ran at half the store rate).
     int64_t out_strip = -1;
     int it = 0, out_it = 0;
+    float2 pe1[ADD ? NLC : 1], pe2[ADD ? NLC : 1];
     auto store_out = [&]() {
         if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
@@ -279,12 +283,53 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         float* dst = C + out_strip * kStrip * n;
         if (cnt2 == kStrip * (n >> 1)) {             // a full strip: 16 n floats from a 64-byte aligned address, 16-byte lanes
 #pragma unroll
-            for (int jq = 0; jq < NLC / 2; ++jq)
-                if (jq * 64 + lane < (kStrip / 4) * n) reinterpret_cast<float4*>(dst)[jq * 64 + lane] = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
+            for (int jq = 0; jq < NLC / 2; ++jq) {
+                if (jq * 64 + lane < (kStrip / 4) * n) {
+                    float4 c = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
+                    if constexpr (ADD) {
+                        c = make_float4(pe1[2 * jq].x + c.x, pe1[2 * jq].y + c.y, pe1[2 * jq + 1].x + c.z, pe1[2 * jq + 1].y + c.w);
+                        if (p.add2) c = make_float4(c.x + pe2[2 * jq].x, c.y + pe2[2 * jq].y, c.z + pe2[2 * jq + 1].x, c.w + pe2[2 * jq + 1].y);
+                    }
+                    reinterpret_cast<float4*>(dst)[jq * 64 + lane] = c;
+                }
+            }
         } else {
 #pragma unroll
-            for (int j = 0; j < NLC; ++j)
-                if (j * 64 + lane < cnt2) reinterpret_cast<float2*>(dst)[j * 64 + lane] = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+            for (int j = 0; j < NLC; ++j) {
+                if (j * 64 + lane < cnt2) {
+                    float2 c = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+                    if constexpr (ADD) {
+                        c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
+                        if (p.add2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
+                    }
+                    reinterpret_cast<float2*>(dst)[j * 64 + lane] = c;
+                }
+            }
+        }
+    };
+    // kAddPlain: the epilogue's two extra operands of strip `s_` in store_out's indexing (loaded one iteration ahead of their use)
+    auto load_adds = [&](int64_t s_) {
+        if constexpr (ADD) {
+            const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
+            const float* b1 = p.add1 + s_ * kStrip * n;
+            const float* b2 = (p.add2 ? p.add2 : p.add1) + s_ * kStrip * n;          // (branch-free loads; add2 == NULL: not used)
+            if (cnt2 == kStrip * (n >> 1)) {
+                const int last4 = (kStrip / 4) * n - 1;
+#pragma unroll
+                for (int jq = 0; jq < NLC / 2; ++jq) {
+                    const int q = min(jq * 64 + lane, last4);
+                    const float4 u = reinterpret_cast<const float4*>(b1)[q], v = reinterpret_cast<const float4*>(b2)[q];
+                    pe1[2 * jq] = make_float2(u.x, u.y); pe1[2 * jq + 1] = make_float2(u.z, u.w);
+                    pe2[2 * jq] = make_float2(v.x, v.y); pe2[2 * jq + 1] = make_float2(v.z, v.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NLC; ++j) {
+                    const int q = min(j * 64 + lane, cnt2 - 1);
+                    pe1[j] = reinterpret_cast<const float2*>(b1)[q];
+                    pe2[j] = reinterpret_cast<const float2*>(b2)[q];
+                }
+            }
         }
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
@@ -295,6 +340,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
         if (out_strip >= 0) store_out();
+        load_adds(strip);
         if (strip + step < n_strips) fetch(strip + step);
 
         f4 acc[NT];
@@ -494,10 +540,11 @@ static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T
 // ---- dispatch: one translation unit per kernel family (dgn_linear*.hip), each instantiating its (NT, KB) grid --------
 // kActPlain holds two prefetched strips: the widest tile shapes would not fit the registers and are not instantiated
 constexpr bool linear_act_shape_ok(int NT, int KB) { return 4 * NT + 8 * KB <= 104; }
+constexpr bool linear_add_shape_ok(int NT, int KB) { return 16 * NT + 4 * KB <= 128; }      // (kAddPlain: two result-shaped strips per wave in registers)
 
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
-    if constexpr (MODE == kActPlain && !linear_act_shape_ok(NT, KB)) {
+    if constexpr ((MODE == kActPlain && !linear_act_shape_ok(NT, KB)) || (MODE == kAddPlain && !linear_add_shape_ok(NT, KB))) {
         return hipErrorInvalidValue;
     } else {
     static bool attr = false;
@@ -573,6 +620,7 @@ hipError_t launch_linear_combine(int nt, int kb, const LinParams& p, int threads
 hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_act(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_add(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 

@@ -6,6 +6,7 @@
 // host side of a step is two calls.  No new device code: the calls below are the library's own entry points.
 // Reference: realworld_benchmark/nets/dgn_layer.py:254-325 (DGNTower.forward x towers, mixing network, residual).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdint>
 
@@ -220,13 +221,18 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, &gr, ws + s.agg_ws,
                              dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
     // P|Q Linear: input gradient, weight + bias gradient (the bias rides in the weight-gradient pass)
-    DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
+    // d h = [residual] + d h_in + (d P|Q) W_sd: as the product's epilogue ((d h_in + product) + residual, add3's order) where the shapes
+    // allow, else the product and a three-way add
+    const float* res = L->residual ? G->g_out : nullptr;
+    static const bool no_add_epilogue = getenv("DGN_NO_ADD_EPILOGUE") != nullptr;
+    const bool al = ((reinterpret_cast<uintptr_t>(G->g_h) | reinterpret_cast<uintptr_t>(G->g_out)) & 15) == 0;
+    const bool fused_add = !no_add_epilogue && al && (reinterpret_cast<uintptr_t>(g_in) & 15) == 0 && dgn_linear_add_supported(2 * d.Fm, d.Fm);
+    if (fused_add) DGN_TRY(dgn_linear_forward_add(d.N, 2 * d.Fm, d.Fm, g_pq, L->w_sd, d.Fm, 1, g_in, res, G->g_h, stream));
+    else DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
     DGN_TRY(dgn_linear_wgrad(d.N, d.Fm, 2 * d.Fm, 1, g_pq, 2 * d.Fm, 0, L->h, d.Fm, 0, G->g_w_sd, d.Fm, 0, G->g_bias_sd, 0, ws + s.wg_sd,
                              dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1), stream));
-    // d h = [residual] + d h_in + (d P|Q) W_sd
+    if (fused_add) return DGN_OK;
     const int64_t n = d.N * d.Fm, n4 = n / 4;
-    const bool al = ((reinterpret_cast<uintptr_t>(G->g_h) | reinterpret_cast<uintptr_t>(G->g_out)) & 15) == 0;
-    const float* res = L->residual ? G->g_out : nullptr;
     if (al && n4 > 0) {
         hipLaunchKernelGGL(add3_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, reinterpret_cast<const float4*>(res),
                            reinterpret_cast<const float4*>(g_in), reinterpret_cast<const float4*>(g_hpq), reinterpret_cast<float4*>(G->g_h));

@@ -325,6 +325,11 @@ int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const float* g, co
  * strips of g and z ([n_rows, k] dense) are staged, then the Linear's input-gradient product; gz_out (may be NULL) receives the formed
  * operand (the Linear's weight gradient needs it: dgn_linear_wgrad / _bn, whose dbias output is then the bias gradient).
  * Replaces dgn_bias_act_backward + dgn_linear_forward(w_is_kn = 1) for LeakyReLU(Linear(.)) (mixing network, nets/dgn_layer.py:319). */
+/* c = (add1 + a . op(w)) + add2: two more [n_rows, n] dense operands added in the product's epilogue (add2 may be NULL) -- the three-way
+ * sum of the contributions to d h at the end of the towers layer's backward (residual, h_in of the sweep, the P|Q input gradient). */
+int dgn_linear_add_supported(int32_t k, int32_t n);
+int dgn_linear_forward_add(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, int32_t w_is_kn,
+                           const float* add1, const float* add2, float* c, void* stream);
 int dgn_linear_act_supported(int32_t k, int32_t n);      /* (the widest tile shapes are not: two prefetched strips per wave) */
 int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
                            float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);

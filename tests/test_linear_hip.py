@@ -251,3 +251,26 @@ def test_linear_with_activation_gradient_prologue_is_bitwise(shape, act):
     c_no = torch.empty(M, n, device=dev)                                                # without the side output
     _lib.check(lib.dgn_linear_forward_act(M, k, n, g.data_ptr(), z.data_ptr(), b.data_ptr(), act, 0.01, w.data_ptr(), n, 1, c_no.data_ptr(), None, st), "lin act")
     assert torch.equal(c_ref, c_no)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4099, 140, 70), (275, 140, 70), (19, 84, 42), (1000, 70, 70), (3, 6, 2)])
+@pytest.mark.parametrize("two", [True, False])
+def test_linear_with_add_epilogue_is_bitwise(shape, two):
+    """dgn_linear_forward_add: (add1 + a w) + add2 in the product's epilogue against the product followed by the sums in that order."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    M, k, n = shape
+    if not lib.dgn_linear_add_supported(k, n):
+        pytest.skip("shape outside the add-epilogue set")
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + k + int(two))
+    a, w = torch.randn(M, k, device=dev, generator=gen), torch.randn(k, n, device=dev, generator=gen)
+    e1, e2 = torch.randn(M, n, device=dev, generator=gen), torch.randn(M, n, device=dev, generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    c = torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward(M, k, n, 1, a.data_ptr(), k, 0, w.data_ptr(), n, 0, 1, None, 0, c.data_ptr(), n, 0, st), "lin")
+    want = (e1 + c) + e2 if two else e1 + c
+    got = torch.full((M, n), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_add(M, k, n, a.data_ptr(), w.data_ptr(), n, 1, e1.data_ptr(), e2.data_ptr() if two else None, got.data_ptr(), st), "lin add")
+    assert torch.equal(got, want)
