@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
         lib.dgn_linear_forward_bn.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
         lib.dgn_linear_forward_act.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp, vp, vp]
         lib.dgn_linear_forward_add.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
+        lib.dgn_linear_forward_bn_act.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, C.c_float, vp, vp, vp, vp]
         lib.dgn_linear_wgrad_bn.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         lib.dgn_agg_edge_table_workspace_bytes.restype = C.c_size_t
         lib.dgn_agg_edge_table_workspace_bytes.argtypes = [C.c_int64, C.c_int32]

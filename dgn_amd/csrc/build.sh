@@ -13,7 +13,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -W
        -munsafe-fp-atomics -ffp-contract=off -Rpass-analysis=kernel-resource-usage ${DGN_EXTRA_FLAGS:-})
 objs=()
 pids=()
-for f in dgn_abi dgn_towers dgn_gemm dgn_fused dgn_graph_build dgn_edge_weights dgn_combine dgn_bn_tail dgn_linear dgn_linear_bn dgn_linear_act dgn_linear_add dgn_linear_combine dgn_linear_expand dgn_linear_wgrad dgn_agg dgn_agg_v1 dgn_agg_v2 dgn_agg_v4; do
+for f in dgn_abi dgn_towers dgn_gemm dgn_fused dgn_graph_build dgn_edge_weights dgn_combine dgn_bn_tail dgn_linear dgn_linear_bn dgn_linear_act dgn_linear_add dgn_linear_mix dgn_linear_combine dgn_linear_expand dgn_linear_wgrad dgn_agg dgn_agg_v1 dgn_agg_v2 dgn_agg_v4; do
   ( "$HIPCC" "${FLAGS[@]}" -c "$here/$f.hip" -o "$objdir/$f.o" 2> "$objdir/$f.remarks" ) &
   pids+=($!)
   objs+=("$objdir/$f.o")

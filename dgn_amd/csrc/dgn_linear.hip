@@ -41,7 +41,8 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
     const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr, addm = p.add1 != nullptr;
-    const int mode = bn ? kBnPlain : (actm ? kActPlain : (addm ? kAddPlain : kPlain));
+    const bool mixm = p.out2 != nullptr;
+    const int mode = mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (addm ? kAddPlain : kPlain)));
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
@@ -56,6 +57,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const hipError_t e = p.ex.gy ? launch_linear_expand(NT, KB, p, waves * 64, lds, st)
                        : p.S > 0 ? launch_linear_combine(NT, KB, p, waves * 64, lds, st)
+                       : mixm    ? launch_linear_mix(NT, KB, p, waves * 64, lds, st)
                        : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
                        : actm    ? launch_linear_act(NT, KB, p, waves * 64, lds, st)
                        : addm    ? launch_linear_add(NT, KB, p, waves * 64, lds, st)
@@ -119,6 +121,24 @@ extern "C" int dgn_linear_forward_add(int64_t n_rows, int32_t k, int32_t n, cons
     p.A = a; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
     p.C = c;
     p.add1 = add1; p.add2 = add2;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_forward_bn_act(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, const float* bn_mean,
+                                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const float* act_bias, int32_t act,
+                                         float slope, const float* residual, float* z_out, float* out, void* stream) {
+    const char* fn = "dgn_linear_forward_bn_act";
+    if (n_rows < 0 || !dgn_linear_add_supported(k, n)) { set_error("%s: widths outside the supported set (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!a || !w || !z_out || !out || !bn_mean || !bn_invstd) { set_error("%s: null operand", fn); return -1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!aligned8(a) || !al16(z_out) || !al16(out) || (residual && !al16(residual))) { set_error("%s: a must be 8-byte, z_out / out / residual 16-byte aligned", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = a; p.W = w; p.ldw = ldw; p.w_kn = 0;
+    p.C = z_out;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    p.ep_bias = act_bias; p.act_kind = act; p.act_slope = slope; p.add1 = residual; p.out2 = out;
     return launch_linear(fn, p, stream);
 }
 

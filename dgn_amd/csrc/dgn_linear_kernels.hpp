@@ -58,10 +58,13 @@ struct LinParams {
     // kAddPlain: C = (add1 + A op(W)) + add2 -- two more [M, n] dense operands added in the epilogue (add2 may be NULL), the sum of
     // gradient contributions that otherwise costs its own pass
     const float* add1; const float* add2;
+    // kMixFwd: kBnPlain's prologue AND an epilogue that also delivers out2 = act(C + ep_bias[c]) (+ add1: the residual), C itself being
+    // written as well (the pre-activation the backward needs): BatchNorm -> Linear -> bias + LeakyReLU + residual in one pass
+    const float* ep_bias; float* out2;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 5 ? 64 : 0)); }    // kBnPlain: column state; kActPlain: a second prefetched strip
+constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 5 || mode == 6 ? 64 : 0)); }    // kBnPlain: column state; kActPlain: a second prefetched strip
 constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
@@ -181,11 +184,11 @@ __device__ __forceinline__ void store_strip_act(float* Xl, const float2 (&pre)[N
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5 };        // ts_linear variants
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
 __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
-    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, BNP = MODE == kBnPlain, ACT = MODE == kActPlain, ADD = MODE == kAddPlain;
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain, ADD = MODE == kAddPlain || MIX;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     if constexpr (ACT) {
         for (int i = tid; i < KB * 16; i += blockDim.x) Bn[i] = (i < k && p.act_bias) ? p.act_bias[i] : 0.f;
     }
+    if constexpr (MIX) {
+        for (int i = tid; i < NT * 16; i += blockDim.x) Cb[i] = (i < n && p.ep_bias) ? p.ep_bias[i] : 0.f;
+    }
     if constexpr (BNP) {
         for (int i = tid; i < KB * 16; i += blockDim.x) {
             const bool in = i < k;
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     int64_t out_strip = -1;
     int it = 0, out_it = 0;
     float2 pe1[ADD ? NLC : 1], pe2[ADD ? NLC : 1];
+    const int mix_c4 = (4 * lane) % n, mix_d4 = 256 % n;       // kMixFwd: column of the lane's float4 number lane (+ 64 jq) of a result strip
     auto store_out = [&]() {
         if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
@@ -286,7 +293,13 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
             for (int jq = 0; jq < NLC / 2; ++jq) {
                 if (jq * 64 + lane < (kStrip / 4) * n) {
                     float4 c = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
-                    if constexpr (ADD) {
+                    if constexpr (MIX) {
+                        const int cc = (mix_c4 + jq * mix_d4) % n, c2 = cc + 2 >= n ? cc + 2 - n : cc + 2;
+                        auto af = [&](float v) { return p.act_kind == 1 ? fmaxf(v, 0.f) : (p.act_kind == 2 ? (v > 0.f ? v : v * p.act_slope) : v); };
+                        float4 o = make_float4(af(c.x + Cb[cc]), af(c.y + Cb[cc + 1]), af(c.z + Cb[c2]), af(c.w + Cb[c2 + 1]));
+                        if (p.add1) o = make_float4(o.x + pe1[2 * jq].x, o.y + pe1[2 * jq].y, o.z + pe1[2 * jq + 1].x, o.w + pe1[2 * jq + 1].y);
+                        reinterpret_cast<float4*>(p.out2 + out_strip * kStrip * n)[jq * 64 + lane] = o;
+                    } else if constexpr (ADD) {
                         c = make_float4(pe1[2 * jq].x + c.x, pe1[2 * jq].y + c.y, pe1[2 * jq + 1].x + c.z, pe1[2 * jq + 1].y + c.w);
                         if (p.add2) c = make_float4(c.x + pe2[2 * jq].x, c.y + pe2[2 * jq].y, c.z + pe2[2 * jq + 1].x, c.w + pe2[2 * jq + 1].y);
                     }
@@ -298,7 +311,13 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
             for (int j = 0; j < NLC; ++j) {
                 if (j * 64 + lane < cnt2) {
                     float2 c = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
-                    if constexpr (ADD) {
+                    if constexpr (MIX) {
+                        const int cc = (2 * (j * 64 + lane)) % n;
+                        auto af = [&](float v) { return p.act_kind == 1 ? fmaxf(v, 0.f) : (p.act_kind == 2 ? (v > 0.f ? v : v * p.act_slope) : v); };
+                        float2 o = make_float2(af(c.x + Cb[cc]), af(c.y + Cb[cc + 1]));
+                        if (p.add1) o = make_float2(o.x + pe1[j].x, o.y + pe1[j].y);
+                        reinterpret_cast<float2*>(p.out2 + out_strip * kStrip * n)[j * 64 + lane] = o;
+                    } else if constexpr (ADD) {
                         c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
                         if (p.add2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
                     }
@@ -311,8 +330,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     auto load_adds = [&](int64_t s_) {
         if constexpr (ADD) {
             const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
-            const float* b1 = p.add1 + s_ * kStrip * n;
-            const float* b2 = (p.add2 ? p.add2 : p.add1) + s_ * kStrip * n;          // (branch-free loads; add2 == NULL: not used)
+            const float* b1 = (p.add1 ? p.add1 : C) + s_ * kStrip * n;               // (branch-free loads; a NULL operand is not used)
+            const float* b2 = (p.add2 ? p.add2 : (p.add1 ? p.add1 : C)) + s_ * kStrip * n;
             if (cnt2 == kStrip * (n >> 1)) {
                 const int last4 = (kStrip / 4) * n - 1;
 #pragma unroll
@@ -544,7 +563,7 @@ constexpr bool linear_add_shape_ok(int NT, int KB) { return 16 * NT + 4 * KB <= 
 
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
-    if constexpr ((MODE == kActPlain && !linear_act_shape_ok(NT, KB)) || (MODE == kAddPlain && !linear_add_shape_ok(NT, KB))) {
+    if constexpr ((MODE == kActPlain && !linear_act_shape_ok(NT, KB)) || ((MODE == kAddPlain || MODE == kMixFwd) && !linear_add_shape_ok(NT, KB))) {
         return hipErrorInvalidValue;
     } else {
     static bool attr = false;
@@ -621,6 +640,7 @@ hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads,
 hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_act(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_add(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_mix(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 

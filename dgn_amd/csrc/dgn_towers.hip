@@ -126,6 +126,14 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
                                 nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
+    static const bool no_mix_fused = getenv("DGN_NO_MIX_FUSED") != nullptr;
+    const bool al = ((reinterpret_cast<uintptr_t>(L->z) | reinterpret_cast<uintptr_t>(L->out) | reinterpret_cast<uintptr_t>(L->h)) & 15) == 0;
+    if (!L->y1 && !no_mix_fused && al && dgn_linear_add_supported(d.Fo, d.Fo)) {
+        // ... all of it in one pass: the normalised operand formed while staged, bias + LeakyReLU + residual in the epilogue
+        DGN_TRY(dgn_linear_forward_bn_act(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta, L->b_mix, 2,
+                                          L->slope, L->residual ? L->h : nullptr, L->z, L->out, stream));
+        return DGN_OK;
+    }
     if (L->y1) DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
     else DGN_TRY(dgn_linear_forward_bn(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, 0, nullptr, L->z, L->save_mean, L->save_invstd, L->bn_gamma,
                                        L->bn_beta, stream));

@@ -330,6 +330,13 @@ int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const float* g, co
 int dgn_linear_add_supported(int32_t k, int32_t n);
 int dgn_linear_forward_add(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, int32_t w_is_kn,
                            const float* add1, const float* add2, float* c, void* stream);
+/* BatchNorm -> Linear -> bias + activation (+ residual) in one pass: z_out = BatchNorm(a) w^T (the pre-activation the backward needs),
+ * out = act(z_out + act_bias) + residual (dgn_bn_tail's apply, dgn_linear_forward and dgn_bias_act_forward in their arithmetic and order);
+ * widths as dgn_linear_add_supported.  The tail of the towers layer: batchnorm_h -> mixing_network -> residual (nets/dgn_layer.py:272-273,
+ * :318-324).                                                                                                                          */
+int dgn_linear_forward_bn_act(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, const float* bn_mean,
+                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const float* act_bias, int32_t act,
+                              float slope, const float* residual, float* z_out, float* out, void* stream);
 int dgn_linear_act_supported(int32_t k, int32_t n);      /* (the widest tile shapes are not: two prefetched strips per wave) */
 int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
                            float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);

@@ -274,3 +274,37 @@ def test_linear_with_add_epilogue_is_bitwise(shape, two):
     got = torch.full((M, n), float("nan"), device=dev)
     _lib.check(lib.dgn_linear_forward_add(M, k, n, a.data_ptr(), w.data_ptr(), n, 1, e1.data_ptr(), e2.data_ptr() if two else None, got.data_ptr(), st), "lin add")
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4099, 70, 70), (275, 70, 70), (19, 84, 42), (3, 6, 2)])
+@pytest.mark.parametrize("residual", [True, False])
+def test_bn_linear_act_residual_in_one_pass_is_bitwise(shape, residual):
+    """dgn_linear_forward_bn_act against dgn_bn_tail_forward (apply) -> dgn_linear_forward -> dgn_bias_act_forward: both outputs bit-identical."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    M, k, n = shape
+    if not lib.dgn_linear_add_supported(k, n):
+        pytest.skip("shape outside the supported set")
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + 3 * k)
+    x = torch.randn(M, k, device=dev, generator=gen) + 0.3
+    w, b = torch.randn(n, k, device=dev, generator=gen), torch.randn(n, device=dev, generator=gen)
+    gamma, beta = torch.rand(k, device=dev, generator=gen) + 0.5, torch.randn(k, device=dev, generator=gen)
+    res = torch.randn(M, n, device=dev, generator=gen) if residual else None
+    rm, rv = torch.zeros(k, device=dev), torch.ones(k, device=dev)
+    mean, invstd, y1 = torch.empty(k, device=dev), torch.empty(k, device=dev), torch.empty_like(x)
+    nb = lib.dgn_bn_tail_workspace_bytes(M, k)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()
+    _lib.check(lib.dgn_bn_tail_forward(M, k, x.data_ptr(), k, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, 1, 0, None,
+                                       y1.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nb, None, st), "bn")
+    z_ref, o_ref = torch.empty(M, n, device=dev), torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward(M, k, n, 1, y1.data_ptr(), k, 0, w.data_ptr(), k, 0, 0, None, 0, z_ref.data_ptr(), n, 0, st), "lin")
+    _lib.check(lib.dgn_bias_act_forward(M, n, z_ref.data_ptr(), n, b.data_ptr(), 2, 0.01, P(res), o_ref.data_ptr(), st), "act")
+    z_f, o_f = torch.full((M, n), float("nan"), device=dev), torch.full((M, n), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_bn_act(M, k, n, x.data_ptr(), w.data_ptr(), k, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             b.data_ptr(), 2, 0.01, P(res), z_f.data_ptr(), o_f.data_ptr(), st), "fused")
+    assert torch.equal(z_ref, z_f)
+    assert torch.equal(o_ref, o_f)
