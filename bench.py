@@ -51,6 +51,10 @@ WORKLOADS = {
                     "mean max min dir1-av dir1-dx x identity amplification attenuation",
                gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
+    "c2c": dict(desc="ZINC-12k, DGN complex (the type_net of configs/molecules_graph_regression_DGN_ZINC.json): hidden 70, one tower, "
+                     "mean max min dir1-av dir1-dx x identity amplification attenuation",
+                gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=70,
+                aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=1),
     "c2e": dict(desc="ZINC-12k towers as c2 WITH edge features (edge_dim 10: pretrans on [h_src || h_dst || ef])",
                 gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                 aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5, edge_dim=10),
@@ -728,7 +732,7 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()
