@@ -25,7 +25,10 @@ constexpr int kWaves = 8;            // ts_gemm: rows per workgroup pass = 16 * 
 #ifndef DGN_GEMM_KC
 #define DGN_GEMM_KC 16     // 32 (half the barriers) measured 5-15 % slower: more registers, one workgroup per CU either way
 #endif
-constexpr int kKC = DGN_GEMM_KC;              // reduction columns per LDS chunk (one barrier per chunk)
+constexpr int kKC = DGN_GEMM_KC;
+#ifndef DGN_GEMM_ABL
+#define DGN_GEMM_ABL 0      // timing ablations (tools only, results wrong): 1 no A loads after the first chunk, 2 no W fetch / commit after the first, 3 no barrier in the k loop, 4 = 1 + 2
+#endif              // reduction columns per LDS chunk (one barrier per chunk)
 constexpr int kKS = kKC + 4;         // LDS row stride of a weight chunk (floats): spreads the rows over the banks
 constexpr int kMaxNT = 16;           // n-slice of at most 256 columns per workgroup column (128: measured 5-15 % slower)
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
         __syncthreads();
         for (int kc = 0; kc < KB; ++kc) {
             AChunk xn = xv;
-            if (kc + 1 < KB) { xn = load_a(arow, kc + 1); fetch(wreg, kc + 1); }              // next chunk's A and W in flight during the MFMAs
+            if (kc + 1 < KB) { if (DGN_GEMM_ABL != 1 && DGN_GEMM_ABL != 4) xn = load_a(arow, kc + 1); if (DGN_GEMM_ABL != 2 && DGN_GEMM_ABL != 4) fetch(wreg, kc + 1); }              // next chunk's A and W in flight during the MFMAs
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
             const float* wl = Wc_dyn + (kc & 1) * kBuf + i16 * kKS + 16 * sb + 4 * g;
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
             }
             }
             xv = xn;
-            if (kc + 1 < KB) commit(wreg, (kc + 1) & 1);
-            __syncthreads();                                   // chunk kc+1 is staged; everyone is done reading chunk kc
+            if (kc + 1 < KB && DGN_GEMM_ABL != 2 && DGN_GEMM_ABL != 4) commit(wreg, (kc + 1) & 1);
+            if (DGN_GEMM_ABL != 3) __syncthreads();            // chunk kc+1 is staged; everyone is done reading chunk kc
         }
         if (row < p.M) {
             float* crow = p.C + row * p.ldc + n0;
