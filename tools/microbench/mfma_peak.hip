@@ -42,6 +42,53 @@ __global__ __launch_bounds__(1024) void spin(float* out, int iters) {
     for (int q = 0; q < ACC; ++q) r += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
     if (r == 12345.678f) out[0] = r;
 }
+// sixteen accumulators, 64 + 4 DISTINCT operand registers (the register pattern of the GEMM kernels' inner loop, nothing else in the loop);
+// LDS != 0: the 16 A-operand quads are re-read from LDS every iteration with ds_read_b128, as the GEMM kernels do
+template <int LDS>
+__global__ __launch_bounds__(512) void spin_regs(float* out, int iters) {
+    __shared__ float tile[16 * 16 * 20];
+    f4 acc[16], wv[16];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16 * 16 * 20; i += blockDim.x) tile[i] = 1e-3f * (i % 97);
+    __syncthreads();
+    const float* wl = tile + (lane & 15) * 20 + 4 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[q] = f4{0.f, 0.f, 0.f, 0.f}; wv[q] = *reinterpret_cast<const f4*>(wl + 16 * q * 20); }
+    f4 xv = f4{1.f + lane, 2.f, 3.f, 4.f};
+    for (int i = 0; i < iters; ++i) {
+        if (LDS) {
+#pragma unroll
+            for (int q = 0; q < LDS; ++q) wv[q] = *reinterpret_cast<const volatile f4*>(wl + 16 * q * 20);
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0 += 4)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q0 + j][s], xv[s], acc[q0 + j], 0, 0, 0);
+        xv[0] += 1e-6f;
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (r == 12345.678f) out[0] = r;
+}
+template <int LDS>
+void run_regs(int waves_per_simd, int iters) {
+    float* out; (void)hipMalloc(&out, 4);
+    const int threads = 64 * 4 * waves_per_simd > 512 ? 512 : 64 * 4 * waves_per_simd;
+    const int blocks = 256 * (64 * 4 * waves_per_simd / threads);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(spin_regs<LDS>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(spin_regs<LDS>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    const double mfmas = (double)blocks * (threads / 64) * iters * 64.0;
+    printf("distinct operand registers%s, waves/SIMD=%d: %.3f ms  %.1f TFLOP/s  (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n",
+           LDS == 16 ? " + 16 ds_read_b128 per 64 MFMAs" : (LDS == 8 ? " + 8 ds_read_b128 per 64 MFMAs" : (LDS == 4 ? " + 4 ds_read_b128 per 64 MFMAs" : "")), waves_per_simd, ms, mfmas * 2048 / (ms * 1e-3) / 1e12, 1024.0 * 2.4e9 * ms * 1e-3 / mfmas);
+    (void)hipFree(out);
+}
 template <int ACC>
 void run(int waves_per_simd, int iters, bool data = false) {
     float* out; hipMalloc(&out, 4);
@@ -66,6 +113,7 @@ void run(int waves_per_simd, int iters, bool data = false) {
 int main() {
     for (int w : {1, 2, 4}) { run<3>(w, 20000); run<9>(w, 8000); }
     run<9>(4, 200000);      // ~0.3 s: sustained
+    for (int w : {1, 2}) { run_regs<0>(w, 4000); run_regs<16>(w, 4000); run_regs<8>(w, 4000); run_regs<4>(w, 4000); }
     run<9>(2, 8000, true);
     run<9>(4, 8000, true);
     run<9>(4, 200000, true);
