@@ -130,7 +130,34 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
         const int64_t r0 = slab * rows_per_block;
         const int rows = (int)min((int64_t)rows_per_block, n_nodes - r0);
         __syncthreads();                             // previous slab fully consumed
-        {
+        const bool pairs = has_bn && (wy & 1) == 0 && (bn.ld & 1) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(bn.y) | reinterpret_cast<uintptr_t>(bn.g_out)) & 7) == 0;
+        if (pairs) {
+            // two columns per thread (8-byte loads of the BatchNorm input and of the tail's gradient; the same arithmetic per element)
+            const int wy2 = wy >> 1;
+            Cursor k((int)threadIdx.x, wy2);
+#pragma unroll 4
+            for (int i = threadIdx.x; i < rows * wy2; i += kThreads, k.next()) {
+                const int c = 2 * k.c;
+                const int64_t off = (r0 + k.r) * bn.ld + c;
+                const float2 yv = *reinterpret_cast<const float2*>(bn.y + off), gv = *reinterpret_cast<const float2*>(bn.g_out + off);
+                const float rs = row_scale ? row_scale[r0 + k.r] : 1.f;
+                float out[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int ce = c + e;
+                    const float is = c_t[wy + ce], ga = c_t[2 * wy + ce];
+                    const float xh = ((e ? yv.y : yv.x) - c_t[ce]) * is;
+                    float g = e ? gv.y : gv.x;
+                    if (bn.relu && !(xh * ga + c_t[3 * wy + ce] > 0.f)) g = 0.f;
+                    g = ga * is * (g - c_t[4 * wy + ce] - xh * c_t[5 * wy + ce]);
+                    if (r0 + k.r >= n_valid) g = 0.f;
+                    if (row_scale) g *= rs;
+                    out[e] = g;
+                }
+                *reinterpret_cast<float2*>(g_t + k.r * wy + c) = make_float2(out[0], out[1]);
+            }
+        } else {
             Cursor k((int)threadIdx.x, wy);
 #pragma unroll 4
             for (int i = threadIdx.x; i < rows * wy; i += kThreads, k.next()) {
