@@ -2,6 +2,7 @@
 #include "dgn_gemm_kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dgn {
 namespace gemm {
@@ -97,6 +98,29 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
     if (!a || !w || !c || lda < k || ldc < n || ldw < (w_is_kn ? n : k)) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     GemmParams p{};
     p.M = n_rows; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.bias = bias; p.C = c; p.ldc = ldc;
+    // 256-row tiles with both operands through LDS: wide outputs of nn.Linear-layout weights on many rows
+    const char* tile_env = getenv("DGN_TILE_GEMM");          // (read per call: the tests switch it)
+    const bool tile = tile_env ? atoi(tile_env) != 0 : (n >= 64 && n_rows >= 131072);     // (fewer rows: too few 256-row tiles to fill the CUs -- measured slower at 52 k rows)
+    if (tile && !w_is_kn) {
+        // column tiles of 16 NQ (NQ <= 8): the split with the least padded columns, fewer tiles on a tie
+        // (NQ = 8 would need 265 registers: one wave per SIMD)
+        int best_nq = 7, best_tiles = (n + 111) / 112, best_pad = best_tiles * 112 - n;
+        for (int nq = 7; nq >= 4; --nq) {
+            const int tiles = (n + 16 * nq - 1) / (16 * nq), pad = tiles * 16 * nq - n;
+            if (pad < best_pad) { best_nq = nq; best_tiles = tiles; best_pad = pad; }
+        }
+        p.n_slice = 16 * best_nq;
+        const dim3 grid((unsigned)((n_rows + kTileM - 1) / kTileM), (unsigned)best_tiles);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        switch (best_nq) {
+            case 4: hipLaunchKernelGGL(tile_gemm<4>, grid, dim3(256), 0, st, p); break;
+            case 5: hipLaunchKernelGGL(tile_gemm<5>, grid, dim3(256), 0, st, p); break;
+            case 6: hipLaunchKernelGGL(tile_gemm<6>, grid, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL(tile_gemm<7>, grid, dim3(256), 0, st, p); break;
+        }
+        DGN_HIP_CHECK(hipGetLastError());
+        return DGN_OK;
+    }
     const int slices = (n + 16 * kMaxNT - 1) / (16 * kMaxNT);
     const int nt = ((n + slices - 1) / slices + 15) / 16;
     p.n_slice = nt * 16;

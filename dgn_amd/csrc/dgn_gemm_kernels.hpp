@@ -188,6 +188,105 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
     }
 }
 
+// ---- 256 x (16 NQ) tile GEMM (C = A W^T + bias, W [n, k]) -------------------------------------------------------------------
+// Both operands staged through LDS per 16-k chunk (16-byte copies, fetched into registers before the chunk's MFMAs and committed after
+// them); four waves stacked over the rows, each with a 64-row x 16 NQ-column register tile (4 x NQ MFMA tiles, NQ <= 7): the 4 + NQ
+// ds_read_b128 of a chunk feed 16 NQ MFMAs -- one operand read per ~10 MFMAs where ts_gemm pays one per four (tools/microbench/
+// mfma_peak.hip: that ratio is what caps the fp32 MFMA stream).  The host picks NQ and the number of column tiles with the least padding
+// (n = 210: two tiles of 112; 420: four of 112; 225: three of 80).
+constexpr int kTileM = 256, kTKS = 20;
+
+template <int NQ>
+__global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
+    __shared__ float As[2][kTileM * kTKS];
+    __shared__ float Bs[2][NQ * 16 * kTKS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * kTileM;
+    const int n0 = blockIdx.y * p.n_slice;                    // n_slice = 16 NQ
+    const int KB = (p.k + 15) >> 4;
+    // this thread's 16-byte pieces of the operand chunks: A rows lr + 64 j (j < 4), W rows lr + 64 j (j < 2), k offset c4
+    const int lr = tid >> 2, c4 = (tid & 3) * 4;
+    constexpr int NBJ = (NQ * 16 + 63) / 64;
+    auto load16 = [&](const float* src, int k0) {
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k0 + e < p.k) v[e] = src[e];
+        }
+        return v;
+    };
+    auto fetch = [&](f4 (&ra)[4], f4 (&rb)[NBJ], int kc) {
+        const int k0 = 16 * kc + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = row0 + lr + 64 * j;
+            ra[j] = r < p.M ? load16(p.A + r * p.lda + k0, k0) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+            const int rl = lr + 64 * j, c = n0 + rl;
+            rb[j] = (rl < NQ * 16 && c < p.n) ? load16(p.W + (int64_t)c * p.ldw + k0, k0) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](const f4 (&ra)[4], const f4 (&rb)[NBJ], int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[buf][(lr + 64 * j) * kTKS + c4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)
+            if (lr + 64 * j < NQ * 16) *reinterpret_cast<f4*>(&Bs[buf][(lr + 64 * j) * kTKS + c4]) = rb[j];
+    };
+    f4 acc[4][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = n0 + 16 * q + 4 * g + r;
+            const float b = (p.bias && col < p.n) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt][q][r] = b;
+        }
+    }
+    f4 ra[4], rb[NBJ];
+    fetch(ra, rb, 0);
+    commit(ra, rb, 0);
+    __syncthreads();
+    for (int kc = 0; kc < KB; ++kc) {
+        if (kc + 1 < KB) fetch(ra, rb, kc + 1);                    // next chunk in flight during the MFMAs
+        const float* al = &As[kc & 1][(64 * wave + i16) * kTKS + 4 * g];
+        const float* bl = &Bs[kc & 1][i16 * kTKS + 4 * g];
+        f4 xa[4], wb[NQ];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const f4*>(al + 16 * t * kTKS);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) wb[q] = *reinterpret_cast<const f4*>(bl + 16 * q * kTKS);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[q][s], xa[rt][s], acc[rt][q], 0, 0, 0);
+        if (kc + 1 < KB) commit(ra, rb, (kc + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int64_t row = row0 + 64 * wave + 16 * rt + i16;
+        if (row < p.M) {
+            float* crow = p.C + row * p.ldc;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int col = n0 + 16 * q + 4 * g;
+                if (col + 3 < p.n) *reinterpret_cast<f4u*>(crow + col) = acc[rt][q];
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (col + r < p.n) crow[col + r] = acc[rt][q][r];
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradient ----------------------------------------------------------------------------------------------------
 constexpr int kWgWaves = 16;
 constexpr int kMaxKT = 16;           // k-tiles one wave accumulates (64 registers): k-slice of at most 256 columns
