@@ -127,7 +127,19 @@ class EdgeTypeFeatures:
         return self.table.index_select(0, self.types.long())
 
     def slot_types(self, graph: DGNGraph) -> torch.Tensor:
-        return graph.to_slot_order(self.types).to(torch.int32).contiguous()
+        """The types in CSR slot order, int32, CLAMPED to the table's rows (a type outside [0, K) would index outside the sweep's LDS
+        table; ``nn.Embedding`` raises a device assert there, ``validate()`` is the host-side equivalent); cached per graph."""
+        ent = graph.__dict__.get("_slot_types")
+        if ent is not None and ent[0] is self.types and ent[1] == self.types._version:
+            return ent[2]
+        t = graph.to_slot_order(self.types).clamp(0, self.table.shape[0] - 1).to(torch.int32).contiguous()
+        graph.__dict__["_slot_types"] = (self.types, self.types._version, t)
+        return t
+
+    def validate(self) -> None:
+        """Raise if a type lies outside the table (one host sync; what ``nn.Embedding`` would assert on the device)."""
+        if self.types.numel() and (int(self.types.min()) < 0 or int(self.types.max()) >= self.table.shape[0]):
+            raise IndexError(f"EdgeTypeFeatures: edge types must lie in [0, {self.table.shape[0]})")
 
 
 def _edge_term(graph: DGNGraph, e, w_edge):
@@ -136,24 +148,35 @@ def _edge_term(graph: DGNGraph, e, w_edge):
     if isinstance(e, EdgeTypeFeatures):
         Fm = w_edge.shape[0]
         det = (Fm % 2 == 0) if _ops.DETERMINISTIC_BACKWARD == "auto" else bool(_ops.DETERMINISTIC_BACKWARD)
-        if e.table.shape[0] * Fm <= _ops.MAX_EDGE_TABLE and det:
+        if e.table.shape[0] * Fm <= _ops.MAX_EDGE_TABLE and det and not hasattr(graph, "_pad"):
             return F.linear(e.table, w_edge), e.slot_types(graph)
         e = e.dense()
     # the permuted copy is edge_dim floats per edge (40 B), the product runs on the streaming Linear kernels (k = edge_dim)
     return node_linear(graph.to_slot_order(e), w_edge), None
 
 
-def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features):
+def _messages(pretrans: MLP, graph: DGNGraph, h, e, in_dim, edge_features, pad_to=None):
     """(x_pair, m_edge, edge_type) such that m_j = P[src_j] + Q[i] + m_edge[j] (or + m_edge[edge_type[j]]) with
-    x_pair = P | Q [N, 2*in] equals pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80."""
+    x_pair = P | Q [N, 2*in] equals pretrans([h_src || h_dst (|| ef)]) of dgn_layer.py:75-80.
+    ``pad_to`` = Fp > in: ``h`` is [N, Fp] (zero columns appended) and the messages come out Fp wide with zero columns
+    (zero weight rows / bias entries): an odd hidden size (ZINC json: 45, PATTERN json: 47) then runs the 8-byte-lane
+    sweep and the two-phase scatter like an even one."""
     if pretrans.is_single_affine():
         lin = pretrans.fully_connected[0].linear
         W = lin.weight                                     # [in, 2*in (+edge_dim)]
         bias = lin.bias
-        w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
-        b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
-        pq = node_linear(h, w_sd, b_sd)                    # [N, 2*in]: P | Q
-        m_edge, edge_type = _edge_term(graph, e, W[:, 2 * in_dim:]) if edge_features else (None, None)
+        Fp = in_dim if pad_to is None else pad_to
+        if Fp != in_dim:
+            # rows in -> Fp (the padded message columns), columns in -> Fp (the padded input columns)
+            w_sd = F.pad(torch.stack([W[:, :in_dim], W[:, in_dim:2 * in_dim]]), (0, Fp - in_dim, 0, Fp - in_dim)).reshape(2 * Fp, Fp)
+            b_sd = None if bias is None else F.pad(bias, (Fp, Fp - in_dim))
+            w_e = F.pad(W[:, 2 * in_dim:], (0, 0, 0, Fp - in_dim)) if edge_features else None
+        else:
+            w_sd = torch.cat([W[:, :in_dim], W[:, in_dim:2 * in_dim]], dim=0)   # [2*in, in]
+            b_sd = None if bias is None else torch.cat([torch.zeros_like(bias), bias])
+            w_e = W[:, 2 * in_dim:]
+        pq = node_linear(h, w_sd, b_sd)                    # [N, 2*Fp]: P | Q
+        m_edge, edge_type = _edge_term(graph, e, w_e) if edge_features else (None, None)
         return pq, m_edge, edge_type
     # general pretrans (ReLU between layers): materialise the messages, directly in slot order
     z = [h.index_select(0, graph.src.long()), h.index_select(0, _slot_dst(graph))]
@@ -329,10 +352,10 @@ class DGNLayerComplex(nn.Module):
         if in_dim != out_dim:
             self.residual = False
 
-    def aggregate(self, g, h, e, plan=None, eig=None):
+    def aggregate(self, g, h, e, plan=None, eig=None, pad_to=None):
         eig = g.ndata["eig"] if eig is None else eig           # (the caller's current eig, see DGNLayerSimple.aggregate)
         graph = as_dgn_graph(g, h.device)
-        x_pair, m_edge, edge_type = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features)
+        x_pair, m_edge, edge_type = _messages(self.pretrans, graph, h, e, self.in_dim, self.edge_features, pad_to)
         return directional_aggregate(graph, plan or self.plan, self._avg_log, x_pair=x_pair, m_edge=m_edge,
                                      x_in=h, eig=eig, edge_type=edge_type)
 
@@ -351,8 +374,17 @@ class DGNLayerComplex(nn.Module):
             graph = as_dgn_graph(g, h.device)
             lin = self.posttrans.fully_connected[0].linear
             S, fo = self.plan.n_scalers, lin.weight.shape[0]
-            aggx = self.aggregate(graph, h, e, self._kplan_x, eig)                     # [N, A*F | F]
-            w = _folded_weight(lin.weight[:, self.in_dim:], lin.weight[:, :self.in_dim], S, id_slot)
+            F0 = self.in_dim
+            w_agg, w_h = lin.weight[:, F0:], lin.weight[:, :F0]
+            if F0 % 2 and self.pretrans.is_single_affine():
+                # odd hidden size (ZINC json 45, PATTERN json 47): one zero feature column through the whole message path, met by
+                # zero posttrans columns -- outputs and gradients unchanged, the sweep runs its 8-byte-lane kernels
+                Fp = F0 + 1
+                aggx = self.aggregate(graph, F.pad(h, (0, 1)), e, self._kplan_x, eig, pad_to=Fp)  # [N, A*Fp | Fp]
+                w_agg, w_h = _pad_blocks(w_agg, S * len(self.aggregators), F0, Fp), F.pad(w_h, (0, 1))
+            else:
+                aggx = self.aggregate(graph, h, e, self._kplan_x, eig)                     # [N, A*F | F]
+            w = _folded_weight(w_agg, w_h, S, id_slot)
             z = node_linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)          # (+snorm, BatchNorm, ReLU, residual)

@@ -124,6 +124,10 @@ class DGNGraph:
         _lib.check(lib.dgn_graph_build_csc(n_cap, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(),
                                            self._csc_order.data_ptr(), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build_csc")
         self.n_valid.fill_(N)
+        if E < pad["e_cap"]:
+            # slots beyond the batch's edges: no row points at them, but per-edge tensors are e_cap rows long (to_slot_order gathers through
+            # eid, the edge-feature Linear runs over all rows) -- keep the tail a valid, fixed gather of edge 0 instead of the previous batch's ids
+            self.eid[E:].zero_()
         if eig is not None:
             buf = self.ndata["eig"]
             buf[:N].copy_(eig, non_blocking=True)
@@ -137,7 +141,7 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        for k in ("_scale_cache", "_dst_slots", "_eig_norm"):
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types"):
             self.__dict__.pop(k, None)
 
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):

@@ -132,6 +132,9 @@ class CapturedNetStep:
     def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None):
         from .graph import DGNGraph
         dev = torch.device(device if device is not None else next(net.parameters()).device)
+        if getattr(net, "edge_feat", False):
+            raise ValueError("CapturedNetStep: nets with edge_feat=True are not supported (the captured step has no static bond-type "
+                             "buffer); run them eagerly or build the net with edge_feat=False")
         self.net, self.device, self.g_cap = net, dev, int(g_cap)
         self.pb = PaddedBatch(n_cap, e_cap, dev, eig_dim)
         self.atoms = torch.zeros(n_cap, dtype=torch.int64, device=dev)

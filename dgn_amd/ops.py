@@ -56,8 +56,13 @@ class padded_rows:
 
 
 def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
-    key = (n_towers, float(avg_log), int(tower_stride))
+    # (tower_stride = N * K of the batch at hand is patched into the cached structs per call: keying the cache on it would add a
+    # permanent entry per distinct batch node count over a training run.  Calls are synchronous: the struct is read before return.)
+    key = (n_towers, float(avg_log))
     cache = plan.__dict__.setdefault("_spec_cache", {})
+    if key in cache:
+        for s in cache[key]:
+            s.tower_stride = int(tower_stride)
     if key not in cache:
         specs = []
         for l in plan.launches:
@@ -206,6 +211,9 @@ class _DirectionalAggregate(torch.autograd.Function):
         if edge_type is not None:
             if m_edge is None or x_src is None:
                 raise ValueError("edge_type needs the table (m_edge [K, F]) and x_src")
+            if hasattr(graph, "_pad"):
+                raise _lib.DgnError("edge-type table on a padded graph: the table-gradient reduction runs over all e_cap slots; "
+                                    "pass the gathered rows (EdgeTypeFeatures does so by itself on padded graphs)")
             if edge_type.dtype != torch.int32 or edge_type.shape != (E,) or not edge_type.is_contiguous() or not edge_type.is_cuda:
                 raise ValueError(f"edge_type: expected a contiguous CUDA int32 [{E}] in CSR slot order")
             if m_edge.shape[0] * F > MAX_EDGE_TABLE:
@@ -257,7 +265,8 @@ class _DirectionalAggregate(torch.autograd.Function):
         else:
             g_src = _empty_rows(x_src) if (x_src is not None and (need_src or ctx.xin_is_src)) else None
             g_dst = _empty_rows(x_dst) if (x_dst is not None and need_dst) else None
-        g_edge = torch.empty_like(m_edge) if (m_edge is not None and need_edge) else None
+        # (a padded graph has e_cap slots of which the sweep touches the batch's: the untouched gradient rows must read as zero)
+        g_edge = (torch.zeros_like(m_edge) if hasattr(graph, "_pad") else torch.empty_like(m_edge)) if (m_edge is not None and need_edge) else None
         if ctx.xin_is_src:
             g_in = g_src
         else:
@@ -561,6 +570,9 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
     if not simple or x.shape[1] > 1024 or (not training and needs_grad):   # (fused: training-mode backward, F <= 1024)
         # configurations the fused kernels do not cover: plain torch modules
+        if _N_VALID is not None and training:
+            raise _lib.DgnError("padded batch (n_valid): this BatchNorm configuration runs on plain torch modules, which would count the "
+                                "padding rows in the batch statistics; use affine BatchNorm with running statistics, width <= 1024")
         w = x.shape[1] // len(bns)
         y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)
         y = torch.relu(y) if relu else y

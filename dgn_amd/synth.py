@@ -117,6 +117,30 @@ def knn_batch(n_graphs: int = 128, seed: int = 41, n_lo: int = 85, n_hi: int = 1
                 sizes=torch.tensor(sizes), eig=torch.from_numpy(np.concatenate(eigs)), snorm_n=snorm)
 
 
+def sbm_batch(n_graphs: int = 128, seed: int = 41, n_lo: int = 44, n_hi: int = 188, communities: int = 5, p_in: float = 0.5,
+              p_out: float = 0.35, eig_dim: int = 3) -> Dict[str, torch.Tensor]:
+    """PATTERN-like graphs (Benchmarking-GNNs SBM_PATTERN: stochastic block model, 5 communities, p = 0.5 inside / q = 0.35
+    between; 44..188 nodes, mean ~119 nodes and ~6 100 directed edges per graph), symmetric directed edges, Laplacian eig."""
+    rng = np.random.default_rng(seed)
+    srcs, dsts, sizes, eigs = [], [], [], []
+    off = 0
+    for _ in range(n_graphs):
+        n = int(rng.integers(n_lo, n_hi + 1))
+        comm = rng.integers(0, communities, n)
+        prob = np.where(comm[:, None] == comm[None, :], p_in, p_out)
+        upper = np.triu(rng.random((n, n)) < prob, k=1)
+        a, b = np.nonzero(upper)
+        und = np.stack([a, b], axis=1).astype(np.int64)
+        srcs.append(np.concatenate([und[:, 0], und[:, 1]]) + off)
+        dsts.append(np.concatenate([und[:, 1], und[:, 0]]) + off)
+        sizes.append(n)
+        eigs.append(_laplacian_eig(n, und, eig_dim))
+        off += n
+    snorm = torch.cat([torch.full((n, 1), 1.0 / n) for n in sizes]).sqrt()
+    return dict(src=torch.from_numpy(np.concatenate(srcs)), dst=torch.from_numpy(np.concatenate(dsts)), num_nodes=off,
+                sizes=torch.tensor(sizes), eig=torch.from_numpy(np.concatenate(eigs)), snorm_n=snorm)
+
+
 def powerlaw_csr(num_nodes: int, num_edges: int, device, seed: int = 0, alpha: float = 2.1, k_eig: int = 4,
                  generator: Optional[torch.Generator] = None):
     """Destination-major CSR of a power-law graph built on ``device``: in-degree ~ Zipf(alpha) clipped to

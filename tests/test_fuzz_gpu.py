@@ -13,7 +13,23 @@ HOT_LISTS = [  # (aggregators, scalers, needs P|Q): the baked-in lists of csrc/d
     (["mean", "dir1-dx", "dir1-av"], ["identity"], False),
     (["mean", "dir1-dx"], ["identity"], False),
     (["mean"], ["identity"], False),
+    (["mean", "max", "min", "dir1-dx", "dir1-av"], ["identity"], False),     # the HIV / PCBA json list in its own (simple) message form
+    (["mean", "dir1-dx", "dir1-av"], ["identity"], True),                     # the ZINC json list on P|Q messages (complex layer)
+    (["mean", "dir1-dx", "dir2-dx"], ["identity"], True),                     # the PATTERN json list on P|Q messages
 ]
+
+
+def _as_good(ours, ref32, ref64, rtol, atol, msg=""):
+    """within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is (x4): max / min / |.| route
+    differently where two messages tie or a derivative crosses zero, in the reference's own fp32 evaluation as much as here"""
+    ours, ref32, ref64 = (t.detach().cpu().double().numpy() for t in (ours, ref32, ref64))
+    if np.allclose(ours, ref32, rtol=rtol, atol=atol):
+        return
+    scale = max(1.0, float(np.abs(ref64).max()))
+    ok32 = np.abs(ours - ref32) <= atol + rtol * np.abs(ref32)
+    ok64 = np.abs(ours - ref64) <= atol * scale + rtol * np.abs(ref64) + 4.0 * np.abs(ref32 - ref64)
+    bad = ~(ok32 | ok64)
+    assert not bad.any(), f"{msg}: {int(bad.sum())} entries off, worst {float(np.abs(ours - ref64)[bad].max()):.3e}"
 
 
 def _batch(rng, n_graphs, extra):
@@ -29,7 +45,7 @@ def _batch(rng, n_graphs, extra):
     return src, dst, N
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_grouped_backward_sweep(monkeypatch, seed):
     import dgn_amd
     from dgn_amd.dgn_layer import X_IN_NAME
@@ -67,13 +83,24 @@ def test_grouped_backward_sweep(monkeypatch, seed):
     assert torch.equal(y1, y4)
     for a, b in zip(g4, g1):
         assert torch.isfinite(a).all() and torch.equal(a, b)
-    if T == 1 and not x_block:                                   # oracle (fp64) on the same inputs
-        lo = [t.double().requires_grad_(True) for t in ((PQ, X) if pq_msg else (X,))]
+    # the oracle on the same inputs, EVERY case: fp32 (the reference's arithmetic) and fp64 (the anchor for tie / sign routings);
+    # towers = one oracle call per tower on its column block; the h_in pass-through block is x_in itself.  1e-5 on values
+    # (north star), 1e-4 on gradients.
+    ft = F_ // T
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        lo = [t.to(dt).requires_grad_(True) for t in ((PQ, X) if pq_msg else (X,))]
         msg = (lo[0][:, :F_][src] + lo[0][:, F_:][dst]) if pq_msg else lo[0][src]
-        yo = orc.aggregate_graph(src, dst, N, msg, eig.double(), lo[-1], aggs, scalers, torch.tensor(1.3).double())
-        np.testing.assert_allclose(y4.cpu().numpy(), yo.detach().float().numpy(), rtol=2e-4, atol=2e-4)
-        for a, b in zip(g4, torch.autograd.grad(yo, lo, ct.cpu().double())):
-            np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())))
+        blocks = []
+        for t in range(T):
+            cols = slice(t * ft, (t + 1) * ft)
+            yt = orc.aggregate_graph(src, dst, N, msg[:, cols], eig.to(dt), lo[-1][:, cols], aggs, scalers, torch.tensor(1.3, dtype=dt))
+            blocks.append(torch.cat([yt, lo[-1][:, cols]], dim=1) if x_block else yt)
+        yo = torch.stack(blocks) if T > 1 else blocks[0]
+        res[dt] = (yo.detach(), torch.autograd.grad(yo, lo, ct.cpu().to(dt)))
+    _as_good(y4, res[torch.float32][0], res[torch.float64][0], 1e-5, 1e-5, f"values {aggs} T={T}")
+    for a, b32, b64, nm in zip(g4, res[torch.float32][1], res[torch.float64][1], ("d pq", "d x") if pq_msg else ("d x",)):
+        _as_good(a, b32, b64, 1e-4, 1e-4, f"{nm} {aggs} T={T}")
 
 
 @pytest.mark.parametrize("seed", range(8))

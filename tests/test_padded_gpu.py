@@ -114,3 +114,69 @@ def test_padded_step_equals_exact_step(type_net):
         for k, v in layer.state_dict().items():
             if "running" in k:
                 np.testing.assert_allclose(v.cpu().numpy(), ref_stats[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=f"{mode} {k}")
+
+
+@pytest.mark.parametrize("type_net,as_types", [("towers", False), ("complex", False), ("towers", True)])
+def test_padded_step_with_edge_features_equals_exact_step(type_net, as_types):
+    """edge features on a padded graph.  The per-edge tensors are e_cap rows long while the batch fills E slots:
+    the untouched gradient rows must read as zero and the slot -> edge map of the tail must not carry the previous batch's ids.
+    Eager padded steps over batches of different sizes against the exact-size graph: output, d h, d ef, every parameter gradient."""
+    import dgn_amd
+    from dgn_amd.hipgraph import PaddedBatch
+    dev = torch.device("cuda")
+    bs = _batches()
+    F_, ed, K = 20, 6, 4
+    n_cap = int(max(int(b["num_nodes"]) for b in bs) * 1.1) + 7
+    e_cap = int(max(b["src"].numel() for b in bs) * 1.1) + 5
+    torch.manual_seed(0)
+    proto = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation",
+                             {"log": torch.tensor(1.1)}, type_net, True, towers=5, edge_features=True, edge_dim=ed).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    with torch.no_grad():
+        for p in proto.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=gen))
+    table = torch.randn(K, ed, device=dev, generator=gen)
+    layer_ref, layer_pad = copy.deepcopy(proto).train(), copy.deepcopy(proto).train()
+    pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=bs[0]["eig"].shape[1])
+    h_buf, sn_buf, ct_buf = pb.add_node_tensor("h", F_, requires_grad=True), pb.add_node_tensor("snorm", 1), pb.add_node_tensor("ct", F_)
+    ef_buf = pb.add_edge_tensor("ef", ed, requires_grad=True)
+    ty_buf = torch.zeros(e_cap, dtype=torch.int64, device=dev)
+    for order in (0, 1, 2, 3, 1):              # (a smaller batch after a larger one leaves a stale tail behind)
+        b = bs[order]
+        N, E = int(b["num_nodes"]), b["src"].numel()
+        h = torch.randn(N, F_, device=dev, generator=gen)
+        ct = torch.randn(N, F_, device=dev, generator=gen)
+        ef = torch.randn(E, ed, device=dev, generator=gen)
+        types = torch.randint(0, K, (E,), device=dev, generator=gen)
+        src, dst, sn = b["src"].to(dev), b["dst"].to(dev), b["snorm_n"].to(dev)
+        # exact-size reference
+        for p in layer_ref.parameters():
+            p.grad = None
+        g = dgn_amd.DGNGraph(src, dst, N, eig=b["eig"].to(dev))
+        hh, ee, tt = h.clone().requires_grad_(True), ef.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        e_in = dgn_amd.EdgeTypeFeatures(tt, types) if as_types else ee
+        y_ref = layer_ref(g, hh, e_in, sn)
+        y_ref.backward(ct)
+        # padded
+        for p in layer_pad.parameters():
+            p.grad = None
+        h_buf.grad = ef_buf.grad = None
+        pb.load(src, dst, N, b["eig"].to(dev), node=dict(h=h, snorm=sn, ct=ct), edge=dict(ef=ef))
+        ty_buf[:E].copy_(types)
+        ty_buf[E:].zero_()
+        tp = table.clone().requires_grad_(True)
+        pb.graph.invalidate_caches()
+        y = layer_pad(pb.graph, h_buf, dgn_amd.EdgeTypeFeatures(tp, ty_buf) if as_types else ef_buf, sn_buf)
+        y.backward(ct_buf)
+        torch.cuda.synchronize()
+        close = lambda a, r, m: np.testing.assert_allclose(a.cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(r.abs().max())), err_msg=m)
+        close(y.detach()[:N], y_ref.detach(), f"batch {order} y")
+        close(h_buf.grad[:N], hh.grad, f"batch {order} d h")
+        if as_types:
+            close(tp.grad, tt.grad, f"batch {order} d table")
+        else:
+            close(ef_buf.grad[:E], ee.grad, f"batch {order} d ef")
+            assert float(ef_buf.grad[E:].abs().max()) == 0.0
+        for (k, p), q in zip(layer_pad.named_parameters(), layer_ref.parameters()):
+            assert torch.isfinite(p.grad).all(), k
+            close(p.grad, q.grad, f"batch {order} grad {k}")

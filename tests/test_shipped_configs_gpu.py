@@ -1,0 +1,149 @@
+"""The reference's SHIPPED layer configurations, each exactly as its json names it, in front of the oracle on the GPU
+(no BASELINE config and no json config may stay without a layer-level oracle test).
+
+* C4 / ogbg-molhiv (configs/molecules_graph_classification_DGN_HIV.json:23-34, PCBA json the same): ``simple``, hidden 70,
+  ``mean max min dir1-dx dir1-av``, ``graph_norm = False``, BatchNorm, residual -- with the json's ``identity`` scaler and with
+  BASELINE's three PNA scalers (the form bench.py times);
+* ZINC json (configs/molecules_graph_regression_DGN_ZINC.json:21-41): ``complex``, hidden **45** (odd), ``mean dir1-dx dir1-av``
+  x three scalers, graph norm;
+* PATTERN json (configs/SBMs_node_clustering_DGN_PATTERN.json:22-42): ``complex``, hidden **47** (odd), ``mean dir1-dx dir2-dx``
+  x three scalers, on SBM-like graphs (dense rows: ~25 in-edges);
+both routes of the dense products (this library's kernels / the library GEMM small batches take).
+Checked: output, d h, every parameter gradient, BatchNorm running statistics.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_grad(a, r32, r64, name):
+    """the headline test's criterion: within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is;
+    and never far from the fp64 evaluation"""
+    a, r32 = a.cpu().double(), r32.double()
+    scale = max(1.0, float(r64.abs().max()))
+    tol = 2e-5 * scale + 1e-4 * r64.abs()
+    ok_ref = (a - r32).abs() <= tol
+    ok_f64 = (a - r64).abs() <= tol + 4 * (r32 - r64).abs()
+    bad = ~(ok_ref | ok_f64)
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {bad.numel()} entries off"
+    assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale, f"{name}: not close to the fp64 evaluation"
+
+
+def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch, min_rows):
+    import dgn_amd
+    from oracle import dgn_oracle as orc
+    if min_rows is not None:
+        monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", min_rows)
+        monkeypatch.setattr(dgn_amd.ops, "WIDE_MIN_ROWS", min_rows)
+    dev = torch.device("cuda")
+    src, dst, N = batch["src"], batch["dst"], int(batch["num_nodes"])
+    avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(avg)}, type_net, True,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():          # O(1) weights: the reference's init (gain 1/in_size) makes layer outputs ~1e-3
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+            else:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    h, ct = torch.randn(N, F_, generator=gen), torch.randn(N, F_, generator=gen)
+
+    def oracle(dtype):
+        sd = {k: (v.detach().to(dtype).requires_grad_("running" not in k) if v.dtype.is_floating_point else v.clone())
+              for k, v in layer.state_dict().items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+        cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg, dtype=dtype), graph_norm=graph_norm, batch_norm=True,
+                   residual=True, towers=1, divide_input=True, edge_features=False)
+        hh = h.to(dtype).requires_grad_(True)
+        y, stats = orc.layer_forward(type_net, sd, cfg, src, dst, N, batch["eig"].to(dtype), hh, None, batch["snorm_n"].to(dtype), training=True)
+        return y, torch.autograd.grad(y, [hh] + [sd[k] for k in names], ct.to(dtype)), names, stats
+
+    y32, g32, names, stats = oracle(torch.float32)
+    y64, g64, _, _ = oracle(torch.float64)
+    layer = layer.to(dev).train()
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=batch["eig"].to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, batch["snorm_n"].to(dev))
+    params = dict(layer.named_parameters())
+    gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
+    yv = y.detach().cpu().double()
+    ok = ((yv - y32.detach().double()).abs() <= 2e-5 + 2e-5 * y32.detach().double().abs()) | \
+         ((yv - y64.detach()).abs() <= 2e-5 + 2e-5 * y64.detach().abs() + 4 * (y32.detach().double() - y64.detach()).abs())
+    assert bool(ok.all()), f"y: {int((~ok).sum())} entries off"
+    for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
+        _check_grad(a, r32, r64, k)
+    for k, v in stats.items():
+        np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+ROUTES = pytest.mark.parametrize("min_rows", [0, 1 << 40], ids=["own-kernels", "library-gemm"])
+
+
+@ROUTES
+@pytest.mark.parametrize("scalers", ["identity", "identity amplification attenuation"], ids=["json-identity", "baseline-3-scalers"])
+def test_c4_molhiv_simple_layer_vs_oracle(monkeypatch, scalers, min_rows):
+    from dgn_amd import synth
+    b = synth.molecule_batch(256, seed=41, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)      # bench.py's c4 generator, 256 graphs
+    _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", scalers, False, b, min_rows)
+
+
+@ROUTES
+def test_zinc_json_complex_hidden45_vs_oracle(monkeypatch, min_rows):
+    from dgn_amd import synth
+    b = synth.molecule_batch(200, seed=41, extra_bonds=3.9, eig_dim=6)
+    _layer_vs_oracle(monkeypatch, "complex", 45, "mean dir1-dx dir1-av", "identity amplification attenuation", True, b, min_rows)
+
+
+@ROUTES
+def test_pattern_json_complex_hidden47_vs_oracle(monkeypatch, min_rows):
+    from dgn_amd import synth
+    b = synth.sbm_batch(12, seed=41, n_lo=44, n_hi=90)
+    _layer_vs_oracle(monkeypatch, "complex", 47, "mean dir1-dx dir2-dx", "identity amplification attenuation", True, b, min_rows)
+
+
+@pytest.mark.parametrize("hidden,towers", [(45, 5), (35, 5)])
+def test_towers_layer_odd_tower_width_vs_oracle(monkeypatch, hidden, towers):
+    """towers with an ODD per-tower width (45 / 5 = 9, 35 / 5 = 7): the padded message path of the towers layer."""
+    import dgn_amd
+    from dgn_amd import synth
+    from oracle import dgn_oracle as orc
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(120, seed=7, extra_bonds=3.9, eig_dim=6)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    aggs, scalers = "mean max min dir1-av dir1-dx", "identity amplification attenuation"
+    avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(hidden, hidden, 0.0, True, True, aggs, scalers, {"log": torch.tensor(avg)}, "towers", True, towers=towers,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    h, ct = torch.randn(N, hidden, generator=gen), torch.randn(N, hidden, generator=gen)
+
+    def oracle(dtype):
+        sd = {k: (v.detach().to(dtype).requires_grad_("running" not in k) if v.dtype.is_floating_point else v.clone())
+              for k, v in layer.state_dict().items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+        cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg, dtype=dtype), graph_norm=True, batch_norm=True,
+                   residual=True, towers=towers, divide_input=True, edge_features=False)
+        hh = h.to(dtype).requires_grad_(True)
+        y, _ = orc.layer_forward("towers", sd, cfg, src, dst, N, b["eig"].to(dtype), hh, None, b["snorm_n"].to(dtype), training=True)
+        return y, torch.autograd.grad(y, [hh] + [sd[k] for k in names], ct.to(dtype)), names
+
+    y32, g32, names = oracle(torch.float32)
+    y64, g64, _ = oracle(torch.float64)
+    layer = layer.to(dev).train()
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=b["eig"].to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, b["snorm_n"].to(dev))
+    params = dict(layer.named_parameters())
+    gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y32.detach().numpy(), rtol=2e-5, atol=2e-5)
+    for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
+        _check_grad(a, r32, r64, k)
