@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -29,7 +29,8 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_windows",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
-           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad")
+           "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
+           "dgn_linear_bd_supported", "dgn_linear_bd_forward", "dgn_linear_bd_backward_input", "dgn_linear_bd_wgrad_workspace_bytes", "dgn_linear_bd_wgrad")
 
 
 class DgnGraph(C.Structure):
@@ -182,6 +183,16 @@ def load() -> C.CDLL:
         lib.dgn_linear_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
+        lib.dgn_linear_bd_supported.restype = C.c_int
+        lib.dgn_linear_bd_supported.argtypes = [C.c_int32, C.c_int32]
+        lib.dgn_linear_bd_forward.restype = C.c_int
+        lib.dgn_linear_bd_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp]
+        lib.dgn_linear_bd_backward_input.restype = C.c_int
+        lib.dgn_linear_bd_backward_input.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp]
+        lib.dgn_linear_bd_wgrad_workspace_bytes.restype = C.c_size_t
+        lib.dgn_linear_bd_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        lib.dgn_linear_bd_wgrad.restype = C.c_int
+        lib.dgn_linear_bd_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
         lib.dgn_gemm_supported.restype = C.c_int
         lib.dgn_gemm_supported.argtypes = [C.c_int32, C.c_int32]
         lib.dgn_gemm_forward.restype = C.c_int

@@ -6,6 +6,7 @@
 // host side of a step is two calls.  No new device code: the calls below are the library's own entry points.
 // Reference: realworld_benchmark/nets/dgn_layer.py:254-325 (DGNTower.forward x towers, mixing network, residual).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 
 #include <cstdint>
@@ -69,6 +70,12 @@ bool dims_of(const DgnTowersLayer* L, Dims& d, const char* fn) {
     return true;
 }
 
+// the P|Q products on the block-diagonal kernels (dgn_linear_bd_*): shape instantiated, operands 16-byte aligned (DGN_NO_BD=1: dense)
+bool use_bd(const DgnTowersLayer* L, const Dims& d) {
+    static const bool off = getenv("DGN_NO_BD") != nullptr;
+    return !off && dgn_linear_bd_supported(d.T, d.fi) && ((reinterpret_cast<uintptr_t>(L->h) | reinterpret_cast<uintptr_t>(L->pq)) & 15) == 0;
+}
+
 DgnMsg sweep_msg(const DgnTowersLayer* L, const Dims& d) {
     DgnMsg m{};
     m.F = d.Fm;
@@ -113,7 +120,9 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
     char* ws = static_cast<char*>(L->ws);
     // P | Q = h [W_s | W_d]^T + [0 | b]                                                     (dgn_layer.py:226-231, decomposed)
-    DGN_TRY(dgn_linear_forward(d.N, d.Fm, 2 * d.Fm, 1, L->h, d.Fm, 0, L->w_sd, d.Fm, 0, 0, L->bias_sd, 0, L->pq, 2 * d.Fm, 0, stream));
+    // (block-diagonal weights: the towers' own [f_in, f_in] blocks only, where that kernel family has the shape)
+    if (use_bd(L, d)) DGN_TRY(dgn_linear_bd_forward(d.N, d.T, d.fi, L->h, L->w_sd, d.Fm, L->bias_sd, L->pq, stream));
+    else DGN_TRY(dgn_linear_forward(d.N, d.Fm, 2 * d.Fm, 1, L->h, d.Fm, 0, L->w_sd, d.Fm, 0, 0, L->bias_sd, 0, L->pq, 2 * d.Fm, 0, stream));
     // all towers' aggregators (+ the h_in block) in one sweep, tower-major                   (:237-249, :261-264)
     const DgnMsg msg = sweep_msg(L, d);
     const size_t agg_ws = L->ws_bytes - bn_ws;
@@ -158,7 +167,7 @@ BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
     s.comb_ws = take(dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo));
     s.wg_mix = take(dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1));
     s.wg_post = take(dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T));
-    s.wg_sd = take(dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1));
+    s.wg_sd = take(std::max(dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1), dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi)));
     s.agg_ws = take(dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1));
     s.total = off;
     return s;
@@ -235,6 +244,13 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     static const bool no_add_epilogue = getenv("DGN_NO_ADD_EPILOGUE") != nullptr;
     const bool al = ((reinterpret_cast<uintptr_t>(G->g_h) | reinterpret_cast<uintptr_t>(G->g_out)) & 15) == 0;
     const bool fused_add = !no_add_epilogue && al && (reinterpret_cast<uintptr_t>(g_in) & 15) == 0 && dgn_linear_add_supported(2 * d.Fm, d.Fm);
+    if (use_bd(L, d) && al && ((reinterpret_cast<uintptr_t>(g_in) | reinterpret_cast<uintptr_t>(g_pq)) & 15) == 0) {
+        // the towers' own blocks only: (d h_in + (d P|Q) W_sd) + residual in the product's epilogue, add3's order
+        DGN_TRY(dgn_linear_bd_backward_input(d.N, d.T, d.fi, g_pq, L->w_sd, d.Fm, g_in, res, G->g_h, stream));
+        DGN_TRY(dgn_linear_bd_wgrad(d.N, d.T, d.fi, g_pq, L->h, G->g_w_sd, d.Fm, G->g_bias_sd, ws + s.wg_sd,
+                                    dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), stream));
+        return DGN_OK;
+    }
     if (fused_add) DGN_TRY(dgn_linear_forward_add(d.N, 2 * d.Fm, d.Fm, g_pq, L->w_sd, d.Fm, 1, g_in, res, G->g_h, stream));
     else DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
     DGN_TRY(dgn_linear_wgrad(d.N, d.Fm, 2 * d.Fm, 1, g_pq, 2 * d.Fm, 0, L->h, d.Fm, 0, G->g_w_sd, d.Fm, 0, G->g_bias_sd, 0, ws + s.wg_sd,

@@ -597,7 +597,10 @@ class DGNLayerTower(nn.Module):
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
         ops = self._operands(h.device)
         x_in = h if self.divide_input else h.repeat(1, T)                                          # (else every tower reads all of h)
-        pq = node_linear(h, ops["w_sd"], ops["bias_sd"])                                            # [N, 2*Fm]: P | Q
+        if self.divide_input and _ops.pair_linear_supported(h, T, fi):
+            pq = _ops.pair_linear(h, ops["w_sd"], ops["bias_sd"], T, fi)                           # (the towers' diagonal blocks only)
+        else:
+            pq = node_linear(h, ops["w_sd"], ops["bias_sd"])                                        # [N, 2*Fm]: P | Q
         m_edge, edge_type = _edge_term(graph, e, ops["w_edge"]) if self.edge_features else (None, None)      # R = ef W_e^T, slot order
         b_p = ops["b_p"]
         S = self.plan.n_scalers

@@ -746,6 +746,67 @@ def node_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return y if bias is None else y + bias.unsqueeze(1)
 
 
+# ---- block-diagonal P|Q Linear of the towers layer (dgn_linear_bd.hip) --------------------------------------------------------------
+
+BLOCK_DIAGONAL = os.environ.get("DGN_NO_BD") is None      # False / DGN_NO_BD=1: the dense streaming kernels multiply the zero blocks too
+
+_BD_OK = {}
+
+
+def pair_linear_supported(x: torch.Tensor, n_towers: int, f_in: int) -> bool:
+    """Whether ``pair_linear`` takes this shape: an instantiated (towers, f_in) pair, fp32 CUDA rows, at least LINEAR_MIN_ROWS of them."""
+    key = (int(n_towers), int(f_in))
+    if key not in _BD_OK:
+        _BD_OK[key] = bool(_lib.load().dgn_linear_bd_supported(*key))
+    return bool(BLOCK_DIAGONAL and _BD_OK[key] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= LINEAR_MIN_ROWS
+                and os.environ.get("DGN_LIBRARY_GEMM") != "1")
+
+
+class _PairLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, T, fi):
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        M, Fm = x.shape
+        c = torch.empty((M, 2 * Fm), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.dgn_linear_bd_forward(M, T, fi, x.data_ptr(), w.data_ptr(), w.stride(0), _ptr(bias.contiguous() if bias is not None else None),
+                                             c.data_ptr(), stream), "dgn_linear_bd_forward")
+        ctx.save_for_backward(x, w)
+        ctx.dims, ctx.has_bias = (T, fi), bias is not None
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        T, fi = ctx.dims
+        M, Fm = x.shape
+        g = g.contiguous()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x)
+            _lib.check(lib.dgn_linear_bd_backward_input(M, T, fi, g.data_ptr(), w.data_ptr(), w.stride(0), None, None, g_x.data_ptr(), stream),
+                       "dgn_linear_bd_backward_input")
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            g_w = torch.empty_like(w)
+            g_b = torch.empty(2 * Fm, dtype=torch.float32, device=x.device) if want_b else None
+            nbytes = lib.dgn_linear_bd_wgrad_workspace_bytes(M, T, fi)
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.dgn_linear_bd_wgrad(M, T, fi, g.data_ptr(), x.data_ptr(), g_w.data_ptr(), g_w.stride(0), _ptr(g_b), ws.data_ptr(), nbytes,
+                                               stream), "dgn_linear_bd_wgrad")
+        return g_x, g_w, g_b, None, None
+
+
+def pair_linear(x: torch.Tensor, w_sd: torch.Tensor, bias_sd: Optional[torch.Tensor], n_towers: int, f_in: int) -> torch.Tensor:
+    """``F.linear(x, w_sd, bias_sd)`` for the towers layer's BLOCK-DIAGONAL P | Q weights (``DGNLayerTower._assemble``: ``w_sd``
+    [2 Fm, Fm] whose only non-zero entries are the towers' [f_in, f_in] blocks, nets/dgn_layer.py:226-231 under divide_input): the
+    structural zeros are neither multiplied nor -- in the weight gradient, which comes back dense with zero off-diagonal blocks -- formed."""
+    return _PairLinear.apply(x, w_sd, bias_sd, int(n_towers), int(f_in))
+
+
 def _lin_wgrad(lib, g, x, want_bias):
     """g [T, M, n], x [T, M, k] dense -> (dW [T, n, k], dbias [T, n] | None)"""
     T, M, n = g.shape

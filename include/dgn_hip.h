@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 18
+#define DGN_ABI_VERSION 19
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -366,6 +366,26 @@ size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, in
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
                      int64_t stride_dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- block-diagonal pretrans Linear of the towers layer (dgn_linear_bd.hip) ---------------------------------------------
+ * With divide_input every tower's pretrans MLP acts on its own f_in-column slice of h (nets/dgn_layer.py:226-231 via :309-316), so
+ * the fused product pq = h [W_s | W_d]^T + [0 | b] has T diagonal blocks of [f_in, f_in] per half: 1/T of the dense
+ * [2 T f_in, T f_in] matrix.  These entry points skip the structural zeros (ZINC towers: 40 instead of 180 MFMAs per 16 rows):
+ *   dgn_linear_bd_forward          c [n_rows, 2 Fm] = a [n_rows, Fm] . blockdiag(w)^T (+ bias [2 Fm]),   Fm = n_towers * f_in
+ *   dgn_linear_bd_backward_input   c [n_rows, Fm]   = (add1 + g [n_rows, 2 Fm] . blockdiag(w)) + add2    (add1 / add2 may be NULL)
+ *   dgn_linear_bd_wgrad            dw [2 Fm, lddw]: diagonal blocks of g^T . x, ZERO elsewhere; dbias [2 Fm] = column sums of g (or NULL)
+ * w is the dense [2 Fm, ldw] operand of dgn_linear_forward (row j Fm + t f_in + a, column t f_in + b; other entries are not read), so
+ * the two routes are interchangeable.  Dense rows, 16-byte aligned operands.  dgn_linear_bd_supported(n_towers, f_in): the
+ * instantiated shapes (five towers x even widths 10..30, + (4 | 2) x 14); callers use dgn_linear_forward / _wgrad otherwise.
+ * Exact fp32 MFMA; the weight gradient is summed over per-workgroup partials in a fixed order (bitwise reproducible).        */
+int dgn_linear_bd_supported(int32_t n_towers, int32_t f_in);
+int dgn_linear_bd_forward(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* a, const float* w, int64_t ldw,
+                          const float* bias, float* c, void* stream);
+int dgn_linear_bd_backward_input(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* g, const float* w, int64_t ldw,
+                                 const float* add1, const float* add2, float* c, void* stream);
+size_t dgn_linear_bd_wgrad_workspace_bytes(int64_t n_rows, int32_t n_towers, int32_t f_in);
+int dgn_linear_bd_wgrad(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* g, const float* x, float* dw, int64_t lddw,
+                        float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- wide tall-skinny fp32 GEMMs (dgn_gemm.hip) -----------------------------------------------------------------------
  * The same nn.Linear (layers.py:101-112) for the widths the simple / complex layers' posttrans has after scaler folding

@@ -310,3 +310,69 @@ def test_bn_linear_act_residual_in_one_pass_is_bitwise(shape, residual):
                                              b.data_ptr(), 2, 0.01, P(res), z_f.data_ptr(), o_f.data_ptr(), st), "fused")
     assert torch.equal(z_ref, z_f)
     assert torch.equal(o_ref, o_f)
+
+
+@pytest.mark.parametrize("T,fi,M", [(5, 14, 4099), (5, 14, 16), (5, 14, 1), (5, 10, 700), (5, 20, 1033), (5, 30, 515), (4, 14, 2000), (2, 14, 333)])
+def test_block_diagonal_pair_linear_vs_fp64(T, fi, M):
+    """dgn_linear_bd_*: the towers' block-diagonal P|Q product, its input gradient (with the two-operand add epilogue) and its weight /
+    bias gradient against an fp64 evaluation of the dense formula; off-diagonal weight-gradient blocks are exactly zero; the dense
+    streaming kernels agree; run-to-run bitwise equality."""
+    import ctypes as C
+    import dgn_amd
+    from dgn_amd import _lib, ops
+    dev = torch.device("cuda")
+    lib = _lib.load()
+    assert lib.dgn_linear_bd_supported(T, fi)
+    Fm = T * fi
+    gen = torch.Generator(device=dev).manual_seed(T * 100 + fi)
+    x = torch.randn(M, Fm, device=dev, generator=gen)
+    blocks = torch.randn(2, T, fi, fi, device=dev, generator=gen)
+    w = torch.zeros(2, T, fi, T, fi, device=dev)
+    idx = torch.arange(T, device=dev)
+    w[:, idx, :, idx, :] = blocks.transpose(0, 1)
+    w = w.view(2 * Fm, Fm)
+    bias = torch.randn(2 * Fm, device=dev, generator=gen)
+    g = torch.randn(M, 2 * Fm, device=dev, generator=gen)
+    a1, a2 = torch.randn(M, Fm, device=dev, generator=gen), torch.randn(M, Fm, device=dev, generator=gen)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    monkey_rows = ops.LINEAR_MIN_ROWS
+    ops.LINEAR_MIN_ROWS = 0
+    try:
+        y = ops.pair_linear(xr, wr, br, T, fi)
+        gx, gw, gb = torch.autograd.grad(y, [xr, wr, br], g)
+        y2 = ops.pair_linear(xr, wr, br, T, fi)
+        gx2, gw2, gb2 = torch.autograd.grad(y2, [xr, wr, br], g)
+    finally:
+        ops.LINEAR_MIN_ROWS = monkey_rows
+    assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    x64, w64, b64, g64 = x.double(), w.double(), bias.double(), g.double()
+    y_ref = x64 @ w64.t() + b64
+    tol = lambda ref: 2e-6 * float(ref.abs().max()) + 1e-30
+    assert float((y.double() - y_ref).abs().max()) <= tol(y_ref)
+    gx_ref = g64 @ w64
+    assert float((gx.double() - gx_ref).abs().max()) <= tol(gx_ref)
+    mask = (w != 0).double()                       # (random blocks: no exact zeros inside a block)
+    gw_ref = (g64.t() @ x64) * mask
+    assert float((gw.double() - gw_ref).abs().max()) <= 1e-5 * float(gw_ref.abs().max()) + 1e-30
+    assert float((gw * (1 - mask.float())).abs().max()) == 0.0
+    gb_ref = g64.sum(0)
+    assert float((gb.double() - gb_ref).abs().max()) <= 1e-5 * max(1.0, float(gb_ref.abs().max()))
+    # the add epilogue: (add1 + product) + add2, through the C entry point
+    out = torch.empty(M, Fm, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for add2 in (a2, None):
+        _lib.check(lib.dgn_linear_bd_backward_input(M, T, fi, g.data_ptr(), w.data_ptr(), Fm, a1.data_ptr(), add2.data_ptr() if add2 is not None else None,
+                                                    out.data_ptr(), stream), "dgn_linear_bd_backward_input")
+        ref = (a1 + gx) + (add2 if add2 is not None else 0)
+        assert torch.equal(out, ref) if add2 is not None else torch.equal(out, a1 + gx)
+    # inf / nan stay in their rows and in their towers' columns
+    if M > 3:
+        xb = x.clone()
+        xb[2, 3] = float("inf")
+        yb = torch.empty(M, 2 * Fm, device=dev)
+        _lib.check(lib.dgn_linear_bd_forward(M, T, fi, xb.data_ptr(), w.data_ptr(), Fm, bias.data_ptr(), yb.data_ptr(), stream), "dgn_linear_bd_forward")
+        bad = ~torch.isfinite(yb)
+        assert bool(bad[2].any()) and not bool(bad[torch.arange(M, device=dev) != 2].any())
+        cols = torch.nonzero(bad[2]).flatten()
+        assert bool(((cols % Fm) < fi).all())                                           # tower 0's outputs only (P and Q halves)

@@ -25,7 +25,9 @@ def _check_grad(a, r32, r64, name):
     scale = max(1.0, float(r64.abs().max()))
     tol = 2e-5 * scale + 1e-4 * r64.abs()
     ok_ref = (a - r32).abs() <= tol
-    ok_f64 = (a - r64).abs() <= tol + 4 * (r32 - r64).abs()
+    # (tensor-wide max of the reference's own error: a bias in front of a BatchNorm has a gradient that is exactly zero in exact
+    #  arithmetic, so every fp32 evaluation -- the reference's as much as ours -- returns its rounding noise there, entry by entry unrelated)
+    ok_f64 = (a - r64).abs() <= tol + 4 * float((r32 - r64).abs().max())
     bad = ~(ok_ref | ok_f64)
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {bad.numel()} entries off"
     assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale, f"{name}: not close to the fp64 evaluation"
