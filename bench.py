@@ -74,7 +74,20 @@ WORKLOADS = {
                aggregators="mean dir1-dx dir2-dx", scalers="identity", towers=1),
     "c4": dict(desc="ogbg-molhiv-like, batch 2048, DGN simple hidden 70, mean max min dir1-dx dir1-av x 3 scalers",
                gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
-               hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
+               hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
+               graph_norm=False),      # configs/molecules_graph_classification_DGN_HIV.json:30
+    # the reference's SHIPPED json configs, as written (odd hidden sizes: the layers pad the message path by one zero column)
+    "zinc_json": dict(desc="configs/molecules_graph_regression_DGN_ZINC.json as shipped: complex, hidden 45, mean dir1-dx dir1-av x 3 scalers, "
+                           "graph norm, ZINC-12k in one batch",
+                      gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=45,
+                      aggregators="mean dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
+    "zinc_json_b128": dict(desc="the same ZINC json layer at the json's batch size (128 molecules)",
+                           gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=45,
+                           aggregators="mean dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
+    "pattern_json": dict(desc="configs/SBMs_node_clustering_DGN_PATTERN.json as shipped: complex, hidden 47, mean dir1-dx dir2-dx x 3 scalers, "
+                              "batch 128 of SBM graphs (~119 nodes, ~6.1 k directed edges each)",
+                         gen=("sbm", dict(n_graphs=128)), type_net="complex", hidden=47,
+                         aggregators="mean dir1-dx dir2-dx", scalers="identity amplification attenuation", towers=1),
     "c5": dict(desc="power-law 10M nodes / 200M edges, k=4 eig, hidden 128, forward only: "
                     "mean max min sum std dir1-dx dir2-dx dir3-dx x 3 scalers",
                gen=("powerlaw", dict(num_nodes=10_000_000, num_edges=200_000_000)), type_net="op", hidden=128,
@@ -140,9 +153,10 @@ def configure_gemm_tuning(mode):
             tn.read_file(TUNING_FILE)
 
 
-def event_ms(fn, reps, dev):
+def event_ms(fn, reps, dev, warm=1):
     """Average duration of fn() over `reps` back-to-back enqueues, HIP events on the current stream."""
-    fn()
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize(dev)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -153,21 +167,23 @@ def event_ms(fn, reps, dev):
     return a.elapsed_time(b) / reps
 
 
-def event_percentiles(fn, dev, warm=20, reps=100):
-    """SURVEY 8(d) timing protocol: 20 warm-up calls, then `reps` calls each bracketed by its own HIP event pair;
-    (p10, median, p90) in ms.  (Single-call brackets include the inter-launch gap, so they sit slightly above the
-    back-to-back average of event_ms for sub-50 us calls.)"""
+def event_stats(fn, dev, warm=20, groups=20, per_group=5):
+    """SURVEY 8(d) timing protocol: `warm` warm-up calls, then groups x per_group = 100 timed calls, each group of back-to-back calls
+    bracketed by its own HIP event pair on the launching stream; the per-call duration of a group = bracket / per_group (a bracket around
+    ONE sub-50-us call would mostly measure the launch gap).  Returns ms: median (the figure the roofline uses), p10, p90, mean."""
     for _ in range(warm):
         fn()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(groups)]
     torch.cuda.synchronize(dev)
     for a, b in ev:
         a.record()
-        fn()
+        for _ in range(per_group):
+            fn()
         b.record()
     torch.cuda.synchronize(dev)
-    t = sorted(a.elapsed_time(b) for a, b in ev)
-    return dict(p10=t[reps // 10], p50=t[reps // 2], p90=t[(reps * 9) // 10])
+    t = sorted(a.elapsed_time(b) / per_group for a, b in ev)
+    return dict(median=t[groups // 2], p10=t[groups // 10], p90=t[(groups * 9) // 10], mean=sum(t) / groups, warmup=warm,
+                timed_calls=groups * per_group)
 
 
 def build_batch(wl, seed, dev, shard=None):
@@ -177,6 +193,8 @@ def build_batch(wl, seed, dev, shard=None):
         b = synth.molecule_batch(seed=seed, **kw)
     elif kind == "knn":
         b = synth.knn_batch(seed=seed, **kw)
+    elif kind == "sbm":
+        b = synth.sbm_batch(seed=seed, **kw)
     else:
         raise ValueError(kind)
     if shard is not None:
@@ -197,10 +215,10 @@ def cpu_baseline(wl, batch, sample_graphs, reps=5):
     F_ = wl["hidden"]
     gen = torch.Generator().manual_seed(0)
     torch.manual_seed(0)
-    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(1.0)},
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(1.0)},
                              wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model
     sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in layer.state_dict().items()}
-    cfg = dict(aggregators=wl["aggregators"], scalers=wl["scalers"], avg_log=torch.tensor(1.0), graph_norm=True,
+    cfg = dict(aggregators=wl["aggregators"], scalers=wl["scalers"], avg_log=torch.tensor(1.0), graph_norm=wl.get("graph_norm", True),
                batch_norm=True, residual=True, towers=wl["towers"], divide_input=True, edge_features=False)
     h = torch.randn(n, F_, generator=gen)
     eig, snorm = batch["eig"][:n], batch["snorm_n"][:n]
@@ -269,7 +287,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     torch.manual_seed(0)
     avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
     edge_dim = wl.get("edge_dim", 0)
-    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
                              wl["type_net"], True, towers=wl["towers"], edge_features=edge_dim > 0, edge_dim=edge_dim).model.to(dev)
     layer.train()
     gen = torch.Generator(device=dev).manual_seed(rank)
@@ -375,7 +393,6 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
         out = torch.empty(N, plan.out_width(Fk), device=dev)
         g_out = torch.randn(N, plan.out_width(Fk), device=dev, generator=gen)
     g_src, g_dst, g_in = torch.zeros(N, Fk, device=dev), (torch.zeros(N, Fk, device=dev) if xd is not None else None), torch.zeros(N, Fk, device=dev)
-    reps = 20
     # with edge features the message has a third, per-edge term R = ef W_e^T [E, F] in slot order (materialised by a streaming
     # Linear): the sweep reads it (+4F per edge, forward and -- with max/min/std -- backward) and the backward writes d R
     # (EdgeTypeFeatures: the term is a [K, F] table + 4 bytes of type per edge; d table = the staged rows summed by type)
@@ -385,9 +402,9 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et)
     bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False,
                                        edge_type=et)
-    ms_f = event_ms(fwd_call, reps, dev)
-    ms_b = event_ms(bwd_call, reps, dev)
-    ms_w = event_ms(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), reps, dev)
+    st_f, st_b = event_stats(fwd_call, dev), event_stats(bwd_call, dev)
+    st_w = event_stats(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), dev)
+    ms_f, ms_b, ms_w = st_f["median"], st_b["median"], st_w["median"]
     bf, bb = algorithmic_bytes(N, E, F_, A, S, Ku, x, r)
     if n_types:
         bf += 4 * E
@@ -395,13 +412,12 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     elif edge_dim:
         bf += 4 * F_ * E
         bb += 4 * F_ * E * (1 + r)
-    pct = (lambda fn: event_percentiles(fn, dev)) if args.percentiles else (lambda fn: None)
     bw = E * (4 + 8 * Ku + 4 * Ku) + N * 4        # edge weights: src id, both eig endpoints per channel, weight out; row pointer
     kernels = {"agg_fwd_rows": dict(ms=ms_f, bytes=bf, GBps=bf / ms_f / 1e6, frac=bf / (ms_f * 1e-3) / HBM_PEAK,
-                                    ms_percentiles=pct(fwd_call)),
+                                    timing=st_f),
                "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK,
-                                    ms_percentiles=pct(bwd_call)),
-               "ew_rows": dict(ms=ms_w, bytes=bw, GBps=bw / ms_w / 1e6, frac=bw / (ms_w * 1e-3) / HBM_PEAK)}
+                                    timing=st_b),
+               "ew_rows": dict(ms=ms_w, bytes=bw, GBps=bw / ms_w / 1e6, frac=bw / (ms_w * 1e-3) / HBM_PEAK, timing=st_w)}
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
     # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
@@ -544,7 +560,7 @@ def compact(result):
     if r:
         out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "frac_of_triad", "model", "frac_with_survey_A") if k in r}
-        out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac")}
+        out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac", "timing")}
                                       for k, v in (r.get("kernels") or {}).items()}
     return out
 
@@ -729,10 +745,37 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
                        "eager, graph preparation included")
 
 
+COMMITTED_LINE = os.path.join(ROOT, "profiles", "r03_bench_default.json")
+
+
+def regression_warnings(results, headline=None):
+    """Measurement hygiene: every roofline fraction of this run is compared with the committed line of the same
+    command (profiles/r03_bench_default.json); a leg that fell below half of its committed value gets a `warning` field instead of
+    passing silently (a box with a disturbed clock, or a regression)."""
+    try:
+        ref = json.load(open(COMMITTED_LINE))
+    except Exception:
+        return
+    def check(name, mine, theirs):
+        k_m, k_t = (mine or {}).get("kernels") or {}, (theirs or {}).get("kernels") or {}
+        bad = [f"{k}: frac {k_m[k]['frac']:.3f} vs committed {k_t[k]['frac']:.3f}" for k in k_m
+               if k in k_t and k_m[k].get("frac") and k_t[k].get("frac") and k_m[k]["frac"] < 0.5 * k_t[k]["frac"]]
+        return bad
+    for name, r in results.items():
+        bad = check(name, r.get("roofline"), (ref.get("extra", {}).get(name) or {}).get("roofline"))
+        if bad:
+            r["warning"] = "roofline leg below half of the committed value: " + "; ".join(bad)
+    if headline is not None:
+        bad = check("c2", headline.get("roofline"), ref.get("roofline"))
+        if bad:
+            headline["warning"] = "roofline leg below half of the committed value: " + "; ".join(bad)
+
+
 def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("c2_b128", 200, 30), ("c5", 3, 1)]
+    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
+            ("pattern_json", 20, 5), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()
@@ -751,6 +794,7 @@ def run_extras(args, dev):
         del wl
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()
+    regression_warnings(extra)
     try:
         extra["c2_inference"] = run_inference(args, dev)
     except Exception as exc:
@@ -786,7 +830,6 @@ def main():
     ap.add_argument("--scalers", default=None, help="override the workload's scaler string (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sub-results of the other configs in the default run")
-    ap.add_argument("--percentiles", action="store_true", help="per-launch p10/p50/p90 of the aggregation calls (SURVEY 8(d) protocol)")
     ap.add_argument("--hipgraph", action="store_true",
                     help="layer workloads, 1 GPU: capture the step (edge weights + forward + backward) in a HIP graph and replay it")
     ap.add_argument("--gemm-tuning", default="off", choices=["off", "file", "tune"],
@@ -839,6 +882,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])))
     else:
         line["cpu_baseline"] = None
+    if world == 1 and args.workload == "c2" and not args.hipgraph and not args.aggregators and not args.scalers:
+        regression_warnings({}, headline=line)
     if world == 1 and args.workload == "c2" and not args.no_extras and not args.hipgraph and not args.aggregators and not args.scalers:
         del res, result, batch
         torch.cuda.empty_cache()

@@ -30,7 +30,9 @@ def _check_grad(a, r32, r64, name):
     ok_f64 = (a - r64).abs() <= tol + 4 * float((r32 - r64).abs().max())
     bad = ~(ok_ref | ok_f64)
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {bad.numel()} entries off"
-    assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale, f"{name}: not close to the fp64 evaluation"
+    # (a max / min / |.| routing that flips between fp32 and fp64 moves a gradient entry by O(weight): with O(1) weights the fp32
+    #  REFERENCE itself is that far from fp64 on a few entries, so the bound carries the reference's own worst error)
+    assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale + 4 * float((r32 - r64).abs().max()), f"{name}: not close to the fp64 evaluation"
 
 
 def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch, min_rows):
