@@ -422,7 +422,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
     # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
     # atomic-free scatter)
-    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "agg_bwd_window", "seg_sum_rows"]}[dom]
+    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "seg_sum_rows"]}[dom]
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
              "agg_bwd_rows": "dgn_agg_backward (agg_bwd_short | agg_bwd_rows, + seg_sum_rows)"}[dom]
     triad = hbm_triad_GBps(dev)

@@ -26,7 +26,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_bias_act_forward", "dgn_bias_act_backward",
            "dgn_layer_fused_supported", "dgn_layer_fused_forward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
-           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_windows",
+           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
@@ -38,9 +38,7 @@ class DgnGraph(C.Structure):
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
                 ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
-                ("n_src", C.c_int64), ("row_base", C.c_int64), ("win_ptr", C.c_void_p), ("win_info", C.c_void_p), ("n_win", C.c_int64),
-                ("win_rows", C.c_int32), ("win_ecap", C.c_int32), ("rem_ptr", C.c_void_p), ("rem_idx", C.c_void_p),
-                ("n_remote", C.c_int64)]
+                ("n_src", C.c_int64), ("row_base", C.c_int64)]
 
 
 class DgnChannel(C.Structure):
@@ -215,9 +213,6 @@ def load() -> C.CDLL:
         lib.dgn_graph_build.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_graph_build_csc.restype = C.c_int
         lib.dgn_graph_build_csc.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
-        lib.dgn_graph_build_windows.restype = C.c_int
-        lib.dgn_graph_build_windows.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_void_p] * 5 + \
-                                              [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_assemble_params.restype = C.c_int
         lib.dgn_assemble_params.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dgn_towers_layer_supported.restype = C.c_int

@@ -313,16 +313,6 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
     }
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
-    // window-local scatter: sinks defined by this call, a square hub-free graph whose rows fit one slot batch, one feature
-    // tile of >= 8-byte lanes, and an LDS footprint that leaves room for two workgroups per CU
-    // (whether it PAYS is the caller's policy -- a caller that does not want it passes a DgnGraph without win_ptr)
-    static const bool no_window = getenv("DGN_NO_WINDOW") != nullptr;
-    if (!no_window && !msg->edge_type && p.fresh && p.g_src && g->win_ptr && g->win_info && g->n_win > 0 && g->n_hub == 0 && g->n_src == 0 && g->max_in_degree > 0 &&
-        g->max_in_degree <= kWave && tiles == 1 && vec >= 2 && (g->n_remote == 0 || (g->rem_ptr && g->rem_idx))) {
-        p.win_ptr = g->win_ptr; p.win_info = g->win_info; p.n_win = g->n_win; p.win_rows = g->win_rows; p.win_ecap = g->win_ecap;
-        if (g->n_remote > 0) { p.rem_ptr = g->rem_ptr; p.rem_idx = g->rem_idx; }
-        if (window_lds_bytes(p) > 80 * 1024) { p.win_ptr = nullptr; p.rem_ptr = nullptr; p.rem_idx = nullptr; }
-    }
     rc = launch(vec, p, tiles, stream, true);
     if (rc || !msg->edge_type || !grads->g_edge) return rc;
     const int K = msg->n_edge_types, KF = K * (int)msg->F;

@@ -108,28 +108,7 @@ struct AggParams {
     const int32_t* csc_pos;
     int32_t n_slots;
     int32_t n_coef;
-    // window-local scatter (agg_bwd_window): row windows of the graph build, see DgnGraph.win_ptr
-    const int32_t* win_ptr;   // [n_win + 1] first row of every window, NULL = row kernels
-    const int32_t* win_info;  // [n_win][8]: first row, rows, first slot, end slot, first csc entry, end csc entry, 0, 0
-    int64_t n_win;
-    int32_t win_rows;         // most rows a window has
-    int32_t win_ecap;         // csc entries of a window that live in LDS (the others go through `stage`)
-    const int32_t* rem_ptr;   // [n_src + 1]  csc entries that go through `stage`, per source (NULL: there are none)
-    const int32_t* rem_idx;   // their csc positions
 };
-
-// LDS views of agg_bwd_window: the window's csc entries [c0, c1) and the rows' d x_dst / d x_in
-struct WinCtx {
-    float* ent;
-    float* rb_dst;
-    float* rb_in;
-    int c0, c1, lrow;
-    const int* s_src;     // the window's slot arrays in LDS (NULL: the window has more slots than the copy holds)
-    const int* s_tp;
-    const float* s_w;
-    int e0;
-};
-constexpr int kWinSlotCap = 192;     // slots (in-edges) of a window whose src / weights / csc positions are copied to LDS
 
 // accumulator slot ids in the hub workspace
 constexpr int SLOT_SUM = 0, SLOT_SQ = 1, SLOT_MAX = 2, SLOT_MIN = 3, SLOT_AMAX = 4, SLOT_AMIN = 5, SLOT_W0 = 6;
@@ -293,18 +272,6 @@ struct SlotBatch {
         for (int c = 0; c < NW; ++c) w[c] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) w[c] = in ? p.w[(int64_t)c * p.ld_w + e] : 0.f;
-    }
-    // the same batch from a workgroup's LDS copy of the window's slot arrays (agg_bwd_window): s_src / s_w[c * ld] hold the
-    // window's slots e0 .. ; off = base - e0
-    __device__ __forceinline__ void load_lds(const int* s_src, const float* s_w, int ld, int off, int cnt, int slot0) {
-        const int l = lane_id();
-        const bool in = l < cnt;
-        src = in ? s_src[off + l] : 0;
-        et = slot0 + l;                                          // (the host keeps the window kernel out of table mode)
-#pragma unroll
-        for (int c = 0; c < NW; ++c) w[c] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) w[c] = in ? s_w[c * ld + off + l] : 0.f;
     }
     __device__ __forceinline__ void weights(float (&wk)[NW], int k) const {
 #pragma unroll
@@ -1139,10 +1106,10 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
 
 // emit dm_j for the cnt slots of one loaded slot batch (my_tpos: the lane's csc position, two-phase scatter);
 // adds them to the row-sum rsum.  Active lanes only.
-template <class C, bool NEED_M, bool WIN = false>
+template <class C, bool NEED_M>
 __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                            const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
-                                           const float (&xd)[C::VEC], const WinCtx& wc = WinCtx{}) {
+                                           const float (&xd)[C::VEC]) {
     constexpr int VEC = C::VEC, U = DGN_UNROLL;
     const MsgSrc<VEC> src(p);
     for (int k0 = 0; k0 < cnt; k0 += U) {
@@ -1206,15 +1173,7 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
                 }
                 rsum[i] += gm[i];
             }
-            bool parked = false;
-            if constexpr (WIN) {
-                // the source lives in this workgroup's window: the row waits in LDS for the window's own reduction
-                if (tp >= wc.c0 && tp < wc.c1) {
-                    stv<VEC>(wc.ent + (tp - wc.c0) * p.F + f0, gm);
-                    parked = true;
-                }
-            }
-            if (p.g_src && !parked) {
+            if (p.g_src) {
                 if (p.stage) {
                     // atomic-free path: park the row at its csc position; seg_sum_rows adds each source's rows
                     stv<VEC>(p.stage + (int64_t)tp * p.F + f0, gm);
@@ -1253,17 +1212,17 @@ __device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C:
     emit_range<C, false>(k, rsum, p, beg, end, f0, active, xd);
 }
 
-template <class C, bool WIN = false>
+template <class C>
 __device__ __forceinline__ void emit_batch_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                                     const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
-                                                    const float (&xd)[C::VEC], const WinCtx& wc = WinCtx{}) {
+                                                    const float (&xd)[C::VEC]) {
     if constexpr (C::STATS) {
         if (p.need & NEED_M_EMIT) {
-            emit_batch<C, true, WIN>(k, rsum, p, b, my_tpos, base, cnt, f0, xd, wc);
+            emit_batch<C, true>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
             return;
         }
     }
-    emit_batch<C, false, WIN>(k, rsum, p, b, my_tpos, base, cnt, f0, xd, wc);
+    emit_batch<C, false>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
 }
 
 // per-row gradients d x_dst (= row sum of dm_j) and d x_in.  `plain`: the caller owns the row (row kernel in
@@ -1295,11 +1254,8 @@ __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f
 // recompute and emit, and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static
 // lists), gathers -- is issued before the first store; separate passes would re-load the batch after the recompute and
 // fetch the gradient after the gather wait (two more dependent round trips per row).
-// WIN (agg_bwd_window): per-edge rows whose source lives in the workgroup's window and the row's own d x_dst / d x_in
-// go to LDS (wc) instead of memory.
-template <class C, class O, bool WIN>
-__device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, int beg, int end, int f0, bool active,
-                                                  const WinCtx& wc) {
+template <class C, class O>
+__device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, int beg, int end, int f0, bool active) {
     constexpr int VEC = C::VEC;
     const int deg = end - beg;
     float xd[VEC], xin[VEC];
@@ -1314,19 +1270,8 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     SlotBatch<C::NCH, C::NW> b;
-    int my_tpos = 0;
-    bool from_lds = false;
-    if constexpr (WIN) {
-        if (wc.s_src) {          // the slot arrays are already in LDS: the gathers below are this row's FIRST memory round trip
-            b.load_lds(wc.s_src, wc.s_w, kWinSlotCap, beg - wc.e0, deg, beg);
-            my_tpos = lane_id() < deg ? wc.s_tp[beg - wc.e0 + lane_id()] : 0;
-            from_lds = true;
-        }
-    }
-    if (!from_lds) {
-        b.load(p, beg, end);
-        my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
-    }
+    b.load(p, beg, end);
+    const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
     const bool recomp = (p.need & NEED_RECOMP) != 0;
     if constexpr (C::NCH > 0) {
         if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
@@ -1365,13 +1310,8 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     } else {
         make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     }
-    emit_batch_dispatch<C, WIN>(k, rsum, p, b, my_tpos, beg, deg, f0, xd, wc);
-    if constexpr (WIN) {
-        if (p.g_dst) stv<VEC>(wc.rb_dst + wc.lrow * p.F + f0, rsum);
-        if (p.g_in) stv<VEC>(wc.rb_in + wc.lrow * p.F + f0, gxin);
-    } else {
-        add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
-    }
+    emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
+    add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
 }
 
 // the backward of ONE destination row, any in-degree (what a wave of agg_bwd_rows does)
@@ -1419,7 +1359,7 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     if (deg <= kWave) {
-        bwd_row_one_batch<C, O, false>(p, row, beg, end, f0, active, WinCtx{});
+        bwd_row_one_batch<C, O>(p, row, beg, end, f0, active);
         return;
     }
     if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
@@ -1686,9 +1626,7 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_hub_emit(const AggParams p) {
 
 // second phase of the atomic-free backward: g_src[u] (+)= sum of the staged rows of source u (contiguous in csc
 // order; p.seg_add selects += over =).  Flat mapping: one thread per (node, VEC-chunk), so short out-neighbourhoods do not cost a wave each.
-// REMOTE (after agg_bwd_window): only the entries that did not stay in their window's LDS -- listed per source in
-// rem_ptr / rem_idx -- are added to what the window kernel wrote.
-template <int VEC, bool REMOTE = false>
+template <int VEC>
 __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     constexpr int PER = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);    // 4 floats per thread whatever the vector width
     const int nchunk = (p.F + VEC * PER - 1) / (VEC * PER);
@@ -1696,9 +1634,9 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     if (t >= p.n_src * nchunk) return;
     const int u = (int)(t / nchunk);
     const int f0 = (int)(t - (int64_t)u * nchunk) * VEC * PER;
-    const int* ptr = REMOTE ? p.rem_ptr : p.csc_ptr;
+    const int* ptr = p.csc_ptr;
     const int beg = ptr[u], end = ptr[u + 1];
-    const bool add = REMOTE || p.seg_add;
+    const bool add = p.seg_add;
     if (beg == end && add) return;
     float acc[PER][VEC];
 #pragma unroll
@@ -1713,7 +1651,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
 #pragma unroll
         for (int j = 0; j < KU; ++j) {
             const int kk = min(k0 + j, end - 1);
-            const float* row = p.stage + (int64_t)(REMOTE ? p.rem_idx[kk] : kk) * p.F + f0;
+            const float* row = p.stage + (int64_t)kk * p.F + f0;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
 #pragma unroll
@@ -1744,118 +1682,6 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
             stv<VEC>(dst + q * VEC, acc[q]);
         }
     }
-}
-
-// ---- window-local scatter -------------------------------------------------------------------------------------
-// Batched small graphs are block diagonal: almost every edge of a molecule stays inside a window of a few dozen
-// consecutive rows.  The graph build cuts the rows into windows (DgnGraph.win_ptr; cuts where no edge crosses whenever
-// there is such a place nearby), and here ONE workgroup owns a window: its waves run the one-batch row routine over the
-// window's rows, but a per-edge gradient row whose SOURCE lies in the window is parked in LDS at its csc position relative
-// to the window (the window's sources own one contiguous csc range), and the rows' own d x_dst / d x_in wait in LDS too.
-// After a barrier the workgroup sums every source's LDS entries in csc order and writes d x_src, d x_dst, d x_in of the
-// whole window as contiguous blocks: the [E, F] staging buffer of the two-phase scatter is neither written nor re-read
-// (-0.33 GB of 1.27 GB on ZINC-12k), the per-row 280-byte stores become full-line block stores, and the summation order is
-// fixed (bitwise reproducible).  Entries past the LDS capacity and edges that do cross a window go through the global
-// staging buffer as before and are added by seg_sum_rows<VEC, true>.
-constexpr int kWinWaves = 8;
-
-// LDS carve-up of agg_bwd_window (floats): [ip | cp | s_src | s_tp] ints, then s_w, ent, rb_dst, rb_in
-__host__ __device__ inline int win_int_words(int win_rows) { return ((2 * (win_rows + 1) + 2 * kWinSlotCap + 3) & ~3); }
-
-template <class C, class O = DynOps>
-__global__ __launch_bounds__(kWave * kWinWaves) void agg_bwd_window(const AggParams p) {
-    constexpr int VEC = C::VEC;
-    extern __shared__ float lds_win[];
-    const int64_t lb = xcd_remap(blockIdx.x, p.n_win);
-    if (lb < 0) return;
-    // one record per window: first row, rows, slot range, csc range -- everything the workgroup needs to ask for its inputs
-    const int* wi = p.win_info + lb * 8;
-    const int r0 = wi[0], nrows = wi[1], e0 = wi[2], e1 = wi[3], c0 = wi[4];
-    if (nrows <= 0) return;                                              // (bins that hold no cut: empty windows)
-    const int c1 = min(wi[5], c0 + p.win_ecap);
-    const int F = p.F, tid = threadIdx.x;
-    int* ip = reinterpret_cast<int*>(lds_win);                            // indptr of the window's rows
-    int* cp = ip + p.win_rows + 1;                                        // csc_ptr of the window's rows
-    int* s_src = cp + p.win_rows + 1;
-    int* s_tp = s_src + kWinSlotCap;
-    float* s_w = lds_win + win_int_words(p.win_rows);
-    float* ent = s_w + C::NCH * kWinSlotCap;
-    float* rb_dst = ent + p.win_ecap * F;
-    float* rb_in = rb_dst + (p.g_dst ? p.win_rows * F : 0);
-    const bool slots_in_lds = e1 - e0 <= kWinSlotCap;
-    for (int i = tid; i <= nrows; i += blockDim.x) {
-        ip[i] = p.indptr[r0 + i];
-        cp[i] = p.csc_ptr[r0 + i];
-    }
-    if (slots_in_lds) {
-        for (int i = tid; i < e1 - e0; i += blockDim.x) {
-            s_src[i] = p.src[e0 + i];
-            s_tp[i] = p.csc_pos[e0 + i];
-#pragma unroll
-            for (int c = 0; c < C::NCH; ++c) s_w[c * kWinSlotCap + i] = p.w[(int64_t)c * p.ld_w + e0 + i];
-        }
-    }
-    for (int i = tid; i < (c1 - c0) * F; i += blockDim.x) ent[i] = 0.f;   // entries whose destination is elsewhere stay zero
-    __syncthreads();
-    const int f0 = lane_id() * VEC;
-    const bool active = f0 < F;
-    WinCtx wc{ent, rb_dst, rb_in, c0, c1, 0, slots_in_lds ? s_src : nullptr, s_tp, s_w, e0};
-    for (int lr = tid >> 6; lr < nrows; lr += kWinWaves) {
-        const int row = uniform_i(r0 + lr);
-        wc.lrow = lr;
-        const int beg = uniform_i(ip[lr]), end = uniform_i(ip[lr + 1]);
-        if (end == beg) {
-            // row without messages: no gradient -- except through the x_in pass-through block
-            if (active) {
-                float gx[VEC], zero[VEC];
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) { gx[i] = 0.f; zero[i] = 0.f; }
-                if ((p.need & NEED_XPASS) && p.g_in) {
-                    const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
-                    for (int a = 0; a < O::n_agg(p); ++a) {
-                        if (O::op(p, a) == DGN_AGG_X_IN) {
-                            float g[VEC];
-                            ldv<VEC>(g, grow + sa_col(p, 0, a));
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) gx[i] += g[i];
-                        }
-                    }
-                }
-                if (p.g_dst) stv<VEC>(rb_dst + lr * F + f0, zero);
-                if (p.g_in) stv<VEC>(rb_in + lr * F + f0, gx);
-            }
-            continue;
-        }
-        bwd_row_one_batch<C, O, true>(p, row, beg, end, f0, active, wc);
-    }
-    __syncthreads();
-    // the window's reduction: thread per (row, feature pair); a source's entries are added in csc order, then its own d x_in
-    // when that lands in the same buffer (simple layer: x_in is x_src)
-    const int nch = F >> 1;
-    const bool alias = p.g_in == p.g_src;
-    for (int it = tid; it < nrows * nch; it += blockDim.x) {
-        const int u = it / nch, f = 2 * (it - u * nch);
-        const int kb = cp[u] - c0, ke = min(cp[u + 1], c1) - c0;
-        float2 a = make_float2(0.f, 0.f);
-        for (int k = kb; k < ke; ++k) {
-            const float2 v = *reinterpret_cast<const float2*>(ent + k * F + f);
-            a.x += v.x;
-            a.y += v.y;
-        }
-        if (alias) {
-            const float2 v = *reinterpret_cast<const float2*>(rb_in + u * F + f);
-            a.x += v.x;
-            a.y += v.y;
-        }
-        *reinterpret_cast<float2*>(p.g_src + (int64_t)(r0 + u) * p.ldg_src + f) = a;
-        if (p.g_dst) *reinterpret_cast<float2*>(p.g_dst + (int64_t)(r0 + u) * p.ldg_dst + f) = *reinterpret_cast<const float2*>(rb_dst + u * F + f);
-        if (p.g_in && !alias) *reinterpret_cast<float2*>(p.g_in + (int64_t)(r0 + u) * p.ldg_in + f) = *reinterpret_cast<const float2*>(rb_in + u * F + f);
-    }
-}
-
-inline size_t window_lds_bytes(const AggParams& p) {
-    const int nbuf = (p.g_dst ? 1 : 0) + (p.g_in ? 1 : 0);
-    return ((size_t)win_int_words(p.win_rows) + (size_t)p.n_ch * kWinSlotCap + (size_t)(p.win_ecap + nbuf * p.win_rows) * p.F) * sizeof(float);
 }
 
 // ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------
@@ -1915,25 +1741,6 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
 
 template <class C, class O = DynOps>
 int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
-    if constexpr (C::VEC >= 2) {
-        if (p.win_ptr) {          // window-local scatter (the host checked: one feature tile, short rows, fresh sinks)
-            const size_t lds = window_lds_bytes(p);
-            static bool attr = false;
-            if (!attr) {
-                DGN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_bwd_window<C, O>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr = true;
-            }
-            hipLaunchKernelGGL((agg_bwd_window<C, O>), dim3((unsigned)xcd_grid(p.n_win)), dim3(kWave * kWinWaves), lds, stream, p);
-            if (p.rem_ptr) {
-                constexpr int per = C::VEC == 2 ? 2 : 1;
-                const int64_t n_threads = p.n_src * ((p.F + C::VEC * per - 1) / (C::VEC * per));
-                hipLaunchKernelGGL((seg_sum_rows<C::VEC, true>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, stream, p);
-            }
-            DGN_HIP_CHECK(hipGetLastError());
-            return DGN_OK;
-        }
-    }
     const int wpb = row_waves_per_block(p);
     const char* rb_env = getenv("DGN_BWD_ROWS_PER_WAVE");     // (read per launch: the tests switch it)
     const int rb = (rb_env && atoi(rb_env) <= 1) ? 1 : kBwdShortRows;

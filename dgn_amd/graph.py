@@ -95,7 +95,7 @@ class DGNGraph:
         self.n_valid = torch.zeros(1, dtype=torch.int64, device=dev)
         self.csc_ptr, self.csc_pos, self._csc_order = i32(n_cap + 1), i32(e_cap), i32(e_cap)
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
-        self._csc_ready, self.n_remote, self.win_ptr = True, 0, None
+        self._csc_ready = True
         lib = _lib.load()
         self._pad["ws_bytes"] = lib.dgn_graph_build_workspace_bytes(n_cap, e_cap)
         self._pad["ws"] = torch.empty(self._pad["ws_bytes"], dtype=torch.uint8, device=dev)
@@ -227,11 +227,10 @@ class DGNGraph:
         ptr[1:] = torch.cumsum(out_deg, 0)
         self.csc_ptr, self.csc_pos = ptr.int().contiguous(), pos.int().contiguous()
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
-        self._build_windows(order, ptr)
         self._csc_ready = True
 
     def _csc_native(self) -> None:
-        """Transposed view + row windows through dgn_graph_build_csc / _windows (two C calls, one read-back)."""
+        """Transposed view through dgn_graph_build_csc (one C call, no read-back)."""
         lib = _lib.load()
         N, E, dev = self.num_nodes, self.num_edges, self.device
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
@@ -242,100 +241,6 @@ class DGNGraph:
         _lib.check(lib.dgn_graph_build_csc(N, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), order.data_ptr(),
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
-        self.n_remote, self.win_ptr = 0, None
-        if not self.BUILD_WINDOWS or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
-            return
-        dst_csr = getattr(self, "dst_csr", None)
-        if dst_csr is None:        # (graph adopted from a CSR: destination of every slot from the row pointers)
-            dst_csr = self.dst_csr = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32), self.in_degree)
-        R0 = self.WIN_BIN
-        nb = (N + R0 - 1) // R0
-        win_ptr, win_info, rem_ptr, rem_idx = i32(nb + 1), i32(nb * 8), i32(N + 1), i32(E)
-        stats = getattr(self, "_stats", None)
-        if stats is None:
-            stats = self._stats = i32(4)
-        _lib.check(lib.dgn_graph_build_windows(N, E, self.indptr.data_ptr(), self.src.data_ptr(), dst_csr.data_ptr(), self.csc_ptr.data_ptr(),
-                                               order.data_ptr(), R0, self.WIN_ECAP, win_ptr.data_ptr(), win_info.data_ptr(), rem_ptr.data_ptr(),
-                                               rem_idx.data_ptr(), stats.data_ptr(), ws.data_ptr(), nbytes, stream), "dgn_graph_build_windows")
-        n_remote = int(stats[2].item())                                          # (host sync of this view)
-        self.local_fraction = 1.0 - n_remote / E
-        if self.local_fraction < 0.5:          # e.g. k-NN graphs with unordered points: the windows catch little
-            return
-        self.n_remote, self.win_ptr, self.win_info = n_remote, win_ptr, win_info.view(nb, 8)
-        c = self._c
-        c.win_ptr, c.win_info, c.n_win, c.win_rows, c.win_ecap = win_ptr.data_ptr(), win_info.data_ptr(), nb, 3 * R0 - 1, self.WIN_ECAP
-        c.n_remote = n_remote
-        if n_remote:
-            self.rem_ptr, self.rem_idx = rem_ptr, rem_idx
-            c.rem_ptr, c.rem_idx = rem_ptr.data_ptr(), rem_idx.data_ptr()
-
-    # ---- row windows of the window-local backward scatter (include/dgn_hip.h: DgnGraph.win_ptr) ----
-    WIN_BIN = 16        # rows per bin; a window spans at most 3 bins - 1 rows
-    WIN_ECAP = 96       # csc entries of a window kept in LDS
-    # Row windows for agg_bwd_window are only built on request: since the grouped row kernel (agg_bwd_short: four rows per wave) the
-    # window-local scatter is the slower backward on every measured batch (ZINC-12k simple layer 0.180 vs 0.136 ms), see ops.WINDOW_BACKWARD
-    BUILD_WINDOWS = False
-    WIN_MIN_EDGES = 32768   # below this the backward is launch-bound and the ~20 device ops of the window build cost more than they save
-
-    def _build_windows(self, order: torch.Tensor, csc_ptr: torch.Tensor) -> None:
-        """Cut the rows into windows of at most ``3 * WIN_BIN - 1`` rows, preferring CLOSED cuts -- places no edge
-        crosses, i.e. the boundaries between the graphs of a batch -- so that (almost) every per-edge gradient row of a
-        batch of small graphs is reduced inside its window's LDS.  Every bin of WIN_BIN rows contributes at most one cut
-        (its last closed one; a forced one at its end when it and the bin before have none), so the number of windows is
-        static and the whole build is a handful of device ops: no host loop over the graphs.  Square graphs whose rows all
-        fit one slot batch only (the kernel's domain)."""
-        N, E, dev = self.num_nodes, self.num_edges, self.device
-        self.n_remote, self.win_ptr = 0, None
-        if not self.BUILD_WINDOWS or self.num_src != N or self.n_hub or E < self.WIN_MIN_EDGES or not (0 < self.max_in_degree <= 64) or N < 2:
-            return
-        R0 = self.WIN_BIN
-        rows = torch.arange(N, device=dev)
-        src = self.src.long()
-        dst = torch.repeat_interleave(rows, self.in_degree)                       # destination of every CSR slot
-        lo_e, hi_e = torch.minimum(src, dst), torch.maximum(src, dst)
-        # a cut after row r is closed iff no edge has one end <= r and the other > r: count the edges spanning it
-        span = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-        span.index_add_(0, lo_e, torch.ones_like(lo_e))
-        span.index_add_(0, hi_e, -torch.ones_like(hi_e))
-        closed = torch.cumsum(span[:N], 0) == 0                                    # [N]: cut after row r crosses nothing
-        nb = (N + R0 - 1) // R0
-        last_closed = torch.full((nb,), -1, dtype=torch.int64, device=dev)
-        last_closed.scatter_reduce_(0, rows // R0, torch.where(closed, rows, torch.full_like(rows, -1)), "amax")
-        has = last_closed >= 0
-        prev_has = torch.cat([has.new_ones(1), has[:-1]])
-        bin_end = torch.clamp((torch.arange(nb, device=dev) + 1) * R0 - 1, max=N - 1)
-        cut = torch.where(has, last_closed, torch.where(~prev_has, bin_end, torch.full_like(bin_end, -1)))
-        cut[-1] = N - 1
-        win_ptr = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
-        win_ptr[1:] = torch.cummax(cut + 1, 0)[0]
-        # which csc entries stay in LDS: source and destination in the same window, position within the window's first
-        # WIN_ECAP csc entries.  The others ("remote") go through the staging buffer; listed per source.
-        win_of_row = torch.bucketize(rows, win_ptr[1:], right=True)               # window b holds rows [ptr[b], ptr[b+1])
-        e_src, e_dst = src[order], dst[order]                                      # csc entry k: source, destination
-        k = torch.arange(E, device=dev)
-        w_src = win_of_row[e_src]
-        local = (w_src == win_of_row[e_dst]) & (k - csc_ptr[win_ptr[w_src]] < self.WIN_ECAP)
-        rem_idx = torch.nonzero(~local).flatten()                                  # (the build's host sync for this view)
-        self.n_remote = int(rem_idx.numel())
-        self.local_fraction = 1.0 - self.n_remote / E
-        if self.local_fraction < 0.5:          # e.g. k-NN graphs with unordered points: the windows catch little
-            self.n_remote = 0
-            return
-        self.win_ptr = win_ptr.int().contiguous()
-        ip64 = self.indptr.long()
-        zero = torch.zeros(nb, dtype=torch.int64, device=dev)
-        self.win_info = torch.stack([win_ptr[:-1], win_ptr[1:] - win_ptr[:-1], ip64[win_ptr[:-1]], ip64[win_ptr[1:]],
-                                     csc_ptr[win_ptr[:-1]], csc_ptr[win_ptr[1:]], zero, zero], dim=1).int().contiguous()
-        c = self._c
-        c.win_ptr, c.n_win, c.win_rows, c.win_ecap = self.win_ptr.data_ptr(), nb, 3 * R0 - 1, self.WIN_ECAP
-        c.win_info = self.win_info.data_ptr()
-        c.n_remote = self.n_remote
-        if self.n_remote:
-            rem_cnt = torch.bincount(e_src[rem_idx], minlength=N)
-            rem_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-            rem_ptr[1:] = torch.cumsum(rem_cnt, 0)
-            self.rem_ptr, self.rem_idx = rem_ptr.int().contiguous(), rem_idx.int().contiguous()
-            c.rem_ptr, c.rem_idx = self.rem_ptr.data_ptr(), self.rem_idx.data_ptr()
 
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----
     def number_of_nodes(self) -> int:
@@ -347,14 +252,6 @@ class DGNGraph:
     @property
     def c_graph(self) -> _lib.DgnGraph:
         return self._c
-
-    @property
-    def c_graph_no_windows(self) -> _lib.DgnGraph:
-        """The same graph description without the row windows (the backward then stages every per-edge row globally)."""
-        c = _lib.DgnGraph()
-        C.memmove(C.byref(c), C.byref(self._c), C.sizeof(_lib.DgnGraph))
-        c.win_ptr, c.win_info, c.n_win, c.rem_ptr, c.rem_idx, c.n_remote = None, None, 0, None, None, 0
-        return c
 
     def to_slot_order(self, per_edge: torch.Tensor) -> torch.Tensor:
         """[E, ...] in original edge-id order -> CSR slot order (differentiable)."""

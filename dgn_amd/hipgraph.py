@@ -157,7 +157,7 @@ class CapturedNetStep:
         i32 = lambda n: torch.arange(n, dtype=torch.int32, device=dev)
         rg.csc_ptr, rg.csc_pos = i32(n_cap + 1), i32(n_cap)                 # node j sits in slot j of exactly one row
         rg._c.csc_ptr, rg._c.csc_pos = rg.csc_ptr.data_ptr(), rg.csc_pos.data_ptr()
-        rg._csc_ready, rg.n_remote, rg.win_ptr = True, 0, None
+        rg._csc_ready = True
         rg.sizes = rg.in_degree
         self.rg = rg
         self.pb.graph._dgn_readout = rg

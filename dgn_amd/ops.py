@@ -23,15 +23,6 @@ from .spec import EPS, AggPlan
 # e.g. hidden 75: 4-byte staging rows make the two-phase path 40 % slower than atomics).
 DETERMINISTIC_BACKWARD = "auto"
 
-# Window-local scatter of the two-phase backward (agg_bwd_window: the per-edge gradient rows of a batch of small graphs are
-# reduced in LDS by the workgroup that owns their window of rows, include/dgn_hip.h: DgnGraph.win_ptr).  False (default): the
-# global [E, F] staging buffer + seg_sum_rows, fed by the grouped row kernel agg_bwd_short -- which overtook the window kernel on
-# every measured batch (ZINC-12k simple layer: windows 0.180 ms, grouped rows 0.136 ms; towers layer 0.375 vs 0.257 ms).  "all":
-# wherever the window kernel applies (needs DGNGraph.BUILD_WINDOWS = True before the graph's csc view is built; the tests compare
-# the two).  "auto": as "all" for layers whose message is x_src alone.
-WINDOW_BACKWARD = False
-
-
 # ---- padded batches -------------------------------------------------------------------------------------------------------------
 # A batch held at a fixed row capacity (shape-bucketed HIP-graph replay: dgn_amd/hipgraph.py::PaddedBatch) carries a DEVICE scalar
 # ``n_valid``: rows >= n_valid are padding (zero features, no edges).  The sweep, the Linears and the elementwise kernels treat them
@@ -164,8 +155,6 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
         raise _lib.DgnError("edge-type table: the backward needs the two-phase scatter (even F, a gradient for x_src)")
     if deterministic:
         graph.ensure_csc()
-        use_windows = bool(WINDOW_BACKWARD) and (WINDOW_BACKWARD == "all" or g_dst is None)
-        g = graph.c_graph if use_windows else graph.c_graph_no_windows
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
         if edge_type is not None:
@@ -981,7 +970,7 @@ class _TowersLayer(torch.autograd.Function):
         out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
         spec = _spec_structs(plan, T, avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
-        cg = graph.c_graph_no_windows        # (P|Q messages keep the global staging path in the backward, see WINDOW_BACKWARD)
+        cg = graph.c_graph
         L.graph, L.spec = C.pointer(cg), C.pointer(spec)
         L.w, L.ld_w, L.log_deg = _ptr(w_edge), (w_edge.stride(0) if w_edge is not None else 0), graph.log_deg.data_ptr()
         L.n_towers, L.f_in, L.f_out, L.n_scalers, L.residual = T, fi, fo, S, int(residual)
@@ -1022,7 +1011,7 @@ class _TowersLayer(torch.autograd.Function):
         graph.ensure_csc()
         spec = _spec_structs(plan, T, ctx.avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
-        cg = graph.c_graph_no_windows
+        cg = graph.c_graph
         L.graph, L.spec = C.pointer(cg), C.pointer(spec)
         L.w, L.ld_w, L.log_deg = _ptr(w_edge), (w_edge.stride(0) if w_edge is not None else 0), graph.log_deg.data_ptr()
         L.n_towers, L.f_in, L.f_out, L.n_scalers, L.residual = T, fi, fo, S, int(residual)

@@ -110,22 +110,6 @@ typedef struct DgnGraph {
      * this CSR is node row_base + i of the source node set.  Only dgn_edge_weights uses it (the destination side of
      * eig is read at row row_base + i); the per-row arrays of the sweep (x_dst, x_in, log_deg, out) are the shard's. */
     int64_t row_base;
-    /* Optional row windows for the backward's window-local scatter (NULL = absent; needs csc_ptr / csc_pos, a square,
-     * hub-free graph whose rows all fit one slot batch).  Window b = rows [win_ptr[b], win_ptr[b+1]) (may be empty), at most
-     * win_rows rows; batched small graphs are block diagonal, so the build puts the cuts where no edge crosses whenever such
-     * a place is nearby.  A per-edge gradient row whose source AND destination lie in the same window, and whose csc position
-     * is among the first win_ecap of the window's csc range, is reduced in LDS by the workgroup that owns the window; all
-     * other csc entries ("remote": rem_ptr[u] .. rem_ptr[u+1] index rem_idx, csc positions in ascending order, per source u)
-     * go through the workspace's staging buffer.  n_remote == 0 with rem_ptr == NULL: there are none.                  */
-    const int32_t* win_ptr;  /* [n_win+1] */
-    const int32_t* win_info; /* [n_win][8]: win_ptr[b], rows, indptr at both ends, csc_ptr at both ends, 0, 0 (one record the
-                                 workgroup of window b reads instead of three dependent look-ups)                           */
-    int64_t n_win;
-    int32_t win_rows;
-    int32_t win_ecap;
-    const int32_t* rem_ptr;  /* [n_nodes+1] */
-    const int32_t* rem_idx;  /* [n_remote]  */
-    int64_t n_remote;
 } DgnGraph;
 
 typedef struct DgnChannel {
@@ -425,9 +409,6 @@ int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec, const Dgn
  *                            ascending edge id), eid [E] (slot -> edge id), log_deg [N], in_degree [N] (int64, may be NULL),
  *                            stats[0] = largest in-degree, stats[1] = rows with more than hub_threshold in-edges
  *   dgn_graph_build_csc      csc_ptr [N+1], csc_pos [E], csc_order [E] (rank -> slot) of DgnGraph's transposed view
- *   dgn_graph_build_windows  win_ptr [nb+1], win_info [nb][8] with nb = ceil(N / bin_rows) windows of at most 3*bin_rows-1 rows
- *                            (cuts where no edge crosses when a bin has such a place), rem_ptr [N+1], rem_idx [<= E];
- *                            stats[2] = stats[3] = number of remote csc entries
  * src / dst are int64 (what torch / DGL hand over); all outputs are caller-allocated device arrays; stats is int32[4] on the
  * device (the caller reads it when it needs the numbers); ws: dgn_graph_build_workspace_bytes() bytes for every call.    */
 size_t dgn_graph_build_workspace_bytes(int64_t n_nodes, int64_t n_edges);
@@ -436,10 +417,7 @@ int dgn_graph_build(int64_t n_nodes, int64_t n_edges, const int64_t* src, const 
                     void* ws, size_t ws_bytes, void* stream);
 int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, int32_t* csc_ptr, int32_t* csc_pos,
                         int32_t* csc_order, void* ws, size_t ws_bytes, void* stream);
-int dgn_graph_build_windows(int64_t n_nodes, int64_t n_edges, const int32_t* indptr, const int32_t* src_csr, const int32_t* dst_csr,
-                            const int32_t* csc_ptr, const int32_t* csc_order, int32_t bin_rows, int32_t ecap, int32_t* win_ptr,
-                            int32_t* win_info, int32_t* rem_ptr, int32_t* rem_idx, int32_t* stats, void* ws, size_t ws_bytes,
-                            void* stream);
+
 
 /* ---- whole towers layer in one call (dgn_towers.hip) ------------------------------------------------------------------
  * DGNLayerTower.forward of the reference (nets/dgn_layer.py:309-325 over DGNTower.forward :254-276) for the fused form the

@@ -60,7 +60,6 @@ def test_grouped_backward_sweep(monkeypatch, seed):
     gen = torch.Generator().manual_seed(seed)
     eig = torch.randn(N, 3, generator=gen)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
-    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
     x_block = pq_msg and seed % 4 < 2
     plan = dgn_amd.make_plan(aggs + ([X_IN_NAME] if x_block else []), scalers)
     X, PQ = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen)
@@ -118,7 +117,6 @@ def test_edge_table_sweep(monkeypatch, seed):
     E = src.numel()
     gen = torch.Generator().manual_seed(seed)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=torch.randn(N, 3, generator=gen).to(dev))
-    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
     plan = dgn_amd.make_plan(aggs + ([X_IN_NAME] if len(scalers) == 1 else []), scalers)
     X, PQ, table = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen), torch.randn(K, F_, generator=gen)
     types_slot = graph.to_slot_order(torch.randint(0, K, (E,), generator=gen).to(dev)).to(torch.int32).contiguous()

@@ -1,5 +1,5 @@
-"""dgn_graph_build / _csc / _windows (the batch preparation as a few kernels behind the C ABI) against the torch-op build it
-replaces: every array of the CSR, the transposed view and the row windows must be identical."""
+"""dgn_graph_build / _csc (the batch preparation as a few kernels behind the C ABI) against the torch-op build it
+replaces: every array of the CSR and of the transposed view must be identical."""
 import numpy as np
 import pytest
 import torch
@@ -27,8 +27,6 @@ def test_native_build_equals_torch_build(monkeypatch, case):
     import dgn_amd.graph as G
     name, src, dst, N, kw = case
     dev = torch.device("cuda")
-    monkeypatch.setattr(G.DGNGraph, "BUILD_WINDOWS", True)
-    monkeypatch.setattr(G.DGNGraph, "WIN_MIN_EDGES", 0)
     built = {}
     for native in (True, False):
         monkeypatch.setattr(G, "NATIVE_BUILD", native)
@@ -43,13 +41,6 @@ def test_native_build_equals_torch_build(monkeypatch, case):
     if a.num_edges:
         assert torch.equal(a.eid, b.eid)
         assert torch.equal(a.dst_csr.long(), torch.repeat_interleave(torch.arange(N, device=dev), a.in_degree))
-    assert (a.win_ptr is None) == (b.win_ptr is None), name
-    if a.win_ptr is not None:
-        assert torch.equal(a.win_ptr, b.win_ptr) and torch.equal(a.win_info, b.win_info)
-        assert a.n_remote == b.n_remote
-        if a.n_remote:
-            assert torch.equal(a.rem_ptr, b.rem_ptr)
-            assert torch.equal(a.rem_idx[:a.n_remote], b.rem_idx)
 
 
 def test_native_build_matches_the_layer_results():

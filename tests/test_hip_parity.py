@@ -651,7 +651,6 @@ def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, ca
     gen = torch.Generator().manual_seed(8)
     eig = torch.randn(N, 4, generator=gen)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
-    monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", False)
     if case == "towers":          # the headline list: static operators, tower-major, h_in pass-through block
         F_, T, aggs, scalers = 70, 5, ["mean", "max", "min", "dir1-av", "dir1-dx"], ["identity"]
         from dgn_amd.dgn_layer import X_IN_NAME
@@ -694,97 +693,6 @@ def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, ca
     for a, r in zip(got, ref):
         assert torch.isfinite(a).all()
         assert torch.equal(a, r)
-
-
-@pytest.mark.parametrize("case", ["pair", "simple", "three_term", "cut_molecules", "one_graph"])
-def test_window_backward_equals_staged_backward(monkeypatch, case):
-    """agg_bwd_window (per-edge gradient rows reduced in the LDS of the workgroup that owns their window of rows) against the
-    global two-phase scatter it replaces, on molecule batches: all sinks, run-to-run bitwise equality, the remote path
-    (edges that cross a window, windows with more csc entries than the LDS holds), and against the oracle."""
-    dev = _dev()
-    import dgn_amd
-    from dgn_amd import synth
-    from dgn_amd.ops import directional_aggregate
-    from oracle import dgn_oracle as orc
-    if case == "one_graph":
-        # ONE connected graph (a 300-node chain with chords i -- i+3): no closed cut anywhere, so every window ends at a
-        # forced cut and the edges across it take the remote path
-        i = torch.arange(299)
-        j = torch.arange(297)
-        u, v = torch.cat([i, j]), torch.cat([i + 1, j + 3])
-        b = dict(src=torch.cat([u, v]), dst=torch.cat([v, u]), num_nodes=300)
-    else:
-        b = synth.molecule_batch(40, seed=11, laplacian_eig=False)
-    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
-    F_ = 12 if case != "simple" else 70
-    gen = torch.Generator().manual_seed(4)
-    eig = torch.randn(N, 4, generator=gen)
-    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
-    monkeypatch.setattr(dgn_amd.DGNGraph, "BUILD_WINDOWS", True)
-    monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_MIN_EDGES", 0)             # (small test graphs: build the windows anyway)
-    if case == "cut_molecules":
-        monkeypatch.setattr(dgn_amd.DGNGraph, "WIN_ECAP", 40)             # fewer LDS entries than a window's csc range
-    graph.ensure_csc()
-    assert graph.win_ptr is not None
-    if case in ("one_graph", "cut_molecules"):
-        assert graph.n_remote > 0
-    aggs, scalers = ["mean", "max", "min", "std", "dir1-av", "dir1-dx", "dir2-dx-no-abs"], ["identity", "attenuation"]
-    plan = dgn_amd.make_plan(aggs, scalers)
-    P, Q, X = (torch.randn(N, F_, generator=gen) for _ in range(3))
-    R = torch.randn(src.numel(), F_, generator=gen)
-    ct = torch.randn(N, plan.out_width(F_), generator=gen)
-
-    def run(window):
-        monkeypatch.setattr(dgn_amd.ops, "WINDOW_BACKWARD", "all" if window else False)
-        if case == "simple":
-            h = X.to(dev).requires_grad_(True)
-            y = directional_aggregate(graph, plan, 1.1, x_src=h, x_in=h)
-            return y, torch.autograd.grad(y, [h], ct.to(dev))
-        pq = torch.cat([P, Q], 1).to(dev).requires_grad_(True)
-        x = X.to(dev).requires_grad_(True)
-        leaves = [pq, x]
-        m_edge = None
-        if case == "three_term":
-            r = R.to(dev).requires_grad_(True)
-            leaves.append(r)
-            m_edge = graph.to_slot_order(r)
-        y = directional_aggregate(graph, plan, 1.1, x_pair=pq, m_edge=m_edge, x_in=x)
-        return y, torch.autograd.grad(y, leaves, ct.to(dev))
-
-    y_w, g_w = run(True)
-    y_w2, g_w2 = run(True)
-    y_s, g_s = run(False)
-    for a, b2, c in zip(g_w, g_w2, g_s):
-        assert torch.equal(a, b2)                                         # fixed summation order: bitwise reproducible
-        _close(a, c, 1e-5, 1e-5)                                          # vs the global staging path (other association)
-    # and against the oracle
-    if case == "simple":
-        lo = [X.clone().requires_grad_(True)]
-        msg, xin = lo[0][src], lo[0]
-    else:
-        lo = [P.clone().requires_grad_(True), Q.clone().requires_grad_(True), X.clone().requires_grad_(True)]
-        msg, xin = lo[0][src] + lo[1][dst], lo[2]
-        if case == "three_term":
-            lo.append(R.clone().requires_grad_(True))
-            msg = msg + lo[3]
-    yo = orc.aggregate_graph(src, dst, N, msg, eig, xin, aggs, scalers, torch.tensor(1.1))
-    go = torch.autograd.grad(yo, lo, ct)
-    # (fp64 evaluation of the same oracle: std of nearly equal messages is ill-conditioned in the reference too)
-    lo64 = [t.detach().double().requires_grad_(True) for t in lo]
-    if case == "simple":
-        msg64, xin64 = lo64[0][src], lo64[0]
-    else:
-        msg64, xin64 = lo64[0][src] + lo64[1][dst] + (lo64[3] if case == "three_term" else 0), lo64[2]
-    y64 = orc.aggregate_graph(src, dst, N, msg64, eig.double(), xin64, aggs, scalers, torch.tensor(1.1, dtype=torch.float64))
-    g64 = torch.autograd.grad(y64, lo64, ct.double())
-    _as_good(y_w, yo, y64, 2e-5, 2e-5, "y")
-    if case == "simple":
-        _as_good(g_w[0], go[0], g64[0], 1e-4, 1e-4, "g_h")
-    else:
-        _as_good(g_w[0], torch.cat([go[0], go[1]], 1), torch.cat([g64[0], g64[1]], 1), 1e-4, 1e-4, "g_pq")
-        _as_good(g_w[1], go[2], g64[2], 1e-4, 1e-4, "g_x")
-        if case == "three_term":
-            _as_good(g_w[2], go[3], g64[3], 1e-4, 1e-4, "g_edge")
 
 
 @pytest.mark.parametrize("residual,graph_norm,scalers", [(True, True, "identity amplification attenuation"), (False, False, "identity attenuation"),
