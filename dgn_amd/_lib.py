@@ -200,7 +200,7 @@ def load() -> C.CDLL:
         lib.dgn_gemm_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_gemm_wgrad.restype = C.c_int
         lib.dgn_gemm_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                       C.c_void_p, C.c_size_t, C.c_void_p]
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_supported.restype = C.c_int
         lib.dgn_layer_fused_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_layer_fused_forward.restype = C.c_int

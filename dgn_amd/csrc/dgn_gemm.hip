@@ -81,6 +81,27 @@ WgPlan wgrad_plan(int64_t M, int k, int n) {
     return w;
 }
 
+// tile_wgrad: blocks of at most 8 x 8 tiles of 32 columns, as even as the widths allow; one workgroup per CU (LDS), the row strips dealt
+// round-robin to `slots` workgroups per block
+struct TwPlan { int nb_tiles, kb_tiles, n_blocks, k_blocks, slots; size_t lds; };
+TwPlan tile_wgrad_plan(int64_t M, int kk, int n) {
+    TwPlan t{};
+    const int nt = (n + 31) / 32, kt = (kk + 31) / 32;
+    t.n_blocks = (nt + 7) / 8;
+    t.nb_tiles = (nt + t.n_blocks - 1) / t.n_blocks;
+    t.k_blocks = (kt + 7) / 8;
+    t.kb_tiles = (kt + t.k_blocks - 1) / t.k_blocks;
+    const int64_t n_strips = (M + kTwRows - 1) / kTwRows;
+    t.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_strips, n_cus() / (t.n_blocks * t.k_blocks)));
+    t.lds = (size_t)2 * kTwRows * (tw_stride(t.nb_tiles * 32) + tw_stride(t.kb_tiles * 32)) * sizeof(float);
+    return t;
+}
+
+bool use_tile_wgrad(int64_t n_rows) {
+    const char* env = getenv("DGN_TILE_WGRAD");              // (read per call: the tests switch it)
+    return env ? atoi(env) != 0 : n_rows >= 4096;
+}
+
 }  // namespace
 }  // namespace gemm
 }  // namespace dgn
@@ -132,22 +153,50 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
 }
 
 extern "C" size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n) {
-    if (n_rows <= 0 || !dgn_gemm_supported(k, n) || n > 16 * kWgWaves) return 0;
-    const WgPlan w = wgrad_plan(n_rows, k, n);
-    return (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float);
+    if (n_rows <= 0 || !dgn_gemm_supported(k, n)) return 0;
+    const TwPlan t = tile_wgrad_plan(n_rows, k + 1, n);
+    size_t bytes = (size_t)t.n_blocks * t.k_blocks * t.slots * (t.nb_tiles * 32) * (t.kb_tiles * 32) * sizeof(float);
+    if (n <= 16 * kWgWaves) {
+        const WgPlan w = wgrad_plan(n_rows, k, n);
+        bytes = std::max(bytes, (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float));
+    }
+    return bytes;
 }
 
 extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw,
-                              int64_t lddw, void* ws, size_t ws_bytes, void* stream) {
+                              int64_t lddw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "dgn_gemm_wgrad";
-    if (n_rows < 0 || !dgn_gemm_supported(k, n) || n > 16 * kWgWaves) { set_error("%s: need n <= %d (k=%d n=%d)", fn, 16 * kWgWaves, k, n); return DGN_ERR_INVALID; }
+    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 1..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
     if (!dw || lddw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (n_rows == 0) return zero_rows_async(dw, n, k, lddw, st);
+    if (n_rows == 0) {
+        if (zero_rows_async(dw, n, k, lddw, st)) return DGN_ERR_HIP;
+        return dbias ? zero_rows_async(dbias, 1, n, n, st) : DGN_OK;
+    }
     if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
-    const WgPlan w = wgrad_plan(n_rows, k, n);
     const size_t need = dgn_gemm_wgrad_workspace_bytes(n_rows, k, n);
     if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
+    // the tile kernel (32 x 32 x 2 MFMA, whole accumulator blocks per workgroup, bias gradient as a ones column) wherever there are
+    // rows enough to fill the CUs, and always for n > 256 or with a bias gradient; the strip kernel on small batches
+    if (use_tile_wgrad(n_rows) || n > 16 * kWgWaves || dbias) {
+        TileWgParams p{};
+        p.M = n_rows; p.n = n; p.k = k; p.kk = dbias ? k + 1 : k;
+        p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
+        const TwPlan t = tile_wgrad_plan(n_rows, p.kk, n);
+        p.slots = t.slots; p.n_blocks = t.n_blocks; p.k_blocks = t.k_blocks; p.nb_tiles = t.nb_tiles; p.kb_tiles = t.kb_tiles;
+        static bool attr = false;
+        if (!attr) {
+            DGN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(tile_wgrad, dim3(t.slots, t.n_blocks * t.k_blocks), dim3(kWave * kTwWaves), t.lds, st, p);
+        const int64_t total = (int64_t)n * p.kk;
+        hipLaunchKernelGGL(tile_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(64 * 16), 0, st, n, k, p.kk, t.slots, t.k_blocks,
+                           t.nb_tiles * 32, t.kb_tiles * 32, p.part, dw, lddw, dbias);
+        DGN_HIP_CHECK(hipGetLastError());
+        return DGN_OK;
+    }
+    const WgPlan w = wgrad_plan(n_rows, k, n);
     WgradParams p{};
     p.M = n_rows; p.n = n; p.k = k; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
     p.k_slice = w.k_slice; p.slots = w.slots;

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dgn_common.hpp"
 
 namespace dgn {
@@ -417,6 +419,203 @@ static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int 
     }
     for (; q < slots; ++q) s0 += src[(int64_t)q * npad * kpad];
     dW[(int64_t)r * lddw + c] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- tile weight gradient (32 x 32 x 2 MFMA, the whole [n-block, k-block] accumulator in one workgroup's registers) -----------------
+// dW [n, k] = G^T X over M rows: the outputs are small and the reduction index is the long one.  A workgroup of 8 waves (2 over n x 4 over
+// k) holds the accumulators of a whole block of up to 256 x 256 outputs -- wave (wn, wk) owns up to 4 x 2 tiles of 32 x 32, 16 registers
+// each -- and streams ITS share of the rows through LDS once, 16 rows at a time (both operand strips fetched into registers before the
+// strip's MFMAs and committed to the other LDS buffer after them).  Per pair of rows a wave reads 4 + 2 operand values for 8
+// v_mfma_f32_32x32x2_f32 (ts_gemm_wgrad: one read per MFMA and G re-read per 256-column k slice).  Tiles are dealt to the waves at run
+// time (wave-uniform guards), so n = 210, k = 420 costs 7 x 14 tiles, not 8 x 16.  The bias gradient rides as column k of X := 1
+// (`ones`).  Per-workgroup partial blocks, fixed-order finalize: bitwise reproducible.  Any n, k (blocks of up to 256 columns each way).
+using f16v = __attribute__((ext_vector_type(16))) float;
+constexpr int kTwRows = 16, kTwWaves = 8, kTwWN = 2, kTwWK = 4, kTwNT = 4, kTwKT = 2;
+
+struct TileWgParams {
+    int64_t M;
+    int n, k, kk;                    // kk = k + 1 with the ones column, else k
+    const float* G; int64_t ldg;     // [M, n]
+    const float* X; int64_t ldx;     // [M, k]
+    float* part;                     // [n_blocks * k_blocks][slots][nb_cols][kb_cols]
+    int slots, n_blocks, k_blocks, nb_tiles, kb_tiles;      // tiles of 32 per block (<= 8 each)
+};
+
+__host__ __device__ inline int tw_stride(int cols) { return ((cols + 63) / 64) * 64 + 32; }      // == 32 mod 64: the two half-waves of an operand read hit disjoint banks
+
+constexpr int kTwItems = (kTwRows * 128 + kWave * kTwWaves - 1) / (kWave * kTwWaves);          // 256 + 256 columns: 4 float4's per thread and strip
+
+// block geometry of one workgroup (uniform)
+struct TwBlock {
+    int n0, k0, n_here, k_here, gs, xs, half, gq, per_row, total;
+};
+
+// a 16-row strip of G's and X's column blocks, zero beyond the matrices, column k of X := 1 (the bias gradient's ones column)
+__device__ __forceinline__ void tw_fetch(f4 (&reg)[kTwItems], const TileWgParams& p, const TwBlock& B, int64_t strip, int tid) {
+    const int64_t r0 = strip * kTwRows;
+#pragma unroll
+    for (int j = 0; j < kTwItems; ++j) {
+        const int it = tid + j * kWave * kTwWaves;
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (it < B.total) {
+            const int r = it / B.per_row, c = it - r * B.per_row;
+            const int64_t row = r0 + r;
+            if (row < p.M) {
+                if (c < B.gq) {
+                    const int col = 4 * c;
+                    const float* src = p.G + row * p.ldg + B.n0 + col;
+                    if (col + 3 < B.n_here) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (col + e < B.n_here) v[e] = src[e];
+                    }
+                } else {
+                    const int gcol = B.k0 + 4 * (c - B.gq);
+                    const float* src = p.X + row * p.ldx + gcol;
+                    if (gcol + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (gcol + e < p.k) v[e] = src[e];
+                            else if (gcol + e == p.k && p.kk > p.k) v[e] = 1.f;
+                        }
+                    }
+                }
+            }
+        }
+        reg[j] = v;
+    }
+}
+__device__ __forceinline__ void tw_commit(const f4 (&reg)[kTwItems], float* Gb, const TwBlock& B, int tid) {
+    float* Xb = Gb + kTwRows * B.gs;
+#pragma unroll
+    for (int j = 0; j < kTwItems; ++j) {
+        const int it = tid + j * kWave * kTwWaves;
+        if (it < B.total) {
+            const int r = it / B.per_row, c = it - r * B.per_row;
+            if (c < B.gq) *reinterpret_cast<f4*>(Gb + r * B.gs + 4 * c) = reg[j];
+            else *reinterpret_cast<f4*>(Xb + r * B.xs + 4 * (c - B.gq)) = reg[j];
+        }
+    }
+}
+
+// The strip loop of a wave that owns NTc x KTc tiles (n tiles from a0, k tiles from b0): counts as template arguments -- MFMAs under
+// run-time guards made the compiler keep copies of the accumulators across the branches (spills).  Every wave of the workgroup runs the
+// same number of iterations and barriers whatever its instantiation.
+template <int NTc, int KTc>
+__device__ __forceinline__ void tw_run(const TileWgParams& p, const TwBlock& B, float* lds, int a0, int b0, int tid) {
+    const int lane = tid & 63, i32 = lane & 31, hi = lane >> 5;
+    f16v acc[NTc > 0 ? NTc : 1][KTc > 0 ? KTc : 1];
+#pragma unroll
+    for (int a = 0; a < NTc; ++a)
+#pragma unroll
+        for (int b = 0; b < KTc; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int64_t n_strips = (p.M + kTwRows - 1) / kTwRows;
+    f4 sreg[kTwItems];
+    if ((int64_t)blockIdx.x < n_strips) {
+        tw_fetch(sreg, p, B, blockIdx.x, tid);
+        tw_commit(sreg, lds, B, tid);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t strip = blockIdx.x; strip < n_strips; strip += gridDim.x, buf ^= 1) {
+        const bool more = strip + gridDim.x < n_strips;
+        if (more) tw_fetch(sreg, p, B, strip + gridDim.x, tid);
+        const float* Gb = lds + buf * B.half + 32 * a0 + i32;
+        const float* Xb = lds + buf * B.half + kTwRows * B.gs + 32 * b0 + i32;
+        // D[n][k] += G[m][n] X[m][k]: the pair of rows m = 2 s + hi is the reduction index of the s-th instruction
+#pragma unroll 2
+        for (int s = 0; s < kTwRows / 2; ++s) {
+            const int r = 2 * s + hi;
+            float gv[NTc > 0 ? NTc : 1], xv[KTc > 0 ? KTc : 1];
+#pragma unroll
+            for (int a = 0; a < NTc; ++a) gv[a] = Gb[r * B.gs + 32 * a];
+#pragma unroll
+            for (int b = 0; b < KTc; ++b) xv[b] = Xb[r * B.xs + 32 * b];
+#pragma unroll
+            for (int a = 0; a < NTc; ++a)
+#pragma unroll
+                for (int b = 0; b < KTc; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[a], xv[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) tw_commit(sreg, lds + (buf ^ 1) * B.half, B, tid);
+        __syncthreads();
+    }
+    // lane holds D[32 a + (r & 3) + 8 (r >> 2) + 4 hi][32 b + i32] of its tiles: the workgroup's partial block goes to its slot
+    const int kbc = p.kb_tiles * 32;
+    float* out = p.part + ((int64_t)blockIdx.y * p.slots + blockIdx.x) * (p.nb_tiles * 32) * kbc;
+#pragma unroll
+    for (int a = 0; a < NTc; ++a)
+#pragma unroll
+        for (int b = 0; b < KTc; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(int64_t)(32 * (a0 + a) + (r & 3) + 8 * (r >> 2) + 4 * hi) * kbc + 32 * (b0 + b) + i32] = acc[a][b][r];
+}
+
+__global__ __launch_bounds__(kWave * kTwWaves) void tile_wgrad(const TileWgParams p) {
+    extern __shared__ float lds_tw[];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int bn = blockIdx.y / p.k_blocks, bk = blockIdx.y - bn * p.k_blocks;
+    TwBlock B;
+    B.n0 = bn * p.nb_tiles * 32; B.k0 = bk * p.kb_tiles * 32;
+    B.n_here = min(p.nb_tiles * 32, p.n - B.n0); B.k_here = min(p.kb_tiles * 32, p.kk - B.k0);      // columns of this block that exist
+    B.gs = tw_stride(p.nb_tiles * 32); B.xs = tw_stride(p.kb_tiles * 32);
+    B.half = kTwRows * (B.gs + B.xs);
+    B.gq = (B.n_here + 3) >> 2;
+    B.per_row = B.gq + ((B.k_here + 3) >> 2);
+    B.total = kTwRows * B.per_row;
+    // this wave's tiles: n tiles [a0, a0 + nt_w), k tiles [b0, b0 + kt_w) of the block, dealt as evenly as possible
+    const int nt_blk = (B.n_here + 31) >> 5, kt_blk = (B.k_here + 31) >> 5;
+    const int wn = wave / kTwWK, wk = wave - wn * kTwWK;
+    const int a0 = (nt_blk * wn) / kTwWN, nt_w = (nt_blk * (wn + 1)) / kTwWN - a0;
+    const int b0 = (kt_blk * wk) / kTwWK, kt_w = (kt_blk * (wk + 1)) / kTwWK - b0;
+    switch ((nt_w > 0 && kt_w > 0) ? nt_w * 4 + kt_w : 0) {
+        case 4 + 1: tw_run<1, 1>(p, B, lds_tw, a0, b0, tid); break;
+        case 4 + 2: tw_run<1, 2>(p, B, lds_tw, a0, b0, tid); break;
+        case 8 + 1: tw_run<2, 1>(p, B, lds_tw, a0, b0, tid); break;
+        case 8 + 2: tw_run<2, 2>(p, B, lds_tw, a0, b0, tid); break;
+        case 12 + 1: tw_run<3, 1>(p, B, lds_tw, a0, b0, tid); break;
+        case 12 + 2: tw_run<3, 2>(p, B, lds_tw, a0, b0, tid); break;
+        case 16 + 1: tw_run<4, 1>(p, B, lds_tw, a0, b0, tid); break;
+        case 16 + 2: tw_run<4, 2>(p, B, lds_tw, a0, b0, tid); break;
+        default: tw_run<0, 0>(p, B, lds_tw, a0, b0, tid); break;       // a wave without tiles still stages and syncs
+    }
+}
+
+// dW[n][k] (and dbias[n] = column k of the padded product) = the slot sums in slot order; a block covers 64 consecutive elements, its
+// sixteen waves take every sixteenth slot, LDS joins them (as dgn_linear's finalize)
+static __global__ __launch_bounds__(64 * 16) void tile_wgrad_finalize(int n, int k, int kk, int slots, int k_blocks, int nbc, int kbc,
+                                                                      const float* __restrict__ part, float* __restrict__ dW, int64_t lddw,
+                                                                      float* __restrict__ dbias) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = e < (int64_t)n * kk;
+    int r = 0, c = 0;
+    float s0 = 0.f, s1 = 0.f;
+    if (live) {
+        r = (int)(e / kk);
+        c = (int)(e - (int64_t)r * kk);
+        const int bn = r / nbc, bk = c / kbc;
+        const float* src = part + (int64_t)(bn * k_blocks + bk) * slots * nbc * kbc + (int64_t)(r - bn * nbc) * kbc + (c - bk * kbc);
+        int q = sg;
+        for (; q + 16 < slots; q += 32) {
+            s0 += src[(int64_t)q * nbc * kbc];
+            s1 += src[(int64_t)(q + 16) * nbc * kbc];
+        }
+        if (q < slots) s0 += src[(int64_t)q * nbc * kbc];
+    }
+    red[sg][lane] = s0 + s1;
+    __syncthreads();
+    if (live && sg == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][lane];
+        if (c < k) dW[(int64_t)r * lddw + c] = v;
+        else if (dbias) dbias[r] = v;
+    }
 }
 
 }  // namespace gemm

@@ -377,14 +377,18 @@ int dgn_linear_bd_wgrad(int64_t n_rows, int32_t n_towers, int32_t f_in, const fl
  * parity (hidden 75 / 65), any row stride >= the row.  Exact fp32 MFMA, shape independent (no library solution selection).
  *   dgn_gemm_forward   c = a . op(w) (+ bias)      a [n_rows, k], c [n_rows, n]; w_is_kn == 0: w [n, k] (forward),
  *                                                   w_is_kn == 1: w [k, n] (input gradient: a = g_out, w = weight)
- *   dgn_gemm_wgrad     dw [n, k] = g^T . x           g [n_rows, n], x [n_rows, k]; n <= 256; per-workgroup partials in ws
- *                                                   (dgn_gemm_wgrad_workspace_bytes), fixed-order sum: bitwise reproducible */
+ *   dgn_gemm_wgrad     dw [n, k] = g^T . x           g [n_rows, n], x [n_rows, k]; dbias [n] = column sums of g (NULL = not wanted:
+ *                                                   it rides as a column of ones appended to x, no extra pass); per-workgroup partials
+ *                                                   in ws (dgn_gemm_wgrad_workspace_bytes), fixed-order sum: bitwise reproducible.
+ *                                                   From 4096 rows on (and always for n > 256 or with dbias): the tile kernel --
+ *                                                   v_mfma_f32_32x32x2_f32, a block of up to 256 x 256 outputs held in one workgroup's
+ *                                                   registers, every operand element read from memory once per k block */
 int dgn_gemm_supported(int32_t k, int32_t n);
 int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw, int32_t w_is_kn,
                      const float* bias, float* c, int64_t ldc, void* stream);
 size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n);
 int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw,
-                   int64_t lddw, void* ws, size_t ws_bytes, void* stream);
+                   int64_t lddw, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the posttrans product inside the sweep (dgn_fused.hip) -----------------------------------------------------------
  * dgn_agg_forward + dgn_linear_combine_forward as ONE kernel: the aggregate rows ([T][A][F/T] per node: 1 680 bytes on the

@@ -143,19 +143,49 @@ def test_wide_gemm_vs_fp64(monkeypatch, M, k, n, tile):
     _lib.check(lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, wt.data_ptr(), n, 0, None, gx2.data_ptr(), k, st), "dgrad t")
     rgx = g.double() @ w.double()
     assert float((gx1.double() - rgx).abs().max()) <= tol(rgx) and float((gx2.double() - rgx).abs().max()) <= tol(rgx)
-    if n <= 256:
-        nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
-        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    # weight gradient: both kernels (DGN_TILE_WGRAD=1: 32 x 32 x 2 MFMA tile kernel, with and without the bias-gradient ones column;
+    # 0: the 16-row strip kernel, n <= 256), against fp64; fixed summation order
+    rgw, rgb = g.double().T @ x.double(), g.double().sum(0)
+    wtol = 2e-6 * float(rgw.abs().max()) * max(1.0, (M / 4096) ** 0.5) + 1e-6
+    nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    for tw, with_bias in (("1", True), ("1", False), ("0", False)):
+        if tw == "0" and n > 256:
+            continue
+        monkeypatch.setenv("DGN_TILE_WGRAD", tw)
         outs = []
         for _ in range(2):
-            gw = torch.full((n, k), float("nan"), device=dev)
-            _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), x.stride(0), gw.data_ptr(), k, ws.data_ptr(), nb, st), "wgrad")
-            outs.append(gw)
-        rgw = g.double().T @ x.double()
-        assert float((outs[0].double() - rgw).abs().max()) <= 2e-6 * float(rgw.abs().max()) * max(1.0, (M / 4096) ** 0.5) + 1e-6
-        assert torch.equal(outs[0], outs[1])                    # fixed summation order
-    else:
-        assert lib.dgn_gemm_wgrad_workspace_bytes(M, k, n) == 0
+            gw = torch.full((n, k + 2), float("nan"), device=dev)                 # (row stride k + 2: the padding columns must stay untouched)
+            gb = torch.full((n,), float("nan"), device=dev) if with_bias else None
+            _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), x.stride(0), gw.data_ptr(), k + 2, gb.data_ptr() if with_bias else None,
+                                          ws.data_ptr(), nb, st), "wgrad")
+            outs.append((gw, gb))
+        assert float((outs[0][0][:, :k].double() - rgw).abs().max()) <= wtol, (tw, with_bias)
+        assert bool(torch.isnan(outs[0][0][:, k:]).all())
+        assert torch.equal(outs[0][0][:, :k], outs[1][0][:, :k])
+        if with_bias:
+            assert float((outs[0][1].double() - rgb).abs().max()) <= 2e-6 * float(g.abs().sum(0).max()) + 1e-6
+            assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("M,k,n", [(4100, 96, 330), (9000, 880, 1320), (33, 64, 32), (70000, 421, 211)])
+def test_tile_wgrad_wide_and_aligned_shapes(M, k, n):
+    """widths beyond one 256-column block either way (PCBA's complex layers: hidden 440 x 3 scalers, README.md:100-103), widths that are
+    multiples of 32 (the ones column then opens a tile of its own), a row count that leaves ragged strips"""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + k)
+    x, g = torch.randn(M, k, device=dev, generator=gen), torch.randn(M, n, device=dev, generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    gw, gb = torch.empty(n, k, device=dev), torch.empty(n, device=dev)
+    _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), k, gw.data_ptr(), k, gb.data_ptr(), ws.data_ptr(), nb, st), "wgrad")
+    rgw, rgb = g.double().T @ x.double(), g.double().sum(0)
+    assert float((gw.double() - rgw).abs().max()) <= 2e-6 * float(rgw.abs().max()) * max(1.0, (M / 4096) ** 0.5) + 1e-6
+    assert float((gb.double() - rgb).abs().max()) <= 2e-6 * float(g.abs().sum(0).max()) + 1e-6
 
 
 def test_wide_linear_autograd_matches_library(monkeypatch):

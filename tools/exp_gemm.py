@@ -48,7 +48,7 @@ for name, M, k, n in shapes:
     own = dict(fwd=lambda: lib.dgn_gemm_forward(M, k, n, x.data_ptr(), k, w.data_ptr(), k, 0, b.data_ptr(), c.data_ptr(), n, st),
                dgrad_kn=lambda: lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, w.data_ptr(), k, 1, None, gx.data_ptr(), k, st),
                dgrad_t=lambda: lib.dgn_gemm_forward(M, n, k, g.data_ptr(), n, wt.data_ptr(), n, 0, None, gx.data_ptr(), k, st),
-               wgrad=lambda: lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), k, gw.data_ptr(), k, ws.data_ptr(), nb, st))
+               wgrad=lambda: lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), k, gw.data_ptr(), k, None, ws.data_ptr(), nb, st))
     libf = dict(fwd=lambda: torch.nn.functional.linear(x, w, b), dgrad=lambda: g @ w, wgrad=lambda: g.t() @ x)
     with torch.no_grad():
         print("   lib: " + "  ".join(f"{k_} {t(f):.3f} ms ({flops / t(f) / 1e9:.0f} TF)" for k_, f in libf.items()))
