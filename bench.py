@@ -366,6 +366,13 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
 
     result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
                   scaling="strong" if strong else "weak")
+    if torch.distributed.is_initialized():
+        # per rank: its shard's size and the gradient all-reduce timed on its own (HIP events around 20 back-to-back calls)
+        ms_ar = event_ms(reducer, 20, dev, warm=3)
+        stats = ddist.gather_rank_stats([rank, N, E, ms_ar], dev)
+        result["ranks"] = [dict(rank=int(r), nodes=int(n), edges=int(e), allreduce_ms=a) for r, n, e, a in stats]
+        result["allreduce"] = dict(params=int(reducer.flat.numel()), bytes=int(reducer.flat.numel()) * 4,
+                                   ms_max=max(a for _, _, _, a in stats), note="one flat fp32 buffer, sum + scale, inside the timed step")
     if rank != 0:
         return result
 
@@ -498,13 +505,24 @@ def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
     for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
+    ms_local = (time.perf_counter() - t0) * 1e3 / steps           # this rank's own sweep time (before it waits for the others)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     ms = ddist.barrier_max_ms((time.perf_counter() - t0) * 1e3 / steps, dev)
     e_total = torch.tensor([float(E)], dtype=torch.float64, device=dev)
     if torch.distributed.is_initialized():
         torch.distributed.all_reduce(e_total)
-    result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
+    ranks_info = None
+    if torch.distributed.is_initialized():
+        ms_ag = None
+        if partition:
+            # the exchange between two sharded layers: the F-wide output rows of every shard all-gathered (dist.all_gather_rows)
+            rows = torch.randn(N, F_, device=dev)
+            rr = [(int(a), int(b)) for a, b in ddist.gather_rank_stats([r0, r1], dev)]
+            ms_ag = event_ms(lambda: ddist.all_gather_rows(rows, rr), 5, dev, warm=2)
+        stats = ddist.gather_rank_stats([rank, N, E, ms_local, ms_ag if ms_ag is not None else -1.0], dev)
+        ranks_info = [dict(rank=int(r), rows=int(n), edges=int(e), sweep_ms=t, all_gather_ms=(a if a >= 0 else None)) for r, n, e, t, a in stats]
+    result = dict(ms_per_step=ms, value=float(e_total.item()) / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N, ranks=ranks_info,
                   eig=eig_info or "random columns", scaling="strong" if partition else "weak",
                   parallelism=(f"1 graph, {world} destination-range shards (balanced edges), features replicated, no exchange "
                                f"inside the sweep") if partition else (f"{world} independent replicas" if world > 1 else "single GPU"))
@@ -878,6 +896,10 @@ def main():
                                   + (" (HIP graph replay)" if args.hipgraph else ""))
                             if wl["type_net"] != "op" else "aggregation forward"),
                 roofline=result.get("roofline"))
+    if result.get("ranks"):
+        line["ranks"] = result["ranks"]
+        if result.get("allreduce"):
+            line["allreduce"] = result["allreduce"]
     if world == 1 and not args.no_cpu_baseline and batch is not None:
         line["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])))
     else:

@@ -109,12 +109,13 @@ bool use_tile_wgrad(int64_t n_rows) {
 using namespace dgn;
 using namespace dgn::gemm;
 
-extern "C" int dgn_gemm_supported(int32_t k, int32_t n) { return k >= 1 && n >= 1 && k <= 4096 && n <= 4096; }
+// (widths of at least 4: the operand prefetches are branch-free 16-byte loads clamped into the row)
+extern "C" int dgn_gemm_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 4096; }
 
 extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
                                 int32_t w_is_kn, const float* bias, float* c, int64_t ldc, void* stream) {
     const char* fn = "dgn_gemm_forward";
-    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 1..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
+    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 4..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
     if (!a || !w || !c || lda < k || ldc < n || ldw < (w_is_kn ? n : k)) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     GemmParams p{};
@@ -166,7 +167,7 @@ extern "C" size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int3
 extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx, float* dw,
                               int64_t lddw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "dgn_gemm_wgrad";
-    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 1..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
+    if (n_rows < 0 || !dgn_gemm_supported(k, n)) { set_error("%s: widths outside 4..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
     if (!dw || lddw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_rows == 0) {

@@ -23,6 +23,34 @@ namespace gemm {
 using f4 = __attribute__((ext_vector_type(4))) float;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte vector at 4-byte alignment (odd row strides)
 
+// Four consecutive floats row[col .. col + 3] of a row that has `limit` (>= 4) columns, zero past the end, WITHOUT a branch: one
+// 16-byte load from an address clamped into the row, the wanted window picked with selects.  A load inside a branch is followed by
+// s_waitcnt vmcnt(0) at the branch's end (measured in these kernels' ISA: every operand prefetch was a synchronous memory round trip
+// in front of the chunk's MFMAs instead of travelling during them); `live` = false gives zeros (rows past the matrix: the caller
+// clamps the row pointer).
+// Split in two so that NOTHING consumes the load where it is issued: load4_raw (the load + the window's shift) goes with the prefetch,
+// load4_window (the selects) with the commit after the MFMAs -- selects right behind the load would again put a wait in front of the
+// MFMAs.
+struct Raw4 { f4 raw; int sh; };
+__device__ __forceinline__ Raw4 load4_raw(const float* row, int col, int limit, bool live = true) {
+    const int cc = max(0, min(col, limit - 4));
+    Raw4 r;
+    r.raw = *reinterpret_cast<const f4u*>(row + cc);
+    r.sh = live ? col - cc : 4;                  // 0..3 inside the row, >= 4: nothing of the window exists
+    return r;
+}
+__device__ __forceinline__ f4 load4_window(const Raw4& r) {
+    const f4 raw = r.raw;
+    const int sh = r.sh;
+    f4 v;
+    v[0] = sh == 0 ? raw[0] : (sh == 1 ? raw[1] : (sh == 2 ? raw[2] : (sh == 3 ? raw[3] : 0.f)));
+    v[1] = sh == 0 ? raw[1] : (sh == 1 ? raw[2] : (sh == 2 ? raw[3] : 0.f));
+    v[2] = sh == 0 ? raw[2] : (sh == 1 ? raw[3] : 0.f);
+    v[3] = sh == 0 ? raw[3] : 0.f;
+    return v;
+}
+__device__ __forceinline__ f4 load4_nb(const float* row, int col, int limit, bool live = true) { return load4_window(load4_raw(row, col, limit, live)); }
+
 constexpr int kWaves = 8;            // ts_gemm: rows per workgroup pass = 16 * kWaves
 #ifndef DGN_GEMM_KC
 #define DGN_GEMM_KC 16     // 32 (half the barriers) measured 5-15 % slower: more registers, one workgroup per CU either way
@@ -64,51 +92,34 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
     // wave sit out the L2 latency in front of every chunk's MFMAs
     constexpr int kC4 = kKC / 4;                                                        // float4's per weight row and chunk
     constexpr int kItems = (NT * 16 * kC4 + kWave * kWaves - 1) / (kWave * kWaves);      // float4's per thread and chunk
-    auto fetch = [&](f4 (&reg)[kItems], int kc) {
+    auto fetch = [&](Raw4 (&reg)[kItems], int kc) {
         const int k0 = kKC * kc;
 #pragma unroll
         for (int j = 0; j < kItems; ++j) {
-            const int it = tid + j * kWave * kWaves;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (it < NT * 16 * kC4) {
-                if (WKN == 0) {
-                    const int r = it / kC4, c4 = (it % kC4) * 4;
-                    if (r < n_here) {
-                        const float* src = p.W + (int64_t)(n0 + r) * p.ldw + k0 + c4;
-                        if (k0 + c4 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (k0 + c4 + e < p.k) v[e] = src[e];
-                        }
-                    }
-                } else {
-                    const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
-                    if (k0 + c < p.k && r4 < n_here) {
-                        const float* src = p.W + (int64_t)(k0 + c) * p.ldw + n0 + r4;
-                        if (r4 + 3 < n_here) v = *reinterpret_cast<const f4u*>(src);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (r4 + e < n_here) v[e] = src[e];
-                        }
-                    }
-                }
+            const int it = min(tid + j * kWave * kWaves, NT * 16 * kC4 - 1);      // (surplus threads repeat the last piece; commit skips them)
+            if (WKN == 0) {
+                const int r = it / kC4, c4 = (it % kC4) * 4;
+                reg[j] = load4_raw(p.W + (int64_t)(n0 + min(r, n_here - 1)) * p.ldw, k0 + c4, p.k, r < n_here);
+            } else {
+                const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
+                reg[j] = load4_raw(p.W + (int64_t)min(k0 + c, p.k - 1) * p.ldw, n0 + r4, p.n, k0 + c < p.k);      // (columns of the next slice land in rows >= n_here: never stored)
             }
-            reg[j] = v;
         }
     };
-    auto commit = [&](const f4 (&reg)[kItems], int buf) {
+    auto commit = [&](const Raw4 (&reg)[kItems], int buf) {
         float* dst = Wc_dyn + buf * kBuf;
 #pragma unroll
         for (int j = 0; j < kItems; ++j) {
             const int it = tid + j * kWave * kWaves;
             if (it < NT * 16 * kC4) {
+                const f4 v = load4_window(reg[j]);
                 if (WKN == 0) {
                     const int r = it / kC4, c4 = (it % kC4) * 4;
-                    *reinterpret_cast<f4*>(dst + r * kKS + c4) = reg[j];
+                    *reinterpret_cast<f4*>(dst + r * kKS + c4) = v;
                 } else {
                     const int c = it / (NT * 4), r4 = (it - c * (NT * 4)) * 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[(r4 + e) * kKS + c] = reg[j][e];
+                    for (int e = 0; e < 4; ++e) dst[(r4 + e) * kKS + c] = v[e];
                 }
             }
         }
@@ -116,20 +127,18 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
     // this lane's four A values of chunk kc: A[row][16 kc + 4 g .. + 3]
     constexpr int SB = kKC / 16;                                // 16-column sub-blocks (one MFMA k-group each) per chunk
     struct AChunk { f4 v[SB]; };
+    struct ARaw { Raw4 r[SB]; };
     auto load_a = [&](const float* arow, int kc) {
-        AChunk a;
+        ARaw a;
 #pragma unroll
-        for (int sb = 0; sb < SB; ++sb) {
-            const int k0 = kKC * kc + 16 * sb + 4 * g;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(arow + k0);
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (k0 + j < p.k) v[j] = arow[k0 + j];
-            }
-            a.v[sb] = v;
-        }
+        for (int sb = 0; sb < SB; ++sb) a.r[sb] = load4_raw(arow, kKC * kc + 16 * sb + 4 * g, p.k);
         return a;
+    };
+    auto window_a = [&](const ARaw& a) {
+        AChunk x;
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) x.v[sb] = load4_window(a.r[sb]);
+        return x;
     };
 
     for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -145,13 +154,13 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
             }
         }
         __syncthreads();                                       // (the previous row block is done with both buffers)
-        f4 wreg[kItems];
+        Raw4 wreg[kItems];
         fetch(wreg, 0);
         commit(wreg, 0);
-        AChunk xv = load_a(arow, 0);
+        AChunk xv = window_a(load_a(arow, 0));
         __syncthreads();
         for (int kc = 0; kc < KB; ++kc) {
-            AChunk xn = xv;
+            ARaw xn = ARaw{};
             if (kc + 1 < KB) { if (DGN_GEMM_ABL != 1 && DGN_GEMM_ABL != 4) xn = load_a(arow, kc + 1); if (DGN_GEMM_ABL != 2 && DGN_GEMM_ABL != 4) fetch(wreg, kc + 1); }              // next chunk's A and W in flight during the MFMAs
 #pragma unroll
             for (int sb = 0; sb < SB; ++sb) {
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
                         if (q0 + j < NT) acc[q0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][s], xv.v[sb][s], acc[q0 + j], 0, 0, 0);
             }
             }
-            xv = xn;
+            if (kc + 1 < KB) xv = window_a(xn);
             if (kc + 1 < KB && DGN_GEMM_ABL != 2 && DGN_GEMM_ABL != 4) commit(wreg, (kc + 1) & 1);
             if (DGN_GEMM_ABL != 3) __syncthreads();            // chunk kc+1 is staged; everyone is done reading chunk kc
         }
@@ -209,34 +218,25 @@ __global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
     // this thread's 16-byte pieces of the operand chunks: A rows lr + 64 j (j < 4), W rows lr + 64 j (j < 2), k offset c4
     const int lr = tid >> 2, c4 = (tid & 3) * 4;
     constexpr int NBJ = (NQ * 16 + 63) / 64;
-    auto load16 = [&](const float* src, int k0) {
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (k0 + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (k0 + e < p.k) v[e] = src[e];
-        }
-        return v;
-    };
-    auto fetch = [&](f4 (&ra)[4], f4 (&rb)[NBJ], int kc) {
+    auto fetch = [&](Raw4 (&ra)[4], Raw4 (&rb)[NBJ], int kc) {
         const int k0 = 16 * kc + c4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t r = row0 + lr + 64 * j;
-            ra[j] = r < p.M ? load16(p.A + r * p.lda + k0, k0) : f4{0.f, 0.f, 0.f, 0.f};
+            ra[j] = load4_raw(p.A + min(r, p.M - 1) * p.lda, k0, p.k, r < p.M);
         }
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
             const int rl = lr + 64 * j, c = n0 + rl;
-            rb[j] = (rl < NQ * 16 && c < p.n) ? load16(p.W + (int64_t)c * p.ldw + k0, k0) : f4{0.f, 0.f, 0.f, 0.f};
+            rb[j] = load4_raw(p.W + (int64_t)min(c, p.n - 1) * p.ldw, k0, p.k, rl < NQ * 16 && c < p.n);
         }
     };
-    auto commit = [&](const f4 (&ra)[4], const f4 (&rb)[NBJ], int buf) {
+    auto commit = [&](const Raw4 (&ra)[4], const Raw4 (&rb)[NBJ], int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[buf][(lr + 64 * j) * kTKS + c4]) = ra[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[buf][(lr + 64 * j) * kTKS + c4]) = load4_window(ra[j]);
 #pragma unroll
         for (int j = 0; j < NBJ; ++j)
-            if (lr + 64 * j < NQ * 16) *reinterpret_cast<f4*>(&Bs[buf][(lr + 64 * j) * kTKS + c4]) = rb[j];
+            if (lr + 64 * j < NQ * 16) *reinterpret_cast<f4*>(&Bs[buf][(lr + 64 * j) * kTKS + c4]) = load4_window(rb[j]);
     };
     f4 acc[4][NQ];
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
             for (int rt = 0; rt < 4; ++rt) acc[rt][q][r] = b;
         }
     }
-    f4 ra[4], rb[NBJ];
+    Raw4 ra[4], rb[NBJ];
     fetch(ra, rb, 0);
     commit(ra, rb, 0);
     __syncthreads();
@@ -318,48 +318,26 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
     // current strip's MFMAs, committed to the other LDS buffer after them (see ts_gemm)
     constexpr int kMaxItems = (16 * (kWgWaves * 4 + KT * 4) + kWave * kWgWaves - 1) / (kWave * kWgWaves);
     const int gq = NTn * 4, xq = KT * 4;                         // float4's per staged row
-    auto fetch = [&](f4 (&reg)[kMaxItems], int64_t strip) {
+    auto fetch = [&](Raw4 (&reg)[kMaxItems], int64_t strip) {
         const int64_t r0 = strip * 16;
 #pragma unroll
         for (int j = 0; j < kMaxItems; ++j) {
-            const int it = tid + j * kWave * kWgWaves;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (it < 16 * (gq + xq)) {
-                const int r = it / (gq + xq), c = it - r * (gq + xq);
-                const int64_t row = r0 + r;
-                if (c < gq) {
-                    const int col = 4 * c;
-                    if (row < p.M && col < p.n) {
-                        const float* src = p.G + row * p.ldg + col;
-                        if (col + 3 < p.n) v = *reinterpret_cast<const f4u*>(src);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (col + e < p.n) v[e] = src[e];
-                        }
-                    }
-                } else {
-                    const int col = 4 * (c - gq);
-                    if (row < p.M && col < k_here) {
-                        const float* src = p.X + row * p.ldx + k0 + col;
-                        if (col + 3 < k_here) v = *reinterpret_cast<const f4u*>(src);
-                        else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) if (col + e < k_here) v[e] = src[e];
-                        }
-                    }
-                }
-            }
-            reg[j] = v;
+            const int it = min(tid + j * kWave * kWgWaves, 16 * (gq + xq) - 1);      // (surplus threads repeat the last piece; commit skips them)
+            const int r = it / (gq + xq), c = it - r * (gq + xq);
+            const int64_t row = min(r0 + r, p.M - 1);
+            const bool is_g = c < gq;
+            reg[j] = load4_raw(is_g ? p.G + row * p.ldg : p.X + row * p.ldx, is_g ? 4 * c : k0 + 4 * (c - gq), is_g ? p.n : p.k, r0 + r < p.M);
         }
     };
-    auto commit = [&](const f4 (&reg)[kMaxItems], int buf) {
+    auto commit = [&](const Raw4 (&reg)[kMaxItems], int buf) {
 #pragma unroll
         for (int j = 0; j < kMaxItems; ++j) {
             const int it = tid + j * kWave * kWgWaves;
             if (it < 16 * (gq + xq)) {
                 const int r = it / (gq + xq), c = it - r * (gq + xq);
-                if (c < gq) *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + 4 * c) = reg[j];
-                else *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + 4 * (c - gq)) = reg[j];
+                const f4 v = load4_window(reg[j]);
+                if (c < gq) *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + 4 * c) = v;
+                else *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + 4 * (c - gq)) = v;
             }
         }
     };
@@ -369,7 +347,7 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
     const bool has_tile = wave < NTn;
     int64_t strip = blockIdx.x;
     int buf = 0;
-    f4 sreg[kMaxItems];
+    Raw4 sreg[kMaxItems];
     if (strip < n_strips) {
         fetch(sreg, strip);
         commit(sreg, 0);
@@ -451,50 +429,35 @@ struct TwBlock {
 };
 
 // a 16-row strip of G's and X's column blocks, zero beyond the matrices, column k of X := 1 (the bias gradient's ones column)
-__device__ __forceinline__ void tw_fetch(f4 (&reg)[kTwItems], const TileWgParams& p, const TwBlock& B, int64_t strip, int tid) {
+__device__ __forceinline__ void tw_fetch(Raw4 (&reg)[kTwItems], const TileWgParams& p, const TwBlock& B, int64_t strip, int tid) {
     const int64_t r0 = strip * kTwRows;
 #pragma unroll
     for (int j = 0; j < kTwItems; ++j) {
-        const int it = tid + j * kWave * kTwWaves;
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (it < B.total) {
-            const int r = it / B.per_row, c = it - r * B.per_row;
-            const int64_t row = r0 + r;
-            if (row < p.M) {
-                if (c < B.gq) {
-                    const int col = 4 * c;
-                    const float* src = p.G + row * p.ldg + B.n0 + col;
-                    if (col + 3 < B.n_here) v = *reinterpret_cast<const f4u*>(src);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (col + e < B.n_here) v[e] = src[e];
-                    }
-                } else {
-                    const int gcol = B.k0 + 4 * (c - B.gq);
-                    const float* src = p.X + row * p.ldx + gcol;
-                    if (gcol + 3 < p.k) v = *reinterpret_cast<const f4u*>(src);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (gcol + e < p.k) v[e] = src[e];
-                            else if (gcol + e == p.k && p.kk > p.k) v[e] = 1.f;
-                        }
-                    }
-                }
-            }
-        }
-        reg[j] = v;
+        const int it = min(tid + j * kWave * kTwWaves, B.total - 1);          // (surplus threads repeat the last piece; commit skips them)
+        const int r = it / B.per_row, c = it - r * B.per_row;
+        const int64_t row = min(r0 + r, p.M - 1);
+        const bool is_g = c < B.gq;
+        // (absolute columns against the whole row's width: always >= 4 columns to clamp into; X: its real columns, the ones column is set at commit)
+        reg[j] = load4_raw(is_g ? p.G + row * p.ldg : p.X + row * p.ldx, (is_g ? B.n0 : B.k0) + 4 * (is_g ? c : c - B.gq), is_g ? p.n : p.k, r0 + r < p.M);
     }
 }
-__device__ __forceinline__ void tw_commit(const f4 (&reg)[kTwItems], float* Gb, const TwBlock& B, int tid) {
+__device__ __forceinline__ void tw_commit(const Raw4 (&reg)[kTwItems], float* Gb, const TileWgParams& p, const TwBlock& B, int64_t strip, int tid) {
     float* Xb = Gb + kTwRows * B.gs;
 #pragma unroll
     for (int j = 0; j < kTwItems; ++j) {
         const int it = tid + j * kWave * kTwWaves;
         if (it < B.total) {
             const int r = it / B.per_row, c = it - r * B.per_row;
-            if (c < B.gq) *reinterpret_cast<f4*>(Gb + r * B.gs + 4 * c) = reg[j];
-            else *reinterpret_cast<f4*>(Xb + r * B.xs + 4 * (c - B.gq)) = reg[j];
+            f4 v = load4_window(reg[j]);
+            if (c < B.gq) *reinterpret_cast<f4*>(Gb + r * B.gs + 4 * c) = v;
+            else {
+                const int gcol = B.k0 + 4 * (c - B.gq);
+                if (p.kk > p.k && strip * kTwRows + r < p.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gcol + e == p.k ? 1.f : v[e];        // column k of X := 1 on the rows that exist
+                }
+                *reinterpret_cast<f4*>(Xb + r * B.xs + 4 * (c - B.gq)) = v;
+            }
         }
     }
 }
@@ -513,10 +476,10 @@ __device__ __forceinline__ void tw_run(const TileWgParams& p, const TwBlock& B, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int64_t n_strips = (p.M + kTwRows - 1) / kTwRows;
-    f4 sreg[kTwItems];
+    Raw4 sreg[kTwItems];
     if ((int64_t)blockIdx.x < n_strips) {
         tw_fetch(sreg, p, B, blockIdx.x, tid);
-        tw_commit(sreg, lds, B, tid);
+        tw_commit(sreg, lds, p, B, blockIdx.x, tid);
     }
     __syncthreads();
     int buf = 0;
@@ -539,7 +502,7 @@ __device__ __forceinline__ void tw_run(const TileWgParams& p, const TwBlock& B, 
 #pragma unroll
                 for (int b = 0; b < KTc; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[a], xv[b], acc[a][b], 0, 0, 0);
         }
-        if (more) tw_commit(sreg, lds + (buf ^ 1) * B.half, B, tid);
+        if (more) tw_commit(sreg, lds + (buf ^ 1) * B.half, p, B, strip + gridDim.x, tid);
         __syncthreads();
     }
     // lane holds D[32 a + (r & 3) + 8 (r >> 2) + 4 hi][32 b + i32] of its tiles: the workgroup's partial block goes to its slot

@@ -30,6 +30,10 @@ constexpr int kMaxWgradTiles = 45;  // accumulator tiles (4 registers each) one 
 
 __host__ __device__ inline int lds_stride(int k) { return ((k + 15) / 16) * 16 + 4; }   // == 4 mod 8: spreads rows over banks
 
+// The per-row factors of a strip (scale table / graph norm) travel with the strip's prefetch as RAW loaded values: replacing an absent
+// factor by 1 (`p.sc ? f : 1.f`) is done where the factors are consumed, one iteration later.  Anything that consumes a just-issued
+// load makes the wave wait, at that point, for every load issued before it -- the next strip's prefetch included (loads retire in
+// order) -- i.e. the prefetch became a synchronous round trip in front of the strip's MFMAs (seen in the ISA of the round-2 kernels).
 struct ExpandSrc {
     const float* gy; int64_t sT;                     // [T][M][fo] dense rows, sT between towers
     const float* sc;                                 // [M][S] or null
@@ -111,15 +115,14 @@ __device__ __forceinline__ void load_expand(float2 (&pre)[NL], f4& fac, const Ex
 #pragma unroll
     for (int j = 0; j < (NL + 1) / 2; ++j) pre[j] = base[min(j * 64 + lane, last)];     // S >= 2: the run is at most half the expanded width
     const int64_t row = min(row0 + (lane & 15), M - 1);
-    const float* scp = e.sc ? e.sc + row * e.S : e.gy;       // (branch-free: see ts_linear)
-    const float f0 = scp[0], f1 = scp[min(1, e.S - 1)], f2 = scp[min(2, e.S - 1)];
-    fac = f4{e.sc ? f0 : 1.f, e.sc ? f1 : 1.f, e.sc ? f2 : 1.f, 0.f};
+    const float* scp = e.sc ? e.sc + row * e.S : e.gy;       // (branch-free; without a table the values are dummies: store_expand puts 1)
+    fac = f4{scp[0], scp[min(1, e.S - 1)], scp[min(2, e.S - 1)], 0.f};
 }
 // Xl: [16][S*fo]; Fl: 16 x f4 scratch of this wave.  Rows >= rows_valid become zero.
 template <int NL>
 __device__ __forceinline__ void store_expand(float* Xl, float* Fl, const float2 (&pre)[NL], const f4& fac, const ExpandSrc& e,
                                              int rows_valid, int lane) {
-    if (lane < 16) *reinterpret_cast<f4*>(Fl + 4 * lane) = fac;
+    if (lane < 16) *reinterpret_cast<f4*>(Fl + 4 * lane) = e.sc ? fac : f4{1.f, 1.f, 1.f, 0.f};
     const int fo2 = e.fo >> 1, width = e.S * e.fo;
 #pragma unroll
     for (int j = 0; j < (NL + 1) / 2; ++j) {
@@ -214,10 +217,9 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     auto load_fac = [&](int64_t strip) {
         if constexpr (!COMBINE) return;
         const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
-        const float* scp = p.sc ? p.sc + row * S1 : A;
+        const float* scp = p.sc ? p.sc + row * S1 : A;               // (absent factors: dummy loads, replaced by 1 where `fac` is consumed)
         const float* rsp = p.rs ? p.rs + row : A;
-        const float f0 = scp[0], f1 = scp[min(1, S1 - 1)], f2 = scp[min(2, S1 - 1)], f3 = *rsp;
-        fac = f4{p.sc ? f0 : 1.f, p.sc ? f1 : 1.f, p.sc ? f2 : 1.f, p.rs ? f3 : 1.f};
+        fac = f4{scp[0], scp[min(1, S1 - 1)], scp[min(2, S1 - 1)], *rsp};
     };
     float2 prez[ACT ? NL : 1];
     auto fetch = [&](int64_t strip) {
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         else if constexpr (ACT) store_strip_act<NL>(Xl, pre, prez, k, lane, Bn, p.act_kind, p.act_slope,
                                                     p.gz_out ? p.gz_out + strip * kStrip * k : nullptr, (int)min((int64_t)kStrip, p.M - strip * kStrip) * (k >> 1));
         else store_strip<NL>(Xl, pre, k, lane);
-        if (COMBINE && lane < 16) *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = fac;
+        if (COMBINE && lane < 16)
+            *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = f4{p.sc ? fac[0] : 1.f, p.sc ? fac[1] : 1.f, p.sc ? fac[2] : 1.f, p.rs ? fac[3] : 1.f};
         if (out_strip >= 0) store_out();
         load_adds(strip);
         if (strip + step < n_strips) fetch(strip + step);

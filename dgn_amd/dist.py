@@ -33,7 +33,14 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     force = os.environ.get("DGN_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU (tests)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: start the ranks with a launcher (torch.distributed.run) "
+                                   "or export MASTER_ADDR / MASTER_PORT")
+            import socket                      # a forced single-rank group (tests): any free port, never a fixed one that may be taken
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -144,6 +151,17 @@ class FlatGradAllReduce:
             if p.grad is None:
                 p.grad = g
         torch._foreach_copy_(grads, self.views)
+
+
+def gather_rank_stats(values: Sequence[float], device) -> List[List[float]]:
+    """Every rank's list of numbers on every rank (one all-gather of a small fp64 tensor): per-rank shard sizes and collective
+    timings for bench.py's line.  Without a process group: this rank's values alone."""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return [t.tolist()]
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [q.tolist() for q in parts]
 
 
 def barrier_max_ms(ms: float, device) -> float:

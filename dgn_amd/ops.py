@@ -715,8 +715,8 @@ WIDE_MIN_ROWS = int(os.environ.get("DGN_WIDE_MIN_ROWS", "4096"))
 
 def wide_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return bool(x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and weight.dim() == 2
-                and x.shape[0] >= WIDE_MIN_ROWS and weight.shape[0] <= 4096 and os.environ.get("DGN_LIBRARY_GEMM") != "1"
-                and x.shape[1] <= 4096)
+                and x.shape[0] >= WIDE_MIN_ROWS and 4 <= weight.shape[0] <= 4096 and os.environ.get("DGN_LIBRARY_GEMM") != "1"
+                and 4 <= x.shape[1] <= 4096)
 
 
 def wide_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:

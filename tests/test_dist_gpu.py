@@ -96,3 +96,87 @@ def test_bench_refuses_more_ranks_than_devices():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+_SHARDED_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["DGN_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import dgn_amd
+from dgn_amd import dist as ddist, synth
+from dgn_amd.ops import directional_aggregate
+from oracle import dgn_oracle as orc
+rank, world, local = ddist.init_from_env("nccl")
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+dev = torch.device("cuda", local)
+N, F_ = 1500, 16
+indptr, src, eig = synth.powerlaw_csr(num_nodes=N, num_edges=24000, device=dev, seed=5)
+E = int(indptr[-1])
+aggs, scalers = "mean max min sum std dir1-dx dir2-dx dir3-dx".split(), "identity amplification attenuation".split()     # C5's list
+plan = dgn_amd.make_plan(aggs, scalers)
+deg = (indptr[1:] - indptr[:-1])
+avg = float(torch.log(deg.float() + 1).mean())
+gen = torch.Generator(device=dev).manual_seed(1)
+X0 = torch.randn(N, F_, device=dev, generator=gen)
+W1 = torch.randn(F_, plan.out_width(F_), device=dev, generator=gen) / plan.out_width(F_) ** 0.5
+W2 = torch.randn(F_, plan.out_width(F_), device=dev, generator=gen) / plan.out_width(F_) ** 0.5
+ct = torch.randn(N, F_, device=dev, generator=gen)
+ranges = ddist.row_ranges_by_edges(indptr, 3)            # three destination-range shards, run one after the other by this one rank
+shards = [ddist.shard_rows(indptr, src, r0, r1, hub_threshold=256, hub_chunk=64) for r0, r1 in ranges]
+assert any(s.n_hub > 0 for s in shards)
+
+def sharded_layer(H, W):
+    # every shard: the sweep over its destination rows (features replicated), the F-wide post-transformation on its rows; the rows
+    # then travel through the RCCL all-gather (world 1: one range) exactly as between two sharded layers of a net
+    parts = []
+    for (r0, r1), sh in zip(ranges, shards):
+        y = directional_aggregate(sh, plan, avg, x_src=H, x_in=H[r0:r1], eig=eig)
+        parts.append(torch.tanh(y @ W.t()))
+    own = torch.cat(parts)
+    return ddist.all_gather_rows(own, [(0, N)])
+
+X = X0.clone().requires_grad_(True)
+out = sharded_layer(sharded_layer(X, W1), W2)
+(gX,) = torch.autograd.grad(out, X, ct)
+torch.cuda.synchronize()
+
+# the oracle: the same two layers on the WHOLE graph, CPU, fp32 and fp64
+dst = torch.repeat_interleave(torch.arange(N, device=dev), deg).cpu()
+srcc = src.long().cpu()
+res = {}
+for dt in (torch.float32, torch.float64):
+    Xo = X0.cpu().to(dt).requires_grad_(True)
+    H = Xo
+    for W in (W1, W2):
+        y = orc.aggregate_graph(srcc, dst, N, H[srcc], eig.cpu().to(dt), H, aggs, scalers, torch.tensor(avg, dtype=dt))
+        H = torch.tanh(y @ W.cpu().to(dt).t())
+    res[dt] = (H.detach(), torch.autograd.grad(H, Xo, ct.cpu().to(dt))[0])
+rows = torch.unique(torch.cat([torch.randint(0, N, (200,)), torch.tensor([0, N - 1]), torch.tensor([r for rr in ranges for r in (rr[0], max(rr[1] - 1, 0))]),
+                               torch.argsort(deg.cpu())[-5:]]))
+def worst(ours, r32, r64):
+    ours, r32, r64 = ours.cpu().double(), r32.double(), r64.double()
+    scale = max(1.0, float(r64.abs().max()))
+    tol = 1e-5 * scale + 1e-4 * r64.abs()
+    ok = ((ours - r32).abs() <= tol) | ((ours - r64).abs() <= tol + 4 * float((r32 - r64).abs().max()))
+    return int((~ok).sum()), float((ours - r64).abs().max()) / scale
+bad_y, err_y = worst(out.detach()[rows.to(dev)], res[torch.float32][0][rows], res[torch.float64][0][rows])
+bad_g, err_g = worst(gX, res[torch.float32][1], res[torch.float64][1])
+print("RESULT " + json.dumps(dict(bad_y=bad_y, err_y=err_y, bad_g=bad_g, err_g=err_g, n_rows=int(rows.numel()), hubs=sum(s.n_hub for s in shards))))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_row_sharded_two_layer_path_vs_oracle_through_rccl():
+    """f4 (one giant graph cut into destination-range shards) against the ORACLE, not against the unsharded kernels: a two-layer
+    stack over a power-law graph -- three row shards with hub rows, features replicated, the layer outputs exchanged through
+    dist.all_gather_rows on a real RCCL process group (DGN_FORCE_DIST=1, world 1) -- forward on sampled rows (incl. the shard
+    boundaries and the heaviest hubs) and the full input gradient against the oracle's whole-graph evaluation."""
+    env = dict(os.environ, DGN_ROOT=ROOT, DGN_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _SHARDED_SCRIPT], env=env, capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["bad_y"] == 0 and res["bad_g"] == 0 and res["hubs"] > 0, res
+    assert res["err_y"] < 1e-3 and res["err_g"] < 1e-3, res
