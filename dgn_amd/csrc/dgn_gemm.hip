@@ -97,9 +97,9 @@ TwPlan tile_wgrad_plan(int64_t M, int kk, int n) {
     return t;
 }
 
-bool use_tile_wgrad(int64_t n_rows) {
+bool use_tile_wgrad(int n) {
     const char* env = getenv("DGN_TILE_WGRAD");              // (read per call: the tests switch it)
-    return env ? atoi(env) != 0 : n_rows >= 4096;
+    return env ? atoi(env) != 0 : n > 16 * kWgWaves;
 }
 
 }  // namespace
@@ -158,7 +158,7 @@ extern "C" size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int3
     const TwPlan t = tile_wgrad_plan(n_rows, k + 1, n);
     size_t bytes = (size_t)t.n_blocks * t.k_blocks * t.slots * (t.nb_tiles * 32) * (t.kb_tiles * 32) * sizeof(float);
     if (n <= 16 * kWgWaves) {
-        const WgPlan w = wgrad_plan(n_rows, k, n);
+        const WgPlan w = wgrad_plan(n_rows, k + 1, n);
         bytes = std::max(bytes, (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float));
     }
     return bytes;
@@ -177,9 +177,10 @@ extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float*
     if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     const size_t need = dgn_gemm_wgrad_workspace_bytes(n_rows, k, n);
     if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
-    // the tile kernel (32 x 32 x 2 MFMA, whole accumulator blocks per workgroup, bias gradient as a ones column) wherever there are
-    // rows enough to fill the CUs, and always for n > 256 or with a bias gradient; the strip kernel on small batches
-    if (use_tile_wgrad(n_rows) || n > 16 * kWgWaves || dbias) {
+    // n <= 256: the strip kernel (16 waves, one n tile each; measured 75-80 TFLOP/s on the posttrans shapes, where the tile kernel's
+    // 2 x 4 wave grid of 32 x 32 tiles leaves SIMDs unevenly loaded: 0.347 vs 0.259 ms at n = 225, k = 152).  Wider outputs: the tile
+    // kernel (v_mfma_f32_32x32x2_f32, whole accumulator blocks per workgroup).  Both carry the bias gradient as a column of ones.
+    if (use_tile_wgrad(n) || n > 16 * kWgWaves) {
         TileWgParams p{};
         p.M = n_rows; p.n = n; p.k = k; p.kk = dbias ? k + 1 : k;
         p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
@@ -197,14 +198,15 @@ extern "C" int dgn_gemm_wgrad(int64_t n_rows, int32_t k, int32_t n, const float*
         DGN_HIP_CHECK(hipGetLastError());
         return DGN_OK;
     }
-    const WgPlan w = wgrad_plan(n_rows, k, n);
+    const int kk = dbias ? k + 1 : k;
+    const WgPlan w = wgrad_plan(n_rows, kk, n);
     WgradParams p{};
-    p.M = n_rows; p.n = n; p.k = k; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
+    p.M = n_rows; p.n = n; p.k = k; p.kk = kk; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx; p.part = static_cast<float*>(ws);
     p.k_slice = w.k_slice; p.slots = w.slots;
     DGN_HIP_CHECK(launch_wgrad(w.kt, p, dim3(w.slots, w.k_slices), w.lds, st));
-    const int64_t total = (int64_t)n * k;
-    hipLaunchKernelGGL(ts_gemm_wgrad_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, k, w.k_slice, w.slots, w.nt * 16,
-                       w.kt * 16, p.part, dw, lddw);
+    const int64_t total = (int64_t)n * kk;
+    hipLaunchKernelGGL(ts_gemm_wgrad_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, k, kk, w.k_slice, w.slots, w.nt * 16,
+                       w.kt * 16, p.part, dw, lddw, dbias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

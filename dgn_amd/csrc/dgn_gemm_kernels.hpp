@@ -295,7 +295,7 @@ constexpr int kMaxKT = 16;           // k-tiles one wave accumulates (64 registe
 
 struct WgradParams {
     int64_t M;
-    int n, k;                        // n <= 16 * kWgWaves
+    int n, k, kk;                    // n <= 16 * kWgWaves; kk = k + 1: column k of X := 1 (the bias gradient rides along), else kk = k
     const float* G; int64_t ldg;     // [M, n]
     const float* X; int64_t ldx;     // [M, k]
     float* part;                     // [k-slices][slots][NT*16][KT*16] per-workgroup partials
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
     extern __shared__ float lds_g[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int NTn = (p.n + 15) >> 4;
-    const int k0 = blockIdx.y * p.k_slice, k_here = min(KT * 16, p.k - k0);
+    const int k0 = blockIdx.y * p.k_slice, k_here = min(KT * 16, p.kk - k0);
     const int gs = NTn * 16 + 4, xs = KT * 16 + 4;              // LDS row strides (== 4 mod 8... spreads the rows over the banks)
     const int half = 16 * (gs + xs);                              // floats of one (G strip, X strip) buffer
     auto Gbuf = [&](int b) { return lds_g + b * half; };         // (pointer arithmetic, not a pointer table: a dynamically indexed
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
             const int64_t row = min(r0 + r, p.M - 1);
             const bool is_g = c < gq;
             reg[j] = load4_raw(is_g ? p.G + row * p.ldg : p.X + row * p.ldx, is_g ? 4 * c : k0 + 4 * (c - gq), is_g ? p.n : p.k, r0 + r < p.M);
+            if (r0 + r >= p.M) reg[j].sh = 8;                              // (a row past the matrix: zeros, and no ones column either)
         }
     };
     auto commit = [&](const Raw4 (&reg)[kMaxItems], int buf) {
@@ -335,9 +336,15 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
             const int it = tid + j * kWave * kWgWaves;
             if (it < 16 * (gq + xq)) {
                 const int r = it / (gq + xq), c = it - r * (gq + xq);
-                const f4 v = load4_window(reg[j]);
+                f4 v = load4_window(reg[j]);
                 if (c < gq) *reinterpret_cast<f4*>(Gbuf(buf) + r * gs + 4 * c) = v;
-                else *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + 4 * (c - gq)) = v;
+                else {
+                    if (p.kk > p.k && reg[j].sh < 8) {                  // (sh >= 8 marks a row past the matrix, see fetch)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = k0 + 4 * (c - gq) + e == p.k ? 1.f : v[e];      // column k of X := 1
+                    }
+                    *reinterpret_cast<f4*>(Xbuf(buf) + r * xs + 4 * (c - gq)) = v;
+                }
             }
         }
     };
@@ -380,11 +387,12 @@ __global__ __launch_bounds__(kWave * kWgWaves) void ts_gemm_wgrad(const WgradPar
 }
 
 // dW[n][k] = sum over the workgroup slots, in slot order (bitwise reproducible); thread per element, 4 slots in flight
-static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int k, int k_slice, int slots, int npad, int kpad,
-                                                                      const float* __restrict__ part, float* __restrict__ dW, int64_t lddw) {
+static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int k, int kk, int k_slice, int slots, int npad, int kpad,
+                                                                      const float* __restrict__ part, float* __restrict__ dW, int64_t lddw,
+                                                                      float* __restrict__ dbias) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (int64_t)n * k) return;
-    const int r = (int)(e / k), c = (int)(e - (int64_t)r * k);
+    if (e >= (int64_t)n * kk) return;
+    const int r = (int)(e / kk), c = (int)(e - (int64_t)r * kk);
     const int sl = c / k_slice, cc = c - sl * k_slice;
     const float* src = part + (int64_t)sl * slots * npad * kpad + (int64_t)r * kpad + cc;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -396,7 +404,9 @@ static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int 
         s3 += src[(int64_t)(q + 3) * npad * kpad];
     }
     for (; q < slots; ++q) s0 += src[(int64_t)q * npad * kpad];
-    dW[(int64_t)r * lddw + c] = (s0 + s1) + (s2 + s3);
+    const float v = (s0 + s1) + (s2 + s3);
+    if (c < k) dW[(int64_t)r * lddw + c] = v;
+    else if (dbias) dbias[r] = v;
 }
 
 // ---- tile weight gradient (32 x 32 x 2 MFMA, the whole [n-block, k-block] accumulator in one workgroup's registers) -----------------

@@ -150,7 +150,7 @@ def test_wide_gemm_vs_fp64(monkeypatch, M, k, n, tile):
     nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
     assert nb > 0
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    for tw, with_bias in (("1", True), ("1", False), ("0", False)):
+    for tw, with_bias in (("1", True), ("1", False), ("0", False), ("0", True)):
         if tw == "0" and n > 256:
             continue
         monkeypatch.setenv("DGN_TILE_WGRAD", tw)
