@@ -30,6 +30,8 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
+           "dgn_dense_layer_supported", "dgn_dense_layer_forward_workspace_bytes", "dgn_dense_layer_forward", "dgn_dense_layer_backward_workspace_bytes",
+           "dgn_dense_layer_backward",
            "dgn_linear_bd_supported", "dgn_linear_bd_forward", "dgn_linear_bd_backward_input", "dgn_linear_bd_wgrad_workspace_bytes", "dgn_linear_bd_wgrad")
 
 
@@ -83,6 +85,23 @@ class DgnTowersLayer(C.Structure):
 class DgnTowersGrads(C.Structure):
     _fields_ = [("g_out", C.c_void_p), ("g_h", C.c_void_p), ("g_w_sd", C.c_void_p), ("g_bias_sd", C.c_void_p), ("g_w_post", C.c_void_p),
                 ("g_b_post", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p), ("g_w_mix", C.c_void_p), ("g_b_mix", C.c_void_p)]
+
+
+class DgnDenseLayer(C.Structure):
+    _fields_ = [("graph", C.POINTER(DgnGraph)), ("spec", C.POINTER(DgnAggSpec)), ("w", C.c_void_p), ("ld_w", C.c_int64), ("log_deg", C.c_void_p),
+                ("type", C.c_int32), ("f_in", C.c_int32), ("f_out", C.c_int32), ("n_scalers", C.c_int32), ("n_agg", C.c_int32), ("id_slot", C.c_int32),
+                ("residual", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float),
+                ("h", C.c_void_p), ("snorm", C.c_void_p), ("scale", C.c_void_p), ("w_pre", C.c_void_p), ("b_pre", C.c_void_p),
+                ("w_post", C.c_void_p), ("b_post", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("hp", C.c_void_p), ("pq", C.c_void_p), ("agg", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("wsd", C.c_void_p),
+                ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("n_valid", C.c_void_p)]
+
+
+class DgnDenseGrads(C.Structure):
+    _fields_ = [("g_out", C.c_void_p), ("g_h", C.c_void_p), ("g_w_pre", C.c_void_p), ("g_b_pre", C.c_void_p), ("g_w_post", C.c_void_p),
+                ("g_b_post", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p)]
 
 
 class DgnError(RuntimeError):
@@ -181,6 +200,16 @@ def load() -> C.CDLL:
         lib.dgn_linear_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
+        lib.dgn_dense_layer_supported.restype = C.c_int
+        lib.dgn_dense_layer_supported.argtypes = [C.c_int32] * 5
+        lib.dgn_dense_layer_forward_workspace_bytes.restype = C.c_size_t
+        lib.dgn_dense_layer_forward_workspace_bytes.argtypes = [C.POINTER(DgnDenseLayer)]
+        lib.dgn_dense_layer_backward_workspace_bytes.restype = C.c_size_t
+        lib.dgn_dense_layer_backward_workspace_bytes.argtypes = [C.POINTER(DgnDenseLayer)]
+        lib.dgn_dense_layer_forward.restype = C.c_int
+        lib.dgn_dense_layer_forward.argtypes = [C.POINTER(DgnDenseLayer), vp]
+        lib.dgn_dense_layer_backward.restype = C.c_int
+        lib.dgn_dense_layer_backward.argtypes = [C.POINTER(DgnDenseLayer), C.POINTER(DgnDenseGrads), vp]
         lib.dgn_linear_bd_supported.restype = C.c_int
         lib.dgn_linear_bd_supported.argtypes = [C.c_int32, C.c_int32]
         lib.dgn_linear_bd_forward.restype = C.c_int

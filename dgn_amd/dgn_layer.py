@@ -286,7 +286,28 @@ class DGNLayerSimple(nn.Module):
         with _ops.padded_rows(getattr(g, "n_valid", None)):
             return self._forward(g, h, e, snorm_n)
 
+    def _whole_layer(self, g, h, snorm_n):
+        """The layer through dgn_dense_layer_forward / _backward (one C call per direction), or None outside that entry point's domain
+        (training-mode BatchNorm, single-affine posttrans, no dropout, enough rows for this library's own GEMM kernels)."""
+        bn = self.batchnorm_h
+        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and self.dropout == 0 and h.is_cuda
+                and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and self.posttrans.is_single_affine()
+                and bn_tail_supported([bn], h, True, bn.num_features)):
+            return None
+        lin = self.posttrans.fully_connected[0].linear
+        S, A = self.plan.n_scalers, len(self.aggregators)
+        if len(self._kplan.launches) != 1 or not _ops.dense_layer_supported(0, h.shape[1], lin.weight.shape[0], S, A):
+            return None
+        eig = g.ndata["eig"]
+        graph = as_dgn_graph(g, h.device)
+        sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+        return _ops.dense_layer(graph, self._kplan, self._avg_log, graph.edge_weights(self._kplan, eig), h, snorm_n if self.graph_norm else None, sc, bn,
+                                None, None, lin.weight, lin.bias, 0, A, 0, self.residual)
+
     def _forward(self, g, h, e, snorm_n):
+        y = self._whole_layer(g, h, snorm_n)
+        if y is not None:
+            return y
         h_in = h
         F0 = h.shape[1]
         # Odd widths (ZINC simple: 75, CIFAR10: 65) would run the sweep with 4-byte lanes, a second, nearly empty
@@ -364,7 +385,28 @@ class DGNLayerComplex(nn.Module):
         with _ops.padded_rows(getattr(g, "n_valid", None)):
             return self._forward(g, h, e, snorm_n)
 
+    def _whole_layer(self, g, h, snorm_n):
+        """As DGNLayerSimple._whole_layer; additionally: single-affine pretrans, no edge features, identity among the applied scalers."""
+        bn = self.batchnorm_h
+        id_slot = _identity_slot(self.plan.applied_scalers)
+        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and self.dropout == 0 and not self.edge_features
+                and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and id_slot is not None
+                and self.posttrans.is_single_affine() and self.pretrans.is_single_affine() and bn_tail_supported([bn], h, True, bn.num_features)):
+            return None
+        pre, lin = self.pretrans.fully_connected[0].linear, self.posttrans.fully_connected[0].linear
+        S, A = self.plan.n_scalers, len(self.aggregators)
+        if len(self._kplan_x.launches) != 1 or not _ops.dense_layer_supported(1, h.shape[1], lin.weight.shape[0], S, A):
+            return None
+        eig = g.ndata["eig"]
+        graph = as_dgn_graph(g, h.device)
+        sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
+        return _ops.dense_layer(graph, self._kplan_x, self._avg_log, graph.edge_weights(self._kplan_x, eig), h, snorm_n if self.graph_norm else None, sc,
+                                bn, pre.weight, pre.bias, lin.weight, lin.bias, 1, A, id_slot, self.residual)
+
     def _forward(self, g, h, e, snorm_n):
+        y = self._whole_layer(g, h, snorm_n)
+        if y is not None:
+            return y
         h_in = h
         eig = g.ndata["eig"]
         id_slot = _identity_slot(self.plan.applied_scalers)

@@ -1060,6 +1060,122 @@ def towers_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snor
     return out
 
 
+# ---- the whole simple / complex layer as ONE autograd node over two C calls (dgn_layers.hip) ----------------------------------------
+
+_DENSE_OK = {}
+
+
+def dense_layer_supported(type_net: int, f_in: int, f_out: int, n_scalers: int, n_agg: int) -> bool:
+    key = (type_net, f_in, f_out, n_scalers, n_agg)
+    if key not in _DENSE_OK:
+        _DENSE_OK[key] = bool(_lib.load().dgn_dense_layer_supported(*key))
+    return _DENSE_OK[key]
+
+
+def _dense_sizes(cfg, N):
+    type_net, F0, fo, S, A = cfg[:5]
+    Fp = F0 + (F0 & 1)
+    K = (A + (1 if type_net == 1 else 0)) * Fp
+    return [N * Fp if Fp != F0 else 0, N * 2 * Fp if type_net == 1 else 0, N * K, N * fo, 2 * S * fo * K,
+            (4 * Fp * Fp + 2 * Fp) if type_net == 1 else 0, fo, fo], Fp, K
+
+
+def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, n_valid):
+    type_net, F0, fo, S, A, id_slot, residual, momentum, eps = cfg
+    hp, pq, agg, y, wf, wsd, mean, invstd = bufs
+    spec = _spec_structs(plan, 1, avg_log, 0)[0]
+    L = _lib.DgnDenseLayer()
+    cg = graph.c_graph
+    L.graph, L.spec = C.pointer(cg), C.pointer(spec)
+    L.w, L.ld_w, L.log_deg = _ptr(w_edge), (w_edge.stride(0) if w_edge is not None else 0), graph.log_deg.data_ptr()
+    L.type, L.f_in, L.f_out, L.n_scalers, L.n_agg, L.id_slot, L.residual = type_net, F0, fo, S, A, max(id_slot, 0), int(residual)
+    L.momentum, L.eps = float(momentum), float(eps)
+    L.h, L.snorm, L.scale = h.data_ptr(), _ptr(snorm), _ptr(scale)
+    L.w_pre, L.b_pre, L.w_post, L.b_post = _ptr(w_pre), _ptr(b_pre), w_post.data_ptr(), _ptr(b_post)
+    L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
+    q = lambda t: t.data_ptr() if t.numel() else None
+    L.hp, L.pq, L.agg, L.y, L.wf, L.wsd, L.save_mean, L.save_invstd = q(hp), q(pq), q(agg), q(y), q(wf), q(wsd), q(mean), q(invstd)
+    L.n_valid = _ptr(n_valid)
+    return L, (cg, spec)
+
+
+class _DenseLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var, w_pre, b_pre, w_post, b_post, gamma, beta):
+        lib = _lib.load()
+        if not h.is_cuda:
+            raise _lib.DgnError("dense_layer: CUDA tensors only (dgn_amd has no CPU path)")
+        N, fo = h.shape[0], cfg[2]
+        dev = h.device
+        h, w_post, gamma, beta = h.contiguous(), w_post.contiguous(), gamma.contiguous(), beta.contiguous()
+        w_pre = w_pre.contiguous() if w_pre is not None else None
+        sizes, Fp, K = _dense_sizes(cfg, N)
+        saved_buf, bufs = _carve(sizes, dev)
+        out = torch.empty((N, fo), dtype=torch.float32, device=dev)
+        ctx.n_valid = _N_VALID
+        L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
+        L.running_mean, L.running_var, L.out = running_mean.data_ptr(), running_var.data_ptr(), out.data_ptr()
+        nbytes = lib.dgn_dense_layer_forward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_dense_layer_forward(C.byref(L), stream), "dgn_dense_layer_forward")
+        ctx.save_for_backward(w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf)
+        ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf = ctx.saved_tensors
+        cfg, graph = ctx.cfg, ctx.graph
+        type_net, F0, fo = cfg[:3]
+        N, dev = h.shape[0], h.device
+        sizes, Fp, K = _dense_sizes(cfg, N)
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) & ~63
+        bufs = [saved_buf[o:o + n] for o, n in zip(offs, sizes)]
+        g_out = g_out.contiguous()
+        graph.ensure_csc()
+        L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
+        nbytes = lib.dgn_dense_layer_backward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        g_h = torch.empty((N, F0), dtype=torch.float32, device=dev)
+        n_pre = w_pre.numel() if w_pre is not None else 0
+        _, (g_w_pre, g_b_pre, g_w_post, g_b_post, g_gamma, g_beta) = _carve([n_pre, F0 if (type_net == 1 and b_pre is not None) else 0, w_post.numel(), fo, fo, fo], dev)
+        q = lambda t: t.data_ptr() if t.numel() else None
+        G = _lib.DgnDenseGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_w_pre=q(g_w_pre), g_b_pre=q(g_b_pre), g_w_post=g_w_post.data_ptr(),
+                               g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(), g_beta=g_beta.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dgn_dense_layer_backward(C.byref(L), C.byref(G), stream), "dgn_dense_layer_backward")
+        return (None, None, None, None, None, g_h, None, None, None, None,
+                g_w_pre.view_as(w_pre) if w_pre is not None else None, g_b_pre if (b_pre is not None and type_net == 1) else None,
+                g_w_post.view_as(w_post), g_b_post if b_post is not None else None, g_gamma, g_beta)
+
+
+def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm, scale, bn, w_pre, b_pre, w_post, b_post, type_net: int, n_agg: int,
+                id_slot: int, residual: bool) -> torch.Tensor:
+    """``DGNLayerSimple.forward`` / ``DGNLayerComplex.forward`` (nets/dgn_layer.py:178-202, :103-132) of the fused configuration as one
+    autograd node over ``dgn_dense_layer_forward / _backward`` (``include/dgn_hip.h: DgnDenseLayer``): odd hidden sizes are padded, the
+    posttrans weight is folded and its gradient un-folded inside the calls; parameters and their gradients keep the reference's layout.
+    ``plan``: the sweep's list (with the h_in block last for the complex layer), identity scaler.  Training mode; the BatchNorm running
+    statistics and ``num_batches_tracked`` are updated in place."""
+    S = 1 if scale is None else scale.shape[1]
+    if snorm is not None:
+        snorm = snorm.reshape(-1).contiguous()
+    if scale is not None:
+        scale = scale.contiguous()
+    cfg = (int(type_net), h.shape[1], w_post.shape[0], S, int(n_agg), int(id_slot), bool(residual), float(bn.momentum), float(bn.eps))
+    out = _DenseLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, bn.running_mean, bn.running_var, w_pre, b_pre, w_post, b_post,
+                            bn.weight, bn.bias)
+    with torch.no_grad():
+        bn.num_batches_tracked.add_(1)
+    return out
+
+
 # ---- the posttrans product inside the sweep (dgn_fused.hip) ---------------------------------------------------------------------
 
 # True: when no gradient is needed (inference / validation passes) the towers layer runs sweep + posttrans + scale-combine as ONE

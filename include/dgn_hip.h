@@ -468,6 +468,55 @@ typedef struct DgnTowersGrads {
  * launch: out[i] = ((const float*)param_ptrs[map_param[i]])[map_off[i]], or 0 where map_param[i] < 0.  param_ptrs is a DEVICE array of
  * device addresses (int64), the maps are device int32 arrays built once per layer (dgn_amd/dgn_layer.py::_operands).          */
 int dgn_assemble_params(int64_t n_out, const int64_t* param_ptrs, const int32_t* map_param, const int32_t* map_off, float* out, void* stream);
+
+/* ---- the simple / complex layers as ONE call per direction (dgn_layers.hip) --------------------------------------------------
+ * DGNLayerSimple.forward (nets/dgn_layer.py:178-202) and DGNLayerComplex.forward (:103-132) in the fused form of
+ * dgn_amd/dgn_layer.py: single-affine pretrans / posttrans, the degree scalers folded behind the posttrans Linear, training-mode
+ * BatchNorm -> ReLU -> residual, no edge features, no dropout:
+ *     hp   = h with a zero column appended when f_in is odd (hidden 75 / 65 / 45 / 47: 8-byte lanes + two-phase scatter in the sweep)
+ *     pq   = hp [W_s | W_d]^T + [0 | b]                     complex only (pretrans on [h_src || h_dst], decomposed)
+ *     agg  = sweep(hp | pq)  [N, K],  K = (n_agg (+ 1: the h_in block, complex)) * f_pad
+ *     y    = snorm * (b_post + sum_s scale_s * (agg W_f^T)_s)   W_f = the posttrans weight folded scaler-major, zero columns at the padding
+ *     out  = relu(BatchNorm(y)) [+ h]
+ * Parameters keep the REFERENCE's layout (w_post [f_out, (complex: f_in +) S * n_agg * f_in], w_pre [f_in, 2 f_in]); the folds, the
+ * padding and their adjoints are kernels of the call.  hp, pq, agg, y, wf, wsd, save_mean, save_invstd are written by the forward and
+ * read by the backward (caller-owned: the autograd-saved tensors): hp [N, f_pad] (used only when f_in is odd), pq [N, 2 f_pad],
+ * agg [N, K], y [N, f_out], wf [2 * S f_out * K] (W_f and its transpose), wsd [4 f_pad^2 + 2 f_pad] (complex: W_sd, its transpose,
+ * bias_sd).  spec: the sweep's list (aggregators, + DGN_AGG_X_IN last for the complex layer) with ONE identity scaler, one tower.   */
+typedef struct DgnDenseLayer {
+    const DgnGraph* graph;
+    const DgnAggSpec* spec;
+    const float* w;            /* edge weights [n_ch][ld_w] (dgn_edge_weights), or NULL                      */
+    int64_t ld_w;
+    const float* log_deg;
+    int32_t type;              /* 0 = simple, 1 = complex                                                    */
+    int32_t f_in, f_out, n_scalers, n_agg;
+    int32_t id_slot;           /* complex: position of the identity scaler among the applied ones           */
+    int32_t residual;
+    float momentum, eps;
+    const float* h;            /* [N, f_in]                                                                  */
+    const float* snorm;        /* [N] graph-norm factor or NULL                                              */
+    const float* scale;        /* [N, S] degree-scaler table (NULL iff S == 1)                               */
+    const float* w_pre;  const float* b_pre;     /* complex: pretrans Linear (bias may be NULL)              */
+    const float* w_post; const float* b_post;    /* posttrans Linear (bias may be NULL)                      */
+    const float* bn_gamma; const float* bn_beta;
+    float* running_mean; float* running_var;
+    float* hp; float* pq; float* agg; float* y; float* wf; float* wsd; float* save_mean; float* save_invstd;
+    float* out;                /* [N, f_out]  (forward only)                                                 */
+    void* ws; size_t ws_bytes;
+    const int64_t* n_valid;    /* DEVICE scalar or NULL (padded batches, see dgn_bn_tail_forward)            */
+} DgnDenseLayer;
+typedef struct DgnDenseGrads {
+    const float* g_out;        /* [N, f_out]                                                                 */
+    float* g_h;                /* [N, f_in]  (written; includes the residual's share)                        */
+    float* g_w_pre; float* g_b_pre; float* g_w_post; float* g_b_post; float* g_gamma; float* g_beta;   /* written */
+} DgnDenseGrads;
+int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg);
+size_t dgn_dense_layer_forward_workspace_bytes(const DgnDenseLayer* layer);
+int dgn_dense_layer_forward(const DgnDenseLayer* layer, void* stream);
+size_t dgn_dense_layer_backward_workspace_bytes(const DgnDenseLayer* layer);
+int dgn_dense_layer_backward(const DgnDenseLayer* layer, const DgnDenseGrads* grads, void* stream);
+
 int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total);
 size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);

@@ -788,3 +788,61 @@ def test_fused_forward_equals_separate_kernels(monkeypatch, n_graphs, scalers):
         assert bool(taken) == fused
     assert torch.equal(outs[True], outs[False])                     # same arithmetic in the same order: bit-identical
     _close(outs[True], yo, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("type_net,F_,aggs,scalers,graph_norm,residual", [
+    ("simple", 75, "mean dir1-dx-no-abs", "identity amplification attenuation", True, True),          # c1 (odd width: padded inside the call)
+    ("simple", 70, "mean max min dir1-dx dir1-av", "identity", False, True),                            # HIV json: one scaler, no graph norm
+    ("simple", 65, "mean dir1-dx dir2-dx", "identity", True, False),                                    # CIFAR10 json widths
+    ("complex", 45, "mean dir1-dx dir1-av", "identity amplification attenuation", True, True),          # ZINC json
+    ("complex", 20, "mean max std dir1-dx", "attenuation identity", False, True),                       # identity not first
+    ("complex", 8, "mean max", "identity", True, False),                                                # one scaler
+])
+def test_whole_dense_layer_call_equals_per_kernel_route(monkeypatch, type_net, F_, aggs, scalers, graph_norm, residual):
+    """dgn_dense_layer_forward / _backward (the simple / complex layers as one C call per direction: padding, weight folds and their
+    adjoints inside) against the same layer run kernel by kernel through the per-op autograd nodes: output, d h, every parameter
+    gradient (in the reference's layout), BatchNorm running statistics."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    monkeypatch.setattr(dgn_amd.ops, "WIDE_MIN_ROWS", 0)
+    b = synth.molecule_batch(150, seed=11, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    torch.manual_seed(2)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(1.2)}, type_net, residual,
+                             edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, device=dev, generator=gen) / p.shape[1] ** 0.5)
+            else:
+                p.add_(0.1 * torch.randn(p.shape, device=dev, generator=gen))
+    h0 = torch.randn(N, F_, device=dev, generator=gen)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    res = {}
+    for whole in (True, False):
+        monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER", whole)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        used = []
+        orig = dgn_amd.ops.dense_layer
+        monkeypatch.setattr(dgn_amd.ops, "dense_layer", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        monkeypatch.setattr(dgn_amd.ops, "dense_layer", orig)
+        assert bool(used) == whole, "whole-layer entry point " + ("not taken" if whole else "taken")
+        res[whole] = (y.detach(), h.grad, {k: v.grad for k, v in lay.named_parameters()}, {k: v.clone() for k, v in lay.state_dict().items() if "running" in k or "num_batches" in k})
+    (ya, ga, pa, sa), (yb, gb, pb, sb) = res[True], res[False]
+    _close(ya, yb, 2e-6, 2e-6 * float(yb.abs().max()))
+    _close(ga, gb, 1e-5, 1e-5 * float(gb.abs().max()))
+    assert set(pa) == set(pb)
+    for k in pa:
+        assert pa[k] is not None and pb[k] is not None, k
+        _close(pa[k], pb[k], 1e-5, 2e-5 * max(1.0, float(pb[k].abs().max())), msg=k)
+    for k in sa:
+        _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
