@@ -385,14 +385,15 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     w = graph.edge_weights(plan)
     hd = h.detach()
     Fk = F_          # width the kernels are launched with
+    if F_ % 2 and wl["type_net"] in ("simple", "complex"):
+        # the simple and complex layers pad an odd hidden size with one zero column through the whole message path
+        hd = torch.nn.functional.pad(hd, (0, 1))
+        Fk = F_ + 1
     if wl["type_net"] == "simple":
-        if F_ % 2:   # the simple layer pads odd widths with one zero column (dgn_layer.py: DGNLayerSimple.forward)
-            hd = torch.nn.functional.pad(hd, (0, 1))
-            Fk = F_ + 1
         xs, xd = hd, None
     else:
-        pq = torch.randn(N, 2 * F_, device=dev, generator=gen)
-        xs, xd = pq[:, :F_], pq[:, F_:]
+        pq = torch.randn(N, 2 * Fk, device=dev, generator=gen)
+        xs, xd = pq[:, :Fk], pq[:, Fk:]
     if T > 1:    # the towers layer runs the sweep tower-major ([T, N, A*F/T], dgn_layer.py: _fused_towers): time that layout
         out = torch.empty(T, N, plan.out_width(Fk) // T, device=dev)
         g_out = torch.randn(T, N, plan.out_width(Fk) // T, device=dev, generator=gen)
@@ -403,7 +404,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     # with edge features the message has a third, per-edge term R = ef W_e^T [E, F] in slot order (materialised by a streaming
     # Linear): the sweep reads it (+4F per edge, forward and -- with max/min/std -- backward) and the backward writes d R
     # (EdgeTypeFeatures: the term is a [K, F] table + 4 bytes of type per edge; d table = the staged rows summed by type)
-    me = torch.randn(n_types if n_types else E, F_, device=dev, generator=gen) if edge_dim else None
+    me = torch.randn(n_types if n_types else E, Fk, device=dev, generator=gen) if edge_dim else None
     g_me = torch.empty_like(me) if edge_dim else None
     et = graph.to_slot_order(ef.types).to(torch.int32).contiguous() if n_types else None
     fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et)

@@ -843,6 +843,8 @@ def test_whole_dense_layer_call_equals_per_kernel_route(monkeypatch, type_net, F
     assert set(pa) == set(pb)
     for k in pa:
         assert pa[k] is not None and pb[k] is not None, k
-        _close(pa[k], pb[k], 1e-5, 2e-5 * max(1.0, float(pb[k].abs().max())), msg=k)
+        # (the posttrans bias feeds a BatchNorm: its exact gradient is zero, both routes return the rounding noise of a column sum)
+        scale = float(ct.abs().sum(0).max()) if k.endswith("posttrans.fully_connected.0.linear.bias") else max(1.0, float(pb[k].abs().max()))
+        _close(pa[k], pb[k], 1e-5, 2e-5 * scale, msg=k)
     for k in sa:
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
