@@ -24,7 +24,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
-           "dgn_layer_fused_supported", "dgn_layer_fused_forward",
+           "dgn_layer_fused_supported", "dgn_layer_fused_forward", "dgn_layer_fused_backward_supported", "dgn_layer_fused_backward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
            "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
@@ -232,6 +232,12 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_supported.restype = C.c_int
         lib.dgn_layer_fused_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
+        lib.dgn_layer_fused_backward_supported.restype = C.c_int
+        lib.dgn_layer_fused_backward_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
+        lib.dgn_layer_fused_backward.restype = C.c_int
+        lib.dgn_layer_fused_backward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.POINTER(DgnMsgGrad), C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_forward.restype = C.c_int
         lib.dgn_layer_fused_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,

@@ -265,18 +265,20 @@ extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const 
     return launch(vec, p, tiles, static_cast<hipStream_t>(stream_), false);
 }
 
-extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
-                                const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
-                                void* ws, size_t ws_bytes, void* stream_) {
+namespace dgn {
+// Everything dgn_agg_backward does before its launches: validation, the parameter block, the staging buffer of the two-phase scatter,
+// define / accumulate mode of the sinks (zero fills where needed).  Shared with the fused backward (dgn_fused.hip), whose upstream
+// gradient is formed in LDS: `g_out` may then be NULL (`lds_gout`).  *tab_part_out: workspace of the edge-type table's gradient.
+int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                         const float* log_deg, const float* g_out, int64_t ld_gout, bool lds_gout, const DgnMsgGrad* grads, void* ws,
+                         size_t ws_bytes, void* stream_, float** tab_part_out) {
     int rc = validate(g, spec, msg, w, log_deg);
     if (rc) return rc;
     if (!grads) { set_error("null grads"); return DGN_ERR_INVALID; }
-    if (g->n_nodes == 0) return DGN_OK;
     const int64_t width = (int64_t)spec->n_scalers * (spec->agg_total > 0 ? spec->agg_total : spec->n_agg) *
                           (spec->tower_stride > 0 ? msg->F / spec->n_towers : msg->F);
-    if (!g_out || ld_gout < width) { set_error("g_out is null or ld_gout too small"); return DGN_ERR_INVALID; }
+    if (!lds_gout && (!g_out || ld_gout < width)) { set_error("g_out is null or ld_gout too small"); return DGN_ERR_INVALID; }
     if (g->n_hub > 0 && (!ws || ws_bytes < hub_ws_bytes(g, spec, msg->F))) { set_error("workspace too small: need %zu bytes", hub_ws_bytes(g, spec, msg->F)); return DGN_ERR_WORKSPACE; }
-    AggParams p;
     fill_params(p, g, spec, msg, w, ld_w, log_deg);
     if (ld_gout > INT32_MAX || grads->ld_src > INT32_MAX || grads->ld_dst > INT32_MAX || grads->ld_edge > INT32_MAX || grads->ld_in > INT32_MAX) { set_error("strides must fit in int32"); return DGN_ERR_INVALID; }
     p.g_out = g_out; p.ld_gout = (int32_t)ld_gout;
@@ -311,6 +313,20 @@ extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const
         if (p.g_dst && zero(p.g_dst, p.ldg_dst, p.n_nodes)) return DGN_ERR_HIP;
         if (p.g_in && p.g_in != p.g_src && zero(p.g_in, p.ldg_in, p.n_nodes)) return DGN_ERR_HIP;
     }
+    if (tab_part_out) *tab_part_out = tab_part;
+    return DGN_OK;
+}
+}  // namespace dgn
+
+extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                                const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
+                                void* ws, size_t ws_bytes, void* stream_) {
+    if (g && g->n_nodes == 0 && spec && msg && grads) return validate(g, spec, msg, w, log_deg);
+    AggParams p;
+    float* tab_part = nullptr;
+    int rc = agg_backward_prepare(p, g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, false, grads, ws, ws_bytes, stream_, &tab_part);
+    if (rc) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
     rc = launch(vec, p, tiles, stream, true);

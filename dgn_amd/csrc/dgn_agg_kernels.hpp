@@ -1406,20 +1406,13 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 // groups, and launches outside the fast case (dynamic lists, several scalers, accumulate mode, an m_edge term, the atomic scatter)
 // take the per-row routine.
 // EDGE: the message has an edge-TYPE table term (DgnMsg.edge_type): a second tile of (L1-resident) table rows.
-template <class C, class O, int RB, bool EDGE = false>
-__global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
+// The backward of RB consecutive rows [row0, row0 + nrows) by one wave (what a wave of agg_bwd_short does; also the sweep half of the
+// fused backward kernel, layer_bwd_fused, whose p.g_out points at upstream-gradient rows it has just formed in LDS).
+// GLDS: p.g_out points into LDS -- the upstream-gradient blocks are then read where they are used instead of being requested up front
+// (48 registers on the ZINC list: with them the fused kernel's 16-wave workgroups would spill).
+template <class C, class O, int RB, bool EDGE = false, bool GLDS = false>
+__device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, int nrows, int f0, bool active) {
     constexpr int VEC = C::VEC, J = kShortDeg;
-    const int wpb = blockDim.x >> 6;
-    const int64_t n_groups = (p.n_nodes + RB - 1) / RB;
-    const int64_t n_blocks = (n_groups + wpb - 1) / wpb;
-    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
-    if (lb < 0) return;
-    const int64_t g64 = lb * wpb + (threadIdx.x >> 6);
-    if (g64 >= n_groups) return;
-    const int row0 = uniform_i((int)(g64 * RB));
-    const int nrows = (int)min((int64_t)RB, p.n_nodes - row0);
-    const int f0 = (blockIdx.y * kWave + lane_id()) * VEC;
-    const bool active = f0 < p.F;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
     constexpr bool PRE = O::kStatic && NG <= 8;
     bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.g_edge && (EDGE ? (p.m_edge && p.edge_type) : !p.m_edge) &&
@@ -1447,7 +1440,7 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
         const int my_tpos = lane_id() < total ? p.csc_pos[beg0 + lane_id()] : 0;
         if (!active) return;
         // every load of the group, issued before anything is consumed
-        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[RB][NG][VEC], t[RB][J][VEC], t2[EDGE ? RB : 1][EDGE ? J : 1][VEC];
+        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[GLDS ? 1 : RB][GLDS ? 1 : NG][VEC], t[RB][J][VEC], t2[EDGE ? RB : 1][EDGE ? J : 1][VEC];
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int row = row0 + r;
@@ -1456,11 +1449,13 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
             logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
             if (p.x_dst) ldv<VEC>(xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0);
             if (p.need & NEED_XIN) ldv<VEC>(xin[r], p.x_in + (int64_t)row * p.ld_in + f0);
-            const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+            if constexpr (!GLDS) {
+                const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
 #pragma unroll
-            for (int sc = 0; sc < O::kNS; ++sc)
+                for (int sc = 0; sc < O::kNS; ++sc)
 #pragma unroll
-                for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[r][sc * O::NA + a], grow + sa_col(p, sc, a));
+                    for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[r][sc * O::NA + a], grow + sa_col(p, sc, a));
+            }
         }
         if (recomp) {
 #pragma unroll
@@ -1506,11 +1501,15 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
             Coef<C> k;
             float gxin[VEC], rsum[VEC];
             make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int sc, float (&g)[VEC]) {
+                if constexpr (GLDS) {
+                    ldv<VEC>(g, p.g_out + (int64_t)(row0 + r) * p.ld_gout + lane_col(p, f0) + sa_col(p, sc, a));
+                } else {
 #pragma unroll
-                for (int q = 0; q < NG; ++q) {
-                    if (q == sc * O::NA + a) {
+                    for (int q = 0; q < NG; ++q) {
+                        if (q == sc * O::NA + a) {
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) g[i] = gpre[r][q][i];
+                            for (int i = 0; i < VEC; ++i) g[i] = gpre[r][q][i];
+                        }
                     }
                 }
             }, deg[r], xin[r], logd[r]);
@@ -1548,6 +1547,21 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
             add_row_grads<VEC>(p, row0 + r, f0, rsum, gxin, true, true);
         }
     }
+}
+
+template <class C, class O, int RB, bool EDGE = false>
+__global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
+    const int wpb = blockDim.x >> 6;
+    const int64_t n_groups = (p.n_nodes + RB - 1) / RB;
+    const int64_t n_blocks = (n_groups + wpb - 1) / wpb;
+    const int64_t lb = xcd_remap(blockIdx.x, n_blocks);
+    if (lb < 0) return;
+    const int64_t g64 = lb * wpb + (threadIdx.x >> 6);
+    if (g64 >= n_groups) return;
+    const int row0 = uniform_i((int)(g64 * RB));
+    const int nrows = (int)min((int64_t)RB, p.n_nodes - row0);
+    const int f0 = (blockIdx.y * kWave + lane_id()) * C::VEC;
+    bwd_short_group<C, O, RB, EDGE>(p, row0, nrows, f0, f0 < p.F);
 }
 
 // hub backward, phase 2: merge slice partials, build the row's coefficient vectors, park them

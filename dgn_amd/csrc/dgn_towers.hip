@@ -222,9 +222,13 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     DGN_TRY(zero_rows_async(G->g_b_post, 1, d.Fo, d.Fo, st));
     DGN_TRY(dgn_scale_combine_backward(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
                                        dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream));
-    // posttrans: the scaler expansion happens inside the two products
-    DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
-                                              g_aggx, d.N * d.K, stream));
+    // posttrans: the scaler expansion happens inside the two products.  The input-gradient product runs INSIDE the backward sweep where
+    // that kernel has the shape (dgn_layer_fused_backward: g_aggx is formed and consumed in LDS; DGN_FUSED_BACKWARD=0: separate kernels)
+    const char* fb_env = getenv("DGN_FUSED_BACKWARD");          // (read per call: the tests switch it)
+    const bool fused_bwd = (!fb_env || atoi(fb_env) != 0) && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
+    if (!fused_bwd)
+        DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
+                                                  g_aggx, d.N * d.K, stream));
     DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
                                                (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
                                                dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
@@ -235,8 +239,13 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     gr.g_dst = g_pq + d.Fm; gr.ld_dst = 2 * d.Fm;
     gr.g_in = g_in; gr.ld_in = d.Fm;
     gr.accumulate = 0;
-    DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, &gr, ws + s.agg_ws,
-                             dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
+    if (fused_bwd)
+        DGN_TRY(dgn_layer_fused_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, d.S, d.fo,
+                                         L->scale, g_yr, d.N * d.fo, &gr, ws + s.agg_ws, dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1),
+                                         stream));
+    else
+        DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, &gr, ws + s.agg_ws,
+                                 dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
     // P|Q Linear: input gradient, weight + bias gradient (the bias rides in the weight-gradient pass)
     // d h = [residual] + d h_in + (d P|Q) W_sd: as the product's epilogue ((d h_in + product) + residual, add3's order) where the shapes
     // allow, else the product and a three-way add

@@ -404,6 +404,17 @@ int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec, const Dgn
                             const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers,
                             int32_t f_out, const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
                             void* stream);
+/* The mirror image for the backward: the sweep's upstream gradient g_agg[t] = G[t] . weight[t], G[t][m][s f_out + o] = scale[m][s] *
+ * gy[t][m][o] (what dgn_linear_combine_backward_input writes as a [T, N, K] tensor and dgn_agg_backward reads back) is formed 64
+ * rows at a time in LDS -- same MFMA arithmetic and k-order, bit-identical rows -- and consumed there by the grouped short-row
+ * backward; then the second phase of the two-phase scatter.  gy [T][n_nodes][f_out] (stride_gy between towers) = row_scale * the
+ * combine's upstream gradient; grads / ws as dgn_agg_backward with `deterministic` (define-mode sinks: grads->accumulate == 0).
+ * Domain: dgn_layer_fused_backward_supported (that of the forward kernel, + the graph's csc view, S * f_out <= 48, <= 32 units).   */
+int dgn_layer_fused_backward_supported(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t n_scalers, int32_t f_out);
+int dgn_layer_fused_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                             const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers, int32_t f_out,
+                             const float* scale, const float* gy, int64_t stride_gy, const DgnMsgGrad* grads, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* ---- graph batch preparation on the device (dgn_graph_build.hip) ------------------------------------------------------
  * The edge list of a (batched) graph in edge-id order -> the DgnGraph arrays, by a handful of kernels on `stream`, no host
