@@ -222,10 +222,13 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     DGN_TRY(zero_rows_async(G->g_b_post, 1, d.Fo, d.Fo, st));
     DGN_TRY(dgn_scale_combine_backward(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
                                        dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream));
-    // posttrans: the scaler expansion happens inside the two products.  The input-gradient product runs INSIDE the backward sweep where
-    // that kernel has the shape (dgn_layer_fused_backward: g_aggx is formed and consumed in LDS; DGN_FUSED_BACKWARD=0: separate kernels)
+    // posttrans: the scaler expansion happens inside the two products.  DGN_FUSED_BACKWARD=1: the input-gradient product runs INSIDE
+    // the backward sweep (dgn_layer_fused_backward: g_aggx is formed and consumed in LDS, bit-identical gradients).  Built, tested and
+    // NOT the default: measured 0.53 ms against 0.36 ms for the two separate kernels on ZINC-12k -- a persistent
+    // workgroup's sixteen waves start their dependent load chains together after every barrier, where the stand-alone sweep's
+    // workgroups are staggered.
     const char* fb_env = getenv("DGN_FUSED_BACKWARD");          // (read per call: the tests switch it)
-    const bool fused_bwd = (!fb_env || atoi(fb_env) != 0) && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
+    const bool fused_bwd = fb_env && atoi(fb_env) != 0 && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
     if (!fused_bwd)
         DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
                                                   g_aggx, d.N * d.K, stream));
