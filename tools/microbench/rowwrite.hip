@@ -52,6 +52,39 @@ __global__ void block_tile(float* __restrict__ out, int n_rows, int A, int F, fl
     for (size_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = make_float2(v, v);
 }
 
+// the sweep's staged store: one wave per 4 rows, every row = T tower pieces of K floats (row stride LD >= K inside a tower
+// plane), written as 16-byte lanes over all pieces of the row.  K = 84, LD = 84: today's layout (336-byte pieces at 16-byte
+// alignment); K = LD = 96: padded pieces, three full 128-byte lines each
+__global__ void staged_rows(float* __restrict__ out, int n_rows, int T, int K, int LD, float v) {
+    int g = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    const int K4 = K >> 2, total4 = T * K4;
+    for (int r = 0; r < 4; ++r) {
+        int row = g * 4 + r;
+        if (row >= n_rows) return;
+        float* orow = out + (size_t)row * LD;
+        for (int i4 = lane; i4 < total4; i4 += 64) {
+            int q = i4 / K4, c4 = i4 - q * K4;
+            *reinterpret_cast<float4*>(orow + (size_t)q * n_rows * LD + 4 * c4) = make_float4(v, v + r, v, v);
+        }
+    }
+}
+
+// the same bytes with the R rows of a wave written TOGETHER per tower: R * K contiguous floats (1344 bytes for R = 4) as
+// consecutive 16-byte lanes, i.e. full 128-byte lines apart from the two ends of the run
+__global__ void staged_group(float* __restrict__ out, int n_rows, int T, int K, int R, float v) {
+    int g = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int row0 = g * R;
+    if (row0 >= n_rows) return;
+    int rows = min(R, n_rows - row0);
+    const int run4 = rows * K >> 2;
+    for (int q = 0; q < T; ++q) {
+        float* base = out + ((size_t)q * n_rows + row0) * K;
+        for (int i4 = lane; i4 < run4; i4 += 64) *reinterpret_cast<float4*>(base + 4 * i4) = make_float4(v, v + q, v, v);
+    }
+}
+
 template <class F> float time_us(F&& f, int reps = 20) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -61,7 +94,23 @@ template <class F> float time_us(F&& f, int reps = 20) {
 
 int main() {
     const int N = 275167, A = 6;
-    for (int F : {70, 64, 128}) {
+    {
+        const int T = 5;
+        float* out; CK(hipMalloc(&out, (size_t)N * T * 128 * 4 + 4096));
+        unsigned g = ((N + 3) / 4 + 3) / 4;
+        for (int k : {84, 96, 128}) for (int ld : {84, 96, 128}) {
+            if (ld < k) continue;
+            float t = time_us([&] { hipLaunchKernelGGL(staged_rows, dim3(g), dim3(256), 0, 0, out, N, T, k, ld, 1.f); });
+            printf("staged rows, 5 towers, K=%3d LD=%3d : %6.1f us  %.2f TB/s written (%.0f MB)\n", k, ld, t, (double)N * T * k * 4 / t / 1e6, (double)N * T * k * 4 / 1e6);
+        }
+        for (int R : {4, 8, 16}) for (int wpb : {1, 4}) {
+            unsigned gg = ((N + R - 1) / R + wpb - 1) / wpb;
+            float t = time_us([&] { hipLaunchKernelGGL(staged_group, dim3(gg), dim3(64 * wpb), 0, 0, out, N, T, 84, R, 1.f); });
+            printf("grouped rows, 5 towers, K=84, %2d rows per wave, %d waves per block : %6.1f us  %.2f TB/s\n", R, wpb, t, (double)N * T * 84 * 4 / t / 1e6);
+        }
+        CK(hipFree(out));
+    }
+    for (int F : {70}) {
         size_t bytes = (size_t)N * A * F * 4;
         float* out; CK(hipMalloc(&out, bytes + 4096));
         unsigned nb = (N + 3) / 4;

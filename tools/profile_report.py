@@ -35,11 +35,15 @@ def main(tag, rnd="r01"):
     with redirect_stdout(buf):
         prof_summary.main(f"{src}/trace/{tag}_kernel_stats.csv", 30)
     os.makedirs("profiles", exist_ok=True)
-    cmd = open(f"{src}/trace.log").read().strip().splitlines()[-1][:400] if os.path.exists(f"{src}/trace.log") else ""
+    lines = [l for l in open(f"{src}/trace.log").read().splitlines() if l.startswith("{")] if os.path.exists(f"{src}/trace.log") else []
+    cmd = lines[-1][:400] if lines else ""
     with open(f"profiles/{rnd}_{tag}_kernel_stats.txt", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py (workload tag {tag}); avg_us = average launch duration\n")
         f.write(buf.getvalue())
         f.write("\n# bench line of the profiled run (durations inside include profiler overhead):\n# " + cmd + "\n")
+    if not os.path.exists(f"{src}/pmc_FETCH_SIZE/{tag}_counter_collection.csv"):   # trace-only tag
+        print(open(f"profiles/{rnd}_{tag}_kernel_stats.txt").read()[:1200])
+        return
     fetch = pmc_avgs(f"{src}/pmc_FETCH_SIZE/{tag}_counter_collection.csv")
     write = pmc_avgs(f"{src}/pmc_WRITE_SIZE/{tag}_counter_collection.csv")
     path = "profiles/pmc_traffic.json"
