@@ -122,7 +122,9 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
     p.M = n_rows; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.bias = bias; p.C = c; p.ldc = ldc;
     // 256-row tiles with both operands through LDS: wide outputs of nn.Linear-layout weights on many rows
     const char* tile_env = getenv("DGN_TILE_GEMM");          // (read per call: the tests switch it)
-    const bool tile = tile_env ? atoi(tile_env) != 0 : (n >= 64 && n_rows >= 131072);     // (fewer rows: too few 256-row tiles to fill the CUs -- measured slower at 52 k rows)
+    static const char* min_env = getenv("DGN_TILE_GEMM_MIN_ROWS");
+    static const int64_t tile_min_rows = min_env ? atoll(min_env) : 131072;
+    const bool tile = tile_env ? atoi(tile_env) != 0 : (n >= 64 && n_rows >= tile_min_rows);     // (fewer rows: too few 256-row tiles to fill the CUs -- measured slower at 52 k rows)
     if (tile && !w_is_kn) {
         // column tiles of 16 NQ (NQ <= 8): the split with the least padded columns, fewer tiles on a tie
         // (NQ = 8 would need 265 registers: one wave per SIMD)
@@ -132,7 +134,12 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
             if (pad < best_pad) { best_nq = nq; best_tiles = tiles; best_pad = pad; }
         }
         p.n_slice = 16 * best_nq;
-        const dim3 grid((unsigned)((n_rows + kTileM - 1) / kTileM), (unsigned)best_tiles);
+        // one workgroup per resident slot (two per CU: 256 registers per lane, 51-59 KB of LDS each), each with an equal range of
+        // rows: 2150 tiles over 512 slots used to run as five rounds of which the last was a fifth full
+        const int per_cu = 2;
+        const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * per_cu / best_tiles);
+        p.rows_per_block = std::max<int64_t>(64, (((n_rows + slots_x - 1) / slots_x) + 63) / 64 * 64);
+        const dim3 grid((unsigned)((n_rows + p.rows_per_block - 1) / p.rows_per_block), (unsigned)best_tiles);
         hipStream_t st = static_cast<hipStream_t>(stream);
         switch (best_nq) {
             case 4: hipLaunchKernelGGL(tile_gemm<4>, grid, dim3(256), 0, st, p); break;

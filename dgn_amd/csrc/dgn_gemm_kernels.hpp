@@ -70,6 +70,7 @@ struct GemmParams {
     const float* bias;               // [n] or NULL
     float* C; int64_t ldc;
     int n_slice;                     // columns per blockIdx.y (a multiple of 16)
+    int64_t rows_per_block;          // tile_gemm: rows of one workgroup's range (a multiple of 64)
 };
 
 #ifdef DGN_GEMM_WPE
@@ -207,21 +208,21 @@ __global__ __launch_bounds__(kWave * kWaves) DGN_GEMM_ATTR void ts_gemm(const Ge
 // (n = 210: two tiles of 112; 420: four of 112; 225: three of 80).
 constexpr int kTileM = 256, kTKS = 20;
 
-template <int NQ>
-__global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
-    __shared__ float As[2][kTileM * kTKS];
-    __shared__ float Bs[2][NQ * 16 * kTKS];
+// One tile of 64 RT rows (RT <= 4) x 16 NQ columns: rows [row0, row0 + 64 RT) of which only those below row_end are written (the
+// rest belong to the next workgroup's range or lie past M).  Wave w owns rows 16 RT w .. 16 RT (w + 1) of the tile.
+template <int NQ, int RT>
+__device__ __forceinline__ void tile_pass(const GemmParams& p, float* As, float* Bs, int64_t row0, int64_t row_end, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * kTileM;
-    const int n0 = blockIdx.y * p.n_slice;                    // n_slice = 16 NQ
     const int KB = (p.k + 15) >> 4;
-    // this thread's 16-byte pieces of the operand chunks: A rows lr + 64 j (j < 4), W rows lr + 64 j (j < 2), k offset c4
+    // this thread's 16-byte pieces of the operand chunks: A rows lr + 64 j (j < RT), W rows lr + 64 j (j < NBJ), k offset c4
     const int lr = tid >> 2, c4 = (tid & 3) * 4;
     constexpr int NBJ = (NQ * 16 + 63) / 64;
-    auto fetch = [&](Raw4 (&ra)[4], Raw4 (&rb)[NBJ], int kc) {
+    constexpr int kABuf = kTileM * kTKS, kBBuf = NQ * 16 * kTKS;
+    Raw4 ra[RT], rb[NBJ];
+    auto fetch = [&](int kc) {
         const int k0 = 16 * kc + c4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RT; ++j) {
             const int64_t r = row0 + lr + 64 * j;
             ra[j] = load4_raw(p.A + min(r, p.M - 1) * p.lda, k0, p.k, r < p.M);
         }
@@ -231,14 +232,14 @@ __global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
             rb[j] = load4_raw(p.W + (int64_t)min(c, p.n - 1) * p.ldw, k0, p.k, rl < NQ * 16 && c < p.n);
         }
     };
-    auto commit = [&](const Raw4 (&ra)[4], const Raw4 (&rb)[NBJ], int buf) {
+    auto commit = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[buf][(lr + 64 * j) * kTKS + c4]) = load4_window(ra[j]);
+        for (int j = 0; j < RT; ++j) *reinterpret_cast<f4*>(As + buf * kABuf + (lr + 64 * j) * kTKS + c4) = load4_window(ra[j]);
 #pragma unroll
         for (int j = 0; j < NBJ; ++j)
-            if (lr + 64 * j < NQ * 16) *reinterpret_cast<f4*>(&Bs[buf][(lr + 64 * j) * kTKS + c4]) = load4_window(rb[j]);
+            if (lr + 64 * j < NQ * 16) *reinterpret_cast<f4*>(Bs + buf * kBBuf + (lr + 64 * j) * kTKS + c4) = load4_window(rb[j]);
     };
-    f4 acc[4][NQ];
+    f4 acc[RT][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -246,35 +247,34 @@ __global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
             const int col = n0 + 16 * q + 4 * g + r;
             const float b = (p.bias && col < p.n) ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) acc[rt][q][r] = b;
+            for (int rt = 0; rt < RT; ++rt) acc[rt][q][r] = b;
         }
     }
-    Raw4 ra[4], rb[NBJ];
-    fetch(ra, rb, 0);
-    commit(ra, rb, 0);
+    fetch(0);
+    commit(0);
     __syncthreads();
     for (int kc = 0; kc < KB; ++kc) {
-        if (kc + 1 < KB) fetch(ra, rb, kc + 1);                    // next chunk in flight during the MFMAs
-        const float* al = &As[kc & 1][(64 * wave + i16) * kTKS + 4 * g];
-        const float* bl = &Bs[kc & 1][i16 * kTKS + 4 * g];
-        f4 xa[4], wb[NQ];
+        if (kc + 1 < KB) fetch(kc + 1);                            // next chunk in flight during the MFMAs
+        const float* al = As + (kc & 1) * kABuf + (16 * RT * wave + i16) * kTKS + 4 * g;
+        const float* bl = Bs + (kc & 1) * kBBuf + i16 * kTKS + 4 * g;
+        f4 xa[RT], wb[NQ];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const f4*>(al + 16 * t * kTKS);
+        for (int t = 0; t < RT; ++t) xa[t] = *reinterpret_cast<const f4*>(al + 16 * t * kTKS);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) wb[q] = *reinterpret_cast<const f4*>(bl + 16 * q * kTKS);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[q][s], xa[rt][s], acc[rt][q], 0, 0, 0);
-        if (kc + 1 < KB) commit(ra, rb, (kc + 1) & 1);
+        if (kc + 1 < KB) commit((kc + 1) & 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        const int64_t row = row0 + 64 * wave + 16 * rt + i16;
-        if (row < p.M) {
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t row = row0 + 16 * RT * wave + 16 * rt + i16;
+        if (row < row_end) {
             float* crow = p.C + row * p.ldc;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -286,6 +286,30 @@ __global__ __launch_bounds__(256) void tile_gemm(const GemmParams p) {
                 }
             }
         }
+    }
+}
+
+// A workgroup owns the rows [blockIdx.x * rows_per_block, + rows_per_block) (a multiple of 64; the host sizes it so that ONE
+// workgroup per resident slot covers all rows: no partial last round of tiles) and walks them in tiles of 256, 192, 128 or 64 rows,
+// the range cut into the fewest tiles of nearly equal height.
+template <int NQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void tile_gemm(const GemmParams p) {   // two workgroups per CU: 256 registers
+
+    __shared__ float As[2 * kTileM * kTKS];
+    __shared__ float Bs[2 * NQ * 16 * kTKS];
+    const int n0 = blockIdx.y * p.n_slice;                    // n_slice = 16 NQ
+    int64_t r = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t end = min(p.M, r + p.rows_per_block);
+    while (r < end) {
+        const int left = (int)(end - r), tiles = (left + kTileM - 1) / kTileM;
+        const int h = min(4, ((left + tiles - 1) / tiles + 63) >> 6);         // 64-row units of this tile
+        switch (h) {
+            case 4: tile_pass<NQ, 4>(p, As, Bs, r, end, n0); break;
+            case 3: tile_pass<NQ, 3>(p, As, Bs, r, end, n0); break;
+            case 2: tile_pass<NQ, 2>(p, As, Bs, r, end, n0); break;
+            default: tile_pass<NQ, 1>(p, As, Bs, r, end, n0); break;
+        }
+        r += 64 * h;
     }
 }
 
