@@ -76,6 +76,14 @@ WORKLOADS = {
                gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
                hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
                graph_norm=False),      # configs/molecules_graph_classification_DGN_HIV.json:30
+    # "also run a saturating mega-batch so the roofline fraction is not just launch latency"
+    "c3_mega": dict(desc="CIFAR10-superpixel-like, 8192 graphs in one batch (8-NN rows at a saturating size), layer as c3",
+                    gen=("knn", dict(n_graphs=8192)), type_net="simple", hidden=65,
+                    aggregators="mean dir1-dx dir2-dx", scalers="identity", towers=1),
+    "c4_mega": dict(desc="ogbg-molhiv-like, the whole 41 127-graph dataset in one batch, layer as c4",
+                    gen=("molecules", dict(n_graphs=41127, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
+                    hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
+                    graph_norm=False),
     # the reference's SHIPPED json configs, as written (odd hidden sizes: the layers pad the message path by one zero column)
     "zinc_json": dict(desc="configs/molecules_graph_regression_DGN_ZINC.json as shipped: complex, hidden 45, mean dir1-dx dir1-av x 3 scalers, "
                            "graph norm, ZINC-12k in one batch",
@@ -794,7 +802,7 @@ def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
     plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
-            ("pattern_json", 20, 5), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c5", 3, 1)]
+            ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c5", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()

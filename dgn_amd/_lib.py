@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 20
+ABI_VERSION = 19
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -26,7 +26,7 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_bias_act_forward", "dgn_bias_act_backward",
            "dgn_layer_fused_supported", "dgn_layer_fused_forward", "dgn_layer_fused_backward_supported", "dgn_layer_fused_backward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
-           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_csc_dst", "dgn_edge_weights_to_csc", "dgn_agg_backward_csc",
+           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
@@ -39,7 +39,7 @@ class DgnGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_int64), ("n_edges", C.c_int64), ("indptr", C.c_void_p), ("src", C.c_void_p),
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
-                ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("csc_dst", C.c_void_p), ("max_in_degree", C.c_int32),
+                ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
                 ("n_src", C.c_int64), ("row_base", C.c_int64)]
 
 
@@ -96,7 +96,7 @@ class DgnDenseLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("hp", C.c_void_p), ("pq", C.c_void_p), ("agg", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("wsd", C.c_void_p),
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("n_valid", C.c_void_p), ("w_csc", C.c_void_p), ("ld_w_csc", C.c_int64)]
+                ("n_valid", C.c_void_p)]
 
 
 class DgnDenseGrads(C.Structure):
@@ -152,14 +152,6 @@ def load() -> C.CDLL:
         lib.dgn_agg_backward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(DgnMsgGrad),
                                          C.c_void_p, C.c_size_t, C.c_void_p]
-        lib.dgn_agg_backward_csc.restype = C.c_int
-        lib.dgn_agg_backward_csc.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64, C.c_void_p,
-                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(DgnMsgGrad), C.c_void_p, C.c_size_t,
-                                             C.c_void_p]
-        lib.dgn_graph_csc_dst.restype = C.c_int
-        lib.dgn_graph_csc_dst.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.dgn_edge_weights_to_csc.restype = C.c_int
-        lib.dgn_edge_weights_to_csc.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dgn_scale_combine_forward.restype = C.c_int
         lib.dgn_scale_combine_forward.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]

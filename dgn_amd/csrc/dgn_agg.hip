@@ -239,21 +239,10 @@ extern "C" size_t dgn_agg_edge_table_workspace_bytes(int64_t F, int32_t n_edge_t
     return (F > 0 && n_edge_types > 0) ? edge_table_ws_bytes(F, n_edge_types) : 0;
 }
 
-// the pull backward's coefficient rows: [n_nodes][1 + n_ch (1 + any dir-av)][F]
-size_t pull_coef_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F) {
-    bool av = false;
-    for (int a = 0; a < spec->n_agg; ++a) av |= spec->agg_op[a] == DGN_AGG_DIR_AV;
-    return ((size_t)g->n_nodes * (1 + spec->n_ch * (av ? 2 : 1)) * F * sizeof(float) + 255) & ~(size_t)255;
-}
-
 extern "C" size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t deterministic) {
     if (!g || !spec) return 0;
     size_t n = hub_ws_bytes(g, spec, F);
-    if (deterministic && g->csc_ptr && g->csc_pos && g->n_edges > 0) {
-        size_t extra = stage_bytes(g, F);
-        if (g->csc_dst) extra = std::max(extra, pull_coef_bytes(g, spec, F));       // (dgn_agg_backward_csc may take the pull path)
-        n += extra;
-    }
+    if (deterministic && g->csc_ptr && g->csc_pos && g->n_edges > 0) n += stage_bytes(g, F);
     return n;
 }
 
@@ -282,7 +271,7 @@ namespace dgn {
 // gradient is formed in LDS: `g_out` may then be NULL (`lds_gout`).  *tab_part_out: workspace of the edge-type table's gradient.
 int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                          const float* log_deg, const float* g_out, int64_t ld_gout, bool lds_gout, const DgnMsgGrad* grads, void* ws,
-                         size_t ws_bytes, void* stream_, float** tab_part_out, const float* w_csc, int64_t ld_w_csc) {
+                         size_t ws_bytes, void* stream_, float** tab_part_out) {
     int rc = validate(g, spec, msg, w, log_deg);
     if (rc) return rc;
     if (!grads) { set_error("null grads"); return DGN_ERR_INVALID; }
@@ -298,23 +287,6 @@ int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec
     p.g_edge = msg->m_edge ? grads->g_edge : nullptr; p.ldg_edge = (int32_t)grads->ld_edge;
     p.g_in = msg->x_in ? grads->g_in : nullptr; p.ldg_in = (int32_t)grads->ld_in;
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
-    // Pull backward (agg_bwd_pull): lists without max / min / std / var on graphs with more than three in-edges per row on average,
-    // when the caller brought the csc view's destination rows and the weights in csc order -- no staging buffer at all
-    static const bool no_pull = getenv("DGN_NO_PULL") != nullptr;
-    const bool pull = !no_pull && !lds_gout && p.g_src && g->csc_ptr && g->csc_dst && (w_csc || spec->n_ch == 0) && ld_w_csc <= INT32_MAX &&
-                      grads->accumulate == 0 && !p.g_edge && !msg->edge_type && g->n_hub == 0 && g->n_edges > 0 &&
-                      !(p.need & (NEED_M_EMIT | NEED_SQ | NEED_MAX | NEED_MIN)) && !short_rows(p) && ws &&
-                      ws_bytes >= hub_ws_bytes(g, spec, msg->F) + pull_coef_bytes(g, spec, msg->F);
-    if (pull) {
-        p.pull_coef = reinterpret_cast<float*>(static_cast<char*>(ws) + hub_ws_bytes(g, spec, msg->F));
-        p.pull_g_src = p.g_src;
-        p.g_src = nullptr;                    // (the row kernel emits nothing per edge)
-        p.csc_ptr = g->csc_ptr; p.csc_dst = g->csc_dst; p.w_csc = w_csc; p.ld_w_csc = (int32_t)ld_w_csc;
-        p.fresh = true;
-        p.seg_add = p.g_in == p.pull_g_src;   // (simple layer: d x_in and d x_src meet in one tensor; the row kernel wrote d x_in)
-        if (tab_part_out) *tab_part_out = nullptr;
-        return DGN_OK;
-    }
     // atomic-free scatter when the transposed view and the [E, F] staging buffer are available
     if (p.g_src && g->csc_ptr && g->csc_pos && g->n_edges > 0 && ws &&
         ws_bytes >= hub_ws_bytes(g, spec, msg->F) + stage_bytes(g, msg->F)) {
@@ -349,17 +321,10 @@ int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec
 extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                                 const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                                 void* ws, size_t ws_bytes, void* stream_) {
-    return dgn_agg_backward_csc(g, spec, msg, w, ld_w, nullptr, 0, log_deg, g_out, ld_gout, grads, ws, ws_bytes, stream_);
-}
-
-extern "C" int dgn_agg_backward_csc(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
-                                    const float* w_csc, int64_t ld_w_csc, const float* log_deg, const float* g_out, int64_t ld_gout,
-                                    const DgnMsgGrad* grads, void* ws, size_t ws_bytes, void* stream_) {
     if (g && g->n_nodes == 0 && spec && msg && grads) return validate(g, spec, msg, w, log_deg);
     AggParams p;
     float* tab_part = nullptr;
-    int rc = agg_backward_prepare(p, g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, false, grads, ws, ws_bytes, stream_, &tab_part, w_csc,
-                                  ld_w_csc);
+    int rc = agg_backward_prepare(p, g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, false, grads, ws, ws_bytes, stream_, &tab_part);
     if (rc) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);

@@ -108,17 +108,7 @@ struct AggParams {
     const int32_t* csc_pos;
     int32_t n_slots;
     int32_t n_coef;
-    // "pull" backward (no staging buffer): the row kernel parks each row's coefficient vectors, agg_bwd_pull walks every source's
-    // out-edges in csc order and re-forms dm_j from them (see agg_bwd_pull)
-    float* pull_coef;            // [n_nodes][pull_nv][F], or NULL
-    float* pull_g_src;           // the d x_src sink of that second kernel (g_src is NULL for the row kernel in this mode)
-    const int32_t* csc_dst;      // [n_edges] destination row of the csc entry
-    const float* w_csc;          // [n_ch][ld_w_csc] the edge weights in csc order
-    int32_t ld_w_csc;
 };
-
-// vectors per row of pull_coef: c0, then per weight channel cs_c (and ca_c with dir-av present)
-template <class C> constexpr int pull_nv() { return 1 + C::NCH * (C::AV ? 2 : 1); }
 
 // accumulator slot ids in the hub workspace
 constexpr int SLOT_SUM = 0, SLOT_SQ = 1, SLOT_MAX = 2, SLOT_MIN = 3, SLOT_AMAX = 4, SLOT_AMIN = 5, SLOT_W0 = 6;
@@ -1128,19 +1118,6 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
                          deg, xin, logd);
 }
 
-// pull mode: the row's coefficient vectors go to p.pull_coef (rows without in-edges are never read back)
-template <class C>
-__device__ __forceinline__ void store_pull_coef(const AggParams& p, int row, int f0, const Coef<C>& k) {
-    constexpr int VEC = C::VEC, NV = pull_nv<C>();
-    float* base = p.pull_coef + (int64_t)row * NV * p.F + f0;
-    stv<VEC>(base, k.c0);
-#pragma unroll
-    for (int c = 0; c < C::NCH; ++c) {
-        stv<VEC>(base + (int64_t)(1 + c * (C::AV ? 2 : 1)) * p.F, k.cs[c]);
-        if constexpr (C::AV) stv<VEC>(base + (int64_t)(2 + 2 * c) * p.F, k.ca[c]);
-    }
-}
-
 // emit dm_j for the cnt slots of one loaded slot batch (my_tpos: the lane's csc position, two-phase scatter);
 // adds them to the row-sum rsum.  Active lanes only.
 template <class C, bool NEED_M>
@@ -1347,7 +1324,6 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     } else {
         make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     }
-    if constexpr (!C::STATS) { if (p.pull_coef) store_pull_coef<C>(p, row, f0, k); }
     emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
     add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
 }
@@ -1418,7 +1394,6 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
         for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(part[c]);
     }
     if (active) make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
-    if constexpr (!C::STATS) { if (active && p.pull_coef) store_pull_coef<C>(p, row, f0, k); }
     emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
     if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
 }
@@ -1737,88 +1712,6 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
     }
 }
 
-// Second kernel of the "pull" backward, for aggregator lists whose dm_j depends on the destination row only through per-row
-// coefficient vectors (no max / min / std / var):  dm_j = c0[i] + sum_c (w_jc cs_c[i] + |w_jc| ca_c[i]).  Instead of parking every dm_j
-// in an [E, F] staging buffer and summing it back per source (2 E F floats of traffic), each source node walks its out-edges in csc
-// order -- destination row and weights are stored in that order -- and gathers the destinations' coefficient rows, which a batch of
-// graphs keeps in L2 (a graph's rows are read once per out-edge by its own nodes).  Same expression and the same order of additions as
-// emit_batch + seg_sum_rows: bit-identical d x_src.  Flat mapping like seg_sum_rows: one thread per (node, 4 floats).
-template <class C>
-__global__ __launch_bounds__(256) void agg_bwd_pull(const AggParams p) {
-    constexpr int VEC = C::VEC, NV = pull_nv<C>();
-    constexpr int PER = VEC == 1 ? 4 : (VEC == 2 ? 2 : 1);
-    const int nchunk = (p.F + VEC * PER - 1) / (VEC * PER);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.n_src * nchunk) return;
-    const int u = (int)(t / nchunk);
-    const int f0 = (int)(t - (int64_t)u * nchunk) * VEC * PER;
-    const int beg = p.csc_ptr[u], end = p.csc_ptr[u + 1];
-    const bool add = p.seg_add;
-    if (beg == end && add) return;
-    float acc[PER][VEC];
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
-    constexpr int KU = NV <= 3 ? 4 : 2;               // out-edges whose coefficient pieces are requested before the first is used
-    for (int k0 = beg; k0 < end; k0 += KU) {
-        int d[KU];
-        float w[KU][C::NW];
-#pragma unroll
-        for (int j = 0; j < KU; ++j) {
-            const int kk = min(k0 + j, end - 1);
-            d[j] = p.csc_dst[kk];
-#pragma unroll
-            for (int c = 0; c < C::NW; ++c) w[j][c] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C::NCH; ++c) w[j][c] = p.w_csc[(int64_t)c * p.ld_w_csc + kk];
-        }
-        float r[KU][NV][PER][VEC];
-#pragma unroll
-        for (int j = 0; j < KU; ++j) {
-            const float* row = p.pull_coef + (int64_t)d[j] * NV * p.F + f0;
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int q = 0; q < PER; ++q) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) r[j][v][q][i] = 0.f;
-                    if (f0 + q * VEC < p.F) ldv<VEC>(r[j][v][q], row + (int64_t)v * p.F + q * VEC);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < KU; ++j) {
-            if (k0 + j < end) {
-#pragma unroll
-                for (int q = 0; q < PER; ++q)
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        float gm = r[j][0][q][i];
-#pragma unroll
-                        for (int c = 0; c < C::NCH; ++c) {
-                            gm = fmaf(w[j][c], r[j][1 + c * (C::AV ? 2 : 1)][q][i], gm);
-                            if constexpr (C::AV) gm = fmaf(fabsf(w[j][c]), r[j][2 + 2 * c][q][i], gm);
-                        }
-                        acc[q][i] += gm;
-                    }
-            }
-        }
-    }
-    float* dst = p.pull_g_src + (int64_t)u * p.ldg_src + f0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        if (f0 + q * VEC < p.F) {
-            if (add) {
-                float cur[VEC];
-                ldv<VEC>(cur, dst + q * VEC);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[q][i] += cur[i];
-            }
-            stv<VEC>(dst + q * VEC, acc[q]);
-        }
-    }
-}
-
 // ---- launchers (one translation unit per VEC: dgn_agg_v{1,2,4}.hip) ----------------------------
 
 // Workgroup shape of the row kernels.  The dispatcher starts ~4.6 workgroups per ns whatever their size
@@ -1905,16 +1798,6 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
         constexpr int per = C::VEC == 1 ? 4 : (C::VEC == 2 ? 2 : 1);
         const int64_t n_threads = p.n_src * ((p.F + C::VEC * per - 1) / (C::VEC * per));
         hipLaunchKernelGGL((seg_sum_rows<C::VEC>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, stream, p);
-    }
-    if (p.pull_coef) {
-        if constexpr (!C::STATS) {
-            constexpr int per = C::VEC == 1 ? 4 : (C::VEC == 2 ? 2 : 1);
-            const int64_t n_threads = p.n_src * ((p.F + C::VEC * per - 1) / (C::VEC * per));
-            hipLaunchKernelGGL((agg_bwd_pull<C>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, stream, p);
-        } else {
-            set_error("pull backward launched with a max / min / std list");
-            return DGN_ERR_INVALID;
-        }
     }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;

@@ -142,49 +142,3 @@ extern "C" int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
-
-// ---- the csc view's destination rows and csc-ordered edge weights (the "pull" backward of dgn_agg_backward_csc) ---------------------
-namespace dgn {
-namespace {
-// csc_dst[e] = row whose slot range holds slot csc_order[e]  (upper_bound over indptr; the row pointers stay in L2)
-__global__ void gb_csc_dst(int64_t n_edges, int64_t n_nodes, const int32_t* __restrict__ indptr, const int32_t* __restrict__ csc_order,
-                           int32_t* __restrict__ csc_dst) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_edges) return;
-    const int32_t slot = csc_order[e];
-    int64_t lo = 0, hi = n_nodes;            // the answer r satisfies indptr[r] <= slot < indptr[r + 1]
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] <= slot) lo = mid; else hi = mid;
-    }
-    csc_dst[e] = (int32_t)lo;
-}
-__global__ void gb_permute_rows(int64_t n_edges, int32_t n_ch, const float* __restrict__ w, int64_t ld_w, const int32_t* __restrict__ csc_order,
-                                float* __restrict__ w_csc, int64_t ld_w_csc) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_edges) return;
-    const int32_t slot = csc_order[e];
-    for (int c = 0; c < n_ch; ++c) w_csc[(int64_t)c * ld_w_csc + e] = w[(int64_t)c * ld_w + slot];
-}
-}  // namespace
-}  // namespace dgn
-
-extern "C" int dgn_graph_csc_dst(int64_t n_nodes, int64_t n_edges, const int32_t* indptr, const int32_t* csc_order, int32_t* csc_dst,
-                                 void* stream_) {
-    if (n_edges <= 0) return DGN_OK;
-    if (!indptr || !csc_order || !csc_dst || n_nodes < 1) { dgn::set_error("dgn_graph_csc_dst: null array"); return DGN_ERR_INVALID; }
-    hipLaunchKernelGGL(dgn::gb_csc_dst, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), n_edges, n_nodes,
-                       indptr, csc_order, csc_dst);
-    DGN_HIP_CHECK(hipGetLastError());
-    return DGN_OK;
-}
-
-extern "C" int dgn_edge_weights_to_csc(int64_t n_edges, int32_t n_channels, const float* w, int64_t ld_w, const int32_t* csc_order,
-                                       float* w_csc, int64_t ld_w_csc, void* stream_) {
-    if (n_edges <= 0 || n_channels <= 0) return DGN_OK;
-    if (!w || !csc_order || !w_csc || ld_w < n_edges || ld_w_csc < n_edges) { dgn::set_error("dgn_edge_weights_to_csc: null array or short plane"); return DGN_ERR_INVALID; }
-    hipLaunchKernelGGL(dgn::gb_permute_rows, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), n_edges,
-                       n_channels, w, ld_w, csc_order, w_csc, ld_w_csc);
-    DGN_HIP_CHECK(hipGetLastError());
-    return DGN_OK;
-}

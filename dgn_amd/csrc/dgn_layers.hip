@@ -289,8 +289,8 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         gr.g_in = g_hp; gr.ld_in = d.Fp;
     }
     gr.accumulate = 0;
-    DGN_TRY(dgn_agg_backward_csc(L->graph, L->spec, &msg, L->w, L->ld_w, L->w_csc, L->ld_w_csc, L->log_deg, g_agg, d.K, &gr, ws + s.agg_ws,
-                                 dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1), stream));
+    DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_agg, d.K, &gr, ws + s.agg_ws,
+                             dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1), stream));
     const float* g_res = L->residual ? G->g_out : nullptr;
     if (d.cx) {
         // pretrans P|Q Linear: input gradient (transposed weight), weight + bias gradient, un-folded

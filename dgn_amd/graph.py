@@ -27,7 +27,6 @@ HUB_CHUNK = 1024
 # True: a graph given as CUDA edge lists is prepared by dgn_graph_build* (a handful of kernels behind one C call each);
 # False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
 NATIVE_BUILD = True
-PULL_BACKWARD = True     # staging-free backward on longer rows (dgn_agg_backward_csc) when the list allows it
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -95,9 +94,8 @@ class DGNGraph:
         self._init_csr(indptr, src_csr, eid, n_cap, e_cap, deg, HUB_THRESHOLD, HUB_CHUNK, log_deg=log_deg, max_in_degree=0, n_hub_hint=0)
         self.n_valid = torch.zeros(1, dtype=torch.int64, device=dev)
         self.csc_ptr, self.csc_pos, self._csc_order = i32(n_cap + 1), i32(e_cap), i32(e_cap)
-        self.csc_dst = i32(e_cap)
-        self._c.csc_ptr, self._c.csc_pos, self._c.csc_dst = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), self.csc_dst.data_ptr()
-        self._csc_ready = self._csc_dst_ready = True
+        self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+        self._csc_ready = True
         lib = _lib.load()
         self._pad["ws_bytes"] = lib.dgn_graph_build_workspace_bytes(n_cap, e_cap)
         self._pad["ws"] = torch.empty(self._pad["ws_bytes"], dtype=torch.uint8, device=dev)
@@ -125,8 +123,6 @@ class DGNGraph:
                                        int(self.hub_threshold), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build")
         _lib.check(lib.dgn_graph_build_csc(n_cap, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(),
                                            self._csc_order.data_ptr(), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build_csc")
-        _lib.check(lib.dgn_graph_csc_dst(n_cap, E, self.indptr.data_ptr(), self._csc_order.data_ptr(), self.csc_dst.data_ptr(), stream),
-                   "dgn_graph_csc_dst")
         self.n_valid.fill_(N)
         if E < pad["e_cap"]:
             # slots beyond the batch's edges: no row points at them, but per-edge tensors are e_cap rows long (to_slot_order gathers through
@@ -145,7 +141,6 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        self.__dict__.pop("_wcsc", None)
         for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types"):
             self.__dict__.pop(k, None)
 
@@ -225,7 +220,6 @@ class DGNGraph:
             self._csc_ready = True
             return
         order = torch.sort(self.src.long(), stable=True)[1]                 # slots ordered by (source, slot)
-        self._csc_order = order.int().contiguous()
         pos = torch.empty(E, dtype=torch.int64, device=dev)
         pos[order] = torch.arange(E, device=dev)
         out_deg = torch.bincount(self.src.long(), minlength=self.num_src) if E else torch.zeros(self.num_src, dtype=torch.int64, device=dev)
@@ -247,42 +241,6 @@ class DGNGraph:
         _lib.check(lib.dgn_graph_build_csc(N, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), order.data_ptr(),
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
-        self._csc_order = order
-
-    @property
-    def pull_capable(self) -> bool:
-        """Graphs on which dgn_agg_backward_csc may take its staging-free path: more than three in-edges per row on average, no hub
-        rows, one node set.  (The library decides per launch: the aggregator list must be free of max / min / std / var.)"""
-        return PULL_BACKWARD and self.num_edges > 3 * self.num_nodes and self.n_hub == 0 and self.num_src == self.num_nodes and self.src.is_cuda
-
-    def ensure_csc_dst(self) -> None:
-        """Destination row of every csc entry (dgn_graph_csc_dst): the pull backward's second index array."""
-        self.ensure_csc()
-        if getattr(self, "_csc_dst_ready", False):
-            return
-        lib = _lib.load()
-        self.csc_dst = torch.empty(max(self.num_edges, 1), dtype=torch.int32, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(lib.dgn_graph_csc_dst(self.num_nodes, self.num_edges, self.indptr.data_ptr(), self._csc_order.data_ptr(),
-                                         self.csc_dst.data_ptr(), stream), "dgn_graph_csc_dst")
-        self._c.csc_dst = self.csc_dst.data_ptr()
-        self._csc_dst_ready = True
-
-    def weights_csc(self, w: torch.Tensor) -> torch.Tensor:
-        """The edge-weight planes ``w`` [C, E] in csc order (w_csc[c][e] = w[c][csc_order[e]]), cached per weight tensor."""
-        self.ensure_csc_dst()
-        cache = self.__dict__.setdefault("_wcsc", {})
-        ent = cache.get(id(w))
-        if ent is None or ent[0] is not w or ent[1] != w._version:
-            lib = _lib.load()
-            out = torch.empty_like(w)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(lib.dgn_edge_weights_to_csc(self.num_edges, w.shape[0], w.data_ptr(), w.stride(0), self._csc_order.data_ptr(),
-                                                   out.data_ptr(), out.stride(0), stream), "dgn_edge_weights_to_csc")
-            if len(cache) >= 8:
-                cache.clear()
-            cache[id(w)] = ent = (w, w._version, out)
-        return ent[2]
 
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----
     def number_of_nodes(self) -> int:

@@ -155,12 +155,6 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
         raise _lib.DgnError("edge-type table: the backward needs the two-phase scatter (even F, a gradient for x_src)")
     if deterministic:
         graph.ensure_csc()
-    # longer rows: the csc view's destination rows + the weights in csc order let the library skip the [E, F] staging buffer for
-    # lists without max / min / std / var (dgn_agg_backward_csc decides per launch and falls back to the staged path)
-    w_csc = None
-    if deterministic and not accumulate and g_edge is None and edge_type is None and graph.pull_capable:
-        graph.ensure_csc_dst()
-        w_csc = graph.weights_csc(w) if w is not None else None
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
         if edge_type is not None:
@@ -173,12 +167,10 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
             tmp = torch.empty_like(g_edge)
             grads.g_edge = tmp.data_ptr()
         grads.accumulate = 1 if (accumulate or not first) else 0
-        wcl = w_csc[l.ch_offset:] if (w_csc is not None and l.channels) else None
-        rc = lib.dgn_agg_backward_csc(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                      _ptr(wcl), w_csc.stride(0) if w_csc is not None else 0,
-                                      graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, C.byref(grads),
-                                      _ptr(ws), nbytes, stream)
-        _lib.check(rc, "dgn_agg_backward_csc")
+        rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                  graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, C.byref(grads),
+                                  _ptr(ws), nbytes, stream)
+        _lib.check(rc, "dgn_agg_backward")
         if tmp is not None:
             g_edge += tmp
             grads.g_edge = g_edge.data_ptr()
@@ -1147,12 +1139,7 @@ class _DenseLayer(torch.autograd.Function):
         bufs = [saved_buf[o:o + n] for o, n in zip(offs, sizes)]
         g_out = g_out.contiguous()
         graph.ensure_csc()
-        w_csc = None
-        if graph.pull_capable:               # longer rows: the sweep's backward may skip its staging buffer (dgn_agg_backward_csc)
-            graph.ensure_csc_dst()
-            w_csc = graph.weights_csc(w_edge) if w_edge is not None else None
         L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
-        L.w_csc, L.ld_w_csc = _ptr(w_csc), (w_csc.stride(0) if w_csc is not None else 0)
         nbytes = lib.dgn_dense_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes

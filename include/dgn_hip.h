@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 20
+#define DGN_ABI_VERSION 19
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -99,9 +99,6 @@ typedef struct DgnGraph {
      * to its csc position and a second kernel sums each source's contiguous rows: deterministic, no atomics. */
     const int32_t* csc_ptr;  /* [n_src+1]   */
     const int32_t* csc_pos;  /* [n_edges]   */
-    /* Optional (NULL = absent): destination row of every csc entry (dgn_graph_csc_dst).  With it, and the edge weights in csc
-     * order, dgn_agg_backward_csc runs lists without max / min / std / var on longer rows with NO staging buffer ("pull").   */
-    const int32_t* csc_dst;  /* [n_edges]   */
     /* Hint: largest in-degree, 0 = unknown.  Lets launches that only concern long rows be skipped.       */
     int32_t max_in_degree;
     /* Number of SOURCE nodes when it differs from n_nodes (0 = same): a bipartite CSR whose rows are e.g. the
@@ -213,16 +210,6 @@ size_t dgn_agg_edge_table_workspace_bytes(int64_t F, int32_t n_edge_types);
 int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                      const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                      void* ws, size_t ws_bytes, void* stream);
-/* The same backward with the edge weights ALSO in csc order (w_csc [n_ch][ld_w_csc]: plane c holds w[c][csc_order[e]] at e, from
- * dgn_edge_weights_to_csc; NULL = dgn_agg_backward).  When g->csc_dst is set, the list has no max / min / std / var, the graph has more
- * than three in-edges per row on average and no hub rows, the gradients are defined (accumulate == 0) and no per-edge gradient is
- * asked for, the per-edge gradient rows are never materialised: the row kernel parks each row's coefficient vectors
- * ([N][1 + n_ch (1 + dir-av)][F] in the workspace) and a second kernel walks every source's out-edges, gathering the destinations'
- * coefficient rows -- the same expression and order of additions as the staged path (bit-identical), 2 E F floats less traffic.
- * Any other case takes the staged / atomic path of dgn_agg_backward.  DGN_NO_PULL=1 disables it.                                */
-int dgn_agg_backward_csc(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
-                         const float* w_csc, int64_t ld_w_csc, const float* log_deg, const float* g_out, int64_t ld_gout,
-                         const DgnMsgGrad* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* Degree scalers folded behind the post-aggregation Linear (they are per-row factors):
  *     y[n, t*f_out + o] = row_scale[n] * (bias[t*f_out + o] + sum_s scale[n, s] * z[t][n][s*f_out + o])
@@ -445,11 +432,6 @@ int dgn_graph_build(int64_t n_nodes, int64_t n_edges, const int64_t* src, const 
                     void* ws, size_t ws_bytes, void* stream);
 int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, int32_t* csc_ptr, int32_t* csc_pos,
                         int32_t* csc_order, void* ws, size_t ws_bytes, void* stream);
-/* csc_dst[e] = destination row of csc entry e (the row whose slot range holds slot csc_order[e]); and the edge weights permuted
- * into csc order, w_csc[c][e] = w[c][csc_order[e]] -- the two extra inputs of dgn_agg_backward_csc's pull path.                */
-int dgn_graph_csc_dst(int64_t n_nodes, int64_t n_edges, const int32_t* indptr, const int32_t* csc_order, int32_t* csc_dst, void* stream);
-int dgn_edge_weights_to_csc(int64_t n_edges, int32_t n_channels, const float* w, int64_t ld_w, const int32_t* csc_order,
-                            float* w_csc, int64_t ld_w_csc, void* stream);
 
 
 /* ---- whole towers layer in one call (dgn_towers.hip) ------------------------------------------------------------------
@@ -534,8 +516,6 @@ typedef struct DgnDenseLayer {
     float* out;                /* [N, f_out]  (forward only)                                                 */
     void* ws; size_t ws_bytes;
     const int64_t* n_valid;    /* DEVICE scalar or NULL (padded batches, see dgn_bn_tail_forward)            */
-    const float* w_csc;        /* backward only, optional: the edge weights in csc order (dgn_agg_backward_csc) */
-    int64_t ld_w_csc;
 } DgnDenseLayer;
 typedef struct DgnDenseGrads {
     const float* g_out;        /* [N, f_out]                                                                 */
