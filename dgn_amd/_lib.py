@@ -268,3 +268,11 @@ def load() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise DgnError(f"{what} failed (rc={rc}): {load().dgn_last_error().decode()}")
+
+
+def stream_ptr(device) -> int:
+    """Raw handle of torch's current stream on ``device`` (what every entry point takes as its ``stream`` argument).
+    ``torch.cuda.current_stream(d).cuda_stream`` builds a Stream object per call (~7 us of an eager step that is launch-bound)."""
+    import torch
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)

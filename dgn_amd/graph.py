@@ -17,6 +17,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
+import functools
+
 import torch
 
 from . import _lib
@@ -116,7 +118,7 @@ class DGNGraph:
             raise ValueError(f"batch ({N} nodes, {E} edges) exceeds the capacity ({pad['n_cap']}, {pad['e_cap']})")
         dev = self.device
         src64, dst64 = src.to(dev).long().contiguous(), dst.to(dev).long().contiguous()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         n_cap = pad["n_cap"]
         _lib.check(lib.dgn_graph_build(n_cap, E, _ptr(src64), _ptr(dst64), self.indptr.data_ptr(), self.src.data_ptr(), self.dst_csr.data_ptr(),
                                        self.eid.data_ptr(), self.log_deg.data_ptr(), self.in_degree.data_ptr(), self._stats.data_ptr(),
@@ -159,7 +161,7 @@ class DGNGraph:
         stats = i32(4)
         nbytes = lib.dgn_graph_build_workspace_bytes(num_nodes, E)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_graph_build(num_nodes, E, _ptr(src64), _ptr(dst64), indptr.data_ptr(), _ptr(src_csr), _ptr(dst_csr), _ptr(eid),
                                        log_deg.data_ptr(), deg.data_ptr(), stats.data_ptr(), int(hub_threshold), ws.data_ptr(), nbytes,
                                        stream), "dgn_graph_build")
@@ -234,7 +236,7 @@ class DGNGraph:
         lib = _lib.load()
         N, E, dev = self.num_nodes, self.num_edges, self.device
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.csc_ptr, self.csc_pos, order = i32(N + 1), i32(E), i32(E)
@@ -290,6 +292,7 @@ class DGNGraph:
         return ent[1]
 
 
+@functools.lru_cache(maxsize=64)
 def _channel_array(channels: Tuple[Channel, ...]):
     arr = (_lib.DgnChannel * len(channels))()
     for i, (kind, col, alpha) in enumerate(channels):
@@ -307,7 +310,7 @@ def compute_edge_weights(graph: DGNGraph, channels: Tuple[Channel, ...], eig: Op
     E = graph.num_edges
     w = torch.empty((len(channels), max(E, 1)), dtype=torch.float32, device=ref.device)
     ld = ref.stride(0) if ref.dim() == 2 and ref.shape[0] > 0 else ref.shape[-1]
-    stream = torch.cuda.current_stream(ref.device).cuda_stream
+    stream = _lib.stream_ptr(ref.device)
     for c0 in range(0, len(channels), _lib.DGN_MAX_CH):
         chunk = channels[c0:c0 + _lib.DGN_MAX_CH]
         for ch in chunk:

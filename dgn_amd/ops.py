@@ -116,7 +116,7 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
     F = ref.shape[1]
-    stream = torch.cuda.current_stream(ref.device).cuda_stream
+    stream = _lib.stream_ptr(ref.device)
     tower_stride, ld_out = _out_layout(out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
     msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
@@ -144,7 +144,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
     grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
     grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
     msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.stream_ptr(dev)
     tower_stride, ld_gout = _out_layout(g_out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
     g = graph.c_graph
@@ -308,7 +308,7 @@ class _ScaleCombine(torch.autograd.Function):
         fo = W // S
         z = z.contiguous()
         y = torch.empty((N, T * fo), dtype=torch.float32, device=z.device)
-        stream = torch.cuda.current_stream(z.device).cuda_stream
+        stream = _lib.stream_ptr(z.device)
         rc = lib.dgn_scale_combine_forward(N, T, S, fo, z.data_ptr(), _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(),
                                            y.stride(0), stream)
         _lib.check(rc, "dgn_scale_combine_forward")
@@ -326,7 +326,7 @@ class _ScaleCombine(torch.autograd.Function):
         g_b = torch.zeros(T * fo, dtype=torch.float32, device=g_y.device) if (has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.dgn_scale_combine_backward_workspace_bytes(N, T, fo) if g_b is not None else 0
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=g_y.device) if ws_bytes else None
-        stream = torch.cuda.current_stream(g_y.device).cuda_stream
+        stream = _lib.stream_ptr(g_y.device)
         rc = lib.dgn_scale_combine_backward(N, T, S, fo, g_y.data_ptr(), g_y.stride(0), _ptr(scale), _ptr(row_scale),
                                             g_z.data_ptr(), _ptr(g_b), _ptr(ws), ws_bytes, None, stream)
         _lib.check(rc, "dgn_scale_combine_backward")
@@ -364,7 +364,7 @@ class _BNTail(torch.autograd.Function):
         save_invstd = torch.empty(F, dtype=torch.float32, device=x.device)
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F) if training else 0
         ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         ctx.n_valid = _N_VALID
         rc = lib.dgn_bn_tail_forward(N, F, x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                      float(momentum), float(eps), 1 if training else 0, 1 if relu else 0, _ptr(residual), y.data_ptr(),
@@ -385,7 +385,7 @@ class _BNTail(torch.autograd.Function):
         g_beta = torch.empty(F, dtype=torch.float32, device=x.device) if beta is not None else None
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         rc = lib.dgn_bn_tail_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
                                       save_invstd.data_ptr(), 1 if ctx.relu else 0, g_x.data_ptr(), _ptr(g_gamma), _ptr(g_beta),
                                       None, ws.data_ptr(), ws_bytes, _ptr(ctx.n_valid), stream)
@@ -409,7 +409,7 @@ class _CombineBNTail(torch.autograd.Function):
         F = T * fo
         z = z.contiguous()
         dev = z.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         y = torch.empty((N, F), dtype=torch.float32, device=dev)
         rc = lib.dgn_scale_combine_forward(N, T, S, fo, z.data_ptr(), _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
         _lib.check(rc, "dgn_scale_combine_forward")
@@ -437,7 +437,7 @@ class _CombineBNTail(torch.autograd.Function):
         F = T * fo
         dev = y.device
         g_out = g_out.contiguous()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         g_gamma = torch.empty(F, dtype=torch.float32, device=dev) if gamma is not None else None
         g_beta = torch.empty(F, dtype=torch.float32, device=dev) if beta is not None else None
         sums = torch.empty(2 * F, dtype=torch.float32, device=dev)
@@ -493,7 +493,7 @@ class _BiasAct(torch.autograd.Function):
         if bias is not None:
             bias = bias.contiguous()
         y = torch.empty_like(x)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         rc = lib.dgn_bias_act_forward(N, F, x.data_ptr(), x.stride(0), _ptr(bias), act, float(slope), _ptr(residual), y.data_ptr(), stream)
         _lib.check(rc, "dgn_bias_act_forward")
         ctx.save_for_backward(x, bias)
@@ -510,7 +510,7 @@ class _BiasAct(torch.autograd.Function):
         g_b = torch.empty(F, dtype=torch.float32, device=x.device) if (bias is not None and ctx.needs_input_grad[1]) else None
         ws_bytes = lib.dgn_bn_tail_workspace_bytes(N, F)
         ws = torch.empty(max(ws_bytes // 8, 1), dtype=torch.float64, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         rc = lib.dgn_bias_act_backward(N, F, g_y.data_ptr(), x.data_ptr(), x.stride(0), _ptr(bias), ctx.act, ctx.slope, g_x.data_ptr(),
                                        _ptr(g_b), ws.data_ptr(), ws_bytes, stream)
         _lib.check(rc, "dgn_bias_act_backward")
@@ -586,7 +586,7 @@ def _lin_fwd(lib, a, w, w_is_kn, bias, n):
     """a [T, M, k] dense, w [T, n, k] (or [T, k, n] with w_is_kn) -> [T, M, n]"""
     T, M, k = a.shape
     c = torch.empty(T, M, n, dtype=torch.float32, device=a.device)
-    stream = torch.cuda.current_stream(a.device).cuda_stream
+    stream = _lib.stream_ptr(a.device)
     rc = lib.dgn_linear_forward(M, k, n, T, a.data_ptr(), k, a.stride(0), w.data_ptr(), w.stride(1), w.stride(0), int(w_is_kn),
                                 _ptr(bias), bias.stride(0) if bias is not None else 0, c.data_ptr(), n, M * n, stream)
     _lib.check(rc, "dgn_linear_forward")
@@ -676,7 +676,7 @@ class _WideLinear(torch.autograd.Function):
         M, k = x.shape
         n = w.shape[0]
         c = torch.empty((M, n), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         rc = lib.dgn_gemm_forward(M, k, n, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), 0, _ptr(bias.contiguous() if bias is not None else None),
                                   c.data_ptr(), n, stream)
         _lib.check(rc, "dgn_gemm_forward")
@@ -691,7 +691,7 @@ class _WideLinear(torch.autograd.Function):
         M, k = x.shape
         n = w.shape[0]
         g = g.contiguous()
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
             g_x = torch.empty((M, k), dtype=torch.float32, device=x.device)
@@ -760,7 +760,7 @@ class _PairLinear(torch.autograd.Function):
         x, w = x.contiguous(), w.contiguous()
         M, Fm = x.shape
         c = torch.empty((M, 2 * Fm), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         _lib.check(lib.dgn_linear_bd_forward(M, T, fi, x.data_ptr(), w.data_ptr(), w.stride(0), _ptr(bias.contiguous() if bias is not None else None),
                                              c.data_ptr(), stream), "dgn_linear_bd_forward")
         ctx.save_for_backward(x, w)
@@ -774,7 +774,7 @@ class _PairLinear(torch.autograd.Function):
         T, fi = ctx.dims
         M, Fm = x.shape
         g = g.contiguous()
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
             g_x = torch.empty_like(x)
@@ -806,7 +806,7 @@ def _lin_wgrad(lib, g, x, want_bias):
     g_b = torch.empty(T, n, dtype=torch.float32, device=x.device) if (want_bias and k % 16 != 0) else None
     ws_bytes = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, T)
     ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
-    stream = torch.cuda.current_stream(x.device).cuda_stream
+    stream = _lib.stream_ptr(x.device)
     rc = lib.dgn_linear_wgrad(M, k, n, T, g.data_ptr(), n, g.stride(0), x.data_ptr(), k, x.stride(0), g_w.data_ptr(), k, n * k,
                               _ptr(g_b), n, ws.data_ptr(), ws_bytes, stream)
     _lib.check(rc, "dgn_linear_wgrad")
@@ -831,7 +831,7 @@ class _LinCombineBNTail(torch.autograd.Function):
         fo = w.shape[1] // S
         F = T * fo
         dev = aggx.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         y = torch.empty((N, F), dtype=torch.float32, device=dev)
         rc = lib.dgn_linear_combine_forward(N, k, T, S, fo, aggx.data_ptr(), aggx.stride(0), w.data_ptr(), w.stride(1), w.stride(0),
                                             _ptr(scale), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
@@ -860,7 +860,7 @@ class _LinCombineBNTail(torch.autograd.Function):
         F, k = T * fo, aggx.shape[2]
         dev = y.device
         g_out = g_out.contiguous()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         g_gamma = torch.empty(F, dtype=torch.float32, device=dev) if gamma is not None else None
         g_beta = torch.empty(F, dtype=torch.float32, device=dev) if beta is not None else None
         sums = torch.empty(2 * F, dtype=torch.float32, device=dev)
@@ -951,6 +951,18 @@ def _carve(sizes, device):
     return buf, [buf[o:o + n] for o, n in zip(offs, sizes)]
 
 
+def _carve_ptrs(sizes, device, buf=None):
+    """_carve for callers that only pass addresses on: (buffer, [address or None per view]) -- no view tensors are created"""
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) & ~63
+    if buf is None:
+        buf = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    base = buf.data_ptr()
+    return buf, [base + 4 * o if n else None for o, n in zip(offs, sizes)]
+
+
 class _TowersLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var,
@@ -988,7 +1000,7 @@ class _TowersLayer(torch.autograd.Function):
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
         ctx.n_valid = _N_VALID
         L.n_valid = _ptr(ctx.n_valid)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_towers_layer_forward(C.byref(L), stream), "dgn_towers_layer_forward")
         ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf)
         ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
@@ -1034,7 +1046,7 @@ class _TowersLayer(torch.autograd.Function):
         G = _lib.DgnTowersGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_w_sd=g_w_sd.data_ptr(), g_bias_sd=g_bias_sd.data_ptr(),
                                 g_w_post=g_w_post.data_ptr(), g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(),
                                 g_beta=g_beta.data_ptr(), g_w_mix=g_w_mix.data_ptr(), g_b_mix=g_b_mix.data_ptr())
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_towers_layer_backward(C.byref(L), C.byref(G), stream), "dgn_towers_layer_backward")
         return (None, None, None, None, None, g_h, None, None, None, None, g_w_sd.view(2 * Fm, Fm), g_bias_sd, g_w_post.view(T, S * fo, K),
                 g_b_post, g_gamma, g_beta, g_w_mix.view(Fo, Fo), g_b_mix)
@@ -1093,8 +1105,7 @@ def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_p
     L.h, L.snorm, L.scale = h.data_ptr(), _ptr(snorm), _ptr(scale)
     L.w_pre, L.b_pre, L.w_post, L.b_post = _ptr(w_pre), _ptr(b_pre), w_post.data_ptr(), _ptr(b_post)
     L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
-    q = lambda t: t.data_ptr() if t.numel() else None
-    L.hp, L.pq, L.agg, L.y, L.wf, L.wsd, L.save_mean, L.save_invstd = q(hp), q(pq), q(agg), q(y), q(wf), q(wsd), q(mean), q(invstd)
+    L.hp, L.pq, L.agg, L.y, L.wf, L.wsd, L.save_mean, L.save_invstd = hp, pq, agg, y, wf, wsd, mean, invstd          # (addresses, _carve_ptrs)
     L.n_valid = _ptr(n_valid)
     return L, (cg, spec)
 
@@ -1110,7 +1121,7 @@ class _DenseLayer(torch.autograd.Function):
         h, w_post, gamma, beta = h.contiguous(), w_post.contiguous(), gamma.contiguous(), beta.contiguous()
         w_pre = w_pre.contiguous() if w_pre is not None else None
         sizes, Fp, K = _dense_sizes(cfg, N)
-        saved_buf, bufs = _carve(sizes, dev)
+        saved_buf, bufs = _carve_ptrs(sizes, dev)
         out = torch.empty((N, fo), dtype=torch.float32, device=dev)
         ctx.n_valid = _N_VALID
         L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
@@ -1118,7 +1129,7 @@ class _DenseLayer(torch.autograd.Function):
         nbytes = lib.dgn_dense_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_dense_layer_forward(C.byref(L), stream), "dgn_dense_layer_forward")
         ctx.save_for_backward(w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf)
         ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
@@ -1132,11 +1143,7 @@ class _DenseLayer(torch.autograd.Function):
         type_net, F0, fo = cfg[:3]
         N, dev = h.shape[0], h.device
         sizes, Fp, K = _dense_sizes(cfg, N)
-        offs, total = [], 0
-        for n in sizes:
-            offs.append(total)
-            total += (n + 63) & ~63
-        bufs = [saved_buf[o:o + n] for o, n in zip(offs, sizes)]
+        _, bufs = _carve_ptrs(sizes, dev, saved_buf)
         g_out = g_out.contiguous()
         graph.ensure_csc()
         L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
@@ -1149,7 +1156,7 @@ class _DenseLayer(torch.autograd.Function):
         q = lambda t: t.data_ptr() if t.numel() else None
         G = _lib.DgnDenseGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_w_pre=q(g_w_pre), g_b_pre=q(g_b_pre), g_w_post=g_w_post.data_ptr(),
                                g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(), g_beta=g_beta.data_ptr())
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_dense_layer_backward(C.byref(L), C.byref(G), stream), "dgn_dense_layer_backward")
         return (None, None, None, None, None, g_h, None, None, None, None,
                 g_w_pre.view_as(w_pre) if w_pre is not None else None, g_b_pre if (b_pre is not None and type_net == 1) else None,
@@ -1209,7 +1216,7 @@ def fused_sweep_posttrans_forward(graph: DGNGraph, plan: AggPlan, n_towers: int,
     y = torch.empty((N, T * fo), dtype=torch.float32, device=x_in.device)
     if row_scale is not None:
         row_scale = row_scale.reshape(-1).contiguous()
-    stream = torch.cuda.current_stream(x_in.device).cuda_stream
+    stream = _lib.stream_ptr(x_in.device)
     rc = lib.dgn_layer_fused_forward(C.byref(graph.c_graph), C.byref(spec), C.byref(msg), _ptr(w_edge), w_edge.stride(0) if w_edge is not None else 0,
                                      graph.log_deg.data_ptr(), weight.data_ptr(), weight.stride(1), weight.stride(0), S, fo,
                                      _ptr(scale.contiguous() if scale is not None else None), _ptr(bias), _ptr(row_scale), y.data_ptr(), y.stride(0), stream)
@@ -1232,7 +1239,7 @@ class _AssembleOperands(torch.autograd.Function):
             maps["ptr_host"] = ptrs
         dev = params[0].device
         out = torch.empty(maps["total"], dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_assemble_params(maps["total"], maps["ptr_table"].data_ptr(), maps["map_param"].data_ptr(), maps["map_off"].data_ptr(),
                                            out.data_ptr(), stream), "dgn_assemble_params")
         ctx.maps = maps
