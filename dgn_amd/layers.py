@@ -1,6 +1,7 @@
 """FCLayer / MLP with the reference's constructor arguments, init and state_dict layout
-(realworld_benchmark/nets/layers.py:21-154).  These are the dense pre/post-aggregation
-transforms: plain torch.nn.functional.linear -> hipBLASLt/rocBLAS (fp32 MFMA) on MI355X.
+(realworld_benchmark/nets/layers.py:21-154).  These are the dense pre/post-aggregation transforms.  The Linear inside goes
+through ``ops.node_linear``: the library's own fp32-MFMA kernels (``dgn_linear_*`` up to 160 columns, ``dgn_gemm_*`` beyond) from a
+few thousand rows on, ``torch.nn.functional.linear`` only for smaller batches.
 """
 from __future__ import annotations
 
