@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows(const AggParams p) {
 // batches (2-3 edges per row) need 4 rows per workgroup.
 inline int row_waves_per_block(const AggParams& p) {
     static const char* env = getenv("DGN_ROW_WPB");
-    if (env) return atoi(env) == 1 ? 1 : 4;
+    if (env) { const int v = atoi(env); return v == 1 ? 1 : (v == 2 ? 2 : 4); }
     return (p.n_edges >= 8 * p.n_nodes) ? 1 : 4;
 }
 

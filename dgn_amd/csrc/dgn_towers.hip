@@ -76,6 +76,30 @@ bool use_bd(const DgnTowersLayer* L, const Dims& d) {
     return !off && dgn_linear_bd_supported(d.T, d.fi) && ((reinterpret_cast<uintptr_t>(L->h) | reinterpret_cast<uintptr_t>(L->pq)) & 15) == 0;
 }
 
+// Weight-gradient products on a second stream: they depend on their operands only, not on each other or on the input-gradient chain
+// (act -> BatchNorm -> combine -> posttrans input gradient -> sweep -> P|Q input gradient), which is a chain of memory-bound kernels
+// that leave the MFMA pipes idle.  fork(): the side stream waits for everything enqueued on the main stream so far; join(): the main
+// stream waits for the side stream.  Events are reused (a wait refers to the record that precedes it).
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
+    bool ok = false;
+    bool init() {
+        if (ok) return true;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        for (auto& e : ev_fork) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+    bool fork(hipStream_t main, int i) { return hipEventRecord(ev_fork[i], main) == hipSuccess && hipStreamWaitEvent(side, ev_fork[i], 0) == hipSuccess; }
+    bool join(hipStream_t main) { return hipEventRecord(ev_join, side) == hipSuccess && hipStreamWaitEvent(main, ev_join, 0) == hipSuccess; }
+};
+SideStream& side_stream() {
+    static thread_local SideStream s;
+    return s;
+}
+
 DgnMsg sweep_msg(const DgnTowersLayer* L, const Dims& d) {
     DgnMsg m{};
     m.F = d.Fm;
@@ -199,10 +223,19 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // g_z = g_out * act'(z + b_mix) is formed while the strips are staged and leaves as a side output for the weight gradient, whose
     // ones-column delivers the bias gradient (the separate path: dgn_bias_act_backward, then the two products)
     const bool fused_act = L->y1 == nullptr && d.Fo % 16 != 0 && (reinterpret_cast<uintptr_t>(g_z) & 15) == 0 && dgn_linear_act_supported(d.Fo, d.Fo);
+    // DGN_BWD_AUX=2: the three weight-gradient products go to a second stream and overlap the input-gradient chain including the
+    // sweep: step 1.55 -> 1.51 ms on ZINC-12k, the co-running sweep stretching from 0.215 to 0.35 ms.  =1: the same with the sweep kept
+    // alone: no gain.  Off by default: 3 % of the step against kernel times in a profile that no longer say what a kernel can do.
+    const char* aux_s = getenv("DGN_BWD_AUX");                  // (read per call: the bench switches it)
+    const bool aux_env = aux_s != nullptr && atoi(aux_s) != 0;
+    SideStream& ss = side_stream();
+    const bool aux = aux_env && fused_act && ss.init();
+    void* wstream = aux ? static_cast<void*>(ss.side) : stream;          // where the weight-gradient products go
     if (fused_act) {
         DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
+        if (aux && !ss.fork(st, 0)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }
         DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
-                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), wstream));
     } else {
         DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
                                       dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
@@ -227,6 +260,7 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // NOT the default: measured 0.53 ms against 0.36 ms for the two separate kernels on ZINC-12k -- a persistent
     // workgroup's sixteen waves start their dependent load chains together after every barrier, where the stand-alone sweep's
     // workgroups are staggered.
+    if (aux && !ss.fork(st, 1)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }          // (g_yr is ready: the weight gradient may start)
     const char* fb_env = getenv("DGN_FUSED_BACKWARD");          // (read per call: the tests switch it)
     const bool fused_bwd = fb_env && atoi(fb_env) != 0 && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
     if (!fused_bwd)
@@ -234,7 +268,10 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                                                   g_aggx, d.N * d.K, stream));
     DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
                                                (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
-                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
+                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), wstream));
+    // (the sweep runs alone: co-running it with a weight gradient stretched it from 0.215 to 0.35 ms for a net 2 %)
+    const bool aux_over_sweep = aux_s != nullptr && atoi(aux_s) == 2;
+    if (aux && !aux_over_sweep && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
     // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
     const DgnMsg msg = sweep_msg(L, d);
     DgnMsgGrad gr{};
@@ -258,11 +295,15 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     const bool fused_add = !no_add_epilogue && al && (reinterpret_cast<uintptr_t>(g_in) & 15) == 0 && dgn_linear_add_supported(2 * d.Fm, d.Fm);
     if (use_bd(L, d) && al && ((reinterpret_cast<uintptr_t>(g_in) | reinterpret_cast<uintptr_t>(g_pq)) & 15) == 0) {
         // the towers' own blocks only: (d h_in + (d P|Q) W_sd) + residual in the product's epilogue, add3's order
+        if (aux && !ss.fork(st, 2)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }
         DGN_TRY(dgn_linear_bd_backward_input(d.N, d.T, d.fi, g_pq, L->w_sd, d.Fm, g_in, res, G->g_h, stream));
         DGN_TRY(dgn_linear_bd_wgrad(d.N, d.T, d.fi, g_pq, L->h, G->g_w_sd, d.Fm, G->g_bias_sd, ws + s.wg_sd,
-                                    dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), stream));
+                                    dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), wstream));
+        if (aux && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
         return DGN_OK;
     }
+    if (aux && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
+    wstream = stream;
     if (fused_add) DGN_TRY(dgn_linear_forward_add(d.N, 2 * d.Fm, d.Fm, g_pq, L->w_sd, d.Fm, 1, g_in, res, G->g_h, stream));
     else DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
     DGN_TRY(dgn_linear_wgrad(d.N, d.Fm, 2 * d.Fm, 1, g_pq, 2 * d.Fm, 0, L->h, d.Fm, 0, G->g_w_sd, d.Fm, 0, G->g_bias_sd, 0, ws + s.wg_sd,
