@@ -292,14 +292,21 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
     DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_agg, d.K, &gr, ws + s.agg_ws,
                              dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1), stream));
     const float* g_res = L->residual ? G->g_out : nullptr;
+    bool fused_dh = false;
     if (d.cx) {
         // pretrans P|Q Linear: input gradient (transposed weight), weight + bias gradient, un-folded
         const float* wsdt = L->wsd + (size_t)2 * d.Fp * d.Fp;
-        DGN_TRY(lin_fwd(d.N, 2 * d.Fp, d.Fp, g_pq, wsdt, nullptr, g_hq, stream));
+        // even hidden size: d h = (d h_in + (d P|Q) W_sd) + residual leaves as the product's epilogue (unpad_add's order of additions)
+        const bool al16 = ((reinterpret_cast<uintptr_t>(g_pq) | reinterpret_cast<uintptr_t>(g_hp) | reinterpret_cast<uintptr_t>(G->g_h) |
+                            reinterpret_cast<uintptr_t>(g_res)) & 15) == 0;
+        fused_dh = d.Fp == d.F0 && al16 && dgn_linear_supported(2 * d.Fp, d.Fp, 0) && dgn_linear_add_supported(2 * d.Fp, d.Fp);
+        if (fused_dh) DGN_TRY(dgn_linear_forward_add(d.N, 2 * d.Fp, d.Fp, g_pq, wsdt, 2 * d.Fp, 0, g_hp, g_res, G->g_h, stream));
+        else DGN_TRY(lin_fwd(d.N, 2 * d.Fp, d.Fp, g_pq, wsdt, nullptr, g_hq, stream));
         DGN_TRY(lin_wgrad(d.N, d.Fp, 2 * d.Fp, g_pq, hp, g_wsd, g_bsd, ws + s.wg_ws, wgrad_ws(d.N, d.Fp, 2 * d.Fp), stream));
         hipLaunchKernelGGL(unfold_pre, dim3(nblk((int64_t)2 * d.F0 * d.F0)), dim3(256), 0, st, d.F0, d.Fp, (int64_t)2 * d.F0, g_wsd, g_bsd, G->g_w_pre, G->g_b_pre);
     }
     // d h = d h_in (+ d x_src, same buffer) [+ (d P|Q) W_sd] [+ residual], un-padded
+    if (fused_dh) return DGN_OK;
     hipLaunchKernelGGL(unpad_add, dim3(nblk(d.N * d.F0)), dim3(256), 0, st, d.N, d.F0, d.Fp, g_hp, d.cx ? g_hq : nullptr, g_res, G->g_h);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
