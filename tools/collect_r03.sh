@@ -11,7 +11,7 @@ python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_defa
 for tag in c2 c1 c5; do
   tools/gpu_profile.sh $tag --workload $tag --no-extras --no-cpu-baseline $( [ $tag = c5 ] && echo "--steps 3 --warmup 1" ) > /dev/null 2>&1
 done
-for tag in c3 c4 c2c c2e zinc_json pattern_json; do
+for tag in c3 c4 c2c c2e zinc_json pattern_json c3_mega; do
   out="gpurun_out/prof_$tag"; mkdir -p "$out"
   timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o "$tag" -- python bench.py --workload $tag --no-extras --no-cpu-baseline > "$out/trace.log" 2>&1
 done
@@ -19,6 +19,10 @@ sq="gpurun_out/pmc_sq_c2"; mkdir -p "$sq"
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$sq/a" -o c2 -- python bench.py --no-extras --no-cpu-baseline > "$sq/a.log" 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d "$sq/b" -o c2 -- python bench.py --no-extras --no-cpu-baseline > "$sq/b.log" 2>&1
 { echo "# rocprofv3 --pmc (two passes), fractions of SQ_WAVE_CYCLES per kernel, c2 (bench.py --no-extras): tools/pmc_sq_summary.py"; python tools/pmc_sq_summary.py "$sq/a"; echo; python tools/pmc_sq_summary.py "$sq/b"; } > gpurun_out/r03_c2_sq_counters.txt 2>&1
+tools/microbench/mfma_peak > gpurun_out/r03_mfma_peak.txt 2>&1
+tools/microbench/rowwrite > gpurun_out/r03_rowwrite.txt 2>&1
+python tools/exp_gemm.py 2>&1 | grep -v "^W\|amdgpu.ids" > gpurun_out/r03_gemm.txt
+python tools/exp_linear.py 2>&1 | grep -v "^W\|amdgpu.ids" > gpurun_out/r03_linear.txt
 # keep the merge-back small: the per-launch traces are not needed
 find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*.db" -delete; find gpurun_out/pmc_sq_c2 -name "*counter_collection.csv" -delete
 ls gpurun_out | head -40
