@@ -14,13 +14,13 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
@@ -79,7 +79,8 @@ class DgnTowersLayer(C.Structure):
                 ("w_post", C.c_void_p), ("b_post", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
-                ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p)]
+                ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
+                ("zmask", C.c_void_p)]
 
 
 class DgnTowersGrads(C.Structure):
@@ -142,6 +143,14 @@ def load() -> C.CDLL:
         lib.dgn_linear_forward_add.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
         lib.dgn_linear_forward_bn_act.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, C.c_float, vp, vp, vp, vp]
         lib.dgn_linear_wgrad_bn.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.dgn_linear_act_mask_bytes.restype = C.c_size_t
+        lib.dgn_linear_act_mask_bytes.argtypes = [C.c_int64, C.c_int32]
+        lib.dgn_linear_forward_bn_act_mask.restype = C.c_int
+        lib.dgn_linear_forward_bn_act_mask.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, C.c_float, vp, vp, vp, vp]
+        lib.dgn_linear_forward_act_mask.restype = C.c_int
+        lib.dgn_linear_forward_act_mask.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp, vp, vp]
+        lib.dgn_towers_layer_zmask_supported.restype = C.c_int
+        lib.dgn_towers_layer_zmask_supported.argtypes = [C.c_int32, C.c_int32]
         lib.dgn_agg_edge_table_workspace_bytes.restype = C.c_size_t
         lib.dgn_agg_edge_table_workspace_bytes.argtypes = [C.c_int64, C.c_int32]
         lib.dgn_agg_forward.restype = C.c_int

@@ -41,8 +41,8 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
     const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr, addm = p.add1 != nullptr;
-    const bool mixm = p.out2 != nullptr;
-    const int mode = mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (addm ? kAddPlain : kPlain)));
+    const bool mixm = p.out2 != nullptr, maskm = p.act_mask != nullptr;
+    const int mode = mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (maskm ? kActMask : (addm ? kAddPlain : kPlain))));
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
@@ -60,6 +60,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
                        : mixm    ? launch_linear_mix(NT, KB, p, waves * 64, lds, st)
                        : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
                        : actm    ? launch_linear_act(NT, KB, p, waves * 64, lds, st)
+                       : maskm   ? launch_linear_actm(NT, KB, p, waves * 64, lds, st)
                        : addm    ? launch_linear_add(NT, KB, p, waves * 64, lds, st)
                                  : launch_linear_plain(NT, KB, p, waves * 64, lds, st);
     DGN_HIP_CHECK(e);
@@ -158,6 +159,41 @@ extern "C" int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, cons
     p.A = g; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
     p.C = c;
     p.act_z = z; p.act_bias = act_bias; p.act_kind = act; p.act_slope = slope; p.gz_out = gz_out;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" size_t dgn_linear_act_mask_bytes(int64_t n_rows, int32_t n) { return n_rows > 0 && n > 0 ? (((size_t)n_rows * n / 2) + 15) & ~(size_t)15 : 0; }
+
+extern "C" int dgn_linear_forward_bn_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, const float* bn_mean,
+                                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const float* act_bias, int32_t act,
+                                              float slope, const float* residual, unsigned char* zmask_out, float* out, void* stream) {
+    const char* fn = "dgn_linear_forward_bn_act_mask";
+    if (n_rows < 0 || !dgn_linear_add_supported(k, n)) { set_error("%s: widths outside the supported set (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!a || !w || !zmask_out || !out || !bn_mean || !bn_invstd) { set_error("%s: null operand", fn); return -1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!aligned8(a) || !al16(zmask_out) || !al16(out) || (residual && !al16(residual))) { set_error("%s: a must be 8-byte, zmask_out / out / residual 16-byte aligned", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = a; p.W = w; p.ldw = ldw; p.w_kn = 0;
+    p.C = nullptr; p.zmask_out = zmask_out;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    p.ep_bias = act_bias; p.act_kind = act; p.act_slope = slope; p.add1 = residual; p.out2 = out;
+    return launch_linear(fn, p, stream);
+}
+
+extern "C" int dgn_linear_forward_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                           const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream) {
+    const char* fn = "dgn_linear_forward_act_mask";
+    if (n_rows < 0 || !dgn_linear_act_supported(k, n)) { set_error("%s: need even k, n in [2, 160] (k=%d n=%d)", fn, k, n); return -1; }
+    if (n_rows == 0) return 0;
+    if (!g || !zmask || !w || !c) { set_error("%s: null operand", fn); return -1; }
+    if (!aligned8(g) || (reinterpret_cast<uintptr_t>(zmask) & 1) || !aligned8(c) || (gz_out && (reinterpret_cast<uintptr_t>(gz_out) & 15))) { set_error("%s: g / c must be 8-byte aligned (dense rows), zmask 2-byte, gz_out 16-byte aligned", fn); return -1; }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = g; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
+    p.C = c;
+    p.act_mask = zmask; p.act_kind = act; p.act_slope = slope; p.gz_out = gz_out;
     return launch_linear(fn, p, stream);
 }
 

@@ -59,6 +59,10 @@ struct LinParams {
     // kActPlain: the operand is a * act'(z + bias[c]) -- the gradient through bias + activation (dgn_bias_act_backward's arithmetic) --
     // formed while the strip is staged from a and z (both [M, k] dense); gz_out (may be NULL) receives the formed operand
     const float* act_z; const float* act_bias; int act_kind; float act_slope; float* gz_out;
+    // kActMask: the activation's derivative comes from a byte mask instead of z: byte i2 describes the float2 number i2 of the dense [M, k]
+    // tensor, bit 0 / bit 1 = (z + bias > 0) of its first / second element (written by kMixFwd with zmask_out set, which then does
+    // not write the pre-activation C at all: 1/8 of its bytes)
+    const unsigned char* act_mask; unsigned char* zmask_out;
     // kAddPlain: C = (add1 + A op(W)) + add2 -- two more [M, n] dense operands added in the epilogue (add2 may be NULL), the sum of
     // gradient contributions that otherwise costs its own pass
     const float* add1; const float* add2;
@@ -68,7 +72,7 @@ struct LinParams {
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 5 || mode == 6 ? 64 : 0)); }    // kBnPlain: column state; kActPlain: a second prefetched strip
+constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 7 ? 2 * KB + 28 : (mode == 5 || mode == 6 ? 64 : 0))); }    // kBnPlain: column state; kActPlain: a second prefetched strip
 constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
@@ -187,11 +191,49 @@ __device__ __forceinline__ void store_strip_act(float* Xl, const float2 (&pre)[N
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6 };        // ts_linear variants
+// kActMask: the mask bytes of a strip travel as the prefetch's second part: mz[jq] = byte of pre[2 jq] | byte of pre[2 jq + 1] << 8
+template <int NL>
+__device__ __forceinline__ void load_mask(unsigned (&mz)[NL / 2], const unsigned char* mask, int64_t M, int k, int64_t strip, int lane) {
+    const int64_t row0 = strip * kStrip;
+    const int n2 = (int)min((int64_t)kStrip, M - row0) * (k >> 1);               // float2's (= mask bytes) of the strip that exist
+    const unsigned char* base = mask + strip * (kStrip / 2) * k;                 // wave-uniform; 8 k bytes per strip
+    if (n2 == kStrip * (k >> 1)) {
+        const int last4 = (kStrip / 4) * k - 1;
+#pragma unroll
+        for (int jq = 0; jq < NL / 2; ++jq) mz[jq] = reinterpret_cast<const unsigned short*>(base)[min(jq * 64 + lane, last4)];
+    } else {
+#pragma unroll
+        for (int jq = 0; jq < NL / 2; ++jq)
+            mz[jq] = (unsigned)base[min(strip_idx2(2 * jq, lane), n2 - 1)] | ((unsigned)base[min(strip_idx2(2 * jq + 1, lane), n2 - 1)] << 8);
+    }
+}
+// store_strip_act with the derivative read from the mask (act_grad_lin's values: 1 where z + bias > 0, else slope / 0)
+template <int NL>
+__device__ __forceinline__ void store_strip_mask(float* Xl, const float2 (&pre)[NL], const unsigned (&mz)[NL / 2], int k, int lane, int act, float slope,
+                                                 float* gz, int n2) {
+    const float off = act == 2 ? slope : (act == 1 ? 0.f : 1.f);
+    auto tf = [&](float a, unsigned bit) { return a * (bit ? 1.f : off); };
+#pragma unroll
+    for (int jq = 0; jq < NL / 2; ++jq) {
+        const int q = jq * 64 + lane;
+        if (q < (kStrip / 4) * k) {
+            const unsigned m = mz[jq];
+            const float4 v = make_float4(tf(pre[2 * jq].x, m & 1u), tf(pre[2 * jq].y, m & 2u), tf(pre[2 * jq + 1].x, m & 0x100u), tf(pre[2 * jq + 1].y, m & 0x200u));
+            reinterpret_cast<float4*>(Xl)[q] = v;
+            if (gz) {
+                if (2 * q + 1 < n2) reinterpret_cast<float4*>(gz)[q] = v;
+                else if (2 * q < n2) reinterpret_cast<float2*>(gz)[2 * q] = make_float2(v.x, v.y);
+            }
+        }
+    }
+}
+
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6, kActMask = 7 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
 __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
     constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain, ADD = MODE == kAddPlain || MIX;
+    constexpr bool ACTM = MODE == kActMask;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -222,10 +264,12 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         fac = f4{scp[0], scp[min(1, S1 - 1)], scp[min(2, S1 - 1)], *rsp};
     };
     float2 prez[ACT ? NL : 1];
+    unsigned mz[ACTM ? NL / 2 : 1];
     auto fetch = [&](int64_t strip) {
         if constexpr (EXPAND) load_expand<NL>(pre, fac, p.ex, t, p.M, strip, lane);
         else { load_strip<NL>(pre, A, p.M, k, strip, lane); load_fac(strip); }
         if constexpr (ACT) load_strip<NL>(prez, p.act_z, p.M, k, strip, lane);
+        if constexpr (ACTM) load_mask<NL>(mz, p.act_mask, p.M, k, strip, lane);
     };
     if (first < n_strips) fetch(first);              // in flight while the weights are set up
 
@@ -298,9 +342,15 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
                     if constexpr (MIX) {
                         const int cc = (mix_c4 + jq * mix_d4) % n, c2 = cc + 2 >= n ? cc + 2 - n : cc + 2;
                         auto af = [&](float v) { return p.act_kind == 1 ? fmaxf(v, 0.f) : (p.act_kind == 2 ? (v > 0.f ? v : v * p.act_slope) : v); };
-                        float4 o = make_float4(af(c.x + Cb[cc]), af(c.y + Cb[cc + 1]), af(c.z + Cb[c2]), af(c.w + Cb[c2 + 1]));
+                        const float v0 = c.x + Cb[cc], v1 = c.y + Cb[cc + 1], v2 = c.z + Cb[c2], v3 = c.w + Cb[c2 + 1];
+                        float4 o = make_float4(af(v0), af(v1), af(v2), af(v3));
                         if (p.add1) o = make_float4(o.x + pe1[2 * jq].x, o.y + pe1[2 * jq].y, o.z + pe1[2 * jq + 1].x, o.w + pe1[2 * jq + 1].y);
                         reinterpret_cast<float4*>(p.out2 + out_strip * kStrip * n)[jq * 64 + lane] = o;
+                        if (p.zmask_out) {          // the backward's act'(z + b) as two mask bytes; the pre-activation itself is not written
+                            const unsigned m = (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 0x100u : 0u) | (v3 > 0.f ? 0x200u : 0u);
+                            reinterpret_cast<unsigned short*>(p.zmask_out + out_strip * (kStrip / 2) * n)[jq * 64 + lane] = (unsigned short)m;
+                            continue;
+                        }
                     } else if constexpr (ADD) {
                         c = make_float4(pe1[2 * jq].x + c.x, pe1[2 * jq].y + c.y, pe1[2 * jq + 1].x + c.z, pe1[2 * jq + 1].y + c.w);
                         if (p.add2) c = make_float4(c.x + pe2[2 * jq].x, c.y + pe2[2 * jq].y, c.z + pe2[2 * jq + 1].x, c.w + pe2[2 * jq + 1].y);
@@ -316,9 +366,14 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
                     if constexpr (MIX) {
                         const int cc = (2 * (j * 64 + lane)) % n;
                         auto af = [&](float v) { return p.act_kind == 1 ? fmaxf(v, 0.f) : (p.act_kind == 2 ? (v > 0.f ? v : v * p.act_slope) : v); };
-                        float2 o = make_float2(af(c.x + Cb[cc]), af(c.y + Cb[cc + 1]));
+                        const float v0 = c.x + Cb[cc], v1 = c.y + Cb[cc + 1];
+                        float2 o = make_float2(af(v0), af(v1));
                         if (p.add1) o = make_float2(o.x + pe1[j].x, o.y + pe1[j].y);
                         reinterpret_cast<float2*>(p.out2 + out_strip * kStrip * n)[j * 64 + lane] = o;
+                        if (p.zmask_out) {
+                            p.zmask_out[out_strip * (kStrip / 2) * n + j * 64 + lane] = (unsigned char)((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u));
+                            continue;
+                        }
                     } else if constexpr (ADD) {
                         c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
                         if (p.add2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
@@ -332,8 +387,9 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     auto load_adds = [&](int64_t s_) {
         if constexpr (ADD) {
             const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
-            const float* b1 = (p.add1 ? p.add1 : C) + s_ * kStrip * n;               // (branch-free loads; a NULL operand is not used)
-            const float* b2 = (p.add2 ? p.add2 : (p.add1 ? p.add1 : C)) + s_ * kStrip * n;
+            const float* any = MIX ? p.out2 : C;                                      // (kMixFwd with a mask output has no C)
+            const float* b1 = (p.add1 ? p.add1 : any) + s_ * kStrip * n;             // (branch-free loads; a NULL operand is not used)
+            const float* b2 = (p.add2 ? p.add2 : (p.add1 ? p.add1 : any)) + s_ * kStrip * n;
             if (cnt2 == kStrip * (n >> 1)) {
                 const int last4 = (kStrip / 4) * n - 1;
 #pragma unroll
@@ -358,6 +414,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         else if constexpr (BNP) store_strip_bn<NL>(Xl, pre, k, lane, Bn, KB * 16);
         else if constexpr (ACT) store_strip_act<NL>(Xl, pre, prez, k, lane, Bn, p.act_kind, p.act_slope,
                                                     p.gz_out ? p.gz_out + strip * kStrip * k : nullptr, (int)min((int64_t)kStrip, p.M - strip * kStrip) * (k >> 1));
+        else if constexpr (ACTM) store_strip_mask<NL>(Xl, pre, mz, k, lane, p.act_kind, p.act_slope,
+                                                      p.gz_out ? p.gz_out + strip * kStrip * k : nullptr, (int)min((int64_t)kStrip, p.M - strip * kStrip) * (k >> 1));
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16)
             *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = f4{p.sc ? fac[0] : 1.f, p.sc ? fac[1] : 1.f, p.sc ? fac[2] : 1.f, p.rs ? fac[3] : 1.f};
@@ -566,7 +624,7 @@ constexpr bool linear_add_shape_ok(int NT, int KB) { return 16 * NT + 4 * KB <= 
 
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
-    if constexpr ((MODE == kActPlain && !linear_act_shape_ok(NT, KB)) || ((MODE == kAddPlain || MODE == kMixFwd) && !linear_add_shape_ok(NT, KB))) {
+    if constexpr (((MODE == kActPlain || MODE == kActMask) && !linear_act_shape_ok(NT, KB)) || ((MODE == kAddPlain || MODE == kMixFwd) && !linear_add_shape_ok(NT, KB))) {
         return hipErrorInvalidValue;
     } else {
     static bool attr = false;
@@ -640,6 +698,7 @@ hipError_t launch_wgrad_grid(int nt, int kt, const WgParams& p, size_t lds, hipS
 hipError_t launch_linear_plain(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_combine(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_expand(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_actm(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_act(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_add(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);

@@ -127,6 +127,12 @@ extern "C" int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_
            (Fm % 16) != 0 && (f_out & 1) == 0 && Fo <= 1024;
 }
 
+extern "C" int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out) {
+    const bool off = getenv("DGN_NO_ZMASK") != nullptr || getenv("DGN_NO_MIX_FUSED") != nullptr;          // (read per call: the tests switch it)
+    const int Fo = n_towers * f_out;
+    return !off && n_towers >= 1 && f_out >= 1 && Fo % 16 != 0 && dgn_linear_add_supported(Fo, Fo) && dgn_linear_act_supported(Fo, Fo);
+}
+
 extern "C" size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* L) {
     Dims d;
     if (!dims_of(L, d, "dgn_towers_layer_forward_workspace_bytes")) return 0;
@@ -138,7 +144,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     Dims d;
     if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
     if (d.N == 0) return DGN_OK;
-    if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || !L->z || !L->out || !L->save_mean ||
+    if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || (!L->z && !L->zmask) || !L->out || !L->save_mean ||
         !L->save_invstd || (d.S > 1 && !L->scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
     const size_t bn_ws = up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
     if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
@@ -160,13 +166,18 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
                                 nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
     static const bool no_mix_fused = getenv("DGN_NO_MIX_FUSED") != nullptr;
-    const bool al = ((reinterpret_cast<uintptr_t>(L->z) | reinterpret_cast<uintptr_t>(L->out) | reinterpret_cast<uintptr_t>(L->h)) & 15) == 0;
+    const bool al = ((reinterpret_cast<uintptr_t>(L->z) | reinterpret_cast<uintptr_t>(L->zmask) | reinterpret_cast<uintptr_t>(L->out) |
+                      reinterpret_cast<uintptr_t>(L->h)) & 15) == 0;
     if (!L->y1 && !no_mix_fused && al && dgn_linear_add_supported(d.Fo, d.Fo)) {
         // ... all of it in one pass: the normalised operand formed while staged, bias + LeakyReLU + residual in the epilogue
-        DGN_TRY(dgn_linear_forward_bn_act(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta, L->b_mix, 2,
-                                          L->slope, L->residual ? L->h : nullptr, L->z, L->out, stream));
+        // (with zmask: the pre-activation leaves as a sign mask, 1/8 of its bytes)
+        if (L->zmask) DGN_TRY(dgn_linear_forward_bn_act_mask(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
+                                                             L->b_mix, 2, L->slope, L->residual ? L->h : nullptr, L->zmask, L->out, stream));
+        else DGN_TRY(dgn_linear_forward_bn_act(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta, L->b_mix, 2,
+                                               L->slope, L->residual ? L->h : nullptr, L->z, L->out, stream));
         return DGN_OK;
     }
+    if (!L->z) { set_error("%s: zmask without the fused mixing-network kernel (operands 16-byte aligned, no y1): give z", fn); return DGN_ERR_INVALID; }
     if (L->y1) DGN_TRY(dgn_linear_forward(d.N, d.Fo, d.Fo, 1, L->y1, d.Fo, 0, L->w_mix, d.Fo, 0, 0, nullptr, 0, L->z, d.Fo, 0, stream));
     else DGN_TRY(dgn_linear_forward_bn(d.N, d.Fo, d.Fo, L->y0, L->w_mix, d.Fo, 0, nullptr, L->z, L->save_mean, L->save_invstd, L->bn_gamma,
                                        L->bn_beta, stream));
@@ -232,11 +243,13 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     const bool aux = aux_env && fused_act && ss.init();
     void* wstream = aux ? static_cast<void*>(ss.side) : stream;          // where the weight-gradient products go
     if (fused_act) {
-        DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
+        if (L->zmask) DGN_TRY(dgn_linear_forward_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
+        else DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
         if (aux && !ss.fork(st, 0)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }
         DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
                                     ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), wstream));
     } else {
+        if (!L->z) { set_error("%s: zmask without the fused activation-gradient kernel: give z", fn); return DGN_ERR_INVALID; }
         DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
                                       dgn_bn_tail_workspace_bytes(d.N, d.Fo), stream));
         // mixing Linear: input and weight gradients

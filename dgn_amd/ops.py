@@ -979,8 +979,12 @@ class _TowersLayer(torch.autograd.Function):
         # y1 = BatchNorm(y0) is not materialised (FUSE_BN_MIXING): the mixing Linear and its weight gradient normalise y0 while they
         # stage their strips (dgn_linear_forward_bn / dgn_linear_wgrad_bn) -- one pass and N * Fo saved floats per layer less
         n_y1 = 0 if FUSE_BN_MIXING else N * Fo
-        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, n_y1, N * Fo, Fo, Fo], dev)
-        ctx.n_y1 = n_y1
+        # the mixing network's pre-activation is only needed for the sign of (z + b): where the fused kernels run it is kept as a byte
+        # mask (DgnTowersLayer.zmask, 1/8 of the bytes) in the slot z would take
+        use_mask = n_y1 == 0 and (h.data_ptr() & 15) == 0 and bool(lib.dgn_towers_layer_zmask_supported(T, fo))
+        n_z = (lib.dgn_linear_act_mask_bytes(N, Fo) + 3) // 4 if use_mask else N * Fo
+        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, n_y1, n_z, Fo, Fo], dev)
+        ctx.n_y1, ctx.n_z, ctx.use_mask = n_y1, n_z, use_mask
         out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
         spec = _spec_structs(plan, T, avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
@@ -993,7 +997,8 @@ class _TowersLayer(torch.autograd.Function):
         L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
         L.bn_gamma, L.bn_beta, L.running_mean, L.running_var = gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr()
         L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
-        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None), z.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None)
+        L.z, L.zmask = (None, z.data_ptr()) if use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
         nbytes = lib.dgn_towers_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -1015,7 +1020,7 @@ class _TowersLayer(torch.autograd.Function):
         N, Fm, Fo = h.shape[0], T * fi, T * fo
         K = plan.n_agg * fi
         dev = h.device
-        sizes = [N * 2 * Fm, T * N * K, N * Fo, ctx.n_y1, N * Fo, Fo, Fo]
+        sizes = [N * 2 * Fm, T * N * K, N * Fo, ctx.n_y1, ctx.n_z, Fo, Fo]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -1034,7 +1039,8 @@ class _TowersLayer(torch.autograd.Function):
         L.w_sd, L.bias_sd, L.w_post, L.b_post = w_sd.data_ptr(), bias_sd.data_ptr(), w_post.data_ptr(), b_post.data_ptr()
         L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
         L.w_mix, L.b_mix = w_mix.data_ptr(), b_mix.data_ptr()
-        L.pq, L.aggx, L.y0, L.y1, L.z = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if ctx.n_y1 else None), z.data_ptr()
+        L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if ctx.n_y1 else None)
+        L.z, L.zmask = (None, z.data_ptr()) if ctx.use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 19
+#define DGN_ABI_VERSION 20
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -321,6 +321,16 @@ int dgn_linear_forward_add(int64_t n_rows, int32_t k, int32_t n, const float* a,
 int dgn_linear_forward_bn_act(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, const float* bn_mean,
                               const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const float* act_bias, int32_t act,
                               float slope, const float* residual, float* z_out, float* out, void* stream);
+/* The same two products with the pre-activation replaced by a byte mask (1/8 of its bytes): byte i of zmask describes elements 2 i and
+ * 2 i + 1 of the dense [n_rows, n] pre-activation, bit 0 / bit 1 = (z + act_bias > 0).  dgn_linear_forward_bn_act_mask writes it (and
+ * `out`) instead of z_out; dgn_linear_forward_act_mask takes the activation's derivative from it (1 where set, else slope for
+ * LeakyReLU / 0 for ReLU): the values dgn_linear_forward_act computes from z.                                                    */
+size_t dgn_linear_act_mask_bytes(int64_t n_rows, int32_t n);
+int dgn_linear_forward_bn_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* a, const float* w, int64_t ldw, const float* bn_mean,
+                                   const float* bn_invstd, const float* bn_gamma, const float* bn_beta, const float* act_bias, int32_t act,
+                                   float slope, const float* residual, unsigned char* zmask_out, float* out, void* stream);
+int dgn_linear_forward_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);
 int dgn_linear_act_supported(int32_t k, int32_t n);      /* (the widest tile shapes are not: two prefetched strips per wave) */
 int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
                            float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);
@@ -469,6 +479,10 @@ typedef struct DgnTowersLayer {
     float* out;                /* [N, T*f_out]  (forward only)                                              */
     void* ws; size_t ws_bytes; /* scratch: dgn_towers_layer_{forward,backward}_workspace_bytes()            */
     const int64_t* n_valid;    /* DEVICE scalar or NULL: rows >= *n_valid are padding (see dgn_bn_tail_forward)         */
+    /* Optional (dgn_towers_layer_zmask_supported): dgn_linear_act_mask_bytes(N, T*f_out) bytes.  When set, the mixing network's
+     * pre-activation is never written: the forward leaves the sign mask of (z + b_mix) here, the backward reads the activation's
+     * derivative from it (same values bit for bit), and `z` may be NULL.                                                      */
+    unsigned char* zmask;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */
@@ -529,6 +543,9 @@ size_t dgn_dense_layer_backward_workspace_bytes(const DgnDenseLayer* layer);
 int dgn_dense_layer_backward(const DgnDenseLayer* layer, const DgnDenseGrads* grads, void* stream);
 
 int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total);
+/* 1 when dgn_towers_layer_forward / _backward can work from DgnTowersLayer.zmask alone (the fused mixing-network kernels exist for
+ * T * f_out columns and are not switched off): the caller then need not allocate `z`.                                            */
+int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out);
 size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);
 size_t dgn_towers_layer_backward_workspace_bytes(const DgnTowersLayer* layer);

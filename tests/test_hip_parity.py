@@ -745,6 +745,44 @@ def test_whole_layer_call_equals_per_kernel_route(monkeypatch, residual, graph_n
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
 
 
+@pytest.mark.parametrize("n_graphs", [200, 3])
+@pytest.mark.parametrize("residual", [True, False])
+def test_towers_layer_with_the_activation_mask_is_bitwise_the_layer_with_z(monkeypatch, n_graphs, residual):
+    """DgnTowersLayer.zmask: the mixing network's pre-activation kept as a sign mask (1/8 of the bytes).  Output and every gradient must be
+    the bits of the run that stores z (DGN_NO_ZMASK=1); 3 graphs: only a partial last strip."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    assert _lib.load().dgn_towers_layer_zmask_supported(5, 14) == 1
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    b = synth.molecule_batch(n_graphs, seed=5, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    torch.manual_seed(4)
+    layer = dgn_amd.DGNLayer(70, 70, 0.0, True, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation", {"log": torch.tensor(1.2)},
+                             "towers", residual, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(6)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=gen))
+    h0 = torch.randn(N, 70, device=dev, generator=gen)
+    ct = torch.randn(N, 70, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    res = []
+    for mask in (True, False):
+        if not mask:
+            monkeypatch.setenv("DGN_NO_ZMASK", "1")
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        res.append([y.detach(), h.grad] + [p.grad for p in lay.parameters()])
+    for a, c in zip(*res):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("n_graphs,scalers", [(300, "identity amplification attenuation"), (7, "identity attenuation"), (40, "identity")])
 def test_fused_forward_equals_separate_kernels(monkeypatch, n_graphs, scalers):
     """layer_fwd_fused (the posttrans product inside the sweep: aggregate rows in LDS -> MFMA -> scale-combine) against the

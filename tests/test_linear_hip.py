@@ -342,6 +342,53 @@ def test_bn_linear_act_residual_in_one_pass_is_bitwise(shape, residual):
     assert torch.equal(o_ref, o_f)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4099, 70, 70), (275, 70, 70), (19, 84, 42), (16, 70, 70), (3, 6, 2), (1000, 112, 112)])
+@pytest.mark.parametrize("act,residual", [(2, True), (1, True), (2, False)])
+def test_activation_mask_round_trip_is_bitwise_the_z_path(shape, act, residual):
+    """dgn_linear_forward_bn_act_mask writes the sign mask of (z + b) instead of z; dgn_linear_forward_act_mask reads the activation's
+    derivative from it: `out`, the input-gradient product and its side output must be the bits of the z-based pair, and the mask itself
+    must be exactly (z + b > 0), two bits per byte."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    M, k, n = shape
+    if not (lib.dgn_linear_add_supported(k, n) and lib.dgn_linear_act_supported(n, k)):
+        pytest.skip("shape outside the supported set")
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + 3 * k + act)
+    x = torch.randn(M, k, device=dev, generator=gen) + 0.3
+    w, b = torch.randn(n, k, device=dev, generator=gen) / k ** 0.5, torch.randn(n, device=dev, generator=gen)
+    gamma, beta = torch.rand(k, device=dev, generator=gen) + 0.5, torch.randn(k, device=dev, generator=gen)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    res = torch.randn(M, n, device=dev, generator=gen) if residual else None
+    rp = res.data_ptr() if residual else None
+    st = torch.cuda.current_stream().cuda_stream
+    z, o = torch.empty(M, n, device=dev), torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward_bn_act(M, k, n, x.data_ptr(), w.data_ptr(), k, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             b.data_ptr(), act, 0.01, rp, z.data_ptr(), o.data_ptr(), st), "bn_act")
+    nb = lib.dgn_linear_act_mask_bytes(M, n)
+    assert nb >= M * n // 2 and nb % 16 == 0
+    mask = torch.full((nb,), 0xAA, dtype=torch.uint8, device=dev)
+    o_m = torch.full((M, n), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_bn_act_mask(M, k, n, x.data_ptr(), w.data_ptr(), k, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                                  beta.data_ptr(), b.data_ptr(), act, 0.01, rp, mask.data_ptr(), o_m.data_ptr(), st), "bn_act_mask")
+    assert torch.equal(o, o_m)
+    pos = ((z + b) > 0).reshape(-1, 2)
+    want = (pos[:, 0].to(torch.uint8) | (pos[:, 1].to(torch.uint8) << 1))
+    assert torch.equal(mask[:M * n // 2], want)
+    assert bool((mask[M * n // 2:] == 0xAA).all())                                    # nothing written past the tensor's bytes
+    # backward: g * act'(z + b) and the product with the mixing weight ([n, k] read as the reduction-major operand)
+    g = torch.randn(M, n, device=dev, generator=gen)
+    wt = torch.randn(n, k, device=dev, generator=gen)
+    c_ref, gz_ref = torch.empty(M, k, device=dev), torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward_act(M, n, k, g.data_ptr(), z.data_ptr(), b.data_ptr(), act, 0.01, wt.data_ptr(), k, 1, c_ref.data_ptr(), gz_ref.data_ptr(), st), "act")
+    c_m, gz_m = torch.full((M, k), float("nan"), device=dev), torch.full((M, n), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_act_mask(M, n, k, g.data_ptr(), mask.data_ptr(), act, 0.01, wt.data_ptr(), k, 1, c_m.data_ptr(), gz_m.data_ptr(), st), "act_mask")
+    assert torch.equal(gz_ref, gz_m)
+    assert torch.equal(c_ref, c_m)
+
+
 @pytest.mark.parametrize("T,fi,M", [(5, 14, 4099), (5, 14, 16), (5, 14, 1), (5, 10, 700), (5, 20, 1033), (5, 30, 515), (4, 14, 2000), (2, 14, 333)])
 def test_block_diagonal_pair_linear_vs_fp64(T, fi, M):
     """dgn_linear_bd_*: the towers' block-diagonal P|Q product, its input gradient (with the two-operand add epilogue) and its weight /
