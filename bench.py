@@ -43,6 +43,7 @@ from dgn_amd import dist as ddist  # noqa: E402
 from dgn_amd import synth  # noqa: E402
 from dgn_amd.ops import launch_backward, launch_forward  # noqa: E402
 
+AUX_LAYERS = ("towers", "simple", "complex")    # layer types whose whole-layer call passes the sweep's aux table from the forward to the backward
 HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -415,9 +416,14 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     me = torch.randn(n_types if n_types else E, Fk, device=dev, generator=gen) if edge_dim else None
     g_me = torch.empty_like(me) if edge_dim else None
     et = graph.to_slot_order(ef.types).to(torch.int32).contiguous() if n_types else None
-    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et)
+    # the forward / backward pair as the layer runs it in training: where the launch has an aux table (dgn_agg_forward_aux: slots of the
+    # first max / min and dx signs, one byte per row and feature) the forward writes it and the backward works from it
+    from dgn_amd import ops as _ops
+    n_aux = _ops.agg_aux_bytes(graph, plan, T, Fk, xs, xd, me, hd, et) if (_ops.AGG_AUX and g_me is None and wl["type_net"] in AUX_LAYERS) else 0
+    aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
+    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et, aux=aux)
     bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False,
-                                       edge_type=et)
+                                       edge_type=et, aux=aux)
     st_f, st_b = event_stats(fwd_call, dev), event_stats(bwd_call, dev)
     st_w = event_stats(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), dev)
     ms_f, ms_b, ms_w = st_f["median"], st_b["median"], st_w["median"]
@@ -452,7 +458,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     result["roofline"] = dict(bound="hbm", kernel=label, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
                               frac=kernels[dom]["frac"], traffic=traffic, traffic_source=TRAFFIC_SOURCE if traffic else None,
                               kernels=kernels, triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
-                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r),
+                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, aux_bytes=n_aux),
                               frac_with_survey_A=dict(A=A_survey, frac=frac_survey,
                                                       note="same launch priced without the h_in pass-through block"))
     return result, batch

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward",
@@ -80,7 +80,7 @@ class DgnTowersLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
-                ("zmask", C.c_void_p)]
+                ("zmask", C.c_void_p), ("agg_aux", C.c_void_p)]
 
 
 class DgnTowersGrads(C.Structure):
@@ -97,7 +97,7 @@ class DgnDenseLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("hp", C.c_void_p), ("pq", C.c_void_p), ("agg", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("wsd", C.c_void_p),
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("n_valid", C.c_void_p)]
+                ("n_valid", C.c_void_p), ("agg_aux", C.c_void_p)]
 
 
 class DgnDenseGrads(C.Structure):
@@ -157,6 +157,18 @@ def load() -> C.CDLL:
         lib.dgn_agg_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
                                         C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
                                         C.c_void_p]
+        lib.dgn_agg_aux_bytes.restype = C.c_size_t
+        lib.dgn_agg_aux_bytes.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg)]
+        lib.dgn_agg_forward_aux.restype = C.c_int
+        lib.dgn_agg_forward_aux.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_agg_backward_aux.restype = C.c_int
+        lib.dgn_agg_backward_aux.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(DgnMsgGrad), C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_dense_layer_agg_aux_bytes.restype = C.c_size_t
+        lib.dgn_dense_layer_agg_aux_bytes.argtypes = [C.POINTER(DgnDenseLayer)]
+        lib.dgn_towers_layer_agg_aux_bytes.restype = C.c_size_t
+        lib.dgn_towers_layer_agg_aux_bytes.argtypes = [C.POINTER(DgnTowersLayer)]
         lib.dgn_agg_backward.restype = C.c_int
         lib.dgn_agg_backward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(DgnMsgGrad),

@@ -235,6 +235,21 @@ extern "C" size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* s
 
 size_t stage_bytes(const DgnGraph* g, int64_t F) { return ((size_t)g->n_edges * F * sizeof(float) + 255) & ~(size_t)255; }
 
+// The aux byte table (AggParams.aux) applies when the 4-rows-per-wave kernels run a baked-in list that recomputes (max / min / dx)
+// but needs no message value in the emit pass (no std / var), with at most two weight channels: short-row graph, even width.
+static bool agg_aux_supported(const AggParams& p, const DgnMsg* msg) {
+    static const bool off = getenv("DGN_NO_AUX") != nullptr;
+    return !off && short_rows(p) && is_hot_list(p) && p.n_ch <= 2 && (p.need & NEED_RECOMP) && !(p.need & (NEED_M_EMIT | NEED_SQ)) &&
+           msg->x_src && !(msg->m_edge && !msg->edge_type) && (msg->F % 2) == 0 && p.n_nodes > 0;
+}
+
+extern "C" size_t dgn_agg_aux_bytes(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg) {
+    if (!g || !spec || !msg || msg->F <= 0 || spec->n_agg < 1 || spec->n_agg > DGN_MAX_AGG || spec->n_towers < 1) return 0;
+    AggParams p;
+    fill_params(p, g, spec, msg, nullptr, 0, nullptr);
+    return agg_aux_supported(p, msg) ? (((size_t)((g->n_nodes + 3) / 4) * 4 * msg->F + 255) & ~(size_t)255) : 0;     // (groups of four rows)
+}
+
 extern "C" size_t dgn_agg_edge_table_workspace_bytes(int64_t F, int32_t n_edge_types) {
     return (F > 0 && n_edge_types > 0) ? edge_table_ws_bytes(F, n_edge_types) : 0;
 }
@@ -248,6 +263,12 @@ extern "C" size_t dgn_agg_backward_workspace_bytes(const DgnGraph* g, const DgnA
 
 extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                                const float* log_deg, float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream_) {
+    return dgn_agg_forward_aux(g, spec, msg, w, ld_w, log_deg, out, ld_out, nullptr, ws, ws_bytes, stream_);
+}
+
+extern "C" int dgn_agg_forward_aux(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                                   const float* log_deg, float* out, int64_t ld_out, unsigned char* aux, void* ws, size_t ws_bytes,
+                                   void* stream_) {
     int rc = validate(g, spec, msg, w, log_deg);
     if (rc) return rc;
     if (g->n_nodes == 0) return DGN_OK;
@@ -259,6 +280,10 @@ extern "C" int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const 
     fill_params(p, g, spec, msg, w, ld_w, log_deg);
     if (ld_out > INT32_MAX) { set_error("ld_out must fit in int32"); return DGN_ERR_INVALID; }
     p.out = out; p.ld_out = (int32_t)ld_out;
+    if (aux) {
+        if (!agg_aux_supported(p, msg)) { set_error("dgn_agg_forward_aux: this launch has no aux table (dgn_agg_aux_bytes() == 0)"); return DGN_ERR_INVALID; }
+        p.aux = aux;
+    }
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     const int vec = pick_vec(spec, msg, out, ld_out, nullptr);
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
@@ -271,7 +296,7 @@ namespace dgn {
 // gradient is formed in LDS: `g_out` may then be NULL (`lds_gout`).  *tab_part_out: workspace of the edge-type table's gradient.
 int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                          const float* log_deg, const float* g_out, int64_t ld_gout, bool lds_gout, const DgnMsgGrad* grads, void* ws,
-                         size_t ws_bytes, void* stream_, float** tab_part_out) {
+                         size_t ws_bytes, void* stream_, float** tab_part_out, const unsigned char* aux) {
     int rc = validate(g, spec, msg, w, log_deg);
     if (rc) return rc;
     if (!grads) { set_error("null grads"); return DGN_ERR_INVALID; }
@@ -286,6 +311,10 @@ int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec
     p.g_dst = msg->x_dst ? grads->g_dst : nullptr; p.ldg_dst = (int32_t)grads->ld_dst;
     p.g_edge = msg->m_edge ? grads->g_edge : nullptr; p.ldg_edge = (int32_t)grads->ld_edge;
     p.g_in = msg->x_in ? grads->g_in : nullptr; p.ldg_in = (int32_t)grads->ld_in;
+    if (aux) {
+        if (lds_gout || !agg_aux_supported(p, msg)) { set_error("dgn_agg_backward_aux: this launch has no aux table (dgn_agg_aux_bytes() == 0)"); return DGN_ERR_INVALID; }
+        p.aux = const_cast<unsigned char*>(aux);
+    }
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     // atomic-free scatter when the transposed view and the [E, F] staging buffer are available
     if (p.g_src && g->csc_ptr && g->csc_pos && g->n_edges > 0 && ws &&
@@ -321,10 +350,16 @@ int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec
 extern "C" int dgn_agg_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                                 const float* log_deg, const float* g_out, int64_t ld_gout, const DgnMsgGrad* grads,
                                 void* ws, size_t ws_bytes, void* stream_) {
+    return dgn_agg_backward_aux(g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, nullptr, grads, ws, ws_bytes, stream_);
+}
+
+extern "C" int dgn_agg_backward_aux(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                                    const float* log_deg, const float* g_out, int64_t ld_gout, const unsigned char* aux,
+                                    const DgnMsgGrad* grads, void* ws, size_t ws_bytes, void* stream_) {
     if (g && g->n_nodes == 0 && spec && msg && grads) return validate(g, spec, msg, w, log_deg);
     AggParams p;
     float* tab_part = nullptr;
-    int rc = agg_backward_prepare(p, g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, false, grads, ws, ws_bytes, stream_, &tab_part);
+    int rc = agg_backward_prepare(p, g, spec, msg, w, ld_w, log_deg, g_out, ld_gout, false, grads, ws, ws_bytes, stream_, &tab_part, aux);
     if (rc) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int vec = pick_vec(spec, msg, g_out, ld_gout, grads);

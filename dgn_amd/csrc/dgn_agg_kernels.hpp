@@ -101,6 +101,11 @@ struct AggParams {
     float* part_sw;       // [n_chunks][DGN_MAX_CH]
     float* coef;          // [n_hub][n_coef][F]  (backward)
     float* stage;         // [n_edges][F] per-edge gradient rows in csc order (atomic-free backward), or NULL
+    // Per-row facts the backward otherwise recomputes from the messages (a second gather of every source row), one byte per (row,
+    // feature): bits 0-1 / 2-3 = slot (within the row) of the first maximum / minimum, bits 4-5 / 6-7 = sign of the dx residual of
+    // weight channel 0 / 1 (0: zero, 1: positive, 2: negative).  Written by agg_fwd_short for groups of rows with at most kShortDeg
+    // in-edges, read by agg_bwd_short for the same groups (lists with at most two channels and no std / var).  NULL = recompute.
+    unsigned char* aux;
     int32_t stage_out;    // forward, agg_fwd_short: rows go through the wave's LDS slice (tower-major output, one feature tile)
     bool fresh;           // backward: g_dst / g_in rows are WRITTEN by the row kernel (buffers arrive uninitialised)
     bool seg_add;         // backward: seg_sum_rows adds to g_src (accumulate mode, or g_in aliases g_src) instead of writing it
@@ -540,8 +545,8 @@ __device__ __forceinline__ void agg_value(float (&val)[C::VEC], int op, int c, c
 
 // write one finished row: aggregator values x scalers in the reference concat order.
 // orow already includes the lane's column part; xin / logd were loaded by the caller (early).
-template <class C, class O = DynOps>
-__device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggParams& p, float* orow, int deg,
+template <class C, class O = DynOps, bool TRACK = false>
+__device__ __forceinline__ void write_row(const Acc<C, TRACK>& acc, const AggParams& p, float* orow, int deg,
                                           const float (&xin)[C::VEC], float logd) {
     constexpr int VEC = C::VEC;
     if (deg == 0) {      // no messages: zeros (DGL fills such rows from the zero initializer); the x_in block is still x_in
@@ -555,13 +560,13 @@ __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggPar
     }
     const float d = (float)deg;
     RowStats<VEC> st;
-    row_stats<C, false>(st, acc, d, p);
+    row_stats<C, TRACK>(st, acc, d, p);
     float fac[DGN_MAX_SCALERS];
 #pragma unroll
     for (int s = 0; s < DGN_MAX_SCALERS; ++s) fac[s] = s < O::n_scalers(p) ? scaler_factor(O::scaler(p, s), logd, p.avg_log) : 1.f;
     for_each_agg<O>(p, [&](int a) {
         float val[VEC];
-        agg_value<C, false>(val, O::op(p, a), O::ch(p, a), acc, st, xin);
+        agg_value<C, TRACK>(val, O::op(p, a), O::ch(p, a), acc, st, xin);
 #pragma unroll
         for (int s = 0; s < DGN_MAX_SCALERS; ++s) {
             if (s < O::n_scalers(p)) {
@@ -575,6 +580,49 @@ __device__ __forceinline__ void write_row(const Acc<C, false>& acc, const AggPar
             }
         }
     });
+}
+
+// AggParams.aux: the byte of one (row, feature) from the row's tracked accumulators (arg max / min tracked as positions within the row)
+template <class C>
+__device__ __forceinline__ unsigned aux_byte(const Acc<C, true>& acc, int i, float xin_i) {
+    unsigned b = 0;
+    if constexpr (C::STATS) b = ((unsigned)acc.amax[i] & 3u) | (((unsigned)acc.amin[i] & 3u) << 2);      // (tracked as positions within the row)
+#pragma unroll
+    for (int c = 0; c < (C::NCH < 2 ? C::NCH : 2); ++c) {
+        const float r = dx_residual(acc.ws[c][i], acc.sw[c], xin_i);
+        b |= (r > 0.f ? 1u : (r < 0.f ? 2u : 0u)) << (4 + 2 * c);
+    }
+    return b;
+}
+// The table is laid out per group of four rows and per lane: a lane's bytes of the four rows are adjacent (4 VEC bytes at
+// group * 4 F + 4 f0), so a group is ONE store / load instruction of consecutive 8-byte (VEC = 2) lanes.
+__device__ __forceinline__ int64_t aux_offset(const AggParams& p, int row0, int f0) { return (int64_t)(row0 >> 2) * 4 * p.F + 4 * f0; }
+template <int VEC>
+__device__ __forceinline__ void store_aux_group(unsigned char* at, const unsigned (&b)[4][VEC]) {
+    unsigned w[4];                           // VEC bytes per row, packed
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w[r] = 0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) w[r] |= b[r][i] << (8 * i);
+    }
+    if constexpr (VEC == 1) *reinterpret_cast<unsigned*>(at) = w[0] | (w[1] << 8) | (w[2] << 16) | (w[3] << 24);
+    else if constexpr (VEC == 2) *reinterpret_cast<uint2*>(at) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+    else *reinterpret_cast<uint4*>(at) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// w[r] = the VEC bytes of row r of the group, byte i = feature f0 + i
+template <int VEC>
+__device__ __forceinline__ void load_aux_group(unsigned (&w)[4], const unsigned char* at) {
+    if constexpr (VEC == 1) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(at);
+        w[0] = v & 0xffu; w[1] = (v >> 8) & 0xffu; w[2] = (v >> 16) & 0xffu; w[3] = v >> 24;
+    } else if constexpr (VEC == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(at);
+        w[0] = v.x & 0xffffu; w[1] = v.x >> 16; w[2] = v.y & 0xffffu; w[3] = v.y >> 16;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(at);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
 }
 
 // ---- hub workspace I/O ----------------------------------------------------------------------
@@ -775,7 +823,7 @@ __device__ __forceinline__ void short_group_to_lds(const AggParams& p, const Sho
     }
 }
 
-template <class C, class O = DynOps>
+template <class C, class O = DynOps, bool AUX = false>
 __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     constexpr int VEC = C::VEC, R = kShortRows, J = kShortDeg;
     extern __shared__ float lds_rows[];
@@ -836,6 +884,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     // tile [row][j-th slot of the row]: the register index is static, the slot (= lane of the batch) is not --
     // one compare per tile instead of a range check of every slot against every row
     float t[R][J][VEC];
+    unsigned auxv[AUX ? R : 1][VEC] = {};
     if (active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -849,7 +898,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
         if (r != 0 && r >= grp.nrows) break;
         float* orow = p.out + (int64_t)(grp.row0 + r) * p.ld_out;
         if (active) {
-            Acc<C, false> acc;
+            Acc<C, AUX> acc;
             acc.init();
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -863,10 +912,14 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                         for (int i = 0; i < VEC; ++i) mm[i] += tr[i];
                     }
                     b.weights(wk, lo[r] + j);
-                    acc.add(mm, wk, beg0 + lo[r] + j);
+                    acc.add(mm, wk, AUX ? j : beg0 + lo[r] + j);          // (AUX: the tracked "slot" is the position within the row)
                 }
             }
-            write_row<C, O>(acc, p, staged ? lds_row + (grouped ? r * K : 0) : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
+            write_row<C, O, AUX>(acc, p, staged ? lds_row + (grouped ? r * K : 0) : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
+            if constexpr (AUX) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) auxv[r][i] = aux_byte<C>(acc, i, side[r].xin[i]);
+            }
         }
         if (staged && !grouped) {
             // (same wave: LDS operations complete in program order, no barrier needed)
@@ -889,6 +942,10 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                 }
             }
         }
+    }
+    if constexpr (AUX) {
+        static_assert(R == 4, "the aux table is laid out per group of four rows");
+        if (active) store_aux_group<VEC>(p.aux + aux_offset(p, grp.row0, f0), auxv);      // (rows past the graph's end: unread)
     }
     if (grouped) {
         // (same wave: LDS operations complete in program order, no barrier needed)
@@ -1424,7 +1481,9 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 // fused backward kernel, layer_bwd_fused, whose p.g_out points at upstream-gradient rows it has just formed in LDS).
 // GLDS: p.g_out points into LDS -- the upstream-gradient blocks are then read where they are used instead of being requested up front
 // (48 registers on the ZINC list: with them the fused kernel's 16-wave workgroups would spill).
-template <class C, class O, int RB, bool EDGE = false, bool GLDS = false>
+// AUX: p.aux holds, for every (row, feature) of such a group, what the recompute would find (aux_byte): no message is formed again --
+// no source gathers, no x_dst / x_in rows -- and the coefficient code runs on accumulators that carry just those facts.
+template <class C, class O, int RB, bool EDGE = false, bool GLDS = false, bool AUX = false>
 __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, int nrows, int f0, bool active) {
     constexpr int VEC = C::VEC, J = kShortDeg;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
@@ -1454,15 +1513,23 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
         const int my_tpos = lane_id() < total ? p.csc_pos[beg0 + lane_id()] : 0;
         if (!active) return;
         // every load of the group, issued before anything is consumed
-        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[GLDS ? 1 : RB][GLDS ? 1 : NG][VEC], t[RB][J][VEC], t2[EDGE ? RB : 1][EDGE ? J : 1][VEC];
+        float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[GLDS ? 1 : RB][GLDS ? 1 : NG][VEC], t[AUX ? 1 : RB][AUX ? 1 : J][VEC],
+              t2[(EDGE && !AUX) ? RB : 1][(EDGE && !AUX) ? J : 1][VEC];
+        unsigned auxw[AUX ? 4 : 1];
+        if constexpr (AUX) {
+            static_assert(RB == 4, "the aux table is laid out per group of four rows");
+            load_aux_group<VEC>(auxw, p.aux + aux_offset(p, row0, f0));
+        }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int row = row0 + r;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { xd[r][i] = 0.f; xin[r][i] = 0.f; }
             logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
-            if (p.x_dst) ldv<VEC>(xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0);
-            if (p.need & NEED_XIN) ldv<VEC>(xin[r], p.x_in + (int64_t)row * p.ld_in + f0);
+            if constexpr (!AUX) {
+                if (p.x_dst) ldv<VEC>(xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0);
+                if (p.need & NEED_XIN) ldv<VEC>(xin[r], p.x_in + (int64_t)row * p.ld_in + f0);
+            }
             if constexpr (!GLDS) {
                 const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
 #pragma unroll
@@ -1471,14 +1538,16 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
                     for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[r][sc * O::NA + a], grow + sa_col(p, sc, a));
             }
         }
-        if (recomp) {
+        if constexpr (!AUX) {
+            if (recomp) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
+                for (int r = 0; r < RB; ++r) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    if (j < deg[r]) {
-                        ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
-                        if constexpr (EDGE) ldv<VEC>(t2[r][j], p.m_edge + (int64_t)bcast_i(b.et, lo[r] + j) * p.ld_edge + f0);
+                    for (int j = 0; j < J; ++j) {
+                        if (j < deg[r]) {
+                            ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                            if constexpr (EDGE) ldv<VEC>(t2[r][j], p.m_edge + (int64_t)bcast_i(b.et, lo[r] + j) * p.ld_edge + f0);
+                        }
                     }
                 }
             }
@@ -1487,7 +1556,30 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
         for (int r = 0; r < RB; ++r) {
             Acc<C, true> acc;
             acc.init();
-            if (recomp) {
+            if constexpr (AUX) {
+                // what acc.add() over the row's messages would leave in the fields the coefficient code reads: sum_j w_jc in slot
+                // order, the slots of the first maximum / minimum, and a stand-in of the dx residual with its sign (x_in reads as 0)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    if (j < deg[r]) {
+#pragma unroll
+                        for (int c = 0; c < C::NCH; ++c) acc.sw[c] += bcast_f(b.w[c], lo[r] + j);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const unsigned ab = (auxw[r] >> (8 * i)) & 0xffu;
+                    if constexpr (C::STATS) {
+                        acc.amax[i] = beg0 + lo[r] + (int)(ab & 3u);
+                        acc.amin[i] = beg0 + lo[r] + (int)((ab >> 2) & 3u);
+                    }
+#pragma unroll
+                    for (int c = 0; c < (C::NCH < 2 ? C::NCH : 2); ++c) {
+                        const unsigned code = (ab >> (4 + 2 * c)) & 3u;
+                        acc.ws[c][i] = code == 1u ? 1.f : (code == 2u ? -1.f : 0.f);
+                    }
+                }
+            } else if (recomp) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     if (j < deg[r]) {
@@ -1563,7 +1655,7 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
     }
 }
 
-template <class C, class O, int RB, bool EDGE = false>
+template <class C, class O, int RB, bool EDGE = false, bool AUX = false>
 __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
     const int wpb = blockDim.x >> 6;
     const int64_t n_groups = (p.n_nodes + RB - 1) / RB;
@@ -1575,7 +1667,7 @@ __global__ __launch_bounds__(256) void agg_bwd_short(const AggParams p) {
     const int row0 = uniform_i((int)(g64 * RB));
     const int nrows = (int)min((int64_t)RB, p.n_nodes - row0);
     const int f0 = (blockIdx.y * kWave + lane_id()) * C::VEC;
-    bwd_short_group<C, O, RB, EDGE>(p, row0, nrows, f0, f0 < p.F);
+    bwd_short_group<C, O, RB, EDGE, false, AUX>(p, row0, nrows, f0, f0 < p.F);
 }
 
 // hub backward, phase 2: merge slice partials, build the row's coefficient vectors, park them
@@ -1756,7 +1848,11 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
             q.tab_off = (int32_t)(lds / sizeof(float));
             lds += (size_t)p.n_edge_types * p.F * sizeof(float);
         }
-        hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), lds, stream, q);
+        bool launched = false;
+        if constexpr (O::kStatic && C::NCH <= 2) {
+            if (q.aux) { hipLaunchKernelGGL((agg_fwd_short<C, O, true>), grid, dim3(kWave * wpb), lds, stream, q); launched = true; }
+        }
+        if (!launched) hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), lds, stream, q);
     } else {
         const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
         dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
@@ -1780,8 +1876,18 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
     if (O::kStatic && short_rows(p) && p.stage && p.fresh && rb > 1) {       // molecule-like batches, static lists: rows in groups per wave
         const int64_t n_groups = (p.n_nodes + rb - 1) / rb;
         dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);
-        if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true>), grid, dim3(kWave * wpb), 0, stream, p);
-        else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false>), grid, dim3(kWave * wpb), 0, stream, p);
+        bool launched = false;
+        if constexpr (O::kStatic && C::NCH <= 2) {
+            if (p.aux) {           // (the host sets it only for lists and graphs agg_aux_supported() accepts)
+                if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true, true>), grid, dim3(kWave * wpb), 0, stream, p);
+                else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false, true>), grid, dim3(kWave * wpb), 0, stream, p);
+                launched = true;
+            }
+        }
+        if (!launched) {
+            if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true>), grid, dim3(kWave * wpb), 0, stream, p);
+            else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false>), grid, dim3(kWave * wpb), 0, stream, p);
+        }
     } else {
         const int64_t n_blocks = (p.n_nodes + wpb - 1) / wpb;
         dim3 grid((unsigned)xcd_grid(n_blocks), tiles);
@@ -1832,6 +1938,18 @@ int launch_vec(const AggParams& p, unsigned tiles, hipStream_t stream) {
 #undef DGN_GO
     set_error("no kernel for vec=%d n_ch=%d stats=%d av=%d", VEC, p.n_ch, (int)stats, (int)av);
     return DGN_ERR_INVALID;
+}
+
+// is the launch's (list, scalers, channels) one of the baked-in hot lists (launch_vec would pick a StaticOps kernel)?
+inline bool is_hot_list(const AggParams& p) {
+    static const bool no_hot = getenv("DGN_NO_HOT") != nullptr;
+    if (no_hot) return false;
+#define DGN_HOT(NA, OPS, CHS, NS, SCS, N, S, A)                                                                  \
+    if (p.n_agg == NA && p.op_pack == OPS && p.ch_pack == CHS && p.n_scalers == NS && p.scaler_pack == SCS && \
+        p.agg_total == NA && p.agg_offset == 0 && p.n_ch == N) return true;
+#include "dgn_agg_hot.hpp"
+#undef DGN_HOT
+    return false;
 }
 
 // defined in dgn_agg_v1.hip / _v2.hip / _v4.hip

@@ -12,7 +12,7 @@ int agg_validate_and_fill(AggParams& p, const DgnGraph* g, const DgnAggSpec* spe
                           const float* log_deg);
 int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                          const float* log_deg, const float* g_out, int64_t ld_gout, bool lds_gout, const DgnMsgGrad* grads, void* ws,
-                         size_t ws_bytes, void* stream_, float** tab_part_out);
+                         size_t ws_bytes, void* stream_, float** tab_part_out, const unsigned char* aux);
 namespace {
 
 int n_cus() {
@@ -176,7 +176,7 @@ extern "C" int dgn_layer_fused_backward(const DgnGraph* g, const DgnAggSpec* spe
     if (!g || !spec || !msg) { set_error("%s: null graph / spec / msg", fn); return DGN_ERR_INVALID; }
     if (!dgn_layer_fused_backward_supported(g, spec, msg->F, n_scalers, f_out)) { set_error("%s: configuration outside the fused kernel's domain", fn); return DGN_ERR_INVALID; }
     FusedBwdParams p{};
-    int rc = agg_backward_prepare(p.a, g, spec, msg, w, ld_w, log_deg, nullptr, 0, true, grads, ws, ws_bytes, stream, nullptr);
+    int rc = agg_backward_prepare(p.a, g, spec, msg, w, ld_w, log_deg, nullptr, 0, true, grads, ws, ws_bytes, stream, nullptr, nullptr);
     if (rc) return rc;
     if (g->n_nodes == 0) return DGN_OK;
     if (!weight || !gy || (n_scalers > 1 && !scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }

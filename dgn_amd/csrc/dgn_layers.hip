@@ -178,6 +178,16 @@ using namespace dgn;
         if (_rc != 0) return _rc;  \
     } while (0)
 
+extern "C" size_t dgn_dense_layer_agg_aux_bytes(const DgnDenseLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_dense_layer_agg_aux_bytes")) return 0;
+    static float dummy;                       // (only which operands exist matters here)
+    DgnDenseLayer tmp = *L;
+    if (!tmp.pq) tmp.pq = &dummy;
+    const DgnMsg msg = sweep_msg(&tmp, d, &dummy);
+    return dgn_agg_aux_bytes(L->graph, L->spec, &msg);
+}
+
 extern "C" int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg) {
     const int Fp = f_in + (f_in & 1), K = (n_agg + (type == 1)) * Fp, n = n_scalers * f_out;
     return (type == 0 || type == 1) && f_in >= 2 && f_out >= 2 && f_out <= 1024 && n_scalers >= 1 && n_scalers <= 3 && n_agg >= 1 &&
@@ -224,7 +234,8 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     DGN_HIP_CHECK(hipGetLastError());
     // the sweep (+ the h_in pass-through block of the complex layer)                            (:86-98 / :161-173)
     const DgnMsg msg = sweep_msg(L, d, hp);
-    DGN_TRY(dgn_agg_forward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->agg, d.K, ws + z_b + bn_b, L->ws_bytes - z_b - bn_b, stream));
+    DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->agg, d.K, L->agg_aux, ws + z_b + bn_b, L->ws_bytes - z_b - bn_b,
+                                stream));
     // posttrans with the folded scalers, bias and graph norm                                    (:116-122 / :187-193)
     DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
     DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
@@ -289,8 +300,8 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         gr.g_in = g_hp; gr.ld_in = d.Fp;
     }
     gr.accumulate = 0;
-    DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_agg, d.K, &gr, ws + s.agg_ws,
-                             dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1), stream));
+    DGN_TRY(dgn_agg_backward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_agg, d.K, L->agg_aux, &gr, ws + s.agg_ws,
+                                 dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1), stream));
     const float* g_res = L->residual ? G->g_out : nullptr;
     bool fused_dh = false;
     if (d.cx) {

@@ -127,6 +127,17 @@ extern "C" int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_
            (Fm % 16) != 0 && (f_out & 1) == 0 && Fo <= 1024;
 }
 
+extern "C" size_t dgn_towers_layer_agg_aux_bytes(const DgnTowersLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_towers_layer_agg_aux_bytes")) return 0;
+    DgnTowersLayer tmp = *L;
+    static float dummy;                       // (only which operands exist matters here)
+    if (!tmp.pq) tmp.pq = &dummy;
+    if (!tmp.h) tmp.h = &dummy;
+    const DgnMsg msg = sweep_msg(&tmp, d);
+    return dgn_agg_aux_bytes(L->graph, L->spec, &msg);
+}
+
 extern "C" int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out) {
     const bool off = getenv("DGN_NO_ZMASK") != nullptr || getenv("DGN_NO_MIX_FUSED") != nullptr;          // (read per call: the tests switch it)
     const int Fo = n_towers * f_out;
@@ -156,7 +167,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     // all towers' aggregators (+ the h_in block) in one sweep, tower-major                   (:237-249, :261-264)
     const DgnMsg msg = sweep_msg(L, d);
     const size_t agg_ws = L->ws_bytes - bn_ws;
-    DGN_TRY(dgn_agg_forward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, ws + bn_ws, agg_ws, stream));
+    DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, L->agg_aux, ws + bn_ws, agg_ws, stream));
     // posttrans([h || agg]) with the folded scalers, bias and graph norm                     (:266-271)
     DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
@@ -297,8 +308,8 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                                          L->scale, g_yr, d.N * d.fo, &gr, ws + s.agg_ws, dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1),
                                          stream));
     else
-        DGN_TRY(dgn_agg_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, &gr, ws + s.agg_ws,
-                                 dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
+        DGN_TRY(dgn_agg_backward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, L->agg_aux, &gr, ws + s.agg_ws,
+                                     dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
     // P|Q Linear: input gradient, weight + bias gradient (the bias rides in the weight-gradient pass)
     // d h = [residual] + d h_in + (d P|Q) W_sd: as the product's epilogue ((d h_in + product) + residual, add3's order) where the shapes
     // allow, else the product and a three-way add

@@ -110,7 +110,18 @@ def _out_layout(t: torch.Tensor):
     return 0, t.stride(0)
 
 
-def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out, edge_type=None):
+def agg_aux_bytes(graph: DGNGraph, plan: AggPlan, n_towers: int, F: int, x_src, x_dst, m_edge, x_in, edge_type=None) -> int:
+    """Bytes of the aux table of a forward / backward pair over this message (0: none; see dgn_agg_forward_aux in include/dgn_hip.h)."""
+    if len(plan.launches) != 1:
+        return 0
+    lib = _lib.load()
+    spec = _spec_structs(plan, n_towers, 1.0, 0)[0]
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
+    g = graph.c_graph
+    return int(lib.dgn_agg_aux_bytes(C.byref(g), C.byref(spec), C.byref(msg)))
+
+
+def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out, edge_type=None, aux=None):
     """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream.  ``edge_type`` (int32 [E], CSR slot
     order): ``m_edge`` is a [K, F] table and slot j adds row ``edge_type[j]``."""
     lib = _lib.load()
@@ -125,13 +136,13 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
         nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
         ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device) if nbytes else None
         wl = w[l.ch_offset:] if (w is not None and l.channels) else None
-        rc = lib.dgn_agg_forward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                 graph.log_deg.data_ptr(), out.data_ptr(), ld_out, _ptr(ws), nbytes, stream)
+        rc = lib.dgn_agg_forward_aux(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                     graph.log_deg.data_ptr(), out.data_ptr(), ld_out, _ptr(aux), _ptr(ws), nbytes, stream)
         _lib.check(rc, "dgn_agg_forward")
 
 
 def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, g_out,
-                    g_src, g_dst, g_edge, g_in, accumulate: bool = True, edge_type=None):
+                    g_src, g_dst, g_edge, g_in, accumulate: bool = True, edge_type=None, aux=None):
     """Enqueue dgn_agg_backward.  ``accumulate=False``: the sinks g_src/g_dst/g_in may be uninitialised, the first
     launch of the plan defines them and later launches add; ``True``: every launch adds.  g_edge is overwritten."""
     lib = _lib.load()
@@ -167,9 +178,9 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
             tmp = torch.empty_like(g_edge)
             grads.g_edge = tmp.data_ptr()
         grads.accumulate = 1 if (accumulate or not first) else 0
-        rc = lib.dgn_agg_backward(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
-                                  graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, C.byref(grads),
-                                  _ptr(ws), nbytes, stream)
+        rc = lib.dgn_agg_backward_aux(C.byref(g), C.byref(spec), C.byref(msg), _ptr(wl), w.stride(0) if w is not None else 0,
+                                      graph.log_deg.data_ptr(), g_out.data_ptr(), ld_gout, _ptr(aux), C.byref(grads),
+                                      _ptr(ws), nbytes, stream)
         _lib.check(rc, "dgn_agg_backward")
         if tmp is not None:
             g_edge += tmp
@@ -1000,6 +1011,10 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
+        # what the backward sweep would recompute from the messages (first max / min slot, dx signs): one byte per (row, feature)
+        n_aux = int(lib.dgn_towers_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0
+        aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
+        L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_towers_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
@@ -1007,14 +1022,14 @@ class _TowersLayer(torch.autograd.Function):
         L.n_valid = _ptr(ctx.n_valid)
         stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_towers_layer_forward(C.byref(L), stream), "dgn_towers_layer_forward")
-        ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf)
+        ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux)
         ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf = ctx.saved_tensors
+        w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux = ctx.saved_tensors
         graph, plan = ctx.graph, ctx.plan
         T, fi, fo, S, residual, momentum, eps, slope = ctx.cfg
         N, Fm, Fo = h.shape[0], T * fi, T * fo
@@ -1042,6 +1057,7 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if ctx.n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if ctx.use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
+        L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
@@ -1132,19 +1148,22 @@ class _DenseLayer(torch.autograd.Function):
         ctx.n_valid = _N_VALID
         L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
         L.running_mean, L.running_var, L.out = running_mean.data_ptr(), running_var.data_ptr(), out.data_ptr()
+        n_aux = int(lib.dgn_dense_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0      # (see _TowersLayer)
+        aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
+        L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_dense_layer_forward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
         stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_dense_layer_forward(C.byref(L), stream), "dgn_dense_layer_forward")
-        ctx.save_for_backward(w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf)
+        ctx.save_for_backward(w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf, aux)
         ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf = ctx.saved_tensors
+        w_edge, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, saved_buf, aux = ctx.saved_tensors
         cfg, graph = ctx.cfg, ctx.graph
         type_net, F0, fo = cfg[:3]
         N, dev = h.shape[0], h.device
@@ -1153,6 +1172,7 @@ class _DenseLayer(torch.autograd.Function):
         g_out = g_out.contiguous()
         graph.ensure_csc()
         L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
+        L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_dense_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
@@ -1196,6 +1216,9 @@ def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm
 # the separate kernels: the backward needs the aggregate rows for the posttrans weight gradient, and the recompute twin of this kernel
 # measured slower than reading them back.
 FUSED_FORWARD = os.environ.get("DGN_FUSED_FORWARD", "1") != "0"
+# True: the towers layer's forward sweep records the slots of each row's first maximum / minimum and the dx signs (one byte per row
+# and feature) and the backward sweep works from that table instead of gathering the source rows again (bit-identical gradients)
+AGG_AUX = os.environ.get("DGN_AGG_AUX", "1") != "0"
 
 
 def fused_sweep_posttrans_supported(graph: DGNGraph, plan: AggPlan, n_towers: int, F: int, n_scalers: int, f_out: int) -> bool:

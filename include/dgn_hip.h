@@ -201,6 +201,19 @@ size_t dgn_agg_workspace_bytes(const DgnGraph* g, const DgnAggSpec* spec, int64_
 int dgn_agg_forward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
                     const float* log_deg, float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
 
+/* The forward / backward pair with an AUX table between them (training): one byte per (row, feature) in which the forward records
+ * what the backward otherwise recomputes from the messages -- the slots of the row's first maximum / minimum and the sign of each
+ * dx residual -- so that the backward gathers no source row, reads no x_dst / x_in row and still produces the same bits.
+ * dgn_agg_aux_bytes() > 0 says the launch has such a table (molecule-like batches: at most three in-edges per row on average,
+ * a baked-in list with max / min / dx but without std / var, at most two weight channels, even F); `aux` NULL = the plain calls.
+ * Rows the 4-rows-per-wave kernels hand to the per-row routine (more than four in-edges, ...) are recomputed as before.          */
+size_t dgn_agg_aux_bytes(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg);
+int dgn_agg_forward_aux(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                        const float* log_deg, float* out, int64_t ld_out, unsigned char* aux, void* ws, size_t ws_bytes, void* stream);
+int dgn_agg_backward_aux(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
+                         const float* log_deg, const float* g_out, int64_t ld_gout, const unsigned char* aux, const DgnMsgGrad* grads,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* Backward of dgn_agg_forward for upstream gradient g_out [n_nodes, ld_gout].
  * Workspace: dgn_agg_backward_workspace_bytes(); with `deterministic` != 0 (needs g->csc_*) it includes the
  * [n_edges, F] staging buffer of the two-phase scatter; a smaller workspace silently selects the atomic path. */
@@ -483,6 +496,9 @@ typedef struct DgnTowersLayer {
      * pre-activation is never written: the forward leaves the sign mask of (z + b_mix) here, the backward reads the activation's
      * derivative from it (same values bit for bit), and `z` may be NULL.                                                      */
     unsigned char* zmask;
+    /* Optional: dgn_agg_aux_bytes(graph, spec, the sweep's message) bytes -- the forward sweep leaves its aux table here, the
+     * backward sweep works from it (dgn_agg_forward_aux / dgn_agg_backward_aux).  NULL: the backward recomputes.                */
+    unsigned char* agg_aux;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */
@@ -530,6 +546,7 @@ typedef struct DgnDenseLayer {
     float* out;                /* [N, f_out]  (forward only)                                                 */
     void* ws; size_t ws_bytes;
     const int64_t* n_valid;    /* DEVICE scalar or NULL (padded batches, see dgn_bn_tail_forward)            */
+    unsigned char* agg_aux;    /* optional: dgn_dense_layer_agg_aux_bytes() bytes, the sweep's aux table (dgn_agg_forward_aux) */
 } DgnDenseLayer;
 typedef struct DgnDenseGrads {
     const float* g_out;        /* [N, f_out]                                                                 */
@@ -537,6 +554,7 @@ typedef struct DgnDenseGrads {
     float* g_w_pre; float* g_b_pre; float* g_w_post; float* g_b_post; float* g_gamma; float* g_beta;   /* written */
 } DgnDenseGrads;
 int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg);
+size_t dgn_dense_layer_agg_aux_bytes(const DgnDenseLayer* L);      /* graph, spec, type and widths set; 0: no aux table */
 size_t dgn_dense_layer_forward_workspace_bytes(const DgnDenseLayer* layer);
 int dgn_dense_layer_forward(const DgnDenseLayer* layer, void* stream);
 size_t dgn_dense_layer_backward_workspace_bytes(const DgnDenseLayer* layer);
@@ -546,6 +564,8 @@ int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, in
 /* 1 when dgn_towers_layer_forward / _backward can work from DgnTowersLayer.zmask alone (the fused mixing-network kernels exist for
  * T * f_out columns and are not switched off): the caller then need not allocate `z`.                                            */
 int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out);
+/* bytes of DgnTowersLayer.agg_aux for this layer (graph, spec and widths set; 0: the sweep has no aux table)                    */
+size_t dgn_towers_layer_agg_aux_bytes(const DgnTowersLayer* L);
 size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);
 size_t dgn_towers_layer_backward_workspace_bytes(const DgnTowersLayer* layer);

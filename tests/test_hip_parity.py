@@ -745,6 +745,91 @@ def test_whole_layer_call_equals_per_kernel_route(monkeypatch, residual, graph_n
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
 
 
+@pytest.mark.parametrize("aggs,T", [("mean max min dir1-av dir1-dx", 5), ("mean max min dir1-dx dir1-av", 1), ("mean max min dir1-av dir1-dx", 1)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_backward_from_the_aux_table_is_bitwise_the_recomputing_backward(monkeypatch, aggs, T, ties):
+    """dgn_agg_forward_aux / dgn_agg_backward_aux: the forward records the slots of every row's first maximum / minimum and the sign of
+    the dx residual, the backward works from that byte table instead of forming the messages again.  Gradients must be the bits of the
+    recomputing backward -- also with ties everywhere (integer features: first occurrence wins) and with dx residuals that are exactly
+    zero (constant eig column on part of the batch: sign(0) = 0)."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import ops, synth
+    b = synth.molecule_batch(60, seed=13, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    eig = b["eig"].clone()
+    eig[: N // 3] = 0.25                                           # no direction on these graphs: all weights zero
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=eig.to(dev))
+    F_ = 70
+    names = aggs.split()
+    plan = dgn_amd.make_plan(names + ["__x_in__"], ["identity"]) if T > 1 else dgn_amd.make_plan(names, ["identity"])
+    gen = torch.Generator().manual_seed(3)
+    mk = (lambda: torch.randint(-2, 3, (N, F_), generator=gen).float().to(dev)) if ties else (lambda: torch.randn(N, F_, generator=gen).to(dev))
+    xs, xd, xin = mk(), mk(), mk()
+    nb = ops.agg_aux_bytes(graph, plan, T, F_, xs, xd, None, xin)
+    assert nb >= N * F_, "this launch should have an aux table"
+    w = graph.edge_weights(plan)
+    A = plan.n_agg
+    K = A * (F_ // T)
+    out = torch.empty(T, N, K, device=dev) if T > 1 else torch.empty(N, A * F_, device=dev)
+    out2 = torch.empty_like(out)
+    aux = torch.full((nb,), 0xEE, dtype=torch.uint8, device=dev)
+    ops.launch_forward(graph, plan, T, 1.0, w, xs, xd, None, xin, out, aux=aux)
+    ops.launch_forward(graph, plan, T, 1.0, w, xs, xd, None, xin, out2)
+    assert torch.equal(out, out2)                                    # the tracking forward computes the same values
+    g_out = torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(a):
+        sinks = [torch.full((N, F_), float("nan"), device=dev) for _ in range(3)]
+        ops.launch_backward(graph, plan, T, 1.0, w, xs, xd, None, xin, g_out, sinks[0], sinks[1], None, sinks[2], accumulate=False, aux=a)
+        return sinks
+
+    with_aux, recomputed = run(aux), run(None)
+    for x, y in zip(with_aux, recomputed):
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y)
+    # poisoned operands prove that the aux backward of the grouped rows does not read the messages' inputs at all: only rows in groups
+    # the per-row routine handles (a row with more than four or no in-edges in the group, the last partial group) may differ
+    deg = (graph.indptr[1:] - graph.indptr[:-1]).long()
+    grp_ok = ((deg >= 1) & (deg <= 4)).view(-1)[: (N // 4) * 4].view(-1, 4).all(1).repeat_interleave(4)
+    xs_bad = torch.full_like(xs, float("nan"))
+    sinks = [torch.full((N, F_), float("nan"), device=dev) for _ in range(3)]
+    ops.launch_backward(graph, plan, T, 1.0, w, xs_bad, torch.full_like(xd, float("nan")), None, torch.full_like(xin, float("nan")), g_out,
+                        sinks[0], sinks[1], None, sinks[2], accumulate=False, aux=aux)
+    rows = torch.nonzero(grp_ok).view(-1)
+    assert rows.numel() > N // 2
+    assert torch.equal(sinks[1][rows], recomputed[1][rows])          # d x_dst of the grouped rows
+    assert torch.equal(sinks[2][rows], recomputed[2][rows])          # d x_in
+
+
+def test_towers_layer_with_the_aux_table_is_bitwise_the_recomputing_layer(monkeypatch):
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    b = synth.molecule_batch(150, seed=8, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    torch.manual_seed(1)
+    layer = dgn_amd.DGNLayer(70, 70, 0.0, True, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation", {"log": torch.tensor(1.2)},
+                             "towers", True, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    h0 = torch.randn(N, 70, device=dev, generator=gen)
+    ct = torch.randn(N, 70, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    res = []
+    for aux in (True, False):
+        monkeypatch.setattr(dgn_amd.ops, "AGG_AUX", aux)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        res.append([y.detach(), h.grad] + [p.grad for p in lay.parameters()])
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("n_graphs", [200, 3])
 @pytest.mark.parametrize("residual", [True, False])
 def test_towers_layer_with_the_activation_mask_is_bitwise_the_layer_with_z(monkeypatch, n_graphs, residual):
