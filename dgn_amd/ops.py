@@ -232,8 +232,13 @@ class _DirectionalAggregate(torch.autograd.Function):
             out = torch.empty((n_towers, N, plan.out_width(F) // n_towers), dtype=torch.float32, device=ref.device)
         else:
             out = torch.empty((N, plan.out_width(F)), dtype=torch.float32, device=ref.device)
-        launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out, edge_type)
-        ctx.edge_type = edge_type
+        # training: the forward leaves what the backward would recompute from the messages in a byte table (dgn_agg_forward_aux)
+        aux = None
+        if AGG_AUX and any(ctx.needs_input_grad):
+            n_aux = agg_aux_bytes(graph, plan, n_towers, F, x_src, x_dst, m_edge, x_in, edge_type)
+            aux = torch.empty(n_aux, dtype=torch.uint8, device=ref.device) if n_aux else None
+        launch_forward(graph, plan, n_towers, avg_log, w, x_src, x_dst, m_edge, x_in, out, edge_type, aux=aux)
+        ctx.edge_type, ctx.aux = edge_type, aux
         ctx.graph, ctx.plan, ctx.n_towers, ctx.avg_log, ctx.xin_is_src, ctx.F = graph, plan, n_towers, avg_log, xin_is_src, F
         ctx.paired = x_pair is not None
         if ctx.paired:
@@ -275,7 +280,7 @@ class _DirectionalAggregate(torch.autograd.Function):
         if ctx.edge_type is not None and g_src is None:
             g_src = _empty_rows(x_src)               # (the table's gradient is a reduction of the staged per-edge rows)
         launch_backward(graph, plan, ctx.n_towers, ctx.avg_log, w, x_src, x_dst, m_edge, x_in, g_out, g_src, g_dst, g_edge, g_in,
-                        accumulate=False, edge_type=ctx.edge_type)
+                        accumulate=False, edge_type=ctx.edge_type, aux=ctx.aux)
         if x_in is not None and not ctx.xin_is_src and need_in and g_in is None:
             g_in = torch.zeros_like(x_in)
         if ctx.paired:
