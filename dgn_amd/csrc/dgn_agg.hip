@@ -239,9 +239,14 @@ size_t stage_bytes(const DgnGraph* g, int64_t F) { return ((size_t)g->n_edges * 
 // but needs no message value in the emit pass (no std / var), with at most two weight channels: short-row graph, even width.
 static bool agg_aux_supported(const AggParams& p, const DgnMsg* msg) {
     static const bool off = getenv("DGN_NO_AUX") != nullptr;
-    return !off && short_rows(p) && is_hot_list(p) && p.n_ch <= 2 && (p.need & NEED_RECOMP) && !(p.need & (NEED_M_EMIT | NEED_SQ)) &&
-           msg->x_src && !(msg->m_edge && !msg->edge_type) && (msg->F % 2) == 0 && p.n_nodes > 0;
+    if (off || !is_hot_list(p) || p.n_ch > 2 || !(p.need & NEED_RECOMP) || (p.need & (NEED_M_EMIT | NEED_SQ)) || p.n_nodes <= 0) return false;
+    if (short_rows(p)) return msg->x_src && !(msg->m_edge && !msg->edge_type) && (msg->F % 2) == 0;
+    // longer rows (row-per-wave kernels): the dx signs only -- lists without max / min, no hub rows
+    static const bool no_rows = getenv("DGN_NO_AUX_ROWS") != nullptr;
+    return !no_rows && p.n_ch >= 1 && !(p.need & (NEED_MAX | NEED_MIN)) && p.n_hub == 0;
 }
+// (row-major sign table of the row-per-wave kernels, see AggParams.aux_rows)
+static bool agg_aux_is_rows(const AggParams& p) { return !short_rows(p); }
 
 extern "C" size_t dgn_agg_aux_bytes(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg) {
     if (!g || !spec || !msg || msg->F <= 0 || spec->n_agg < 1 || spec->n_agg > DGN_MAX_AGG || spec->n_towers < 1) return 0;
@@ -283,6 +288,7 @@ extern "C" int dgn_agg_forward_aux(const DgnGraph* g, const DgnAggSpec* spec, co
     if (aux) {
         if (!agg_aux_supported(p, msg)) { set_error("dgn_agg_forward_aux: this launch has no aux table (dgn_agg_aux_bytes() == 0)"); return DGN_ERR_INVALID; }
         p.aux = aux;
+        p.aux_rows = agg_aux_is_rows(p);
     }
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     const int vec = pick_vec(spec, msg, out, ld_out, nullptr);
@@ -314,6 +320,7 @@ int agg_backward_prepare(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec
     if (aux) {
         if (lds_gout || !agg_aux_supported(p, msg)) { set_error("dgn_agg_backward_aux: this launch has no aux table (dgn_agg_aux_bytes() == 0)"); return DGN_ERR_INVALID; }
         p.aux = const_cast<unsigned char*>(aux);
+        p.aux_rows = agg_aux_is_rows(p);
     }
     if (g->n_hub > 0) carve_ws(p, g, spec, ws);
     // atomic-free scatter when the transposed view and the [E, F] staging buffer are available

@@ -106,6 +106,9 @@ struct AggParams {
     // weight channel 0 / 1 (0: zero, 1: positive, 2: negative).  Written by agg_fwd_short for groups of rows with at most kShortDeg
     // in-edges, read by agg_bwd_short for the same groups (lists with at most two channels and no std / var).  NULL = recompute.
     unsigned char* aux;
+    // aux_rows: the graph runs the row-per-wave kernels (longer rows) and the list has no max / min: the table then holds the dx signs
+    // only, row-major [n_nodes][F] (bits 4-7 of aux_byte), written by fwd_one_row and read by the per-row backward
+    int32_t aux_rows;
     int32_t stage_out;    // forward, agg_fwd_short: rows go through the wave's LDS slice (tower-major output, one feature tile)
     bool fresh;           // backward: g_dst / g_in rows are WRITTEN by the row kernel (buffers arrive uninitialised)
     bool seg_add;         // backward: seg_sum_rows adds to g_src (accumulate mode, or g_in aliases g_src) instead of writing it
@@ -583,16 +586,42 @@ __device__ __forceinline__ void write_row(const Acc<C, TRACK>& acc, const AggPar
 }
 
 // AggParams.aux: the byte of one (row, feature) from the row's tracked accumulators (arg max / min tracked as positions within the row)
-template <class C>
-__device__ __forceinline__ unsigned aux_byte(const Acc<C, true>& acc, int i, float xin_i) {
+template <class C, bool TRACK>
+__device__ __forceinline__ unsigned aux_byte(const Acc<C, TRACK>& acc, int i, float xin_i) {
     unsigned b = 0;
-    if constexpr (C::STATS) b = ((unsigned)acc.amax[i] & 3u) | (((unsigned)acc.amin[i] & 3u) << 2);      // (tracked as positions within the row)
+    if constexpr (C::STATS && TRACK) b = ((unsigned)acc.amax[i] & 3u) | (((unsigned)acc.amin[i] & 3u) << 2);      // (tracked as positions within the row)
 #pragma unroll
     for (int c = 0; c < (C::NCH < 2 ? C::NCH : 2); ++c) {
         const float r = dx_residual(acc.ws[c][i], acc.sw[c], xin_i);
         b |= (r > 0.f ? 1u : (r < 0.f ? 2u : 0u)) << (4 + 2 * c);
     }
     return b;
+}
+template <int VEC>
+__device__ __forceinline__ void store_aux_row(unsigned char* at, const unsigned (&b)[VEC]) {
+    if constexpr (VEC == 1) *at = (unsigned char)b[0];
+    else if constexpr (VEC == 2) *reinterpret_cast<unsigned short*>(at) = (unsigned short)(b[0] | (b[1] << 8));
+    else *reinterpret_cast<unsigned*>(at) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+}
+template <int VEC>
+__device__ __forceinline__ unsigned load_aux_row(const unsigned char* at) {
+    if constexpr (VEC == 1) return *at;
+    else if constexpr (VEC == 2) return *reinterpret_cast<const unsigned short*>(at);
+    else return *reinterpret_cast<const unsigned*>(at);
+}
+// the fields of an accumulator the coefficient code reads for a dx aggregator, from the aux byte(s) `w` (byte i = feature i): a stand-in
+// of sum_j w_jc m_j with the residual's sign (x_in then reads as zero)
+template <class C, bool TRACK>
+__device__ __forceinline__ void acc_signs_from_aux(Acc<C, TRACK>& acc, unsigned w) {
+#pragma unroll
+    for (int i = 0; i < C::VEC; ++i) {
+        const unsigned ab = (w >> (8 * i)) & 0xffu;
+#pragma unroll
+        for (int c = 0; c < (C::NCH < 2 ? C::NCH : 2); ++c) {
+            const unsigned code = (ab >> (4 + 2 * c)) & 3u;
+            acc.ws[c][i] = code == 1u ? 1.f : (code == 2u ? -1.f : 0.f);
+        }
+    }
 }
 // The table is laid out per group of four rows and per lane: a lane's bytes of the four rows are adjacent (4 VEC bytes at
 // group * 4 F + 4 f0), so a group is ONE store / load instruction of consecutive 8-byte (VEC = 2) lanes.
@@ -700,6 +729,14 @@ __device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0,
     acc.init();
     accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
     if (active) write_row<C, O>(acc, p, orow_override ? orow_override : p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+    if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
+        if (active && p.aux_rows) {          // the dx signs for the backward (AggParams.aux_rows)
+            unsigned ab[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ab[i] = aux_byte<C, false>(acc, i, xin[i]);
+            store_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0, ab);
+        }
+    }
 }
 
 template <class C, class O = DynOps>
@@ -918,7 +955,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
             write_row<C, O, AUX>(acc, p, staged ? lds_row + (grouped ? r * K : 0) : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
             if constexpr (AUX) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) auxv[r][i] = aux_byte<C>(acc, i, side[r].xin[i]);
+                for (int i = 0; i < VEC; ++i) auxv[r][i] = aux_byte<C, true>(acc, i, side[r].xin[i]);
             }
         }
         if (staged && !grouped) {
@@ -1343,16 +1380,26 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     SlotBatch<C::NCH, C::NW> b;
     b.load(p, beg, end);
     const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
-    const bool recomp = (p.need & NEED_RECOMP) != 0;
+    bool recomp = (p.need & NEED_RECOMP) != 0;
+    // aux_rows: the forward left the dx signs (the only thing such a list recomputes for): no gathers, no x_dst / x_in rows
+    bool signs = false;
+    unsigned auxw = 0;
+    if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
+        signs = recomp && p.aux_rows != 0;
+        if (signs && active) auxw = load_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0);
+    }
+    if (signs) recomp = false;
     if constexpr (C::NCH > 0) {
-        if (!recomp) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
+        if (!recomp && !signs) {       // only sum_j w_jc is needed (d x_in of dx-no-abs): the batch's weights alone, no gathers
 #pragma unroll
             for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(b.w[c]);       // (all lanes still here)
         }
     }
     if (!active) return;
-    if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    if (!signs) {
+        if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+        if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    }
     constexpr bool PRE = O::kStatic && O::NA <= 8;
     float gpre[PRE ? O::NA : 1][VEC];
     const bool pre = PRE && O::n_scalers(p) == 1;
@@ -1364,6 +1411,15 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     }
     const MsgSrc<VEC> src(p);
     if (recomp) accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
+    if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
+        if (signs) {                   // sum_j w_jc in acc.add()'s order, the residual's sign from the table
+            for (int k_ = 0; k_ < deg; ++k_) {
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) acc.sw[c] += bcast_f(b.w[c], k_);
+            }
+            acc_signs_from_aux<C, true>(acc, auxw);
+        }
+    }
     if constexpr (PRE) {
         if (pre) {
             make_coef_from<C, O>(k, gxin, acc, p, [&](int a, int, float (&g)[VEC]) {
@@ -1433,9 +1489,31 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
         bwd_row_one_batch<C, O>(p, row, beg, end, f0, active);
         return;
     }
-    if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
-    if (p.need & NEED_RECOMP) {
+    bool signs = false;
+    if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) signs = (p.need & NEED_RECOMP) && p.aux_rows != 0;
+    if (!signs) {
+        if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
+        if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    }
+    if (signs) {
+        if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
+            // (aux_rows, see bwd_row_one_batch) the weights of the row's slots summed in slot order, batch after batch
+            const unsigned auxw = active ? load_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0) : 0u;
+            for (int base = beg; base < end; base += kWave) {
+                const int e = base + lane_id(), cnt = min(kWave, end - base);
+                float wl[C::NW];
+#pragma unroll
+                for (int c = 0; c < C::NW; ++c) wl[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) wl[c] = e < end ? p.w[(int64_t)c * p.ld_w + e] : 0.f;
+                for (int k_ = 0; k_ < cnt; ++k_) {
+#pragma unroll
+                    for (int c = 0; c < C::NCH; ++c) acc.sw[c] += bcast_f(wl[c], k_);
+                }
+            }
+            acc_signs_from_aux<C, true>(acc, auxw);
+        }
+    } else if (p.need & NEED_RECOMP) {
         accumulate_range<C, true>(acc, p, beg, end, f0, active, xd);
     } else if constexpr (C::NCH > 0) {
         // only sum_j w_jc is needed (d x_in of dx-no-abs): weights alone, no gathers

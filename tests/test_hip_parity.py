@@ -802,6 +802,61 @@ def test_backward_from_the_aux_table_is_bitwise_the_recomputing_backward(monkeyp
     assert torch.equal(sinks[2][rows], recomputed[2][rows])          # d x_in
 
 
+@pytest.mark.parametrize("kind", ["knn", "sbm"])
+@pytest.mark.parametrize("form", ["simple", "complex"])
+def test_backward_from_the_sign_table_on_longer_rows_is_bitwise_the_recomputing_backward(kind, form):
+    """Row-per-wave kernels (k-NN / SBM batches: CIFAR10, PATTERN json lists `mean dir1-dx dir2-dx`): the aux table holds the dx signs
+    only, the backward then gathers nothing.  Same bits as the recomputing backward; rows with more than 64 in-edges (SBM) included."""
+    dev = _dev()
+    import dgn_amd
+    from dgn_amd import ops, synth
+    b = synth.knn_batch(n_graphs=6, seed=3) if kind == "knn" else synth.sbm_batch(n_graphs=3, seed=3)
+    N = int(b["num_nodes"])
+    eig = b["eig"].float().clone()
+    eig[: N // 4] = 0.5                                              # residuals that are exactly zero on part of the batch
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=eig.to(dev))
+    deg = (graph.indptr[1:] - graph.indptr[:-1])
+    if kind == "sbm":
+        assert int(deg.max()) > 64
+    F_ = 66 if form == "simple" else 48
+    names = ["mean", "dir1-dx", "dir2-dx"] + (["__x_in__"] if form == "complex" else [])
+    plan = dgn_amd.make_plan(names, ["identity"])
+    gen = torch.Generator().manual_seed(5)
+    xs = torch.randn(N, F_, generator=gen).to(dev)
+    xd = torch.randn(N, F_, generator=gen).to(dev) if form == "complex" else None
+    xin = torch.randn(N, F_, generator=gen).to(dev) if form == "complex" else xs
+    nb = ops.agg_aux_bytes(graph, plan, 1, F_, xs, xd, None, xin)
+    assert nb >= N * F_, "this launch should have a sign table"
+    w = graph.edge_weights(plan)
+    out, out2 = torch.empty(N, plan.out_width(F_), device=dev), torch.empty(N, plan.out_width(F_), device=dev)
+    aux = torch.full((nb,), 0xEE, dtype=torch.uint8, device=dev)
+    ops.launch_forward(graph, plan, 1, 1.0, w, xs, xd, None, xin, out, aux=aux)
+    ops.launch_forward(graph, plan, 1, 1.0, w, xs, xd, None, xin, out2)
+    assert torch.equal(out, out2)
+    g_out = torch.randn(out.shape, generator=gen).to(dev)
+
+    def run(a, xs_, xd_, xin_):
+        if form == "simple":
+            g = torch.full((N, F_), float("nan"), device=dev)
+            ops.launch_backward(graph, plan, 1, 1.0, w, xs_, None, None, xs_, g_out, g, None, None, g, accumulate=False, aux=a)
+            return [g]
+        sinks = [torch.full((N, F_), float("nan"), device=dev) for _ in range(3)]
+        ops.launch_backward(graph, plan, 1, 1.0, w, xs_, xd_, None, xin_, g_out, sinks[0], sinks[1], None, sinks[2], accumulate=False, aux=a)
+        return sinks
+
+    ref = run(None, xs, xd, xin)
+    got = run(aux, xs, xd, xin)
+    for x, y in zip(got, ref):
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y)
+    # with the table the backward reads none of the message operands
+    nan = lambda t: None if t is None else torch.full_like(t, float("nan"))
+    xs_bad = nan(xs)
+    poisoned = run(aux, xs_bad, nan(xd), xs_bad if form == "simple" else nan(xin))
+    for x, y in zip(poisoned, ref):
+        assert torch.equal(x, y)
+
+
 def test_towers_layer_with_the_aux_table_is_bitwise_the_recomputing_layer(monkeypatch):
     dev = _dev()
     import copy
