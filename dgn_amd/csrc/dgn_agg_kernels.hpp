@@ -550,7 +550,7 @@ __device__ __forceinline__ void agg_value(float (&val)[C::VEC], int op, int c, c
 // orow already includes the lane's column part; xin / logd were loaded by the caller (early).
 template <class C, class O = DynOps, bool TRACK = false>
 __device__ __forceinline__ void write_row(const Acc<C, TRACK>& acc, const AggParams& p, float* orow, int deg,
-                                          const float (&xin)[C::VEC], float logd) {
+                                          const float (&xin)[C::VEC], float logd, bool to_global = false) {      // to_global: streaming stores
     constexpr int VEC = C::VEC;
     if (deg == 0) {      // no messages: zeros (DGL fills such rows from the zero initializer); the x_in block is still x_in
         float z[VEC];
@@ -558,7 +558,8 @@ __device__ __forceinline__ void write_row(const Acc<C, TRACK>& acc, const AggPar
         for (int i = 0; i < VEC; ++i) z[i] = 0.f;
         for (int s = 0; s < O::n_scalers(p); ++s)
             for (int a = 0; a < O::n_agg(p); ++a)
-                stv<VEC>(orow + sa_col(p, s, a), (O::op(p, a) == DGN_AGG_X_IN && O::scaler(p, s) == DGN_SCALE_IDENTITY) ? xin : z);
+                if (to_global) stv_stream<VEC>(orow + sa_col(p, s, a), (O::op(p, a) == DGN_AGG_X_IN && O::scaler(p, s) == DGN_SCALE_IDENTITY) ? xin : z);
+                else stv<VEC>(orow + sa_col(p, s, a), (O::op(p, a) == DGN_AGG_X_IN && O::scaler(p, s) == DGN_SCALE_IDENTITY) ? xin : z);
         return;
     }
     const float d = (float)deg;
@@ -576,10 +577,8 @@ __device__ __forceinline__ void write_row(const Acc<C, TRACK>& acc, const AggPar
                 float o[VEC];
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) o[i] = O::scaler(p, s) == DGN_SCALE_IDENTITY ? val[i] : val[i] * fac[s];
-#ifdef DGN_EXP_NOSTORE
-                if (o[0] == 123.456f)
-#endif
-                stv<VEC>(orow + sa_col(p, s, a), o);      // (orow may point into the wave's LDS staging slice, see agg_fwd_short)
+                if (to_global) stv_stream<VEC>(orow + sa_col(p, s, a), o);
+                else stv<VEC>(orow + sa_col(p, s, a), o);      // (orow may point into the wave's LDS staging slice, see agg_fwd_short)
             }
         }
     });
@@ -728,7 +727,7 @@ __device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0,
     Acc<C, false> acc;
     acc.init();
     accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
-    if (active) write_row<C, O>(acc, p, orow_override ? orow_override : p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd);
+    if (active) write_row<C, O>(acc, p, orow_override ? orow_override : p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, logd, orow_override == nullptr);
     if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
         if (active && p.aux_rows) {          // the dx signs for the backward (AggParams.aux_rows)
             unsigned ab[VEC];
@@ -952,7 +951,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                     acc.add(mm, wk, AUX ? j : beg0 + lo[r] + j);          // (AUX: the tracked "slot" is the position within the row)
                 }
             }
-            write_row<C, O, AUX>(acc, p, staged ? lds_row + (grouped ? r * K : 0) : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd);
+            write_row<C, O, AUX>(acc, p, staged ? lds_row + (grouped ? r * K : 0) : orow + lane_col(p, f0), deg[r], side[r].xin, side[r].logd, !staged);
             if constexpr (AUX) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) auxv[r][i] = aux_byte<C, true>(acc, i, side[r].xin[i]);
@@ -966,7 +965,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                 const int K4 = K >> 2, total4 = p.n_towers * K4;
                 for (int i4 = lane_id(); i4 < total4; i4 += kWave) {
                     const int q = i4 / K4, c4 = i4 - q * K4;
-                    *reinterpret_cast<float4*>(orow + (int64_t)q * p.tower_stride + 4 * c4) = reinterpret_cast<const float4*>(slice)[i4];
+                    st_stream(reinterpret_cast<float4*>(orow + (int64_t)q * p.tower_stride + 4 * c4), reinterpret_cast<const float4*>(slice)[i4]);
                 }
             } else {
                 const int c = lane_id() * VEC;
@@ -974,7 +973,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                     for (int q = 0; q < p.n_towers; ++q) {
                         float v[VEC];
                         ldv<VEC>(v, slice + q * K + c);
-                        stv<VEC>(orow + (int64_t)q * p.tower_stride + c, v);
+                        stv_stream<VEC>(orow + (int64_t)q * p.tower_stride + c, v);
                     }
                 }
             }
@@ -986,12 +985,16 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     }
     if (grouped) {
         // (same wave: LDS operations complete in program order, no barrier needed)
-        const int run4 = grp.nrows * K >> 2;
+        const int run = grp.nrows * K;                   // (K is even; a full group's 4 K floats are a whole number of 16-byte pieces)
         float* obase = p.out + (int64_t)grp.row0 * p.ld_out;
         for (int q = 0; q < p.n_towers; ++q) {
-            const float4* from = reinterpret_cast<const float4*>(slice + q * R * K);
-            float4* to = reinterpret_cast<float4*>(obase + (int64_t)q * p.tower_stride);
-            for (int i4 = lane_id(); i4 < run4; i4 += kWave) to[i4] = from[i4];
+            const float* from = slice + q * R * K;
+            float* to = obase + (int64_t)q * p.tower_stride;
+            if ((run & 3) == 0) {
+                for (int i4 = lane_id(); i4 < (run >> 2); i4 += kWave) st_stream(reinterpret_cast<float4*>(to) + i4, reinterpret_cast<const float4*>(from)[i4]);
+            } else {
+                for (int i2 = lane_id(); i2 < (run >> 1); i2 += kWave) st_stream(reinterpret_cast<float2*>(to) + i2, reinterpret_cast<const float2*>(from)[i2]);
+            }
         }
     }
 }
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void agg_fwd_hub_combine(const AggParams p)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) xin[i] = 0.f;
     if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
-    write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, p.log_deg ? p.log_deg[row] : 0.f);
+    write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, p.log_deg ? p.log_deg[row] : 0.f, true);
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -1916,11 +1919,13 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
         const bool sa_in_tower = p.agg_offset == 0 && p.n_agg == p.agg_total;     // the launch writes the whole row of every tower
         q.stage_out = (!no_stage && p.n_towers > 1 && tiles == 1 && p.n_scalers == 1 && sa_in_tower && K <= kWave * C::VEC &&
                        (size_t)wpb * p.n_towers * K * sizeof(float) <= 32768) ? 1 : 0;
-        // ... and the whole group at once when the rows of a tower plane are contiguous and 16-byte pieces line up
+        // ... and the whole group at once when the rows of a tower plane are contiguous and 16-byte pieces line up: also for ONE
+        // tower (simple / complex layers: the group's four rows are one run of 4 A F floats)
         static const bool no_group = getenv("DGN_NO_STAGE_GROUP") != nullptr;
         const size_t group_lds = (size_t)wpb * kShortRows * p.n_towers * K * sizeof(float);
-        if (q.stage_out && !no_group && p.ld_out == K && (K & 3) == 0 && (p.tower_stride & 3) == 0 &&
-            (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && group_lds <= 32768) q.stage_out = 2;
+        if (!no_stage && !no_group && tiles == 1 && p.n_scalers == 1 && sa_in_tower && p.ld_out == K && (K & 1) == 0 &&
+            (p.n_towers == 1 || ((p.tower_stride & 3) == 0 && (K & 3) == 0)) && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && group_lds <= 32768)
+            q.stage_out = 2;
         size_t lds = q.stage_out == 2 ? group_lds : q.stage_out ? (size_t)wpb * p.n_towers * K * sizeof(float) : 0;
         if (p.edge_type) {
             q.tab_off = (int32_t)(lds / sizeof(float));

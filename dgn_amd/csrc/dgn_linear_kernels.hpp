@@ -355,7 +355,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
                         c = make_float4(pe1[2 * jq].x + c.x, pe1[2 * jq].y + c.y, pe1[2 * jq + 1].x + c.z, pe1[2 * jq + 1].y + c.w);
                         if (p.add2) c = make_float4(c.x + pe2[2 * jq].x, c.y + pe2[2 * jq].y, c.z + pe2[2 * jq + 1].x, c.w + pe2[2 * jq + 1].y);
                     }
-                    reinterpret_cast<float4*>(dst)[jq * 64 + lane] = c;
+                    if constexpr (EXPAND) st_stream(reinterpret_cast<float4*>(dst) + (jq * 64 + lane), c);        // (the [N, A F] gradient: read by the NEXT kernel, too large to stay cached)
+                    else reinterpret_cast<float4*>(dst)[jq * 64 + lane] = c;
                 }
             }
         } else {
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
                         c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
                         if (p.add2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
                     }
-                    reinterpret_cast<float2*>(dst)[j * 64 + lane] = c;
+                    if constexpr (EXPAND) st_stream(reinterpret_cast<float2*>(dst) + (j * 64 + lane), c);
+                    else reinterpret_cast<float2*>(dst)[j * 64 + lane] = c;
                 }
             }
         }
