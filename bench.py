@@ -419,7 +419,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     # the forward / backward pair as the layer runs it in training: where the launch has an aux table (dgn_agg_forward_aux: slots of the
     # first max / min and dx signs, one byte per row and feature) the forward writes it and the backward works from it
     from dgn_amd import ops as _ops
-    n_aux = _ops.agg_aux_bytes(graph, plan, T, Fk, xs, xd, me, hd, et) if (_ops.AGG_AUX and (g_me is None or et is not None) and wl["type_net"] in AUX_LAYERS) else 0
+    n_aux = _ops.agg_aux_bytes(graph, plan, T, Fk, xs, xd, me, hd, et) if (_ops.AGG_AUX and wl["type_net"] in AUX_LAYERS) else 0
     aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
     fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et, aux=aux)
     bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False,

@@ -240,7 +240,7 @@ size_t stage_bytes(const DgnGraph* g, int64_t F) { return ((size_t)g->n_edges * 
 static bool agg_aux_supported(const AggParams& p, const DgnMsg* msg) {
     static const bool off = getenv("DGN_NO_AUX") != nullptr;
     if (off || !is_hot_list(p) || p.n_ch > 2 || !(p.need & NEED_RECOMP) || (p.need & (NEED_M_EMIT | NEED_SQ)) || p.n_nodes <= 0) return false;
-    if (short_rows(p)) return msg->x_src && !(msg->m_edge && !msg->edge_type) && (msg->F % 2) == 0;
+    if (short_rows(p)) return msg->x_src && (msg->F % 2) == 0;
     // longer rows (row-per-wave kernels): the dx signs only -- lists without max / min, no hub rows
     static const bool no_rows = getenv("DGN_NO_AUX_ROWS") != nullptr;
     return !no_rows && p.n_ch >= 1 && !(p.need & (NEED_MAX | NEED_MIN)) && p.n_hub == 0;

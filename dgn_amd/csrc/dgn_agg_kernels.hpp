@@ -859,7 +859,9 @@ __device__ __forceinline__ void short_group_to_lds(const AggParams& p, const Sho
     }
 }
 
-template <class C, class O = DynOps, bool AUX = false>
+// MEDGE: the message has a third, per-edge term m_edge[slot] (dense edge features: rows in slot order, so a group's rows are one
+// contiguous block): a second tile, issued with the gathers.
+template <class C, class O = DynOps, bool AUX = false, bool MEDGE = false>
 __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     constexpr int VEC = C::VEC, R = kShortRows, J = kShortDeg;
     extern __shared__ float lds_rows[];
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
         deg[r] = grp.ptr(min(r + 1, grp.nrows)) - beg0 - lo[r];
         max_deg = max(max_deg, deg[r]);
     }
-    if (max_deg > J || (p.x_src && p.m_edge && !tab)) {   // a longer row, or two gathered parts per message: row at a time
+    if (max_deg > J || (!MEDGE && p.x_src && p.m_edge && !tab)) {   // a longer row, or an untiled second part per message: row at a time
         for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active);
         return;
     }
@@ -919,14 +921,22 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     const MsgSrc<VEC> src(p);
     // tile [row][j-th slot of the row]: the register index is static, the slot (= lane of the batch) is not --
     // one compare per tile instead of a range check of every slot against every row
-    float t[R][J][VEC];
+    float t[R][J][VEC], t2[MEDGE ? R : 1][MEDGE ? J : 1][VEC];
     unsigned auxv[AUX ? R : 1][VEC] = {};
     if (active) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
 #pragma unroll
-            for (int j = 0; j < J; ++j)
-                if (j < deg[r]) src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
+            for (int j = 0; j < J; ++j) {
+                if (j < deg[r]) {
+                    if constexpr (MEDGE) {
+                        ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                        ldv<VEC>(t2[r][j], p.m_edge + (int64_t)(beg0 + lo[r] + j) * p.ld_edge + f0);
+                    } else {
+                        src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
+                    }
+                }
+            }
         }
     }
 #pragma unroll
@@ -942,6 +952,10 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
                     float mm[VEC], wk[C::NW];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) mm[i] = side[r].xd[i] + t[r][j][i];
+                    if constexpr (MEDGE) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) mm[i] += t2[r][j][i];            // (load_msg's order: (x_dst + x_src) + m_edge)
+                    }
                     if (tab) {
                         const float* tr = tab + bcast_i(b.et, lo[r] + j) * p.F + f0;
 #pragma unroll
@@ -1569,7 +1583,7 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
     constexpr int VEC = C::VEC, J = kShortDeg;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
     constexpr bool PRE = O::kStatic && NG <= 8;
-    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && !p.g_edge && (EDGE ? (p.m_edge && p.edge_type) : !p.m_edge) &&
+    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && (EDGE ? p.m_edge != nullptr : (!p.m_edge && !p.g_edge)) &&
                 !(p.need & NEED_M_EMIT);      // (no static list carries std / var: their emit term stays with the per-row routine)
     const bool recomp = (p.need & NEED_RECOMP) != 0;     // (otherwise only sum_j w_jc is needed: no gathers at all)
     int lo[RB], deg[RB], beg0 = 0;
@@ -1729,6 +1743,9 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
                         rsum[i] += gm[i];
                     }
                     stv<VEC>(p.stage + (int64_t)bcast_i(my_tpos, l) * p.F + f0, gm);
+                    if constexpr (EDGE) {          // dense edge term: its gradient is dm_j itself, rows in slot order
+                        if (p.g_edge) stv<VEC>(p.g_edge + (int64_t)pos * p.ldg_edge + f0, gm);
+                    }
                 }
             }
             add_row_grads<VEC>(p, row0 + r, f0, rsum, gxin, true, true);
@@ -1932,8 +1949,16 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
             lds += (size_t)p.n_edge_types * p.F * sizeof(float);
         }
         bool launched = false;
+        const bool medge = p.x_src && p.m_edge && !p.edge_type;        // dense per-slot rows next to the gathered part
         if constexpr (O::kStatic && C::NCH <= 2) {
-            if (q.aux) { hipLaunchKernelGGL((agg_fwd_short<C, O, true>), grid, dim3(kWave * wpb), lds, stream, q); launched = true; }
+            if (q.aux) {
+                if (medge) hipLaunchKernelGGL((agg_fwd_short<C, O, true, true>), grid, dim3(kWave * wpb), lds, stream, q);
+                else hipLaunchKernelGGL((agg_fwd_short<C, O, true>), grid, dim3(kWave * wpb), lds, stream, q);
+                launched = true;
+            }
+        }
+        if constexpr (O::kStatic) {
+            if (!launched && medge) { hipLaunchKernelGGL((agg_fwd_short<C, O, false, true>), grid, dim3(kWave * wpb), lds, stream, q); launched = true; }
         }
         if (!launched) hipLaunchKernelGGL((agg_fwd_short<C, O>), grid, dim3(kWave * wpb), lds, stream, q);
     } else {
@@ -1962,13 +1987,13 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
         bool launched = false;
         if constexpr (O::kStatic && C::NCH <= 2) {
             if (p.aux) {           // (the host sets it only for lists and graphs agg_aux_supported() accepts)
-                if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true, true>), grid, dim3(kWave * wpb), 0, stream, p);
+                if (p.m_edge) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true, true>), grid, dim3(kWave * wpb), 0, stream, p);
                 else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false, true>), grid, dim3(kWave * wpb), 0, stream, p);
                 launched = true;
             }
         }
         if (!launched) {
-            if (p.edge_type) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true>), grid, dim3(kWave * wpb), 0, stream, p);
+            if (p.m_edge) hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, true>), grid, dim3(kWave * wpb), 0, stream, p);
             else hipLaunchKernelGGL((agg_bwd_short<C, O, kBwdShortRows, false>), grid, dim3(kWave * wpb), 0, stream, p);
         }
     } else {
