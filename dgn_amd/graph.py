@@ -29,6 +29,7 @@ HUB_CHUNK = 1024
 # True: a graph given as CUDA edge lists is prepared by dgn_graph_build* (a handful of kernels behind one C call each);
 # False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
 NATIVE_BUILD = True
+DEFERRED_STATS = True      # DGNGraph.rebuild: the batch's (max in-degree, hub rows) are checked at the next load instead of with a host sync
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -108,8 +109,8 @@ class DGNGraph:
         return self
 
     def rebuild(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None) -> None:
-        """Load a batch into a ``padded`` graph, in place (dgn_graph_build + dgn_graph_build_csc into the static arrays, one
-        read-back of the largest in-degree).  Cached per-graph tables (edge weights, scaler tables) are dropped: a step function
+        """Load a batch into a ``padded`` graph, in place (dgn_graph_build + dgn_graph_build_csc into the static arrays; no host
+        sync: the batch's statistics are checked at the next load, see check_deferred).  Cached per-graph tables (edge weights, scaler tables) are dropped: a step function
         captured on this object must recompute them INSIDE the captured region (they then replay with every batch)."""
         lib = _lib.load()
         pad = self._pad
@@ -134,11 +135,37 @@ class DGNGraph:
             buf = self.ndata["eig"]
             buf[:N].copy_(eig, non_blocking=True)
             buf[N:].zero_()
-        max_deg, n_hub = self._stats[:2].tolist()                                  # the one host sync of a load
-        if n_hub:
-            raise _lib.DgnError("padded graphs take batches without hub rows (in-degree <= hub_threshold) only")
-        self.max_in_degree, self.batch_nodes, self.batch_edges = int(max_deg), N, E
+        # No host sync: (max in-degree, hub rows) of THIS batch go to pinned memory asynchronously and are looked at when the NEXT batch
+        # is loaded (or by check_deferred()).  A padded graph carries no hub tables, so a batch with rows beyond hub_threshold is still
+        # computed correctly -- by the row kernels, slowly -- and the error below arrives one batch late instead of stalling every load.
+        self.check_deferred()
+        if DEFERRED_STATS:
+            if getattr(self, "_stats_host", None) is None:
+                self._stats_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+                self._stats_event = torch.cuda.Event()
+            self._stats_host.copy_(self._stats, non_blocking=True)
+            self._stats_event.record(torch.cuda.current_stream(dev))
+            self._stats_pending = True
+            self.max_in_degree = 0                                                  # (unknown: no launch is skipped on its account)
+        else:
+            max_deg, n_hub = self._stats[:2].tolist()                               # one host sync per load
+            if n_hub:
+                raise _lib.DgnError("padded graphs take batches without hub rows (in-degree <= hub_threshold) only")
+            self.max_in_degree = int(max_deg)
+        self.batch_nodes, self.batch_edges = N, E
         self.invalidate_caches()
+
+    def check_deferred(self) -> None:
+        """Look at the statistics of the batch loaded last (``rebuild`` without a host sync): raises if it had hub rows."""
+        if not getattr(self, "_stats_pending", False):
+            return
+        self._stats_event.synchronize()
+        self._stats_pending = False
+        max_deg, n_hub = int(self._stats_host[0]), int(self._stats_host[1])
+        self.max_in_degree = max_deg
+        if n_hub:
+            raise _lib.DgnError("padded graphs take batches without hub rows (in-degree <= hub_threshold) only "
+                                f"(the batch loaded before this call had {n_hub}, largest in-degree {max_deg})")
 
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""

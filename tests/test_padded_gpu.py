@@ -180,3 +180,35 @@ def test_padded_step_with_edge_features_equals_exact_step(type_net, as_types):
         for (k, p), q in zip(layer_pad.named_parameters(), layer_ref.parameters()):
             assert torch.isfinite(p.grad).all(), k
             close(p.grad, q.grad, f"batch {order} grad {k}")
+
+
+def test_rebuild_has_no_host_sync_and_reports_hub_rows_one_load_late():
+    """DGNGraph.rebuild leaves the batch's statistics in pinned memory: a batch with a row beyond hub_threshold is computed correctly (a
+    padded graph has no hub tables: the row kernels take it) and reported by check_deferred() / the next load."""
+    import dgn_amd
+    from dgn_amd import _lib
+    from dgn_amd.ops import directional_aggregate
+    dev = torch.device("cuda")
+    n_hub_edges = dgn_amd.graph.HUB_THRESHOLD + 50
+    N = 300
+    gen = torch.Generator().manual_seed(0)
+    src = torch.cat([torch.randint(0, N, (n_hub_edges,), generator=gen), torch.randint(0, N, (400,), generator=gen)])
+    dst = torch.cat([torch.zeros(n_hub_edges, dtype=torch.long), torch.randint(1, N, (400,), generator=gen)])
+    eig = torch.randn(N, 3, generator=gen)
+    g = dgn_amd.DGNGraph.padded(N + 20, src.numel() + 64, dev, eig_dim=3)
+    g.rebuild(src, dst, N, eig=eig.to(dev))                       # no exception here
+    plan = dgn_amd.make_plan(["mean", "max", "dir1-dx"], ["identity"])
+    x = torch.randn(N + 20, 6, generator=gen).to(dev)
+    x[N:] = 0
+    y = directional_aggregate(g, plan, 1.0, x_src=x, x_in=x)
+    exact = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    assert exact.n_hub == 1
+    y_ref = directional_aggregate(exact, plan, 1.0, x_src=x[:N].contiguous(), x_in=x[:N].contiguous())
+    assert torch.allclose(y[:N], y_ref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(_lib.DgnError, match="hub rows"):
+        g.check_deferred()
+    g.check_deferred()                                               # reported once
+    small = torch.randint(0, N, (200,), generator=gen)
+    g.rebuild(small, small.roll(1), N, eig=eig.to(dev))
+    g.check_deferred()
+    assert g.max_in_degree > 0
