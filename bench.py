@@ -635,14 +635,14 @@ def run_inference(args, dev, steps=20, warmup=5):
     return out
 
 
-def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8):
+def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8, workload="c2_b128"):
     """The reference's operating point -- batches of 128 molecules whose node / edge counts differ from step to step -- on ONE
     captured HIP graph: the batch lives in static buffers at a fixed capacity (hipgraph.PaddedBatch), BatchNorm reads the number of
-    real rows from the device.  A timed step = graph preparation of the NEXT batch in place (dgn_graph_build + _csc, one read-back)
+    real rows from the device.  A timed step = graph preparation of the NEXT batch in place (dgn_graph_build + _csc, no host sync)
     + copies of its features / eig / graph norm / cotangent into the static buffers + one graph launch (edge weights, forward,
     backward).  The batches are on the device beforehand (as after a data loader's H2D copy)."""
     from dgn_amd.hipgraph import PaddedBatch, bucket_capacity, capture
-    wl = dict(WORKLOADS["c2_b128"])
+    wl = dict(WORKLOADS[workload])
     F_ = wl["hidden"]
     raw = [synth.molecule_batch(seed=41 + i, **wl["gen"][1]) for i in range(n_batches)]
     n_cap, e_cap = bucket_capacity(max(int(b["num_nodes"]) for b in raw), max(b["src"].numel() for b in raw))
@@ -695,7 +695,7 @@ def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8):
     edges = sum(d["src"].numel() for d in data) / n_batches
     return dict(ms_per_step=ms, value=edges / (ms * 1e-3), unit="edges/s", steps=steps, warmup=warmup,
                 capacity=dict(nodes=n_cap, edges=e_cap), batches=[dict(nodes=d["N"], edges=int(d["src"].numel())) for d in data],
-                config=f"{n_batches} different batches of 128 molecules cycled through ONE captured HIP graph (padded to the capacity); a step = "
+                config=f"{workload}: {n_batches} different batches of 128 molecules cycled through ONE captured HIP graph (padded to the capacity); a step = "
                        "in-place graph preparation + input copies + graph launch (edge weights + layer forward + backward)")
 
 
@@ -862,6 +862,10 @@ def run_extras(args, dev):
         extra["c2_b128_bucketed"] = run_bucketed(args, dev)
     except Exception as exc:
         extra["c2_b128_bucketed"] = dict(error=f"{type(exc).__name__}: {exc}")
+    try:      # the reference's shipped ZINC layer (complex, hidden 45) at its own batch size, the same way
+        extra["zinc_json_b128_bucketed"] = run_bucketed(args, dev, workload="zinc_json_b128")
+    except Exception as exc:
+        extra["zinc_json_b128_bucketed"] = dict(error=f"{type(exc).__name__}: {exc}")
     return extra
 
 
