@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -32,7 +32,10 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
            "dgn_dense_layer_supported", "dgn_dense_layer_forward_workspace_bytes", "dgn_dense_layer_forward", "dgn_dense_layer_backward_workspace_bytes",
            "dgn_dense_layer_backward",
-           "dgn_linear_bd_supported", "dgn_linear_bd_forward", "dgn_linear_bd_backward_input", "dgn_linear_bd_wgrad_workspace_bytes", "dgn_linear_bd_wgrad")
+           "dgn_linear_bd_supported", "dgn_linear_bd_forward", "dgn_linear_bd_backward_input", "dgn_linear_bd_wgrad_workspace_bytes", "dgn_linear_bd_wgrad",
+           "dgn_dc_supported", "dgn_dc_wgrad_supported", "dgn_dc_fold", "dgn_dc_gemm", "dgn_dc_wgrad_workspace_bytes", "dgn_dc_wgrad")
+
+DGN_DC_CLASSES, DGN_DC_UNIT = 32, 64
 
 
 class DgnGraph(C.Structure):
@@ -88,6 +91,10 @@ class DgnTowersGrads(C.Structure):
                 ("g_b_post", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p), ("g_w_mix", C.c_void_p), ("g_b_mix", C.c_void_p)]
 
 
+class DgnDegreeClasses(C.Structure):
+    _fields_ = [("n_units", C.c_int64), ("vperm", C.c_void_p), ("unit_class", C.c_void_p), ("present", C.c_void_p), ("scale", C.c_void_p)]
+
+
 class DgnDenseLayer(C.Structure):
     _fields_ = [("graph", C.POINTER(DgnGraph)), ("spec", C.POINTER(DgnAggSpec)), ("w", C.c_void_p), ("ld_w", C.c_int64), ("log_deg", C.c_void_p),
                 ("type", C.c_int32), ("f_in", C.c_int32), ("f_out", C.c_int32), ("n_scalers", C.c_int32), ("n_agg", C.c_int32), ("id_slot", C.c_int32),
@@ -97,7 +104,7 @@ class DgnDenseLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("hp", C.c_void_p), ("pq", C.c_void_p), ("agg", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("wsd", C.c_void_p),
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("n_valid", C.c_void_p), ("agg_aux", C.c_void_p)]
+                ("n_valid", C.c_void_p), ("agg_aux", C.c_void_p), ("dc", C.POINTER(DgnDegreeClasses))]
 
 
 class DgnDenseGrads(C.Structure):
@@ -241,6 +248,19 @@ def load() -> C.CDLL:
         lib.dgn_linear_bd_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_linear_bd_wgrad.restype = C.c_int
         lib.dgn_linear_bd_wgrad.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, C.c_size_t, vp]
+        for name in ("dgn_dc_supported", "dgn_dc_wgrad_supported"):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
+        lib.dgn_dc_fold.restype = C.c_int
+        lib.dgn_dc_fold.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        lib.dgn_dc_gemm.restype = C.c_int
+        lib.dgn_dc_gemm.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int64,
+                                    C.c_int32, vp]
+        lib.dgn_dc_wgrad_workspace_bytes.restype = C.c_size_t
+        lib.dgn_dc_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        lib.dgn_dc_wgrad.restype = C.c_int
+        lib.dgn_dc_wgrad.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp,
+                                     C.c_size_t, vp]
         lib.dgn_gemm_supported.restype = C.c_int
         lib.dgn_gemm_supported.argtypes = [C.c_int32, C.c_int32]
         lib.dgn_gemm_forward.restype = C.c_int

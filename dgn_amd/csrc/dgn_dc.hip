@@ -1,0 +1,166 @@
+// Host side of the degree-class posttrans products (include/dgn_hip.h: dgn_dc_*), kernels in dgn_dc_kernels.hpp.
+#include "dgn_dc_kernels.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace dgn {
+namespace dc {
+namespace {
+
+int n_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+bool check_classes(const char* fn, const DgnDegreeClasses* d) {
+    if (!d || d->n_units < 0 || (d->n_units > 0 && (!d->vperm || !d->unit_class || !d->present || !d->scale))) {
+        set_error("%s: incomplete DgnDegreeClasses", fn);
+        return false;
+    }
+    return true;
+}
+
+struct WgPlan { int ntn, kt, k_slice, k_slices, kpad, slots; int64_t units_per_block; size_t lds, part_floats; };
+WgPlan wgrad_plan(int64_t n_units, int k, int n) {
+    WgPlan w{};
+    w.ntn = (n + 15) / 16;
+    // k tiles per wave: at most 4 (n <= 80), 3 (n <= 96), 2 (n <= 128) -- the accumulators of NTN x KT tiles must fit 256 registers
+    const int kt_max = w.ntn <= 5 ? 4 : (w.ntn == 6 ? 3 : 2), slice_max = 16 * kWgWaves * kt_max;
+    w.k_slices = (k + slice_max - 1) / slice_max;
+    const int per = (k + w.k_slices - 1) / w.k_slices;
+    w.kt = ((per + 15) / 16 + kWgWaves - 1) / kWgWaves;
+    w.k_slice = 16 * kWgWaves * w.kt;
+    w.k_slices = (k + w.k_slice - 1) / w.k_slice;
+    w.kpad = (std::min(w.k_slice, k) + 15) / 16 * 16;
+    const int64_t want = std::max<int64_t>(1, n_cus() / w.k_slices);
+    w.units_per_block = std::max<int64_t>(1, (n_units + want - 1) / want);
+    w.slots = (int)std::max<int64_t>(1, (n_units + w.units_per_block - 1) / w.units_per_block);
+    w.lds = (size_t)2 * 16 * ((w.ntn * 16 + 4) + (w.kt * 128 + 4)) * sizeof(float);
+    w.part_floats = (size_t)w.k_slices * (w.slots + kClasses) * (w.ntn * 16) * w.kpad;
+    return w;
+}
+
+template <int NTN, int KT>
+hipError_t launch_wgrad_t(const DcWgradParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dc_wgrad<NTN, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((dc_wgrad<NTN, KT>), grid, dim3(kWave * kWgWaves), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad(int ntn, int kt, const DcWgradParams& p, dim3 grid, size_t lds, hipStream_t st) {
+    switch (ntn * 4 + kt) {      // kt in 1..4, see wgrad_plan
+#define DGN_CASE(N, K) case N * 4 + K: return launch_wgrad_t<N, K>(p, grid, lds, st);
+        DGN_CASE(1, 1) DGN_CASE(1, 2) DGN_CASE(1, 3) DGN_CASE(1, 4) DGN_CASE(2, 1) DGN_CASE(2, 2) DGN_CASE(2, 3) DGN_CASE(2, 4)
+        DGN_CASE(3, 1) DGN_CASE(3, 2) DGN_CASE(3, 3) DGN_CASE(3, 4) DGN_CASE(4, 1) DGN_CASE(4, 2) DGN_CASE(4, 3) DGN_CASE(4, 4)
+        DGN_CASE(5, 1) DGN_CASE(5, 2) DGN_CASE(5, 3) DGN_CASE(5, 4) DGN_CASE(6, 1) DGN_CASE(6, 2) DGN_CASE(6, 3)
+        DGN_CASE(7, 1) DGN_CASE(7, 2) DGN_CASE(8, 1) DGN_CASE(8, 2)
+#undef DGN_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+}  // namespace dc
+}  // namespace dgn
+
+using namespace dgn;
+using namespace dgn::dc;
+
+// widths: k, n >= 4 (16-byte clamped operand loads); the weight gradient keeps n <= 128 output rows in one wave's accumulators
+extern "C" int dgn_dc_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 4096; }
+extern "C" int dgn_dc_wgrad_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 128; }
+
+extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, const float* wf, float* wc, float* wct, void* stream) {
+    const char* fn = "dgn_dc_fold";
+    if (!check_classes(fn, d)) return DGN_ERR_INVALID;
+    if (S < 1 || S > 3 || n < 1 || k < 1 || !wf || !wc || !wct) { set_error("%s: bad shape or null buffer", fn); return DGN_ERR_INVALID; }
+    if (d->n_units == 0) return DGN_OK;
+    hipLaunchKernelGGL(dc_fold, dim3((unsigned)(((int64_t)n * k + 255) / 256), kClasses), dim3(256), 0, static_cast<hipStream_t>(stream), S, n, k, d->present,
+                       d->scale, wf, wc, wct);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
+                           int64_t class_stride, const float* bias, const float* row_scale, float* c, int64_t ldc, int32_t stream_out, void* stream) {
+    const char* fn = "dgn_dc_gemm";
+    if (!check_classes(fn, d)) return DGN_ERR_INVALID;
+    if (!dgn_dc_supported(k, n)) { set_error("%s: widths outside 4..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
+    if (d->n_units == 0) return DGN_OK;
+    if (!a || !w || !c || lda < k || ldc < n || ldw < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
+    DcGemmParams p{};
+    p.n_units = d->n_units; p.vperm = d->vperm; p.unit_class = d->unit_class; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw;
+    p.class_stride = class_stride; p.bias = bias; p.row_scale = row_scale; p.C = c; p.ldc = ldc; p.stream_out = stream_out;
+    // column tiles of 16 NQ (NQ <= 7): the split with the least padded columns, fewer tiles on a tie
+    int best_nq = 7, best_tiles = (n + 111) / 112, best_pad = best_tiles * 112 - n;
+    for (int nq = 7; nq >= 1; --nq) {
+        const int tiles = (n + 16 * nq - 1) / (16 * nq), pad = tiles * 16 * nq - n;
+        if (pad < best_pad) { best_nq = nq; best_tiles = tiles; best_pad = pad; }
+    }
+    p.n_slice = 16 * best_nq;
+    // one workgroup per resident slot (two per CU), each with an equal range of units
+    const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * 2 / best_tiles);
+    p.units_per_block = std::max<int64_t>(1, (d->n_units + slots_x - 1) / slots_x);
+    const dim3 grid((unsigned)((d->n_units + p.units_per_block - 1) / p.units_per_block), (unsigned)best_tiles);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (best_nq) {
+        case 1: hipLaunchKernelGGL(dc_gemm<1>, grid, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(dc_gemm<2>, grid, dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(dc_gemm<3>, grid, dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(dc_gemm<4>, grid, dim3(256), 0, st, p); break;
+        case 5: hipLaunchKernelGGL(dc_gemm<5>, grid, dim3(256), 0, st, p); break;
+        case 6: hipLaunchKernelGGL(dc_gemm<6>, grid, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(dc_gemm<7>, grid, dim3(256), 0, st, p); break;
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" size_t dgn_dc_wgrad_workspace_bytes(int64_t n_units, int32_t k, int32_t n) {
+    if (n_units <= 0 || !dgn_dc_wgrad_supported(k, n)) return 0;
+    const WgPlan w = wgrad_plan(n_units, k, n);
+    return w.part_floats * sizeof(float) + (size_t)(w.slots + kClasses) * sizeof(int32_t) + 256;
+}
+
+extern "C" int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx,
+                            float* g_wf, int64_t ldw, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "dgn_dc_wgrad";
+    if (!check_classes(fn, d)) return DGN_ERR_INVALID;
+    if (!dgn_dc_wgrad_supported(k, n) || S < 1 || S > 3) { set_error("%s: unsupported widths (k=%d n=%d S=%d)", fn, k, n, S); return DGN_ERR_INVALID; }
+    if (!g_wf || ldw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->n_units == 0) return zero_rows_async(g_wf, (int64_t)S * n, k, ldw, st);
+    if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
+    const size_t need = dgn_dc_wgrad_workspace_bytes(d->n_units, k, n);
+    if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
+    const WgPlan w = wgrad_plan(d->n_units, k, n);
+    DcWgradParams p{};
+    p.n_units = d->n_units; p.vperm = d->vperm; p.unit_class = d->unit_class; p.n = n; p.k = k; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx;
+    p.part = static_cast<float*>(ws);
+    p.run_class = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + ((w.part_floats * sizeof(float) + 255) & ~(size_t)255));
+    p.k_slice = w.k_slice; p.kpad = w.kpad; p.slots = w.slots; p.units_per_block = w.units_per_block;
+    const int ids = w.slots + kClasses;
+    hipLaunchKernelGGL(fill_i32, dim3((ids + 255) / 256), dim3(256), 0, st, ids, -1, p.run_class);
+    DGN_HIP_CHECK(launch_wgrad(w.ntn, w.kt, p, dim3(w.slots, w.k_slices), w.lds, st));
+    const int64_t total = (int64_t)n * k;
+    const dim3 fgrid((unsigned)((total + 63) / 64));
+    switch (S) {
+        case 1: hipLaunchKernelGGL(dc_wgrad_finalize<1>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
+        case 2: hipLaunchKernelGGL(dc_wgrad_finalize<2>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
+        default: hipLaunchKernelGGL(dc_wgrad_finalize<3>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}

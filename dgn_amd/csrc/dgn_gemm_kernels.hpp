@@ -16,40 +16,10 @@
 #include <type_traits>
 
 #include "dgn_common.hpp"
+#include "dgn_load4.hpp"
 
 namespace dgn {
 namespace gemm {
-
-using f4 = __attribute__((ext_vector_type(4))) float;
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte vector at 4-byte alignment (odd row strides)
-
-// Four consecutive floats row[col .. col + 3] of a row that has `limit` (>= 4) columns, zero past the end, WITHOUT a branch: one
-// 16-byte load from an address clamped into the row, the wanted window picked with selects.  A load inside a branch is followed by
-// s_waitcnt vmcnt(0) at the branch's end (measured in these kernels' ISA: every operand prefetch was a synchronous memory round trip
-// in front of the chunk's MFMAs instead of travelling during them); `live` = false gives zeros (rows past the matrix: the caller
-// clamps the row pointer).
-// Split in two so that NOTHING consumes the load where it is issued: load4_raw (the load + the window's shift) goes with the prefetch,
-// load4_window (the selects) with the commit after the MFMAs -- selects right behind the load would again put a wait in front of the
-// MFMAs.
-struct Raw4 { f4 raw; int sh; };
-__device__ __forceinline__ Raw4 load4_raw(const float* row, int col, int limit, bool live = true) {
-    const int cc = max(0, min(col, limit - 4));
-    Raw4 r;
-    r.raw = *reinterpret_cast<const f4u*>(row + cc);
-    r.sh = live ? col - cc : 4;                  // 0..3 inside the row, >= 4: nothing of the window exists
-    return r;
-}
-__device__ __forceinline__ f4 load4_window(const Raw4& r) {
-    const f4 raw = r.raw;
-    const int sh = r.sh;
-    f4 v;
-    v[0] = sh == 0 ? raw[0] : (sh == 1 ? raw[1] : (sh == 2 ? raw[2] : (sh == 3 ? raw[3] : 0.f)));
-    v[1] = sh == 0 ? raw[1] : (sh == 1 ? raw[2] : (sh == 2 ? raw[3] : 0.f));
-    v[2] = sh == 0 ? raw[2] : (sh == 1 ? raw[3] : 0.f);
-    v[3] = sh == 0 ? raw[3] : 0.f;
-    return v;
-}
-__device__ __forceinline__ f4 load4_nb(const float* row, int col, int limit, bool live = true) { return load4_window(load4_raw(row, col, limit, live)); }
 
 constexpr int kWaves = 8;            // ts_gemm: rows per workgroup pass = 16 * kWaves
 #ifndef DGN_GEMM_KC

@@ -26,6 +26,7 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 struct Dims {
     int64_t N;
     int F0, Fp, fo, S, A, Ab, K, n, cx;      // Ab = aggregator blocks of the sweep (A + 1 with the h_in block), K = Ab * Fp, n = S * fo
+    int dc;                                  // degree-class posttrans (dgn_dc_kernels.hpp): one f_out-column product per in-degree class
 };
 
 bool dims_of(const DgnDenseLayer* L, Dims& d, const char* fn) {
@@ -43,6 +44,7 @@ bool dims_of(const DgnDenseLayer* L, Dims& d, const char* fn) {
     }
     if (d.cx && (L->id_slot < 0 || L->id_slot >= d.S)) { set_error("%s: complex layer needs the identity scaler's slot", fn); return false; }
     if (d.fo > 1024 || d.K < 4 || d.n < 4 || d.K > 4096 || d.n > 4096) { set_error("%s: widths outside the kernels' range", fn); return false; }
+    d.dc = L->dc && d.S > 1 && dgn_dc_supported(d.K, d.fo) && dgn_dc_supported(d.fo, d.K) && dgn_dc_wgrad_supported(d.K, d.fo);
     return true;
 }
 
@@ -161,7 +163,8 @@ BwdScratch bwd_scratch(const DgnDenseLayer* L, const Dims& d) {
     s.g_wsd = take(d.cx ? (size_t)2 * d.Fp * d.Fp * 4 : 0); s.g_bsd = take(d.cx ? (size_t)2 * d.Fp * 4 : 0);
     s.bn_ws = take(dgn_bn_tail_workspace_bytes(d.N, d.fo));
     s.comb_ws = take(dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo));
-    s.wg_ws = take(std::max(wgrad_ws(d.N, d.K, d.n), d.cx ? wgrad_ws(d.N, d.Fp, 2 * d.Fp) : (size_t)0));
+    s.wg_ws = take(std::max(d.dc ? dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo) : wgrad_ws(d.N, d.K, d.n),
+                            d.cx ? wgrad_ws(d.N, d.Fp, 2 * d.Fp) : (size_t)0));
     s.agg_ws = take(dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fp, 1));
     s.total = off;
     return s;
@@ -197,7 +200,7 @@ extern "C" int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_o
 extern "C" size_t dgn_dense_layer_forward_workspace_bytes(const DgnDenseLayer* L) {
     Dims d;
     if (!dims_of(L, d, "dgn_dense_layer_forward_workspace_bytes")) return 0;
-    return up256((size_t)d.N * d.n * 4) + up256(dgn_bn_tail_workspace_bytes(d.N, d.fo)) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fp));
+    return up256(d.dc ? 0 : (size_t)d.N * d.n * 4) + up256(dgn_bn_tail_workspace_bytes(d.N, d.fo)) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fp));
 }
 
 extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
@@ -212,7 +215,7 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(L->ws);
     float* z = reinterpret_cast<float*>(ws);
-    const size_t z_b = up256((size_t)d.N * d.n * 4), bn_b = up256(dgn_bn_tail_workspace_bytes(d.N, d.fo));
+    const size_t z_b = up256(d.dc ? 0 : (size_t)d.N * d.n * 4), bn_b = up256(dgn_bn_tail_workspace_bytes(d.N, d.fo));
     const float* hp = L->h;
     if (padded) {
         hipLaunchKernelGGL(pad_rows, dim3(nblk(d.N * d.Fp)), dim3(256), 0, st, d.N, d.F0, d.Fp, L->h, L->hp);
@@ -237,8 +240,16 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->agg, d.K, L->agg_aux, ws + z_b + bn_b, L->ws_bytes - z_b - bn_b,
                                 stream));
     // posttrans with the folded scalers, bias and graph norm                                    (:116-122 / :187-193)
-    DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
-    DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
+    if (d.dc) {
+        // one product per in-degree class: y = snorm (b + agg W_class^T), W_class = sum_s scale_s(class) W_f[s]
+        float* wc = L->wf + (size_t)2 * d.n * d.K;
+        float* wct = wc + (size_t)DGN_DC_CLASSES * d.fo * d.K;
+        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, L->wf, wc, wct, stream));
+        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, L->agg, d.K, wc, d.K, (int64_t)d.fo * d.K, L->b_post, L->snorm, L->y, d.fo, 0, stream));
+    } else {
+        DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
+        DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
+    }
     // BatchNorm -> ReLU -> residual                                                             (:123-128 / :194-199)
     DGN_TRY(dgn_bn_tail_forward(d.N, d.fo, L->y, d.fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 1,
                                 L->residual ? L->h : nullptr, L->out, L->save_mean, L->save_invstd, ws + z_b, bn_b, L->n_valid, stream));
@@ -280,11 +291,21 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
     bn.g_out = G->g_out; bn.y = L->y; bn.ld = d.fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
     bn.sums = sums; bn.relu = 1; bn.n_valid = L->n_valid;
     DGN_TRY(zero_rows_async(G->g_b_post, 1, d.fo, d.fo, st));
-    DGN_TRY(dgn_scale_combine_backward(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
-                                       dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
-    // posttrans: input gradient (on the transposed folded weight), weight gradient, un-folded into the reference's layout
-    DGN_TRY(lin_fwd(d.N, d.n, d.K, g_z, wft, nullptr, g_agg, stream));
-    DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));
+    if (d.dc) {
+        // g_t = snorm * (BatchNorm input gradient) [N, f_out]; per class: d agg = g_t W_class, G_class = g_t^T agg; g_wf = sum_class scale G_class
+        const float* wct = L->wf + (size_t)2 * d.n * d.K + (size_t)DGN_DC_CLASSES * d.fo * d.K;
+        DGN_TRY(dgn_scale_combine_backward(d.N, 1, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
+                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
+        DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, g_z, d.fo, wct, d.fo, (int64_t)d.fo * d.K, nullptr, nullptr, g_agg, d.K, 0, stream));
+        DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, g_wf, d.K, ws + s.wg_ws, dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo),
+                             stream));
+    } else {
+        DGN_TRY(dgn_scale_combine_backward(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
+                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
+        // posttrans: input gradient (on the transposed folded weight), weight gradient, un-folded into the reference's layout
+        DGN_TRY(lin_fwd(d.N, d.n, d.K, g_z, wft, nullptr, g_agg, stream));
+        DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));
+    }
     hipLaunchKernelGGL(unfold_post, dim3(nblk((int64_t)d.fo * ld_post)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : 0, ld_post,
                        g_wf, G->g_w_post);
     DGN_HIP_CHECK(hipGetLastError());

@@ -29,6 +29,7 @@ HUB_CHUNK = 1024
 # True: a graph given as CUDA edge lists is prepared by dgn_graph_build* (a handful of kernels behind one C call each);
 # False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
 NATIVE_BUILD = True
+DC_CLASSES, DC_UNIT = 32, 64      # include/dgn_hip.h: DGN_DC_CLASSES, DGN_DC_UNIT
 DEFERRED_STATS = True      # DGNGraph.rebuild: the batch's (max in-degree, hub rows) are checked at the next load instead of with a host sync
 
 
@@ -170,7 +171,7 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types"):
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale"):
             self.__dict__.pop(k, None)
 
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
@@ -238,6 +239,35 @@ class DGNGraph:
         self.n_chunks = int(c.n_chunks)
         self._c = c
         self._wcache: Dict[tuple, torch.Tensor] = {}
+
+    # ---- degree classes (dgn_dc_kernels.hpp): nodes stably sorted by in-degree, every class padded to DC_UNIT rows ------------------
+    def degree_classes(self):
+        """``None`` when an in-degree reaches ``DC_CLASSES`` (or the graph is a padded / bipartite one), else a dict with the virtual
+        row space of the degree-class posttrans products: ``vperm`` int32 [64 n_units] (node of a virtual row, -1: padding),
+        ``unit_class`` int32 [n_units], ``present`` int32 [32] (rows per class), ``rep`` int64 [32] (one node of each class, 0 where
+        absent: its row of a per-node scaler table is the class's row).  Built once per graph (one host read-back), torch ops."""
+        if "_dc" in self.__dict__:
+            return self._dc
+        dc = None
+        N = self.num_nodes
+        if (N > 0 and self.in_degree is not None and getattr(self, "_pad", None) is None
+                and self.num_src == self.num_nodes and self.max_in_degree < DC_CLASSES):
+            dev = self.device
+            key = self.in_degree.long()
+            skey, order = torch.sort(key, stable=True)
+            counts = torch.zeros(DC_CLASSES, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))
+            padded = (counts + DC_UNIT - 1) // DC_UNIT * DC_UNIT
+            seg_end = torch.cumsum(padded, 0)
+            seg_start, first = seg_end - padded, torch.cumsum(counts, 0) - counts
+            n_units = int(seg_end[-1].item()) // DC_UNIT                      # the one host read-back
+            pos = seg_start[skey] + (torch.arange(N, device=dev) - first[skey])
+            vperm = torch.full((n_units * DC_UNIT,), -1, dtype=torch.int32, device=dev)
+            vperm[pos] = order.int()
+            uc = torch.searchsorted(seg_end, torch.arange(n_units, device=dev) * DC_UNIT, right=True)
+            rep = torch.where(counts > 0, order[first.clamp(max=N - 1)], torch.zeros_like(first))
+            dc = dict(n_units=n_units, vperm=vperm, unit_class=uc.int().contiguous(), present=counts.int().contiguous(), rep=rep)
+        self._dc = dc
+        return dc
 
     def ensure_csc(self) -> None:
         """Transposed view for the atomic-free backward (built on first use, one extra sort per graph)."""

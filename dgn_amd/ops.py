@@ -1111,15 +1111,38 @@ def dense_layer_supported(type_net: int, f_in: int, f_out: int, n_scalers: int, 
     return _DENSE_OK[key]
 
 
-def _dense_sizes(cfg, N):
+# True: simple / complex layers with several degree scalers run posttrans as ONE f_out-column product per in-degree class
+# (dgn_dc_kernels.hpp) instead of the folded S * f_out-column product + scale-combine: a third of the MFMA flops in the forward, the
+# input gradient and the weight gradient.  Graphs with an in-degree >= 32 (and padded graphs) keep the folded route.
+DC_POSTTRANS = os.environ.get("DGN_DC_POSTTRANS", "1") != "0"
+
+
+def _degree_classes(graph, scale, fo, K):
+    """(graph.degree_classes(), class scaler table [32, S]) or None."""
+    if not DC_POSTTRANS or scale is None or not scale.is_cuda:
+        return None
+    lib = _lib.load()
+    if not (lib.dgn_dc_supported(K, fo) and lib.dgn_dc_supported(fo, K) and lib.dgn_dc_wgrad_supported(K, fo)):
+        return None
+    dc = graph.degree_classes()
+    if dc is None:
+        return None
+    cache = graph.__dict__.setdefault("_dc_scale", {})
+    key = scale.data_ptr()
+    if key not in cache:
+        cache[key] = (scale, scale.index_select(0, dc["rep"]).contiguous())      # (the per-node table is kept alive with its class rows)
+    return dc, cache[key][1]
+
+
+def _dense_sizes(cfg, N, dc=False):
     type_net, F0, fo, S, A = cfg[:5]
     Fp = F0 + (F0 & 1)
     K = (A + (1 if type_net == 1 else 0)) * Fp
-    return [N * Fp if Fp != F0 else 0, N * 2 * Fp if type_net == 1 else 0, N * K, N * fo, 2 * S * fo * K,
+    return [N * Fp if Fp != F0 else 0, N * 2 * Fp if type_net == 1 else 0, N * K, N * fo, (2 * S + (2 * _lib.DGN_DC_CLASSES if dc else 0)) * fo * K,
             (4 * Fp * Fp + 2 * Fp) if type_net == 1 else 0, fo, fo], Fp, K
 
 
-def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, n_valid):
+def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, n_valid, dc=None):
     type_net, F0, fo, S, A, id_slot, residual, momentum, eps = cfg
     hp, pq, agg, y, wf, wsd, mean, invstd = bufs
     spec = _spec_structs(plan, 1, avg_log, 0)[0]
@@ -1134,7 +1157,13 @@ def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_p
     L.bn_gamma, L.bn_beta = gamma.data_ptr(), beta.data_ptr()
     L.hp, L.pq, L.agg, L.y, L.wf, L.wsd, L.save_mean, L.save_invstd = hp, pq, agg, y, wf, wsd, mean, invstd          # (addresses, _carve_ptrs)
     L.n_valid = _ptr(n_valid)
-    return L, (cg, spec)
+    dcs = None
+    if dc is not None:
+        g, cls_scale = dc
+        dcs = _lib.DgnDegreeClasses(n_units=g["n_units"], vperm=g["vperm"].data_ptr(), unit_class=g["unit_class"].data_ptr(),
+                                    present=g["present"].data_ptr(), scale=cls_scale.data_ptr())
+        L.dc = C.pointer(dcs)
+    return L, (cg, spec, dcs)
 
 
 class _DenseLayer(torch.autograd.Function):
@@ -1147,11 +1176,14 @@ class _DenseLayer(torch.autograd.Function):
         dev = h.device
         h, w_post, gamma, beta = h.contiguous(), w_post.contiguous(), gamma.contiguous(), beta.contiguous()
         w_pre = w_pre.contiguous() if w_pre is not None else None
-        sizes, Fp, K = _dense_sizes(cfg, N)
+        _, _, K = _dense_sizes(cfg, 0)
+        dc = _degree_classes(graph, scale, fo, K)
+        sizes, Fp, K = _dense_sizes(cfg, N, dc is not None)
         saved_buf, bufs = _carve_ptrs(sizes, dev)
         out = torch.empty((N, fo), dtype=torch.float32, device=dev)
         ctx.n_valid = _N_VALID
-        L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
+        ctx.dc = dc
+        L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid, dc)
         L.running_mean, L.running_var, L.out = running_mean.data_ptr(), running_var.data_ptr(), out.data_ptr()
         n_aux = int(lib.dgn_dense_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0      # (see _TowersLayer)
         aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
@@ -1172,11 +1204,12 @@ class _DenseLayer(torch.autograd.Function):
         cfg, graph = ctx.cfg, ctx.graph
         type_net, F0, fo = cfg[:3]
         N, dev = h.shape[0], h.device
-        sizes, Fp, K = _dense_sizes(cfg, N)
+        sizes, Fp, K = _dense_sizes(cfg, N, ctx.dc is not None)
         _, bufs = _carve_ptrs(sizes, dev, saved_buf)
         g_out = g_out.contiguous()
         graph.ensure_csc()
-        L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid)
+        L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid,
+                                ctx.dc)
         L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_dense_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 20
+#define DGN_ABI_VERSION 21
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -524,6 +524,32 @@ int dgn_assemble_params(int64_t n_out, const int64_t* param_ptrs, const int32_t*
  * read by the backward (caller-owned: the autograd-saved tensors): hp [N, f_pad] (used only when f_in is odd), pq [N, 2 f_pad],
  * agg [N, K], y [N, f_out], wf [2 * S f_out * K] (W_f and its transpose), wsd [4 f_pad^2 + 2 f_pad] (complex: W_sd, its transpose,
  * bias_sd).  spec: the sweep's list (aggregators, + DGN_AGG_X_IN last for the complex layer) with ONE identity scaler, one tower.   */
+/* ---- degree classes: the posttrans product with its degree scalers at 1 / S of the folded product's flops -------------------------
+ * Every scaler of nets/scalers.py:7-18 multiplies a node's whole aggregate row by a function of its IN-DEGREE, so all nodes of one
+ * in-degree d share y = agg (sum_s scale_s(d) W_f[s])^T: one product with f_out columns instead of S f_out (dgn_dc_kernels.hpp).
+ * The kernels walk a virtual row space: nodes stably sorted by class = in-degree (0 .. DGN_DC_CLASSES - 1; graphs with larger
+ * in-degrees keep the folded route), each class padded to a multiple of DGN_DC_UNIT rows.                                          */
+#define DGN_DC_CLASSES 32
+#define DGN_DC_UNIT 64
+typedef struct DgnDegreeClasses {
+    int64_t n_units;              /* units (DGN_DC_UNIT rows) of the virtual row space                                  */
+    const int32_t* vperm;         /* [DGN_DC_UNIT * n_units] node of a virtual row, -1: padding                          */
+    const int32_t* unit_class;    /* [n_units] class of a unit, -1: empty                                                */
+    const int32_t* present;       /* [DGN_DC_CLASSES] rows per class                                                     */
+    const float* scale;           /* [DGN_DC_CLASSES, S] the layer's scaler factors per class (set per layer)            */
+} DgnDegreeClasses;
+int dgn_dc_supported(int32_t k, int32_t n);
+int dgn_dc_wgrad_supported(int32_t k, int32_t n);
+/* wc[c][o][kk] = sum_s scale[c][s] wf[s n + o][kk] and wct[c][kk][o] (its transpose), classes present only; wf [S n, k]           */
+int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, const float* wf, float* wc, float* wct, void* stream);
+/* c[node] = row_scale[node] * (bias + a[node] w_class(node)^T); w: class c at w + c * class_stride, [n, k] rows of stride ldw       */
+int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
+                int64_t class_stride, const float* bias, const float* row_scale, float* c, int64_t ldc, int32_t stream_out, void* stream);
+/* g_wf[s n + o][kk] = sum_nodes scale[class(node)][s] g[node][o] x[node][kk]  (per-class products, fixed-order finalize)             */
+size_t dgn_dc_wgrad_workspace_bytes(int64_t n_units, int32_t k, int32_t n);
+int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx,
+                 float* g_wf, int64_t ldw, void* ws, size_t ws_bytes, void* stream);
+
 typedef struct DgnDenseLayer {
     const DgnGraph* graph;
     const DgnAggSpec* spec;
@@ -547,6 +573,7 @@ typedef struct DgnDenseLayer {
     void* ws; size_t ws_bytes;
     const int64_t* n_valid;    /* DEVICE scalar or NULL (padded batches, see dgn_bn_tail_forward)            */
     unsigned char* agg_aux;    /* optional: dgn_dense_layer_agg_aux_bytes() bytes, the sweep's aux table (dgn_agg_forward_aux) */
+    const DgnDegreeClasses* dc; /* optional (S > 1, f_out <= 128): degree-class posttrans; wf then holds (2 S + 2 DGN_DC_CLASSES) f_out K floats */
 } DgnDenseLayer;
 typedef struct DgnDenseGrads {
     const float* g_out;        /* [N, f_out]                                                                 */

@@ -1,0 +1,182 @@
+"""Degree-class posttrans (dgn_dc_*: one f_out-column product per in-degree class instead of the folded S * f_out-column product +
+scale-combine; reference nets/dgn_layer.py:116-119 / :187-190 with nets/scalers.py:7-18) through the C ABI on the GPU:
+the three kernels against fp64, ragged class sizes / absent classes / isolated nodes, run-to-run reproducibility of the weight
+gradient, and the whole simple / complex layer with the route on against the folded route (the oracle comparisons of
+test_configs_gpu.py / test_shipped_configs_gpu.py run with the route on, its default)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(N, max_deg, seed, isolated=0):
+    """A graph whose in-degrees are uniform in 0..max_deg except ``isolated`` nodes of degree 0 at the end."""
+    import dgn_amd
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.randint(1, max_deg + 1, (N,), generator=g)
+    if isolated:
+        deg[-isolated:] = 0
+    dst = torch.repeat_interleave(torch.arange(N), deg)
+    src = torch.randint(0, N, (dst.numel(),), generator=g)
+    return dgn_amd.DGNGraph(src.cuda(), dst.cuda(), N), deg.cuda()
+
+
+def _classes(graph, scale):
+    from dgn_amd import _lib
+    dc = graph.degree_classes()
+    assert dc is not None
+    s = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
+                              present=dc["present"].data_ptr(), scale=scale.data_ptr())
+    return dc, s
+
+
+def _close(a, r, tol=1e-5):
+    scale = float(r.abs().max()) + 1e-30
+    err = float((a.double() - r).abs().max()) / scale
+    assert err <= tol, err
+
+
+def test_virtual_row_space():
+    graph, deg = _graph(5000, 6, 0, isolated=37)
+    dc = graph.degree_classes()
+    vperm, uc, present = dc["vperm"].cpu(), dc["unit_class"].cpu(), dc["present"].cpu()
+    assert vperm.numel() == 64 * dc["n_units"] and uc.numel() == dc["n_units"]
+    live = vperm[vperm >= 0]
+    assert sorted(live.tolist()) == list(range(5000))                       # every node exactly once
+    d = deg.cpu()
+    for u in range(dc["n_units"]):
+        rows = vperm[64 * u: 64 * u + 64]
+        rows = rows[rows >= 0]
+        assert rows.numel() > 0 and bool((d[rows] == uc[u]).all())            # a unit holds nodes of its class only
+    assert bool((uc[1:] >= uc[:-1]).all())                                   # classes ascend along the virtual rows
+    assert present.tolist() == torch.bincount(d, minlength=32).tolist()
+    # stable: ascending node id inside a class
+    for c in range(7):
+        nodes = live[d[live] == c]
+        assert bool((nodes[1:] > nodes[:-1]).all())
+
+
+def test_large_in_degree_keeps_the_folded_route():
+    import dgn_amd
+    N = 100
+    dst = torch.cat([torch.zeros(40, dtype=torch.long), torch.arange(1, N)])
+    src = torch.randint(0, N, (dst.numel(),))
+    graph = dgn_amd.DGNGraph(src.cuda(), dst.cuda(), N)
+    assert graph.max_in_degree == 40 and graph.degree_classes() is None
+
+
+@pytest.mark.parametrize("N,k,n,max_deg,bias,rs", [(20000, 420, 70, 4, True, True), (3333, 70, 420, 6, False, False), (777, 46, 45, 3, True, False),
+                                                   (300000, 152, 65, 8, True, True), (64, 8, 4, 2, True, True), (5000, 300, 75, 31, False, True),
+                                                   (1, 16, 16, 1, True, True), (4000, 45, 184, 4, False, False), (4000, 184, 45, 4, True, True),
+                                                   (9000, 47, 141, 5, False, True)])
+def test_dc_gemm_matches_fp64(N, k, n, max_deg, bias, rs):
+    from dgn_amd import _lib
+    lib = _lib.load()
+    graph, deg = _graph(N, max_deg, 1, isolated=min(5, N - 1))
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = torch.randn(N, k, device="cuda", generator=g)
+    w = torch.randn(32, n, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(n, device="cuda", generator=g) if bias else None
+    r = torch.rand(N, device="cuda", generator=g) + 0.5 if rs else None
+    scale = torch.ones(32, 1, device="cuda")
+    dc, s = _classes(graph, scale)
+    c = torch.full((N, n), float("nan"), device="cuda")
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for stream_out in (0, 1):
+        _lib.check(lib.dgn_dc_gemm(C.byref(s), k, n, a.data_ptr(), k, w.data_ptr(), k, n * k, ptr(b), ptr(r), c.data_ptr(), n, stream_out,
+                                   _lib.stream_ptr(a.device)), "dgn_dc_gemm")
+        ref = torch.zeros(N, n, dtype=torch.float64, device="cuda")
+        for cls in deg.unique().tolist():
+            m = deg == cls
+            ref[m] = a[m].double() @ w[cls].double().t()
+        if b is not None:
+            ref = ref + b.double()
+        if r is not None:
+            ref = ref * r.double().unsqueeze(1)
+        _close(c, ref)
+
+
+@pytest.mark.parametrize("N,k,n,max_deg,S", [(20000, 420, 70, 4, 3), (3333, 230, 45, 6, 2), (300000, 152, 65, 8, 3), (100, 8, 4, 2, 1),
+                                             (5000, 600, 128, 31, 3), (1, 16, 16, 1, 3), (4000, 184, 45, 4, 3), (4000, 141, 47, 4, 3)])
+def test_dc_wgrad_matches_fp64_and_is_reproducible(N, k, n, max_deg, S):
+    from dgn_amd import _lib
+    lib = _lib.load()
+    graph, deg = _graph(N, max_deg, 3, isolated=min(5, N - 1))
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    gy = torch.randn(N, n, device="cuda", generator=gen)
+    x = torch.randn(N, k, device="cuda", generator=gen)
+    scale = torch.rand(32, S, device="cuda", generator=gen) + 0.5
+    dc, s = _classes(graph, scale)
+    nbytes = lib.dgn_dc_wgrad_workspace_bytes(dc["n_units"], k, n)
+    outs = []
+    for _ in range(2):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        out = torch.full((S * n, k), float("nan"), device="cuda")
+        _lib.check(lib.dgn_dc_wgrad(C.byref(s), S, k, n, gy.data_ptr(), n, x.data_ptr(), k, out.data_ptr(), k, ws.data_ptr(), nbytes,
+                                    _lib.stream_ptr(x.device)), "dgn_dc_wgrad")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    sc = scale.double()[deg]                                                    # [N, S]
+    ref = torch.cat([(gy.double() * sc[:, j:j + 1]).t() @ x.double() for j in range(S)], 0)
+    _close(outs[0], ref)
+
+
+def test_dc_fold_matches_fp64():
+    from dgn_amd import _lib
+    lib = _lib.load()
+    graph, deg = _graph(2000, 5, 5)
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    S, n, k = 3, 70, 420
+    wf = torch.randn(S * n, k, device="cuda", generator=gen)
+    scale = torch.rand(32, S, device="cuda", generator=gen) + 0.5
+    dc, s = _classes(graph, scale)
+    wc = torch.zeros(32, n, k, device="cuda")
+    wct = torch.zeros(32, k, n, device="cuda")
+    _lib.check(lib.dgn_dc_fold(C.byref(s), S, n, k, wf.data_ptr(), wc.data_ptr(), wct.data_ptr(), _lib.stream_ptr(wf.device)), "dgn_dc_fold")
+    ref = torch.einsum("cs,sok->cok", scale.double(), wf.double().view(S, n, k))
+    present = dc["present"].bool()
+    _close(wc[present], ref[present], 1e-6)
+    assert torch.equal(wct[present], wc[present].transpose(1, 2))
+    assert float(wc[~present].abs().max()) == 0.0                               # absent classes are not touched
+
+
+@pytest.mark.parametrize("type_net,F,aggs", [("simple", 70, "mean max min dir1-dx dir1-av"), ("complex", 70, "mean max min dir1-av dir1-dx"),
+                                             ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx")])
+def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
+    """The whole layer (forward, d h, every parameter gradient, BatchNorm running statistics) with the degree-class posttrans against the
+    folded product + scale-combine of rounds 1-2: the same arithmetic regrouped, so fp32 rounding apart."""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    b = synth.molecule_batch(400, seed=11)
+    dev = torch.device("cuda")
+    N = int(b["num_nodes"])
+    gen = torch.Generator().manual_seed(12)
+    h0 = torch.randn(N, F, generator=gen)
+    g_out = torch.randn(N, F, generator=gen).to(dev)
+    res = {}
+    for dc_on in (True, False):
+        ops.DC_POSTTRANS = dc_on
+        try:
+            torch.manual_seed(13)
+            layer = dgn_amd.DGNLayer(F, F, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.tensor(1.2)}, type_net, True,
+                                     towers=1, edge_features=False, edge_dim=0).model.to(dev)
+            graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+            h = h0.to(dev).requires_grad_(True)
+            y = layer(graph, h, None, b["snorm_n"].to(dev))
+            y.backward(g_out)
+            res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [layer.batchnorm_h.running_mean, layer.batchnorm_h.running_var]
+        finally:
+            ops.DC_POSTTRANS = True
+    names = ["y", "d h"] + [n for n, _ in layer.named_parameters()] + ["running_mean", "running_var"]
+    for name, a, r in zip(names, res[True], res[False]):
+        if name in ("y", "running_mean", "running_var"):
+            _close(a, r.double(), 2e-5)
+        else:
+            # gradients: an output within rounding of the ReLU's kink may fall on the other side of it in the two routes, which changes the
+            # gradient of that one (node, feature) by O(1) -- 99.9 % of the entries at the tolerance, none far away
+            scale = float(r.abs().max()) + 1e-30
+            err = ((a.double() - r.double()).abs() / scale).flatten()
+            assert float(torch.quantile(err[:: max(1, err.numel() // 1000000)], 0.999)) <= 2e-5, (name, float(err.max()))
+            assert float(err.max()) <= 5e-2, (name, float(err.max()))
