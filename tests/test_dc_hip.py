@@ -146,37 +146,38 @@ def test_dc_fold_matches_fp64():
                                              ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx")])
 def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
     """The whole layer (forward, d h, every parameter gradient, BatchNorm running statistics) with the degree-class posttrans against the
-    folded product + scale-combine of rounds 1-2: the same arithmetic regrouped, so fp32 rounding apart."""
+    folded product + scale-combine of rounds 1-2: the same arithmetic regrouped, so fp32 rounding apart.  An activation within rounding
+    of the ReLU's kink may fall on the other side of it in the two routes (visible in the forward as a differing zero pattern of
+    relu(.) = y - h); that one flipped mask entry moves every gradient downstream by more than rounding, so the comparison is made on
+    the first seeded batch without such a flip (the kernels are deterministic: the choice is stable)."""
     import dgn_amd
     from dgn_amd import ops, synth
-    b = synth.molecule_batch(400, seed=11)
     dev = torch.device("cuda")
-    N = int(b["num_nodes"])
-    gen = torch.Generator().manual_seed(12)
-    h0 = torch.randn(N, F, generator=gen)
-    g_out = torch.randn(N, F, generator=gen).to(dev)
-    res = {}
-    for dc_on in (True, False):
-        ops.DC_POSTTRANS = dc_on
-        try:
-            torch.manual_seed(13)
-            layer = dgn_amd.DGNLayer(F, F, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.tensor(1.2)}, type_net, True,
-                                     towers=1, edge_features=False, edge_dim=0).model.to(dev)
-            graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
-            h = h0.to(dev).requires_grad_(True)
-            y = layer(graph, h, None, b["snorm_n"].to(dev))
-            y.backward(g_out)
-            res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [layer.batchnorm_h.running_mean, layer.batchnorm_h.running_var]
-        finally:
-            ops.DC_POSTTRANS = True
-    names = ["y", "d h"] + [n for n, _ in layer.named_parameters()] + ["running_mean", "running_var"]
-    for name, a, r in zip(names, res[True], res[False]):
-        if name in ("y", "running_mean", "running_var"):
+    for seed in (11, 21, 31, 41, 51, 61):
+        b = synth.molecule_batch(400, seed=seed)
+        N = int(b["num_nodes"])
+        gen = torch.Generator().manual_seed(seed + 1)
+        h0 = torch.randn(N, F, generator=gen)
+        g_out = torch.randn(N, F, generator=gen).to(dev)
+        res = {}
+        for dc_on in (True, False):
+            ops.DC_POSTTRANS = dc_on
+            try:
+                torch.manual_seed(seed + 2)
+                layer = dgn_amd.DGNLayer(F, F, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.tensor(1.2)}, type_net, True,
+                                         towers=1, edge_features=False, edge_dim=0).model.to(dev)
+                graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+                h = h0.to(dev).requires_grad_(True)
+                y = layer(graph, h, None, b["snorm_n"].to(dev))
+                y.backward(g_out)
+                res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [layer.batchnorm_h.running_mean, layer.batchnorm_h.running_var]
+            finally:
+                ops.DC_POSTTRANS = True
+        hd = h0.to(dev)
+        _close(res[True][0], res[False][0].double(), 2e-5)
+        if int((((res[True][0] - hd) == 0) != ((res[False][0] - hd) == 0)).sum()):
+            continue
+        for a, r in zip(res[True], res[False]):
             _close(a, r.double(), 2e-5)
-        else:
-            # gradients: an output within rounding of the ReLU's kink may fall on the other side of it in the two routes, which changes the
-            # gradient of that one (node, feature) by O(1) -- 99.9 % of the entries at the tolerance, none far away
-            scale = float(r.abs().max()) + 1e-30
-            err = ((a.double() - r.double()).abs() / scale).flatten()
-            assert float(torch.quantile(err[:: max(1, err.numel() // 1000000)], 0.999)) <= 2e-5, (name, float(err.max()))
-            assert float(err.max()) <= 5e-2, (name, float(err.max()))
+        return
+    pytest.fail("no seeded batch without a ReLU flip between the two routes")
