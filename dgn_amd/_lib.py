@@ -252,10 +252,10 @@ def load() -> C.CDLL:
             getattr(lib, name).restype = C.c_int
             getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
         lib.dgn_dc_fold.restype = C.c_int
-        lib.dgn_dc_fold.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        lib.dgn_dc_fold.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
         lib.dgn_dc_gemm.restype = C.c_int
-        lib.dgn_dc_gemm.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int64,
-                                    C.c_int32, vp]
+        lib.dgn_dc_gemm.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64,
+                                    C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]
         lib.dgn_dc_wgrad_workspace_bytes.restype = C.c_size_t
         lib.dgn_dc_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_dc_wgrad.restype = C.c_int

@@ -82,38 +82,40 @@ using namespace dgn::dc;
 extern "C" int dgn_dc_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 4096; }
 extern "C" int dgn_dc_wgrad_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 128; }
 
-extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, const float* wf, float* wc, float* wct, void* stream) {
+extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, float* wc, float* wct, void* stream) {
     const char* fn = "dgn_dc_fold";
     if (!check_classes(fn, d)) return DGN_ERR_INVALID;
-    if (S < 1 || S > 3 || n < 1 || k < 1 || !wf || !wc || !wct) { set_error("%s: bad shape or null buffer", fn); return DGN_ERR_INVALID; }
+    if (S < 1 || S > 3 || n < 1 || k < 1 || towers < 1 || towers > 64 || !wf || !wc || !wct) { set_error("%s: bad shape or null buffer", fn); return DGN_ERR_INVALID; }
     if (d->n_units == 0) return DGN_OK;
-    hipLaunchKernelGGL(dc_fold, dim3((unsigned)(((int64_t)n * k + 255) / 256), kClasses), dim3(256), 0, static_cast<hipStream_t>(stream), S, n, k, d->present,
-                       d->scale, wf, wc, wct);
+    hipLaunchKernelGGL(dc_fold, dim3((unsigned)(((int64_t)n * k + 255) / 256), kClasses * towers), dim3(256), 0, static_cast<hipStream_t>(stream), S, n, k,
+                       towers, d->present, d->scale, wf, wc, wct);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
 
-extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
-                           int64_t class_stride, const float* bias, const float* row_scale, float* c, int64_t ldc, int32_t stream_out, void* stream) {
+extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w,
+                           int64_t ldw, int64_t class_stride, int64_t w_tower, const float* bias, const float* row_scale, float* c, int64_t ldc,
+                           int64_t c_tower, int32_t stream_out, void* stream) {
     const char* fn = "dgn_dc_gemm";
     if (!check_classes(fn, d)) return DGN_ERR_INVALID;
-    if (!dgn_dc_supported(k, n)) { set_error("%s: widths outside 4..4096 (k=%d n=%d)", fn, k, n); return DGN_ERR_INVALID; }
+    if (!dgn_dc_supported(k, n) || towers < 1 || towers > 64) { set_error("%s: widths outside 4..4096 (k=%d n=%d) or towers outside 1..64", fn, k, n); return DGN_ERR_INVALID; }
     if (d->n_units == 0) return DGN_OK;
     if (!a || !w || !c || lda < k || ldc < n || ldw < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     DcGemmParams p{};
     p.n_units = d->n_units; p.vperm = d->vperm; p.unit_class = d->unit_class; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw;
     p.class_stride = class_stride; p.bias = bias; p.row_scale = row_scale; p.C = c; p.ldc = ldc; p.stream_out = stream_out;
-    // column tiles of 16 NQ (NQ <= 7): the split with the least padded columns, fewer tiles on a tie
-    int best_nq = 7, best_tiles = (n + 111) / 112, best_pad = best_tiles * 112 - n;
-    for (int nq = 7; nq >= 1; --nq) {
-        const int tiles = (n + 16 * nq - 1) / (16 * nq), pad = tiles * 16 * nq - n;
-        if (pad < best_pad) { best_nq = nq; best_tiles = tiles; best_pad = pad; }
+    p.a_tower = a_tower; p.w_tower = w_tower; p.c_tower = c_tower; p.bias_tower = n;
+    // column tiles of 16 NQ (NQ <= 7): the fewest padded columns, a tile's fixed cost (prologue, operand re-reads) priced at 16 columns
+    int best_nq = 7, best_tiles = (n + 111) / 112, best_cost = best_tiles * (112 + 16);
+    for (int nq = 6; nq >= 1; --nq) {
+        const int tiles = (n + 16 * nq - 1) / (16 * nq), cost = tiles * (16 * nq + 16);
+        if (cost < best_cost) { best_nq = nq; best_tiles = tiles; best_cost = cost; }
     }
     p.n_slice = 16 * best_nq;
     // one workgroup per resident slot (two per CU), each with an equal range of units
-    const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * 2 / best_tiles);
+    const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * 2 / (best_tiles * towers));
     p.units_per_block = std::max<int64_t>(1, (d->n_units + slots_x - 1) / slots_x);
-    const dim3 grid((unsigned)((d->n_units + p.units_per_block - 1) / p.units_per_block), (unsigned)best_tiles);
+    const dim3 grid((unsigned)((d->n_units + p.units_per_block - 1) / p.units_per_block), (unsigned)best_tiles, (unsigned)towers);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (best_nq) {
         case 1: hipLaunchKernelGGL(dc_gemm<1>, grid, dim3(256), 0, st, p); break;

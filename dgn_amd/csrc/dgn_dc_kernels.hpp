@@ -36,17 +36,20 @@ constexpr int kTileM = 256, kTKS = 20;
 
 // ---- class weights ---------------------------------------------------------------------------------------------------------------
 // wc[c][o][kk] = sum_s scale[c][s] wf[(s n + o)][kk],  wct[c][kk][o] the same transposed; classes without rows are skipped
-static __global__ __launch_bounds__(256) void dc_fold(int S, int n, int k, const int32_t* __restrict__ present, const float* __restrict__ scale,
+static __global__ __launch_bounds__(256) void dc_fold(int S, int n, int k, int towers, const int32_t* __restrict__ present, const float* __restrict__ scale,
                                                       const float* __restrict__ wf, float* __restrict__ wc, float* __restrict__ wct) {
-    const int c = blockIdx.y;
+    // blockIdx.y = class * towers + tower; tower t: wf + t S n k, class c / tower t: wc + (c towers + t) n k
+    const int c = blockIdx.y / towers, t = blockIdx.y - c * towers;
     if (present[c] <= 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * k) return;
     const int o = i / k, kk = i - o * k;
+    const float* w = wf + (int64_t)t * S * n * k;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += scale[c * S + s] * wf[(int64_t)(s * n + o) * k + kk];
-    wc[(int64_t)c * n * k + i] = v;
-    wct[(int64_t)c * n * k + (int64_t)kk * n + o] = v;
+    for (int s = 0; s < S; ++s) v += scale[c * S + s] * w[(int64_t)(s * n + o) * k + kk];
+    const int64_t base = ((int64_t)c * towers + t) * n * k;
+    wc[base + i] = v;
+    wct[base + (int64_t)kk * n + o] = v;
 }
 
 // ---- forward / input gradient ----------------------------------------------------------------------------------------------------
@@ -64,6 +67,7 @@ struct DcGemmParams {
     int n_slice;                     // 16 NQ
     int64_t units_per_block;
     int stream_out;                  // nontemporal result stores
+    int64_t a_tower, w_tower, c_tower, bias_tower;      // blockIdx.z = tower: element offsets of its A rows / weights / C columns / bias
 };
 
 // One tile of 64 RT virtual rows (units u0 .. u0 + RT, all of one class) x 16 NQ columns.  Wave w owns rows 16 RT w .. of the tile.
@@ -153,12 +157,15 @@ __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float*
 // A workgroup owns the units [blockIdx.x * units_per_block, + units_per_block) and walks them in tiles of up to four units of one class,
 // the range cut into the fewest tiles of nearly equal height (dgn_gemm_kernels.hpp: tile_gemm).
 template <int NQ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dc_gemm(const DcGemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dc_gemm(const DcGemmParams p_in) {
     __shared__ float As[2 * kTileM * kTKS];
     __shared__ float Bs[2 * NQ * 16 * kTKS];
+    DcGemmParams p = p_in;
     const int n0 = blockIdx.y * p.n_slice;
     int64_t u = (int64_t)blockIdx.x * p.units_per_block;
     const int64_t end = min(p.n_units, u + p.units_per_block);
+    p.A += blockIdx.z * p.a_tower; p.W += blockIdx.z * p.w_tower; p.C += blockIdx.z * p.c_tower;
+    if (p.bias) p.bias += blockIdx.z * p.bias_tower;
     while (u < end) {
         const int c = uniform_i(p.unit_class[u]);
         if (c < 0) { ++u; continue; }

@@ -244,8 +244,8 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
         // one product per in-degree class: y = snorm (b + agg W_class^T), W_class = sum_s scale_s(class) W_f[s]
         float* wc = L->wf + (size_t)2 * d.n * d.K;
         float* wct = wc + (size_t)DGN_DC_CLASSES * d.fo * d.K;
-        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, L->wf, wc, wct, stream));
-        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, L->agg, d.K, wc, d.K, (int64_t)d.fo * d.K, L->b_post, L->snorm, L->y, d.fo, 0, stream));
+        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, 1, L->wf, wc, wct, stream));
+        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, 1, L->agg, d.K, 0, wc, d.K, (int64_t)d.fo * d.K, 0, L->b_post, L->snorm, L->y, d.fo, 0, 0, stream));
     } else {
         DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
         DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
@@ -296,7 +296,8 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         const float* wct = L->wf + (size_t)2 * d.n * d.K + (size_t)DGN_DC_CLASSES * d.fo * d.K;
         DGN_TRY(dgn_scale_combine_backward(d.N, 1, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
                                            dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
-        DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, g_z, d.fo, wct, d.fo, (int64_t)d.fo * d.K, nullptr, nullptr, g_agg, d.K, 0, stream));
+        static const int dc_stream = getenv("DGN_DC_STREAM") ? atoi(getenv("DGN_DC_STREAM")) : 0;      // (experiment: nontemporal d agg rows)
+        DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, 1, g_z, d.fo, 0, wct, d.fo, (int64_t)d.fo * d.K, 0, nullptr, nullptr, g_agg, d.K, 0, dc_stream, stream));
         DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, g_wf, d.K, ws + s.wg_ws, dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo),
                              stream));
     } else {

@@ -540,11 +540,14 @@ typedef struct DgnDegreeClasses {
 } DgnDegreeClasses;
 int dgn_dc_supported(int32_t k, int32_t n);
 int dgn_dc_wgrad_supported(int32_t k, int32_t n);
-/* wc[c][o][kk] = sum_s scale[c][s] wf[s n + o][kk] and wct[c][kk][o] (its transpose), classes present only; wf [S n, k]           */
-int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, const float* wf, float* wc, float* wct, void* stream);
-/* c[node] = row_scale[node] * (bias + a[node] w_class(node)^T); w: class c at w + c * class_stride, [n, k] rows of stride ldw       */
-int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, const float* a, int64_t lda, const float* w, int64_t ldw,
-                int64_t class_stride, const float* bias, const float* row_scale, float* c, int64_t ldc, int32_t stream_out, void* stream);
+/* wc[c][t][o][kk] = sum_s scale[c][s] wf[t][s n + o][kk] and wct[c][t][kk][o] (its transpose), classes present only;
+ * wf [towers][S n, k], wc / wct [DGN_DC_CLASSES][towers][n k]                                                                       */
+int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, float* wc, float* wct, void* stream);
+/* c[node] = row_scale[node] * (bias + a[node] w_class(node)^T) for every tower t (element offsets t * a_tower / w_tower / c_tower, bias
+ * t * n); w: class c at w + c * class_stride, [n, k] rows of stride ldw                                                             */
+int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w,
+                int64_t ldw, int64_t class_stride, int64_t w_tower, const float* bias, const float* row_scale, float* c, int64_t ldc,
+                int64_t c_tower, int32_t stream_out, void* stream);
 /* g_wf[s n + o][kk] = sum_nodes scale[class(node)][s] g[node][o] x[node][kk]  (per-class products, fixed-order finalize)             */
 size_t dgn_dc_wgrad_workspace_bytes(int64_t n_units, int32_t k, int32_t n);
 int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx,

@@ -85,7 +85,7 @@ def test_dc_gemm_matches_fp64(N, k, n, max_deg, bias, rs):
     c = torch.full((N, n), float("nan"), device="cuda")
     ptr = lambda t: t.data_ptr() if t is not None else None
     for stream_out in (0, 1):
-        _lib.check(lib.dgn_dc_gemm(C.byref(s), k, n, a.data_ptr(), k, w.data_ptr(), k, n * k, ptr(b), ptr(r), c.data_ptr(), n, stream_out,
+        _lib.check(lib.dgn_dc_gemm(C.byref(s), k, n, 1, a.data_ptr(), k, 0, w.data_ptr(), k, n * k, 0, ptr(b), ptr(r), c.data_ptr(), n, 0, stream_out,
                                    _lib.stream_ptr(a.device)), "dgn_dc_gemm")
         ref = torch.zeros(N, n, dtype=torch.float64, device="cuda")
         for cls in deg.unique().tolist():
@@ -134,7 +134,7 @@ def test_dc_fold_matches_fp64():
     dc, s = _classes(graph, scale)
     wc = torch.zeros(32, n, k, device="cuda")
     wct = torch.zeros(32, k, n, device="cuda")
-    _lib.check(lib.dgn_dc_fold(C.byref(s), S, n, k, wf.data_ptr(), wc.data_ptr(), wct.data_ptr(), _lib.stream_ptr(wf.device)), "dgn_dc_fold")
+    _lib.check(lib.dgn_dc_fold(C.byref(s), S, n, k, 1, wf.data_ptr(), wc.data_ptr(), wct.data_ptr(), _lib.stream_ptr(wf.device)), "dgn_dc_fold")
     ref = torch.einsum("cs,sok->cok", scale.double(), wf.double().view(S, n, k))
     present = dc["present"].bool()
     _close(wc[present], ref[present], 1e-6)
