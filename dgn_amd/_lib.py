@@ -83,7 +83,7 @@ class DgnTowersLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
-                ("zmask", C.c_void_p), ("agg_aux", C.c_void_p)]
+                ("zmask", C.c_void_p), ("agg_aux", C.c_void_p), ("dc", C.c_void_p), ("wc", C.c_void_p)]
 
 
 class DgnTowersGrads(C.Structure):

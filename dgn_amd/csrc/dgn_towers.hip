@@ -100,6 +100,11 @@ SideStream& side_stream() {
     return s;
 }
 
+// degree-class posttrans (forward and input gradient): classes and the class-weight buffer given, several scalers, widths >= 4
+bool use_dc(const DgnTowersLayer* L, const Dims& d) {
+    return L->dc && L->wc && d.S > 1 && dgn_dc_supported(d.K, d.fo) && dgn_dc_supported(d.fo, d.K);
+}
+
 DgnMsg sweep_msg(const DgnTowersLayer* L, const Dims& d) {
     DgnMsg m{};
     m.F = d.Fm;
@@ -169,6 +174,13 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     const size_t agg_ws = L->ws_bytes - bn_ws;
     DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, L->agg_aux, ws + bn_ws, agg_ws, stream));
     // posttrans([h || agg]) with the folded scalers, bias and graph norm                     (:266-271)
+    if (use_dc(L, d)) {
+        // ... as ONE f_out-column product per in-degree class and tower (dgn_dc_kernels.hpp): W_class = sum_s scale_s(class) W_s
+        const int64_t wsz = (int64_t)d.T * d.fo * d.K;
+        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, d.T, L->w_post, L->wc, L->wc + DGN_DC_CLASSES * wsz, stream));
+        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, d.T, L->aggx, d.K, d.N * d.K, L->wc, d.K, wsz, (int64_t)d.fo * d.K, L->b_post, L->snorm, L->y0, d.Fo, d.fo, 0,
+                            stream));
+    } else
     DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
@@ -287,7 +299,11 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     if (aux && !ss.fork(st, 1)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }          // (g_yr is ready: the weight gradient may start)
     const char* fb_env = getenv("DGN_FUSED_BACKWARD");          // (read per call: the tests switch it)
     const bool fused_bwd = fb_env && atoi(fb_env) != 0 && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
-    if (!fused_bwd)
+    if (!fused_bwd && use_dc(L, d)) {
+        const int64_t wsz = (int64_t)d.T * d.fo * d.K;
+        DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, d.T, g_yr, d.fo, d.N * d.fo, L->wc + DGN_DC_CLASSES * wsz, d.fo, wsz, (int64_t)d.fo * d.K, nullptr, nullptr, g_aggx,
+                            d.K, d.N * d.K, 0, stream));
+    } else if (!fused_bwd)
         DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
                                                   g_aggx, d.N * d.K, stream));
     DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,

@@ -471,6 +471,7 @@ int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr
  * save_mean, save_invstd are written by the forward and read by the backward (caller-owned: the autograd-saved tensors).
  * Shapes: h [N, T*f_in]; w_sd [2 T f_in, T f_in]; w_post [T][S*f_out][K], K = agg_total * f_in; w_mix [T f_out, T f_out].
  * dgn_towers_layer_supported() says whether the widths fit the streaming Linear kernels.                            */
+struct DgnDegreeClasses;          /* (declared below: degree-class posttrans)                                  */
 typedef struct DgnTowersLayer {
     const DgnGraph* graph;
     const DgnAggSpec* spec;
@@ -499,6 +500,10 @@ typedef struct DgnTowersLayer {
     /* Optional: dgn_agg_aux_bytes(graph, spec, the sweep's message) bytes -- the forward sweep leaves its aux table here, the
      * backward sweep works from it (dgn_agg_forward_aux / dgn_agg_backward_aux).  NULL: the backward recomputes.                */
     unsigned char* agg_aux;
+    /* Optional (S > 1): degree-class posttrans for the forward and the input gradient (dgn_dc_fold / dgn_dc_gemm over the towers);
+     * wc: 2 * DGN_DC_CLASSES * T * f_out * K floats (class weights and their transposes), written by the forward, read by the backward */
+    const struct DgnDegreeClasses* dc;
+    float* wc;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */

@@ -143,7 +143,8 @@ def test_dc_fold_matches_fp64():
 
 
 @pytest.mark.parametrize("type_net,F,aggs", [("simple", 70, "mean max min dir1-dx dir1-av"), ("complex", 70, "mean max min dir1-av dir1-dx"),
-                                             ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx")])
+                                             ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx"),
+                                             ("towers", 70, "mean max min dir1-av dir1-dx")])
 def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
     """The whole layer (forward, d h, every parameter gradient, BatchNorm running statistics) with the degree-class posttrans against the
     folded product + scale-combine of rounds 1-2: the same arithmetic regrouped, so fp32 rounding apart.  An activation within rounding
@@ -161,23 +162,29 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
         g_out = torch.randn(N, F, generator=gen).to(dev)
         res = {}
         for dc_on in (True, False):
-            ops.DC_POSTTRANS = dc_on
+            ops.DC_POSTTRANS, towers_default = dc_on, ops.DC_TOWERS
+            ops.DC_TOWERS = True                                           # (the towers layer's route is off by default: slower)
             try:
                 torch.manual_seed(seed + 2)
                 layer = dgn_amd.DGNLayer(F, F, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.tensor(1.2)}, type_net, True,
-                                         towers=1, edge_features=False, edge_dim=0).model.to(dev)
+                                         towers=5 if type_net == "towers" else 1, edge_features=False, edge_dim=0).model.to(dev)
                 graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
                 h = h0.to(dev).requires_grad_(True)
                 y = layer(graph, h, None, b["snorm_n"].to(dev))
                 y.backward(g_out)
-                res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [layer.batchnorm_h.running_mean, layer.batchnorm_h.running_var]
+                res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [bf for n_, bf in layer.named_buffers() if "running" in n_]
             finally:
-                ops.DC_POSTTRANS = True
+                ops.DC_POSTTRANS, ops.DC_TOWERS = True, towers_default
+        _close(res[True][0], res[False][0].double(), 2e-5)               # the forward: always
         hd = h0.to(dev)
-        _close(res[True][0], res[False][0].double(), 2e-5)
-        if int((((res[True][0] - hd) == 0) != ((res[False][0] - hd) == 0)).sum()):
-            continue
-        for a, r in zip(res[True], res[False]):
-            _close(a, r.double(), 2e-5)
+        if type_net != "towers" and int((((res[True][0] - hd) == 0) != ((res[False][0] - hd) == 0)).sum()):
+            continue                                                       # a ReLU flip, seen in the zero pattern of relu(.) = y - h
+        try:
+            for a, r in zip(res[True], res[False]):
+                _close(a, r.double(), 2e-5)
+        except AssertionError:
+            if type_net != "towers":
+                raise
+            continue                                                       # (towers: LeakyReLU flips leave no trace in y: next batch)
         return
-    pytest.fail("no seeded batch without a ReLU flip between the two routes")
+    pytest.fail("no seeded batch on which the two routes agree in every gradient (ReLU flips cannot explain six batches)")
