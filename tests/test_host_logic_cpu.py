@@ -83,3 +83,47 @@ def test_layer_algebra_vs_oracle_layer(oracle_backend, case):
         np.testing.assert_allclose(a.numpy(), r.numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(r.abs().max())), err_msg=k)
     for k, v in stats.items():
         np.testing.assert_allclose(layer.state_dict()[k].numpy(), v.numpy(), rtol=1e-6, atol=1e-8, err_msg=k)
+
+
+def test_degree_class_algebra_and_virtual_row_space():
+    """Degree-class posttrans on CPU (the kernels: tests/test_dc_hip.py): (1) DGNGraph.degree_classes() -- every node once, units hold one
+    class, classes ascend, stable inside a class; (2) the identity the route rests on, with the oracle's scalers
+    (oracle/dgn_oracle.py, nets/scalers.py:7-18): posttrans(cat(agg x scalers)) == agg (sum_s scale_s(deg) W_s)^T per in-degree."""
+    import dgn_amd
+    from dgn_amd.dgn_layer import _scale_table
+    from dgn_amd.spec import make_plan
+    g = torch.Generator().manual_seed(0)
+    N = 700
+    deg = torch.randint(0, 7, (N,), generator=g)
+    dst = torch.repeat_interleave(torch.arange(N), deg)
+    src = torch.randint(0, N, (dst.numel(),), generator=g)
+    graph = dgn_amd.DGNGraph(src, dst, N)
+    dc = graph.degree_classes()
+    vperm, uc = dc["vperm"], dc["unit_class"]
+    assert vperm.numel() == 64 * dc["n_units"]
+    live = vperm[vperm >= 0]
+    assert sorted(live.tolist()) == list(range(N))
+    for u in range(dc["n_units"]):
+        rows = vperm[64 * u: 64 * u + 64]
+        rows = rows[rows >= 0].long()
+        assert rows.numel() and bool((deg[rows] == uc[u]).all())
+    assert bool((uc[1:] >= uc[:-1]).all())
+    assert dc["present"].tolist() == torch.bincount(deg, minlength=32).tolist()
+    for c in range(7):
+        nodes = live[deg[live.long()] == c]
+        assert bool((nodes[1:] > nodes[:-1]).all())
+    assert bool((deg[dc["rep"]][dc["present"] > 0] == torch.arange(32)[dc["present"] > 0]).all())
+    # the algebra, fp64: scalers applied to the aggregates then one Linear == per-class folded weights
+    plan = make_plan(["mean", "max"], ["identity", "amplification", "attenuation"])
+    sc = _scale_table(graph, plan.applied_scalers, 1.3).double()                 # [N, S] per node
+    S, A, F, fo = sc.shape[1], 2, 6, 5
+    agg = torch.randn(N, A * F, generator=g, dtype=torch.float64)
+    W = torch.randn(fo, S * A * F, generator=g, dtype=torch.float64)             # reference layout: scaler-major input blocks
+    ref = torch.cat([agg * sc[:, s:s + 1] for s in range(S)], dim=1) @ W.t()
+    cls = sc[dc["rep"]]                                                          # [32, S]: the class rows of the table
+    Wc = torch.einsum("cs,osk->cok", cls, W.view(fo, S, A * F))
+    out = torch.einsum("nk,nok->no", agg, Wc[deg])
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-12, atol=1e-12)
+    # a graph with an in-degree of 32 or more keeps the folded route
+    dst2 = torch.cat([torch.zeros(40, dtype=torch.long), torch.arange(1, 50)])
+    assert dgn_amd.DGNGraph(torch.randint(0, 50, (dst2.numel(),), generator=g), dst2, 50).degree_classes() is None
