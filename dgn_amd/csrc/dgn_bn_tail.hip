@@ -212,20 +212,34 @@ __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const
                                                     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                     double* __restrict__ part, const int64_t* __restrict__ n_valid) {
     if (n_valid) n_rows = min(n_rows, *n_valid);
-    auto one = [&](float xv, float g, int c, float& v0, float& v1) {
-        const float xh = (xv - mean[c]) * invstd[c];
-        if (relu && !(xh * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f) > 0.f)) g = 0.f;
+    // a thread's columns are fixed for the whole row loop (one pass of the helpers' column loop unless F > 256 / 512): their BatchNorm
+    // constants are read ONCE -- inside the loop they were four more (cached) loads per element in the same in-order queue as the rows,
+    // and the ReLU variant ran at half the rate of the plain one
+    struct Col { float mu, is, ga, be; };
+    auto col = [&](int c) {
+        const int cc = min(c, F - 1);
+        return Col{mean[cc], invstd[cc], gamma ? gamma[cc] : 1.f, beta ? beta[cc] : 0.f};
+    };
+    auto one = [&](float xv, float g, const Col& k, float& v0, float& v1) {
+        const float xh = (xv - k.mu) * k.is;
+        if (relu && !(xh * k.ga + k.be > 0.f)) g = 0.f;
         v0 = g;
         v1 = g * xh;
     };
     if constexpr (PAIRS) {
+        const int F2 = F >> 1;
+        const bool fixed = F2 <= 256;
+        const int mine = 2 * ((int)threadIdx.x % F2);
+        const Col k0 = col(mine), k1 = col(mine + 1);
         column_partials_pairs(n_rows, F, part, [&](int64_t n, int c, float (&v0)[2], float (&v1)[2]) {
             const float2 xv = *reinterpret_cast<const float2*>(x + n * ld + c), g = *reinterpret_cast<const float2*>(gy + n * ld + c);
-            one(xv.x, g.x, c, v0[0], v1[0]);
-            one(xv.y, g.y, c + 1, v0[1], v1[1]);
+            one(xv.x, g.x, fixed ? k0 : col(c), v0[0], v1[0]);
+            one(xv.y, g.y, fixed ? k1 : col(c + 1), v0[1], v1[1]);
         });
     } else {
-        column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) { one(x[n * ld + c], gy[n * ld + c], c, v0, v1); });
+        const bool fixed = F <= 256;
+        const Col k0 = col((int)threadIdx.x % F);
+        column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) { one(x[n * ld + c], gy[n * ld + c], fixed ? k0 : col(c), v0, v1); });
     }
 }
 
