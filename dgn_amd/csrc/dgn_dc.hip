@@ -115,7 +115,11 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
     // one workgroup per resident slot (two per CU), each with an equal range of units
     const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * 2 / (best_tiles * towers));
     p.units_per_block = std::max<int64_t>(1, (d->n_units + slots_x - 1) / slots_x);
-    const dim3 grid((unsigned)((d->n_units + p.units_per_block - 1) / p.units_per_block), (unsigned)best_tiles, (unsigned)towers);
+    const int64_t ranges = (d->n_units + p.units_per_block - 1) / p.units_per_block;
+    static const bool no_xcd = getenv("DGN_DC_NO_XCD") != nullptr;
+    p.col_tiles = (best_tiles > 1 && !no_xcd) ? best_tiles : 1;
+    const dim3 grid = p.col_tiles > 1 ? dim3((unsigned)((ranges + kXcds - 1) / kXcds * kXcds * best_tiles), 1, (unsigned)towers)
+                                      : dim3((unsigned)ranges, (unsigned)best_tiles, (unsigned)towers);
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (best_nq) {
         case 1: hipLaunchKernelGGL(dc_gemm<1>, grid, dim3(256), 0, st, p); break;

@@ -67,6 +67,7 @@ struct DcGemmParams {
     int n_slice;                     // 16 NQ
     int64_t units_per_block;
     int stream_out;                  // nontemporal result stores
+    int col_tiles;                   // > 1: 1-D grid of 8-aligned row ranges x column tiles (XCD-aware dealing), else blockIdx.y = 0
     int64_t a_tower, w_tower, c_tower, bias_tower;      // blockIdx.z = tower: element offsets of its A rows / weights / C columns / bias
 };
 
@@ -161,8 +162,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ float As[2 * kTileM * kTKS];
     __shared__ float Bs[2 * NQ * 16 * kTKS];
     DcGemmParams p = p_in;
-    const int n0 = blockIdx.y * p.n_slice;
-    int64_t u = (int64_t)blockIdx.x * p.units_per_block;
+    // several column tiles: a 1-D grid dealt so that the column tiles of ONE row range are consecutive workgroups of ONE XCD (the
+    // dispatcher places workgroup b on XCD b % 8): they run together and share the range's A rows in that XCD's L2
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.col_tiles > 1) {
+        const int xcd = bx % kXcds, j = bx / kXcds;
+        by = j % p.col_tiles;
+        bx = (j / p.col_tiles) * kXcds + xcd;
+    }
+    const int n0 = by * p.n_slice;
+    int64_t u = (int64_t)bx * p.units_per_block;
     const int64_t end = min(p.n_units, u + p.units_per_block);
     p.A += blockIdx.z * p.a_tower; p.W += blockIdx.z * p.w_tower; p.C += blockIdx.z * p.c_tower;
     if (p.bias) p.bias += blockIdx.z * p.bias_tower;
@@ -203,9 +212,11 @@ struct DcWgradParams {
 // 8 waves; wave w owns all NTN n-tiles x the k-tiles w + 8 b (b < KT <= 4) of the workgroup's k slice.  A run (workgroup x, class c) gets the
 // partial block x + c: the workgroups' unit ranges are contiguous and ascending and the classes ascend along the virtual rows, so
 // (x, c) -> x + c is strictly increasing along the sequence of runs, hence unique and ascending in class for the finalize.
-template <int NTN, int KT>
-__global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams p) {
-    extern __shared__ float lds_dc[];
+// KT: k tiles per wave the LDS strips are laid out for; KTW (KT or KT - 1): the k tiles THIS wave accumulates (w + 8 b, b < KTW) -- with
+// k = 420 (27 tiles) three waves own four tiles and five own three: the wave-uniform count is a template argument (MFMAs under run-time
+// guards make the compiler copy the accumulators), every wave runs the same barriers whatever its instantiation.
+template <int NTN, int KT, int KTW>
+__device__ __forceinline__ void dc_wgrad_run(const DcWgradParams& p, float* lds_dc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int k0 = blockIdx.y * p.k_slice, k_here = min(p.k_slice, p.k - k0);
     constexpr int gs = NTN * 16 + 4, xs = KT * 128 + 4;          // LDS row strides
@@ -259,11 +270,11 @@ __global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams
             run_end += kUnit / 16;
         }
         run_end = min(run_end, s_end);
-        f4 acc[NTN][KT];
+        f4 acc[NTN][KTW];
 #pragma unroll
         for (int a = 0; a < NTN; ++a)
 #pragma unroll
-            for (int b = 0; b < KT; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < KTW; ++b) acc[a][b] = f4{0.f, 0.f, 0.f, 0.f};
         for (; strip < run_end; ++strip, buf ^= 1) {
             const bool more = strip + 1 < s_end;
             if (more) fetch(sreg, strip + 1);
@@ -272,22 +283,22 @@ __global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams
             // D[n][k] += G[m][n] X[m][k], the strip's rows are the reduction index: m = 4 s + g in the s-th instruction
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float gv[NTN], xv[KT];
+                float gv[NTN], xv[KTW];
 #pragma unroll
                 for (int a = 0; a < NTN; ++a) gv[a] = Gb[(4 * s + g) * gs + 16 * a + i16];
 #pragma unroll
-                for (int b = 0; b < KT; ++b) xv[b] = Xb[(4 * s + g) * xs + 16 * (wave + kWgWaves * b) + i16];
+                for (int b = 0; b < KTW; ++b) xv[b] = Xb[(4 * s + g) * xs + 16 * (wave + kWgWaves * b) + i16];
 #pragma unroll
                 for (int a = 0; a < NTN; ++a)
 #pragma unroll
-                    for (int b = 0; b < KT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[a], xv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < KTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[a], xv[b], acc[a][b], 0, 0, 0);
             }
             if (more) commit(sreg, buf ^ 1);
             __syncthreads();
         }
         float* out = p.part + ((int64_t)blockIdx.y * ids + blockIdx.x + cls) * (NTN * 16) * p.kpad;
 #pragma unroll
-        for (int b = 0; b < KT; ++b) {
+        for (int b = 0; b < KTW; ++b) {
             const int col = 16 * (wave + kWgWaves * b) + i16;
             if (col < p.kpad) {
 #pragma unroll
@@ -298,6 +309,18 @@ __global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams
         }
         if (tid == 0 && blockIdx.y == 0) p.run_class[blockIdx.x + cls] = cls;
     }
+}
+
+template <int NTN, int KT>
+__global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams p) {
+    extern __shared__ float lds_dc[];
+    if constexpr (KT > 1) {
+        const int wave = uniform_i((int)threadIdx.x >> 6);
+        const int tiles = (min(p.k_slice, p.k - (int)blockIdx.y * p.k_slice) + 15) >> 4;
+        const int mine = wave < tiles ? (tiles - wave + kWgWaves - 1) / kWgWaves : 0;      // tiles w, w + 8, ... below `tiles`
+        if (mine < KT) { dc_wgrad_run<NTN, KT, KT - 1>(p, lds_dc); return; }
+    }
+    dc_wgrad_run<NTN, KT, KT>(p, lds_dc);
 }
 
 // g_wf[(s n + o)][kk] = sum over the runs, in run order, of scale[class][s] * part[run][o][kk]; a block covers 64 consecutive elements,
