@@ -95,6 +95,10 @@ class DgnDegreeClasses(C.Structure):
     _fields_ = [("n_units", C.c_int64), ("vperm", C.c_void_p), ("unit_class", C.c_void_p), ("present", C.c_void_p), ("scale", C.c_void_p)]
 
 
+class DgnDcLayout(C.Structure):
+    _fields_ = [("n_agg", C.c_int32), ("f_pad", C.c_int32), ("f_in", C.c_int32), ("h_off", C.c_int32), ("id_slot", C.c_int32), ("ld", C.c_int64)]
+
+
 class DgnDenseLayer(C.Structure):
     _fields_ = [("graph", C.POINTER(DgnGraph)), ("spec", C.POINTER(DgnAggSpec)), ("w", C.c_void_p), ("ld_w", C.c_int64), ("log_deg", C.c_void_p),
                 ("type", C.c_int32), ("f_in", C.c_int32), ("f_out", C.c_int32), ("n_scalers", C.c_int32), ("n_agg", C.c_int32), ("id_slot", C.c_int32),
@@ -252,15 +256,15 @@ def load() -> C.CDLL:
             getattr(lib, name).restype = C.c_int
             getattr(lib, name).argtypes = [C.c_int32, C.c_int32]
         lib.dgn_dc_fold.restype = C.c_int
-        lib.dgn_dc_fold.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        lib.dgn_dc_fold.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.POINTER(DgnDcLayout), vp, vp, vp]
         lib.dgn_dc_gemm.restype = C.c_int
         lib.dgn_dc_gemm.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int64,
                                     C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, vp]
         lib.dgn_dc_wgrad_workspace_bytes.restype = C.c_size_t
         lib.dgn_dc_wgrad_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.dgn_dc_wgrad.restype = C.c_int
-        lib.dgn_dc_wgrad.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp,
-                                     C.c_size_t, vp]
+        lib.dgn_dc_wgrad.argtypes = [C.POINTER(DgnDegreeClasses), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64,
+                                     C.POINTER(DgnDcLayout), vp, C.c_size_t, vp]
         lib.dgn_gemm_supported.restype = C.c_int
         lib.dgn_gemm_supported.argtypes = [C.c_int32, C.c_int32]
         lib.dgn_gemm_forward.restype = C.c_int

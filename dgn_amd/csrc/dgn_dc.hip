@@ -82,13 +82,31 @@ using namespace dgn::dc;
 extern "C" int dgn_dc_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 4096; }
 extern "C" int dgn_dc_wgrad_supported(int32_t k, int32_t n) { return k >= 4 && n >= 4 && k <= 4096 && n <= 128; }
 
-extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, float* wc, float* wct, void* stream) {
+namespace {
+bool check_layout(const char* fn, const DgnDcLayout* lay, int k) {
+    if (!lay) return true;
+    if (lay->n_agg < 1 || lay->f_pad < lay->f_in || lay->f_in < 1 || (lay->h_off != 0 && lay->h_off != lay->f_in) ||
+        k != (lay->n_agg + (lay->h_off ? 1 : 0)) * lay->f_pad) {
+        set_error("%s: DgnDcLayout does not describe %d columns", fn, k);
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, const DgnDcLayout* layout, float* wc,
+                           float* wct, void* stream) {
     const char* fn = "dgn_dc_fold";
     if (!check_classes(fn, d)) return DGN_ERR_INVALID;
-    if (S < 1 || S > 3 || n < 1 || k < 1 || towers < 1 || towers > 64 || !wf || !wc || !wct) { set_error("%s: bad shape or null buffer", fn); return DGN_ERR_INVALID; }
+    if (S < 1 || S > 3 || n < 1 || k < 1 || towers < 1 || towers > 64 || !wf || !wc || !wct || (layout && towers != 1)) {
+        set_error("%s: bad shape or null buffer", fn);
+        return DGN_ERR_INVALID;
+    }
+    if (!check_layout(fn, layout, k)) return DGN_ERR_INVALID;
     if (d->n_units == 0) return DGN_OK;
+    const DgnDcLayout none{};
     hipLaunchKernelGGL(dc_fold, dim3((unsigned)(((int64_t)n * k + 255) / 256), kClasses * towers), dim3(256), 0, static_cast<hipStream_t>(stream), S, n, k,
-                       towers, d->present, d->scale, wf, wc, wct);
+                       towers, d->present, d->scale, wf, wc, wct, layout ? *layout : none, layout ? 1 : 0);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
@@ -137,17 +155,18 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
 extern "C" size_t dgn_dc_wgrad_workspace_bytes(int64_t n_units, int32_t k, int32_t n) {
     if (n_units <= 0 || !dgn_dc_wgrad_supported(k, n)) return 0;
     const WgPlan w = wgrad_plan(n_units, k, n);
-    return w.part_floats * sizeof(float) + (size_t)(w.slots + kClasses) * sizeof(int32_t) + 256;
+    return w.part_floats * sizeof(float) + (size_t)w.slots * sizeof(uint32_t) + 256;
 }
 
 extern "C" int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx,
-                            float* g_wf, int64_t ldw, void* ws, size_t ws_bytes, void* stream) {
+                            float* g_wf, int64_t ldw, const DgnDcLayout* layout, void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "dgn_dc_wgrad";
     if (!check_classes(fn, d)) return DGN_ERR_INVALID;
     if (!dgn_dc_wgrad_supported(k, n) || S < 1 || S > 3) { set_error("%s: unsupported widths (k=%d n=%d S=%d)", fn, k, n, S); return DGN_ERR_INVALID; }
-    if (!g_wf || ldw < k) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
+    if (!g_wf || (!layout && ldw < k)) { set_error("%s: null output", fn); return DGN_ERR_INVALID; }
+    if (!check_layout(fn, layout, k)) return DGN_ERR_INVALID;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d->n_units == 0) return zero_rows_async(g_wf, (int64_t)S * n, k, ldw, st);
+    if (d->n_units == 0) return layout ? zero_rows_async(g_wf, n, layout->ld, layout->ld, st) : zero_rows_async(g_wf, (int64_t)S * n, k, ldw, st);
     if (!g || !x || ldg < n || ldx < k) { set_error("%s: null operand or row stride smaller than the row", fn); return DGN_ERR_INVALID; }
     const size_t need = dgn_dc_wgrad_workspace_bytes(d->n_units, k, n);
     if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
@@ -155,17 +174,18 @@ extern "C" int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int
     DcWgradParams p{};
     p.n_units = d->n_units; p.vperm = d->vperm; p.unit_class = d->unit_class; p.n = n; p.k = k; p.G = g; p.ldg = ldg; p.X = x; p.ldx = ldx;
     p.part = static_cast<float*>(ws);
-    p.run_class = reinterpret_cast<int32_t*>(static_cast<char*>(ws) + ((w.part_floats * sizeof(float) + 255) & ~(size_t)255));
+    p.run_mask = reinterpret_cast<uint32_t*>(static_cast<char*>(ws) + ((w.part_floats * sizeof(float) + 255) & ~(size_t)255));
     p.k_slice = w.k_slice; p.kpad = w.kpad; p.slots = w.slots; p.units_per_block = w.units_per_block;
-    const int ids = w.slots + kClasses;
-    hipLaunchKernelGGL(fill_i32, dim3((ids + 255) / 256), dim3(256), 0, st, ids, -1, p.run_class);
+    const DgnDcLayout none{};
+    const DgnDcLayout lay = layout ? *layout : none;
+    const int hl = layout ? 1 : 0;
     DGN_HIP_CHECK(launch_wgrad(w.ntn, w.kt, p, dim3(w.slots, w.k_slices), w.lds, st));
     const int64_t total = (int64_t)n * k;
     const dim3 fgrid((unsigned)((total + 63) / 64));
     switch (S) {
-        case 1: hipLaunchKernelGGL(dc_wgrad_finalize<1>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
-        case 2: hipLaunchKernelGGL(dc_wgrad_finalize<2>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
-        default: hipLaunchKernelGGL(dc_wgrad_finalize<3>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, ids, p.run_class, d->scale, p.part, g_wf, ldw); break;
+        case 1: hipLaunchKernelGGL(dc_wgrad_finalize<1>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, w.slots, p.run_mask, d->scale, p.part, g_wf, ldw, lay, hl); break;
+        case 2: hipLaunchKernelGGL(dc_wgrad_finalize<2>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, w.slots, p.run_mask, d->scale, p.part, g_wf, ldw, lay, hl); break;
+        default: hipLaunchKernelGGL(dc_wgrad_finalize<3>, fgrid, dim3(64 * 16), 0, st, n, k, w.k_slice, w.kpad, w.ntn * 16, w.slots, p.run_mask, d->scale, p.part, g_wf, ldw, lay, hl); break;
     }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;

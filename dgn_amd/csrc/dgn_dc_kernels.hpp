@@ -34,10 +34,21 @@ constexpr int kClasses = DGN_DC_CLASSES;     // in-degrees 0 .. 31
 constexpr int kUnit = DGN_DC_UNIT;           // rows per unit of the virtual row space
 constexpr int kTileM = 256, kTKS = 20;
 
+// The posttrans weight in the reference's layout (DgnDcLayout) seen as the scaler-major folded matrix wf[(s n + o)][kk]:
+// kk = a f_pad + f; aggregator blocks a < n_agg at W[o][h_off + (s n_agg + a) f_in + f], the h block (a == n_agg, complex layer) at W[o][f]
+// in the identity scaler's rows only, padded feature columns (f >= f_in) zero.  Returns the element's offset in W, or -1.
+__device__ __forceinline__ int64_t dc_ref_offset(const DgnDcLayout& L, int s, int o, int kk) {
+    const int a = kk / L.f_pad, f = kk - a * L.f_pad;
+    if (f >= L.f_in) return -1;
+    if (a < L.n_agg) return (int64_t)o * L.ld + L.h_off + (s * L.n_agg + a) * L.f_in + f;
+    return s == L.id_slot ? (int64_t)o * L.ld + f : -1;
+}
+
 // ---- class weights ---------------------------------------------------------------------------------------------------------------
 // wc[c][o][kk] = sum_s scale[c][s] wf[(s n + o)][kk],  wct[c][kk][o] the same transposed; classes without rows are skipped
 static __global__ __launch_bounds__(256) void dc_fold(int S, int n, int k, int towers, const int32_t* __restrict__ present, const float* __restrict__ scale,
-                                                      const float* __restrict__ wf, float* __restrict__ wc, float* __restrict__ wct) {
+                                                      const float* __restrict__ wf, float* __restrict__ wc, float* __restrict__ wct, const DgnDcLayout lay,
+                                                      int has_layout) {
     // blockIdx.y = class * towers + tower; tower t: wf + t S n k, class c / tower t: wc + (c towers + t) n k
     const int c = blockIdx.y / towers, t = blockIdx.y - c * towers;
     if (present[c] <= 0) return;
@@ -46,7 +57,16 @@ static __global__ __launch_bounds__(256) void dc_fold(int S, int n, int k, int t
     const int o = i / k, kk = i - o * k;
     const float* w = wf + (int64_t)t * S * n * k;
     float v = 0.f;
-    for (int s = 0; s < S; ++s) v += scale[c * S + s] * w[(int64_t)(s * n + o) * k + kk];
+    for (int s = 0; s < S; ++s) {
+        float ws;
+        if (has_layout) {
+            const int64_t off = dc_ref_offset(lay, s, o, kk);
+            ws = off >= 0 ? wf[off] : 0.f;
+        } else {
+            ws = w[(int64_t)(s * n + o) * k + kk];
+        }
+        v += scale[c * S + s] * ws;
+    }
     const int64_t base = ((int64_t)c * towers + t) * n * k;
     wc[base + i] = v;
     wct[base + (int64_t)kk * n + o] = v;
@@ -204,7 +224,7 @@ struct DcWgradParams {
     const float* G; int64_t ldg;
     const float* X; int64_t ldx;
     float* part;                     // [k_slices][slots + kClasses][NTN * 16][kpad]
-    int32_t* run_class;              // [slots + kClasses], preset to -1
+    uint32_t* run_mask;              // [slots] classes flushed by each workgroup (bit c: partial block x + c is valid)
     int k_slice, kpad, slots;        // k_slice = columns per blockIdx.y = 128 KT
     int64_t units_per_block;
 };
@@ -251,7 +271,11 @@ __device__ __forceinline__ void dc_wgrad_run(const DcWgradParams& p, float* lds_
     const int ids = p.slots + kClasses;
     const int64_t s_begin = (int64_t)blockIdx.x * p.units_per_block * (kUnit / 16);
     const int64_t s_end = min(p.n_units, ((int64_t)blockIdx.x + 1) * p.units_per_block) * (kUnit / 16);
-    if (s_begin >= s_end) return;
+    if (s_begin >= s_end) {
+        if (tid == 0 && blockIdx.y == 0) p.run_mask[blockIdx.x] = 0u;
+        return;
+    }
+    uint32_t flushed = 0u;
     Raw4 sreg[kMaxItems];
     fetch(sreg, s_begin);
     commit(sreg, 0);
@@ -307,8 +331,9 @@ __device__ __forceinline__ void dc_wgrad_run(const DcWgradParams& p, float* lds_
                     for (int r = 0; r < 4; ++r) out[(16 * a + 4 * g + r) * p.kpad + col] = acc[a][b][r];
             }
         }
-        if (tid == 0 && blockIdx.y == 0) p.run_class[blockIdx.x + cls] = cls;
+        flushed |= 1u << cls;
     }
+    if (tid == 0 && blockIdx.y == 0) p.run_mask[blockIdx.x] = flushed;
 }
 
 template <int NTN, int KT>
@@ -323,28 +348,33 @@ __global__ __launch_bounds__(kWave * kWgWaves) void dc_wgrad(const DcWgradParams
     dc_wgrad_run<NTN, KT, KT>(p, lds_dc);
 }
 
-// g_wf[(s n + o)][kk] = sum over the runs, in run order, of scale[class][s] * part[run][o][kk]; a block covers 64 consecutive elements,
-// its sixteen waves take every sixteenth run, LDS joins them in wave order (bitwise reproducible)
+// g_wf[(s n + o)][kk] = sum over the runs, in (workgroup, class) order, of scale[class][s] * part[run][o][kk]; a block covers 64
+// consecutive elements, its sixteen waves take every sixteenth workgroup, LDS joins them in wave order (bitwise reproducible).
+// has_layout: the sums go straight into the reference's weight-gradient layout (DgnDcLayout) instead.
 template <int S>
-static __global__ __launch_bounds__(64 * 16) void dc_wgrad_finalize(int n, int k, int k_slice, int kpad, int npad, int ids, const int32_t* __restrict__ run_class,
+static __global__ __launch_bounds__(64 * 16) void dc_wgrad_finalize(int n, int k, int k_slice, int kpad, int npad, int slots, const uint32_t* __restrict__ run_mask,
                                                                     const float* __restrict__ scale, const float* __restrict__ part,
-                                                                    float* __restrict__ g_wf, int64_t ldw) {
+                                                                    float* __restrict__ g_wf, int64_t ldw, const DgnDcLayout lay, int has_layout) {
     __shared__ float red[S][16][64];
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     const bool live = e < (int64_t)n * k;
     const int o = live ? (int)(e / k) : 0, kk = live ? (int)(e - (int64_t)o * k) : 0;
     const int sl = kk / k_slice, cc = kk - sl * k_slice;
+    const int ids = slots + kClasses;
     const float* src = part + (int64_t)sl * ids * npad * kpad + (int64_t)o * kpad + cc;
     float out[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) out[s] = 0.f;
-    for (int id = sg; id < ids; id += 16) {
-        const int c = run_class[id];
-        if (c < 0) continue;
-        const float v = live ? src[(int64_t)id * npad * kpad] : 0.f;
+    for (int x = sg; x < slots; x += 16) {
+        uint32_t m = run_mask[x];
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            const float v = live ? src[(int64_t)(x + c) * npad * kpad] : 0.f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) out[s] += scale[c * S + s] * v;
+            for (int s = 0; s < S; ++s) out[s] += scale[c * S + s] * v;
+        }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) red[s][sg][lane] = out[s];
@@ -353,13 +383,13 @@ static __global__ __launch_bounds__(64 * 16) void dc_wgrad_finalize(int n, int k
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += red[sg][w][lane];
-        g_wf[(int64_t)(sg * n + o) * ldw + kk] = v;
+        if (has_layout) {
+            const int64_t off = dc_ref_offset(lay, sg, o, kk);
+            if (off >= 0) g_wf[off] = v;
+        } else {
+            g_wf[(int64_t)(sg * n + o) * ldw + kk] = v;
+        }
     }
-}
-
-static __global__ __launch_bounds__(256) void fill_i32(int n, int v, int32_t* __restrict__ p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }
 
 }  // namespace dc

@@ -224,8 +224,11 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     const int hoff = d.cx ? d.F0 : 0;
     const int64_t ld_post = hoff + (int64_t)d.S * d.A * d.F0;
     float* wft = L->wf + (size_t)d.n * d.K;
-    hipLaunchKernelGGL(fold_post, dim3(nblk((int64_t)d.n * d.K)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : -1, ld_post,
-                       L->w_post, L->wf, wft);
+    DgnDcLayout lay{};                              // (degree-class route: the kernels read / write the reference layout themselves)
+    lay.n_agg = d.A; lay.f_pad = d.Fp; lay.f_in = d.F0; lay.h_off = hoff; lay.id_slot = d.cx ? L->id_slot : -1; lay.ld = ld_post;
+    if (!d.dc)
+        hipLaunchKernelGGL(fold_post, dim3(nblk((int64_t)d.n * d.K)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : -1, ld_post,
+                           L->w_post, L->wf, wft);
     if (d.cx) {
         float* wsdt = L->wsd + (size_t)2 * d.Fp * d.Fp;
         float* bsd = wsdt + (size_t)2 * d.Fp * d.Fp;
@@ -244,7 +247,7 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
         // one product per in-degree class: y = snorm (b + agg W_class^T), W_class = sum_s scale_s(class) W_f[s]
         float* wc = L->wf + (size_t)2 * d.n * d.K;
         float* wct = wc + (size_t)DGN_DC_CLASSES * d.fo * d.K;
-        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, 1, L->wf, wc, wct, stream));
+        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, 1, L->w_post, &lay, wc, wct, stream));
         DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, 1, L->agg, d.K, 0, wc, d.K, (int64_t)d.fo * d.K, 0, L->b_post, L->snorm, L->y, d.fo, 0, 0, stream));
     } else {
         DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
@@ -298,8 +301,10 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
                                            dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
         static const int dc_stream = getenv("DGN_DC_STREAM") ? atoi(getenv("DGN_DC_STREAM")) : 0;      // (experiment: nontemporal d agg rows)
         DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, 1, g_z, d.fo, 0, wct, d.fo, (int64_t)d.fo * d.K, 0, nullptr, nullptr, g_agg, d.K, 0, dc_stream, stream));
-        DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, g_wf, d.K, ws + s.wg_ws, dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo),
-                             stream));
+        DgnDcLayout lay{};
+        lay.n_agg = d.A; lay.f_pad = d.Fp; lay.f_in = d.F0; lay.h_off = hoff; lay.id_slot = d.cx ? L->id_slot : -1; lay.ld = ld_post;
+        DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, G->g_w_post, 0, &lay, ws + s.wg_ws,
+                             dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo), stream));
     } else {
         DGN_TRY(dgn_scale_combine_backward(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
                                            dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
@@ -307,8 +312,9 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         DGN_TRY(lin_fwd(d.N, d.n, d.K, g_z, wft, nullptr, g_agg, stream));
         DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));
     }
-    hipLaunchKernelGGL(unfold_post, dim3(nblk((int64_t)d.fo * ld_post)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : 0, ld_post,
-                       g_wf, G->g_w_post);
+    if (!d.dc)
+        hipLaunchKernelGGL(unfold_post, dim3(nblk((int64_t)d.fo * ld_post)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : 0, ld_post,
+                           g_wf, G->g_w_post);
     DGN_HIP_CHECK(hipGetLastError());
     // the sweep
     const DgnMsg msg = sweep_msg(L, d, hp);

@@ -177,7 +177,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     if (use_dc(L, d)) {
         // ... as ONE f_out-column product per in-degree class and tower (dgn_dc_kernels.hpp): W_class = sum_s scale_s(class) W_s
         const int64_t wsz = (int64_t)d.T * d.fo * d.K;
-        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, d.T, L->w_post, L->wc, L->wc + DGN_DC_CLASSES * wsz, stream));
+        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, d.T, L->w_post, nullptr, L->wc, L->wc + DGN_DC_CLASSES * wsz, stream));
         DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, d.T, L->aggx, d.K, d.N * d.K, L->wc, d.K, wsz, (int64_t)d.fo * d.K, L->b_post, L->snorm, L->y0, d.Fo, d.fo, 0,
                             stream));
     } else

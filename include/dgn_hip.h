@@ -543,11 +543,19 @@ typedef struct DgnDegreeClasses {
     const int32_t* present;       /* [DGN_DC_CLASSES] rows per class                                                     */
     const float* scale;           /* [DGN_DC_CLASSES, S] the layer's scaler factors per class (set per layer)            */
 } DgnDegreeClasses;
+/* Optional: the posttrans weight (and its gradient) in the reference's OWN layout, nn.Linear [f_out, (h_off +) S n_agg f_in], instead of
+ * the scaler-major folded matrix wf [S f_out, k]: column kk = a f_pad + f of the product reads W[o][h_off + (s n_agg + a) f_in + f]; the
+ * complex layer's h block (a == n_agg; h_off = f_in) reads W[o][f] through the identity scaler's slot; padded columns f >= f_in are 0.   */
+typedef struct DgnDcLayout {
+    int32_t n_agg, f_pad, f_in, h_off, id_slot;
+    int64_t ld;
+} DgnDcLayout;
 int dgn_dc_supported(int32_t k, int32_t n);
 int dgn_dc_wgrad_supported(int32_t k, int32_t n);
 /* wc[c][t][o][kk] = sum_s scale[c][s] wf[t][s n + o][kk] and wct[c][t][kk][o] (its transpose), classes present only;
  * wf [towers][S n, k], wc / wct [DGN_DC_CLASSES][towers][n k]                                                                       */
-int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, float* wc, float* wct, void* stream);
+int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int32_t k, int32_t towers, const float* wf, const DgnDcLayout* layout /* NULL: wf as above */,
+                float* wc, float* wct, void* stream);
 /* c[node] = row_scale[node] * (bias + a[node] w_class(node)^T) for every tower t (element offsets t * a_tower / w_tower / c_tower, bias
  * t * n); w: class c at w + c * class_stride, [n, k] rows of stride ldw                                                             */
 int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w,
@@ -556,7 +564,8 @@ int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers,
 /* g_wf[s n + o][kk] = sum_nodes scale[class(node)][s] g[node][o] x[node][kk]  (per-class products, fixed-order finalize)             */
 size_t dgn_dc_wgrad_workspace_bytes(int64_t n_units, int32_t k, int32_t n);
 int dgn_dc_wgrad(const DgnDegreeClasses* d, int32_t S, int32_t k, int32_t n, const float* g, int64_t ldg, const float* x, int64_t ldx,
-                 float* g_wf, int64_t ldw, void* ws, size_t ws_bytes, void* stream);
+                 float* g_wf, int64_t ldw, const DgnDcLayout* layout /* NULL, or: g_wf is the reference-layout gradient [n, layout->ld] */, void* ws,
+                 size_t ws_bytes, void* stream);
 
 typedef struct DgnDenseLayer {
     const DgnGraph* graph;

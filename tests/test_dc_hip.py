@@ -114,7 +114,7 @@ def test_dc_wgrad_matches_fp64_and_is_reproducible(N, k, n, max_deg, S):
     for _ in range(2):
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         out = torch.full((S * n, k), float("nan"), device="cuda")
-        _lib.check(lib.dgn_dc_wgrad(C.byref(s), S, k, n, gy.data_ptr(), n, x.data_ptr(), k, out.data_ptr(), k, ws.data_ptr(), nbytes,
+        _lib.check(lib.dgn_dc_wgrad(C.byref(s), S, k, n, gy.data_ptr(), n, x.data_ptr(), k, out.data_ptr(), k, None, ws.data_ptr(), nbytes,
                                     _lib.stream_ptr(x.device)), "dgn_dc_wgrad")
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
@@ -134,7 +134,7 @@ def test_dc_fold_matches_fp64():
     dc, s = _classes(graph, scale)
     wc = torch.zeros(32, n, k, device="cuda")
     wct = torch.zeros(32, k, n, device="cuda")
-    _lib.check(lib.dgn_dc_fold(C.byref(s), S, n, k, 1, wf.data_ptr(), wc.data_ptr(), wct.data_ptr(), _lib.stream_ptr(wf.device)), "dgn_dc_fold")
+    _lib.check(lib.dgn_dc_fold(C.byref(s), S, n, k, 1, wf.data_ptr(), None, wc.data_ptr(), wct.data_ptr(), _lib.stream_ptr(wf.device)), "dgn_dc_fold")
     ref = torch.einsum("cs,sok->cok", scale.double(), wf.double().view(S, n, k))
     present = dc["present"].bool()
     _close(wc[present], ref[present], 1e-6)
