@@ -440,6 +440,9 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
                "agg_bwd_rows": dict(ms=ms_b, bytes=bb, GBps=bb / ms_b / 1e6, frac=bb / (ms_b * 1e-3) / HBM_PEAK,
                                     timing=st_b),
                "ew_rows": dict(ms=ms_w, bytes=bw, GBps=bw / ms_w / 1e6, frac=bw / (ms_w * 1e-3) / HBM_PEAK, timing=st_w)}
+    # simple / complex layers with several scalers: the three posttrans products on the degree-class kernels (MFMA-bound: exact fp32
+    # v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense peak), priced on the USEFUL flops 2 N K f_out each
+    kernels.update(dc_posttrans_legs(graph, wl, N, F_, plan.out_width(Fk), dev, gen))
     dom = "agg_bwd_rows" if ms_b >= ms_f else "agg_fwd_rows"
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
     # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
@@ -462,6 +465,46 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
                               frac_with_survey_A=dict(A=A_survey, frac=frac_survey,
                                                       note="same launch priced without the h_in pass-through block"))
     return result, batch
+
+
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, dense fp32 MFMA (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def dc_posttrans_legs(graph, wl, N, fo, K, dev, gen):
+    """dgn_dc_gemm (forward, input gradient) and dgn_dc_wgrad on the layer's shapes, through the C ABI: {} where the layer does not take
+    that route (towers, a single scaler, an in-degree >= 32)."""
+    import ctypes as C
+    from dgn_amd import _lib, ops as _ops
+    S = len(wl["scalers"].split())
+    dc = graph.degree_classes() if (wl["type_net"] in ("simple", "complex") and S > 1 and _ops.DC_POSTTRANS) else None
+    lib = _lib.load()
+    if dc is None or not (lib.dgn_dc_supported(K, fo) and lib.dgn_dc_supported(fo, K) and lib.dgn_dc_wgrad_supported(K, fo)):
+        return {}
+    scale = torch.rand(32, S, device=dev, generator=gen) + 0.5
+    d = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
+                              present=dc["present"].data_ptr(), scale=scale.data_ptr())
+    agg, g = torch.randn(N, K, device=dev, generator=gen), torch.randn(N, fo, device=dev, generator=gen)
+    wc = torch.randn(32, fo, K, device=dev, generator=gen) / K ** 0.5
+    wct = wc.transpose(1, 2).contiguous()
+    y, g_agg, g_wf = torch.empty(N, fo, device=dev), torch.empty(N, K, device=dev), torch.empty(S * fo, K, device=dev)
+    nbytes = lib.dgn_dc_wgrad_workspace_bytes(dc["n_units"], K, fo)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    st = _lib.stream_ptr(dev)
+    calls = {
+        "dc_gemm_forward": lambda: _lib.check(lib.dgn_dc_gemm(C.byref(d), K, fo, 1, agg.data_ptr(), K, 0, wc.data_ptr(), K, fo * K, 0, None, None,
+                                                              y.data_ptr(), fo, 0, 0, st), "dgn_dc_gemm"),
+        "dc_gemm_input_grad": lambda: _lib.check(lib.dgn_dc_gemm(C.byref(d), fo, K, 1, g.data_ptr(), fo, 0, wct.data_ptr(), fo, fo * K, 0, None, None,
+                                                                 g_agg.data_ptr(), K, 0, 0, st), "dgn_dc_gemm"),
+        "dc_wgrad": lambda: _lib.check(lib.dgn_dc_wgrad(C.byref(d), S, K, fo, g.data_ptr(), fo, agg.data_ptr(), K, g_wf.data_ptr(), K, None,
+                                                        ws.data_ptr(), nbytes, st), "dgn_dc_wgrad"),
+    }
+    flops = 2.0 * N * K * fo
+    out = {}
+    for name, fn in calls.items():
+        stt = event_stats(fn, dev)
+        out[name] = dict(ms=stt["median"], flops=flops, TFLOPs=flops / stt["median"] / 1e9, bound="mfma", peak_TFLOPs=MFMA_F32_PEAK / 1e12,
+                         frac=flops / (stt["median"] * 1e-3) / MFMA_F32_PEAK, bytes=4 * N * (K + fo), timing=stt)
+    return out
 
 
 def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
@@ -593,7 +636,7 @@ def compact(result):
     if r:
         out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                                                  "frac_of_triad", "model", "frac_with_survey_A") if k in r}
-        out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac", "timing")}
+        out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac", "timing", "TFLOPs", "bound", "flops")}
                                       for k, v in (r.get("kernels") or {}).items()}
     return out
 
