@@ -476,7 +476,7 @@ def dc_posttrans_legs(graph, wl, N, fo, K, dev, gen):
     import ctypes as C
     from dgn_amd import _lib, ops as _ops
     S = len(wl["scalers"].split())
-    dc = graph.degree_classes() if (wl["type_net"] in ("simple", "complex") and S > 1 and _ops.DC_POSTTRANS) else None
+    dc = graph.degree_classes() if (wl["type_net"] in ("simple", "complex") and S > 1 and _ops.DC_POSTTRANS and N >= _ops.DC_MIN_NODES) else None
     lib = _lib.load()
     if dc is None or not (lib.dgn_dc_supported(K, fo) and lib.dgn_dc_supported(fo, K) and lib.dgn_dc_wgrad_supported(K, fo)):
         return {}

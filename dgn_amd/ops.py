@@ -1123,11 +1123,14 @@ def dense_layer_supported(type_net: int, f_in: int, f_out: int, n_scalers: int, 
 # (dgn_dc_kernels.hpp) instead of the folded S * f_out-column product + scale-combine: a third of the MFMA flops in the forward, the
 # input gradient and the weight gradient.  Graphs with an in-degree >= 32 (and padded graphs) keep the folded route.
 DC_POSTTRANS = os.environ.get("DGN_DC_POSTTRANS", "1") != "0"
+# ... from this many nodes on: building the virtual row space costs a sort, a dozen small launches and one read-back per GRAPH, which a
+# training loop pays per batch -- at the reference's batch 128 (3 000 nodes) the products it speeds up are ~10 us each
+DC_MIN_NODES = int(os.environ.get("DGN_DC_MIN_NODES", "16384"))
 
 
 def _degree_classes(graph, scale, fo, K):
     """(graph.degree_classes(), class scaler table [32, S]) or None."""
-    if not DC_POSTTRANS or scale is None or not scale.is_cuda:
+    if not DC_POSTTRANS or scale is None or not scale.is_cuda or graph.num_nodes < DC_MIN_NODES:
         return None
     lib = _lib.load()
     if not (lib.dgn_dc_supported(K, fo) and lib.dgn_dc_supported(fo, K) and lib.dgn_dc_wgrad_supported(K, fo)):

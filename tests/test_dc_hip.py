@@ -162,8 +162,9 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
         g_out = torch.randn(N, F, generator=gen).to(dev)
         res = {}
         for dc_on in (True, False):
-            ops.DC_POSTTRANS, towers_default = dc_on, ops.DC_TOWERS
+            ops.DC_POSTTRANS, towers_default, min_default = dc_on, ops.DC_TOWERS, ops.DC_MIN_NODES
             ops.DC_TOWERS = True                                           # (the towers layer's route is off by default: slower)
+            ops.DC_MIN_NODES = 0                                           # (and small batches keep the folded route by default)
             try:
                 torch.manual_seed(seed + 2)
                 layer = dgn_amd.DGNLayer(F, F, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.tensor(1.2)}, type_net, True,
@@ -174,7 +175,7 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
                 y.backward(g_out)
                 res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [bf for n_, bf in layer.named_buffers() if "running" in n_]
             finally:
-                ops.DC_POSTTRANS, ops.DC_TOWERS = True, towers_default
+                ops.DC_POSTTRANS, ops.DC_TOWERS, ops.DC_MIN_NODES = True, towers_default, min_default
         _close(res[True][0], res[False][0].double(), 2e-5)               # the forward: always
         hd = h0.to(dev)
         if type_net != "towers" and int((((res[True][0] - hd) == 0) != ((res[False][0] - hd) == 0)).sum()):
