@@ -151,3 +151,23 @@ def test_towers_layer_odd_tower_width_vs_oracle(monkeypatch, hidden, towers):
     np.testing.assert_allclose(y.detach().cpu().numpy(), y32.detach().numpy(), rtol=2e-5, atol=2e-5)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
         _check_grad(a, r32, r64, k)
+
+
+def test_c4_at_the_default_threshold_takes_the_degree_class_route_vs_oracle(monkeypatch):
+    """The node count from which the simple / complex layers run posttrans per in-degree class is 16 384 by default (the other tests
+    lower it, tests/conftest.py): here the default, on a batch above it -- the route must be taken and meet the oracle."""
+    import dgn_amd
+    from dgn_amd import synth
+    monkeypatch.setattr(dgn_amd.ops, "DC_MIN_NODES", 16384)
+    b = synth.molecule_batch(720, seed=43, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)
+    assert int(b["num_nodes"]) >= 16384
+    taken = []
+    real = dgn_amd.ops._degree_classes
+    monkeypatch.setattr(dgn_amd.ops, "_degree_classes", lambda *a: taken.append(real(*a)) or taken[-1])
+    _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, b, None)
+    assert taken and taken[0] is not None
+    small = synth.molecule_batch(450, seed=43, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)      # ~11.5 k nodes
+    assert 8192 <= int(small["num_nodes"]) < 16384
+    taken.clear()
+    _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, small, None)
+    assert taken and taken[0] is None                      # below the threshold: the folded route
