@@ -22,8 +22,8 @@ def pmc_avgs(path):
         n = r.get("Kernel_Name") or r.get("Kernel Name")
         if "dgn::" not in n:
             continue
-        m = re.search(r"dgn::(?:lin::)?(?:\(anonymous namespace\)::)?(\w+(?:<[\w, ]+>)?)", n)
-        key = m.group(1) if m.group(1).startswith("ts_") else m.group(1).split("<")[0]
+        m = re.search(r"dgn::(?:lin::|dc::|gemm::)?(?:\(anonymous namespace\)::)?(\w+(?:<[\w, ]+>)?)", n)
+        key = m.group(1) if m.group(1).startswith(("ts_", "dc_")) else m.group(1).split("<")[0]
         acc[key][0] += 1
         acc[key][1] += float(r["Counter_Value"])
     return {k: v[1] / v[0] for k, v in acc.items()}
