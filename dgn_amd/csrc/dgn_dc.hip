@@ -139,23 +139,6 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
     const dim3 grid = p.col_tiles > 1 ? dim3((unsigned)((ranges + kXcds - 1) / kXcds * kXcds * best_tiles), 1, (unsigned)towers)
                                       : dim3((unsigned)ranges, (unsigned)best_tiles, (unsigned)towers);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const char* rt3_env = getenv("DGN_DC_RT3");                 // (experiment: 192-row tiles, three workgroups per CU)
-    if (rt3_env && atoi(rt3_env) != 0 && best_nq == 5) {
-        const int64_t slots3 = std::max<int64_t>(1, (int64_t)n_cus() * 3 / (best_tiles * towers));
-        p.units_per_block = std::max<int64_t>(1, (d->n_units + slots3 - 1) / slots3);
-        const int64_t r3 = (d->n_units + p.units_per_block - 1) / p.units_per_block;
-        const dim3 g3 = p.col_tiles > 1 ? dim3((unsigned)((r3 + kXcds - 1) / kXcds * kXcds * best_tiles), 1, (unsigned)towers)
-                                        : dim3((unsigned)r3, (unsigned)best_tiles, (unsigned)towers);
-        hipLaunchKernelGGL((dc_gemm<5, 3>), g3, dim3(256), 0, st, p);
-        DGN_HIP_CHECK(hipGetLastError());
-        return DGN_OK;
-    }
-    const char* deep_env = getenv("DGN_DC_DEEP");               // (experiment: operand chunks two ahead)
-    if (deep_env && atoi(deep_env) != 0 && best_nq == 5 && k > 32) {
-        hipLaunchKernelGGL((dc_gemm<5, 4, true>), grid, dim3(256), 0, st, p);
-        DGN_HIP_CHECK(hipGetLastError());
-        return DGN_OK;
-    }
     switch (best_nq) {
         case 1: hipLaunchKernelGGL(dc_gemm<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(dc_gemm<2>, grid, dim3(256), 0, st, p); break;

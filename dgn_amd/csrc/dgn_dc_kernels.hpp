@@ -92,24 +92,22 @@ struct DcGemmParams {
 };
 
 // One tile of 64 RT virtual rows (units u0 .. u0 + RT, all of one class) x 16 NQ columns.  Wave w owns rows 16 RT w .. of the tile.
-template <int NQ, int RT, int MAXRT = 4, bool DEEP = false>
+template <int NQ, int RT>
 __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float* Bs, int64_t u0, const float* __restrict__ W, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int KB = (p.k + 15) >> 4;
     const int lr = tid >> 2, c4 = (tid & 3) * 4;
     constexpr int NBJ = (NQ * 16 + 63) / 64;
-    constexpr int kABuf = 64 * MAXRT * kTKS, kBBuf = NQ * 16 * kTKS;
+    constexpr int kABuf = kTileM * kTKS, kBBuf = NQ * 16 * kTKS;
     int node[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) node[j] = p.vperm[(u0 + j) * kUnit + lr];
-    // operand chunks travel TWO chunks ahead (DEEP: two register sets, the LDS ring stays at two buffers): with one chunk of lead the
-    // loads had a single MFMA block (2.5-5 k cycles) to arrive and the waves sat in s_waitcnt for a quarter of their cycles
-    Raw4 ra0[RT], rb0[NBJ], ra1[DEEP ? RT : 1], rb1[DEEP ? NBJ : 1];
+    Raw4 ra0[RT], rb0[NBJ];
     auto fetch = [&](Raw4 (&ra)[RT], Raw4 (&rb)[NBJ], int kc) {
         const int k0 = 16 * kc + c4;
-#pragma unroll
         // (padding rows and the weight rows past n are loaded from a clamped address and NOT zeroed: each row of A and of W only feeds
         //  its own output row / column, which is never stored -- so `sh` stays 0 in every lane except in a ragged last k chunk)
+#pragma unroll
         for (int j = 0; j < RT; ++j) ra[j] = load4_raw(p.A + (int64_t)max(node[j], 0) * p.lda, k0, p.k);
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) {
@@ -152,30 +150,12 @@ __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float*
     };
     fetch(ra0, rb0, 0);
     commit(ra0, rb0, 0);
-    if constexpr (DEEP) {
-        if (KB > 1) fetch(ra1, rb1, 1);
+    __syncthreads();
+    for (int kc = 0; kc < KB; ++kc) {
+        if (kc + 1 < KB) fetch(ra0, rb0, kc + 1);                      // next chunk in flight during the MFMAs
+        mma(kc & 1);
+        if (kc + 1 < KB) commit(ra0, rb0, (kc + 1) & 1);
         __syncthreads();
-        for (int kc = 0; kc < KB; kc += 2) {
-            // chunk kc from buffer 0; set 1 holds chunk kc + 1; chunk kc + 2 starts travelling into set 0
-            if (kc + 2 < KB) fetch(ra0, rb0, kc + 2);
-            mma(0);
-            if (kc + 1 < KB) commit(ra1, rb1, 1);
-            __syncthreads();
-            if (kc + 1 >= KB) break;
-            // chunk kc + 1 from buffer 1; set 0 holds chunk kc + 2; chunk kc + 3 into set 1
-            if (kc + 3 < KB) fetch(ra1, rb1, kc + 3);
-            mma(1);
-            if (kc + 2 < KB) commit(ra0, rb0, 0);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-        for (int kc = 0; kc < KB; ++kc) {
-            if (kc + 1 < KB) fetch(ra0, rb0, kc + 1);                  // next chunk in flight during the MFMAs
-            mma(kc & 1);
-            if (kc + 1 < KB) commit(ra0, rb0, (kc + 1) & 1);
-            __syncthreads();
-        }
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -202,10 +182,9 @@ __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float*
 
 // A workgroup owns the units [blockIdx.x * units_per_block, + units_per_block) and walks them in tiles of up to four units of one class,
 // the range cut into the fewest tiles of nearly equal height (dgn_gemm_kernels.hpp: tile_gemm).
-// MAXRT = 4: tiles of up to 256 rows, two workgroups per CU (256 registers); MAXRT = 3: up to 192 rows, three per CU (168 registers).
-template <int NQ, int MAXRT = 4, bool DEEP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXRT == 3 ? 3 : 2, MAXRT == 3 ? 3 : 2))) void dc_gemm(const DcGemmParams p_in) {
-    __shared__ float As[2 * 64 * MAXRT * kTKS];
+template <int NQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dc_gemm(const DcGemmParams p_in) {
+    __shared__ float As[2 * kTileM * kTKS];
     __shared__ float Bs[2 * NQ * 16 * kTKS];
     DcGemmParams p = p_in;
     // several column tiles: a 1-D grid dealt so that the column tiles of ONE row range are consecutive workgroups of ONE XCD (the
@@ -224,16 +203,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXRT == 3 
     while (u < end) {
         const int c = uniform_i(p.unit_class[u]);
         if (c < 0) { ++u; continue; }
-        const int left = (int)min((int64_t)64, end - u), tiles = (left + MAXRT - 1) / MAXRT;
-        const int h = min(MAXRT, (left + tiles - 1) / tiles);
+        const int left = (int)min((int64_t)64, end - u), tiles = (left + 3) >> 2;
+        const int h = min(4, (left + tiles - 1) / tiles);
         int run = 1;
         while (run < h && uniform_i(p.unit_class[u + run]) == c) ++run;
         const float* W = p.W + (int64_t)c * p.class_stride;
         switch (run) {
-            case 4: if constexpr (MAXRT >= 4) dc_tile<NQ, 4, MAXRT, DEEP>(p, As, Bs, u, W, n0); break;
-            case 3: dc_tile<NQ, 3, MAXRT, DEEP>(p, As, Bs, u, W, n0); break;
-            case 2: dc_tile<NQ, 2, MAXRT, DEEP>(p, As, Bs, u, W, n0); break;
-            default: dc_tile<NQ, 1, MAXRT, DEEP>(p, As, Bs, u, W, n0); break;
+            case 4: dc_tile<NQ, 4>(p, As, Bs, u, W, n0); break;
+            case 3: dc_tile<NQ, 3>(p, As, Bs, u, W, n0); break;
+            case 2: dc_tile<NQ, 2>(p, As, Bs, u, W, n0); break;
+            default: dc_tile<NQ, 1>(p, As, Bs, u, W, n0); break;
         }
         u += run;
     }
