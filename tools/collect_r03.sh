@@ -19,8 +19,11 @@ sq="gpurun_out/pmc_sq_c2"; mkdir -p "$sq"
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$sq/a" -o c2 -- python bench.py --no-extras --no-cpu-baseline > "$sq/a.log" 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d "$sq/b" -o c2 -- python bench.py --no-extras --no-cpu-baseline > "$sq/b.log" 2>&1
 { echo "# rocprofv3 --pmc (two passes), fractions of SQ_WAVE_CYCLES per kernel, c2 (bench.py --no-extras): tools/pmc_sq_summary.py"; python tools/pmc_sq_summary.py "$sq/a"; echo; python tools/pmc_sq_summary.py "$sq/b"; } > gpurun_out/r03_c2_sq_counters.txt 2>&1
-tools/microbench/mfma_peak > gpurun_out/r03_mfma_peak.txt 2>&1
-tools/microbench/rowwrite > gpurun_out/r03_rowwrite.txt 2>&1
+# (the microbenchmark binaries are git-ignored: built here when missing; a table is only written when its binary ran)
+for mb in mfma_peak rowwrite; do
+  [ -x tools/microbench/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/$mb.hip -o tools/microbench/$mb > /dev/null 2>&1
+  if [ -x tools/microbench/$mb ] && tools/microbench/$mb > gpurun_out/r03_$mb.tmp 2>&1; then mv gpurun_out/r03_$mb.tmp gpurun_out/r03_$mb.txt; else rm -f gpurun_out/r03_$mb.tmp; fi
+done
 python tools/exp_gemm.py 2>&1 | grep -v "^W\|amdgpu.ids" > gpurun_out/r03_gemm.txt
 python tools/exp_linear.py 2>&1 | grep -v "^W\|amdgpu.ids" > gpurun_out/r03_linear.txt
 # keep the merge-back small: the per-launch traces are not needed
