@@ -171,3 +171,22 @@ def test_c4_at_the_default_threshold_takes_the_degree_class_route_vs_oracle(monk
     taken.clear()
     _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, small, None)
     assert taken and taken[0] is None                      # below the threshold: the folded route
+
+
+@pytest.mark.parametrize("type_net", ["simple", "complex"])
+def test_isolated_nodes_through_the_degree_class_route_vs_oracle(monkeypatch, type_net):
+    """Zero in-degree nodes are a class of their own (class 0: amplification and attenuation factors 0, the complex layer's h block
+    still contributes): a molecule batch with every in-edge of ~6 % of the nodes removed, three scalers, against the oracle."""
+    import dgn_amd
+    from dgn_amd import synth
+    b = dict(synth.molecule_batch(220, seed=47, extra_bonds=3.9, eig_dim=6))
+    N = int(b["num_nodes"])
+    cut = torch.rand(N, generator=torch.Generator().manual_seed(48)) < 0.06
+    keep = ~cut[b["dst"]]
+    b["src"], b["dst"] = b["src"][keep], b["dst"][keep]
+    assert int((torch.bincount(b["dst"], minlength=N) == 0).sum()) > 50
+    taken = []
+    real = dgn_amd.ops._degree_classes
+    monkeypatch.setattr(dgn_amd.ops, "_degree_classes", lambda *a: taken.append(real(*a)) or taken[-1])
+    _layer_vs_oracle(monkeypatch, type_net, 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", True, b, 0)
+    assert taken and taken[0] is not None and int(taken[0][0]["present"][0]) > 50
