@@ -162,11 +162,16 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
 
 extern "C" size_t dgn_gemm_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n) {
     if (n_rows <= 0 || !dgn_gemm_supported(k, n)) return 0;
-    const TwPlan t = tile_wgrad_plan(n_rows, k + 1, n);
-    size_t bytes = (size_t)t.n_blocks * t.k_blocks * t.slots * (t.nb_tiles * 32) * (t.kb_tiles * 32) * sizeof(float);
-    if (n <= 16 * kWgWaves) {
-        const WgPlan w = wgrad_plan(n_rows, k + 1, n);
-        bytes = std::max(bytes, (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float));
+    // dgn_gemm_wgrad plans with kk = k (no bias gradient) or k + 1 (bias gradient as a ones column), and neither plan is monotone in
+    // kk (k = 256, n = 192: kk = 256 needs 50 MB of partials, kk = 257 needs 31 MB): the query covers BOTH
+    size_t bytes = 0;
+    for (int kk = k; kk <= k + 1; ++kk) {
+        const TwPlan t = tile_wgrad_plan(n_rows, kk, n);
+        bytes = std::max(bytes, (size_t)t.n_blocks * t.k_blocks * t.slots * (t.nb_tiles * 32) * (t.kb_tiles * 32) * sizeof(float));
+        if (n <= 16 * kWgWaves) {
+            const WgPlan w = wgrad_plan(n_rows, kk, n);
+            bytes = std::max(bytes, (size_t)w.k_slices * w.slots * (w.nt * 16) * (w.kt * 16) * sizeof(float));
+        }
     }
     return bytes;
 }

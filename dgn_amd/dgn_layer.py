@@ -118,10 +118,15 @@ class EdgeTypeFeatures:
     LDS): no [E, F] edge term is written or read, and the table's gradient is a reduction of the per-edge gradient rows the backward
     stages anyway.  Layers that cannot use the table (other pretrans depths, tables over ops.MAX_EDGE_TABLE floats) gather it."""
 
-    def __init__(self, table: torch.Tensor, types: torch.Tensor):
+    def __init__(self, table: torch.Tensor, types: torch.Tensor, validate: bool = True):
+        """``validate`` (default): one host sync checking every type against the table, the host-side twin of the device assert
+        ``nn.Embedding`` raises in the reference; pass False inside stream captures / static padded batches (types checked by the
+        loader once), where out-of-range types are CLAMPED by ``slot_types``."""
         if table.dim() != 2 or types.dim() != 1:
             raise ValueError("EdgeTypeFeatures: table [K, edge_dim], types [E]")
         self.table, self.types = table, types
+        if validate and not (types.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.validate()
 
     def dense(self) -> torch.Tensor:
         return self.table.index_select(0, self.types.long())
@@ -130,10 +135,11 @@ class EdgeTypeFeatures:
         """The types in CSR slot order, int32, CLAMPED to the table's rows (a type outside [0, K) would index outside the sweep's LDS
         table; ``nn.Embedding`` raises a device assert there, ``validate()`` is the host-side equivalent); cached per graph."""
         ent = graph.__dict__.get("_slot_types")
-        if ent is not None and ent[0] is self.types and ent[1] == self.types._version:
+        K = int(self.table.shape[0])
+        if ent is not None and ent[0] is self.types and ent[1] == self.types._version and ent[3] == K:
             return ent[2]
-        t = graph.to_slot_order(self.types).clamp(0, self.table.shape[0] - 1).to(torch.int32).contiguous()
-        graph.__dict__["_slot_types"] = (self.types, self.types._version, t)
+        t = graph.to_slot_order(self.types).clamp(0, K - 1).to(torch.int32).contiguous()
+        graph.__dict__["_slot_types"] = (self.types, self.types._version, t, K)
         return t
 
     def validate(self) -> None:

@@ -115,6 +115,9 @@ class DGNGraph:
         captured on this object must recompute them INSIDE the captured region (they then replay with every batch)."""
         lib = _lib.load()
         pad = self._pad
+        # The previous batch's deferred statistics are looked at BEFORE anything is overwritten: an error then leaves the object in the
+        # (complete) state of the batch it is about, not half-way into the next one.  Callers run check_deferred() after the LAST batch.
+        self.check_deferred()
         E, N = src.numel(), int(num_nodes)
         if N > pad["n_cap"] or E > pad["e_cap"]:
             raise ValueError(f"batch ({N} nodes, {E} edges) exceeds the capacity ({pad['n_cap']}, {pad['e_cap']})")
@@ -138,8 +141,8 @@ class DGNGraph:
             buf[N:].zero_()
         # No host sync: (max in-degree, hub rows) of THIS batch go to pinned memory asynchronously and are looked at when the NEXT batch
         # is loaded (or by check_deferred()).  A padded graph carries no hub tables, so a batch with rows beyond hub_threshold is still
-        # computed correctly -- by the row kernels, slowly -- and the error below arrives one batch late instead of stalling every load.
-        self.check_deferred()
+        # computed correctly -- by the row kernels, slowly -- and the error arrives one batch late (top of this function) instead of
+        # stalling every load.
         if DEFERRED_STATS:
             if getattr(self, "_stats_host", None) is None:
                 self._stats_host = torch.zeros(4, dtype=torch.int32).pin_memory()

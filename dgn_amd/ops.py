@@ -47,13 +47,11 @@ class padded_rows:
 
 
 def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: int = 0):
-    # (tower_stride = N * K of the batch at hand is patched into the cached structs per call: keying the cache on it would add a
-    # permanent entry per distinct batch node count over a training run.  Calls are synchronous: the struct is read before return.)
+    # (tower_stride = N * K of the batch at hand: keying the cache on it would add a permanent entry per distinct batch node count over
+    # a training run, and patching the cached structs would alias two callers holding them at once -- so the cache keeps stride-less
+    # templates and every call gets its own ~200-byte copies.)
     key = (n_towers, float(avg_log))
     cache = plan.__dict__.setdefault("_spec_cache", {})
-    if key in cache:
-        for s in cache[key]:
-            s.tower_stride = int(tower_stride)
     if key not in cache:
         specs = []
         for l in plan.launches:
@@ -67,10 +65,15 @@ def _spec_structs(plan: AggPlan, n_towers: int, avg_log: float, tower_stride: in
                 s.scaler[i] = k
             s.avg_log, s.eps, s.n_towers = float(avg_log), EPS, n_towers
             s.agg_total, s.agg_offset = plan.n_agg, l.agg_offset
-            s.tower_stride = int(tower_stride)
+            s.tower_stride = 0
             specs.append(s)
         cache[key] = specs
-    return cache[key]
+    out = []
+    for t in cache[key]:
+        s = _lib.DgnAggSpec.from_buffer_copy(t)
+        s.tower_stride = int(tower_stride)
+        out.append(s)
+    return out
 
 
 def _check(t: Optional[torch.Tensor], name: str, rows: int, F: int):

@@ -539,7 +539,10 @@ int dgn_assemble_params(int64_t n_out, const int64_t* param_ptrs, const int32_t*
 typedef struct DgnDegreeClasses {
     int64_t n_units;              /* units (DGN_DC_UNIT rows) of the virtual row space                                  */
     const int32_t* vperm;         /* [DGN_DC_UNIT * n_units] node of a virtual row, -1: padding                          */
-    const int32_t* unit_class;    /* [n_units] class of a unit, -1: empty                                                */
+    const int32_t* unit_class;    /* [n_units] class of a unit, -1: empty.  INVARIANT (not checked on the device): every class
+                                   * lies in [0, DGN_DC_CLASSES) and the classes ASCEND along the units -- dgn_dc_wgrad keys its partial
+                                   * blocks on (workgroup + class) and a 32-bit class mask, which alias otherwise.  DGNGraph.degree_classes()
+                                   * (dgn_amd/graph.py) builds it from a stable sort by in-degree and refuses in-degrees >= DGN_DC_CLASSES. */
     const int32_t* present;       /* [DGN_DC_CLASSES] rows per class                                                     */
     const float* scale;           /* [DGN_DC_CLASSES, S] the layer's scaler factors per class (set per layer)            */
 } DgnDegreeClasses;

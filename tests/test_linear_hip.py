@@ -188,6 +188,32 @@ def test_tile_wgrad_wide_and_aligned_shapes(M, k, n):
     assert float((gb.double() - rgb).abs().max()) <= 2e-6 * float(g.abs().sum(0).max()) + 1e-6
 
 
+@pytest.mark.parametrize("M,k,n,tile", [(4096, 256, 192, "1"), (8192, 512, 192, "1"), (4096, 256, 192, "0"), (5000, 768, 320, None)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_gemm_wgrad_never_writes_past_its_workspace(M, k, n, tile, with_bias, monkeypatch):
+    """the workspace query planned with k + 1 while a bias-less call plans with k, and the plans are not monotone in
+    k (k = 256, n = 192: 50 MB vs 31 MB).  A poisoned guard region behind the queried workspace must survive both kinds of call."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    if tile is not None:
+        monkeypatch.setenv("DGN_TILE_WGRAD", tile)
+    gen = torch.Generator(device=dev).manual_seed(k + n)
+    x, g = torch.randn(M, k, device=dev, generator=gen), torch.randn(M, n, device=dev, generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.dgn_gemm_wgrad_workspace_bytes(M, k, n)
+    guard = 64 << 20
+    buf = torch.full((nb + guard,), 0xA5, dtype=torch.uint8, device=dev)
+    gw = torch.empty(n, k, device=dev)
+    gb = torch.empty(n, device=dev) if with_bias else None
+    _lib.check(lib.dgn_gemm_wgrad(M, k, n, g.data_ptr(), n, x.data_ptr(), k, gw.data_ptr(), k, gb.data_ptr() if with_bias else None,
+                                  buf.data_ptr(), nb, st), "wgrad")
+    torch.cuda.synchronize()
+    assert bool((buf[nb:] == 0xA5).all()), "dgn_gemm_wgrad wrote behind the workspace it asked for"
+    rgw = g.double().T @ x.double()
+    assert float((gw.double() - rgw).abs().max()) <= 2e-6 * float(rgw.abs().max()) * max(1.0, (M / 4096) ** 0.5) + 1e-6
+
+
 def test_wide_linear_autograd_matches_library(monkeypatch):
     from dgn_amd import ops
     dev = torch.device("cuda")
