@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -23,10 +23,10 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
-           "dgn_bias_act_forward", "dgn_bias_act_backward",
+           "dgn_bias_act_forward", "dgn_bias_act_backward", "dgn_dropout_mask_bytes", "dgn_dropout_forward", "dgn_dropout_backward",
            "dgn_layer_fused_supported", "dgn_layer_fused_forward", "dgn_layer_fused_backward_supported", "dgn_layer_fused_backward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
-           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc",
+           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_cuts",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
@@ -43,7 +43,7 @@ class DgnGraph(C.Structure):
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
                 ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
-                ("n_src", C.c_int64), ("row_base", C.c_int64)]
+                ("n_src", C.c_int64), ("row_base", C.c_int64), ("blk_cut", C.c_void_p), ("blk_gap", C.c_int32)]
 
 
 class DgnChannel(C.Structure):
@@ -206,6 +206,12 @@ def load() -> C.CDLL:
         lib.dgn_bias_act_forward.restype = C.c_int
         lib.dgn_bias_act_forward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
+        lib.dgn_dropout_mask_bytes.restype = C.c_size_t
+        lib.dgn_dropout_mask_bytes.argtypes = [C.c_int64]
+        lib.dgn_dropout_forward.restype = C.c_int
+        lib.dgn_dropout_forward.argtypes = [C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dgn_dropout_backward.restype = C.c_int
+        lib.dgn_dropout_backward.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         lib.dgn_bias_act_backward.restype = C.c_int
         lib.dgn_bias_act_backward.argtypes = [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -291,6 +297,8 @@ def load() -> C.CDLL:
         lib.dgn_graph_build_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
         lib.dgn_graph_build.restype = C.c_int
         lib.dgn_graph_build.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.dgn_graph_build_cuts.restype = C.c_int
+        lib.dgn_graph_build_cuts.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_graph_build_csc.restype = C.c_int
         lib.dgn_graph_build_csc.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_assemble_params.restype = C.c_int

@@ -1,0 +1,6 @@
+// Instantiations of the block backward (dgn_agg_block.hpp) for VEC = 4 floats per lane, hot lists only.
+#include "dgn_agg_block.hpp"
+
+namespace dgn {
+int launch_agg_block_v4(const AggParams& p, int gap, hipStream_t stream) { return launch_block_vec<4>(p, gap, stream); }
+}  // namespace dgn

@@ -116,6 +116,16 @@ struct AggParams {
     const int32_t* csc_pos;
     int32_t n_slots;
     int32_t n_coef;
+    // Block backward (agg_bwd_block): blk_cut[i] = the last CLOSED cut <= i, i in [0, N] -- a cut c is closed when no edge joins a node
+    // below c to a node at or above it (graph boundaries of a batch); workgroup b owns rows [blk_cut[b * blk_bin],
+    // blk_cut[min((b + 1) * blk_bin, N)]): every source of every one of its rows lies in that range, so d x_src of the range is
+    // accumulated in LDS (ds_add_f32, any order) and written once -- no [E, F] staging buffer, no csc positions, no seg_sum_rows.
+    const int32_t* blk_cut;
+    int32_t blk_bin;
+    int32_t blk_rows;     // LDS rows per workgroup (blk_bin + the largest gap between closed cuts - 1 fits)
+    // set per workgroup by the kernel (a copy of the parameter block):
+    float* blk_lds;       // [blk_rows][F] accumulator of d x_src (+ d x_in when g_in aliases g_src)
+    int32_t blk_lo, blk_hi;
 };
 
 // accumulator slot ids in the hub workspace
@@ -280,6 +290,17 @@ struct SlotBatch {
         for (int c = 0; c < NW; ++c) w[c] = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) w[c] = in ? p.w[(int64_t)c * p.ld_w + e] : 0.f;
+    }
+    // prefetch form: branch-free loads clamped into the slot arrays (lanes beyond the range hold some other slot's values and are never
+    // read: the consumer broadcasts lanes below its slot count only); no edge-type table
+    __device__ __forceinline__ void load_raw(const AggParams& p, int base) {
+        const int e = min(base + lane_id(), (int)p.n_edges - 1);
+        src = p.src[e];
+        et = e;
+#pragma unroll
+        for (int c = 0; c < NW; ++c) w[c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + e];
     }
     __device__ __forceinline__ void weights(float (&wk)[NW], int k) const {
 #pragma unroll
@@ -1231,7 +1252,20 @@ __device__ __forceinline__ void make_coef(Coef<C>& k, float (&gxin)[C::VEC], con
 
 // emit dm_j for the cnt slots of one loaded slot batch (my_tpos: the lane's csc position, two-phase scatter);
 // adds them to the row-sum rsum.  Active lanes only.
-template <class C, bool NEED_M>
+// block backward: one per-edge gradient row added to its source's accumulator row in LDS.  The rows belong to ONE wave (a workgroup
+// of agg_bwd_block is a single wave that owns whole graphs) and a lane owns its features: a plain read-add-write, in program order.
+// (ds_add_f32 from several waves was measured first: ~2 cycles per LANE on this part -- 75 us of a 250 us backward on ZINC-12k.)
+template <int VEC>
+__device__ __forceinline__ void blk_add(const AggParams& p, int node, int f0, const float (&v)[VEC]) {
+    float* at = p.blk_lds + (node - p.blk_lo) * p.F + f0;
+    float cur[VEC];
+    ldv<VEC>(cur, at);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) cur[i] += v[i];
+    stv<VEC>(at, cur);
+}
+
+template <class C, bool NEED_M, bool BLK = false>
 __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                            const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
                                            const float (&xd)[C::VEC]) {
@@ -1298,7 +1332,9 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
                 }
                 rsum[i] += gm[i];
             }
-            if (p.g_src) {
+            if constexpr (BLK) {
+                blk_add<VEC>(p, s, f0, gm);
+            } else if (p.g_src) {
                 if (p.stage) {
                     // atomic-free path: park the row at its csc position; seg_sum_rows adds each source's rows
                     stv<VEC>(p.stage + (int64_t)tp * p.F + f0, gm);
@@ -1314,47 +1350,57 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
 }
 
 // emit dm_j for slots [beg, end) of a row; returns the row-sum of dm_j in rsum
-template <class C, bool NEED_M>
+template <class C, bool NEED_M, bool BLK = false>
 __device__ __forceinline__ void emit_range(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
                                            int f0, bool active, const float (&xd)[C::VEC]) {
     for (int base = beg; base < end; base += kWave) {
         SlotBatch<C::NCH, C::NW> b;
         b.load(p, base, end);
-        const int my_tpos = (p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
-        if (active) emit_batch<C, NEED_M>(k, rsum, p, b, my_tpos, base, min(kWave, end - base), f0, xd);   // (lanes beyond F only help loading the slot batch)
+        const int my_tpos = (!BLK && p.stage && base + lane_id() < end) ? p.csc_pos[base + lane_id()] : 0;
+        if (active) emit_batch<C, NEED_M, BLK>(k, rsum, p, b, my_tpos, base, min(kWave, end - base), f0, xd);   // (lanes beyond F only help loading the slot batch)
     }
 }
 
-template <class C>
+template <class C, bool BLK = false>
 __device__ __forceinline__ void emit_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p, int beg, int end,
                                               int f0, bool active, const float (&xd)[C::VEC]) {
     if constexpr (C::STATS) {
         if (p.need & NEED_M_EMIT) {
-            emit_range<C, true>(k, rsum, p, beg, end, f0, active, xd);
+            emit_range<C, true, BLK>(k, rsum, p, beg, end, f0, active, xd);
             return;
         }
     }
-    emit_range<C, false>(k, rsum, p, beg, end, f0, active, xd);
+    emit_range<C, false, BLK>(k, rsum, p, beg, end, f0, active, xd);
 }
 
-template <class C>
+template <class C, bool BLK = false>
 __device__ __forceinline__ void emit_batch_dispatch(const Coef<C>& k, float (&rsum)[C::VEC], const AggParams& p,
                                                     const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
                                                     const float (&xd)[C::VEC]) {
     if constexpr (C::STATS) {
         if (p.need & NEED_M_EMIT) {
-            emit_batch<C, true>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
+            emit_batch<C, true, BLK>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
             return;
         }
     }
-    emit_batch<C, false>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
+    emit_batch<C, false, BLK>(k, rsum, p, b, my_tpos, base, cnt, f0, xd);
 }
 
 // per-row gradients d x_dst (= row sum of dm_j) and d x_in.  `plain`: the caller owns the row (row kernel in
 // fresh mode) and stores; otherwise hardware atomics into initialised buffers (accumulate mode, hub slices).
-template <int VEC>
+template <int VEC, bool BLK = false>
 __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f0, const float (&rsum)[VEC],
                                               const float (&gxin)[VEC], bool with_xin, bool plain = false) {
+    if constexpr (BLK) {
+        // the workgroup owns the row: d x_dst stored; d x_in stored -- or, where it aliases d x_src (simple layers: x_src = x_in = h),
+        // added to the row's accumulator in LDS, which the workgroup writes once
+        if (p.g_dst) stv<VEC>(p.g_dst + (int64_t)row * p.ldg_dst + f0, rsum);
+        if (with_xin && p.g_in) {
+            if (p.g_in == p.g_src) blk_add<VEC>(p, row, f0, gxin);
+            else stv<VEC>(p.g_in + (int64_t)row * p.ldg_in + f0, gxin);
+        }
+        return;
+    }
     if (p.g_dst) {
         float* dst = p.g_dst + (int64_t)row * p.ldg_dst + f0;
         if (plain) {
@@ -1379,7 +1425,7 @@ __device__ __forceinline__ void add_row_grads(const AggParams& p, int row, int f
 // recompute and emit, and every load of the row -- slot batch, csc positions, side inputs, upstream gradient (static
 // lists), gathers -- is issued before the first store; separate passes would re-load the batch after the recompute and
 // fetch the gradient after the gather wait (two more dependent round trips per row).
-template <class C, class O>
+template <class C, class O, bool BLK = false>
 __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, int beg, int end, int f0, bool active) {
     constexpr int VEC = C::VEC;
     const int deg = end - beg;
@@ -1396,7 +1442,7 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     SlotBatch<C::NCH, C::NW> b;
     b.load(p, beg, end);
-    const int my_tpos = (p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
+    const int my_tpos = (!BLK && p.stage && beg + lane_id() < end) ? p.csc_pos[beg + lane_id()] : 0;
     bool recomp = (p.need & NEED_RECOMP) != 0;
     // aux_rows: the forward left the dx signs (the only thing such a list recomputes for): no gathers, no x_dst / x_in rows
     bool signs = false;
@@ -1454,12 +1500,12 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     } else {
         make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
     }
-    emit_batch_dispatch<C>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
-    add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
+    emit_batch_dispatch<C, BLK>(k, rsum, p, b, my_tpos, beg, deg, f0, xd);
+    add_row_grads<VEC, BLK>(p, row, f0, rsum, gxin, true, p.fresh);
 }
 
 // the backward of ONE destination row, any in-degree (what a wave of agg_bwd_rows does)
-template <class C, class O>
+template <class C, class O, bool BLK = false>
 __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0, bool active) {
     constexpr int VEC = C::VEC;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
@@ -1482,8 +1528,8 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
                 }
             }
         }
-        if (p.fresh) {
-            add_row_grads<VEC>(p, row, f0, zero, gx, true, true);
+        if (BLK || p.fresh) {
+            add_row_grads<VEC, BLK>(p, row, f0, zero, gx, true, true);
         } else if (deg == 0 && (p.need & NEED_XPASS) && p.g_in) {
             float* dst = p.g_in + (int64_t)row * p.ldg_in + f0;
 #pragma unroll
@@ -1503,7 +1549,7 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
 #pragma unroll
     for (int i = 0; i < VEC; ++i) rsum[i] = 0.f;
     if (deg <= kWave) {
-        bwd_row_one_batch<C, O>(p, row, beg, end, f0, active);
+        bwd_row_one_batch<C, O, BLK>(p, row, beg, end, f0, active);
         return;
     }
     bool signs = false;
@@ -1546,8 +1592,8 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
         for (int c = 0; c < C::NCH; ++c) acc.sw[c] = wave_sum(part[c]);
     }
     if (active) make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
-    emit_dispatch<C>(k, rsum, p, beg, end, f0, active, xd);
-    if (active) add_row_grads<VEC>(p, row, f0, rsum, gxin, true, p.fresh);
+    emit_dispatch<C, BLK>(k, rsum, p, beg, end, f0, active, xd);
+    if (active) add_row_grads<VEC, BLK>(p, row, f0, rsum, gxin, true, p.fresh);
 }
 
 template <class C, class O = DynOps>
@@ -1578,17 +1624,59 @@ __global__ __launch_bounds__(256) void agg_bwd_rows(const AggParams p) {
 // (48 registers on the ZINC list: with them the fused kernel's 16-wave workgroups would spill).
 // AUX: p.aux holds, for every (row, feature) of such a group, what the recompute would find (aux_byte): no message is formed again --
 // no source gathers, no x_dst / x_in rows -- and the coefficient code runs on accumulators that carry just those facts.
-template <class C, class O, int RB, bool EDGE = false, bool GLDS = false, bool AUX = false>
-__device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, int nrows, int f0, bool active) {
+// The row-indexed operands of a group of RB rows (what bwd_short_group requests up front), as a value the block kernel can request
+// one group AHEAD: upstream-gradient blocks, log-degrees, the aux words or the x_dst / x_in rows.
+template <class C, int RB, int NG, bool AUX>
+struct GroupRows {
+    float xd[RB][C::VEC], xin[RB][C::VEC], logd[RB], gpre[RB][NG][C::VEC];
+    unsigned auxw[AUX ? 4 : 1];
+};
+template <class O>
+constexpr int n_gout_blocks() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 1; }
+// branch-free, clamped into the arrays (rows beyond the graph and lanes beyond the row re-read the last valid one: prefetches must not
+// sit under a branch or a select -- the compiler would wait for them on the spot)
+template <class C, class O, int RB, bool AUX>
+__device__ __forceinline__ void load_group_rows(GroupRows<C, RB, n_gout_blocks<O>(), AUX>& R, const AggParams& p, int row0, int f0) {
+    constexpr int VEC = C::VEC;
+    const int last = (int)p.n_nodes - 1;
+    row0 = min(row0, last & ~(RB - 1));
+    const int f0c = min(f0, p.F - VEC);
+    if constexpr (AUX) load_aux_group<VEC>(R.auxw, p.aux + aux_offset(p, row0, f0c));
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = min(row0 + r, last);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { R.xd[r][i] = 0.f; R.xin[r][i] = 0.f; }
+        R.logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
+        if constexpr (!AUX) {
+            if (p.x_dst) ldv<VEC>(R.xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0c);
+            if (p.need & NEED_XIN) ldv<VEC>(R.xin[r], p.x_in + (int64_t)row * p.ld_in + f0c);
+        }
+        const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0c);
+#pragma unroll
+        for (int sc = 0; sc < O::kNS; ++sc)
+#pragma unroll
+            for (int a = 0; a < O::NA; ++a) ldv<VEC>(R.gpre[r][sc * O::NA + a], grow + sa_col(p, sc, a));
+    }
+}
+
+// BLK (agg_bwd_block): d x_src goes to the wave's accumulator rows in LDS; the group's row pointers (ipv_in: lane r holds
+// indptr[row0 + r], r <= RB), its slot batch (b_in) and its row operands (rows_in: a GroupRows) were requested an iteration
+// earlier by the caller.
+template <class C, class O, int RB, bool EDGE = false, bool GLDS = false, bool AUX = false, bool BLK = false, bool PREROWS = false>
+__device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, int nrows, int f0, bool active, int ipv_in = 0,
+                                                const SlotBatch<C::NCH, C::NW>* b_in = nullptr, const void* rows_in = nullptr) {
     constexpr int VEC = C::VEC, J = kShortDeg;
     constexpr int NG = []() { if constexpr (O::kStatic) return O::NA * O::kNS; else return 99; }();     // upstream-gradient blocks per row
     constexpr bool PRE = O::kStatic && NG <= 8;
-    bool fast = PRE && nrows == RB && p.stage && p.fresh && p.g_src && p.x_src && (EDGE ? p.m_edge != nullptr : (!p.m_edge && !p.g_edge)) &&
+    bool fast = PRE && nrows == RB && (BLK || (p.stage && p.fresh)) && p.g_src && p.x_src && (EDGE ? p.m_edge != nullptr : (!p.m_edge && !p.g_edge)) &&
                 !(p.need & NEED_M_EMIT);      // (no static list carries std / var: their emit term stays with the per-row routine)
     const bool recomp = (p.need & NEED_RECOMP) != 0;     // (otherwise only sum_j w_jc is needed: no gathers at all)
     int lo[RB], deg[RB], beg0 = 0;
     if (fast) {
-        const int ipv = p.indptr[row0 + min(lane_id(), RB)];
+        int ipv;
+        if constexpr (BLK) ipv = ipv_in;
+        else ipv = p.indptr[row0 + min(lane_id(), RB)];
         beg0 = bcast_i(ipv, 0);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -1598,25 +1686,45 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
         }
     }
     if (!fast) {
-        for (int r = 0; r < nrows; ++r) bwd_any_row<C, O>(p, row0 + r, f0, active);
+        for (int r = 0; r < nrows; ++r) {
+            if (BLK && (row0 + r < p.blk_lo || row0 + r >= p.blk_hi)) continue;      // (a group across a block boundary: the neighbour's rows)
+            bwd_any_row<C, O, BLK>(p, row0 + r, f0, active);
+        }
         return;
     }
     if constexpr (PRE) {
         const int total = lo[RB - 1] + deg[RB - 1];
         SlotBatch<C::NCH, C::NW> b;
-        b.load(p, beg0, beg0 + total);
-        const int my_tpos = lane_id() < total ? p.csc_pos[beg0 + lane_id()] : 0;
+        if constexpr (BLK) b = *b_in;
+        else b.load(p, beg0, beg0 + total);
+        const int my_tpos = (!BLK && lane_id() < total) ? p.csc_pos[beg0 + lane_id()] : 0;
         if (!active) return;
         // every load of the group, issued before anything is consumed
         float xd[RB][VEC], xin[RB][VEC], logd[RB], gpre[GLDS ? 1 : RB][GLDS ? 1 : NG][VEC], t[AUX ? 1 : RB][AUX ? 1 : J][VEC],
               t2[(EDGE && !AUX) ? RB : 1][(EDGE && !AUX) ? J : 1][VEC];
         unsigned auxw[AUX ? 4 : 1];
-        if constexpr (AUX) {
+        if constexpr (PREROWS) {
+            static_assert(BLK && !GLDS && !EDGE, "the block kernel takes the plain message forms");
+            const auto& R = *static_cast<const GroupRows<C, RB, n_gout_blocks<O>(), AUX>*>(rows_in);
+#pragma unroll
+            for (int q = 0; q < (AUX ? 4 : 1); ++q) auxw[q] = R.auxw[q];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                logd[r] = R.logd[r];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { xd[r][i] = R.xd[r][i]; xin[r][i] = R.xin[r][i]; }
+#pragma unroll
+                for (int q = 0; q < NG; ++q)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gpre[r][q][i] = R.gpre[r][q][i];
+            }
+        }
+        if constexpr (AUX && !PREROWS) {
             static_assert(RB == 4, "the aux table is laid out per group of four rows");
             load_aux_group<VEC>(auxw, p.aux + aux_offset(p, row0, f0));
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
+        for (int r = 0; r < (PREROWS ? 0 : RB); ++r) {
             const int row = row0 + r;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { xd[r][i] = 0.f; xin[r][i] = 0.f; }
@@ -1649,6 +1757,7 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
+            if (BLK && (row0 + r < p.blk_lo || row0 + r >= p.blk_hi)) continue;      // (a group across a block boundary: the neighbour's rows)
             Acc<C, true> acc;
             acc.init();
             if constexpr (AUX) {
@@ -1742,13 +1851,14 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
                         }
                         rsum[i] += gm[i];
                     }
-                    stv<VEC>(p.stage + (int64_t)bcast_i(my_tpos, l) * p.F + f0, gm);
+                    if constexpr (BLK) blk_add<VEC>(p, bcast_i(b.src, l), f0, gm);
+                    else stv<VEC>(p.stage + (int64_t)bcast_i(my_tpos, l) * p.F + f0, gm);
                     if constexpr (EDGE) {          // dense edge term: its gradient is dm_j itself, rows in slot order
                         if (p.g_edge) stv<VEC>(p.g_edge + (int64_t)pos * p.ldg_edge + f0, gm);
                     }
                 }
             }
-            add_row_grads<VEC>(p, row0 + r, f0, rsum, gxin, true, true);
+            add_row_grads<VEC, BLK>(p, row0 + r, f0, rsum, gxin, true, true);
         }
     }
 }
@@ -2064,5 +2174,8 @@ inline bool is_hot_list(const AggParams& p) {
 int launch_agg_v1(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
 int launch_agg_v2(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
 int launch_agg_v4(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
+// defined in dgn_agg_blk_v2.hip / _v4.hip (dgn_agg_block.hpp): DGN_OK, an error, or 1 = no block kernel for this launch
+int launch_agg_block_v2(const AggParams& p, int gap, hipStream_t stream);
+int launch_agg_block_v4(const AggParams& p, int gap, hipStream_t stream);
 
 }  // namespace dgn

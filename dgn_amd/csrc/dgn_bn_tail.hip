@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "dgn_common.hpp"
 
@@ -353,7 +354,109 @@ size_t part_bytes(int64_t n_rows, int F) { return (size_t)2 * F * stat_groups(n_
 }  // namespace
 }  // namespace dgn
 
+// ---- dropout (F.dropout at the end of DGNLayerSimple / DGNLayerComplex.forward, nets/dgn_layer.py:130, :201; configs HIV / PCBA /
+// CIFAR10: dropout 0.3) -----------------------------------------------------------------------------------------------------------
+// Philox4x32-10, counter = (index of the 8-element group, half, offset lo, offset hi), key = the two halves of *seed (a DEVICE scalar:
+// drawn by the caller's generator, so the launch is capturable and replays draw new masks when the scalar is refreshed inside the
+// captured region).  A thread owns 8 consecutive elements = one byte of the keep mask the backward re-applies.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_fwd(int64_t n, const float* __restrict__ x, uint32_t threshold, float scale,
+                                                   const int64_t* __restrict__ seed, uint64_t offset, float* __restrict__ y,
+                                                   unsigned char* __restrict__ mask) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // group of 8 elements
+    const int64_t e0 = g * 8;
+    if (e0 >= n) return;
+    const uint64_t sd = (uint64_t)*seed;
+    uint32_t r[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32) * 2u + (uint32_t)half, (uint32_t)offset, (uint32_t)(offset >> 32)};
+        philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[4 * half + i] = c[i];
+    }
+    float v[8];
+    const bool full = e0 + 8 <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (full) {
+        const float4 a = *reinterpret_cast<const float4*>(x + e0), b = *reinterpret_cast<const float4*>(x + e0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = e0 + i < n ? x[e0 + i] : 0.f;
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool keep = r[i] >= threshold;                                   // P(keep) = 1 - p
+        m |= (keep ? 1u : 0u) << i;
+        v[i] = keep ? v[i] * scale : 0.f;
+    }
+    mask[g] = (unsigned char)m;
+    if (full) {
+        *reinterpret_cast<float4*>(y + e0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(y + e0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (e0 + i < n) y[e0 + i] = v[i];
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd(int64_t n, const float* __restrict__ gy, const unsigned char* __restrict__ mask, float scale,
+                                                   float* __restrict__ gx) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e0 = g * 8;
+    if (e0 >= n) return;
+    const unsigned m = mask[g];
+    const bool full = e0 + 8 <= n && (reinterpret_cast<uintptr_t>(gy) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
+    if (full) {
+        const float4 a = *reinterpret_cast<const float4*>(gy + e0), b = *reinterpret_cast<const float4*>(gy + e0 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (m >> i) & 1u ? v[i] * scale : 0.f;
+        *reinterpret_cast<float4*>(gx + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(gx + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (e0 + i < n) gx[e0 + i] = (m >> i) & 1u ? gy[e0 + i] * scale : 0.f;
+    }
+}
+
 using namespace dgn;
+
+extern "C" size_t dgn_dropout_mask_bytes(int64_t n_elems) { return n_elems > 0 ? (size_t)((n_elems + 7) / 8) : 0; }
+
+extern "C" int dgn_dropout_forward(int64_t n_elems, const float* x, float p, const int64_t* seed, uint64_t offset, float* y,
+                                   unsigned char* mask, void* stream_) {
+    if (n_elems < 0 || !(p >= 0.f && p < 1.f)) { set_error("dgn_dropout_forward: need n_elems >= 0 and 0 <= p < 1"); return DGN_ERR_INVALID; }
+    if (n_elems == 0) return DGN_OK;
+    if (!x || !y || !mask || !seed) { set_error("dgn_dropout_forward: null buffer"); return DGN_ERR_INVALID; }
+    const uint32_t threshold = (uint32_t)std::min<double>(4294967295.0, std::floor((double)p * 4294967296.0));
+    const int64_t groups = (n_elems + 7) / 8;
+    hipLaunchKernelGGL(dropout_fwd, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), n_elems, x, threshold,
+                       1.f / (1.f - p), seed, offset, y, mask);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" int dgn_dropout_backward(int64_t n_elems, const float* g_y, const unsigned char* mask, float p, float* g_x, void* stream_) {
+    if (n_elems < 0 || !(p >= 0.f && p < 1.f)) { set_error("dgn_dropout_backward: need n_elems >= 0 and 0 <= p < 1"); return DGN_ERR_INVALID; }
+    if (n_elems == 0) return DGN_OK;
+    if (!g_y || !g_x || !mask) { set_error("dgn_dropout_backward: null buffer"); return DGN_ERR_INVALID; }
+    const int64_t groups = (n_elems + 7) / 8;
+    hipLaunchKernelGGL(dropout_bwd, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), n_elems, g_y, mask,
+                       1.f / (1.f - p), g_x);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
 
 extern "C" size_t dgn_bn_tail_workspace_bytes(int64_t n_rows, int32_t F) {
     if (n_rows <= 0 || F < 1 || F > kMaxF) return 0;

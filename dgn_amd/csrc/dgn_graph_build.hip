@@ -63,13 +63,40 @@ __global__ void gb_invert(int64_t E, const int32_t* __restrict__ order, int32_t*
     if (k < E) pos[order[k]] = (int)k;
 }
 
+// ---- closed cuts (DgnGraph.blk_cut): where a batch of graphs can be split without cutting an edge -----------------------------------
+// an edge (s, d) crosses every cut in (min, max]: +1 / -1 at the ends of that range, prefix sums give the crossings per cut
+__global__ void gb_span(int64_t E, const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int32_t* __restrict__ diff) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const int s = src[k], d = dst[k];
+    const int a = min(s, d), b = max(s, d);
+    if (a < b) {
+        atomicAdd(diff + a + 1, 1);
+        atomicAdd(diff + b + 1, -1);
+    }
+}
+__global__ void gb_mark_closed(int64_t N, const int32_t* __restrict__ cross, int32_t* __restrict__ val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= N) val[i] = cross[i] == 0 ? (int)i : 0;
+}
+__global__ void gb_max_gap(int64_t N, const int32_t* __restrict__ cross, const int32_t* __restrict__ lastcut, int32_t* __restrict__ gap_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    int g = 0;
+    if (i <= N && cross[i] == 0) g = (int)i - lastcut[i - 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) g = max(g, __shfl_xor(g, o, kWave));
+    if ((threadIdx.x & 63) == 0 && g > 0) atomicMax(gap_out, g);
+}
+
 // temp storage the hipCUB calls of this file need, for n items
 size_t cub_bytes(int64_t n) {
     size_t a = 0, b = 0;
     int32_t* p = nullptr;
     hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
     hipcub::DeviceScan::ExclusiveSum(nullptr, b, p, p, (int)n);
-    return up256(std::max(a, b)) + 256;
+    size_t c = 0;
+    hipcub::DeviceScan::InclusiveScan(nullptr, c, p, p, hipcub::Max(), (int)n);
+    return up256(std::max(std::max(a, b), c)) + 256;
 }
 
 }  // namespace
@@ -112,6 +139,31 @@ extern "C" int dgn_graph_build(int64_t n_nodes, int64_t n_edges, const int64_t* 
         hipLaunchKernelGGL(gb_gather, dim3(blocks(n_edges)), dim3(256), 0, st, n_edges, src, perm, src_csr, eid);
     }
     if (n_nodes > 0) hipLaunchKernelGGL(gb_node_stats, dim3(blocks(n_nodes)), dim3(256), 0, st, n_nodes, deg, log_deg, in_degree, stats, hub_threshold);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" int dgn_graph_build_cuts(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, const int32_t* dst_csr, int32_t* blk_cut,
+                                    int32_t* gap_out, void* ws, size_t ws_bytes, void* stream_) {
+    const char* fn = "dgn_graph_build_cuts";
+    if (n_nodes < 0 || n_edges < 0 || n_nodes >= INT32_MAX - 1) { set_error("%s: sizes outside the int32 CSR range", fn); return DGN_ERR_INVALID; }
+    if (!blk_cut || !gap_out || (n_edges > 0 && (!src_csr || !dst_csr))) { set_error("%s: null array", fn); return DGN_ERR_INVALID; }
+    if (!ws || ws_bytes < dgn_graph_build_workspace_bytes(n_nodes, n_edges)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    char* w = static_cast<char*>(ws);
+    const size_t nbytes = up256((size_t)(n_nodes + 2) * 4);
+    int32_t* diff = reinterpret_cast<int32_t*>(w); w += nbytes;
+    int32_t* cross = reinterpret_cast<int32_t*>(w); w += nbytes;
+    int32_t* val = reinterpret_cast<int32_t*>(w); w += nbytes;
+    void* cub = w;
+    size_t cub_sz = ws_bytes - (size_t)(w - static_cast<char*>(ws));
+    DGN_HIP_CHECK(hipMemsetAsync(diff, 0, (size_t)(n_nodes + 2) * 4, st));
+    DGN_HIP_CHECK(hipMemsetAsync(gap_out, 0, sizeof(int32_t), st));
+    if (n_edges > 0) hipLaunchKernelGGL(gb_span, dim3(blocks(n_edges)), dim3(256), 0, st, n_edges, src_csr, dst_csr, diff);
+    DGN_HIP_CHECK(hipcub::DeviceScan::InclusiveSum(cub, cub_sz, diff, cross, (int)(n_nodes + 1), st));
+    hipLaunchKernelGGL(gb_mark_closed, dim3(blocks(n_nodes + 1)), dim3(256), 0, st, n_nodes, cross, val);
+    DGN_HIP_CHECK(hipcub::DeviceScan::InclusiveScan(cub, cub_sz, val, blk_cut, hipcub::Max(), (int)(n_nodes + 1), st));
+    if (n_nodes > 0) hipLaunchKernelGGL(gb_max_gap, dim3(blocks(n_nodes)), dim3(256), 0, st, n_nodes, cross, blk_cut, gap_out);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

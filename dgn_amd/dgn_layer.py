@@ -110,6 +110,13 @@ def _slot_dst(graph: DGNGraph) -> torch.Tensor:
     return graph._dst_slots
 
 
+def _dropout(x, p, training):
+    """F.dropout of the reference's tails; CUDA fp32 tensors through the bit-mask kernels (ops.dropout), anything else through torch."""
+    if training and p > 0 and x.is_cuda and x.dtype == torch.float32:
+        return _ops.dropout(x, p, True)
+    return F.dropout(x, p, training=training)
+
+
 class EdgeTypeFeatures:
     """Edge features that are an embedding lookup -- ``e = embedding_e(bond_type)`` in the reference's nets
     (nets/molecules_graph_regression/dgn_net.py:53,75) -- handed to the layers as (table, types) instead of the gathered [E, edge_dim]
@@ -296,7 +303,7 @@ class DGNLayerSimple(nn.Module):
         """The layer through dgn_dense_layer_forward / _backward (one C call per direction), or None outside that entry point's domain
         (training-mode BatchNorm, single-affine posttrans, no dropout, enough rows for this library's own GEMM kernels)."""
         bn = self.batchnorm_h
-        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and self.dropout == 0 and h.is_cuda
+        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and h.is_cuda
                 and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and self.posttrans.is_single_affine()
                 and bn_tail_supported([bn], h, True, bn.num_features)):
             return None
@@ -313,7 +320,7 @@ class DGNLayerSimple(nn.Module):
     def _forward(self, g, h, e, snorm_n):
         y = self._whole_layer(g, h, snorm_n)
         if y is not None:
-            return y
+            return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:201: the layer's last op)
         h_in = h
         F0 = h.shape[1]
         # Odd widths (ZINC simple: 75, CIFAR10: 65) would run the sweep with 4-byte lanes, a second, nearly empty
@@ -335,7 +342,7 @@ class DGNLayerSimple(nn.Module):
                 z = node_linear(agg, w)
                 sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
                 h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)      # (+snorm, BatchNorm, ReLU, residual)
-                return F.dropout(h, self.dropout, training=self.training)
+                return _dropout(h, self.dropout, self.training)
             else:
                 agg = self.aggregate(graph, hp, None, eig)                                    # [N, A*Fp] (single scaler: not applied)
                 h = node_linear(agg, _pad_blocks(lin.weight, A, F0, Fp), lin.bias)
@@ -354,7 +361,7 @@ class DGNLayerSimple(nn.Module):
             h = F.relu(h)
             if self.residual:
                 h = h_in + h
-        return F.dropout(h, self.dropout, training=self.training)
+        return _dropout(h, self.dropout, self.training)
 
 
 class DGNLayerComplex(nn.Module):
@@ -395,7 +402,7 @@ class DGNLayerComplex(nn.Module):
         """As DGNLayerSimple._whole_layer; additionally: single-affine pretrans, no edge features, identity among the applied scalers."""
         bn = self.batchnorm_h
         id_slot = _identity_slot(self.plan.applied_scalers)
-        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and self.dropout == 0 and not self.edge_features
+        if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and not self.edge_features
                 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and id_slot is not None
                 and self.posttrans.is_single_affine() and self.pretrans.is_single_affine() and bn_tail_supported([bn], h, True, bn.num_features)):
             return None
@@ -412,7 +419,7 @@ class DGNLayerComplex(nn.Module):
     def _forward(self, g, h, e, snorm_n):
         y = self._whole_layer(g, h, snorm_n)
         if y is not None:
-            return y
+            return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:130: the layer's last op)
         h_in = h
         eig = g.ndata["eig"]
         id_slot = _identity_slot(self.plan.applied_scalers)
@@ -436,7 +443,7 @@ class DGNLayerComplex(nn.Module):
             z = node_linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
             h = _combine_and_tail(self, z.unsqueeze(0), sc, lin.bias, snorm_n, h_in)          # (+snorm, BatchNorm, ReLU, residual)
-            return F.dropout(h, self.dropout, training=self.training)
+            return _dropout(h, self.dropout, self.training)
         else:
             h = _posttrans_split(self.posttrans, h, self.aggregate(g, h, e, None, eig), self.in_dim)
             if self.graph_norm:
@@ -447,7 +454,7 @@ class DGNLayerComplex(nn.Module):
             h = F.relu(h)
             if self.residual:
                 h = h_in + h
-        return F.dropout(h, self.dropout, training=self.training)
+        return _dropout(h, self.dropout, self.training)
 
 
 class DGNTower(nn.Module):
@@ -480,7 +487,7 @@ class DGNTower(nn.Module):
             h = h * snorm_n
         if self.batch_norm:
             h = self.batchnorm_h(h)
-        return F.dropout(h, self.dropout, training=self.training)
+        return _dropout(h, self.dropout, self.training)
 
 
 class DGNLayerTower(nn.Module):
@@ -673,7 +680,7 @@ class DGNLayerTower(nn.Module):
                         y = bn_tail_fused(y, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps, self.training)
                     else:
                         y = bn_tail(y, bns, self.training)
-                return F.dropout(y, self.dropout, training=self.training)
+                return _dropout(y, self.dropout, self.training)
             aggx = directional_aggregate(graph, self._kplan_x, self._avg_log, x_pair=pq, m_edge=m_edge, x_in=x_in,
                                          eig=g.ndata["eig"], n_towers=T, tower_major=True, edge_type=edge_type)
             bns = [t.batchnorm_h for t in self.towers]
@@ -682,12 +689,12 @@ class DGNLayerTower(nn.Module):
                 rm, rv, nbt = self._linked_bn_stats(aggx.device)                                   # posttrans + combine + BatchNorm: one autograd node
                 y = linear_combine_bn_tail(aggx, ops["w"], sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt,
                                            bns[0].momentum, bns[0].eps)
-                return F.dropout(y, self.dropout, training=self.training)
+                return _dropout(y, self.dropout, self.training)
             z = node_linear(aggx, ops["w"])                                                        # [T, N, S*fo]
             if fused_tail:
                 rm, rv, nbt = self._linked_bn_stats(z.device)                                      # combine + BatchNorm: one autograd node
                 y = combine_bn_tail(z, sc, b_p, row_scale, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps)
-                return F.dropout(y, self.dropout, training=self.training)
+                return _dropout(y, self.dropout, self.training)
             y = scale_combine(z, sc, b_p, row_scale)                                               # [N, T*fo]
         else:
             agg = directional_aggregate(graph, self._kplan, self._avg_log, x_pair=pq, m_edge=m_edge,
@@ -705,7 +712,7 @@ class DGNLayerTower(nn.Module):
                 y = bn_tail_fused(y, ops["bn_gamma"], ops["bn_beta"], rm, rv, nbt, bns[0].momentum, bns[0].eps, self.training)
             else:
                 y = bn_tail(y, bns, self.training)
-        return F.dropout(y, self.dropout, training=self.training)
+        return _dropout(y, self.dropout, self.training)
 
     def _whole_layer(self, g, h, snorm_n):
         """The layer through dgn_towers_layer_forward / _backward (one C call per direction), or None when the configuration

@@ -30,6 +30,7 @@ HUB_CHUNK = 1024
 # False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
 NATIVE_BUILD = True
 DC_CLASSES, DC_UNIT = 32, 64      # include/dgn_hip.h: DGN_DC_CLASSES, DGN_DC_UNIT
+BLOCK_MAX_GAP = 52         # largest graph of a batch (nodes) for which the block backward is tried (a wave's block is at most 56 rows: csrc/dgn_agg_block.hpp; the C side checks the LDS budget per F)
 DEFERRED_STATS = True      # DGNGraph.rebuild: the batch's (max in-degree, hub rows) are checked at the next load instead of with a host sync
 
 
@@ -174,7 +175,7 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale"):
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale", "_blk"):
             self.__dict__.pop(k, None)
 
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
@@ -303,6 +304,38 @@ class DGNGraph:
         _lib.check(lib.dgn_graph_build_csc(N, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), order.data_ptr(),
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
+
+    # ---- block description for the LDS-accumulating backward (csrc/dgn_agg_block.hpp) -----------------------------------------------
+    def ensure_blocks(self, enabled: bool = True) -> bool:
+        """Attach (or detach) DgnGraph.blk_cut / blk_gap: the closed cuts of a batch of small graphs (dgn_graph_build_cuts, built on
+        first use: five kernels and ONE read-back of the largest gap).  Graphs without usable cuts (hub rows, a bipartite CSR, a padded
+        batch, more than 3 edges per node on average -- the four-rows-per-wave kernels do not run there --, a component of more than
+        BLOCK_MAX_GAP nodes) never get them: the staged backward runs.  Returns whether attached."""
+        ok = False
+        if enabled and self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None \
+                and self.num_nodes > 0 and 0 < self.num_edges <= 3 * self.num_nodes and self.row_base == 0:
+            if "_blk" not in self.__dict__:
+                lib = _lib.load()
+                N, E, dev = self.num_nodes, self.num_edges, self.device
+                dst_csr = getattr(self, "dst_csr", None)
+                if dst_csr is None:
+                    deg = (self.indptr[1:] - self.indptr[:-1]).long()
+                    dst_csr = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32), deg)
+                    self.dst_csr = dst_csr
+                cut = torch.empty(N + 1, dtype=torch.int32, device=dev)
+                gap = torch.zeros(1, dtype=torch.int32, device=dev)
+                nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.dgn_graph_build_cuts(N, E, self.src.data_ptr(), dst_csr.data_ptr(), cut.data_ptr(), gap.data_ptr(),
+                                                    ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "dgn_graph_build_cuts")
+                self._blk = (cut, int(gap.item()))                                    # the one read-back
+            cut, gap = self._blk
+            ok = 0 < gap <= BLOCK_MAX_GAP
+        if ok:
+            self._c.blk_cut, self._c.blk_gap = cut.data_ptr(), gap
+        else:
+            self._c.blk_cut, self._c.blk_gap = None, 0
+        return ok
 
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----
     def number_of_nodes(self) -> int:

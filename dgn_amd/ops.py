@@ -22,6 +22,11 @@ from .spec import EPS, AggPlan
 # sweep can use >= 8-byte lanes (even F: measured 8-14 % faster on the molecule configs), atomics otherwise (odd F,
 # e.g. hidden 75: 4-byte staging rows make the two-phase path 40 % slower than atomics).
 DETERMINISTIC_BACKWARD = "auto"
+# Block backward (csrc/dgn_agg_block.hpp): on batches of small graphs (molecules) one wave owns whole graphs and accumulates d x_src in
+# its own LDS rows -- one kernel, no [E, F] staging round trip (1.2-1.7x the algorithmic traffic on the measured configs), the adds in
+# the staged path's own order (run-to-run reproducible).  True (default): used wherever the graph and the aggregator list have such a
+# kernel (the C side decides per launch); False: always the staged two-phase scatter.
+BLOCK_BACKWARD = os.environ.get("DGN_BLOCK_BACKWARD", "1") != "0"
 
 # ---- padded batches -------------------------------------------------------------------------------------------------------------
 # A batch held at a fixed row capacity (shape-bucketed HIP-graph replay: dgn_amd/hipgraph.py::PaddedBatch) carries a DEVICE scalar
@@ -169,6 +174,7 @@ def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: floa
         raise _lib.DgnError("edge-type table: the backward needs the two-phase scatter (even F, a gradient for x_src)")
     if deterministic:
         graph.ensure_csc()
+    graph.ensure_blocks(bool(BLOCK_BACKWARD) and deterministic and not accumulate and len(plan.launches) == 1)
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_backward_workspace_bytes(C.byref(g), C.byref(spec), F, 1 if deterministic else 0)
         if edge_type is not None:
@@ -366,6 +372,53 @@ def scale_combine(z: torch.Tensor, scale: Optional[torch.Tensor], bias: Optional
     if bias is not None:
         bias = bias.reshape(-1).contiguous()
     return _ScaleCombine.apply(z, scale, bias, row_scale)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        lib = _lib.load()
+        x = x.contiguous()
+        n = x.numel()
+        y = torch.empty_like(x)
+        mask = torch.empty(lib.dgn_dropout_mask_bytes(n), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.dgn_dropout_forward(n, x.data_ptr(), float(p), seed.data_ptr(), int(offset), y.data_ptr(), mask.data_ptr(),
+                                           _lib.stream_ptr(x.device)), "dgn_dropout_forward")
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        ctx.mark_non_differentiable(mask)
+        return y, mask
+
+    @staticmethod
+    def backward(ctx, g_y, _g_mask):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        g_y = g_y.contiguous()
+        g_x = torch.empty_like(g_y)
+        _lib.check(lib.dgn_dropout_backward(g_y.numel(), g_y.data_ptr(), mask.data_ptr(), ctx.p, g_x.data_ptr(), _lib.stream_ptr(g_y.device)),
+                   "dgn_dropout_backward")
+        return g_x, None, None, None
+
+
+LAST_DROPOUT_MASK = None     # (tests) the keep-bit tensor of the most recent dropout() call: bit i of byte g = element 8 g + i
+
+
+def dropout(x: torch.Tensor, p: float, training: bool, seed: Optional[torch.Tensor] = None, offset: int = 0) -> torch.Tensor:
+    """``F.dropout(x, p, training)`` of the reference's layer tails (nets/dgn_layer.py:130, :201, :275) as one kernel per direction with a
+    BIT mask saved for the backward (N F / 8 bytes instead of autograd's fp32 product operands).  ``seed``: a device int64 scalar (default:
+    drawn from torch's generator of the device, so ``torch.manual_seed`` reproduces the masks and the draw is capturable)."""
+    global LAST_DROPOUT_MASK
+    if not training or p == 0.0:
+        return x
+    if p >= 1.0:
+        return x * 0.0
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise _lib.DgnError("dropout: CUDA fp32 tensors only (dgn_amd has no CPU path)")
+    if seed is None:
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device)
+    y, mask = _Dropout.apply(x, p, seed, offset)
+    LAST_DROPOUT_MASK = mask
+    return y
 
 
 class _BNTail(torch.autograd.Function):
@@ -1056,6 +1109,7 @@ class _TowersLayer(torch.autograd.Function):
         pq, aggx, y0, y1, z, mean, invstd, wc = (saved_buf[o:o + n] for o, n in zip(offs, sizes))
         g_out = g_out.contiguous()
         graph.ensure_csc()
+        graph.ensure_blocks(bool(BLOCK_BACKWARD))
         spec = _spec_structs(plan, T, ctx.avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
         cg = graph.c_graph
@@ -1233,6 +1287,7 @@ class _DenseLayer(torch.autograd.Function):
         _, bufs = _carve_ptrs(sizes, dev, saved_buf)
         g_out = g_out.contiguous()
         graph.ensure_csc()
+        graph.ensure_blocks(bool(BLOCK_BACKWARD))
         L, keep = _dense_struct(graph, ctx.plan, ctx.avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid,
                                 ctx.dc)
         L.agg_aux = _ptr(aux)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 21
+#define DGN_ABI_VERSION 22
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -110,6 +110,14 @@ typedef struct DgnGraph {
      * this CSR is node row_base + i of the source node set.  Only dgn_edge_weights uses it (the destination side of
      * eig is read at row row_base + i); the per-row arrays of the sweep (x_dst, x_in, log_deg, out) are the shard's. */
     int64_t row_base;
+    /* Optional (NULL = absent): block description of a batch of small graphs, built by dgn_graph_build_cuts.  blk_cut[i], i in
+     * [0, n_nodes], is the last CLOSED cut <= i -- a cut c is closed when no edge joins a node below c to a node at or above it (the
+     * graph boundaries of a dgl.batch, data/molecules.py:229); blk_gap is the largest distance between consecutive closed cuts (the
+     * largest graph).  With it dgn_agg_backward (define mode, hot aggregator lists, one feature tile, no hub rows, no edge term, at most
+     * 3 edges per node) lets ONE WAVE own a run of whole graphs and accumulate d x_src in its LDS rows: one kernel, no [E, F] staging
+     * buffer, the adds in ascending (source, slot) order as in the staged path (run-to-run reproducible).                       */
+    const int32_t* blk_cut;  /* [n_nodes+1] */
+    int32_t blk_gap;
 } DgnGraph;
 
 typedef struct DgnChannel {
@@ -291,6 +299,16 @@ int dgn_bias_act_forward(int64_t n_rows, int32_t F, const float* x, int64_t ld, 
 int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y, const float* x, int64_t ld, const float* bias,
                           int32_t act, float slope, float* g_x, float* g_bias, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- dropout (dgn_bn_tail.hip): F.dropout(h, p, training) at the end of DGNLayerSimple / DGNLayerComplex.forward and inside DGNTower
+ * (nets/dgn_layer.py:130, :201, :275; configs HIV / PCBA / CIFAR10 ship dropout 0.3) -------------------------------------------------
+ * y = keep ? x / (1 - p) : 0 over a CONTIGUOUS array; keep bits from Philox4x32-10 keyed by *seed (a DEVICE int64 scalar the caller
+ * draws from its generator: capturable) and `offset`; mask: dgn_dropout_mask_bytes(n_elems) bytes, bit i of byte g = element 8 g + i,
+ * what the backward re-applies: g_x = keep ? g_y / (1 - p) : 0.  The same (seed, offset) gives the same mask.                       */
+size_t dgn_dropout_mask_bytes(int64_t n_elems);
+int dgn_dropout_forward(int64_t n_elems, const float* x, float p, const int64_t* seed, uint64_t offset, float* y, unsigned char* mask,
+                        void* stream);
+int dgn_dropout_backward(int64_t n_elems, const float* g_y, const unsigned char* mask, float p, float* g_x, void* stream);
+
 /* ---- tall-skinny fp32 Linear (dgn_linear.hip) ---------------------------------------------------------------------
  * The nn.Linear of the reference's pretrans / posttrans MLPs (layers.py:101-112, called from nets/dgn_layer.py:67-75
  * and :116-119) for matrices with ~1e5..1e6 rows (nodes) and k, n <= 160 columns, batched over towers:
@@ -453,6 +471,10 @@ size_t dgn_graph_build_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int dgn_graph_build(int64_t n_nodes, int64_t n_edges, const int64_t* src, const int64_t* dst, int32_t* indptr, int32_t* src_csr,
                     int32_t* dst_csr, int64_t* eid, float* log_deg, int64_t* in_degree, int32_t* stats, int32_t hub_threshold,
                     void* ws, size_t ws_bytes, void* stream);
+/* Closed cuts of a batch (DgnGraph.blk_cut / blk_gap above): blk_cut [n_nodes+1], gap_out a DEVICE int32 (the caller reads it back).
+ * dst_csr [n_edges] = destination of every CSR slot (dgn_graph_build's output).  Workspace: dgn_graph_build_workspace_bytes().  */
+int dgn_graph_build_cuts(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, const int32_t* dst_csr, int32_t* blk_cut,
+                         int32_t* gap_out, void* ws, size_t ws_bytes, void* stream);
 int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr, int32_t* csc_ptr, int32_t* csc_pos,
                         int32_t* csc_order, void* ws, size_t ws_bytes, void* stream);
 

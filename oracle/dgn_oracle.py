@@ -267,11 +267,14 @@ def _pretrans_messages(sd, prefix, h, e, src, dst, edge_features):
 
 
 def layer_forward(type_net: str, sd: Dict[str, torch.Tensor], cfg: dict, src, dst, num_nodes,
-                  eig, h, e, snorm_n, training: bool = True) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                  eig, h, e, snorm_n, training: bool = True, dropout=None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """Forward of ``DGNLayer(...).model`` for a state_dict in the reference's layout.
 
     cfg keys: aggregators (str), scalers (str), avg_log, graph_norm, batch_norm, residual,
-    edge_features, towers, divide_input; dropout is taken as 0 (parity runs).
+    edge_features, towers, divide_input; dropout is taken as 0 (parity runs) unless ``dropout = (p, keep)`` is
+    given for a simple / complex layer: the layer's last op ``F.dropout(h, p, training)`` (dgn_layer.py:130, :201)
+    with the Bernoulli draw replaced by the given keep mask [N, out_dim] -- ``h * keep / (1 - p)``, F.dropout's own
+    arithmetic (torch: ``input * mask * (1 / (1 - p))``).
     Follows dgn_layer.py:178-202 (simple), :103-132 (complex), :254-276 + :309-325 (towers).
     Returns (output, updated BN running stats).
     """
@@ -290,12 +293,18 @@ def layer_forward(type_net: str, sd: Dict[str, torch.Tensor], cfg: dict, src, ds
             y = torch.relu(y)
         return y
 
+    def drop(y):
+        if dropout is None or not training:
+            return y
+        p_drop, keep = dropout
+        return y * keep.to(y.dtype) * (1.0 / (1.0 - p_drop))
+
     if type_net == "simple":
         agg = aggregate_graph(src, dst, num_nodes, h[src], eig, h, aggs, scalers, avg_log)
         y = tail("", _mlp(sd, "posttrans", agg), relu=True)
         if cfg["residual"] and y.shape[1] == in_dim:
             y = h + y
-        return y, stats
+        return drop(y), stats
 
     if type_net == "complex":
         msg = _pretrans_messages(sd, "", h, e, src, dst, cfg.get("edge_features"))
@@ -303,7 +312,7 @@ def layer_forward(type_net: str, sd: Dict[str, torch.Tensor], cfg: dict, src, ds
         y = tail("", _mlp(sd, "posttrans", torch.cat([h, agg], dim=1)), relu=True)
         if cfg["residual"] and y.shape[1] == in_dim:
             y = h + y
-        return y, stats
+        return drop(y), stats
 
     if type_net == "towers":
         towers = cfg.get("towers", 5)

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from dgn_amd import _lib
     # sizes implied by include/dgn_hip.h on LP64
     assert C.sizeof(_lib.DgnChannel) == 16
-    assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2 + 8 + 8 + 8                        # (+ max_in_degree padded, n_src, row_base)
+    assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2 + 8 + 8 + 8 + 8 + 8                # (+ max_in_degree padded, n_src, row_base, blk_cut, blk_gap padded)
     assert C.sizeof(_lib.DgnAggSpec) == 4 * (1 + 16 + 16 + 1 + 1 + 4 + 1 + 1 + 1 + 1 + 1) + 8
     assert C.sizeof(_lib.DgnMsg) == 8 * 9 + 8 + 8                               # (+ edge_type, n_edge_types padded)
     assert C.sizeof(_lib.DgnMsgGrad) == 8 * 8 + 8                                # (+ accumulate, padded)

@@ -1,0 +1,188 @@
+"""Block backward of the sweep (csrc/dgn_agg_block.hpp; DgnGraph.blk_cut / blk_gap): one wave owns a run of whole graphs of the
+batch and accumulates d x_src in its LDS rows instead of staging an [E, F] per-edge gradient row.  Checked here:
+the closed cuts against a numpy restatement; the gradients against the staged two-phase scatter (same per-edge rows, same summation
+order: bit-identical unless d x_in aliases d x_src) on the list / layout of every layer type, with isolated nodes, long rows, ragged
+boundaries, several block sizes; run-to-run reproducibility; against the oracle (the reference's autograd through
+nets/dgn_layer.py:183-186).  The oracle suites of the other files run with the block backward ON (its default)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda")
+
+
+def _cuts_numpy(src, dst, N):
+    diff = np.zeros(N + 2, dtype=np.int64)
+    a, b = np.minimum(src, dst), np.maximum(src, dst)
+    m = a < b
+    np.add.at(diff, a[m] + 1, 1)
+    np.add.at(diff, b[m] + 1, -1)
+    cross = np.cumsum(diff)[: N + 1]
+    closed = cross == 0
+    last = np.maximum.accumulate(np.where(closed, np.arange(N + 1), 0))
+    cuts = np.flatnonzero(closed)
+    gap = int(np.diff(cuts).max()) if cuts.size > 1 else 0
+    return last, gap
+
+
+@pytest.mark.parametrize("kind", ["molecules", "chain_across", "isolated"])
+def test_closed_cuts_match_numpy(kind):
+    import dgn_amd
+    from dgn_amd import synth
+    if kind == "molecules":
+        b = synth.molecule_batch(300, seed=3, laplacian_eig=False)
+        src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    elif kind == "chain_across":      # an edge between two neighbouring graphs: that boundary is not a closed cut
+        b = synth.molecule_batch(50, seed=4, laplacian_eig=False)
+        src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+        n0 = int(b["sizes"][0])
+        src = torch.cat([src, torch.tensor([n0 - 1])])
+        dst = torch.cat([dst, torch.tensor([n0 + 2])])
+    else:                             # isolated nodes: every one of them is a graph of its own; chains of 21 nodes
+        N = 500
+        src = torch.tensor([i for i in range(100) if i % 21 != 20])
+        dst = src + 1
+    g = dgn_amd.DGNGraph(src.to(_dev()), dst.to(_dev()), N)
+    attached = g.ensure_blocks(True)
+    cut, gap = g._blk
+    last, gap_ref = _cuts_numpy(src.numpy(), dst.numpy(), N)
+    assert gap == gap_ref
+    np.testing.assert_array_equal(cut.cpu().numpy(), last)
+    from dgn_amd.graph import BLOCK_MAX_GAP
+    assert attached == (0 < gap <= BLOCK_MAX_GAP)            # (two molecules joined by an edge can exceed a wave's block)
+    if attached:
+        assert g.c_graph.blk_gap == gap and g.c_graph.blk_cut == cut.data_ptr()
+    assert not g.ensure_blocks(False) and not g.c_graph.blk_cut and g.c_graph.blk_gap == 0
+
+
+def _case(case):
+    import dgn_amd
+    from dgn_amd.dgn_layer import X_IN_NAME
+    if case == "towers":          # headline list: P|Q messages, tower-major, h_in pass-through block, aux table
+        return 70, 5, dgn_amd.make_plan(["mean", "max", "min", "dir1-av", "dir1-dx", X_IN_NAME], ["identity"]), True
+    if case == "complex":
+        return 70, 1, dgn_amd.make_plan(["mean", "max", "min", "dir1-dx", "dir1-av", X_IN_NAME], ["identity"]), True
+    if case == "simple":          # x_src = x_in = h: d x_in joins d x_src in the LDS rows
+        return 76, 1, dgn_amd.make_plan(["mean", "dir1-dx-no-abs"], ["identity"]), False
+    if case == "simple_hiv":
+        return 70, 1, dgn_amd.make_plan(["mean", "max", "min", "dir1-dx", "dir1-av"], ["identity"]), False
+    if case == "cifar":
+        return 66, 1, dgn_amd.make_plan(["mean", "dir1-dx", "dir2-dx"], ["identity"]), False
+    if case == "cifar_complex":
+        return 66, 1, dgn_amd.make_plan(["mean", "dir1-dx", "dir2-dx", X_IN_NAME], ["identity"]), True
+    raise KeyError(case)
+
+
+def _grads(graph, plan, F_, T, pair, X, PQ, ct_seed=1):
+    from dgn_amd.ops import directional_aggregate
+    dev = _dev()
+    x = X.to(dev).requires_grad_(True)
+    if pair:
+        pq = PQ.to(dev).requires_grad_(True)
+        y = directional_aggregate(graph, plan, 1.1, x_pair=pq, x_in=x, n_towers=T, tower_major=T > 1)
+        leaves = [pq, x]
+    else:
+        y = directional_aggregate(graph, plan, 1.1, x_src=x, x_in=x)
+        leaves = [x]
+    ct = torch.randn(y.shape, generator=torch.Generator().manual_seed(ct_seed)).to(dev)
+    return y, torch.autograd.grad(y, leaves, ct)
+
+
+@pytest.mark.parametrize("lds_kb", ["13", "11", "24"])
+@pytest.mark.parametrize("case", ["towers", "complex", "simple", "simple_hiv", "cifar", "cifar_complex"])
+def test_block_backward_matches_staged(monkeypatch, case, lds_kb):
+    monkeypatch.setenv("DGN_BLK_LDS_KB", lds_kb)
+    monkeypatch.setenv("DGN_BLK_MIN_NODES", "0")
+    run_matches_staged(case)
+
+
+def run_matches_staged(case):
+    import dgn_amd
+    from dgn_amd import ops, synth
+    dev = _dev()
+    b = synth.molecule_batch(257, seed=17, laplacian_eig=False)
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    # two isolated nodes and one node with 9 in-edges from the LAST graph appended (per-row fallback inside the grouped kernel)
+    last0 = N - int(b["sizes"][-1])
+    hub = N + 2
+    src = torch.cat([src, torch.arange(last0, last0 + 9)])
+    dst = torch.cat([dst, torch.full((9,), hub)])
+    N = N + 3
+    F_, T, plan, pair = _case(case)
+    gen = torch.Generator().manual_seed(8)
+    eig = torch.randn(N, 4, generator=gen)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    X, PQ = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen)
+    ops.BLOCK_BACKWARD = False
+    y_ref, ref = _grads(graph, plan, F_, T, pair, X, PQ)
+    assert not graph.c_graph.blk_cut
+    ops.BLOCK_BACKWARD = True
+    y, got = _grads(graph, plan, F_, T, pair, X, PQ)
+    assert graph.c_graph.blk_cut, "the block description was not attached"
+    assert torch.equal(y, y_ref)
+    again = _grads(graph, plan, F_, T, pair, X, PQ)[1]
+    for a, r, a2 in zip(got, ref, again):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, a2), "the block backward is not run-to-run reproducible"
+        if pair:
+            assert torch.equal(a, r), (case, float((a - r).abs().max()))          # the same adds in the same order
+        else:                                                                      # d x_in joins d x_src in another position of the sum
+            scale = float(r.abs().max())
+            assert float((a - r).abs().max()) <= 2e-6 * scale, (case, float((a - r).abs().max()), scale)
+
+
+def test_graphs_the_block_backward_does_not_take():
+    """k-NN batches (8 in-edges per row, graphs of 85-150 nodes) keep the staged backward: no block description is attached."""
+    import dgn_amd
+    from dgn_amd import synth
+    b = synth.knn_batch(6, seed=9)
+    g = dgn_amd.DGNGraph(b["src"].to(_dev()), b["dst"].to(_dev()), int(b["num_nodes"]))
+    assert not g.ensure_blocks(True) and not g.c_graph.blk_cut
+
+
+@pytest.mark.parametrize("kind", ["simple", "towers"])
+def test_block_backward_layer_vs_oracle(kind, monkeypatch):
+    """Whole layers (one C call per direction) with the block backward on, against the oracle's autograd."""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    from oracle import dgn_oracle as orc
+    dev = _dev()
+    monkeypatch.setenv("DGN_DC_MIN_NODES", "0")
+    monkeypatch.setenv("DGN_BLK_MIN_NODES", "0")
+    b = synth.molecule_batch(40, seed=11)
+    src, dst, N, eig, snorm = b["src"], b["dst"], int(b["num_nodes"]), b["eig"], b["snorm_n"]
+    F_ = 70 if kind == "towers" else 76
+    aggs = "mean max min dir1-av dir1-dx" if kind == "towers" else "mean dir1-dx-no-abs"
+    scalers = "identity amplification attenuation"
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, aggs, scalers, {"log": torch.tensor(1.2)}, kind, True, towers=5,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.2), graph_norm=True, batch_norm=True, residual=True, towers=5,
+               divide_input=True, edge_features=False)
+    h = torch.randn(N, F_, generator=gen)
+    ct = torch.randn(N, F_, generator=gen)
+    ho = h.clone().requires_grad_(True)
+    yo, _ = orc.layer_forward(kind, sd, cfg, src, dst, N, eig, ho, None, snorm, training=True)
+    (yo * ct).sum().backward()
+    layer = layer.to(dev)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, snorm.to(dev))
+    (y * ct.to(dev)).sum().backward()
+    assert graph.c_graph.blk_cut, "the layer's backward did not attach the block description"
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(hd.grad.cpu().numpy(), ho.grad.numpy(), rtol=1e-4, atol=1e-4 * float(ho.grad.abs().max()))

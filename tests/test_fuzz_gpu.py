@@ -66,6 +66,7 @@ def test_grouped_backward_sweep(monkeypatch, seed):
 
     def run(rb):
         monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        monkeypatch.setenv("DGN_BLK_MIN_NODES", "1000000000")     # (the staged kernels against each other: the block backward has its own file)
         x = X.to(dev).requires_grad_(True)
         if pq_msg:
             pq = PQ.to(dev).requires_grad_(True)
