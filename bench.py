@@ -77,6 +77,14 @@ WORKLOADS = {
                gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
                hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
                graph_norm=False),      # configs/molecules_graph_classification_DGN_HIV.json:30
+    # the reference's shipped dropout (configs HIV / CIFAR10 json: "dropout": 0.3; nets/dgn_layer.py:130,201): the same layers with it on
+    "c3_drop": dict(desc="c3 with the CIFAR10 json's dropout 0.3 (bit-mask dropout kernels behind the whole-layer call)",
+                    gen=("knn", dict(n_graphs=128)), type_net="simple", hidden=65, aggregators="mean dir1-dx dir2-dx", scalers="identity",
+                    towers=1, dropout=0.3),
+    "c4_drop": dict(desc="c4 with the HIV json's dropout 0.3",
+                    gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
+                    hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
+                    graph_norm=False, dropout=0.3),
     # "also run a saturating mega-batch so the roofline fraction is not just launch latency"
     "c3_mega": dict(desc="CIFAR10-superpixel-like, 8192 graphs in one batch (8-NN rows at a saturating size), layer as c3",
                     gen=("knn", dict(n_graphs=8192)), type_net="simple", hidden=65,
@@ -296,8 +304,9 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     torch.manual_seed(0)
     avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
     edge_dim = wl.get("edge_dim", 0)
-    layer = dgn_amd.DGNLayer(F_, F_, 0.0, wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
-                             wl["type_net"], True, towers=wl["towers"], edge_features=edge_dim > 0, edge_dim=edge_dim).model.to(dev)
+    layer = dgn_amd.DGNLayer(F_, F_, wl.get("dropout", 0.0), wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"],
+                             {"log": torch.tensor(avg_log)}, wl["type_net"], True, towers=wl["towers"], edge_features=edge_dim > 0,
+                             edge_dim=edge_dim).model.to(dev)
     layer.train()
     gen = torch.Generator(device=dev).manual_seed(rank)
     h = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
@@ -447,9 +456,10 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     # the timed op is one dgn_agg_forward / dgn_agg_backward call: forward = agg_fwd_short (4 rows per wave, short
     # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
     # atomic-free scatter)
-    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "seg_sum_rows"]}[dom]
+    # -- or, on batches of small graphs from 131 072 nodes on, agg_bwd_block ALONE (one wave per run of whole graphs, d x_src in LDS)
+    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "seg_sum_rows", "agg_bwd_block"]}[dom]
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
-             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_short | agg_bwd_rows, + seg_sum_rows)"}[dom]
+             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_block | agg_bwd_short + seg_sum_rows | agg_bwd_rows + seg_sum_rows)"}[dom]
     triad = hbm_triad_GBps(dev)
     # The launched list carries the h_in pass-through block of the complex / towers layers as one more "aggregator"
     # (A = survey's A + 1: the sweep really writes that block).  The same launch priced with SURVEY 8(d)'s own A:
@@ -853,7 +863,7 @@ def run_extras(args, dev):
     # default: the BASELINE five (c2 is the headline); everything else behind --all-extras
     plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c5", 3, 1)]
     if args.all_extras:
-        plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
+        plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
                 ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30),
                 ("c5", 3, 1)]
     for name, steps, warmup in plan:

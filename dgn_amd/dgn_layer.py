@@ -110,11 +110,27 @@ def _slot_dst(graph: DGNGraph) -> torch.Tensor:
     return graph._dst_slots
 
 
+_DROP_STATE = {}     # device -> [seed tensor (device int64 scalar, drawn ONCE from torch's generator of that device), calls so far]
+
+
 def _dropout(x, p, training):
-    """F.dropout of the reference's tails; CUDA fp32 tensors through the bit-mask kernels (ops.dropout), anything else through torch."""
+    """F.dropout of the reference's tails; CUDA fp32 tensors through the bit-mask kernels (ops.dropout), anything else through torch.
+    One Philox key per device for the life of the process (so ``torch.manual_seed`` BEFORE the first training step fixes every mask of
+    the run) and a call counter as the stream offset: no per-call seed kernel -- at the reference's batch sizes the layer is
+    launch-bound and a ``torch.randint`` per layer call costs as much as the dropout itself."""
     if training and p > 0 and x.is_cuda and x.dtype == torch.float32:
-        return _ops.dropout(x, p, True)
+        st = _DROP_STATE.get(x.device)
+        if st is None:
+            st = _DROP_STATE[x.device] = [torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device), 0]
+        st[1] += 1
+        return _ops.dropout(x, p, True, seed=st[0], offset=st[1])
     return F.dropout(x, p, training=training)
+
+
+def reset_dropout_state():
+    """Forget the per-device Philox keys (the next dropout draws new ones from torch's generators: call after ``torch.manual_seed``
+    to replay a run's masks)."""
+    _DROP_STATE.clear()
 
 
 class EdgeTypeFeatures:

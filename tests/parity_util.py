@@ -1,0 +1,41 @@
+"""Shared parity criterion of the layer-level oracle tests, WITH its bookkeeping: an entry passes when it is within
+tolerance of the fp32 oracle (the reference's own arithmetic), or -- the escape clause -- as close to the fp64 oracle as the fp32 oracle
+itself is (x4): max / min / |.| routings flip between fp32 evaluations where two messages tie or a residual sits on zero, in the
+reference as much as here.  Every call REPORTS the achieved maximum error and how many entries needed the escape clause (pytest -rA
+shows the lines) -- apart from the entries on which the fp32 oracle itself left its fp64 evaluation by more than the tolerance, which
+are reported as the oracle's flips -- and asserts that they are at most 0.5 % of the tensor: a regression from 3e-6 to 1.9e-5, or a kernel that leans on
+the clause, no longer passes silently.  Tensors whose true value is numerically zero everywhere (the gradient of a bias in front of a
+BatchNorm) are exempt from the fraction: both evaluations return rounding noise there, entry by entry unrelated."""
+import torch
+
+REPORT = []
+MAX_ESCAPE_FRACTION = 0.005
+
+
+def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True):
+    """``|ours - r32| <= atol * scale + rtol * |r64|`` per entry (scale = max(1, max|r64|) unless given), or the fp64 clause."""
+    a, r32, r64 = ours.detach().cpu().double(), r32.detach().cpu().double(), r64.detach().cpu().double()
+    scale = abs_scale if abs_scale is not None else max(1.0, float(r64.abs().max()) if r64.numel() else 1.0)
+    tol = atol * scale + rtol * r64.abs()
+    ref_err = float((r32 - r64).abs().max()) if r64.numel() else 0.0
+    ok_ref = (a - r32).abs() <= tol
+    ok_f64 = (a - r64).abs() <= tol + 4 * ref_err
+    bad = ~(ok_ref | ok_f64)
+    # entries where the fp32 ORACLE itself is off its fp64 evaluation by more than the tolerance (a max / min / |.| routing that flipped
+    # in the reference's own arithmetic: CPU thread count and summation order move them) are the oracle's, not ours: counted apart
+    oracle_flip = (r32 - r64).abs() > tol
+    flips = int((~ok_ref & ok_f64 & oracle_flip).sum())
+    escaped = int((~ok_ref & ok_f64 & ~oracle_flip).sum())
+    n = a.numel()
+    err32 = float((a - r32).abs().max()) if n else 0.0
+    err64 = float((a - r64).abs().max()) if n else 0.0
+    line = (f"PARITY {name}: n={n} max|ours-fp32 oracle|={err32:.3e} max|ours-fp64 oracle|={err64:.3e} oracle's own fp32 error={ref_err:.3e} "
+            f"scale={scale:.3g} escaped={escaped} ({100.0 * escaped / max(n, 1):.3f} %) oracle_fp32_flips={flips}")
+    REPORT.append(line)
+    print(line)
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {n} entries off ({line})"
+    noise = exempt_noise and float(r64.abs().max() if n else 0.0) <= 1e3 * max(ref_err, 1e-12)
+    if not noise:
+        allowed = max(1, int(MAX_ESCAPE_FRACTION * n))
+        assert escaped <= allowed, f"{name}: {escaped} of {n} entries needed the fp64 clause (allowed {allowed}): {line}"
+    return escaped

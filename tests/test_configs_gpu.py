@@ -32,13 +32,10 @@ def _close(a, b, rtol, atol, msg=""):
 
 def _as_good(ours, ref32, ref64, rtol, atol, msg=""):
     """within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is (x4): std / max / |.| are
-    ill-conditioned where variances vanish or two messages tie, in the reference as much as here"""
-    ours, ref32, ref64 = (t.detach().cpu().double().numpy() for t in (ours, ref32, ref64))
-    if np.allclose(ours, ref32, rtol=rtol, atol=atol):
-        return
-    scale = max(1.0, float(np.abs(ref64).max()))
-    e_ours, e_ref = float(np.abs(ours - ref64).max()), float(np.abs(ref32 - ref64).max())
-    assert e_ours <= atol * scale + 4.0 * e_ref, f"{msg}: max err vs fp64 {e_ours:.3e}, oracle's own {e_ref:.3e}"
+    ill-conditioned where variances vanish or two messages tie, in the reference as much as here.  Counted, reported and bounded
+    (at most 0.5 % of the entries may need the fp64 clause) by parity_util.check."""
+    from parity_util import check
+    check(ours, ref32, ref64, msg or "tensor", rtol=rtol, atol=atol)
 
 
 @pytest.mark.parametrize("hub", [False, True], ids=["row-path", "hub-slices"])

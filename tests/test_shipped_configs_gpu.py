@@ -19,17 +19,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_grad(a, r32, r64, name):
-    """the headline test's criterion: within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is;
-    and never far from the fp64 evaluation"""
+    """the headline test's criterion: within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is -- counted,
+    reported and bounded by parity_util.check; and never far from the fp64 evaluation"""
+    from parity_util import check
+    check(a, r32, r64, name, rtol=1e-4, atol=2e-5)
     a, r32 = a.cpu().double(), r32.double()
     scale = max(1.0, float(r64.abs().max()))
-    tol = 2e-5 * scale + 1e-4 * r64.abs()
-    ok_ref = (a - r32).abs() <= tol
-    # (tensor-wide max of the reference's own error: a bias in front of a BatchNorm has a gradient that is exactly zero in exact
-    #  arithmetic, so every fp32 evaluation -- the reference's as much as ours -- returns its rounding noise there, entry by entry unrelated)
-    ok_f64 = (a - r64).abs() <= tol + 4 * float((r32 - r64).abs().max())
-    bad = ~(ok_ref | ok_f64)
-    assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {bad.numel()} entries off"
     # (a max / min / |.| routing that flips between fp32 and fp64 moves a gradient entry by O(weight): with O(1) weights the fp32
     #  REFERENCE itself is that far from fp64 on a few entries, so the bound carries the reference's own worst error)
     assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale + 4 * float((r32 - r64).abs().max()), f"{name}: not close to the fp64 evaluation"
@@ -74,10 +69,8 @@ def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch
     y = layer(graph, hd, None, batch["snorm_n"].to(dev))
     params = dict(layer.named_parameters())
     gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
-    yv = y.detach().cpu().double()
-    ok = ((yv - y32.detach().double()).abs() <= 2e-5 + 2e-5 * y32.detach().double().abs()) | \
-         ((yv - y64.detach()).abs() <= 2e-5 + 2e-5 * y64.detach().abs() + 4 * (y32.detach().double() - y64.detach()).abs())
-    assert bool(ok.all()), f"y: {int((~ok).sum())} entries off"
+    from parity_util import check
+    check(y, y32, y64, f"{type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
         _check_grad(a, r32, r64, k)
     for k, v in stats.items():
@@ -93,6 +86,43 @@ def test_c4_molhiv_simple_layer_vs_oracle(monkeypatch, scalers, min_rows):
     from dgn_amd import synth
     b = synth.molecule_batch(256, seed=41, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)      # bench.py's c4 generator, 256 graphs
     _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", scalers, False, b, min_rows)
+
+
+@ROUTES
+def test_c1_zinc_simple_hidden75_vs_oracle(monkeypatch, min_rows):
+    """BASELINE configs[0] at its OWN width: simple, hidden 75 (odd), mean dir1-dx-no-abs x the ZINC json's three
+    scalers, graph norm, BatchNorm, residual (configs/molecules_graph_regression_DGN_ZINC.json:26-34)."""
+    from dgn_amd import synth
+    b = synth.molecule_batch(200, seed=41, extra_bonds=3.9, eig_dim=6)
+    _layer_vs_oracle(monkeypatch, "simple", 75, "mean dir1-dx-no-abs", "identity amplification attenuation", True, b, min_rows)
+
+
+@ROUTES
+@pytest.mark.parametrize("type_net", ["simple", "complex"])
+def test_c3_cifar10_hidden65_vs_oracle(monkeypatch, type_net, min_rows):
+    """BASELINE configs[2] at its own width: hidden 65 (odd), mean dir1-dx dir2-dx, the json's identity scaler
+    (configs/superpixels_graph_classification_DGN_CIFAR10.json:23,32-33), k-NN graphs with eig = [0, x, y]."""
+    from dgn_amd import synth
+    b = synth.knn_batch(8, seed=41)
+    _layer_vs_oracle(monkeypatch, type_net, 65, "mean dir1-dx dir2-dx", "identity", True, b, min_rows)
+
+
+@pytest.mark.parametrize("type_net,F_,aggs", [("simple", 70, "mean max min dir1-dx dir1-av"), ("complex", 70, "mean max min dir1-av dir1-dx"),
+                                              ("towers", 70, "mean max min dir1-av dir1-dx")])
+def test_every_layer_type_on_the_default_routes_vs_oracle(monkeypatch, type_net, F_, aggs):
+    """tests/conftest.py lowers the thresholds of the degree-class posttrans and of the block backward so that the small oracle batches
+    run those routes; here every layer type at the library's DEFAULTS: folded posttrans, staged backward, the
+    Linears on whichever route the row count selects."""
+    import dgn_amd
+    from dgn_amd import synth
+    monkeypatch.setattr(dgn_amd.ops, "DC_MIN_NODES", 16384)
+    monkeypatch.delenv("DGN_DC_MIN_NODES", raising=False)
+    monkeypatch.delenv("DGN_BLK_MIN_NODES", raising=False)
+    b = synth.molecule_batch(150, seed=45, extra_bonds=3.9, eig_dim=6)
+    if type_net == "towers":
+        _towers_vs_oracle(monkeypatch, 70, 5, b)
+    else:
+        _layer_vs_oracle(monkeypatch, type_net, F_, aggs, "identity amplification attenuation", True, b, None)
 
 
 @ROUTES
@@ -114,10 +144,14 @@ def test_towers_layer_odd_tower_width_vs_oracle(monkeypatch, hidden, towers):
     """towers with an ODD per-tower width (45 / 5 = 9, 35 / 5 = 7): the padded message path of the towers layer."""
     import dgn_amd
     from dgn_amd import synth
-    from oracle import dgn_oracle as orc
     monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    _towers_vs_oracle(monkeypatch, hidden, towers, synth.molecule_batch(120, seed=7, extra_bonds=3.9, eig_dim=6))
+
+
+def _towers_vs_oracle(monkeypatch, hidden, towers, b):
+    import dgn_amd
+    from oracle import dgn_oracle as orc
     dev = torch.device("cuda")
-    b = synth.molecule_batch(120, seed=7, extra_bonds=3.9, eig_dim=6)
     src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
     aggs, scalers = "mean max min dir1-av dir1-dx", "identity amplification attenuation"
     avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
