@@ -77,6 +77,10 @@ WORKLOADS = {
                gen=("molecules", dict(n_graphs=2048, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple",
                hidden=70, aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1,
                graph_norm=False),      # configs/molecules_graph_classification_DGN_HIV.json:30
+    # SURVEY 8(f) rank 1 / VERDICT r03 item 4: the C5 graph through a whole simple LAYER forward (sweep -> posttrans 3072 -> 128 -> tail)
+    "c5_layer": dict(desc="power-law 10M / 200M, DGN simple layer forward (no grad): 8 aggregators x 3 scalers, hidden 128, posttrans + BatchNorm(eval) + ReLU + residual",
+                     gen=("powerlaw", dict(num_nodes=10_000_000, num_edges=200_000_000)), type_net="layer_fwd", hidden=128,
+                     aggregators="mean max min sum std dir1-dx dir2-dx dir3-dx", scalers="identity amplification attenuation", towers=1),
     # the reference's shipped dropout (configs HIV / CIFAR10 json: "dropout": 0.3; nets/dgn_layer.py:130,201): the same layers with it on
     "c3_drop": dict(desc="c3 with the CIFAR10 json's dropout 0.3 (bit-mask dropout kernels behind the whole-layer call)",
                     gen=("knn", dict(n_graphs=128)), type_net="simple", hidden=65, aggregators="mean dir1-dx dir2-dx", scalers="identity",
@@ -613,6 +617,61 @@ def run_c5(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
     return result, None
 
 
+def run_c5_layer(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
+    """The C5 graph through a WHOLE simple layer forward (nets/dgn_layer.py:178-202 without gradients): sweep with the scalers folded
+    behind posttrans ([N, 8 x 128] aggregates), the folded posttrans product (1024 -> 3 x 128), scale-combine + BatchNorm (running
+    statistics) + ReLU + residual.  Reported with the bytes a FUSED layer would have to move (no aggregate block written or read:
+    E (4 + 4F + 4Ku) + N (4 + 4Ku + 4F + 4F)) and with the product's MFMA time, which is what bounds it."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    kw = dict(wl["gen"][1])
+    kw["num_nodes"], kw["num_edges"] = int(kw["num_nodes"] * args.scale), int(kw["num_edges"] * args.scale)
+    indptr, src, eig = synth.powerlaw_csr(device=dev, seed=0, **kw)
+    graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    del indptr
+    N, E, F_ = graph.num_nodes, graph.num_edges, wl["hidden"]
+    avg_log = float(graph.log_deg.mean().item())
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, False, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)}, "simple", True,
+                             towers=1, edge_features=False, edge_dim=0).model.to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(N, F_, device=dev, generator=gen)
+    plan = layer._kplan
+    lin = layer.posttrans.fully_connected[0].linear
+    A_ = len(layer.aggregators)
+    S_ = layer.plan.n_scalers
+    from dgn_amd.dgn_layer import node_linear
+    w_f = lin.weight.detach().reshape(F_, S_, A_ * F_).permute(1, 0, 2).reshape(S_ * F_, A_ * F_).contiguous()
+
+    def step():
+        with torch.no_grad():
+            return layer(graph, h, None, None)
+
+    parts = {}
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        ms = event_ms(step, steps, dev, warm=0)
+        agg = layer.aggregate(graph, h, plan, graph.ndata["eig"])
+        parts["sweep (scalers folded: [N, 1024] aggregates written)"] = event_ms(lambda: layer.aggregate(graph, h, plan, graph.ndata["eig"]), steps, dev)
+        parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] = event_ms(lambda: node_linear(agg, w_f), steps, dev)
+        del agg
+    A, S, Ku, x, r = plan_model(dgn_amd.make_plan(wl["aggregators"].split(), wl["scalers"].split()))
+    fused_bytes = E * (4 + 4 * F_ + 4 * Ku) + N * (4 + 4 * Ku + 4 * F_ + 4 * F_)
+    unfused_bytes = E * (4 + 4 * F_ + 4 * Ku) + N * (4 + 4 * Ku + 4 * F_) + 2 * N * 4 * A * F_ + 2 * N * 4 * S * F_ + N * 4 * 2 * F_
+    flops = 2.0 * N * (A * F_) * (S * F_)
+    result = dict(ms_per_step=ms, value=E / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N, scaling="weak", parallelism="single GPU",
+                  roofline=dict(bound="mfma", kernel="posttrans product of the layer (tile_gemm / ts_gemm, v_mfma_f32_16x16x4_f32)",
+                                achieved=flops / (parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12,
+                                unit="TFLOP/s", frac=flops / (parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] * 1e-3) / MFMA_F32_PEAK, traffic=None,
+                                kernels={k: dict(ms=v) for k, v in parts.items()},
+                                model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, layer_flops=flops, fused_layer_bytes=fused_bytes,
+                                           unfused_layer_bytes=unfused_bytes, sweep_only_bytes_c5=algorithmic_bytes(N, E, F_, A, S, Ku, x, r)[0],
+                                           hbm_frac_on_fused_bytes=fused_bytes / (ms * 1e-3) / HBM_PEAK,
+                                           mfma_floor_ms=flops / MFMA_F32_PEAK * 1e3)))
+    return result, None
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -865,12 +924,12 @@ def run_extras(args, dev):
     if args.all_extras:
         plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
                 ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30),
-                ("c5", 3, 1)]
+                ("c5", 3, 1), ("c5_layer", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
         t0 = time.perf_counter()
         try:
-            runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
+            runner = run_c5 if wl["type_net"] == "op" else (run_c5_layer if wl["type_net"] == "layer_fwd" else run_layer_workload)
             res, batch = runner(args, wl, 0, 1, dev, steps=steps, warmup=warmup, tag=name)
             extra[name] = compact(res)
             extra[name]["config"] = wl["desc"]
@@ -1053,7 +1112,7 @@ def main():
         wl["aggregators"] = args.aggregators
     if args.scalers:
         wl["scalers"] = args.scalers
-    runner = run_c5 if wl["type_net"] == "op" else run_layer_workload
+    runner = run_c5 if wl["type_net"] == "op" else (run_c5_layer if wl["type_net"] == "layer_fwd" else run_layer_workload)
     res = runner(args, wl, rank, world, dev)
     if rank != 0:
         if torch.distributed.is_initialized():
@@ -1061,7 +1120,7 @@ def main():
         return
     result, batch = res
     backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
-    line = dict(metric="dgn_layer_fwd_bwd_edges_per_sec" if wl["type_net"] != "op" else "dgn_aggregation_fwd_edges_per_sec",
+    line = dict(metric={"op": "dgn_aggregation_fwd_edges_per_sec", "layer_fwd": "dgn_layer_fwd_edges_per_sec"}.get(wl["type_net"], "dgn_layer_fwd_bwd_edges_per_sec"),
                 value=result["value"], unit="edges/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                 ms_per_step=result["ms_per_step"], higher_is_better=True, scaling=result.get("scaling", "weak"), vs_baseline=None,
                 dtype="f32",
@@ -1074,7 +1133,7 @@ def main():
                                 f", flat-gradient all-reduce ({backend} = RCCL, {world} ranks)" if world > 1 else "single GPU"),
                             step=("edge weights + layer forward + backward" + (" + gradient all-reduce" if world > 1 else "")
                                   + (" (HIP graph replay)" if args.hipgraph else ""))
-                            if wl["type_net"] != "op" else "aggregation forward"),
+                            if wl["type_net"] not in ("op", "layer_fwd") else ("aggregation forward" if wl["type_net"] == "op" else "layer forward, no gradients")),
                 roofline=result.get("roofline"))
     if torch.distributed.is_initialized():
         line["rccl_world"] = dict(backend=backend, world_size=torch.distributed.get_world_size())

@@ -444,8 +444,13 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
             f4 wv[NT];
 #pragma unroll
             for (int q = 0; q < NT; ++q) wv[q] = *reinterpret_cast<const f4*>(wrow + 16 * q * kp + 16 * b);
+#ifdef DGN_EXP_MFMA_QUARTER
+            constexpr int SN = 1;                    // (what-if ablation: a quarter of the MFMA work, wrong results)
+#else
+            constexpr int SN = 4;
+#endif
 #pragma unroll
-            for (int s = 0; s < 4; ++s)              // s outer: consecutive MFMAs on one accumulator would wait for each other
+            for (int s = 0; s < SN; ++s)             // s outer: consecutive MFMAs on one accumulator would wait for each other
 #pragma unroll
                 for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], xv[s], acc[q], 0, 0, 0);
         }

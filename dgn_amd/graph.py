@@ -15,6 +15,7 @@ that the L layers (and all towers) of a forward pass share them.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import functools
@@ -312,8 +313,11 @@ class DGNGraph:
         batch, more than 3 edges per node on average -- the four-rows-per-wave kernels do not run there --, a component of more than
         BLOCK_MAX_GAP nodes) never get them: the staged backward runs.  Returns whether attached."""
         ok = False
+        # (the C side takes the block kernels from DGN_BLK_MIN_NODES nodes on -- default 131 072, below it one wave per graph under-fills
+        #  the chip --: smaller batches do not pay for the cut build and its read-back either)
+        min_nodes = int(os.environ.get("DGN_BLK_MIN_NODES", "131072"))
         if enabled and self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None \
-                and self.num_nodes > 0 and 0 < self.num_edges <= 3 * self.num_nodes and self.row_base == 0:
+                and self.num_nodes >= max(1, min_nodes) and 0 < self.num_edges <= 3 * self.num_nodes and self.row_base == 0:
             if "_blk" not in self.__dict__:
                 lib = _lib.load()
                 N, E, dev = self.num_nodes, self.num_edges, self.device
