@@ -260,10 +260,19 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // DGN_BWD_AUX=2: the three weight-gradient products go to a second stream and overlap the input-gradient chain including the
     // sweep: step 1.55 -> 1.51 ms on ZINC-12k, the co-running sweep stretching from 0.215 to 0.35 ms.  =1: the same with the sweep kept
     // alone: no gain.  Off by default: 3 % of the step against kernel times in a profile that no longer say what a kernel can do.
+    // Default: on INSIDE A STREAM CAPTURE of a small batch (<= 32 768 rows), where every kernel of the chain fills a fraction of the chip
+    // and is bound by its own launch-to-store latency: the reference's batch of 128 molecules replays in 0.180 instead of 0.191 ms.
     const char* aux_s = getenv("DGN_BWD_AUX");                  // (read per call: the bench switches it)
-    const bool aux_env = aux_s != nullptr && atoi(aux_s) != 0;
+    bool aux_env = aux_s != nullptr && atoi(aux_s) != 0;
+    if (!aux_s && d.N <= 32768) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        aux_env = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    }
     SideStream& ss = side_stream();
-    const bool aux = aux_env && fused_act && ss.init();
+    // (the stream and its events are created by the first small-batch call, i.e. by a warm-up step BEFORE any capture: creating them
+    //  inside a capture would invalidate it)
+    const bool ss_ready = (aux_env || d.N <= 32768) && !(aux_env && !ss.ok && aux_s == nullptr) ? ss.init() : ss.ok;
+    const bool aux = aux_env && fused_act && ss_ready && ss.ok;
     void* wstream = aux ? static_cast<void*>(ss.side) : stream;          // where the weight-gradient products go
     if (fused_act) {
         if (L->zmask) DGN_TRY(dgn_linear_forward_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
@@ -310,7 +319,7 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                                                (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
                                                dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), wstream));
     // (the sweep runs alone: co-running it with a weight gradient stretched it from 0.215 to 0.35 ms for a net 2 %)
-    const bool aux_over_sweep = aux_s != nullptr && atoi(aux_s) == 2;
+    const bool aux_over_sweep = aux_s ? atoi(aux_s) == 2 : true;          // (the automatic small-batch mode overlaps the sweep as well)
     if (aux && !aux_over_sweep && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
     // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
     const DgnMsg msg = sweep_msg(L, d);
