@@ -71,7 +71,9 @@ struct BlkPlan { int bin, rows; size_t lds; };
 inline bool blk_plan(BlkPlan& out, int64_t F, int gap) {
     const char* kb_env = getenv("DGN_BLK_LDS_KB");                  // (read per launch: the tests switch it)
     const size_t budget = (size_t)(kb_env ? atoi(kb_env) : 13) * 1024;
-    const int rcap = std::min((int)(budget / (4 * (size_t)F)), kBlkRowsMax);
+    // (at most 16 rows of bin beyond the straddling graph: narrow rows would otherwise give a wave 14 groups in a row -- zinc_json,
+    //  F = 46: 0.141 ms with 56-row blocks, 0.135 with 50)
+    const int rcap = std::min(std::min((int)(budget / (4 * (size_t)F)), kBlkRowsMax), gap + 15);
     const int bin = rcap - gap + 1;
     if (bin < 4) return false;
     out.bin = bin; out.rows = rcap;
