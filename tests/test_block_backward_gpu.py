@@ -110,12 +110,13 @@ def run_matches_staged(case):
     dev = _dev()
     b = synth.molecule_batch(257, seed=17, laplacian_eig=False)
     src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
-    # two isolated nodes and one node with 9 in-edges from the LAST graph appended (per-row fallback inside the grouped kernel)
+    # two isolated nodes and one node with 9 in-edges from the LAST graph appended (per-row fallback inside the grouped kernel), and a
+    # node with 70 in-edges from 7 of them (a multigraph row of more than one slot batch: the emit_range path with the LDS adds)
     last0 = N - int(b["sizes"][-1])
-    hub = N + 2
-    src = torch.cat([src, torch.arange(last0, last0 + 9)])
-    dst = torch.cat([dst, torch.full((9,), hub)])
-    N = N + 3
+    hub, dense = N + 2, N + 3
+    src = torch.cat([src, torch.arange(last0, last0 + 9), torch.arange(last0, last0 + 7).repeat(10)])
+    dst = torch.cat([dst, torch.full((9,), hub), torch.full((70,), dense)])
+    N = N + 4
     F_, T, plan, pair = _case(case)
     gen = torch.Generator().manual_seed(8)
     eig = torch.randn(N, 4, generator=gen)
