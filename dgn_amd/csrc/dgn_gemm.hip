@@ -76,7 +76,9 @@ WgPlan wgrad_plan(int64_t M, int k, int n) {
     w.k_slice = w.kt * 16;
     w.k_slices = (k + w.k_slice - 1) / w.k_slice;
     const int64_t n_strips = (M + 15) / 16;
-    w.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus(), n_strips));
+    // (at least eight strips per workgroup: with one slot per strip a 15 k-row batch wrote 256 partial blocks and its finalize --
+    //  20 us on c3 -- cost more than the product itself)
+    w.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus(), (n_strips + 7) / 8));
     w.lds = (size_t)2 * 16 * ((w.nt * 16 + 4) + (w.kt * 16 + 4)) * sizeof(float);
     return w;
 }

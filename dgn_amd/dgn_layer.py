@@ -320,7 +320,7 @@ class DGNLayerSimple(nn.Module):
         (training-mode BatchNorm, single-affine posttrans, no dropout, enough rows for this library's own GEMM kernels)."""
         bn = self.batchnorm_h
         if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and h.is_cuda
-                and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and self.posttrans.is_single_affine()
+                and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WHOLE_LAYER_MIN_ROWS and self.posttrans.is_single_affine()
                 and bn_tail_supported([bn], h, True, bn.num_features)):
             return None
         lin = self.posttrans.fully_connected[0].linear
@@ -419,7 +419,7 @@ class DGNLayerComplex(nn.Module):
         bn = self.batchnorm_h
         id_slot = _identity_slot(self.plan.applied_scalers)
         if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and not self.edge_features
-                and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WIDE_MIN_ROWS and id_slot is not None
+                and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2 and h.shape[0] >= _ops.WHOLE_LAYER_MIN_ROWS and id_slot is not None
                 and self.posttrans.is_single_affine() and self.pretrans.is_single_affine() and bn_tail_supported([bn], h, True, bn.num_features)):
             return None
         pre, lin = self.pretrans.fully_connected[0].linear, self.posttrans.fully_connected[0].linear

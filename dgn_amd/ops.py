@@ -783,6 +783,10 @@ class _WideLinear(torch.autograd.Function):
 
 # Wide products (k or n beyond the streaming kernels' 160 columns, or odd widths) go to the dgn_gemm_* kernels from this many rows on.
 WIDE_MIN_ROWS = int(os.environ.get("DGN_WIDE_MIN_ROWS", "4096"))
+# The whole simple / complex layer as one C call per direction has NO row threshold of that kind: below 4096 rows the alternative is not
+# "the library's GEMM" but the per-op route with its torch glue (13 copies, 11 fills and two library GEMMs per step on the shipped ZINC
+# json layer at batch 128): measured 0.77 -> 0.39 ms eager and 0.229 -> 0.186 ms in a captured step (round 4).
+WHOLE_LAYER_MIN_ROWS = int(os.environ.get("DGN_WHOLE_LAYER_MIN_ROWS", "0"))
 
 
 def wide_linear_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:

@@ -36,6 +36,7 @@ def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch
     if min_rows is not None:
         monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", min_rows)
         monkeypatch.setattr(dgn_amd.ops, "WIDE_MIN_ROWS", min_rows)
+        monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER_MIN_ROWS", min_rows)      # (1 << 40: the per-op route on the library's GEMMs)
     dev = torch.device("cuda")
     src, dst, N = batch["src"], batch["dst"], int(batch["num_nodes"])
     avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
