@@ -76,9 +76,7 @@ WgPlan wgrad_plan(int64_t M, int k, int n) {
     w.k_slice = w.kt * 16;
     w.k_slices = (k + w.k_slice - 1) / w.k_slice;
     const int64_t n_strips = (M + 15) / 16;
-    // (at least eight strips per workgroup: with one slot per strip a 15 k-row batch wrote 256 partial blocks and its finalize --
-    //  20 us on c3 -- cost more than the product itself)
-    w.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus(), (n_strips + 7) / 8));
+    w.slots = (int)std::max<int64_t>(1, std::min<int64_t>(n_cus(), n_strips));
     w.lds = (size_t)2 * 16 * ((w.nt * 16 + 4) + (w.kt * 16 + 4)) * sizeof(float);
     return w;
 }
@@ -152,7 +150,16 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
         DGN_HIP_CHECK(hipGetLastError());
         return DGN_OK;
     }
-    const int slices = (n + 16 * kMaxNT - 1) / (16 * kMaxNT);
+    int slices = (n + 16 * kMaxNT - 1) / (16 * kMaxNT);
+    {   // Small batches: 2 970 rows are 24 row blocks -- 24 workgroups carrying the whole product on 24 of 256 CUs (23 us for 0.15 GFLOP on
+        // the shipped ZINC layer at batch 128).  More, narrower column slices until the grid covers the chip; a slice re-reads the
+        // block's A rows from L2, which at this size is nothing.
+        const int64_t n_blocks0 = (n_rows + 16 * kWaves - 1) / (16 * kWaves);
+        const int max_slices = (n + 15) / 16;
+        const int64_t want = (int64_t)n_cus() / std::max<int64_t>(1, n_blocks0);
+        static const bool no_split = getenv("DGN_GEMM_NO_COL_SPLIT") != nullptr;
+        if (!no_split && want > slices) slices = (int)std::min<int64_t>(want, max_slices);
+    }
     const int nt = ((n + slices - 1) / slices + 15) / 16;
     p.n_slice = nt * 16;
     const int gy = (n + p.n_slice - 1) / p.n_slice;

@@ -389,15 +389,25 @@ static __global__ __launch_bounds__(256) void ts_gemm_wgrad_finalize(int n, int 
     const int r = (int)(e / kk), c = (int)(e - (int64_t)r * kk);
     const int sl = c / k_slice, cc = c - sl * k_slice;
     const float* src = part + (int64_t)sl * slots * npad * kpad + (int64_t)r * kpad + cc;
+    // (sixteen partial blocks in flight, four running sums in slot order -- the same association as with four in flight: s_j takes the
+    //  slots q = j mod 4 --: with four loads per round trip the 256 slots of a 15 k-row batch made this kernel longer than the product)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int64_t st = (int64_t)npad * kpad;
     int q = 0;
-    for (; q + 3 < slots; q += 4) {
-        s0 += src[(int64_t)q * npad * kpad];
-        s1 += src[(int64_t)(q + 1) * npad * kpad];
-        s2 += src[(int64_t)(q + 2) * npad * kpad];
-        s3 += src[(int64_t)(q + 3) * npad * kpad];
+    for (; q + 15 < slots; q += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[(q + j) * st];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
     }
-    for (; q < slots; ++q) s0 += src[(int64_t)q * npad * kpad];
+    for (; q + 3 < slots; q += 4) {
+        s0 += src[(int64_t)q * st];
+        s1 += src[(int64_t)(q + 1) * st];
+        s2 += src[(int64_t)(q + 2) * st];
+        s3 += src[(int64_t)(q + 3) * st];
+    }
+    for (; q < slots; ++q) s0 += src[(int64_t)q * st];
     const float v = (s0 + s1) + (s2 + s3);
     if (c < k) dW[(int64_t)r * lddw + c] = v;
     else if (dbias) dbias[r] = v;

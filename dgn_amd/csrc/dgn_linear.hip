@@ -47,10 +47,17 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
+    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
+    {   // Small batches: 2 970 rows are 186 strips -- twelve 16-wave workgroups on twelve of 256 CUs.  Fewer waves per workgroup until
+        // the strips cover the chip (every workgroup stages the weights itself: 20 KB from L2).
+        static const bool keep = getenv("DGN_LINEAR_NO_SMALL") != nullptr;
+        const char* mw = getenv("DGN_LINEAR_SMALL_MIN_WAVES");
+        const int min_waves = mw ? atoi(mw) : 8;           // (4: no gain, 2 and 1: slower -- the weights are staged by too few threads)
+        while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves /= 2;
+    }
     const size_t lds = w_bytes + waves * strip_bytes;
     if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
     const int per_cu = std::max(1, std::min((int)(kLdsBudget / lds), 32 / waves));
-    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
     int groups = std::max(1, n_cus() * per_cu / p.T);
     groups = (int)std::min<int64_t>(groups, (n_strips + waves - 1) / waves);
     p.groups = groups;
