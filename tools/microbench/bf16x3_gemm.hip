@@ -405,11 +405,10 @@ float run_bf3(int64_t M, int K, int N, const float* A, const unsigned short* WP,
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     static const bool v1 = getenv("BF3_V1") != nullptr;
     auto launch = [&]() {
-        static const int ks = getenv("BF3_KS") ? atoi(getenv("BF3_KS")) : 2;
+        static const int ks = getenv("BF3_KS") ? atoi(getenv("BF3_KS")) : 1;       // 1: kernel v2 (the table of profiles/r04_bf16x3_gemm.txt), 2: v3
         if (v1) hipLaunchKernelGGL((bf3_gemm<NQ, TERMS>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
         else if (ks == 1) hipLaunchKernelGGL((bf3_gemm_v2<NQ, TERMS>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
-        else if (ks == 2) hipLaunchKernelGGL((bf3_gemm_v3<NQ, TERMS, 2>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
-        else hipLaunchKernelGGL((bf3_gemm_v3<NQ, TERMS, 4>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
+        else hipLaunchKernelGGL((bf3_gemm_v3<NQ, TERMS, 2>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);      // (KS = 4 spilled: measured once, not kept)
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipEventRecord(e0));
@@ -429,7 +428,7 @@ int main(int argc, char** argv) {
            "x3 ms", "x1 ms", "fp32 TF", "x6 TF", "speedup");
     for (const Shape& s : shapes) {
         const int64_t M = s.M; const int K = s.K, N = s.N;
-        const int ks = getenv("BF3_KS") ? atoi(getenv("BF3_KS")) : 2;
+        const int ks = getenv("BF3_KS") ? atoi(getenv("BF3_KS")) : 1;       // 1: kernel v2 (the table of profiles/r04_bf16x3_gemm.txt), 2: v3
         const int Np = (N + 15) / 16 * 16, Kp = (K + 32 * ks - 1) / (32 * ks) * (32 * ks);
         std::vector<float> hA((size_t)M * K), hW((size_t)N * K);
         unsigned h = 12345u;
