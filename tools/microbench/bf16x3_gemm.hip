@@ -397,6 +397,135 @@ __global__ __launch_bounds__(256) void bf3_gemm_v3(int64_t M, int K, int N, cons
     }
 }
 
+// v4: 128-row tiles (a wave owns 32 rows: RT = 2), so that four workgroups = sixteen waves stay resident per CU, and the A rows TWO
+// chunks ahead (two register sets, the k loop unrolled by two): twice the bytes in flight of v2.  W's planes as in v2.
+template <int NQ, int TERMS>
+__global__ __launch_bounds__(256) void bf3_gemm_v4(int64_t M, int K, int N, const float* __restrict__ A, int64_t lda, const unsigned short* __restrict__ WP,
+                                                   int Np, int Kp, float* __restrict__ C, int64_t ldc) {
+    constexpr int RT = 2;
+    __shared__ u4 Bs[2][3][NQ * 16][kKC / 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * (64 * RT) + 16 * RT * wave;
+    const int n0 = blockIdx.y * NQ * 16;
+    f4 acc[RT][NQ];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[rt][q] = f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NB = (NQ * 16 * 4 + 255) / 256;
+    const int KB = (K + kKC - 1) / kKC;
+    const float* arow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = A + min(row0 + 16 * rt + i16, M - 1) * lda;
+    struct ASet { f4 v[RT][2]; };
+    auto fetch_a = [&](ASet& a, int kc) {
+        const int k0 = min(kc * kKC + 8 * g, K - 8);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            a.v[rt][0] = *reinterpret_cast<const f4*>(arow[rt] + k0);
+            a.v[rt][1] = *reinterpret_cast<const f4*>(arow[rt] + k0 + 4);
+        }
+    };
+    u4 rb[3][NB];
+    auto fetch_b = [&](int kc) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = tid + 256 * j;
+                const int col = min(n0 + (idx >> 2), Np - 1), grp = idx & 3;
+                rb[pl][j] = *reinterpret_cast<const u4*>(WP + ((size_t)pl * Np + col) * Kp + kc * kKC + 8 * grp);
+            }
+    };
+    auto commit_b = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < NQ * 16 * 4) Bs[buf][pl][idx >> 2][idx & 3] = rb[pl][j];
+            }
+    };
+    s8 xa[RT][3];
+    auto split_a = [&](const ASet& a, int kc) {
+        const bool live = kc * kKC + 8 * g < K;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u4 hi, mid, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = live ? a.v[rt][e >> 1][2 * (e & 1)] : 0.f, x1 = live ? a.v[rt][e >> 1][2 * (e & 1) + 1] : 0.f;
+                unsigned h, m, l;
+                split2(x0, x1, h, m, l);
+                hi[e] = h; mid[e] = m; lo[e] = l;
+            }
+            xa[rt][0] = __builtin_bit_cast(s8, hi); xa[rt][1] = __builtin_bit_cast(s8, mid); xa[rt][2] = __builtin_bit_cast(s8, lo);
+        }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            s8 wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wb[pl] = __builtin_bit_cast(s8, Bs[buf][pl][16 * q + i16][g]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f4 a = acc[rt][q];
+                if (TERMS >= 6) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[rt][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2], xa[rt][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[rt][2], a, 0, 0, 0);
+                }
+                if (TERMS >= 3) {
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[rt][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[rt][1], a, 0, 0, 0);
+                }
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[rt][0], a, 0, 0, 0);
+                acc[rt][q] = a;
+            }
+        }
+    };
+    ASet a0, a1;
+    fetch_a(a0, 0);
+    fetch_b(0);
+    if (KB > 1) fetch_a(a1, 1);
+    commit_b(0);
+    split_a(a0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < KB; kc += 2) {
+        // chunk kc: operands split, W in buffer 0; set a1 holds chunk kc + 1 (in flight); request kc + 2 into a0
+        if (kc + 2 < KB) fetch_a(a0, kc + 2);
+        if (kc + 1 < KB) fetch_b(kc + 1);
+        mma(0);
+        if (kc + 1 >= KB) break;
+        commit_b(1);
+        split_a(a1, kc + 1);
+        __syncthreads();
+        if (kc + 3 < KB) fetch_a(a1, kc + 3);
+        if (kc + 2 < KB) fetch_b(kc + 2);
+        mma(1);
+        if (kc + 2 < KB) {
+            commit_b(0);
+            split_a(a0, kc + 2);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t r = row0 + 16 * rt + i16;
+        if (r < M) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int col = n0 + 16 * q + 4 * g;
+                if (col + 3 < N) __builtin_nontemporal_store(acc[rt][q], reinterpret_cast<f4*>(C + r * ldc + col));
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < N) C[r * ldc + col + e] = acc[rt][q][e];
+            }
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int NQ, int TERMS>
@@ -406,7 +535,9 @@ float run_bf3(int64_t M, int K, int N, const float* A, const unsigned short* WP,
     static const bool v1 = getenv("BF3_V1") != nullptr;
     auto launch = [&]() {
         static const int ks = getenv("BF3_KS") ? atoi(getenv("BF3_KS")) : 1;       // 1: kernel v2 (the table of profiles/r04_bf16x3_gemm.txt), 2: v3
-        if (v1) hipLaunchKernelGGL((bf3_gemm<NQ, TERMS>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
+        static const bool v4 = getenv("BF3_V4") != nullptr;
+        if (v4) hipLaunchKernelGGL((bf3_gemm_v4<NQ, TERMS>), dim3((unsigned)((M + 127) / 128), grid.y), dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
+        else if (v1) hipLaunchKernelGGL((bf3_gemm<NQ, TERMS>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
         else if (ks == 1) hipLaunchKernelGGL((bf3_gemm_v2<NQ, TERMS>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);
         else hipLaunchKernelGGL((bf3_gemm_v3<NQ, TERMS, 2>), grid, dim3(256), 0, 0, M, K, N, A, (int64_t)K, WP, Np, Kp, C, (int64_t)N);      // (KS = 4 spilled: measured once, not kept)
     };
