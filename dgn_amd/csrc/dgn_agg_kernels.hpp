@@ -2174,8 +2174,8 @@ inline bool is_hot_list(const AggParams& p) {
 int launch_agg_v1(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
 int launch_agg_v2(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
 int launch_agg_v4(const AggParams& p, unsigned tiles, hipStream_t stream, bool backward);
-// defined in dgn_agg_blk_v2.hip / _v4.hip (dgn_agg_block.hpp): DGN_OK, an error, or 1 = no block kernel for this launch
+// defined in dgn_agg_blk_v2.hip (dgn_agg_block.hpp): DGN_OK, an error, or 1 = no block kernel for this launch.  8-byte lanes only: with
+// 16-byte lanes (F > 128) a wave's 13 KB of LDS hold fewer rows than one molecule.
 int launch_agg_block_v2(const AggParams& p, int gap, hipStream_t stream);
-int launch_agg_block_v4(const AggParams& p, int gap, hipStream_t stream);
 
 }  // namespace dgn
