@@ -123,7 +123,12 @@ def _dropout(x, p, training):
         if st is None:
             st = _DROP_STATE[x.device] = [torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device), 0]
         st[1] += 1
-        return _ops.dropout(x, p, True, seed=st[0], offset=st[1])
+        y = _ops.dropout(x, p, True, seed=st[0], offset=st[1])
+        if torch.cuda.is_current_stream_capturing():
+            # inside a capture the call counter is frozen into the graph: the KEY moves instead, on the device, as part of the captured
+            # work -- every replay draws new masks (tests/test_dropout_gpu.py::test_captured_dropout_draws_new_masks_per_replay)
+            st[0].add_(1)
+        return y
     return F.dropout(x, p, training=training)
 
 

@@ -130,3 +130,31 @@ def test_layer_with_dropout_vs_oracle_with_the_same_mask(kind, F_, aggs, monkeyp
     params = dict(layer.named_parameters())
     for i, k in enumerate(names):
         close(params[k].grad, go32[1 + i], go64[1 + i], 1e-4 * max(1.0, float(go64[1 + i].abs().max())), k)
+
+
+def test_captured_dropout_draws_new_masks_per_replay():
+    """A HIP graph freezes host-side arguments: the layers' dropout therefore advances its Philox key ON THE DEVICE inside the captured
+    region, so that replays do not repeat one mask."""
+    import dgn_amd
+    from dgn_amd import ops
+    from dgn_amd.dgn_layer import _dropout
+    dev = torch.device("cuda")
+    dgn_amd.reset_dropout_state()
+    x = torch.ones(4096, 64, device=dev)
+    _dropout(x, 0.3, True)                              # (warm-up: creates the per-device key outside the capture)
+    out = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out.copy_(_dropout(x, 0.3, True))
+    torch.cuda.current_stream().wait_stream(s)
+    masks = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        masks.append((out > 0).clone())
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    for m in masks:
+        assert abs(float(m.float().mean()) - 0.7) < 0.01
