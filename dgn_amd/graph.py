@@ -318,7 +318,9 @@ class DGNGraph:
         min_nodes = int(os.environ.get("DGN_BLK_MIN_NODES", "131072"))
         if enabled and self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None \
                 and self.num_nodes >= max(1, min_nodes) and 0 < self.num_edges <= 3 * self.num_nodes and self.row_base == 0:
-            if "_blk" not in self.__dict__:
+            if "_blk" not in self.__dict__ and torch.cuda.is_current_stream_capturing():
+                enabled = False        # (the build reads the largest gap back: not inside a capture -- the staged backward is captured instead)
+            if enabled and "_blk" not in self.__dict__:
                 lib = _lib.load()
                 N, E, dev = self.num_nodes, self.num_edges, self.device
                 dst_csr = getattr(self, "dst_csr", None)
@@ -333,8 +335,9 @@ class DGNGraph:
                 _lib.check(lib.dgn_graph_build_cuts(N, E, self.src.data_ptr(), dst_csr.data_ptr(), cut.data_ptr(), gap.data_ptr(),
                                                     ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "dgn_graph_build_cuts")
                 self._blk = (cut, int(gap.item()))                                    # the one read-back
-            cut, gap = self._blk
-            ok = 0 < gap <= BLOCK_MAX_GAP
+            if enabled:
+                cut, gap = self._blk
+                ok = 0 < gap <= BLOCK_MAX_GAP
         if ok:
             self._c.blk_cut, self._c.blk_gap = cut.data_ptr(), gap
         else:
