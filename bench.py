@@ -904,7 +904,8 @@ def regression_warnings(results, headline=None):
     def check(name, mine, theirs):
         k_m, k_t = (mine or {}).get("kernels") or {}, (theirs or {}).get("kernels") or {}
         bad = [f"{k}: frac {k_m[k]['frac']:.3f} vs committed {k_t[k]['frac']:.3f}" for k in k_m
-               if k in k_t and k_m[k].get("frac") and k_t[k].get("frac") and k_m[k]["frac"] < 0.5 * k_t[k]["frac"]]
+               if k in k_t and k_m[k].get("frac") and k_t[k].get("frac") and k_m[k]["frac"] < 0.5 * k_t[k]["frac"]
+               and max(k_m[k].get("ms", 0), k_t[k].get("ms", 0)) >= 0.03]        # (10-us kernels double with the box's mood: not a signal)
         return bad
     for name, r in results.items():
         bad = check(name, r.get("roofline"), (ref.get("extra", {}).get(name) or {}).get("roofline"))
@@ -934,6 +935,18 @@ def run_extras(args, dev):
             extra[name] = compact(res)
             extra[name]["config"] = wl["desc"]
             extra[name]["steps"], extra[name]["warmup"] = steps, warmup
+            if name in ("c3", "c4") and wl["type_net"] not in ("op", "layer_fwd"):
+                # batch-128 / batch-2048 legs are host-bound when every kernel is launched from Python (the reference's own regime): the
+                # same step captured once into a HIP graph and replayed is what the GPU side costs
+                import copy
+                cap = copy.copy(args)
+                cap.hipgraph = True
+                try:
+                    rc, _ = run_layer_workload(cap, dict(WORKLOADS[name]), 0, 1, dev, steps=100, warmup=20, tag=name)
+                    extra[name]["captured_ms_per_step"] = rc["ms_per_step"]
+                except Exception as exc:
+                    extra[name]["captured_ms_per_step"] = None
+                    extra[name]["captured_error"] = f"{type(exc).__name__}: {exc}"[:200]
             if name == "c1" and not args.no_cpu_baseline:
                 # BASELINE configs[0] is quoted on the reference's CPU path: the same bounded CPU sample for it
                 extra[name]["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])), reps=3)
@@ -1022,7 +1035,7 @@ def compact_line(line):
             if "error" in e:
                 ex[name] = dict(error=str(e["error"])[:80])
                 continue
-            ee = {k: e[k] for k in ("ms_per_step", "value") if k in e}
+            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
             if e.get("cpu_baseline"):
