@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
     }
 }
 
-// g_bias[c] += sum of the G slots (one workgroup per column, fixed order)
-__global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const float* __restrict__ bias_part, float* __restrict__ g_bias) {
+// g_bias[c] += (set: =) sum of the G slots (one workgroup per column, fixed order)
+__global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const float* __restrict__ bias_part, float* __restrict__ g_bias, int set) {
     __shared__ float red[kThreads / 64];
     const int c = (int)blockIdx.x;
     float s = 0.f;
@@ -224,7 +224,10 @@ __global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const f
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) g_bias[c] += (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float v = (red[0] + red[1]) + (red[2] + red[3]);
+        g_bias[c] = set ? 0.f + v : g_bias[c] + v;          // (0.f + v: the bits of "zero-fill, then add")
+    }
 }
 
 int bwd_groups(int64_t n_nodes, int rows) { return (int)std::min<int64_t>((n_nodes + rows - 1) / rows, kMaxGroups); }
@@ -266,6 +269,13 @@ extern "C" size_t dgn_scale_combine_backward_workspace_bytes(int64_t n_nodes, in
 extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy,
                                           const float* scale, const float* row_scale, float* g_z, float* g_bias, void* ws,
                                           size_t ws_bytes, const DgnBnGrad* bn, void* stream) {
+    return dgn::scale_combine_backward_impl(n_nodes, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, g_bias, ws, ws_bytes, bn, stream, 0);
+}
+
+// set_bias: g_bias is WRITTEN (the whole-layer calls: no zero-fill launch in front), else accumulated into (the C ABI's contract)
+int dgn::scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy,
+                                     const float* scale, const float* row_scale, float* g_z, float* g_bias, void* ws,
+                                     size_t ws_bytes, const DgnBnGrad* bn, void* stream, int set_bias) {
     if (int rc = check_shape("dgn_scale_combine_backward", n_nodes, T, S, fo, scale != nullptr)) return rc;
     if (n_nodes == 0) return DGN_OK;
     const int wy = T * fo;
@@ -290,7 +300,7 @@ extern "C" int dgn_scale_combine_backward(int64_t n_nodes, int32_t T, int32_t S,
     const DgnBnGrad none{};
     hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part,
                        bn ? *bn : none, bn ? 1 : 0);
-    if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3(wy), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias);
+    if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3(wy), dim3(kThreads), 0, st, wy, G, (const float*)part, g_bias, set_bias);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }

@@ -18,6 +18,10 @@ constexpr int kXcds = 8;                         // MI355X: 8 XCDs, block b is d
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 int zero_rows_async(float* p, int64_t rows, int64_t width, int64_t ld, hipStream_t stream);   // capture-safe zero fill (dgn_abi.hip)
+// dgn_scale_combine_backward with the bias gradient WRITTEN instead of accumulated (set_bias != 0): the whole-layer calls (dgn_combine.hip)
+int scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy, const float* scale,
+                                const float* row_scale, float* g_z, float* g_bias, void* ws, size_t ws_bytes, const DgnBnGrad* bn,
+                                void* stream, int set_bias);
 
 #define DGN_HIP_CHECK(expr)                                         \
     do {                                                            \

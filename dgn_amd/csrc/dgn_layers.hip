@@ -293,12 +293,11 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
     DgnBnGrad bn{};
     bn.g_out = G->g_out; bn.y = L->y; bn.ld = d.fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
     bn.sums = sums; bn.relu = 1; bn.n_valid = L->n_valid;
-    DGN_TRY(zero_rows_async(G->g_b_post, 1, d.fo, d.fo, st));
     if (d.dc) {
         // g_t = snorm * (BatchNorm input gradient) [N, f_out]; per class: d agg = g_t W_class, G_class = g_t^T agg; g_wf = sum_class scale G_class
         const float* wct = L->wf + (size_t)2 * d.n * d.K + (size_t)DGN_DC_CLASSES * d.fo * d.K;
-        DGN_TRY(dgn_scale_combine_backward(d.N, 1, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
-                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
+        DGN_TRY(scale_combine_backward_impl(d.N, 1, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
+                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream, 1));
         static const int dc_stream = getenv("DGN_DC_STREAM") ? atoi(getenv("DGN_DC_STREAM")) : 0;      // (experiment: nontemporal d agg rows)
         DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, 1, g_z, d.fo, 0, wct, d.fo, (int64_t)d.fo * d.K, 0, nullptr, nullptr, g_agg, d.K, 0, dc_stream, stream));
         DgnDcLayout lay{};
@@ -306,8 +305,8 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, G->g_w_post, 0, &lay, ws + s.wg_ws,
                              dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo), stream));
     } else {
-        DGN_TRY(dgn_scale_combine_backward(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
-                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream));
+        DGN_TRY(scale_combine_backward_impl(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
+                                           dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream, 1));
         // posttrans: input gradient (on the transposed folded weight), weight gradient, un-folded into the reference's layout
         DGN_TRY(lin_fwd(d.N, d.n, d.K, g_z, wft, nullptr, g_agg, stream));
         DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));

@@ -297,9 +297,8 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     DgnBnGrad bn{};
     bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
     bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;
-    DGN_TRY(zero_rows_async(G->g_b_post, 1, d.Fo, d.Fo, st));
-    DGN_TRY(dgn_scale_combine_backward(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
-                                       dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream));
+    DGN_TRY(scale_combine_backward_impl(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
+                                       dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream, 1));
     // posttrans: the scaler expansion happens inside the two products.  DGN_FUSED_BACKWARD=1: the input-gradient product runs INSIDE
     // the backward sweep (dgn_layer_fused_backward: g_aggx is formed and consumed in LDS, bit-identical gradients).  Built, tested and
     // NOT the default: measured 0.53 ms against 0.36 ms for the two separate kernels on ZINC-12k -- a persistent
