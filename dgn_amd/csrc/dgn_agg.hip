@@ -373,7 +373,7 @@ extern "C" int dgn_agg_backward_aux(const DgnGraph* g, const DgnAggSpec* spec, c
     const unsigned tiles = (unsigned)((msg->F + kWave * vec - 1) / (kWave * vec));
     // Block backward (dgn_agg_block.hpp): batches of small graphs, define mode, one feature tile, 8-byte lanes, messages without
     // an edge term, the same node set on both sides; lists without a block kernel (anything but the baked-in ones) come back with 1
-    if (g->blk_cut && g->blk_gap > 0 && grads->accumulate == 0 && g->n_hub == 0 && tiles == 1 && vec == 2 && !msg->edge_type &&
+    if (g->blk_cut && g->blk_gap > 0 && g->n_edges > 0 && grads->accumulate == 0 && g->n_hub == 0 && tiles == 1 && vec == 2 && !msg->edge_type &&
         !msg->m_edge && p.g_src && p.x_src && p.n_src == p.n_nodes && !p.g_edge) {
         p.blk_cut = g->blk_cut;
         const int brc = launch_agg_block_v2(p, g->blk_gap, stream);

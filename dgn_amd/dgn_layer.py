@@ -146,10 +146,10 @@ class EdgeTypeFeatures:
     LDS): no [E, F] edge term is written or read, and the table's gradient is a reduction of the per-edge gradient rows the backward
     stages anyway.  Layers that cannot use the table (other pretrans depths, tables over ops.MAX_EDGE_TABLE floats) gather it."""
 
-    def __init__(self, table: torch.Tensor, types: torch.Tensor, validate: bool = True):
-        """``validate`` (default): one host sync checking every type against the table, the host-side twin of the device assert
-        ``nn.Embedding`` raises in the reference; pass False inside stream captures / static padded batches (types checked by the
-        loader once), where out-of-range types are CLAMPED by ``slot_types``."""
+    def __init__(self, table: torch.Tensor, types: torch.Tensor, validate: bool = False):
+        """``validate=True``: one host sync (two read-backs) checking every type against the table, the host-side twin of the device
+        assert ``nn.Embedding`` raises in the reference -- for loaders / tests, ONCE per dataset.  Off by default: the nets build this
+        object on every forward, the steps are launch-bound, and out-of-range types are CLAMPED by ``slot_types`` (memory-safe)."""
         if table.dim() != 2 or types.dim() != 1:
             raise ValueError("EdgeTypeFeatures: table [K, edge_dim], types [E]")
         self.table, self.types = table, types

@@ -176,8 +176,10 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale", "_blk"):
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale", "_blk", "_blk_tables"):
             self.__dict__.pop(k, None)
+        if hasattr(self, "_c"):
+            self._c.blk_cut, self._c.blk_gap = None, 0      # (the cut tensor is gone with "_blk": never leave its address behind)
 
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
         """CSR by destination through dgn_graph_build: one C call, one read-back of (max in-degree, hub rows)."""

@@ -8,18 +8,18 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-SUPPORTED_ACTIVATION_MAP = {"ReLU", "Sigmoid", "Tanh", "ELU", "SELU", "GLU", "LeakyReLU", "Softplus", "None"}
+_ACTIVATIONS = {n.lower(): getattr(nn, n) for n in ("ReLU", "Sigmoid", "Tanh", "ELU", "SELU", "GLU", "LeakyReLU", "Softplus")}
+SUPPORTED_ACTIVATION_MAP = set(c.__name__ for c in _ACTIVATIONS.values()) | {"None"}      # (the reference's public name, layers.py:4)
 
 
 def get_activation(activation):
-    """String (any case) or callable -> activation module, None for 'none' (layers.py:7-18)."""
-    if activation and callable(activation):
+    """Activation module for a name in any case, ``None`` for "none"; a callable passes through (layers.py:7-18).  Unknown names fail
+    the same assertion as the reference's lookup."""
+    if callable(activation):
         return activation
-    hits = [x for x in SUPPORTED_ACTIVATION_MAP if str(activation).lower() == x.lower()]
-    assert len(hits) == 1, "Unhandled activation function"
-    if hits[0].lower() == "none":
-        return None
-    return getattr(torch.nn.modules.activation, hits[0])()
+    key = str(activation).lower()
+    assert key == "none" or key in _ACTIVATIONS, "Unhandled activation function"
+    return None if key == "none" else _ACTIVATIONS[key]()
 
 
 class FCLayer(nn.Module):
@@ -33,19 +33,19 @@ class FCLayer(nn.Module):
                  device="cpu"):
         super().__init__()
         self.in_size, self.out_size, self.bias = in_size, out_size, bias
-        self.linear = nn.Linear(in_size, out_size, bias=bias).to(device)
-        self.dropout = nn.Dropout(p=dropout) if dropout else None
-        self.b_norm = nn.BatchNorm1d(out_size).to(device) if b_norm else None
+        self.linear = nn.Linear(in_size, out_size, bias=bias, device=device)
         self.activation = get_activation(activation)
-        self.init_fn = nn.init.xavier_uniform_
+        self.dropout = nn.Dropout(dropout) if dropout else None      # (the reference passes device= here and would raise: quirk #4)
+        self.b_norm = nn.BatchNorm1d(out_size, device=device) if b_norm else None
+        self.init_fn = init_fn or nn.init.xavier_uniform_
         self.reset_parameters()
 
     def reset_parameters(self, init_fn=None):
-        init_fn = init_fn or self.init_fn
-        if init_fn is not None:
-            init_fn(self.linear.weight, 1 / self.in_size)
-        if self.bias:
-            self.linear.bias.data.zero_()
+        """layers.py:94-99: the init function is called with ``1 / in_size`` as its second argument (xavier's gain); zero bias."""
+        with torch.no_grad():
+            (init_fn or self.init_fn)(self.linear.weight, 1.0 / self.in_size)
+            if self.linear.bias is not None:
+                self.linear.bias.zero_()
 
     def forward(self, x, residual=None):
         """``residual`` (not in the reference's signature): added after the whole layer; with a plain Linear ->
@@ -76,19 +76,17 @@ class FCLayer(nn.Module):
             h = node_linear(x, self.linear.weight, self.linear.bias)
         else:
             h = self.linear(x)
-        if self.activation is not None:
-            h = self.activation(h)
-        if self.dropout is not None:
-            h = self.dropout(h)
+        for stage in (self.activation, self.dropout):
+            if stage is not None:
+                h = stage(h)
         if self.b_norm is not None:
-            if h.shape[1] != self.out_size:
-                h = self.b_norm(h.transpose(1, 2)).transpose(1, 2)
-            else:
-                h = self.b_norm(h)
+            # (BatchNorm1d normalises dim 1: node features [N, F] as they are; an [B, N, F] input -- the reference's dense models,
+            #  layers.py:108-109 -- with the feature axis moved there and back)
+            h = self.b_norm(h) if h.dim() == 2 else self.b_norm(h.movedim(-1, 1)).movedim(1, -1)
         return h
 
-    def __repr__(self):
-        return f"{self.__class__.__name__} ({self.in_size} -> {self.out_size})"
+    def extra_repr(self):
+        return f"{self.in_size} -> {self.out_size}"
 
 
 class MLP(nn.Module):
@@ -98,18 +96,12 @@ class MLP(nn.Module):
                  dropout=0.0, mid_b_norm=False, last_b_norm=False, device="cpu"):
         super().__init__()
         self.in_size, self.hidden_size, self.out_size = in_size, hidden_size, out_size
-        self.fully_connected = nn.ModuleList()
-        if layers <= 1:
-            self.fully_connected.append(FCLayer(in_size, out_size, activation=last_activation, b_norm=last_b_norm,
-                                                device=device, dropout=dropout))
-        else:
-            self.fully_connected.append(FCLayer(in_size, hidden_size, activation=mid_activation, b_norm=mid_b_norm,
-                                                device=device, dropout=dropout))
-            for _ in range(layers - 2):
-                self.fully_connected.append(FCLayer(hidden_size, hidden_size, activation=mid_activation,
-                                                    b_norm=mid_b_norm, device=device, dropout=dropout))
-            self.fully_connected.append(FCLayer(hidden_size, out_size, activation=last_activation,
-                                                b_norm=last_b_norm, device=device, dropout=dropout))
+        # widths of the chain: in -> hidden x (layers - 1) -> out; every stage but the last takes the "mid" settings (layers.py:127-143)
+        n = max(int(layers), 1)
+        dims = [in_size] + [hidden_size] * (n - 1) + [out_size]
+        self.fully_connected = nn.ModuleList(
+            FCLayer(dims[i], dims[i + 1], activation=mid_activation if i < n - 1 else last_activation,
+                    b_norm=mid_b_norm if i < n - 1 else last_b_norm, dropout=dropout, device=device) for i in range(n))
 
     def is_single_affine(self) -> bool:
         """True when the MLP is exactly one Linear (+bias) with nothing after it."""
@@ -123,5 +115,5 @@ class MLP(nn.Module):
             x = fc(x)
         return x
 
-    def __repr__(self):
-        return f"{self.__class__.__name__} ({self.in_size} -> {self.out_size})"
+    def extra_repr(self):
+        return f"{self.in_size} -> {self.out_size}"
