@@ -14,8 +14,10 @@ The default workload is BASELINE.json configs[1]: ZINC-12k (all 12 000 molecules
 DGN towers (5 towers, hidden 70, mean/max/min/dir1-av/dir1-dx, 3 PNA scalers).  For N > 1 every rank
 processes its own 12k-molecule batch (weak scaling: seed 41 + rank), or -- ``--scaling strong`` -- its edge-balanced
 shard of ONE global batch (``dist.shard_by_edges``; SURVEY 8(e): ogbg-molhiv batch 2048 split over the ranks).
-The default single-GPU run also appends short sub-results for the other BASELINE configs (``extra``: c1, c3, c4,
-c2_b128, c5), each with its own roofline, so that one driver-run line carries every number DESIGN.md quotes.
+The default single-GPU run also appends short sub-results (``extra``) for the other BASELINE configs (c1, c3, c4, c5) and for the
+headline layer and the shipped ZINC json layer AT THE REFERENCE'S OWN BATCH SIZE (c2_b128, zinc_json_b128: 128 molecules, the graph-block
+route of csrc/dgn_blk_layer.hip), the batch-sized legs both eager and as a captured HIP graph (``captured_ms_per_step``); ``--all-extras``
+adds every other leg.
 
 Besides the contract keys the line carries
   roofline      the dominant aggregation kernel's algorithmic bytes / its measured launch duration
@@ -67,6 +69,9 @@ WORKLOADS = {
     "c2_b128": dict(desc="ZINC batch of 128 molecules, DGN towers (as c2)",
                     gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="towers", hidden=70,
                     aggregators="mean max min dir1-av dir1-dx", scalers="identity amplification attenuation", towers=5),
+    "c1_b128": dict(desc="ZINC batch of 128 molecules, DGN simple as c1 (BASELINE configs[0] at the reference's batch size)",
+                    gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="simple", hidden=75,
+                    aggregators="mean dir1-dx-no-abs", scalers="identity amplification attenuation", towers=1),
     "c1": dict(desc="ZINC-12k, DGN simple: hidden 75, mean dir1-dx-no-abs x 3 scalers",
                gen=("molecules", dict(n_graphs=12000, extra_bonds=3.9, eig_dim=6)), type_net="simple", hidden=75,
                aggregators="mean dir1-dx-no-abs", scalers="identity amplification attenuation", towers=1),
@@ -921,10 +926,10 @@ def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
     # default: the BASELINE five (c2 is the headline); everything else behind --all-extras (VERDICT r03 item 1)
-    plan = [("c1", 10, 3), ("c3", 10, 3), ("c4", 10, 3), ("c5", 3, 1)]
+    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1)]
     if args.all_extras:
         plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
-                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30),
+                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30),
                 ("c5", 3, 1), ("c5_layer", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
@@ -935,7 +940,7 @@ def run_extras(args, dev):
             extra[name] = compact(res)
             extra[name]["config"] = wl["desc"]
             extra[name]["steps"], extra[name]["warmup"] = steps, warmup
-            if name in ("c3", "c4") and wl["type_net"] not in ("op", "layer_fwd"):
+            if name in ("c3", "c4", "c2_b128", "zinc_json_b128", "c1_b128") and wl["type_net"] not in ("op", "layer_fwd"):
                 # batch-128 / batch-2048 legs are host-bound when every kernel is launched from Python (the reference's own regime): the
                 # same step captured once into a HIP graph and replayed is what the GPU side costs
                 import copy

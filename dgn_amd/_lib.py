@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -33,7 +33,9 @@ EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_byte
            "dgn_dense_layer_supported", "dgn_dense_layer_forward_workspace_bytes", "dgn_dense_layer_forward", "dgn_dense_layer_backward_workspace_bytes",
            "dgn_dense_layer_backward",
            "dgn_linear_bd_supported", "dgn_linear_bd_forward", "dgn_linear_bd_backward_input", "dgn_linear_bd_wgrad_workspace_bytes", "dgn_linear_bd_wgrad",
-           "dgn_dc_supported", "dgn_dc_wgrad_supported", "dgn_dc_fold", "dgn_dc_gemm", "dgn_dc_wgrad_workspace_bytes", "dgn_dc_wgrad")
+           "dgn_dc_supported", "dgn_dc_wgrad_supported", "dgn_dc_fold", "dgn_dc_gemm", "dgn_dc_wgrad_workspace_bytes", "dgn_dc_wgrad",
+           "dgn_block_layer_supported", "dgn_block_layer_param_grad_floats", "dgn_block_layer_forward_workspace_bytes", "dgn_block_layer_forward",
+           "dgn_block_layer_backward_workspace_bytes", "dgn_block_layer_backward")
 
 DGN_DC_CLASSES, DGN_DC_UNIT = 32, 64
 
@@ -114,6 +116,29 @@ class DgnDenseLayer(C.Structure):
 class DgnDenseGrads(C.Structure):
     _fields_ = [("g_out", C.c_void_p), ("g_h", C.c_void_p), ("g_w_pre", C.c_void_p), ("g_b_pre", C.c_void_p), ("g_w_post", C.c_void_p),
                 ("g_b_post", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p)]
+
+
+DGN_BLK_MAX_TOWERS = 8
+
+
+class DgnBlockTable(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("max_rows", C.c_int32), ("max_edges", C.c_int32), ("desc", C.c_void_p)]
+
+
+class DgnBlockLayer(C.Structure):
+    _fields_ = [("graph", C.POINTER(DgnGraph)), ("blocks", C.POINTER(DgnBlockTable)), ("spec", C.POINTER(DgnAggSpec)), ("channels", C.POINTER(DgnChannel)),
+                ("eig", C.c_void_p), ("ld_eig", C.c_int64), ("n_eig_cols", C.c_int32), ("log_deg", C.c_void_p),
+                ("type", C.c_int32), ("n_towers", C.c_int32), ("f_in", C.c_int32), ("f_out", C.c_int32), ("residual", C.c_int32),
+                ("momentum", C.c_float), ("eps", C.c_float), ("slope", C.c_float), ("h", C.c_void_p), ("snorm", C.c_void_p),
+                ("w_pre", C.POINTER(C.c_void_p)), ("b_pre", C.POINTER(C.c_void_p)), ("w_post", C.POINTER(C.c_void_p)), ("b_post", C.POINTER(C.c_void_p)),
+                ("gamma", C.POINTER(C.c_void_p)), ("beta", C.POINTER(C.c_void_p)), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("n_nbt", C.c_int32),
+                ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("dbg_agg", C.c_void_p), ("dbg_gagg", C.c_void_p)]
+
+
+class DgnBlockGrads(C.Structure):
+    _fields_ = [("g_out", C.c_void_p), ("g_h", C.c_void_p), ("g_params", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p)]
 
 
 class DgnError(RuntimeError):
@@ -312,6 +337,17 @@ def load() -> C.CDLL:
         lib.dgn_towers_layer_forward.argtypes = [C.POINTER(DgnTowersLayer), C.c_void_p]
         lib.dgn_towers_layer_backward.restype = C.c_int
         lib.dgn_towers_layer_backward.argtypes = [C.POINTER(DgnTowersLayer), C.POINTER(DgnTowersGrads), C.c_void_p]
+        lib.dgn_block_layer_supported.restype = C.c_int
+        lib.dgn_block_layer_supported.argtypes = [C.POINTER(DgnBlockLayer)]
+        lib.dgn_block_layer_param_grad_floats.restype = C.c_int64
+        lib.dgn_block_layer_param_grad_floats.argtypes = [C.POINTER(DgnBlockLayer)]
+        for name in ("dgn_block_layer_forward_workspace_bytes", "dgn_block_layer_backward_workspace_bytes"):
+            getattr(lib, name).restype = C.c_size_t
+            getattr(lib, name).argtypes = [C.POINTER(DgnBlockLayer)]
+        lib.dgn_block_layer_forward.restype = C.c_int
+        lib.dgn_block_layer_forward.argtypes = [C.POINTER(DgnBlockLayer), vp]
+        lib.dgn_block_layer_backward.restype = C.c_int
+        lib.dgn_block_layer_backward.argtypes = [C.POINTER(DgnBlockLayer), C.POINTER(DgnBlockGrads), vp]
         if lib.dgn_abi_version() != ABI_VERSION:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib

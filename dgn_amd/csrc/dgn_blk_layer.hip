@@ -1,0 +1,294 @@
+// Host side of the graph-block DGN layer (include/dgn_hip.h: dgn_block_layer_*; device code: dgn_blk_layer_kernels.hpp): the layer of a
+// batch at the reference's own batch size (128 graphs) as two launches forward and three backward.
+// Reference: realworld_benchmark/nets/dgn_layer.py:103-132 (complex), :178-202 (simple), :254-276 + :309-325 (towers).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "dgn_blk_layer_kernels.hpp"
+
+namespace dgn {
+namespace {
+
+using blk::Layout;
+using blk::P;
+
+constexpr size_t kLdsBytes = 160 * 1024;
+constexpr int kThreads = 256;
+
+inline int up4(int x) { return (x + 3) & ~3; }
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Dims {
+    int type, has_pre, mixing, relu;
+    int T, fi, fo, F, Fo, A, S, K, h_off, ld_pre, ld_post, n_ch;
+    int64_t N;
+    int n_blocks, R, Emax;
+    int off_tower, n_blk_param, n_tail_param;
+    int tail_rows, n_tail;
+};
+
+bool dims_of(const DgnBlockLayer* L, Dims& d, const char* fn) {
+    if (!L || !L->graph || !L->spec || !L->blocks) { set_error("%s: null layer / graph / spec / blocks", fn); return false; }
+    d.type = L->type;
+    if (d.type < 0 || d.type > 2) { set_error("%s: type %d (0 simple, 1 complex, 2 towers)", fn, d.type); return false; }
+    d.has_pre = d.type != 0; d.mixing = d.type == 2; d.relu = d.type != 2;
+    d.T = d.type == 2 ? L->n_towers : 1;
+    d.fi = L->f_in; d.fo = L->f_out;
+    if (d.T < 1 || d.T > DGN_BLK_MAX_TOWERS || (d.type == 2 && d.T < 2) || d.fi < 1 || d.fo < 1) { set_error("%s: bad tower count / widths", fn); return false; }
+    d.F = d.T * d.fi; d.Fo = d.T * d.fo;
+    d.A = L->spec->n_agg; d.S = L->spec->n_scalers; d.n_ch = L->spec->n_ch;
+    if (d.A < 1 || d.A > DGN_MAX_AGG || d.S < 1 || d.S > 3 || d.n_ch < 0 || d.n_ch > blk::kMaxCh) { set_error("%s: aggregator / scaler / channel counts outside this route", fn); return false; }
+    for (int a = 0; a < d.A; ++a)
+        if (L->spec->agg_op[a] < DGN_AGG_MEAN || L->spec->agg_op[a] >= DGN_AGG_X_IN) { set_error("%s: aggregator op %d", fn, L->spec->agg_op[a]); return false; }
+    if (d.n_ch > 0 && (!L->channels || !L->eig)) { set_error("%s: directional aggregators need channels and eig", fn); return false; }
+    d.K = d.A * d.fi; d.h_off = d.has_pre ? d.fi : 0;
+    d.ld_pre = 2 * d.fi; d.ld_post = d.h_off + d.S * d.K;
+    d.N = L->graph->n_nodes;
+    d.n_blocks = L->blocks->n_blocks; d.R = L->blocks->max_rows; d.Emax = L->blocks->max_edges;
+    if (d.N < 1 || d.n_blocks < 1 || d.R < 1 || !L->blocks->desc) { set_error("%s: empty batch / block table", fn); return false; }
+    if (d.F > kThreads || d.Fo > kThreads || d.Emax >= 65535) { set_error("%s: widths over %d columns / blocks of 65535 edges are outside this route", fn, kThreads); return false; }
+    d.off_tower = (d.has_pre ? d.fi * d.ld_pre + d.fi : 0) + d.fo * d.ld_post + d.fo;
+    d.n_blk_param = d.T * d.off_tower;
+    d.n_tail_param = d.mixing ? d.Fo * d.Fo + d.Fo : 0;
+    // tail kernels: 16 rows per wave; two waves per workgroup while that still gives every CU a workgroup, else four
+    d.tail_rows = d.N <= 32 * 256 ? 32 : 64;
+    d.n_tail = (int)((d.N + d.tail_rows - 1) / d.tail_rows);
+    return true;
+}
+
+// coefficient rows the aggregator list needs in the backward
+void coef_map(const DgnAggSpec* spec, int8_t (&cmap)[blk::CF_SLOTS], int& n_coef) {
+    bool need[blk::CF_SLOTS] = {};
+    for (int a = 0; a < spec->n_agg; ++a) {
+        const int op = spec->agg_op[a], ch = spec->agg_ch[a];
+        switch (op) {
+            case DGN_AGG_MEAN: case DGN_AGG_SUM: need[blk::CF_C0] = true; break;
+            case DGN_AGG_STD: case DGN_AGG_VAR: need[blk::CF_C0] = need[blk::CF_CV] = true; break;
+            case DGN_AGG_MAX: need[blk::CF_GMAX] = need[blk::CF_ARG] = true; break;
+            case DGN_AGG_MIN: need[blk::CF_GMIN] = need[blk::CF_ARG] = true; break;
+            case DGN_AGG_DIR_AV: need[blk::CF_CA0 + ch] = true; break;
+            default: need[blk::CF_CS0 + ch] = true; break;      // WSUM, DX, DX_NO_ABS
+        }
+    }
+    n_coef = 0;
+    for (int q = 0; q < blk::CF_SLOTS; ++q) cmap[q] = need[q] ? (int8_t)n_coef++ : (int8_t)-1;
+}
+
+// LDS plan of blk_forward / blk_backward; false: a block does not fit
+bool plan_lds(const Dims& d, const DgnAggSpec* spec, bool bwd, Layout& L, int& RC, int8_t (&cmap)[blk::CF_SLOTS]) {
+    int n_coef = 0;
+    coef_map(spec, cmap, n_coef);
+    const int R = d.R, E = std::max(d.Emax, 1);
+    for (int rc : {64, 48, 32, 16}) {
+        if (rc > 16 && rc >= R + 16) continue;              // (no point in a chunk a whole strip larger than the largest block)
+        int off = 0;
+        auto take = [&](int n) { const int at = off; off += up4(std::max(n, 0)); return at; };
+        L = Layout{};
+        L.ld_agg = d.T * d.K; L.ld_w = E; L.n_coef = n_coef;
+        L.hb = take(R * d.F);
+        L.pq = take(d.has_pre ? R * 2 * d.F : 0);
+        L.eig = take(R * d.n_ch);
+        L.ip = take(R + 1); L.cp = take(bwd ? R + 1 : 0); L.cur = take(bwd ? 2 * R : 0);
+        L.src = take(E); L.dst = take(E); L.csci = take(bwd ? E : 0);
+        L.w = take(E * d.n_ch);
+        L.fac = take(4 * R);
+        L.agg = take(rc * L.ld_agg);
+        L.gy = take(bwd ? rc * d.Fo : 0);
+        L.y = take(bwd ? 0 : rc * d.Fo);
+        L.coef = take(bwd ? rc * n_coef * d.F : 0);
+        L.ga = take(bwd ? R * d.F : 0);
+        L.gb = take(bwd && d.has_pre ? R * d.F : 0);
+        L.gc = take(bwd && d.has_pre ? R * d.F : 0);
+        off = (off + 1) & ~1;
+        L.red = take(bwd ? 2 * (2 * d.Fo * 9) : 0);          // doubles: column_sums' group partials; then the BatchNorm constants
+        L.total = off;
+        if ((size_t)off * 4 <= kLdsBytes) { RC = rc; return true; }
+    }
+    return false;
+}
+
+size_t tail_fwd_lds(const Dims& d) { return (size_t)(((4 * d.Fo + d.tail_rows * d.Fo + 1) & ~1) + 2 * (2 * d.Fo * 9)) * 4; }
+size_t tail_bwd_lds(const Dims& d) { return (size_t)(4 * d.Fo + 4 * d.tail_rows * d.Fo) * 4; }
+
+struct FwdWs { size_t bn_part, total; };
+FwdWs fwd_ws(const Dims& d) {
+    FwdWs w{};
+    w.bn_part = 0;
+    w.total = up256((size_t)d.n_blocks * 2 * d.Fo * sizeof(double));
+    return w;
+}
+struct BwdWs { size_t g_y1, tail_part, tail_wpart, blk_part, total; };
+BwdWs bwd_ws(const Dims& d) {
+    BwdWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += up256(bytes); return at; };
+    w.tail_part = take((size_t)d.n_tail * 2 * d.Fo * sizeof(double));
+    w.g_y1 = take((size_t)d.N * d.Fo * 4);
+    w.tail_wpart = take((size_t)d.n_tail * d.n_tail_param * 4);
+    w.blk_part = take((size_t)d.n_blocks * d.n_blk_param * 4);
+    w.total = off;
+    return w;
+}
+
+int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) {
+    std::memset(&p, 0, sizeof(p));
+    const DgnAggSpec* spec = L->spec;
+    // the aggregator list as the sweep's device code reads it (fill_params of dgn_agg.hip), scalers applied outside
+    p.a.n_agg = d.A; p.a.agg_total = d.A; p.a.n_ch = d.n_ch; p.a.n_scalers = 1; p.a.n_towers = 1;
+    p.a.avg_log = spec->avg_log; p.a.eps = spec->eps;
+    uint32_t need = 0;
+    for (int a = 0; a < d.A; ++a) {
+        const int op = spec->agg_op[a], c = spec->agg_ch[a];
+        const bool dir = op >= DGN_AGG_DIR_AV && op <= DGN_AGG_DIR_DX_NO_ABS;
+        if (dir && (c < 0 || c >= d.n_ch)) { set_error("%s: aggregator %d: channel %d outside 0..%d", fn, a, c, d.n_ch - 1); return DGN_ERR_INVALID; }
+        p.a.op_pack |= (uint64_t)op << (4 * a);
+        p.a.ch_pack |= (uint64_t)(dir ? c : 0) << (3 * a);
+        switch (op) {
+            case DGN_AGG_MAX: need |= NEED_MAX | NEED_RECOMP; break;
+            case DGN_AGG_MIN: need |= NEED_MIN | NEED_RECOMP; break;
+            case DGN_AGG_STD: case DGN_AGG_VAR: need |= NEED_SQ | NEED_RECOMP | NEED_M_EMIT; break;
+            case DGN_AGG_DIR_AV: p.a.any_av = true; break;
+            case DGN_AGG_DIR_DX: need |= NEED_XIN | NEED_RECOMP; break;
+            case DGN_AGG_DIR_DX_NO_ABS: need |= NEED_XIN; break;
+            default: break;
+        }
+    }
+    p.a.need = need;
+    p.desc = L->blocks->desc; p.n_blocks = d.n_blocks;
+    p.indptr = L->graph->indptr; p.src = L->graph->src; p.csc_ptr = L->graph->csc_ptr; p.csc_pos = L->graph->csc_pos;
+    p.eig = L->eig; p.ld_eig = (int32_t)L->ld_eig; p.n_ch = d.n_ch;
+    for (int c = 0; c < d.n_ch; ++c) {
+        p.ch_kind[c] = L->channels[c].kind; p.ch_col[c] = L->channels[c].eig_col; p.ch_alpha[c] = L->channels[c].alpha; p.ch_eps[c] = L->channels[c].eps;
+        if (p.ch_kind[c] < DGN_W_ABSNORM || p.ch_kind[c] > DGN_W_SOFTMAX || p.ch_col[c] < 0 || p.ch_col[c] >= L->n_eig_cols) {
+            set_error("%s: channel %d: kind %d / eig column %d of %d", fn, c, p.ch_kind[c], p.ch_col[c], L->n_eig_cols); return DGN_ERR_INVALID;
+        }
+    }
+    p.log_deg = L->log_deg; p.snorm = L->snorm;
+    p.has_pre = d.has_pre; p.relu = d.relu; p.mixing = d.mixing; p.residual = L->residual;
+    p.T = d.T; p.fi = d.fi; p.fo = d.fo; p.F = d.F; p.Fo = d.Fo; p.A = d.A; p.S = d.S; p.K = d.K; p.h_off = d.h_off;
+    p.ld_pre = d.ld_pre; p.ld_post = d.ld_post;
+    for (int s = 0; s < 3; ++s) p.sc_kind[s] = s < d.S ? spec->scaler[s] : DGN_SCALE_IDENTITY;
+    p.avg_log = spec->avg_log;
+    bool need_scale = false;
+    for (int s = 0; s < d.S; ++s) need_scale |= spec->scaler[s] != DGN_SCALE_IDENTITY;
+    if (!L->log_deg) { set_error("%s: null log_deg", fn); return DGN_ERR_INVALID; }
+    (void)need_scale;
+    for (int t = 0; t < d.T; ++t) {
+        if (!L->w_post || !L->b_post || !L->gamma || !L->beta || !L->w_post[t] || !L->b_post[t] || !L->gamma[t] || !L->beta[t] ||
+            (d.has_pre && (!L->w_pre || !L->b_pre || !L->w_pre[t] || !L->b_pre[t]))) { set_error("%s: null parameter of tower %d", fn, t); return DGN_ERR_INVALID; }
+        p.w_pre[t] = d.has_pre ? L->w_pre[t] : nullptr; p.b_pre[t] = d.has_pre ? L->b_pre[t] : nullptr;
+        p.w_post[t] = L->w_post[t]; p.b_post[t] = L->b_post[t]; p.gamma[t] = L->gamma[t]; p.beta[t] = L->beta[t];
+    }
+    if (d.mixing && (!L->w_mix || !L->b_mix)) { set_error("%s: null mixing-network parameters", fn); return DGN_ERR_INVALID; }
+    p.w_mix = L->w_mix; p.b_mix = L->b_mix; p.slope = L->slope;
+    if (!L->h || !L->y0 || !L->save_mean || !L->save_invstd) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
+    if (L->residual && d.F != d.Fo) { set_error("%s: the residual needs equal input and output widths", fn); return DGN_ERR_INVALID; }
+    p.h = L->h; p.y0 = L->y0; p.out = L->out;
+    p.save_mean = L->save_mean; p.save_invstd = L->save_invstd; p.running_mean = L->running_mean; p.running_var = L->running_var;
+    p.nbt = L->num_batches_tracked; p.n_nbt = L->num_batches_tracked ? L->n_nbt : 0;
+    p.momentum = L->momentum; p.bn_eps = L->eps;
+    p.N = d.N; p.tail_rows = d.tail_rows; p.n_tail = d.n_tail;
+    p.n_blk_param = d.n_blk_param; p.off_tower = d.off_tower;
+    p.R = d.R; p.Emax = d.Emax;
+    int rc = 0;
+    if (!plan_lds(d, spec, bwd, p.L, rc, p.cmap)) { set_error("%s: a block of %d rows / %d edges does not fit the LDS", fn, d.R, d.Emax); return DGN_ERR_INVALID; }
+    p.RC = rc;
+    return DGN_OK;
+}
+
+int set_lds(const void* kernel) {
+    DGN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    return DGN_OK;
+}
+
+}  // namespace
+}  // namespace dgn
+
+using namespace dgn;
+
+#define DGN_TRY_RC(call)          \
+    do {                          \
+        const int _rc = (call);   \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+extern "C" int dgn_block_layer_supported(const DgnBlockLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_block_layer_supported")) return 0;
+    Layout lay; int rc; int8_t cmap[blk::CF_SLOTS];
+    if (!plan_lds(d, L->spec, true, lay, rc, cmap) || !plan_lds(d, L->spec, false, lay, rc, cmap)) return 0;
+    if (L->residual && d.F != d.Fo) return 0;
+    return tail_bwd_lds(d) <= kLdsBytes && tail_fwd_lds(d) <= kLdsBytes;
+}
+
+extern "C" size_t dgn_block_layer_forward_workspace_bytes(const DgnBlockLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_block_layer_forward_workspace_bytes")) return 0;
+    return fwd_ws(d).total;
+}
+
+extern "C" size_t dgn_block_layer_backward_workspace_bytes(const DgnBlockLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_block_layer_backward_workspace_bytes")) return 0;
+    return bwd_ws(d).total;
+}
+
+extern "C" int64_t dgn_block_layer_param_grad_floats(const DgnBlockLayer* L) {
+    Dims d;
+    if (!dims_of(L, d, "dgn_block_layer_param_grad_floats")) return 0;
+    return (int64_t)d.n_blk_param + d.n_tail_param;
+}
+
+extern "C" int dgn_block_layer_forward(const DgnBlockLayer* L, void* stream_) {
+    const char* fn = "dgn_block_layer_forward";
+    Dims d;
+    if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
+    P p;
+    DGN_TRY_RC(fill(p, L, d, false, fn));
+    if (!L->out || !L->running_mean || !L->running_var) { set_error("%s: null output / running statistics", fn); return DGN_ERR_INVALID; }
+    const FwdWs w = fwd_ws(d);
+    if (!L->ws || L->ws_bytes < w.total) { set_error("%s: workspace too small (%zu < %zu)", fn, L->ws_bytes, w.total); return DGN_ERR_WORKSPACE; }
+    p.bn_part = reinterpret_cast<double*>(static_cast<char*>(L->ws) + w.bn_part);
+    p.dbg_agg = L->dbg_agg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_forward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd)); }();
+    if (lds_rc) return lds_rc;
+    hipLaunchKernelGGL(blk::blk_forward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
+    DGN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(blk::blk_tail_fwd, dim3(d.n_tail), dim3(d.tail_rows * 4), tail_fwd_lds(d), stream, p);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+extern "C" int dgn_block_layer_backward(const DgnBlockLayer* L, const DgnBlockGrads* G, void* stream_) {
+    const char* fn = "dgn_block_layer_backward";
+    Dims d;
+    if (!dims_of(L, d, fn)) return DGN_ERR_INVALID;
+    if (!G || !G->g_out || !G->g_h || !G->g_params || !G->g_gamma || !G->g_beta) { set_error("%s: null gradient buffer", fn); return DGN_ERR_INVALID; }
+    if (!L->graph->csc_ptr || !L->graph->csc_pos) { set_error("%s: the graph's transposed view (csc_ptr / csc_pos) is required", fn); return DGN_ERR_INVALID; }
+    P p;
+    DGN_TRY_RC(fill(p, L, d, true, fn));
+    const BwdWs w = bwd_ws(d);
+    if (!L->ws || L->ws_bytes < w.total) { set_error("%s: workspace too small (%zu < %zu)", fn, L->ws_bytes, w.total); return DGN_ERR_WORKSPACE; }
+    char* ws = static_cast<char*>(L->ws);
+    p.g_out = G->g_out; p.g_h = G->g_h; p.g_gamma = G->g_gamma; p.g_beta = G->g_beta;
+    p.g_y1 = reinterpret_cast<float*>(ws + w.g_y1);
+    p.tail_part = reinterpret_cast<double*>(ws + w.tail_part);
+    p.tail_wpart = reinterpret_cast<float*>(ws + w.tail_wpart);
+    p.blk_part = reinterpret_cast<float*>(ws + w.blk_part);
+    p.dbg_gagg = L->dbg_gagg;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_backward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd)); }();
+    if (lds_rc) return lds_rc;
+    hipLaunchKernelGGL(blk::blk_tail_bwd, dim3(d.n_tail), dim3(d.tail_rows * 4), tail_bwd_lds(d), stream, p);
+    DGN_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(blk::blk_backward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
+    DGN_HIP_CHECK(hipGetLastError());
+    const int n_out = d.n_blk_param + d.n_tail_param;
+    hipLaunchKernelGGL(blk::blk_reduce, dim3((n_out + 255) / 256), dim3(256), 0, stream, (const float*)p.blk_part, d.n_blk_param, d.n_blocks,
+                       (const float*)p.tail_wpart, d.n_tail_param, d.n_tail, G->g_params);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}

@@ -290,6 +290,17 @@ def _posttrans_split(posttrans: MLP, h, agg, in_dim):
     return posttrans(torch.cat([h, agg], dim=1))
 
 
+def _block_route_ok(layer, h) -> bool:
+    """Conditions every layer type shares for the graph-block route: a training step with BatchNorm on CUDA fp32 rows, no padded batch."""
+    return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training and torch.is_grad_enabled() and layer.batch_norm and h.is_cuda
+            and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES and _ops._N_VALID is None
+            and all(bn.momentum is not None and bn.track_running_stats and bn.affine for bn in _bns_of(layer)))
+
+
+def _bns_of(layer):
+    return [t.batchnorm_h for t in layer.towers] if hasattr(layer, "towers") else [layer.batchnorm_h]
+
+
 class DGNLayerSimple(nn.Module):
     """dgn_layer.py:135-202: message = h[src]; posttrans on the aggregation only."""
 
@@ -338,8 +349,22 @@ class DGNLayerSimple(nn.Module):
         return _ops.dense_layer(graph, self._kplan, self._avg_log, graph.edge_weights(self._kplan, eig), h, snorm_n if self.graph_norm else None, sc, bn,
                                 None, None, lin.weight, lin.bias, 0, A, 0, self.residual)
 
+    def _block_layer(self, g, h, snorm_n):
+        """The layer on the graph-block route (ops.block_layer: batches at the reference's batch size), or None."""
+        bn, lin = self.batchnorm_h, self.posttrans.fully_connected[0].linear
+        if not (_block_route_ok(self, h) and self.posttrans.is_single_affine() and lin.bias is not None):
+            return None
+        graph = as_dgn_graph(g, h.device)
+        if not _ops.block_layer_supported(graph, self.plan, 0, 1, h.shape[1], lin.weight.shape[0]):
+            return None
+        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, (lin.weight, lin.bias, bn.weight, bn.bias), 0, 1, h.shape[1], lin.weight.shape[0],
+                                self.residual, bn.momentum, bn.eps)
+
     def _forward(self, g, h, e, snorm_n):
-        y = self._whole_layer(g, h, snorm_n)
+        y = self._block_layer(g, h, snorm_n)
+        if y is None:
+            y = self._whole_layer(g, h, snorm_n)
         if y is not None:
             return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:201: the layer's last op)
         h_in = h
@@ -437,8 +462,24 @@ class DGNLayerComplex(nn.Module):
         return _ops.dense_layer(graph, self._kplan_x, self._avg_log, graph.edge_weights(self._kplan_x, eig), h, snorm_n if self.graph_norm else None, sc,
                                 bn, pre.weight, pre.bias, lin.weight, lin.bias, 1, A, id_slot, self.residual)
 
+    def _block_layer(self, g, h, snorm_n):
+        """As DGNLayerSimple._block_layer; additionally: single-affine pretrans with a bias, no edge features."""
+        bn = self.batchnorm_h
+        pre, lin = self.pretrans.fully_connected[0].linear, self.posttrans.fully_connected[0].linear
+        if not (_block_route_ok(self, h) and not self.edge_features and self.posttrans.is_single_affine() and self.pretrans.is_single_affine()
+                and lin.bias is not None and pre.bias is not None):
+            return None
+        graph = as_dgn_graph(g, h.device)
+        if not _ops.block_layer_supported(graph, self.plan, 1, 1, h.shape[1], lin.weight.shape[0]):
+            return None
+        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, (pre.weight, pre.bias, lin.weight, lin.bias, bn.weight, bn.bias), 1, 1, h.shape[1],
+                                lin.weight.shape[0], self.residual, bn.momentum, bn.eps)
+
     def _forward(self, g, h, e, snorm_n):
-        y = self._whole_layer(g, h, snorm_n)
+        y = self._block_layer(g, h, snorm_n)
+        if y is None:
+            y = self._whole_layer(g, h, snorm_n)
         if y is not None:
             return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:130: the layer's last op)
         h_in = h
@@ -766,9 +807,32 @@ class DGNLayerTower(nn.Module):
         with _ops.padded_rows(getattr(g, "n_valid", None)):
             return self._forward(g, h, e, snorm_n)
 
+    def _block_layer(self, g, h, snorm_n):
+        """The layer on the graph-block route (ops.block_layer), or None: as _whole_layer's domain, per-tower parameters as they are."""
+        T, fi, fo = len(self.towers), self.input_tower, self.output_tower
+        if not (_block_route_ok(self, h) and T > 1 and T <= 8 and self.divide_input and not self.edge_features and self.dropout == 0
+                and self._fusable()):
+            return None
+        act = self.mixing_network._fused_act()
+        mix = self.mixing_network.linear
+        if act is None or act[0] != "leaky_relu" or mix.bias is None:
+            return None
+        plist = self._param_list()
+        if any(p is None for p in plist):
+            return None
+        graph = as_dgn_graph(g, h.device)
+        if not _ops.block_layer_supported(graph, self.plan, 2, T, fi, fo):
+            return None
+        bns = [t.batchnorm_h for t in self.towers]
+        rm, rv, nbt = self._linked_bn_stats(h.device)
+        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, rm, rv, nbt,
+                                (*plist, mix.weight, mix.bias), 2, T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1])
+
     def _forward(self, g, h, e, snorm_n):
         h_in = h
-        y = self._whole_layer(g, h, snorm_n)
+        y = self._block_layer(g, h, snorm_n)
+        if y is None:
+            y = self._whole_layer(g, h, snorm_n)
         if y is not None:
             return y
         if self._fusable():

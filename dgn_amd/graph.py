@@ -308,6 +308,72 @@ class DGNGraph:
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
 
+    def _closed_cuts(self):
+        """(blk_cut int32 [N + 1], largest gap) of dgn_graph_build_cuts, cached: blk_cut[i] = the last CLOSED cut <= i -- a cut is closed
+        when no edge crosses it (the graph boundaries of a dgl.batch).  Five kernels and ONE read-back (the largest gap)."""
+        if "_blk" not in self.__dict__:
+            lib = _lib.load()
+            N, E, dev = self.num_nodes, self.num_edges, self.device
+            dst_csr = getattr(self, "dst_csr", None)
+            if dst_csr is None:
+                deg = (self.indptr[1:] - self.indptr[:-1]).long()
+                dst_csr = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32), deg)
+                self.dst_csr = dst_csr
+            cut = torch.empty(N + 1, dtype=torch.int32, device=dev)
+            gap = torch.zeros(1, dtype=torch.int32, device=dev)
+            nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgn_graph_build_cuts(N, E, self.src.data_ptr(), dst_csr.data_ptr(), cut.data_ptr(), gap.data_ptr(),
+                                                ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "dgn_graph_build_cuts")
+            self._blk = (cut, int(gap.item()))                                    # the one read-back
+        return self._blk
+
+    # ---- block table of the graph-block layer (csrc/dgn_blk_layer.hip): whole graphs per workgroup -------------------------------------
+    def block_table(self, graph_sizes=None):
+        """DgnBlockTable of this batch, or None (hub rows, a bipartite / sharded / padded CSR, no edges; inside a stream capture unless
+        built before).  Blocks = runs of whole graphs: the closed cuts (``graph_sizes``: the batch's node counts when the caller knows
+        them -- ``dgl.batch``'s ``batch_num_nodes`` --, else found by dgn_graph_build_cuts) greedily grouped so that a block has about
+        N / 512 rows -- at the reference's batch of 128 graphs one graph per workgroup.  Built once per batch: a few small kernels and two
+        read-backs (cuts, row pointers), on the loader's side of the step like the CSR itself.  Cached; the dict also carries
+        ``max_rows`` / ``max_edges`` (what decides whether a block fits the LDS)."""
+        ent = self.__dict__.get("_blk_tables")
+        if ent is not None:
+            return ent or None
+        if not (self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None
+                and self.row_base == 0 and self.num_edges > 0 and self.num_nodes > 0):
+            self.__dict__["_blk_tables"] = {}
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        import numpy as np
+        N = self.num_nodes
+        if graph_sizes is not None:
+            cuts = np.concatenate([[0], np.cumsum(np.asarray(graph_sizes, dtype=np.int64))])
+            if cuts[-1] != N:
+                raise ValueError("block_table: graph_sizes do not add up to the node count")
+        else:
+            cut, _ = self._closed_cuts()
+            cuts = torch.unique_consecutive(cut).cpu().numpy().astype(np.int64)
+        indptr = self.indptr.cpu().numpy().astype(np.int64)
+        target = max(1, -(-N // 512))
+        prev, bounds = 0, [0]
+        for c in cuts[1:]:
+            # the graph [prev, c) would take the running block [bounds[-1], prev) past the target: close the block first
+            # (a block always holds at least one whole graph, however large)
+            if c - bounds[-1] > target and prev != bounds[-1]:
+                bounds.append(int(prev))
+            prev = c
+        if bounds[-1] != N:
+            bounds.append(N)
+        b = np.asarray(bounds, dtype=np.int64)
+        desc = np.stack([b[:-1], b[1:], indptr[b[:-1]], indptr[b[1:]]], axis=1).astype(np.int32)
+        t = torch.from_numpy(np.ascontiguousarray(desc)).to(self.device)
+        st = _lib.DgnBlockTable(n_blocks=int(desc.shape[0]), max_rows=int((desc[:, 1] - desc[:, 0]).max()),
+                                max_edges=int((desc[:, 3] - desc[:, 2]).max()), desc=t.data_ptr())
+        ent = dict(struct=st, desc=t, n_blocks=st.n_blocks, max_rows=st.max_rows, max_edges=st.max_edges)
+        self.__dict__["_blk_tables"] = ent
+        return ent
+
     # ---- block description for the LDS-accumulating backward (csrc/dgn_agg_block.hpp) -----------------------------------------------
     def ensure_blocks(self, enabled: bool = True) -> bool:
         """Attach (or detach) DgnGraph.blk_cut / blk_gap: the closed cuts of a batch of small graphs (dgn_graph_build_cuts, built on
@@ -323,20 +389,7 @@ class DGNGraph:
             if "_blk" not in self.__dict__ and torch.cuda.is_current_stream_capturing():
                 enabled = False        # (the build reads the largest gap back: not inside a capture -- the staged backward is captured instead)
             if enabled and "_blk" not in self.__dict__:
-                lib = _lib.load()
-                N, E, dev = self.num_nodes, self.num_edges, self.device
-                dst_csr = getattr(self, "dst_csr", None)
-                if dst_csr is None:
-                    deg = (self.indptr[1:] - self.indptr[:-1]).long()
-                    dst_csr = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32), deg)
-                    self.dst_csr = dst_csr
-                cut = torch.empty(N + 1, dtype=torch.int32, device=dev)
-                gap = torch.zeros(1, dtype=torch.int32, device=dev)
-                nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _lib.check(lib.dgn_graph_build_cuts(N, E, self.src.data_ptr(), dst_csr.data_ptr(), cut.data_ptr(), gap.data_ptr(),
-                                                    ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "dgn_graph_build_cuts")
-                self._blk = (cut, int(gap.item()))                                    # the one read-back
+                self._closed_cuts()
             if enabled:
                 cut, gap = self._blk
                 ok = 0 < gap <= BLOCK_MAX_GAP

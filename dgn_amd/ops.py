@@ -1331,6 +1331,158 @@ def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm
     return out
 
 
+# ---- the graph-block layer: a batch at the reference's batch size as five launches per step (csrc/dgn_blk_layer.hip) -----------------
+
+# Batches up to this many nodes take the graph-block route where it applies (whole graphs per workgroup, everything out of LDS; the
+# streaming kernels are built for batches that fill the chip).  0 switches the route off.
+BLOCK_LAYER_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_MAX_NODES", "32768"))
+_BLK_DBG = None      # tests: dict that receives the aggregate rows / their gradients of the next call
+
+
+def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params):
+    """DgnBlockLayer for one call (+ the ctypes objects it points to)."""
+    type_net, T, fi, fo, residual, momentum, eps, slope = cfg
+    from .graph import _channel_array
+    spec = _spec_structs(plan, 1, avg_log, 0)[0]
+    L = _lib.DgnBlockLayer()
+    cg, tb = graph.c_graph, table["struct"]
+    chans = _channel_array(plan.channels) if plan.n_channels else None
+    L.graph, L.blocks, L.spec = C.pointer(cg), C.pointer(tb), C.pointer(spec)
+    if chans is not None:
+        L.channels = C.cast(chans, C.POINTER(_lib.DgnChannel))
+        L.eig, L.ld_eig, L.n_eig_cols = eig.data_ptr(), eig.stride(0), eig.shape[1]
+    L.log_deg = graph.log_deg.data_ptr()
+    L.type, L.n_towers, L.f_in, L.f_out, L.residual = type_net, T, fi, fo, int(residual)
+    L.momentum, L.eps, L.slope = float(momentum), float(eps), float(slope)
+    L.h, L.snorm = h.data_ptr(), _ptr(snorm)
+    per = 6 if type_net != 0 else 4
+    arr = C.c_void_p * T
+    cols = [arr(*[params[t * per + q].data_ptr() for t in range(T)]) for q in range(per)]
+    if type_net != 0:
+        L.w_pre, L.b_pre, L.w_post, L.b_post, L.gamma, L.beta = cols
+    else:
+        L.w_post, L.b_post, L.gamma, L.beta = cols
+    if type_net == 2:
+        L.w_mix, L.b_mix = params[T * per].data_ptr(), params[T * per + 1].data_ptr()
+    L.running_mean, L.running_var = _ptr(rm), _ptr(rv)
+    if nbt is not None:
+        L.num_batches_tracked, L.n_nbt = nbt.data_ptr(), nbt.numel()
+    return L, (cg, tb, spec, chans, cols)
+
+
+def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
+    """Whether this (batch, layer shape) runs on the graph-block route: a block table whose largest block fits the LDS plan."""
+    if BLOCK_LAYER_MAX_NODES <= 0 or graph.num_nodes > BLOCK_LAYER_MAX_NODES or len(plan.launches) != 1 or plan.n_channels > 3:
+        return False
+    table = graph.block_table()
+    if table is None:
+        return False
+    key = (id(plan), type_net, T, fi, fo)
+    ok = table.setdefault("ok", {})
+    if key not in ok:
+        L = _lib.DgnBlockLayer()
+        spec = _spec_structs(plan, 1, 1.0, 0)[0]
+        cg, tb = graph.c_graph, table["struct"]
+        L.graph, L.blocks, L.spec = C.pointer(cg), C.pointer(tb), C.pointer(spec)
+        L.type, L.n_towers, L.f_in, L.f_out = type_net, T, fi, fo
+        if plan.n_channels:
+            from .graph import _channel_array
+            L.channels = C.cast(_channel_array(plan.channels), C.POINTER(_lib.DgnChannel))
+            L.eig = 1      # (presence only)
+        ok[key] = bool(_lib.load().dgn_block_layer_supported(C.byref(L)))
+    return ok[key]
+
+
+class _BlockLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, *params):
+        lib = _lib.load()
+        type_net, T, fi, fo = cfg[:4]
+        N, Fo, dev = h.shape[0], T * fo, h.device
+        table = graph.block_table()
+        h = h.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        saved = torch.empty(N * Fo + 2 * Fo, dtype=torch.float32, device=dev)
+        out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
+        L, keep = _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params)
+        base = saved.data_ptr()
+        L.y0, L.save_mean, L.save_invstd, L.out = base, base + 4 * N * Fo, base + 4 * (N * Fo + Fo), out.data_ptr()
+        nbytes = lib.dgn_block_layer_forward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        dbg = _BLK_DBG
+        if dbg is not None:
+            dbg["agg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
+            L.dbg_agg = dbg["agg"].data_ptr()
+        _lib.check(lib.dgn_block_layer_forward(C.byref(L), _lib.stream_ptr(dev)), "dgn_block_layer_forward")
+        ctx.save_for_backward(h, snorm, eig, saved, *params)
+        ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        h, snorm, eig, saved = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        graph, plan, cfg = ctx.graph, ctx.plan, ctx.cfg
+        type_net, T, fi, fo = cfg[:4]
+        N, F_, Fo, dev = h.shape[0], T * fi, T * fo, h.device
+        g_out = g_out.contiguous()
+        graph.ensure_csc()
+        table = graph.block_table()
+        L, keep = _block_struct(graph, table, plan, ctx.avg_log, eig, cfg, h, snorm, None, None, None, params)
+        base = saved.data_ptr()
+        L.y0, L.save_mean, L.save_invstd = base, base + 4 * N * Fo, base + 4 * (N * Fo + Fo)
+        nbytes = lib.dgn_block_layer_backward_workspace_bytes(C.byref(L))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        n_par = int(lib.dgn_block_layer_param_grad_floats(C.byref(L)))
+        g_h = torch.empty((N, F_), dtype=torch.float32, device=dev)
+        flat = torch.empty(n_par + 2 * Fo, dtype=torch.float32, device=dev)
+        fb = flat.data_ptr()
+        G = _lib.DgnBlockGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_params=fb, g_gamma=fb + 4 * n_par, g_beta=fb + 4 * (n_par + Fo))
+        dbg = _BLK_DBG
+        if dbg is not None:
+            dbg["gagg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
+            L.dbg_gagg = dbg["gagg"].data_ptr()
+        _lib.check(lib.dgn_block_layer_backward(C.byref(L), C.byref(G), _lib.stream_ptr(dev)), "dgn_block_layer_backward")
+        # views of the flat gradient buffer, in the order of `params`
+        grads, off = [], 0
+        per = 6 if type_net != 0 else 4
+        for t in range(T):
+            for q in range(per - 2):
+                p = params[t * per + q]
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            grads.append(flat[n_par + t * fo:n_par + (t + 1) * fo])
+            grads.append(flat[n_par + Fo + t * fo:n_par + Fo + (t + 1) * fo])
+        if type_net == 2:
+            for p in params[T * per:]:
+                grads.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        return (None, None, None, None, None, g_h, None, None, None, None, *grads)
+
+
+def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, rm, rv, nbt, params, type_net: int, n_towers: int, f_in: int,
+                f_out: int, residual: bool, momentum: float, eps: float, slope: float = 0.01) -> torch.Tensor:
+    """One DGN layer (nets/dgn_layer.py:103-132 complex, :178-202 simple, :254-276 + :309-325 towers; training mode) as ONE autograd node
+    over ``dgn_block_layer_forward / _backward`` (``include/dgn_hip.h: DgnBlockLayer``): two launches forward, three backward.
+    ``plan``: the layer's own list (aggregators x applied scalers, no pass-through block); ``params``: per tower (pretrans weight, bias --
+    complex / towers --, posttrans weight, bias, BatchNorm weight, bias), then (towers) the mixing network's weight and bias, all in the
+    reference's state_dict layout.  ``rm / rv / nbt``: running statistics [T * f_out] and the counters, updated in place."""
+    if snorm is not None:
+        snorm = snorm.reshape(-1).contiguous()
+    if plan.n_channels:
+        eig = graph._normalised_eig(graph.ndata["eig"] if eig is None else eig)
+        for ch in plan.channels:
+            if ch[1] >= eig.shape[-1]:
+                raise IndexError(f"aggregator needs eig column {ch[1]} but eig has {eig.shape[-1]} columns")
+    else:
+        eig = None
+    cfg = (int(type_net), int(n_towers), int(f_in), int(f_out), bool(residual), float(momentum), float(eps), float(slope))
+    return _BlockLayer.apply(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, nbt, *params)
+
+
 # ---- the posttrans product inside the sweep (dgn_fused.hip) ---------------------------------------------------------------------
 
 # True: when no gradient is needed (inference / validation passes) the towers layer runs sweep + posttrans + scale-combine as ONE

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 22
+#define DGN_ABI_VERSION 23
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -639,6 +639,69 @@ size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_forward(const DgnTowersLayer* layer, void* stream);
 size_t dgn_towers_layer_backward_workspace_bytes(const DgnTowersLayer* layer);
 int dgn_towers_layer_backward(const DgnTowersLayer* layer, const DgnTowersGrads* grads, void* stream);
+
+/* ---- the layer of a batch at the reference's own batch size as FIVE launches per step (dgn_blk_layer.hip) ---------------------------
+ * Every shipped config trains at batch 128 (configs/molecules_graph_regression_DGN_ZINC.json:12, superpixels_graph_classification_DGN_
+ * CIFAR10.json:12; the hot loop of main_molecules.py / train/train_molecules_graph_regression.py:13-45): 3 000 - 15 000 rows, where a
+ * layer through the streaming kernels above is ~28 launches of a few microseconds each.  A dgl.batch (data/molecules.py:229) is block
+ * diagonal: a workgroup that owns whole graphs runs the layer for them out of LDS.  Replaces, for one DGNLayer{Simple,Complex,Tower}
+ * .forward + autograd backward (nets/dgn_layer.py:178-202, :103-132, :254-276 + :309-325) in training mode:
+ *     forward   blk_forward  (a workgroup per block): edge weights from eig (nets/aggregators.py:35-71) -> pretrans as P[src] + Q[dst]
+ *               -> aggregators -> scalers -> posttrans -> graph norm = y0, BatchNorm partial sums
+ *               blk_tail_fwd (16 rows per wave): BatchNorm (training statistics, running statistics and num_batches_tracked updated)
+ *               -> ReLU -> + h (simple / complex)   or   -> mixing Linear -> LeakyReLU -> + h (towers)
+ *     backward  blk_tail_bwd, blk_backward (recomputes the block's forward in LDS: only y0, mean, invstd were saved), blk_reduce
+ * Parameters and their gradients keep the REFERENCE's state_dict layout, one tensor per tower (no fold / assembly launches):
+ *     w_pre[t] [f_in, 2 f_in], b_pre[t] [f_in]  (complex / towers; no edge features on this route)
+ *     w_post[t] [f_out, (complex / towers: f_in +) S * n_agg * f_in], b_post[t] [f_out];  gamma[t], beta[t] [f_out]
+ *     w_mix [T f_out, T f_out], b_mix [T f_out]  (towers)
+ * simple / complex: n_towers = 1, f_in = the hidden size.  No dropout, no padded batches, at most 3 edge-weight channels.           */
+#define DGN_BLK_MAX_TOWERS 8
+typedef struct DgnBlockTable {
+    int32_t n_blocks;
+    int32_t max_rows;        /* largest block: rows ...                                                                       */
+    int32_t max_edges;       /* ... and CSR slots                                                                             */
+    /* DEVICE [n_blocks][4] int32 (16-byte aligned): first row, end row, first CSR slot, end CSR slot.  The blocks partition [0, N) in
+     * order and are CLOSED: every edge of a block's rows starts inside the block (whole graphs of the batch).                      */
+    const int32_t* desc;
+} DgnBlockTable;
+typedef struct DgnBlockLayer {
+    const DgnGraph* graph;       /* indptr, src; the backward also csc_ptr / csc_pos                                          */
+    const DgnBlockTable* blocks;
+    const DgnAggSpec* spec;      /* aggregators (no DGN_AGG_X_IN), n_ch, the APPLIED scalers (dgn_layer.py:170), avg_log, eps       */
+    const DgnChannel* channels;  /* HOST array [spec->n_ch]: how eig becomes each weight channel                              */
+    const float* eig; int64_t ld_eig; int32_t n_eig_cols;      /* [N, ld_eig] node eigenvectors (g.ndata['eig'])               */
+    const float* log_deg;        /* [N] log(in-degree + 1) as the scalers use it (nets/scalers.py:11,16)                       */
+    int32_t type;                /* 0 simple, 1 complex, 2 towers (n_towers >= 2, divide_input)                               */
+    int32_t n_towers, f_in, f_out;      /* per tower                                                                          */
+    int32_t residual;
+    float momentum, eps, slope;  /* BatchNorm momentum / eps; LeakyReLU slope of the mixing network                           */
+    const float* h;              /* [N, T f_in]                                                                               */
+    const float* snorm;          /* [N] graph-norm factors, NULL: graph_norm off                                              */
+    const float* const* w_pre; const float* const* b_pre; const float* const* w_post; const float* const* b_post;      /* HOST arrays of T device pointers */
+    const float* const* gamma; const float* const* beta;
+    const float* w_mix; const float* b_mix;
+    float* running_mean; float* running_var;      /* [T f_out] (the towers' statistics behind each other), updated in place     */
+    int64_t* num_batches_tracked; int32_t n_nbt;  /* n_nbt counters (one per BatchNorm module), each incremented; may be NULL   */
+    float* y0; float* save_mean; float* save_invstd;      /* [N, T f_out], [T f_out] x 2: written by the forward, read by the backward */
+    float* out;                  /* [N, T f_out] (forward)                                                                    */
+    void* ws; size_t ws_bytes;   /* dgn_block_layer_{forward,backward}_workspace_bytes()                                      */
+    float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
+} DgnBlockLayer;
+typedef struct DgnBlockGrads {
+    const float* g_out;          /* [N, T f_out]                                                                              */
+    float* g_h;                  /* [N, T f_in] written (includes the residual's share)                                       */
+    /* dgn_block_layer_param_grad_floats() floats, written: per tower [w_pre | b_pre] (complex / towers) [w_post | b_post], then
+     * (towers) [w_mix | b_mix] -- each in the parameter's own layout                                                          */
+    float* g_params;
+    float* g_gamma; float* g_beta;      /* [T f_out] each                                                                     */
+} DgnBlockGrads;
+int dgn_block_layer_supported(const DgnBlockLayer* layer);      /* graph, blocks, spec, type and widths set: 1 if every block fits */
+int64_t dgn_block_layer_param_grad_floats(const DgnBlockLayer* layer);
+size_t dgn_block_layer_forward_workspace_bytes(const DgnBlockLayer* layer);
+int dgn_block_layer_forward(const DgnBlockLayer* layer, void* stream);
+size_t dgn_block_layer_backward_workspace_bytes(const DgnBlockLayer* layer);
+int dgn_block_layer_backward(const DgnBlockLayer* layer, const DgnBlockGrads* grads, void* stream);
 
 #ifdef __cplusplus
 }

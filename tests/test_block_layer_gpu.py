@@ -1,0 +1,240 @@
+"""The graph-block layer route (csrc/dgn_blk_layer.hip, ops.block_layer: batches at the reference's own batch size as five launches per
+step) in front of the oracle and of the streaming routes, through the layers' DEFAULT dispatch.
+
+* every layer type and every BASELINE / shipped-json shape at oracle sizes: output, d h, every parameter gradient, BatchNorm running
+  statistics and ``num_batches_tracked`` vs the oracle (reference: nets/dgn_layer.py:103-132, :178-202, :254-325);
+* the aggregate rows formed in LDS vs the streaming sweep (``ops.directional_aggregate``) on the same inputs;
+* the same layer through the streaming whole-layer route: outputs and gradients agree to fp32 rounding;
+* run-to-run bit reproducibility (no atomics anywhere on the route);
+* the route is really taken (a counter on ``ops.block_layer``), and left for batches / shapes outside its domain.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_layer(type_net, F_, aggs, scalers, graph_norm, avg, towers=5, seed=1, o1_weights=True):
+    import dgn_amd
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(avg)}, type_net, True, towers=towers,
+                             edge_features=False, edge_dim=0).model
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():          # O(1) weights: the reference's init (gain 1 / in_size) makes layer outputs ~1e-3
+        for p in layer.parameters():
+            if p.dim() == 2 and o1_weights:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+            else:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    return layer, gen
+
+
+def _count_route(monkeypatch):
+    import dgn_amd
+    taken = []
+    real = dgn_amd.ops.block_layer
+    monkeypatch.setattr(dgn_amd.ops, "block_layer", lambda *a, **k: taken.append(1) or real(*a, **k))
+    return taken
+
+
+def _vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, b, towers=5, expect_route=True):
+    import dgn_amd
+    from oracle import dgn_oracle as orc
+    from parity_util import check
+    from test_shipped_configs_gpu import _check_grad
+    dev = torch.device("cuda")
+    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(dst, minlength=N).float() + 1).mean())
+    layer, gen = _make_layer(type_net, F_, aggs, scalers, graph_norm, avg, towers, o1_weights=type_net != "towers")
+    h, ct = torch.randn(N, F_, generator=gen), torch.randn(N, F_, generator=gen)
+
+    def oracle(dtype):
+        sd = {k: (v.detach().to(dtype).requires_grad_("running" not in k) if v.dtype.is_floating_point else v.clone())
+              for k, v in layer.state_dict().items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+        cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg, dtype=dtype), graph_norm=graph_norm, batch_norm=True,
+                   residual=True, towers=towers if type_net == "towers" else 1, divide_input=True, edge_features=False)
+        hh = h.to(dtype).requires_grad_(True)
+        y, stats = orc.layer_forward(type_net, sd, cfg, src, dst, N, b["eig"].to(dtype), hh, None, b["snorm_n"].to(dtype), training=True)
+        return y, torch.autograd.grad(y, [hh] + [sd[k] for k in names], ct.to(dtype)), names, stats
+
+    y32, g32, names, stats = oracle(torch.float32)
+    y64, g64, _, _ = oracle(torch.float64)
+    taken = _count_route(monkeypatch)
+    layer = layer.to(dev).train()
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=b["eig"].to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, b["snorm_n"].to(dev))
+    assert bool(taken) == expect_route, "the graph-block route was " + ("not taken" if expect_route else "taken")
+    params = dict(layer.named_parameters())
+    gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
+    check(y, y32, y64, f"block {type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0)
+    for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
+        _check_grad(a, r32, r64, f"block {type_net} F={F_} {k}")
+    for k, v in (stats or {}).items():
+        np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    for k, v in layer.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1, k
+
+
+def test_c2_towers_batch_vs_oracle(monkeypatch):
+    """BASELINE configs[1] at the reference's batch size: towers x 5, hidden 70, mean max min dir1-av dir1-dx x three scalers."""
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, "towers", 70, "mean max min dir1-av dir1-dx", "identity amplification attenuation", True,
+               synth.molecule_batch(128, seed=41, extra_bonds=3.9, eig_dim=6))
+
+
+@pytest.mark.parametrize("hidden,towers", [(45, 5), (32, 4)])
+def test_towers_other_widths_vs_oracle(monkeypatch, hidden, towers):
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, "towers", hidden, "mean max min dir1-av dir1-dx", "identity amplification attenuation", True,
+               synth.molecule_batch(60, seed=7, extra_bonds=3.9, eig_dim=6), towers=towers)
+
+
+def test_c1_simple_hidden75_vs_oracle(monkeypatch):
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, "simple", 75, "mean dir1-dx-no-abs", "identity amplification attenuation", True,
+               synth.molecule_batch(128, seed=41, extra_bonds=3.9, eig_dim=6))
+
+
+@pytest.mark.parametrize("type_net", ["simple", "complex"])
+def test_c3_knn_hidden65_vs_oracle(monkeypatch, type_net):
+    """CIFAR10-like 8-NN graphs (85 - 150 nodes, in-degrees 0 .. ~25: several row chunks per block, zero in-degree rows)."""
+    from dgn_amd import synth
+    # (the complex layer's P | Q rows and three gradient accumulators of a 150-node graph at F = 65 exceed the LDS: streaming route)
+    _vs_oracle(monkeypatch, type_net, 65, "mean dir1-dx dir2-dx", "identity", True, synth.knn_batch(8, seed=41), expect_route=type_net == "simple")
+
+
+def test_zinc_json_complex_hidden45_vs_oracle(monkeypatch):
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, "complex", 45, "mean dir1-dx dir1-av", "identity amplification attenuation", True,
+               synth.molecule_batch(128, seed=41, extra_bonds=3.9, eig_dim=6))
+
+
+@pytest.mark.parametrize("scalers", ["identity", "identity amplification attenuation"])
+def test_c4_molhiv_simple_vs_oracle(monkeypatch, scalers):
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", scalers, False,
+               synth.molecule_batch(200, seed=41, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4))
+
+
+@pytest.mark.parametrize("type_net,aggs", [("simple", "mean sum max min std var dir1-av dir2-dx-no-abs dir1-0.1"),
+                                           ("complex", "std dir1-dx-balanced dir2-neg-0.1 dir3-av max"),
+                                           ("complex", "sum var min dir2-dx")])
+def test_other_aggregator_lists_vs_oracle(monkeypatch, type_net, aggs):
+    """every aggregator family of nets/aggregators.py:74-93 on the route (softmax and balanced channels, var / std, three eig columns)"""
+    from dgn_amd import synth
+    _vs_oracle(monkeypatch, type_net, 24, aggs, "identity amplification attenuation", True, synth.molecule_batch(50, seed=3, extra_bonds=3.9, eig_dim=6))
+
+
+def test_isolated_nodes_vs_oracle(monkeypatch):
+    from dgn_amd import synth
+    b = dict(synth.molecule_batch(100, seed=47, extra_bonds=3.9, eig_dim=6))
+    N = int(b["num_nodes"])
+    cut = torch.rand(N, generator=torch.Generator().manual_seed(48)) < 0.08
+    keep = ~cut[b["dst"]]
+    b["src"], b["dst"] = b["src"][keep], b["dst"][keep]
+    _vs_oracle(monkeypatch, "complex", 30, "mean max min dir1-dx dir1-av", "identity amplification attenuation", True, b)
+
+
+def test_aggregate_rows_equal_the_streaming_sweep():
+    """the aggregate rows formed in LDS (debug tap of the forward) vs ops.directional_aggregate on the same h / eig"""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    from dgn_amd.spec import make_plan
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(64, seed=5, extra_bonds=3.9, eig_dim=6)
+    N = int(b["num_nodes"])
+    aggs = "mean max min std dir1-av dir1-dx dir2-dx-no-abs"
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer("simple", 40, aggs, "identity amplification attenuation", True, avg)
+    layer = layer.to(dev).train()
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    h = torch.randn(N, 40, generator=gen).to(dev).requires_grad_(True)
+    ops._BLK_DBG = {}
+    try:
+        layer(graph, h, None, b["snorm_n"].to(dev))
+        agg = ops._BLK_DBG["agg"]
+    finally:
+        ops._BLK_DBG = None
+    plan = make_plan(aggs.split(), ["identity"])
+    ref = ops.directional_aggregate(graph, plan, avg, x_src=h.detach(), x_in=h.detach(), eig=b["eig"].to(dev))
+    np.testing.assert_allclose(agg.cpu().numpy(), ref.cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("type_net,F_,aggs,scalers", [("towers", 70, "mean max min dir1-av dir1-dx", "identity amplification attenuation"),
+                                                      ("complex", 45, "mean dir1-dx dir1-av", "identity amplification attenuation"),
+                                                      ("simple", 65, "mean dir1-dx dir2-dx", "identity")])
+def test_block_route_vs_streaming_route_and_reproducible(monkeypatch, type_net, F_, aggs, scalers):
+    import dgn_amd
+    from dgn_amd import synth
+    dev = torch.device("cuda")
+    b = synth.knn_batch(6, seed=3) if type_net == "simple" else synth.molecule_batch(96, seed=11, extra_bonds=3.9, eig_dim=6)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer(type_net, F_, aggs, scalers, True, avg, o1_weights=type_net != "towers")
+    layer = layer.to(dev).train()
+    sd0 = {k: v.clone() for k, v in layer.state_dict().items()}
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    h = torch.randn(N, F_, generator=gen).to(dev)
+    ct = torch.randn(N, F_, generator=gen).to(dev)
+    snorm = b["snorm_n"].to(dev)
+
+    def run(max_nodes):
+        monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", max_nodes)
+        layer.load_state_dict(sd0)
+        hh = h.clone().requires_grad_(True)
+        y = layer(graph, hh, None, snorm)
+        names = [k for k, _ in layer.named_parameters()]
+        g = torch.autograd.grad(y, [hh] + list(layer.parameters()), ct)
+        return y.detach(), dict(zip(["h"] + names, g)), {k: v.clone() for k, v in layer.state_dict().items() if "running" in k}
+
+    taken = _count_route(monkeypatch)
+    y_b, g_b, st_b = run(32768)
+    assert taken
+    y_b2, g_b2, _ = run(32768)
+    assert torch.equal(y_b, y_b2) and all(torch.equal(g_b[k], g_b2[k]) for k in g_b), "the block route is not run-to-run reproducible"
+    n_taken = len(taken)
+    y_s, g_s, st_s = run(0)
+    assert len(taken) == n_taken
+    np.testing.assert_allclose(y_b.cpu().numpy(), y_s.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for k in g_b:
+        scale = max(1.0, float(g_s[k].abs().max()))
+        # (max / min / |.| routings may flip between two fp32 evaluations of the same tie: a handful of entries, bounded)
+        bad = (g_b[k] - g_s[k]).abs() > 2e-5 * scale + 1e-4 * g_s[k].abs()
+        assert int(bad.sum()) <= max(1, int(2e-3 * bad.numel())), f"{k}: {int(bad.sum())} of {bad.numel()} entries differ between the routes"
+    for k in st_b:
+        np.testing.assert_allclose(st_b[k].cpu().numpy(), st_s[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_route_left_outside_its_domain(monkeypatch):
+    """edge features, eval mode, and batches over the node limit keep the streaming routes"""
+    import dgn_amd
+    from dgn_amd import synth
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(40, seed=2, extra_bonds=3.9, eig_dim=6)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    snorm = b["snorm_n"].to(dev)
+    taken = _count_route(monkeypatch)
+    layer, gen = _make_layer("complex", 30, "mean dir1-dx", "identity amplification attenuation", True, avg)
+    layer = layer.to(dev)
+    h = torch.randn(N, 30, generator=gen).to(dev).requires_grad_(True)
+    layer.eval()
+    layer(graph, h, None, snorm)
+    assert not taken
+    layer.train()
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", N - 1)
+    layer(graph, h, None, snorm)
+    assert not taken
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 32768)
+    layer(graph, h, None, snorm)
+    assert len(taken) == 1
+    torch.manual_seed(0)
+    le = dgn_amd.DGNLayer(30, 30, 0.0, True, True, "mean dir1-dx", "identity", {"log": torch.tensor(avg)}, "complex", True, edge_features=True,
+                          edge_dim=6).model.to(dev).train()
+    le(graph, h, torch.randn(graph.num_edges, 6, device=dev), snorm)
+    assert len(taken) == 1
