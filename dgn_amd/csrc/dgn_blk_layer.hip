@@ -15,7 +15,8 @@ using blk::Layout;
 using blk::P;
 
 constexpr size_t kLdsBytes = 160 * 1024;
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;      // blk_forward / blk_backward: 16 waves per workgroup (four per SIMD: the products' memory latencies overlap)
+constexpr int kTailThreads = 512;
 
 inline int up4(int x) { return (x + 3) & ~3; }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -48,7 +49,7 @@ bool dims_of(const DgnBlockLayer* L, Dims& d, const char* fn) {
     d.N = L->graph->n_nodes;
     d.n_blocks = L->blocks->n_blocks; d.R = L->blocks->max_rows; d.Emax = L->blocks->max_edges;
     if (d.N < 1 || d.n_blocks < 1 || d.R < 1 || !L->blocks->desc) { set_error("%s: empty batch / block table", fn); return false; }
-    if (d.F > kThreads || d.Fo > kThreads || d.Emax >= 65535) { set_error("%s: widths over %d columns / blocks of 65535 edges are outside this route", fn, kThreads); return false; }
+    if (d.F > 256 || d.Fo > 256 || d.Emax >= 65535) { set_error("%s: widths over 256 columns / blocks of 65535 edges are outside this route", fn); return false; }
     d.off_tower = (d.has_pre ? d.fi * d.ld_pre + d.fi : 0) + d.fo * d.ld_post + d.fo;
     d.n_blk_param = d.T * d.off_tower;
     d.n_tail_param = d.mixing ? d.Fo * d.Fo + d.Fo : 0;
@@ -102,15 +103,15 @@ bool plan_lds(const Dims& d, const DgnAggSpec* spec, bool bwd, Layout& L, int& R
         L.gb = take(bwd && d.has_pre ? R * d.F : 0);
         L.gc = take(bwd && d.has_pre ? R * d.F : 0);
         off = (off + 1) & ~1;
-        L.red = take(bwd ? 2 * (2 * d.Fo * 9) : 0);          // doubles: column_sums' group partials; then the BatchNorm constants
+        L.red = take(bwd ? 2 * (2 * d.Fo * 17) : 0);          // doubles: column_sums' group partials; then the BatchNorm constants
         L.total = off;
         if ((size_t)off * 4 <= kLdsBytes) { RC = rc; return true; }
     }
     return false;
 }
 
-size_t tail_fwd_lds(const Dims& d) { return (size_t)(((4 * d.Fo + d.tail_rows * d.Fo + 1) & ~1) + 2 * (2 * d.Fo * 9)) * 4; }
-size_t tail_bwd_lds(const Dims& d) { return (size_t)(4 * d.Fo + 4 * d.tail_rows * d.Fo) * 4; }
+size_t tail_fwd_lds(const Dims& d) { return (size_t)(((4 * d.Fo + d.tail_rows * d.Fo + (d.mixing ? d.Fo * d.Fo : 0) + 1) & ~1) + 2 * (2 * d.Fo * 17)) * 4; }
+size_t tail_bwd_lds(const Dims& d) { return (size_t)(4 * d.Fo + 4 * d.tail_rows * d.Fo + (d.mixing ? d.Fo * d.Fo : 0)) * 4; }
 
 struct FwdWs { size_t bn_part, total; };
 FwdWs fwd_ws(const Dims& d) {
@@ -251,13 +252,13 @@ extern "C" int dgn_block_layer_forward(const DgnBlockLayer* L, void* stream_) {
     const FwdWs w = fwd_ws(d);
     if (!L->ws || L->ws_bytes < w.total) { set_error("%s: workspace too small (%zu < %zu)", fn, L->ws_bytes, w.total); return DGN_ERR_WORKSPACE; }
     p.bn_part = reinterpret_cast<double*>(static_cast<char*>(L->ws) + w.bn_part);
-    p.dbg_agg = L->dbg_agg;
+    p.dbg_agg = L->dbg_agg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_forward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd)); }();
     if (lds_rc) return lds_rc;
     hipLaunchKernelGGL(blk::blk_forward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
     DGN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(blk::blk_tail_fwd, dim3(d.n_tail), dim3(d.tail_rows * 4), tail_fwd_lds(d), stream, p);
+    hipLaunchKernelGGL(blk::blk_tail_fwd, dim3(d.n_tail), dim3(kTailThreads), tail_fwd_lds(d), stream, p);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
@@ -278,16 +279,16 @@ extern "C" int dgn_block_layer_backward(const DgnBlockLayer* L, const DgnBlockGr
     p.tail_part = reinterpret_cast<double*>(ws + w.tail_part);
     p.tail_wpart = reinterpret_cast<float*>(ws + w.tail_wpart);
     p.blk_part = reinterpret_cast<float*>(ws + w.blk_part);
-    p.dbg_gagg = L->dbg_gagg;
+    p.dbg_gagg = L->dbg_gagg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_backward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd)); }();
     if (lds_rc) return lds_rc;
-    hipLaunchKernelGGL(blk::blk_tail_bwd, dim3(d.n_tail), dim3(d.tail_rows * 4), tail_bwd_lds(d), stream, p);
+    hipLaunchKernelGGL(blk::blk_tail_bwd, dim3(d.n_tail), dim3(kTailThreads), tail_bwd_lds(d), stream, p);
     DGN_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(blk::blk_backward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
     DGN_HIP_CHECK(hipGetLastError());
     const int n_out = d.n_blk_param + d.n_tail_param;
-    hipLaunchKernelGGL(blk::blk_reduce, dim3((n_out + 255) / 256), dim3(256), 0, stream, (const float*)p.blk_part, d.n_blk_param, d.n_blocks,
+    hipLaunchKernelGGL(blk::blk_reduce, dim3((8 * n_out + 255) / 256), dim3(256), 0, stream, (const float*)p.blk_part, d.n_blk_param, d.n_blocks,
                        (const float*)p.tail_wpart, d.n_tail_param, d.n_tail, G->g_params);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;

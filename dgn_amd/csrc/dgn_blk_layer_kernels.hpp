@@ -76,8 +76,11 @@ struct P {
     Layout L; int32_t R, RC, Emax;
     int8_t cmap[CF_SLOTS];       // coefficient slot -> index in the LDS coefficient rows, -1: absent
     // tests
-    float* dbg_agg; float* dbg_w; float* dbg_gagg;
+    float* dbg_agg; float* dbg_w; float* dbg_gagg; int64_t* dbg_time;
 };
+
+// profiling: wall-clock stamp i of this workgroup (p.dbg_time == NULL: nothing)
+#define BLK_STAMP(i) do { if (p.dbg_time && threadIdx.x == 0) p.dbg_time[(int64_t)blockIdx.x * 16 + (i)] = (int64_t)wall_clock64(); } while (0)
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -98,9 +101,55 @@ __device__ __forceinline__ void tile_mma(f4& acc, int K, int g, FA&& fa, FB&& fb
     }
 }
 
+// The same with the A operand in GLOBAL memory (weights, L2-resident): element k of the lane's A row is arow[k * sk].  The loads of a
+// batch of KB 16-k blocks are all issued -- unconditional, clamped -- before the first MFMA consumes one: a batch costs ONE memory round
+// trip (a load whose value is selected or consumed at once is waited for at once: with one wave per SIMD that made every k step a
+// full L2 latency, 85 us for a forward of 23 rows).
+constexpr int kBatchKB = 8;
+template <int KB = 2, class FB>
+__device__ __forceinline__ void tile_mma_g(f4& acc, int K, int g, const float* arow, int64_t sk, bool aok, FB&& fb) {
+    for (int c0 = 0; c0 < K; c0 += 16 * KB) {
+        float av[KB][4];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) av[b][s] = arow[(int64_t)min(c0 + 16 * b + 4 * g + s, K - 1) * sk];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            if (c0 + 16 * b < K) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int k = c0 + 16 * b + 4 * g + s;
+                    acc = mfma4((aok && k < K) ? av[b][s] : 0.f, fb(k), acc);
+                }
+            }
+        }
+    }
+}
+
+// posttrans' input row is the virtual concatenation [h block (h_off columns) | scaler 0 x aggregates (K) | scaler 1 ... ]: position of a
+// column in it, advanced in steps of 16 (no division per element)
+struct VirtCol { int seg, rel; };      // seg 0: the h block, seg s + 1: scaler s
+__device__ __forceinline__ VirtCol vcol_at(int k, int h_off, int K) {
+    VirtCol v;
+    if (k < h_off) { v.seg = 0; v.rel = k; return v; }
+    v.seg = 1; v.rel = k - h_off;
+    while (v.rel >= K) { v.rel -= K; ++v.seg; }
+    return v;
+}
+__device__ __forceinline__ void vcol_step16(VirtCol& v, int h_off, int K) {
+    v.rel += 16;
+    int len = v.seg == 0 ? h_off : K;
+    while (v.rel >= len) { v.rel -= len; ++v.seg; len = K; }
+}
+
 struct RowFeat { int r, f; };
 __device__ __forceinline__ RowFeat rf_at(int idx, int F) { RowFeat x; x.r = idx / F; x.f = idx - x.r * F; return x; }
 __device__ __forceinline__ void rf_step(RowFeat& x, int step, int F) { x.f += step; while (x.f >= F) { x.f -= F; ++x.r; } }
+// a step given as (whole rows, remainder): one compare instead of a loop when the stride is many rows (1024 threads over 70 features)
+struct RowStep { int dr, df; };
+__device__ __forceinline__ RowStep rf_stride(int step, int F) { RowStep q; q.dr = step / F; q.df = step - q.dr * F; return q; }
+__device__ __forceinline__ void rf_step(RowFeat& x, const RowStep& q, int F) { x.r += q.dr; x.f += q.df; if (x.f >= F) { x.f -= F; ++x.r; } }
 
 __device__ __forceinline__ int tower_of(int f, int fi, int T) {
     int t = 0;
@@ -168,15 +217,18 @@ __device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, b
         }
     }
     __syncthreads();
+    BLK_STAMP(1);
     for (int r = tid; r < R; r += NT)
         for (int j = c.IP[r]; j < c.IP[r + 1]; ++j) c.DST[j] = r;
     __syncthreads();
+    BLK_STAMP(2);
     // delta_jc = eig[src_j, c] - eig[i, c], parked in the weight planes
     for (int i = tid; i < Eb * p.n_ch; i += NT) {
         const int ch = i / Eb, j = i - ch * Eb;
         c.W[ch * L.ld_w + j] = c.EIG[c.SRC[j] * p.n_ch + ch] - c.EIG[c.DST[j] * p.n_ch + ch];
     }
     __syncthreads();
+    BLK_STAMP(3);
     // a thread per (row, channel): the row's normalisers in slot order, then its weights
     for (int i = tid; i < R * p.n_ch; i += NT) {
         const int r = i / p.n_ch, ch = i - r * p.n_ch;
@@ -196,7 +248,7 @@ __device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, b
     }
     // P | Q = h [W_s | W_d]^T + [0 | b]: jobs of (16-row strip, tower, half, 16-column tile)
     if (p.has_pre) {
-        const int lane = tid & 63, wave = tid >> 6, nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
+        const int lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
         const int nstrip = (R + 15) >> 4, ntq = (p.fi + 15) >> 4;
         const int njobs = nstrip * p.T * 2 * ntq;
         for (int job = wave; job < njobs; job += nw) {
@@ -209,9 +261,7 @@ __device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, b
             const float* xrow = c.HB + min(m, R - 1) * F + t * p.fi;
             const bool nok = n < p.fi, mok = m < R;
             f4 acc = {0.f, 0.f, 0.f, 0.f};
-            tile_mma(acc, p.fi, g,
-                     [&](int k) { const float v = wrow[min(k, p.fi - 1)]; return (nok && k < p.fi) ? v : 0.f; },
-                     [&](int k) { const float v = xrow[min(k, p.fi - 1)]; return (mok && k < p.fi) ? v : 0.f; });
+            tile_mma_g(acc, p.fi, g, wrow, 1, nok, [&](int k) { const float v = xrow[min(k, p.fi - 1)]; return (mok && k < p.fi) ? v : 0.f; });
             if (mok) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -222,6 +272,7 @@ __device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, b
         }
     }
     __syncthreads();
+    BLK_STAMP(4);
 }
 
 // message of slot j (source row s) into row r, feature f -- x_dst + x_src, the sweep's rounding order (load_msg)
@@ -237,12 +288,29 @@ __device__ __forceinline__ void accumulate_row(Acc<C1, TRACK>& acc, const P& p, 
     const float* xs = p.has_pre ? c.PQ + f : c.HB + f;
     const int ldx = p.has_pre ? 2 * p.F : p.F;
     const int beg = c.IP[r], end = c.IP[r + 1];
-    for (int j = beg; j < end; ++j) {
-        float m[1], wk[kMaxCh];
-        m[0] = p.has_pre ? q + xs[c.SRC[j] * ldx] : xs[c.SRC[j] * ldx];
+    // four slots per step, every LDS operand of the group requested before the first is consumed (one slot at a time is a chain of
+    // dependent LDS latencies: index -> source row -> accumulate; 8 us for ONE 8-edge row per thread)
+    for (int j0 = beg; j0 < end; j0 += 4) {
+        int sv[4];
+        float xv[4], wv[4][kMaxCh];
 #pragma unroll
-        for (int ch = 0; ch < kMaxCh; ++ch) wk[ch] = ch < p.n_ch ? c.W[ch * p.L.ld_w + j] : 0.f;
-        acc.add(m, wk, j);
+        for (int u = 0; u < 4; ++u) sv[u] = c.SRC[min(j0 + u, end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ch = 0; ch < kMaxCh; ++ch) wv[u][ch] = c.W[min(ch, max(p.n_ch - 1, 0)) * p.L.ld_w + min(j0 + u, end - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = xs[sv[u] * ldx];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u < end) {
+                float m[1], wk[kMaxCh];
+                m[0] = p.has_pre ? q + xv[u] : xv[u];
+#pragma unroll
+                for (int ch = 0; ch < kMaxCh; ++ch) wk[ch] = ch < p.n_ch ? wv[u][ch] : 0.f;
+                acc.add(m, wk, j0 + u);
+            }
+        }
     }
 }
 
@@ -250,11 +318,12 @@ __device__ __forceinline__ void accumulate_row(Acc<C1, TRACK>& acc, const P& p, 
 __device__ __forceinline__ int agg_col(const P& p, int t, int ft, int a) { return t * p.K + a * p.fi + ft; }
 
 // ---- forward -------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blk_forward(const P p) {
+__global__ __launch_bounds__(1024) void blk_forward(const P p) {
     extern __shared__ float lds[];
     Ctx c;
+    BLK_STAMP(0);
     block_prologue(p, c, lds, false);
-    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
     const int R = c.R, F = p.F, Fo = p.Fo, RC = p.RC;
     double s0 = 0.0, s1 = 0.0;                                 // BatchNorm partial sums of column tid
     for (int c0 = 0; c0 < R; c0 += RC) {
@@ -262,7 +331,8 @@ __global__ __launch_bounds__(256) void blk_forward(const P p) {
         // the aggregation: a work item per (row, feature)
         {
             RowFeat x = rf_at(tid, F);
-            for (; x.r < rc; rf_step(x, NT, F)) {
+            const RowStep st_ = rf_stride(NT, F);
+            for (; x.r < rc; rf_step(x, st_, F)) {
                 const int r = c0 + x.r, f = x.f;
                 const int t = tower_of(f, p.fi, p.T), ft = f - t * p.fi;
                 float* arow = c.AGG + x.r * p.L.ld_agg;
@@ -284,6 +354,7 @@ __global__ __launch_bounds__(256) void blk_forward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(5);
         if (p.dbg_agg)
             for (int i = tid; i < rc * p.L.ld_agg; i += NT) p.dbg_agg[(int64_t)(c.lo + c0) * p.L.ld_agg + i] = c.AGG[i];
         // posttrans([h || scaler x aggregate blocks]) (+ bias) * graph norm: jobs of (strip, tower, 16-column tile)
@@ -298,21 +369,34 @@ __global__ __launch_bounds__(256) void blk_forward(const P p) {
                 const bool nok = n < p.fo, mok = m < rc;
                 const int mr = c0 + min(m, rc - 1);
                 const float* wrow = p.w_post[t] + (int64_t)min(n, p.fo - 1) * p.ld_post;
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (p.has_pre) {
-                    const float* xrow = c.HB + mr * F + t * p.fi;
-                    tile_mma(acc, p.fi, g,
-                             [&](int k) { const float v = wrow[min(k, p.fi - 1)]; return (nok && k < p.fi) ? v : 0.f; },
-                             [&](int k) { const float v = xrow[min(k, p.fi - 1)]; return (mok && k < p.fi) ? v : 0.f; });
-                }
+                const float* xrow = c.HB + mr * F + t * p.fi;
                 const float* arow = c.AGG + min(m, rc - 1) * p.L.ld_agg + t * p.K;
                 const f4 fc = *reinterpret_cast<const f4*>(c.FAC + 4 * mr);
-                for (int s = 0; s < p.S; ++s) {
-                    const float sc = s == 0 ? fc[0] : (s == 1 ? fc[1] : fc[2]);
-                    const float* ws = wrow + p.h_off + s * p.K;
-                    tile_mma(acc, p.K, g,
-                             [&](int k) { const float v = ws[min(k, p.K - 1)]; return (nok && k < p.K) ? v : 0.f; },
-                             [&](int k) { const float v = arow[min(k, p.K - 1)] * sc; return (mok && k < p.K) ? v : 0.f; });
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                // ONE product over the weight row's ld_post columns, the input row [h | scale_s * aggregates] formed on the fly
+                VirtCol vc[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) vc[s] = vcol_at(4 * g + s, p.h_off, p.K);
+                for (int c1 = 0; c1 < p.ld_post; c1 += 16 * kBatchKB) {
+                    float av[kBatchKB][4];
+#pragma unroll
+                    for (int b = 0; b < kBatchKB; ++b)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) av[b][s] = wrow[min(c1 + 16 * b + 4 * g + s, p.ld_post - 1)];
+#pragma unroll
+                    for (int b = 0; b < kBatchKB; ++b) {
+                        if (c1 + 16 * b < p.ld_post) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const int k = c1 + 16 * b + 4 * g + s;
+                                const bool kok = k < p.ld_post;
+                                const int seg = vc[s].seg, rel = kok ? vc[s].rel : 0;
+                                float xv = seg == 0 ? xrow[rel] : arow[rel] * (seg == 1 ? fc[0] : (seg == 2 ? fc[1] : fc[2]));
+                                acc = mfma4((nok && kok) ? av[b][s] : 0.f, (mok && kok) ? xv : 0.f, acc);
+                                vcol_step16(vc[s], p.h_off, p.K);
+                            }
+                        }
+                    }
                 }
                 if (mok) {
 #pragma unroll
@@ -324,6 +408,7 @@ __global__ __launch_bounds__(256) void blk_forward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(6);
         {
             float* yrow = p.y0 + (int64_t)(c.lo + c0) * Fo;
             for (int i = tid; i < rc * Fo; i += NT) yrow[i] = c.Y[i];
@@ -334,33 +419,40 @@ __global__ __launch_bounds__(256) void blk_forward(const P p) {
                 }
         }
         __syncthreads();
+        BLK_STAMP(7);
     }
     if (tid < Fo) {
         p.bn_part[((int64_t)blockIdx.x * 2 + 0) * Fo + tid] = s0;
         p.bn_part[((int64_t)blockIdx.x * 2 + 1) * Fo + tid] = s1;
     }
+    BLK_STAMP(10);
 }
 
-// column sums of a [parts][2][Fo] table of doubles in a fixed order: groups of threads take interleaved parts, the groups are added in
-// order.  Result in RED[0 .. Fo) / RED[Fo .. 2 Fo); ends on a barrier.  RED: 2 * Fo * (groups + 1) doubles.
+// column sums of a [parts][2][Fo] table of doubles (a part = one row of 2 Fo doubles) in a fixed order: NT / Fo groups of threads (at most
+// 16) take interleaved parts, a thread owns one 16-byte pair of the row, six loads in flight, and the groups are added in order.  Result
+// in RED[0 .. 2 Fo) ([sum | second sum]); ends on a barrier.  RED: 2 * Fo * 17 doubles.
+constexpr int kRedGroups = 16;
 __device__ __forceinline__ void column_sums(const double* part, int parts, int Fo, double* RED) {
     const int tid = threadIdx.x, NT = blockDim.x;
-    const int G = max(1, min(NT / Fo, 8));
-    const int grp = tid / Fo, col = tid - grp * Fo;
+    const int G = max(1, min(NT / Fo, kRedGroups));
+    const int grp = tid / Fo, q = tid - grp * Fo;          // the pair (2 q, 2 q + 1) of the 2 Fo doubles
     if (grp < G) {
-        double a0 = 0.0, a1 = 0.0;
-        for (int b = grp; b < parts; b += G) {
-            a0 += part[((int64_t)b * 2 + 0) * Fo + col];
-            a1 += part[((int64_t)b * 2 + 1) * Fo + col];
+        double2 a = make_double2(0.0, 0.0);
+        for (int b0 = grp; b0 < parts; b0 += 6 * G) {
+            double2 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[u] = *reinterpret_cast<const double2*>(part + (int64_t)min(b0 + u * G, parts - 1) * 2 * Fo + 2 * q);
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+                if (b0 + u * G < parts) { a.x += v[u].x; a.y += v[u].y; }
         }
-        RED[(grp + 1) * 2 * Fo + col] = a0;
-        RED[(grp + 1) * 2 * Fo + Fo + col] = a1;
+        *reinterpret_cast<double2*>(RED + (grp + 1) * 2 * Fo + 2 * q) = a;
     }
     __syncthreads();
-    if (tid < Fo) {
-        double a0 = 0.0, a1 = 0.0;
-        for (int q = 0; q < G; ++q) { a0 += RED[(q + 1) * 2 * Fo + tid]; a1 += RED[(q + 1) * 2 * Fo + Fo + tid]; }
-        RED[tid] = a0; RED[Fo + tid] = a1;
+    if (tid < 2 * Fo) {
+        double t = 0.0;
+        for (int k = 0; k < G; ++k) t += RED[(k + 1) * 2 * Fo + tid];
+        RED[tid] = t;
     }
     __syncthreads();
 }
@@ -371,18 +463,21 @@ __device__ __forceinline__ float col_param(const float* const (&ptrs)[kMaxT], in
 }
 
 // ---- forward tail: BatchNorm (training statistics) -> ReLU -> + h   or   -> mixing Linear -> LeakyReLU -> + h ------------------------
-// LDS: [mean | invstd | gamma | beta] (4 Fo floats), Y1 [rows][Fo], then the reduction scratch (doubles)
-__global__ __launch_bounds__(256) void blk_tail_fwd(const P p) {
+// LDS: [mean | invstd | gamma | beta] (4 Fo floats), Y1 [rows][Fo], W_mix [Fo][Fo] (towers), then the reduction scratch (doubles)
+__global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
     const int Fo = p.Fo, RW = p.tail_rows;
     float* MEAN = lds; float* INVSTD = lds + Fo; float* GAM = lds + 2 * Fo; float* BET = lds + 3 * Fo;
     float* Y1 = lds + 4 * Fo;
-    double* RED = reinterpret_cast<double*>(lds + ((4 * Fo + RW * Fo + 1) & ~1));
+    float* WM = Y1 + RW * Fo;
+    const int n_wm = p.mixing ? Fo * Fo : 0;
+    double* RED = reinterpret_cast<double*>(lds + ((4 * Fo + RW * Fo + n_wm + 1) & ~1));
     const int64_t m0 = (int64_t)blockIdx.x * RW;
     const int rows = (int)min((int64_t)RW, p.N - m0);
-    // this workgroup's rows are requested before the statistics are summed
+    // this workgroup's rows and the mixing weight are requested before the statistics are summed
     for (int i = tid; i < RW * Fo; i += NT) Y1[i] = i < rows * Fo ? p.y0[m0 * Fo + i] : 0.f;
+    for (int i = tid; i < n_wm; i += NT) WM[i] = p.w_mix[i];
     column_sums(p.bn_part, p.n_blocks, Fo, RED);
     if (tid < Fo) {
         const double n = (double)p.N;
@@ -422,7 +517,7 @@ __global__ __launch_bounds__(256) void blk_tail_fwd(const P p) {
         const int tq = job % ntq, strip = job / ntq;
         const int n = tq * 16 + i16, m = strip * 16 + i16;
         const bool nok = n < Fo;
-        const float* wrow = p.w_mix + (int64_t)min(n, Fo - 1) * Fo;
+        const float* wrow = WM + min(n, Fo - 1) * Fo;
         const float* xrow = Y1 + m * Fo;
         f4 acc = {0.f, 0.f, 0.f, 0.f};
         tile_mma(acc, Fo, g,
@@ -444,13 +539,13 @@ __global__ __launch_bounds__(256) void blk_tail_fwd(const P p) {
 }
 
 // ---- backward tail: g_out -> g_y1 (the gradient at BatchNorm's output), BatchNorm's column sums, the mixing network's parameters --------
-// LDS: [mean | invstd | gamma | beta], XH [RW][Fo] (normalised y0), Y1 [RW][Fo], GZ [RW][Fo], GY1 [RW][Fo]
-__global__ __launch_bounds__(256) void blk_tail_bwd(const P p) {
+// LDS: [mean | invstd | gamma | beta], XH [RW][Fo] (normalised y0), Y1 [RW][Fo], GZ [RW][Fo], GY1 [RW][Fo], W_mix [Fo][Fo] (towers)
+__global__ __launch_bounds__(512) void blk_tail_bwd(const P p) {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
     const int Fo = p.Fo, RW = p.tail_rows;
     float* MEAN = lds; float* INVSTD = lds + Fo; float* GAM = lds + 2 * Fo; float* BET = lds + 3 * Fo;
-    float* XH = lds + 4 * Fo; float* Y1 = XH + RW * Fo; float* GZ = Y1 + RW * Fo; float* GY1 = GZ + RW * Fo;
+    float* XH = lds + 4 * Fo; float* Y1 = XH + RW * Fo; float* GZ = Y1 + RW * Fo; float* GY1 = GZ + RW * Fo; float* WM = GY1 + RW * Fo;
     const int64_t m0 = (int64_t)blockIdx.x * RW;
     const int rows = (int)min((int64_t)RW, p.N - m0);
     if (tid < Fo) {
@@ -461,6 +556,8 @@ __global__ __launch_bounds__(256) void blk_tail_bwd(const P p) {
         XH[i] = i < rows * Fo ? p.y0[m0 * Fo + i] : 0.f;
         GZ[i] = i < rows * Fo ? p.g_out[m0 * Fo + i] : 0.f;
     }
+    if (p.mixing)
+        for (int i = tid; i < Fo * Fo; i += NT) WM[i] = p.w_mix[i];
     __syncthreads();
     {
         RowFeat x = rf_at(tid, Fo);
@@ -481,7 +578,7 @@ __global__ __launch_bounds__(256) void blk_tail_bwd(const P p) {
             const int tq = job % ntq, strip = job / ntq;
             const int n = tq * 16 + i16, m = strip * 16 + i16;
             const bool nok = n < Fo;
-            const float* wrow = p.w_mix + (int64_t)min(n, Fo - 1) * Fo;
+            const float* wrow = WM + min(n, Fo - 1) * Fo;
             const float* xrow = Y1 + m * Fo;
             f4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mma(acc, Fo, g,
@@ -502,11 +599,11 @@ __global__ __launch_bounds__(256) void blk_tail_bwd(const P p) {
             const int tq = job % ntq, strip = job / ntq;
             const int kk = tq * 16 + i16, m = strip * 16 + i16;
             const bool kok = kk < Fo;
-            const float* wcol = p.w_mix + min(kk, Fo - 1);
+            const float* wcol = WM + min(kk, Fo - 1);
             const float* grow = GZ + m * Fo;
             f4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mma(acc, Fo, g,
-                     [&](int n) { const float v = wcol[(int64_t)min(n, Fo - 1) * Fo]; return (kok && n < Fo) ? v : 0.f; },
+                     [&](int n) { const float v = wcol[min(n, Fo - 1) * Fo]; return (kok && n < Fo) ? v : 0.f; },
                      [&](int n) { const float v = grow[min(n, Fo - 1)]; return n < Fo ? v : 0.f; });
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -575,11 +672,12 @@ __device__ __forceinline__ float edge_grad(const P& p, const Ctx& c, int mc, int
 }
 
 // ---- backward of a block ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blk_backward(const P p) {
+__global__ __launch_bounds__(1024) void blk_backward(const P p) {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
     const int F = p.F, Fo = p.Fo, RC = p.RC;
     Ctx c;
+    BLK_STAMP(0);
     {   // BatchNorm's column sums (= d beta, d gamma) from the tail's partials; requested first: they land during the prologue
         double* RED = reinterpret_cast<double*>(lds + p.L.red);
         column_sums(p.tail_part, p.n_tail, Fo, RED);
@@ -595,6 +693,7 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
         SUMS[4 * Fo + tid] = (float)c.RED[tid] * inv_n; SUMS[5 * Fo + tid] = (float)c.RED[Fo + tid] * inv_n;
     }
     __syncthreads();
+    BLK_STAMP(5);
     float* bpart = p.blk_part + (int64_t)blockIdx.x * p.n_blk_param;
     const int off_wpost = p.has_pre ? p.fi * p.ld_pre + p.fi : 0, off_bpost = off_wpost + p.fo * p.ld_post;
     float gb_post = 0.f;                                       // d b_post of column tid
@@ -615,6 +714,7 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(6);
         if (tid < Fo)
             for (int m = 0; m < rc; ++m) gb_post += c.GY[m * Fo + tid];
         // d aggregate rows = sum_s scale_s (g_yr W_post[:, block s]); d h through posttrans' h block
@@ -633,15 +733,36 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
                     const int kk = tk * 16 + i16;
                     const bool kok = kk < p.K;
                     f4 out = {0.f, 0.f, 0.f, 0.f};
-                    for (int s = 0; s < p.S; ++s) {
-                        const float* wcol = p.w_post[t] + p.h_off + s * p.K + min(kk, p.K - 1);
-                        f4 acc = {0.f, 0.f, 0.f, 0.f};
-                        tile_mma(acc, p.fo, g,
-                                 [&](int n) { const float v = wcol[(int64_t)min(n, p.fo - 1) * p.ld_post]; return (kok && n < p.fo) ? v : 0.f; },
-                                 [&](int n) { const float v = grow[min(n, p.fo - 1)]; return (mok && n < p.fo) ? v : 0.f; });
-                        const float sc = s == 0 ? fc[0] : (s == 1 ? fc[1] : fc[2]);
+                    const float* wcol = p.w_post[t] + p.h_off + min(kk, p.K - 1);
+                    f4 acc3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    for (int n0 = 0; n0 < p.fo; n0 += 16) {      // (the three scalers' columns of a 16-n block are requested together)
+                        float av[3][4], gv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) out[u] += sc * acc[u];
+                        for (int s = 0; s < 3; ++s)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                av[s][u] = wcol[(int64_t)min(n0 + 4 * g + u, p.fo - 1) * p.ld_post + min(s, p.S - 1) * p.K];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = n0 + 4 * g + u;
+                            const float v = grow[min(n, p.fo - 1)];
+                            gv[u] = (mok && n < p.fo) ? v : 0.f;
+                        }
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            if (s < p.S) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) acc3[s] = mfma4((kok && n0 + 4 * g + u < p.fo) ? av[s][u] : 0.f, gv[u], acc3[s]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        if (s < p.S) {
+                            const float sc = s == 0 ? fc[0] : (s == 1 ? fc[1] : fc[2]);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) out[u] += sc * acc3[s][u];
+                        }
                     }
                     if (mok) {
 #pragma unroll
@@ -656,9 +777,7 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
                     const bool kok = kk < p.fi;
                     const float* wcol = p.w_post[t] + min(kk, p.fi - 1);
                     f4 acc = {0.f, 0.f, 0.f, 0.f};
-                    tile_mma(acc, p.fo, g,
-                             [&](int n) { const float v = wcol[(int64_t)min(n, p.fo - 1) * p.ld_post]; return (kok && n < p.fo) ? v : 0.f; },
-                             [&](int n) { const float v = grow[min(n, p.fo - 1)]; return (mok && n < p.fo) ? v : 0.f; });
+                    tile_mma_g(acc, p.fo, g, wcol, p.ld_post, kok, [&](int n) { const float v = grow[min(n, p.fo - 1)]; return (mok && n < p.fo) ? v : 0.f; });
                     if (mok) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -670,13 +789,15 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(7);
         if (p.dbg_gagg)
             for (int i = tid; i < rc * p.L.ld_agg; i += NT) p.dbg_gagg[(int64_t)(c.lo + c0) * p.L.ld_agg + i] = c.AGG[i];
         // recompute the rows' accumulators (first-occurrence arg tracking), coefficient rows -> LDS; the aggregate values take the
         // place of their own upstream gradients (a (row, aggregator, feature) entry belongs to exactly one work item)
         {
             RowFeat x = rf_at(tid, F);
-            for (; x.r < rc; rf_step(x, NT, F)) {
+            const RowStep st_ = rf_stride(NT, F);
+            for (; x.r < rc; rf_step(x, st_, F)) {
                 const int r = c0 + x.r, f = x.f;
                 const int t = tower_of(f, p.fi, p.T), ft = f - t * p.fi;
                 float* arow = c.AGG + x.r * p.L.ld_agg;
@@ -717,6 +838,7 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(8);
         // d W_post partial: D[n][kk] (+)= sum over the chunk's rows of g_yr[m][n] * [h | scale_s * aggregate][m][kk]
         {
             const int ntn = (p.fo + 15) >> 4, ntk = (p.ld_post + 15) >> 4;
@@ -759,7 +881,8 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
         // every source row gathers the gradient rows of its out-edges whose destination lies in this chunk, (source, slot) order
         {
             RowFeat x = rf_at(tid, F);
-            for (; x.r < R; rf_step(x, NT, F)) {
+            const RowStep st_ = rf_stride(NT, F);
+            for (; x.r < R; rf_step(x, st_, F)) {
                 const int u = x.r, f = x.f;
                 const int* cur = c.CUR + (((c0 / RC) & 1) ? R : 0);
                 float a = 0.f;
@@ -776,7 +899,8 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
         // d Q: the row sums of the same gradient rows, by the destination's work item
         if (p.has_pre) {
             RowFeat x = rf_at(tid, F);
-            for (; x.r < rc; rf_step(x, NT, F)) {
+            const RowStep st_ = rf_stride(NT, F);
+            for (; x.r < rc; rf_step(x, st_, F)) {
                 const int r = c0 + x.r, f = x.f;
                 float a = 0.f;
                 for (int j = c.IP[r]; j < c.IP[r + 1]; ++j) a += edge_grad(p, c, x.r, j, f, msg_at(p, c, c.SRC[j], r, f));
@@ -784,11 +908,13 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             }
         }
         __syncthreads();
+        BLK_STAMP(9);
     }
     if (tid < Fo) {
         const int t = tower_of(tid, p.fo, p.T);
         bpart[t * p.off_tower + off_bpost + (tid - t * p.fo)] = gb_post;
     }
+    BLK_STAMP(10);
     if (!p.has_pre) {
         // simple layer: x_src = x_in = h: d h = d x_src + d x_in (both in GA) + the residual's share
         const int64_t base = (int64_t)c.lo * F;
@@ -808,9 +934,7 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             for (int half = 0; half < 2; ++half) {
                 const float* wcol = p.w_pre[t] + half * p.fi + min(ii, p.fi - 1);
                 const float* grow = (half ? c.GB : c.GA) + min(m, R - 1) * F + t * p.fi;
-                tile_mma(acc, p.fi, g,
-                         [&](int o) { const float v = wcol[(int64_t)min(o, p.fi - 1) * p.ld_pre]; return (iok && o < p.fi) ? v : 0.f; },
-                         [&](int o) { const float v = grow[min(o, p.fi - 1)]; return (mok && o < p.fi) ? v : 0.f; });
+                tile_mma_g(acc, p.fi, g, wcol, p.ld_pre, iok, [&](int o) { const float v = grow[min(o, p.fi - 1)]; return (mok && o < p.fi) ? v : 0.f; });
             }
             if (mok) {
 #pragma unroll
@@ -852,24 +976,33 @@ __global__ __launch_bounds__(256) void blk_backward(const P p) {
             bpart[t * p.off_tower + p.fi * p.ld_pre + (tid - t * p.fi)] = a;
         }
     }
+    BLK_STAMP(11);
 }
 
-// out[i] = sum over parts of part[q][i], parts in order; two segments (block partials, tail partials) behind each other in `out`
+// out[i] = sum over parts of part[q][i]: eight lanes per output take interleaved parts (all of a lane's loads in flight: the partials are
+// L2 / MALL resident, the kernel is latency-bound), added across the lanes in a fixed order; two segments (block partials, tail partials)
+// behind each other in `out`
 __global__ __launch_bounds__(256) void blk_reduce(const float* __restrict__ part_a, int n_a, int parts_a, const float* __restrict__ part_b, int n_b,
                                                   int parts_b, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_a + n_b) return;
-    const bool a = i < n_a;
-    const float* src = a ? part_a + i : part_b + (i - n_a);
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gt >> 3, sub = gt & 7;
+    const bool live = i < n_a + n_b;
+    const int ii = live ? i : 0;
+    const bool a = ii < n_a;
+    const float* src = a ? part_a + ii : part_b + (ii - n_a);
     const int stride = a ? n_a : n_b, parts = a ? parts_a : parts_b;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int q = 0;
-    for (; q + 4 <= parts; q += 4) {
-        s0 += src[(int64_t)q * stride]; s1 += src[(int64_t)(q + 1) * stride];
-        s2 += src[(int64_t)(q + 2) * stride]; s3 += src[(int64_t)(q + 3) * stride];
+    float acc = 0.f;
+    for (int q0 = sub; q0 < parts; q0 += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)min(q0 + 8 * u, parts - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (q0 + 8 * u < parts) ? v[u] : 0.f;
     }
-    for (; q < parts; ++q) s0 += src[(int64_t)q * stride];
-    out[i] = (s0 + s1) + (s2 + s3);
+    acc += __shfl_xor(acc, 1, kWave);
+    acc += __shfl_xor(acc, 2, kWave);
+    acc += __shfl_xor(acc, 4, kWave);
+    if (live && sub == 0) out[i] = acc;
 }
 
 }  // namespace blk

@@ -687,6 +687,7 @@ typedef struct DgnBlockLayer {
     float* out;                  /* [N, T f_out] (forward)                                                                    */
     void* ws; size_t ws_bytes;   /* dgn_block_layer_{forward,backward}_workspace_bytes()                                      */
     float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
+    int64_t* dbg_time;           /* profiling only: [n_blocks][16] wall-clock stamps (100 MHz) of the block kernel's phases; NULL      */
 } DgnBlockLayer;
 typedef struct DgnBlockGrads {
     const float* g_out;          /* [N, T f_out]                                                                              */
