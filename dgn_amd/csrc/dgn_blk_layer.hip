@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "dgn_blk_layer_kernels.hpp"
@@ -15,7 +16,6 @@ using blk::Layout;
 using blk::P;
 
 constexpr size_t kLdsBytes = 160 * 1024;
-constexpr int kThreads = 1024;      // blk_forward / blk_backward: 16 waves per workgroup (four per SIMD: the products' memory latencies overlap)
 constexpr int kTailThreads = 512;
 
 inline int up4(int x) { return (x + 3) & ~3; }
@@ -54,7 +54,7 @@ bool dims_of(const DgnBlockLayer* L, Dims& d, const char* fn) {
     d.n_blk_param = d.T * d.off_tower;
     d.n_tail_param = d.mixing ? d.Fo * d.Fo + d.Fo : 0;
     // tail kernels: 16 rows per wave; two waves per workgroup while that still gives every CU a workgroup, else four
-    d.tail_rows = d.N <= 32 * 256 ? 32 : 64;
+    d.tail_rows = d.N <= 16 * 256 ? 16 : (d.N <= 32 * 256 ? 32 : 64);
     d.n_tail = (int)((d.N + d.tail_rows - 1) / d.tail_rows);
     return true;
 }
@@ -77,41 +77,74 @@ void coef_map(const DgnAggSpec* spec, int8_t (&cmap)[blk::CF_SLOTS], int& n_coef
     for (int q = 0; q < blk::CF_SLOTS; ++q) cmap[q] = need[q] ? (int8_t)n_coef++ : (int8_t)-1;
 }
 
-// LDS plan of blk_forward / blk_backward; false: a block does not fit
+inline int up16(int x) { return (x + 15) & ~15; }
+
+// threads of a (block, tower) workgroup: about one (row, feature) work item per thread of the largest block, but never so many that
+// the grid's workgroups cannot all be resident at once (registers allow ~12 waves per CU of blk_forward, ~20 of blk_backward:
+// measured on the towers layer -- 640 workgroups of 512 threads ran in three rounds of 256)
+int block_threads(const Dims& d, bool bwd) {
+    const int items = d.R * d.fi;
+    const int64_t need = std::max<int64_t>(1, ((int64_t)d.n_blocks * d.T + 255) / 256);      // workgroups a CU has to hold
+    const int max_waves = bwd ? 20 : 12, bound = bwd ? 16 : 8;
+    int waves = std::min((items + 63) / 64, bound);
+    waves = std::min<int64_t>(waves, std::max<int64_t>(2, max_waves / need));
+    if (waves > 4) waves &= ~3;      // (whole multiples of the four SIMDs: a 6-wave workgroup loads them 2, 2, 1, 1 and three of those do not fit)
+    waves = std::max(waves, std::max((2 * d.fo + 63) / 64, (d.fi + 63) / 64));      // (the column loops want a thread per column / pair)
+    return 64 * std::max(waves, 2);
+}
+int resident_per_cu(const Dims& d, bool bwd) { return std::max(1, (bwd ? 20 : 12) * 64 / block_threads(d, bwd)); }
+
+// LDS plan of blk_forward / blk_backward (per (block, tower) workgroup); false: a block does not fit
 bool plan_lds(const Dims& d, const DgnAggSpec* spec, bool bwd, Layout& L, int& RC, int8_t (&cmap)[blk::CF_SLOTS]) {
     int n_coef = 0;
     coef_map(spec, cmap, n_coef);
     const int R = d.R, E = std::max(d.Emax, 1);
+    // the chunk (rows of posttrans' input / coefficient rows held at a time): as large as possible -- fewer barriers, weight-gradient
+    // tiles finished in one go -- among the sizes with the fewest ROUNDS of workgroups (LDS decides how many share a CU)
+    const int64_t wgs = (int64_t)d.n_blocks * d.T;
+    const int by_threads = resident_per_cu(d, bwd);
+    bool found = false; int64_t best_rounds = 0; Layout bestL{}; int best_rc = 0;
     for (int rc : {64, 48, 32, 16}) {
         if (rc > 16 && rc >= R + 16) continue;              // (no point in a chunk a whole strip larger than the largest block)
         int off = 0;
         auto take = [&](int n) { const int at = off; off += up4(std::max(n, 0)); return at; };
         L = Layout{};
-        L.ld_agg = d.T * d.K; L.ld_w = E; L.n_coef = n_coef;
-        L.hb = take(R * d.F);
-        L.pq = take(d.has_pre ? R * 2 * d.F : 0);
+        L.ldh = up4(d.fi); L.ldy = up4(d.fo); L.ho = d.has_pre ? up4(d.fi) : 0; L.kp = L.ho + up4(d.K); L.ld_w = E; L.n_coef = n_coef;
+        L.hb = take(R * L.ldh);
+        L.pq = take(d.has_pre ? R * 2 * L.ldh : 0);
         L.eig = take(R * d.n_ch);
         L.ip = take(R + 1); L.cp = take(bwd ? R + 1 : 0); L.cur = take(bwd ? 2 * R : 0);
         L.src = take(E); L.dst = take(E); L.csci = take(bwd ? E : 0);
         L.w = take(E * d.n_ch);
         L.fac = take(4 * R);
-        L.agg = take(rc * L.ld_agg);
-        L.gy = take(bwd ? rc * d.Fo : 0);
-        L.y = take(bwd ? 0 : rc * d.Fo);
-        L.coef = take(bwd ? rc * n_coef * d.F : 0);
-        L.ga = take(bwd ? R * d.F : 0);
-        L.gb = take(bwd && d.has_pre ? R * d.F : 0);
-        L.gc = take(bwd && d.has_pre ? R * d.F : 0);
+        L.xp = take(rc * L.kp);
+        L.y = take((bwd ? up16(R) : up16(rc)) * L.ldy);      // forward: a chunk's posttrans output; backward: g_yr of the whole block
+        L.y0s = take(bwd ? R * L.ldy : 0);
+        L.coef = take(bwd ? rc * n_coef * d.fi : 0);
+        L.ga = take(bwd ? R * L.ldh : 0);
+        L.gb = take(bwd && d.has_pre ? R * L.ldh : 0);
+        L.gc = take(bwd && d.has_pre ? R * L.ldh : 0);
+        L.vec = take(d.fi + 7 * d.fo);
         off = (off + 1) & ~1;
-        L.red = take(bwd ? 2 * (2 * d.Fo * 17) : 0);          // doubles: column_sums' group partials; then the BatchNorm constants
+        L.red = take(bwd ? 2 * (2 * d.fo * 17) : 0);          // doubles: column_sums_cols' group partials
         L.total = off;
-        if ((size_t)off * 4 <= kLdsBytes) { RC = rc; return true; }
+        if ((size_t)off * 4 > kLdsBytes) continue;
+        const int per_cu = std::max(1, std::min(by_threads, (int)(kLdsBytes / ((size_t)off * 4))));
+        const int64_t rounds = (wgs + 256 * (int64_t)per_cu - 1) / (256 * (int64_t)per_cu);
+        if (!found || rounds < best_rounds) { found = true; best_rounds = rounds; bestL = L; best_rc = rc; }
     }
-    return false;
+    if (found) { L = bestL; RC = best_rc; }
+    return found;
 }
 
-size_t tail_fwd_lds(const Dims& d) { return (size_t)(((4 * d.Fo + d.tail_rows * d.Fo + (d.mixing ? d.Fo * d.Fo : 0) + 1) & ~1) + 2 * (2 * d.Fo * 17)) * 4; }
-size_t tail_bwd_lds(const Dims& d) { return (size_t)(4 * d.Fo + 4 * d.tail_rows * d.Fo + (d.mixing ? d.Fo * d.Fo : 0)) * 4; }
+size_t tail_fwd_lds(const Dims& d) {
+    const int ldk = up4(d.Fo), c4 = up4(4 * d.Fo);
+    return (size_t)(((c4 + d.tail_rows * ldk + (d.mixing ? d.Fo * ldk : 0) + 1) & ~1) + 2 * (2 * d.Fo * 17)) * 4;
+}
+size_t tail_bwd_lds(const Dims& d) {
+    const int ldk = up4(d.Fo), c4 = up4(4 * d.Fo);
+    return (size_t)(c4 + 4 * d.tail_rows * ldk + (d.mixing ? d.Fo * ldk : 0)) * 4;
+}
 
 struct FwdWs { size_t bn_part, total; };
 FwdWs fwd_ws(const Dims& d) {
@@ -204,6 +237,41 @@ int set_lds(const void* kernel) {
     return DGN_OK;
 }
 
+template <bool FWD, class O, class C, bool PRE>
+int launch_block(const P& p, dim3 grid, int threads, hipStream_t stream) {
+    if constexpr (FWD) {
+        static const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_forward<O, C, PRE>));
+        if (rc) return rc;
+        hipLaunchKernelGGL((blk::blk_forward<O, C, PRE>), grid, dim3(threads), (size_t)p.L.total * 4, stream, p);
+    } else {
+        static const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_backward<O, C, PRE>));
+        if (rc) return rc;
+        hipLaunchKernelGGL((blk::blk_backward<O, C, PRE>), grid, dim3(threads), (size_t)p.L.total * 4, stream, p);
+    }
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
+// The aggregator lists of the reference's configs run kernels with the list baked in (their per-row epilogue and coefficient code is
+// a third of the generic one's instructions -- and this route is instruction-bound); anything else the generic kernels.
+// BLK_LIST(n_agg, op_pack, ch_pack, n_ch, stats, av, has_pre)
+template <bool FWD>
+int launch_for_list(const P& p, bool pre, dim3 grid, int threads, hipStream_t stream) {
+    static const bool no_hot = getenv("DGN_NO_HOT") != nullptr;
+#define BLK_LIST(NA, OPS, CHS, N, S_, A_, PRE_)                                                                              \
+    if (!no_hot && p.a.n_agg == NA && p.a.op_pack == OPS && p.a.ch_pack == CHS && p.n_ch == N && pre == PRE_)               \
+        return launch_block<FWD, StaticOps<NA, OPS, CHS, 1, 0x0u>, Cfg<1, N, S_, A_>, PRE_>(p, grid, threads, stream);
+    BLK_LIST(5, 0x86320ull, 0x0ull, 1, true, true, true)      // mean max min dir1-av dir1-dx: ZINC towers / complex (BASELINE c2)
+    BLK_LIST(5, 0x68320ull, 0x0ull, 1, true, true, false)     // mean max min dir1-dx dir1-av: HIV / PCBA json, simple (BASELINE c4)
+    BLK_LIST(5, 0x68320ull, 0x0ull, 1, true, true, true)      //   ... complex / towers
+    BLK_LIST(2, 0x90ull, 0x0ull, 1, false, false, false)      // mean dir1-dx-no-abs: BASELINE c1 (simple)
+    BLK_LIST(3, 0x880ull, 0x40ull, 2, false, false, false)    // mean dir1-dx dir2-dx: CIFAR10 json, simple (BASELINE c3)
+    BLK_LIST(3, 0x680ull, 0x0ull, 1, false, true, true)       // mean dir1-dx dir1-av: ZINC json, complex
+#undef BLK_LIST
+    if (pre) return launch_block<FWD, DynOps, Cfg<1, blk::kMaxCh, true, true>, true>(p, grid, threads, stream);
+    return launch_block<FWD, DynOps, Cfg<1, blk::kMaxCh, true, true>, false>(p, grid, threads, stream);
+}
+
 }  // namespace
 }  // namespace dgn
 
@@ -254,10 +322,9 @@ extern "C" int dgn_block_layer_forward(const DgnBlockLayer* L, void* stream_) {
     p.bn_part = reinterpret_cast<double*>(static_cast<char*>(L->ws) + w.bn_part);
     p.dbg_agg = L->dbg_agg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_forward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd)); }();
+    static int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd));
     if (lds_rc) return lds_rc;
-    hipLaunchKernelGGL(blk::blk_forward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
-    DGN_HIP_CHECK(hipGetLastError());
+    DGN_TRY_RC(launch_for_list<true>(p, d.has_pre != 0, dim3(d.n_blocks, d.T), block_threads(d, false), stream));
     hipLaunchKernelGGL(blk::blk_tail_fwd, dim3(d.n_tail), dim3(kTailThreads), tail_fwd_lds(d), stream, p);
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
@@ -281,12 +348,11 @@ extern "C" int dgn_block_layer_backward(const DgnBlockLayer* L, const DgnBlockGr
     p.blk_part = reinterpret_cast<float*>(ws + w.blk_part);
     p.dbg_gagg = L->dbg_gagg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static int lds_rc = [] { int r = set_lds(reinterpret_cast<const void*>(&blk::blk_backward)); return r ? r : set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd)); }();
+    static int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd));
     if (lds_rc) return lds_rc;
     hipLaunchKernelGGL(blk::blk_tail_bwd, dim3(d.n_tail), dim3(kTailThreads), tail_bwd_lds(d), stream, p);
     DGN_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(blk::blk_backward, dim3(d.n_blocks), dim3(kThreads), (size_t)p.L.total * 4, stream, p);
-    DGN_HIP_CHECK(hipGetLastError());
+    DGN_TRY_RC(launch_for_list<false>(p, d.has_pre != 0, dim3(d.n_blocks, d.T), block_threads(d, true), stream));
     const int n_out = d.n_blk_param + d.n_tail_param;
     hipLaunchKernelGGL(blk::blk_reduce, dim3((8 * n_out + 255) / 256), dim3(256), 0, stream, (const float*)p.blk_part, d.n_blk_param, d.n_blocks,
                        (const float*)p.tail_wpart, d.n_tail_param, d.n_tail, G->g_params);

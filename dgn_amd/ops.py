@@ -1413,7 +1413,7 @@ class _BlockLayer(torch.autograd.Function):
         dbg = _BLK_DBG
         if dbg is not None:
             dbg["agg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
-            dbg["t_fwd"] = torch.zeros(table["n_blocks"], 16, dtype=torch.int64, device=dev)
+            dbg["t_fwd"] = torch.zeros(T * table["n_blocks"], 16, dtype=torch.int64, device=dev)
             L.dbg_agg, L.dbg_time = dbg["agg"].data_ptr(), dbg["t_fwd"].data_ptr()
         _lib.check(lib.dgn_block_layer_forward(C.byref(L), _lib.stream_ptr(dev)), "dgn_block_layer_forward")
         ctx.save_for_backward(h, snorm, eig, saved, *params)
@@ -1445,7 +1445,7 @@ class _BlockLayer(torch.autograd.Function):
         dbg = _BLK_DBG
         if dbg is not None:
             dbg["gagg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
-            dbg["t_bwd"] = torch.zeros(table["n_blocks"], 16, dtype=torch.int64, device=dev)
+            dbg["t_bwd"] = torch.zeros(T * table["n_blocks"], 16, dtype=torch.int64, device=dev)
             L.dbg_gagg, L.dbg_time = dbg["gagg"].data_ptr(), dbg["t_bwd"].data_ptr()
         _lib.check(lib.dgn_block_layer_backward(C.byref(L), C.byref(G), _lib.stream_ptr(dev)), "dgn_block_layer_backward")
         # views of the flat gradient buffer, in the order of `params`

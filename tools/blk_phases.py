@@ -39,5 +39,9 @@ for key in ("t_fwd", "t_bwd"):
     mean = torch.nanmean(rel, dim=0)
     mx = torch.nan_to_num(rel, nan=0.0).max(dim=0).values
     span = (ts[ts > 0].max() - ts[ts > 0].min()) * 0.01
+    starts = (ts[:, 0] - ts[:, 0].min()) * 0.01
+    nb = t["n_blocks"]
+    print(key, "start offsets of the towers' workgroups (mean per tower):", [round(float(starts[i * nb:(i + 1) * nb].mean()), 2) for i in range(ts.shape[0] // nb)],
+          "latest start:", round(float(starts.max()), 2))
     print(key, "mean us since kernel start per stamp:", [None if m != m else round(float(m), 2) for m in mean])
     print(key, "max:", [round(float(m), 2) for m in mx], "first start -> last stamp:", round(float(span), 2))
