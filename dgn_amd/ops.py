@@ -1393,7 +1393,31 @@ def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
     return ok[key]
 
 
+def _block_sizes(lib, table, L, cfg, params):
+    """Per (batch, layer shape): workspace bytes, parameter-gradient floats and the split of the flat gradient buffer (cached on the
+    block table: they depend on the block table and the widths only)."""
+    key = ("sizes",) + tuple(cfg[:4]) + (len(params),)
+    ent = table.get(key)
+    if ent is None:
+        type_net, T, fi, fo = cfg[:4]
+        per = 6 if type_net != 0 else 4
+        sizes, shapes = [], []
+        for t in range(T):
+            for q in range(per - 2):
+                sizes.append(params[t * per + q].numel()); shapes.append(tuple(params[t * per + q].shape))
+        for p_ in params[T * per:]:
+            sizes.append(p_.numel()); shapes.append(tuple(p_.shape))
+        n_par = int(lib.dgn_block_layer_param_grad_floats(C.byref(L)))
+        assert sum(sizes) == n_par, "block_layer: parameter shapes do not match the layer's widths"
+        sizes += [fo] * (2 * T)
+        ent = table[key] = (int(lib.dgn_block_layer_forward_workspace_bytes(C.byref(L))), int(lib.dgn_block_layer_backward_workspace_bytes(C.byref(L))),
+                            n_par, sizes, shapes)
+    return ent
+
+
 class _BlockLayer(torch.autograd.Function):
+    # The step is launch-bound on the host once the GPU side is ~0.1 ms: the struct built by the forward is kept for the backward, sizes
+    # are cached per (batch, layer shape), scratch and saved tensors share allocations, the gradients leave as ONE split of a flat buffer.
     @staticmethod
     def forward(ctx, graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, *params):
         lib = _lib.load()
@@ -1401,67 +1425,62 @@ class _BlockLayer(torch.autograd.Function):
         N, Fo, dev = h.shape[0], T * fo, h.device
         table = graph.block_table()
         h = h.contiguous()
-        params = tuple(p.contiguous() for p in params)
-        saved = torch.empty(N * Fo + 2 * Fo, dtype=torch.float32, device=dev)
-        out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
+        params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)
         L, keep = _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params)
+        ws_f, ws_b, n_par, sizes, shapes = _block_sizes(lib, table, L, cfg, params)
+        n_saved = N * Fo + 2 * Fo
+        saved = torch.empty(n_saved + (ws_f + 3) // 4 + 64, dtype=torch.float32, device=dev)      # [y0 | mean | invstd | (forward scratch)]
+        out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
         base = saved.data_ptr()
         L.y0, L.save_mean, L.save_invstd, L.out = base, base + 4 * N * Fo, base + 4 * (N * Fo + Fo), out.data_ptr()
-        nbytes = lib.dgn_block_layer_forward_workspace_bytes(C.byref(L))
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
+        L.ws, L.ws_bytes = (base + 4 * n_saved + 255) & ~255, ws_f
         dbg = _BLK_DBG
         if dbg is not None:
             dbg["agg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
             dbg["t_fwd"] = torch.zeros(T * table["n_blocks"], 16, dtype=torch.int64, device=dev)
             L.dbg_agg, L.dbg_time = dbg["agg"].data_ptr(), dbg["t_fwd"].data_ptr()
         _lib.check(lib.dgn_block_layer_forward(C.byref(L), _lib.stream_ptr(dev)), "dgn_block_layer_forward")
+        L.dbg_agg, L.dbg_time = None, None
         ctx.save_for_backward(h, snorm, eig, saved, *params)
-        ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
+        ctx.graph, ctx.cfg, ctx.call = graph, cfg, (L, keep, ws_b, n_par, sizes, shapes)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        h, snorm, eig, saved = ctx.saved_tensors[:4]
-        params = ctx.saved_tensors[4:]
-        graph, plan, cfg = ctx.graph, ctx.plan, ctx.cfg
+        h = ctx.saved_tensors[0]
+        graph, cfg = ctx.graph, ctx.cfg
+        L, keep, ws_b, n_par, sizes, shapes = ctx.call
         type_net, T, fi, fo = cfg[:4]
         N, F_, Fo, dev = h.shape[0], T * fi, T * fo, h.device
         g_out = g_out.contiguous()
         graph.ensure_csc()
-        table = graph.block_table()
-        L, keep = _block_struct(graph, table, plan, ctx.avg_log, eig, cfg, h, snorm, None, None, None, params)
-        base = saved.data_ptr()
-        L.y0, L.save_mean, L.save_invstd = base, base + 4 * N * Fo, base + 4 * (N * Fo + Fo)
-        nbytes = lib.dgn_block_layer_backward_workspace_bytes(C.byref(L))
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        L.ws, L.ws_bytes = ws.data_ptr(), nbytes
-        n_par = int(lib.dgn_block_layer_param_grad_floats(C.byref(L)))
+        n_flat = n_par + 2 * Fo
         g_h = torch.empty((N, F_), dtype=torch.float32, device=dev)
-        flat = torch.empty(n_par + 2 * Fo, dtype=torch.float32, device=dev)
+        flat = torch.empty(n_flat + (ws_b + 3) // 4 + 64, dtype=torch.float32, device=dev)      # [parameter gradients | gamma | beta | (scratch)]
         fb = flat.data_ptr()
+        L.ws, L.ws_bytes = (fb + 4 * n_flat + 255) & ~255, ws_b
+        L.running_mean, L.running_var, L.num_batches_tracked, L.n_nbt, L.out = None, None, None, 0, None
         G = _lib.DgnBlockGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_params=fb, g_gamma=fb + 4 * n_par, g_beta=fb + 4 * (n_par + Fo))
         dbg = _BLK_DBG
         if dbg is not None:
-            dbg["gagg"] = torch.zeros(N, T * plan.n_agg * fi, device=dev)
-            dbg["t_bwd"] = torch.zeros(T * table["n_blocks"], 16, dtype=torch.int64, device=dev)
-            L.dbg_gagg, L.dbg_time = dbg["gagg"].data_ptr(), dbg["t_bwd"].data_ptr()
+            dbg["t_bwd"] = torch.zeros(T * graph.block_table()["n_blocks"], 16, dtype=torch.int64, device=dev)
+            L.dbg_time = dbg["t_bwd"].data_ptr()
         _lib.check(lib.dgn_block_layer_backward(C.byref(L), C.byref(G), _lib.stream_ptr(dev)), "dgn_block_layer_backward")
-        # views of the flat gradient buffer, in the order of `params`
-        grads, off = [], 0
+        # the gradients, in the order of `params`: ONE split of the flat buffer (+ a view per matrix)
+        parts = flat[:n_flat].split(sizes)
         per = 6 if type_net != 0 else 4
+        n_w = len(shapes)
+        grads, q = [], 0
         for t in range(T):
-            for q in range(per - 2):
-                p = params[t * per + q]
-                grads.append(flat[off:off + p.numel()].view(p.shape))
-                off += p.numel()
-            grads.append(flat[n_par + t * fo:n_par + (t + 1) * fo])
-            grads.append(flat[n_par + Fo + t * fo:n_par + Fo + (t + 1) * fo])
-        if type_net == 2:
-            for p in params[T * per:]:
-                grads.append(flat[off:off + p.numel()].view(p.shape))
-                off += p.numel()
+            for _ in range(per - 2):
+                grads.append(parts[q].view(shapes[q]) if len(shapes[q]) != 1 else parts[q])
+                q += 1
+            grads.append(parts[n_w + t])
+            grads.append(parts[n_w + T + t])
+        while q < n_w:
+            grads.append(parts[q].view(shapes[q]) if len(shapes[q]) != 1 else parts[q])
+            q += 1
         return (None, None, None, None, None, g_h, None, None, None, None, *grads)
 
 

@@ -22,6 +22,24 @@ os.environ.setdefault("DGN_DC_MIN_NODES", "0")
 os.environ.setdefault("DGN_BLK_MIN_NODES", "0")
 
 
+# Batches up to 32 768 nodes take the graph-block layer route by default (dgn_amd/ops.py: BLOCK_LAYER_MAX_NODES) -- which is every oracle-
+# sized batch of this suite.  tests/test_block_layer_gpu.py runs that route through the layers' default dispatch (and
+# test_shipped_configs_gpu.py::test_every_layer_type_on_the_default_routes_vs_oracle at the library's defaults); every other module keeps
+# testing the STREAMING kernels it was written for.
+@pytest.fixture(autouse=True)
+def _streaming_routes_outside_the_block_layer_tests(request, monkeypatch):
+    if getattr(request.node, "module", None) is not None and request.node.module.__name__.endswith("test_block_layer_gpu"):
+        yield
+        return
+    try:
+        import dgn_amd.ops as ops
+    except Exception:
+        yield
+        return
+    monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 0)
+    yield
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
