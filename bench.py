@@ -212,6 +212,41 @@ def event_stats(fn, dev, warm=20, groups=20, per_group=5):
                 timed_calls=groups * per_group)
 
 
+def step_min_bytes(N, E, F_in, F_out, Ku, n_params):
+    """Mandatory HBM traffic of ONE layer step (forward + backward), whatever the kernels: inputs and outputs of both directions (h and
+    g_out read, out and g_h written; h read again by the backward), the graph (row pointers and sources, both directions), the eig
+    columns used (both directions), one saved activation of the output's size (what BatchNorm's adjoint needs: written once, read once),
+    parameters read in both directions and their gradients written.  The denominator of ``roofline.step``."""
+    act = 4 * N * (F_in + F_out + F_out + F_in + F_in) + 2 * 4 * N * F_out
+    graph = 2 * (4 * E + 4 * (N + 1)) + 2 * 4 * N * Ku
+    return act + graph + 3 * 4 * n_params
+
+
+def step_kernel_table(step, dev, steps=5):
+    """Per-kernel (calls per step, microseconds per step) of the timed step, from torch.profiler's device activity -- the table the
+    committed rocprofv3 summary (profiles/) must agree with.  None where the profiler gives no device records."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+        rows = {}
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and str(ev.device_type).endswith("CUDA"):
+                d = rows.setdefault(ev.name, [0, 0.0])
+                d[0] += 1
+                d[1] += float(getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0) or 0.0)
+        table = [dict(kernel=k[:96], calls_per_step=c / steps, us_per_step=t / steps) for k, (c, t) in rows.items() if t > 0]
+        table.sort(key=lambda r: -r["us_per_step"])
+        return table or None
+    except Exception as exc:      # (the table is evidence, never a reason to lose the line)
+        return [dict(error=f"{type(exc).__name__}: {exc}"[:160])]
+
+
 def build_batch(wl, seed, dev, shard=None):
     """``shard = (rank, world)``: keep this rank's edge-balanced share of the batch's graphs (strong scaling)."""
     kind, kw = wl["gen"]
@@ -393,6 +428,18 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
 
     result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
                   scaling="strong" if strong else "weak")
+    if rank == 0:
+        # the step against the layer's mandatory traffic (roofline.step), and where its time goes kernel by kernel (full record only)
+        plan0 = layer._kplan_x if (wl["type_net"] != "simple" and hasattr(layer, "_kplan_x")) else layer._kplan
+        n_par = sum(p.numel() for p in params)
+        bmin = step_min_bytes(N, E, F_, F_, plan_model(plan0)[2], n_par)
+        result["step"] = dict(bytes_min=bmin, frac=bmin / (ms * 1e-3) / HBM_PEAK, GBps=bmin / ms / 1e6,
+                              model="h, g_out read; out, g_h written; h re-read by the backward; one saved activation; graph and eig columns "
+                                    "both ways; parameters read twice, their gradients written")
+        table = step_kernel_table(eager_step if args.hipgraph else step, dev)
+        result["step_kernels"] = table
+        if table and "us_per_step" in table[0]:
+            result["step"]["kernel_us_sum"] = sum(r["us_per_step"] for r in table)
     if torch.distributed.is_initialized():
         # per rank: its shard's size and the gradient all-reduce timed on its own (HIP events around 20 back-to-back calls)
         ms_ar = event_ms(reducer, 20, dev, warm=3)
@@ -482,7 +529,8 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
                               kernels=kernels, triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
                               model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, aux_bytes=n_aux),
                               frac_with_survey_A=dict(A=A_survey, frac=frac_survey,
-                                                      note="same launch priced without the h_in pass-through block"))
+                                                      note="same launch priced without the h_in pass-through block"),
+                              step=result.get("step"))
     return result, batch
 
 
@@ -707,9 +755,11 @@ def compact(result):
                nodes=result["nodes_per_rank"])
     if "eig" in result:
         out["eig"] = result["eig"]
+    if result.get("step_kernels"):
+        out["step_kernels"] = result["step_kernels"]
     if r:
         out["roofline"] = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-                                                 "frac_of_triad", "model", "frac_with_survey_A") if k in r}
+                                                 "frac_of_triad", "model", "frac_with_survey_A", "step") if k in r}
         out["roofline"]["kernels"] = {k: {kk: vv for kk, vv in v.items() if kk in ("ms", "bytes", "GBps", "frac", "timing", "TFLOPs", "bound", "flops")}
                                       for k, v in (r.get("kernels") or {}).items()}
     return out
@@ -1021,6 +1071,8 @@ def compact_line(line):
     if r:
         rr = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_of_triad",
                                 "triad_GBps", "model") if k in r}
+        if isinstance(r.get("step"), dict):
+            rr["step"] = {k: r["step"][k] for k in ("bytes_min", "frac", "kernel_us_sum") if k in r["step"]}
         if isinstance(rr.get("traffic_source"), str) and len(rr["traffic_source"]) > 120:
             rr["traffic_source"] = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run)"
         rr["kernels"] = {k: {kk: v[kk] for kk in ("ms", "bytes", "frac") if kk in v} for k, v in (r.get("kernels") or {}).items()
@@ -1043,6 +1095,8 @@ def compact_line(line):
             ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
+                if isinstance(e["roofline"].get("step"), dict):
+                    ee["step_frac"] = e["roofline"]["step"].get("frac")
             if e.get("cpu_baseline"):
                 ee["cpu_edges_per_s"] = e["cpu_baseline"].get("value")
             ex[name] = ee
@@ -1153,6 +1207,8 @@ def main():
                                   + (" (HIP graph replay)" if args.hipgraph else ""))
                             if wl["type_net"] not in ("op", "layer_fwd") else ("aggregation forward" if wl["type_net"] == "op" else "layer forward, no gradients")),
                 roofline=result.get("roofline"))
+    if result.get("step_kernels"):
+        line["step_kernels"] = result["step_kernels"]      # (full record only: compact_line does not carry it)
     if torch.distributed.is_initialized():
         line["rccl_world"] = dict(backend=backend, world_size=torch.distributed.get_world_size())
     if result.get("ranks"):
