@@ -1018,28 +1018,6 @@ def run_extras(args, dev):
         extra["c2_inference"] = run_inference(args, dev)
     except Exception as exc:
         extra["c2_inference"] = dict(error=f"{type(exc).__name__}: {exc}")
-    # row f1 of SURVEY 8(f), the backward half: the same headline step with the posttrans input-gradient product inside the backward
-    # sweep (dgn_layer_fused_backward, bit-identical gradients; not the default because it measures slower)
-    try:
-        os.environ["DGN_FUSED_BACKWARD"] = "1"
-        res, _ = run_layer_workload(args, dict(WORKLOADS["c2"]), 0, 1, dev, steps=10, warmup=3, tag="c2")
-        extra["c2_fused_backward"] = dict(ms_per_step=res["ms_per_step"], value=res["value"], unit="edges/s",
-                                          config="c2 with DGN_FUSED_BACKWARD=1: g_agg formed and consumed in LDS inside the backward sweep")
-    except Exception as exc:
-        extra["c2_fused_backward"] = dict(error=f"{type(exc).__name__}: {exc}")
-    finally:
-        os.environ.pop("DGN_FUSED_BACKWARD", None)
-    # the towers layer's weight-gradient products on a second stream, overlapping the input-gradient chain and the backward sweep
-    # (DGN_BWD_AUX=2; off by default: the co-running kernels stretch each other, see dgn_towers.hip)
-    try:
-        os.environ["DGN_BWD_AUX"] = "2"
-        res, _ = run_layer_workload(args, dict(WORKLOADS["c2"]), 0, 1, dev, steps=10, warmup=3, tag="c2")
-        extra["c2_aux_stream"] = dict(ms_per_step=res["ms_per_step"], value=res["value"], unit="edges/s",
-                                      config="c2 with DGN_BWD_AUX=2: weight gradients on a second stream")
-    except Exception as exc:
-        extra["c2_aux_stream"] = dict(error=f"{type(exc).__name__}: {exc}")
-    finally:
-        os.environ.pop("DGN_BWD_AUX", None)
     try:
         extra["zinc_net_b128"] = run_net(args, dev)
     except Exception as exc:

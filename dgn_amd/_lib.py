@@ -19,12 +19,12 @@ ABI_VERSION = 23
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
-EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
+EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_set_option", "dgn_get_option", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
            "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward", "dgn_dropout_mask_bytes", "dgn_dropout_forward", "dgn_dropout_backward",
-           "dgn_layer_fused_supported", "dgn_layer_fused_forward", "dgn_layer_fused_backward_supported", "dgn_layer_fused_backward",
+           "dgn_layer_fused_supported", "dgn_layer_fused_forward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
            "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_cuts",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
@@ -85,7 +85,7 @@ class DgnTowersLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
-                ("zmask", C.c_void_p), ("agg_aux", C.c_void_p), ("dc", C.c_void_p), ("wc", C.c_void_p)]
+                ("zmask", C.c_void_p), ("agg_aux", C.c_void_p)]
 
 
 class DgnTowersGrads(C.Structure):
@@ -163,6 +163,10 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         lib.dgn_abi_version.restype = C.c_int
         lib.dgn_last_error.restype = C.c_char_p
+        lib.dgn_set_option.restype = C.c_int
+        lib.dgn_set_option.argtypes = [C.c_char_p, C.c_int64]
+        lib.dgn_get_option.restype = C.c_int64
+        lib.dgn_get_option.argtypes = [C.c_char_p]
         lib.dgn_edge_weights_workspace_bytes.restype = C.c_size_t
         lib.dgn_edge_weights_workspace_bytes.argtypes = [C.POINTER(DgnGraph), C.c_int32]
         lib.dgn_edge_weights.restype = C.c_int
@@ -308,12 +312,6 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_supported.restype = C.c_int
         lib.dgn_layer_fused_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
-        lib.dgn_layer_fused_backward_supported.restype = C.c_int
-        lib.dgn_layer_fused_backward_supported.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.c_int64, C.c_int32, C.c_int32]
-        lib.dgn_layer_fused_backward.restype = C.c_int
-        lib.dgn_layer_fused_backward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64, C.c_void_p,
-                                                 C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
-                                                 C.POINTER(DgnMsgGrad), C.c_void_p, C.c_size_t, C.c_void_p]
         lib.dgn_layer_fused_forward.restype = C.c_int
         lib.dgn_layer_fused_forward.argtypes = [C.POINTER(DgnGraph), C.POINTER(DgnAggSpec), C.POINTER(DgnMsg), C.c_void_p, C.c_int64,
                                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
@@ -352,6 +350,23 @@ def load() -> C.CDLL:
             raise DgnError(f"libdgn_hip.so ABI {lib.dgn_abi_version()} != binding {ABI_VERSION}: rebuild")
         _lib = lib
     return _lib
+
+
+class _Options:
+    """The library's process-wide options as attributes (``dgn_set_option`` / ``dgn_get_option`` of the C ABI): ``options.blk_min_nodes = 0``.
+    ``monkeypatch.setattr(_lib.options, name, value)`` switches one for a test and restores it."""
+
+    def __getattr__(self, name):
+        v = load().dgn_get_option(name.encode())
+        if v == -2 ** 63:
+            raise AttributeError(f"unknown libdgn_hip option '{name}'")
+        return v
+
+    def __setattr__(self, name, value):
+        check(load().dgn_set_option(name.encode(), int(value)), "dgn_set_option")
+
+
+options = _Options()
 
 
 def check(rc: int, what: str) -> None:

@@ -1,8 +1,12 @@
 // Error plumbing and version of libdgn_hip.so.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 #include "dgn_common.hpp"
 
@@ -42,6 +46,53 @@ int hip_fail(hipError_t e, const char* what) {
     return DGN_ERR_HIP;
 }
 }  // namespace dgn
+
+namespace dgn {
+namespace {
+struct OptDef { const char* name; const char* env; int64_t def; bool presence; };      // presence: the variable's existence means 1
+const OptDef kOpts[OPT_COUNT] = {
+    {"blk_lds_kb", "DGN_BLK_LDS_KB", 13, false},                 // LDS of a wave's block in agg_bwd_block (KB)
+    {"blk_min_nodes", "DGN_BLK_MIN_NODES", 131072, false},       // batches from this many nodes on take agg_bwd_block
+    {"bwd_rows_per_wave", "DGN_BWD_ROWS_PER_WAVE", 4, false},    // <= 1: the staged backward sweep with one row per wave
+    {"tile_gemm", "DGN_TILE_GEMM", -1, false},                   // 0 / 1: force the strip / tile product (-1: by shape)
+    {"tile_wgrad", "DGN_TILE_WGRAD", -1, false},                 // 0 / 1: force the strip / tile weight gradient (-1: by shape)
+    {"no_zmask", "DGN_NO_ZMASK", 0, true},                       // towers layer: keep the mixing network's pre-activation instead of its sign mask
+    {"linear_small_min_waves", "DGN_LINEAR_SMALL_MIN_WAVES", 8, false},
+};
+std::atomic<int64_t> g_opt[OPT_COUNT];
+std::once_flag g_opt_once;
+void init_options() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        const char* e = getenv(kOpts[i].env);
+        g_opt[i].store(e ? (kOpts[i].presence ? 1 : atoll(e)) : kOpts[i].def, std::memory_order_relaxed);
+    }
+    if (getenv("DGN_NO_MIX_FUSED")) g_opt[OPT_NO_ZMASK].store(1, std::memory_order_relaxed);
+}
+int find_option(const char* name) {
+    if (name)
+        for (int i = 0; i < OPT_COUNT; ++i)
+            if (!strcmp(name, kOpts[i].name)) return i;
+    return -1;
+}
+}  // namespace
+int64_t option(Opt o) {
+    std::call_once(g_opt_once, init_options);
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+}  // namespace dgn
+
+extern "C" int dgn_set_option(const char* name, int64_t value) {
+    const int i = dgn::find_option(name);
+    if (i < 0) { dgn::set_error("dgn_set_option: unknown option '%s'", name ? name : "(null)"); return DGN_ERR_INVALID; }
+    std::call_once(dgn::g_opt_once, dgn::init_options);
+    dgn::g_opt[i].store(value, std::memory_order_relaxed);
+    return DGN_OK;
+}
+extern "C" int64_t dgn_get_option(const char* name) {
+    const int i = dgn::find_option(name);
+    if (i < 0) { dgn::set_error("dgn_get_option: unknown option '%s'", name ? name : "(null)"); return INT64_MIN; }
+    return dgn::option(static_cast<dgn::Opt>(i));
+}
 
 extern "C" int dgn_abi_version(void) { return DGN_ABI_VERSION; }
 extern "C" const char* dgn_last_error(void) { return dgn::g_err; }

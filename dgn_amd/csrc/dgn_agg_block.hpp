@@ -69,8 +69,7 @@ struct BlkPlan { int bin, rows; size_t lds; };
 // One wave per workgroup.  Its LDS rows hold a bin (blk_bin rows) plus the graph that straddles the bin's upper end (gap - 1 rows):
 // 13 KB by default (12 waves per CU), at most kBlkRowsMax rows.
 inline bool blk_plan(BlkPlan& out, int64_t F, int gap) {
-    const char* kb_env = getenv("DGN_BLK_LDS_KB");                  // (read per launch: the tests switch it)
-    const size_t budget = (size_t)(kb_env ? atoi(kb_env) : 13) * 1024;
+    const size_t budget = (size_t)option(OPT_BLK_LDS_KB) * 1024;
     // (at most 16 rows of bin beyond the straddling graph: narrow rows would otherwise give a wave 14 groups in a row -- zinc_json,
     //  F = 46: 0.141 ms with 56-row blocks, 0.135 with 50)
     const int rcap = std::min(std::min((int)(budget / (4 * (size_t)F)), kBlkRowsMax), gap + 15);
@@ -85,12 +84,9 @@ inline bool blk_plan(BlkPlan& out, int64_t F, int gap) {
 template <class C, class O>
 int launch_backward_block_cfg(const AggParams& p, int gap, hipStream_t stream) {
     BlkPlan plan;
-    const char* rb_env = getenv("DGN_BWD_ROWS_PER_WAVE");
     // (small batches: one wave per graph leaves the chip under-filled where the staged kernels start four rows per wave -- c4, 52 k
     // nodes: 0.048 vs 0.033 ms)
-    const char* min_env = getenv("DGN_BLK_MIN_NODES");              // (read per launch: the tests switch it)
-    const int64_t min_nodes = min_env ? atoll(min_env) : 131072;
-    if (p.n_nodes < min_nodes || !short_rows(p) || (rb_env && atoi(rb_env) <= 1) || !blk_plan(plan, p.F, gap)) return 1;
+    if (p.n_nodes < option(OPT_BLK_MIN_NODES) || !short_rows(p) || option(OPT_BWD_ROWS_PER_WAVE) <= 1 || !blk_plan(plan, p.F, gap)) return 1;
     AggParams q = p;
     q.stage = nullptr; q.csc_pos = nullptr; q.csc_ptr = nullptr; q.fresh = true; q.seg_add = false;
     q.blk_bin = plan.bin; q.blk_rows = plan.rows;

@@ -2089,8 +2089,7 @@ int launch_forward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
 template <class C, class O = DynOps>
 int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) {
     const int wpb = row_waves_per_block(p);
-    const char* rb_env = getenv("DGN_BWD_ROWS_PER_WAVE");     // (read per launch: the tests switch it)
-    const int rb = (rb_env && atoi(rb_env) <= 1) ? 1 : kBwdShortRows;
+    const int rb = option(OPT_BWD_ROWS_PER_WAVE) <= 1 ? 1 : kBwdShortRows;
     if (O::kStatic && short_rows(p) && p.stage && p.fresh && rb > 1) {       // molecule-like batches, static lists: rows in groups per wave
         const int64_t n_groups = (p.n_nodes + rb - 1) / rb;
         dim3 grid((unsigned)xcd_grid((n_groups + wpb - 1) / wpb), tiles);

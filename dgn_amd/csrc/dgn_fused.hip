@@ -70,37 +70,6 @@ int dispatch_fwd(const FusedParams& p, size_t lds, hipStream_t st) {
     return DGN_ERR_INVALID;
 }
 
-template <class C, class O>
-int launch_bwd(const FusedBwdParams& p, size_t lds, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        DGN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&layer_bwd_fused<C, O>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          160 * 1024));
-        attr = true;
-    }
-    const unsigned grid = (unsigned)std::min<int64_t>(p.n_iters, (int64_t)n_cus());
-    hipLaunchKernelGGL((layer_bwd_fused<C, O>), dim3(grid), dim3(kWave * kFusedWaves), lds, st, p);
-    // second phase of the atomic-free scatter: d x_src[u] = the staged rows of source u, in csc order (as dgn_agg_backward)
-    const AggParams& a = p.a;
-    const int64_t n_threads = a.n_src * ((a.F + 3) / 4);
-    hipLaunchKernelGGL((seg_sum_rows<2>), dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, a);
-    DGN_HIP_CHECK(hipGetLastError());
-    return DGN_OK;
-}
-
-int dispatch_bwd(const FusedBwdParams& p, size_t lds, hipStream_t st) {
-    const AggParams& a = p.a;
-#define DGN_HOT(NA, OPS, CHS, NS, SCS, N, S, A)                                                                          \
-    if (a.n_agg == NA && a.op_pack == OPS && a.ch_pack == CHS && a.n_scalers == NS && a.scaler_pack == SCS && a.agg_total == NA && \
-        a.agg_offset == 0 && a.n_ch == N) {                                                                              \
-        if constexpr (NS == 1 && NA <= 8) return launch_bwd<Cfg<2, N, S, A>, StaticOps<NA, OPS, CHS, NS, SCS>>(p, lds, st); \
-        else return DGN_ERR_INVALID;                                                                                     \
-    }
-#include "dgn_agg_hot.hpp"
-#undef DGN_HOT
-    set_error("no fused kernel for this aggregator list");
-    return DGN_ERR_INVALID;
-}
 
 bool al8(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; }
 
@@ -155,46 +124,4 @@ extern "C" int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec
     { static const char* e = getenv("DGN_FUSED_DBG"); p.dbg = e ? atoi(e) : 0; }
     const size_t lds = fused_lds_floats(p.a, p.nq) * sizeof(float);
     return dispatch_fwd(p, lds, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int dgn_layer_fused_backward_supported(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t n_scalers, int32_t f_out) {
-    if (!dgn_layer_fused_supported(g, spec, F, n_scalers, f_out)) return 0;
-    const int Ft = (int)(F / spec->n_towers);
-    const int a_total = spec->agg_total > 0 ? spec->agg_total : spec->n_agg;
-    const int K = a_total * Ft, n = n_scalers * f_out;
-    if (n > 16 * kFusedBwdKB || spec->n_towers * ((K + 15) / 16) > kFusedWaves * kFusedBwdUnits || a_total > 8 || !g->csc_ptr || !g->csc_pos) return 0;
-    AggParams a{};
-    a.n_towers = spec->n_towers; a.agg_total = a_total; a.Ft = Ft;
-    return fused_bwd_lds_floats(a, f_out) * sizeof(float) <= 160 * 1024;
-}
-
-extern "C" int dgn_layer_fused_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
-                                        const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers,
-                                        int32_t f_out, const float* scale, const float* gy, int64_t stride_gy, const DgnMsgGrad* grads,
-                                        void* ws, size_t ws_bytes, void* stream) {
-    const char* fn = "dgn_layer_fused_backward";
-    if (!g || !spec || !msg) { set_error("%s: null graph / spec / msg", fn); return DGN_ERR_INVALID; }
-    if (!dgn_layer_fused_backward_supported(g, spec, msg->F, n_scalers, f_out)) { set_error("%s: configuration outside the fused kernel's domain", fn); return DGN_ERR_INVALID; }
-    FusedBwdParams p{};
-    int rc = agg_backward_prepare(p.a, g, spec, msg, w, ld_w, log_deg, nullptr, 0, true, grads, ws, ws_bytes, stream, nullptr, nullptr);
-    if (rc) return rc;
-    if (g->n_nodes == 0) return DGN_OK;
-    if (!weight || !gy || (n_scalers > 1 && !scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
-    if (msg->m_edge || !msg->x_src || !p.a.stage || !p.a.fresh || !p.a.g_src) {
-        set_error("%s: needs x_src messages without an edge term, the two-phase scatter (g_src, csc view, staging workspace) and define-mode sinks", fn);
-        return DGN_ERR_INVALID;
-    }
-    auto ok2 = [&](const float* q, int64_t ld) { return !q || (al8(q) && (ld & 1) == 0); };
-    if (!ok2(msg->x_src, msg->ld_src) || !ok2(msg->x_dst, msg->ld_dst) || !ok2(msg->x_in, msg->ld_in) || !ok2(grads->g_src, grads->ld_src) ||
-        !ok2(grads->g_dst, grads->ld_dst) || !ok2(grads->g_in, grads->ld_in) || !ok2(gy, stride_gy)) {
-        set_error("%s: operands must be 8-byte aligned with even row strides", fn);
-        return DGN_ERR_INVALID;
-    }
-    p.W = weight; p.ldw = ldw; p.sW = stride_w;
-    p.sc = n_scalers > 1 ? scale : nullptr;
-    p.gy = gy; p.s_gy = stride_gy;
-    p.S = n_scalers; p.fo = f_out;
-    p.n_iters = (g->n_nodes + kFusedRows - 1) / kFusedRows;
-    const size_t lds = fused_bwd_lds_floats(p.a, f_out) * sizeof(float);
-    return dispatch_bwd(p, lds, static_cast<hipStream_t>(stream));
 }

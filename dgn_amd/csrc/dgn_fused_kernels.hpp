@@ -181,152 +181,4 @@ __global__ __launch_bounds__(kWave * kFusedWaves) void layer_fwd_fused(const Fus
     }
 }
 
-// ---- the posttrans INPUT-GRADIENT product inside the backward sweep ---------------------------------------------------------------
-// The mirror image of layer_fwd_fused for the backward (reference: autograd through nets/dgn_layer.py:266-271 -> :237-249): the
-// upstream gradient of the sweep, g_agg[t][m][:] = G[t][m][:] . W_post[t]  with  G[t][m][s fo + o] = scale[m][s] * gy[t][m][o], is
-// what dgn_linear_combine_backward_input writes ([T, N, K]: 0.46 GB on ZINC-12k) and dgn_agg_backward reads back.  Here a persistent
-// 16-wave workgroup takes 64 destination rows per iteration:
-//   A. stages the rows' gy strips and scaler factors in LDS, forms the 64 x (T K) block of g_agg with v_mfma_f32_16x16x4_f32 -- wave u
-//      owns up to two (tower, 16-column) units, its W^T tiles fetched per iteration from L2 -- in the arithmetic and k-order of the
-//      stand-alone product (bit-identical rows), and leaves it in LDS;
-//   B. runs the grouped short-row backward (bwd_short_group, four rows per wave) with p.g_out pointing at those LDS rows.
-// Neither g_agg nor -- with the forward's fused kernel -- the aggregate rows' gradient ever reaches memory.  Molecule-like graphs,
-// hot aggregator lists, one feature tile, K <= 96, S f_out <= 48, at most 32 units.
-constexpr int kFusedBwdUnits = 2;
-constexpr int kFusedBwdKB = 3;       // 16-k blocks over the reduction width S * f_out <= 48
-
-struct FusedBwdParams {
-    AggParams a;                      // the backward sweep (a.g_out / ld_gout / tower_stride are set per iteration inside the kernel)
-    const float* W; int64_t ldw, sW;  // posttrans weights [T][S*fo][K]
-    const float* sc;                  // [N, S] or NULL (S == 1)
-    const float* gy; int64_t s_gy;    // [T][N][fo] (= row_scale * the combine's upstream gradient, tower-major)
-    int S, fo;
-    int64_t n_iters;
-};
-
-__host__ __device__ inline size_t fused_bwd_lds_floats(const AggParams& a, int fo) {
-    return (size_t)kFusedRows * (fused_tk(a) + a.n_towers * fo + 4);
-}
-
-template <class C, class O>
-__global__ __launch_bounds__(kWave * kFusedWaves) void layer_bwd_fused(const FusedBwdParams p) {
-    constexpr int VEC = C::VEC;
-    extern __shared__ float lds_f[];
-    const AggParams& a = p.a;
-    const int T = a.n_towers, K = a.agg_total * a.Ft, TK = T * K, fo = p.fo, Tfo = T * fo, n = p.S * fo;
-    const int NQ = (K + 15) >> 4;                        // 16-column tiles of one tower's g_agg row
-    float* AX = lds_f;                                   // [64][T][K]  g_agg rows
-    float* GY = AX + kFusedRows * TK;                    // [64][T][fo] gy strips
-    float* FAC = GY + kFusedRows * Tfo;                  // [64][4]     scale_0..2
-    const int tid_lane = threadIdx.x, lane = tid_lane & 63, wave = uniform_i(tid_lane >> 6);      // (wave-uniform: units, tile pointers -> scalar registers)
-    const int i16_lane = lane & 15, g_lane = lane >> 4;
-    int t_u[kFusedBwdUnits], q_u[kFusedBwdUnits];
-    bool has_unit[kFusedBwdUnits];
-#pragma unroll
-    for (int j = 0; j < kFusedBwdUnits; ++j) {
-        const int u = wave + j * kFusedWaves;
-        has_unit[j] = u < T * NQ;
-        t_u[j] = has_unit[j] ? u / NQ : 0;
-        q_u[j] = has_unit[j] ? u - t_u[j] * NQ : 0;
-    }
-    const int f0_lane = lane * VEC;
-    const bool active = f0_lane < a.F;
-    const int fo2 = fo >> 1;
-    const int64_t per = (p.n_iters + gridDim.x - 1) / gridDim.x;
-    const int64_t it0 = (int64_t)blockIdx.x * per, it1 = min(p.n_iters, it0 + per);
-    for (int64_t it = it0; it < it1; ++it) {
-        const int64_t row_base = it * kFusedRows;
-        // this wave's W^T tiles (16 output columns x the reduction width, 70 KB for all units together: L2 resident), requested first:
-        // they arrive while the rows' gy strips are staged.  (Held across the sweep they would push it past 128 registers.)
-        // (lane coordinates laundered through an empty asm once per iteration: everything derived from them is loop invariant, and the
-        //  compiler would compute the ~250 operand addresses / column indices of the unrolled code below ONCE, outside the iteration loop,
-        //  keep them live across both phases and spill them)
-        int g = g_lane, i16 = i16_lane, f0 = f0_lane, tid = tid_lane;
-        asm volatile("" : "+v"(g), "+v"(i16), "+v"(f0), "+v"(tid));
-        float wreg[kFusedBwdUnits][kFusedBwdKB][4];
-#pragma unroll
-        for (int j = 0; j < kFusedBwdUnits; ++j) {
-            const int nout = 16 * q_u[j] + i16;
-            const float* wp = p.W + (int64_t)t_u[j] * p.sW + min(nout, K - 1);
-#pragma unroll
-            for (int b = 0; b < kFusedBwdKB; ++b)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    const int k = 16 * b + 4 * g + s2;
-                    const float v = wp[(int64_t)min(k, n - 1) * p.ldw];       // (unconditional load, clamped; masked below)
-                    wreg[j][b][s2] = (has_unit[j] && k < n && nout < K) ? v : 0.f;
-                }
-        }
-        // ---- stage gy and the scaler factors of the 64 rows ----
-        for (int idx = tid; idx < kFusedRows * T * fo2; idx += blockDim.x) {
-            const int m = idx / (T * fo2), rem = idx - m * (T * fo2), t = rem / fo2, o = 2 * (rem - t * fo2);
-            const int64_t row = row_base + m;
-            float2 v = *reinterpret_cast<const float2*>(p.gy + (int64_t)t * p.s_gy + min(row, a.n_nodes - 1) * fo + o);
-            if (row >= a.n_nodes) v = make_float2(0.f, 0.f);
-            *reinterpret_cast<float2*>(GY + m * Tfo + t * fo + o) = v;
-        }
-        if (tid < kFusedRows) {
-            const int64_t row = min(row_base + tid, a.n_nodes - 1);
-            f4 f = f4{1.f, 1.f, 1.f, 0.f};
-            if (p.sc) {
-                f[0] = p.sc[row * p.S];
-                f[1] = p.sc[row * p.S + min(1, p.S - 1)];
-                f[2] = p.sc[row * p.S + min(2, p.S - 1)];
-            }
-            *reinterpret_cast<f4*>(FAC + 4 * tid) = f;
-        }
-        __syncthreads();
-        // ---- A: g_agg[m][t][16 q ..] = sum_k G[m][t][k] W[t][k][16 q ..], k = 16 b + 4 g + s (the order of ts_linear) ----
-#pragma unroll
-        for (int j = 0; j < kFusedBwdUnits; ++j) {
-            if (!has_unit[j]) continue;
-            const int t = t_u[j];
-            const float* gyl = GY + i16 * Tfo + t * fo;          // row i16 of strip 0; strips are 16 rows apart
-            const float* facl = FAC + 4 * i16;
-            f4 acc[kFusedRows / 16];
-#pragma unroll
-            for (int strip = 0; strip < kFusedRows / 16; ++strip) acc[strip] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < kFusedBwdKB; ++b) {
-                if (16 * b < n) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) {
-                        const int k = 16 * b + 4 * g + s2;
-                        const int s = (k >= fo ? 1 : 0) + (k >= 2 * fo ? 1 : 0);
-                        const int o = min(k, n - 1) - min(s, p.S - 1) * fo;          // (clamped: an entry past the reduction width is masked)
-                        const bool live = k < n;
-                        float xv[kFusedRows / 16];
-#pragma unroll
-                        for (int strip = 0; strip < kFusedRows / 16; ++strip)
-                            xv[strip] = gyl[strip * 16 * Tfo + o] * facl[strip * 64 + min(s, 2)];
-#pragma unroll
-                        for (int strip = 0; strip < kFusedRows / 16; ++strip)
-                            acc[strip] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][b][s2], live ? xv[strip] : 0.f, acc[strip], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);       // (one k step's operands at a time: hoisting them all spills)
-                    }
-                }
-            }
-            if (16 * q_u[j] + 4 * g < K) {               // (K % 4 == 0: a lane's four columns exist together)
-#pragma unroll
-                for (int strip = 0; strip < kFusedRows / 16; ++strip)
-                    *reinterpret_cast<f4*>(AX + (strip * 16 + i16) * TK + t * K + 16 * q_u[j] + 4 * g) = acc[strip];
-            }
-        }
-        __syncthreads();
-        // ---- B: the grouped short-row backward on the LDS rows ----
-        {
-            AggParams q = a;
-            q.g_out = AX - row_base * TK;                // row r of the graph = LDS row r - row_base
-            q.ld_gout = TK;
-            q.tower_stride = K;
-            const int64_t row0 = row_base + (int64_t)wave * kShortRows;
-#ifndef DGN_FB_NO_B
-            if (row0 < a.n_nodes)
-                bwd_short_group<C, O, kShortRows, false, true>(q, (int)row0, (int)min((int64_t)kShortRows, a.n_nodes - row0), f0, active);
-#endif
-        }
-        __syncthreads();                                  // the next iteration overwrites GY / AX
-    }
-}
-
 }  // namespace dgn

@@ -98,8 +98,8 @@ TwPlan tile_wgrad_plan(int64_t M, int kk, int n) {
 }
 
 bool use_tile_wgrad(int n) {
-    const char* env = getenv("DGN_TILE_WGRAD");              // (read per call: the tests switch it)
-    return env ? atoi(env) != 0 : n > 16 * kWgWaves;
+    const int64_t o = option(OPT_TILE_WGRAD);
+    return o >= 0 ? o != 0 : n > 16 * kWgWaves;
 }
 
 }  // namespace
@@ -121,10 +121,10 @@ extern "C" int dgn_gemm_forward(int64_t n_rows, int32_t k, int32_t n, const floa
     GemmParams p{};
     p.M = n_rows; p.k = k; p.n = n; p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.bias = bias; p.C = c; p.ldc = ldc;
     // 256-row tiles with both operands through LDS: wide outputs of nn.Linear-layout weights on many rows
-    const char* tile_env = getenv("DGN_TILE_GEMM");          // (read per call: the tests switch it)
+    const int64_t tile_opt = option(OPT_TILE_GEMM);
     static const char* min_env = getenv("DGN_TILE_GEMM_MIN_ROWS");
     static const int64_t tile_min_rows = min_env ? atoll(min_env) : 131072;
-    const bool tile = tile_env ? atoi(tile_env) != 0 : (n >= 64 && n_rows >= tile_min_rows);     // (fewer rows: too few 256-row tiles to fill the CUs -- measured slower at 52 k rows)
+    const bool tile = tile_opt >= 0 ? tile_opt != 0 : (n >= 64 && n_rows >= tile_min_rows);     // (fewer rows: too few 256-row tiles to fill the CUs -- measured slower at 52 k rows)
     if (tile && !w_is_kn) {
         // column tiles of 16 NQ (NQ <= 8): the split with the least padded columns, fewer tiles on a tie
         // (NQ = 8 would need 265 registers: one wave per SIMD)

@@ -51,8 +51,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     {   // Small batches: 2 970 rows are 186 strips -- twelve 16-wave workgroups on twelve of 256 CUs.  Fewer waves per workgroup until
         // the strips cover the chip (every workgroup stages the weights itself: 20 KB from L2).
         static const bool keep = getenv("DGN_LINEAR_NO_SMALL") != nullptr;
-        const char* mw = getenv("DGN_LINEAR_SMALL_MIN_WAVES");
-        const int min_waves = mw ? atoi(mw) : 8;           // (4: no gain, 2 and 1: slower -- the weights are staged by too few threads)
+        const int min_waves = (int)option(OPT_LINEAR_SMALL_MIN_WAVES);           // (4: no gain, 2 and 1: slower -- the weights are staged by too few threads)
         while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves /= 2;
     }
     const size_t lds = w_bytes + waves * strip_bytes;

@@ -76,35 +76,6 @@ bool use_bd(const DgnTowersLayer* L, const Dims& d) {
     return !off && dgn_linear_bd_supported(d.T, d.fi) && ((reinterpret_cast<uintptr_t>(L->h) | reinterpret_cast<uintptr_t>(L->pq)) & 15) == 0;
 }
 
-// Weight-gradient products on a second stream: they depend on their operands only, not on each other or on the input-gradient chain
-// (act -> BatchNorm -> combine -> posttrans input gradient -> sweep -> P|Q input gradient), which is a chain of memory-bound kernels
-// that leave the MFMA pipes idle.  fork(): the side stream waits for everything enqueued on the main stream so far; join(): the main
-// stream waits for the side stream.  Events are reused (a wait refers to the record that precedes it).
-struct SideStream {
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
-    bool ok = false;
-    bool init() {
-        if (ok) return true;
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
-        for (auto& e : ev_fork) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return false;
-        ok = true;
-        return true;
-    }
-    bool fork(hipStream_t main, int i) { return hipEventRecord(ev_fork[i], main) == hipSuccess && hipStreamWaitEvent(side, ev_fork[i], 0) == hipSuccess; }
-    bool join(hipStream_t main) { return hipEventRecord(ev_join, side) == hipSuccess && hipStreamWaitEvent(main, ev_join, 0) == hipSuccess; }
-};
-SideStream& side_stream() {
-    static thread_local SideStream s;
-    return s;
-}
-
-// degree-class posttrans (forward and input gradient): classes and the class-weight buffer given, several scalers, widths >= 4
-bool use_dc(const DgnTowersLayer* L, const Dims& d) {
-    return L->dc && L->wc && d.S > 1 && dgn_dc_supported(d.K, d.fo) && dgn_dc_supported(d.fo, d.K);
-}
-
 DgnMsg sweep_msg(const DgnTowersLayer* L, const Dims& d) {
     DgnMsg m{};
     m.F = d.Fm;
@@ -144,7 +115,7 @@ extern "C" size_t dgn_towers_layer_agg_aux_bytes(const DgnTowersLayer* L) {
 }
 
 extern "C" int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out) {
-    const bool off = getenv("DGN_NO_ZMASK") != nullptr || getenv("DGN_NO_MIX_FUSED") != nullptr;          // (read per call: the tests switch it)
+    const bool off = option(OPT_NO_ZMASK) != 0;
     const int Fo = n_towers * f_out;
     return !off && n_towers >= 1 && f_out >= 1 && Fo % 16 != 0 && dgn_linear_add_supported(Fo, Fo) && dgn_linear_act_supported(Fo, Fo);
 }
@@ -174,13 +145,6 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     const size_t agg_ws = L->ws_bytes - bn_ws;
     DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, L->agg_aux, ws + bn_ws, agg_ws, stream));
     // posttrans([h || agg]) with the folded scalers, bias and graph norm                     (:266-271)
-    if (use_dc(L, d)) {
-        // ... as ONE f_out-column product per in-degree class and tower (dgn_dc_kernels.hpp): W_class = sum_s scale_s(class) W_s
-        const int64_t wsz = (int64_t)d.T * d.fo * d.K;
-        DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, d.T, L->w_post, nullptr, L->wc, L->wc + DGN_DC_CLASSES * wsz, stream));
-        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, d.T, L->aggx, d.K, d.N * d.K, L->wc, d.K, wsz, (int64_t)d.fo * d.K, L->b_post, L->snorm, L->y0, d.Fo, d.fo, 0,
-                            stream));
-    } else
     DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
@@ -257,29 +221,11 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // g_z = g_out * act'(z + b_mix) is formed while the strips are staged and leaves as a side output for the weight gradient, whose
     // ones-column delivers the bias gradient (the separate path: dgn_bias_act_backward, then the two products)
     const bool fused_act = L->y1 == nullptr && d.Fo % 16 != 0 && (reinterpret_cast<uintptr_t>(g_z) & 15) == 0 && dgn_linear_act_supported(d.Fo, d.Fo);
-    // DGN_BWD_AUX=2: the three weight-gradient products go to a second stream and overlap the input-gradient chain including the
-    // sweep: step 1.55 -> 1.51 ms on ZINC-12k, the co-running sweep stretching from 0.215 to 0.35 ms.  =1: the same with the sweep kept
-    // alone: no gain.  Off by default: 3 % of the step against kernel times in a profile that no longer say what a kernel can do.
-    // Default: on INSIDE A STREAM CAPTURE of a small batch (<= 32 768 rows), where every kernel of the chain fills a fraction of the chip
-    // and is bound by its own launch-to-store latency: the reference's batch of 128 molecules replays in 0.180 instead of 0.191 ms.
-    const char* aux_s = getenv("DGN_BWD_AUX");                  // (read per call: the bench switches it)
-    bool aux_env = aux_s != nullptr && atoi(aux_s) != 0;
-    if (!aux_s && d.N <= 32768) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        aux_env = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
-    }
-    SideStream& ss = side_stream();
-    // (the stream and its events are created by the first small-batch call, i.e. by a warm-up step BEFORE any capture: creating them
-    //  inside a capture would invalidate it)
-    const bool ss_ready = (aux_env || d.N <= 32768) && !(aux_env && !ss.ok && aux_s == nullptr) ? ss.init() : ss.ok;
-    const bool aux = aux_env && fused_act && ss_ready && ss.ok;
-    void* wstream = aux ? static_cast<void*>(ss.side) : stream;          // where the weight-gradient products go
     if (fused_act) {
         if (L->zmask) DGN_TRY(dgn_linear_forward_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
         else DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
-        if (aux && !ss.fork(st, 0)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }
         DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
-                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), wstream));
+                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
     } else {
         if (!L->z) { set_error("%s: zmask without the fused activation-gradient kernel: give z", fn); return DGN_ERR_INVALID; }
         DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
@@ -299,27 +245,12 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;
     DGN_TRY(scale_combine_backward_impl(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
                                        dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream, 1));
-    // posttrans: the scaler expansion happens inside the two products.  DGN_FUSED_BACKWARD=1: the input-gradient product runs INSIDE
-    // the backward sweep (dgn_layer_fused_backward: g_aggx is formed and consumed in LDS, bit-identical gradients).  Built, tested and
-    // NOT the default: measured 0.53 ms against 0.36 ms for the two separate kernels on ZINC-12k -- a persistent
-    // workgroup's sixteen waves start their dependent load chains together after every barrier, where the stand-alone sweep's
-    // workgroups are staggered.
-    if (aux && !ss.fork(st, 1)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }          // (g_yr is ready: the weight gradient may start)
-    const char* fb_env = getenv("DGN_FUSED_BACKWARD");          // (read per call: the tests switch it)
-    const bool fused_bwd = fb_env && atoi(fb_env) != 0 && dgn_layer_fused_backward_supported(L->graph, L->spec, d.Fm, d.S, d.fo);
-    if (!fused_bwd && use_dc(L, d)) {
-        const int64_t wsz = (int64_t)d.T * d.fo * d.K;
-        DGN_TRY(dgn_dc_gemm(L->dc, d.fo, d.K, d.T, g_yr, d.fo, d.N * d.fo, L->wc + DGN_DC_CLASSES * wsz, d.fo, wsz, (int64_t)d.fo * d.K, nullptr, nullptr, g_aggx,
-                            d.K, d.N * d.K, 0, stream));
-    } else if (!fused_bwd)
-        DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
-                                                  g_aggx, d.N * d.K, stream));
+    // posttrans: the scaler expansion happens inside the two products
+    DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
+                                              g_aggx, d.N * d.K, stream));
     DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
                                                (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
-                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), wstream));
-    // (the sweep runs alone: co-running it with a weight gradient stretched it from 0.215 to 0.35 ms for a net 2 %)
-    const bool aux_over_sweep = aux_s ? atoi(aux_s) == 2 : true;          // (the automatic small-batch mode overlaps the sweep as well)
-    if (aux && !aux_over_sweep && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
+                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
     // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
     const DgnMsg msg = sweep_msg(L, d);
     DgnMsgGrad gr{};
@@ -327,13 +258,8 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     gr.g_dst = g_pq + d.Fm; gr.ld_dst = 2 * d.Fm;
     gr.g_in = g_in; gr.ld_in = d.Fm;
     gr.accumulate = 0;
-    if (fused_bwd)
-        DGN_TRY(dgn_layer_fused_backward(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, d.S, d.fo,
-                                         L->scale, g_yr, d.N * d.fo, &gr, ws + s.agg_ws, dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1),
-                                         stream));
-    else
-        DGN_TRY(dgn_agg_backward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, L->agg_aux, &gr, ws + s.agg_ws,
-                                     dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
+    DGN_TRY(dgn_agg_backward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, g_aggx, d.K, L->agg_aux, &gr, ws + s.agg_ws,
+                                 dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1), stream));
     // P|Q Linear: input gradient, weight + bias gradient (the bias rides in the weight-gradient pass)
     // d h = [residual] + d h_in + (d P|Q) W_sd: as the product's epilogue ((d h_in + product) + residual, add3's order) where the shapes
     // allow, else the product and a three-way add
@@ -343,15 +269,11 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     const bool fused_add = !no_add_epilogue && al && (reinterpret_cast<uintptr_t>(g_in) & 15) == 0 && dgn_linear_add_supported(2 * d.Fm, d.Fm);
     if (use_bd(L, d) && al && ((reinterpret_cast<uintptr_t>(g_in) | reinterpret_cast<uintptr_t>(g_pq)) & 15) == 0) {
         // the towers' own blocks only: (d h_in + (d P|Q) W_sd) + residual in the product's epilogue, add3's order
-        if (aux && !ss.fork(st, 2)) { set_error("%s: stream fork failed", fn); return DGN_ERR_HIP; }
         DGN_TRY(dgn_linear_bd_backward_input(d.N, d.T, d.fi, g_pq, L->w_sd, d.Fm, g_in, res, G->g_h, stream));
         DGN_TRY(dgn_linear_bd_wgrad(d.N, d.T, d.fi, g_pq, L->h, G->g_w_sd, d.Fm, G->g_bias_sd, ws + s.wg_sd,
-                                    dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), wstream));
-        if (aux && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
+                                    dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), stream));
         return DGN_OK;
     }
-    if (aux && !ss.join(st)) { set_error("%s: stream join failed", fn); return DGN_ERR_HIP; }
-    wstream = stream;
     if (fused_add) DGN_TRY(dgn_linear_forward_add(d.N, 2 * d.Fm, d.Fm, g_pq, L->w_sd, d.Fm, 1, g_in, res, G->g_h, stream));
     else DGN_TRY(dgn_linear_forward(d.N, 2 * d.Fm, d.Fm, 1, g_pq, 2 * d.Fm, 0, L->w_sd, d.Fm, 0, 1, nullptr, 0, g_hpq, d.Fm, 0, stream));
     DGN_TRY(dgn_linear_wgrad(d.N, d.Fm, 2 * d.Fm, 1, g_pq, 2 * d.Fm, 0, L->h, d.Fm, 0, G->g_w_sd, d.Fm, 0, G->g_bias_sd, 0, ws + s.wg_sd,

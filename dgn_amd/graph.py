@@ -383,7 +383,7 @@ class DGNGraph:
         ok = False
         # (the C side takes the block kernels from DGN_BLK_MIN_NODES nodes on -- default 131 072, below it one wave per graph under-fills
         #  the chip --: smaller batches do not pay for the cut build and its read-back either)
-        min_nodes = int(os.environ.get("DGN_BLK_MIN_NODES", "131072"))
+        min_nodes = int(_lib.options.blk_min_nodes)
         if enabled and self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None \
                 and self.num_nodes >= max(1, min_nodes) and 0 < self.num_edges <= 3 * self.num_nodes and self.row_base == 0:
             if "_blk" not in self.__dict__ and torch.cuda.is_current_stream_capturing():

@@ -1059,10 +1059,8 @@ class _TowersLayer(torch.autograd.Function):
         # mask (DgnTowersLayer.zmask, 1/8 of the bytes) in the slot z would take
         use_mask = n_y1 == 0 and (h.data_ptr() & 15) == 0 and bool(lib.dgn_towers_layer_zmask_supported(T, fo))
         n_z = (lib.dgn_linear_act_mask_bytes(N, Fo) + 3) // 4 if use_mask else N * Fo
-        dc = _degree_classes(graph, scale, fo, K) if DC_TOWERS else None
-        n_wc = 2 * _lib.DGN_DC_CLASSES * T * fo * K if dc is not None else 0
-        saved_buf, (pq, aggx, y0, y1, z, mean, invstd, wc) = _carve([N * 2 * Fm, T * N * K, N * Fo, n_y1, n_z, Fo, Fo, n_wc], dev)
-        ctx.n_y1, ctx.n_z, ctx.use_mask, ctx.dc, ctx.n_wc = n_y1, n_z, use_mask, dc, n_wc
+        saved_buf, (pq, aggx, y0, y1, z, mean, invstd) = _carve([N * 2 * Fm, T * N * K, N * Fo, n_y1, n_z, Fo, Fo], dev)
+        ctx.n_y1, ctx.n_z, ctx.use_mask = n_y1, n_z, use_mask
         out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
         spec = _spec_structs(plan, T, avg_log, N * K)[0]
         L = _lib.DgnTowersLayer()
@@ -1078,9 +1076,6 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
-        dcs = _dc_struct(dc)
-        if dcs is not None:
-            L.dc, L.wc = C.addressof(dcs), wc.data_ptr()
         # what the backward sweep would recompute from the messages (first max / min slot, dx signs): one byte per (row, feature)
         n_aux = int(lib.dgn_towers_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0
         aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
@@ -1105,12 +1100,12 @@ class _TowersLayer(torch.autograd.Function):
         N, Fm, Fo = h.shape[0], T * fi, T * fo
         K = plan.n_agg * fi
         dev = h.device
-        sizes = [N * 2 * Fm, T * N * K, N * Fo, ctx.n_y1, ctx.n_z, Fo, Fo, ctx.n_wc]
+        sizes = [N * 2 * Fm, T * N * K, N * Fo, ctx.n_y1, ctx.n_z, Fo, Fo]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
             total += (n + 63) & ~63
-        pq, aggx, y0, y1, z, mean, invstd, wc = (saved_buf[o:o + n] for o, n in zip(offs, sizes))
+        pq, aggx, y0, y1, z, mean, invstd = (saved_buf[o:o + n] for o, n in zip(offs, sizes))
         g_out = g_out.contiguous()
         graph.ensure_csc()
         graph.ensure_blocks(bool(BLOCK_BACKWARD))
@@ -1128,9 +1123,6 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if ctx.n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if ctx.use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
-        dcs = _dc_struct(ctx.dc)
-        if dcs is not None:
-            L.dc, L.wc = C.addressof(dcs), wc.data_ptr()
         L.agg_aux = _ptr(aux)
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
@@ -1204,12 +1196,6 @@ def _degree_classes(graph, scale, fo, K):
     if key not in cache:
         cache[key] = (scale, scale.index_select(0, dc["rep"]).contiguous())      # (the per-node table is kept alive with its class rows)
     return dc, cache[key][1]
-
-
-# the towers layer: forward and input gradient of posttrans on the degree-class kernels (its weight gradient keeps the expand kernel).
-# Off by default: with 14 output columns per tower the products are memory-bound either way, and the 256-row LDS-staged tiles of
-# dc_gemm move the tower-major aggregate rows slower than the streaming strips of ts_linear (ZINC-12k: step 1.53-1.55 vs 1.43-1.45 ms).
-DC_TOWERS = os.environ.get("DGN_DC_TOWERS", "0") != "0"
 
 
 def _dc_struct(dc):

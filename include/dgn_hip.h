@@ -188,6 +188,14 @@ typedef struct DgnMsgGrad {
 } DgnMsgGrad;
 
 int dgn_abi_version(void);
+/* Process-wide library options (experiments and tests; every default is what the benchmarks run).  Each option takes its initial value
+ * from an environment variable ONCE, when the library first looks; afterwards only dgn_set_option changes it -- no entry point reads the
+ * environment on a launch path.  Names: "blk_lds_kb" (DGN_BLK_LDS_KB, 13), "blk_min_nodes" (DGN_BLK_MIN_NODES, 131072),
+ * "bwd_rows_per_wave" (DGN_BWD_ROWS_PER_WAVE, 4), "tile_gemm" / "tile_wgrad" (DGN_TILE_GEMM / DGN_TILE_WGRAD, -1 = by shape),
+ * "no_zmask" (DGN_NO_ZMASK set, 0), "linear_small_min_waves" (8).  dgn_set_option: DGN_ERR_INVALID for an unknown name;
+ * dgn_get_option: INT64_MIN for an unknown name.                                                                            */
+int dgn_set_option(const char* name, int64_t value);
+int64_t dgn_get_option(const char* name);
 const char* dgn_last_error(void);
 
 /* Per-edge directional weights, once per (graph, eig): w[c*ld_w + j] for channel c, CSR slot j.
@@ -445,18 +453,6 @@ int dgn_layer_fused_forward(const DgnGraph* g, const DgnAggSpec* spec, const Dgn
                             const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers,
                             int32_t f_out, const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
                             void* stream);
-/* The mirror image for the backward: the sweep's upstream gradient g_agg[t] = G[t] . weight[t], G[t][m][s f_out + o] = scale[m][s] *
- * gy[t][m][o] (what dgn_linear_combine_backward_input writes as a [T, N, K] tensor and dgn_agg_backward reads back) is formed 64
- * rows at a time in LDS -- same MFMA arithmetic and k-order, bit-identical rows -- and consumed there by the grouped short-row
- * backward; then the second phase of the two-phase scatter.  gy [T][n_nodes][f_out] (stride_gy between towers) = row_scale * the
- * combine's upstream gradient; grads / ws as dgn_agg_backward with `deterministic` (define-mode sinks: grads->accumulate == 0).
- * Domain: dgn_layer_fused_backward_supported (that of the forward kernel, + the graph's csc view, S * f_out <= 48, <= 32 units).   */
-int dgn_layer_fused_backward_supported(const DgnGraph* g, const DgnAggSpec* spec, int64_t F, int32_t n_scalers, int32_t f_out);
-int dgn_layer_fused_backward(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const float* w, int64_t ld_w,
-                             const float* log_deg, const float* weight, int64_t ldw, int64_t stride_w, int32_t n_scalers, int32_t f_out,
-                             const float* scale, const float* gy, int64_t stride_gy, const DgnMsgGrad* grads, void* ws, size_t ws_bytes,
-                             void* stream);
-
 /* ---- graph batch preparation on the device (dgn_graph_build.hip) ------------------------------------------------------
  * The edge list of a (batched) graph in edge-id order -> the DgnGraph arrays, by a handful of kernels on `stream`, no host
  * synchronisation inside.  Replaces what DGL does per update_all call (degree bucketing, nets/dgn_layer.py:115,186,264) and
@@ -493,7 +489,6 @@ int dgn_graph_build_csc(int64_t n_nodes, int64_t n_edges, const int32_t* src_csr
  * save_mean, save_invstd are written by the forward and read by the backward (caller-owned: the autograd-saved tensors).
  * Shapes: h [N, T*f_in]; w_sd [2 T f_in, T f_in]; w_post [T][S*f_out][K], K = agg_total * f_in; w_mix [T f_out, T f_out].
  * dgn_towers_layer_supported() says whether the widths fit the streaming Linear kernels.                            */
-struct DgnDegreeClasses;          /* (declared below: degree-class posttrans)                                  */
 typedef struct DgnTowersLayer {
     const DgnGraph* graph;
     const DgnAggSpec* spec;
@@ -522,10 +517,6 @@ typedef struct DgnTowersLayer {
     /* Optional: dgn_agg_aux_bytes(graph, spec, the sweep's message) bytes -- the forward sweep leaves its aux table here, the
      * backward sweep works from it (dgn_agg_forward_aux / dgn_agg_backward_aux).  NULL: the backward recomputes.                */
     unsigned char* agg_aux;
-    /* Optional (S > 1): degree-class posttrans for the forward and the input gradient (dgn_dc_fold / dgn_dc_gemm over the towers);
-     * wc: 2 * DGN_DC_CLASSES * T * f_out * K floats (class weights and their transposes), written by the forward, read by the backward */
-    const struct DgnDegreeClasses* dc;
-    float* wc;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */

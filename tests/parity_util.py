@@ -8,8 +8,22 @@ the clause, no longer passes silently.  Tensors whose true value is numerically 
 BatchNorm) are exempt from the fraction: both evaluations return rounding noise there, entry by entry unrelated."""
 import torch
 
+import os
+
 REPORT = []
 MAX_ESCAPE_FRACTION = 0.005
+REPORT_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+
+
+def _to_report_file(line):
+    """Every comparison's line also goes to gpurun_out/parity_report.txt (merged back from the GPU box): the achieved errors and the number
+    of entries that needed the fp64 clause are on record whatever pytest's verbosity was."""
+    try:
+        os.makedirs(os.path.dirname(REPORT_FILE), exist_ok=True)
+        with open(REPORT_FILE, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
 
 
 def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True):
@@ -19,20 +33,26 @@ def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True):
     tol = atol * scale + rtol * r64.abs()
     ref_err = float((r32 - r64).abs().max()) if r64.numel() else 0.0
     ok_ref = (a - r32).abs() <= tol
+    # the fp64 clause, LOCAL first: an entry may sit as far from the fp64 oracle as the fp32 oracle's OWN error at that entry (x4) -- where
+    # the reference's arithmetic itself is unsure.  Only what that does not cover falls back on the tensor-wide bound (the kernel's max /
+    # min / |.| routing flipped on an entry where the oracle's did not): those entries are the counted, capped ones.
+    ok_local = (a - r64).abs() <= tol + 4 * (r32 - r64).abs()
     ok_f64 = (a - r64).abs() <= tol + 4 * ref_err
-    bad = ~(ok_ref | ok_f64)
+    bad = ~(ok_ref | ok_local | ok_f64)
     # entries where the fp32 ORACLE itself is off its fp64 evaluation by more than the tolerance (a max / min / |.| routing that flipped
     # in the reference's own arithmetic: CPU thread count and summation order move them) are the oracle's, not ours: counted apart
     oracle_flip = (r32 - r64).abs() > tol
-    flips = int((~ok_ref & ok_f64 & oracle_flip).sum())
-    escaped = int((~ok_ref & ok_f64 & ~oracle_flip).sum())
+    flips = int((~ok_ref & (ok_local | ok_f64) & oracle_flip).sum())
+    local = int((~ok_ref & ok_local & ~oracle_flip).sum())
+    escaped = int((~ok_ref & ~ok_local & ok_f64 & ~oracle_flip).sum())
     n = a.numel()
     err32 = float((a - r32).abs().max()) if n else 0.0
     err64 = float((a - r64).abs().max()) if n else 0.0
     line = (f"PARITY {name}: n={n} max|ours-fp32 oracle|={err32:.3e} max|ours-fp64 oracle|={err64:.3e} oracle's own fp32 error={ref_err:.3e} "
-            f"scale={scale:.3g} escaped={escaped} ({100.0 * escaped / max(n, 1):.3f} %) oracle_fp32_flips={flips}")
+            f"scale={scale:.3g} local_clause={local} escaped={escaped} ({100.0 * escaped / max(n, 1):.3f} %) oracle_fp32_flips={flips}")
     REPORT.append(line)
     print(line)
+    _to_report_file(line)
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {n} entries off ({line})"
     noise = exempt_noise and float(r64.abs().max() if n else 0.0) <= 1e3 * max(ref_err, 1e-12)
     if not noise:

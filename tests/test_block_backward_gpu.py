@@ -99,8 +99,9 @@ def _grads(graph, plan, F_, T, pair, X, PQ, ct_seed=1):
 @pytest.mark.parametrize("lds_kb", ["13", "11", "24"])
 @pytest.mark.parametrize("case", ["towers", "complex", "simple", "simple_hiv", "cifar", "cifar_complex"])
 def test_block_backward_matches_staged(monkeypatch, case, lds_kb):
-    monkeypatch.setenv("DGN_BLK_LDS_KB", lds_kb)
-    monkeypatch.setenv("DGN_BLK_MIN_NODES", "0")
+    import dgn_amd
+    monkeypatch.setattr(dgn_amd._lib.options, "blk_lds_kb", int(lds_kb))
+    monkeypatch.setattr(dgn_amd._lib.options, "blk_min_nodes", 0)
     run_matches_staged(case)
 
 
@@ -157,7 +158,7 @@ def test_block_backward_layer_vs_oracle(kind, monkeypatch):
     from oracle import dgn_oracle as orc
     dev = _dev()
     monkeypatch.setenv("DGN_DC_MIN_NODES", "0")
-    monkeypatch.setenv("DGN_BLK_MIN_NODES", "0")
+    monkeypatch.setattr(dgn_amd._lib.options, "blk_min_nodes", 0)
     b = synth.molecule_batch(40, seed=11)
     src, dst, N, eig, snorm = b["src"], b["dst"], int(b["num_nodes"]), b["eig"], b["snorm_n"]
     F_ = 70 if kind == "towers" else 76

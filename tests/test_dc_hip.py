@@ -143,8 +143,7 @@ def test_dc_fold_matches_fp64():
 
 
 @pytest.mark.parametrize("type_net,F,aggs", [("simple", 70, "mean max min dir1-dx dir1-av"), ("complex", 70, "mean max min dir1-av dir1-dx"),
-                                             ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx"),
-                                             ("towers", 70, "mean max min dir1-av dir1-dx")])
+                                             ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean sum max dir1-dx")])
 def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
     """The whole layer (forward, d h, every parameter gradient, BatchNorm running statistics) with the degree-class posttrans against the
     folded product + scale-combine of rounds 1-2: the same arithmetic regrouped, so fp32 rounding apart.  An activation within rounding
@@ -162,8 +161,7 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
         g_out = torch.randn(N, F, generator=gen).to(dev)
         res = {}
         for dc_on in (True, False):
-            ops.DC_POSTTRANS, towers_default, min_default = dc_on, ops.DC_TOWERS, ops.DC_MIN_NODES
-            ops.DC_TOWERS = True                                           # (the towers layer's route is off by default: slower)
+            ops.DC_POSTTRANS, min_default = dc_on, ops.DC_MIN_NODES
             ops.DC_MIN_NODES = 0                                           # (and small batches keep the folded route by default)
             try:
                 torch.manual_seed(seed + 2)
@@ -175,7 +173,7 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
                 y.backward(g_out)
                 res[dc_on] = [y.detach(), h.grad] + [p.grad for p in layer.parameters()] + [bf for n_, bf in layer.named_buffers() if "running" in n_]
             finally:
-                ops.DC_POSTTRANS, ops.DC_TOWERS, ops.DC_MIN_NODES = True, towers_default, min_default
+                ops.DC_POSTTRANS, ops.DC_MIN_NODES = True, min_default
         _close(res[True][0], res[False][0].double(), 2e-5)               # the forward: always
         hd = h0.to(dev)
         if type_net != "towers" and int((((res[True][0] - hd) == 0) != ((res[False][0] - hd) == 0)).sum()):

@@ -65,8 +65,8 @@ def test_grouped_backward_sweep(monkeypatch, seed):
     X, PQ = torch.randn(N, F_, generator=gen), torch.randn(N, 2 * F_, generator=gen)
 
     def run(rb):
-        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
-        monkeypatch.setenv("DGN_BLK_MIN_NODES", "1000000000")     # (the staged kernels against each other: the block backward has its own file)
+        monkeypatch.setattr(dgn_amd._lib.options, "bwd_rows_per_wave", int(rb))
+        monkeypatch.setattr(dgn_amd._lib.options, "blk_min_nodes", 1000000000)     # (the staged kernels against each other: the block backward has its own file)
         x = X.to(dev).requires_grad_(True)
         if pq_msg:
             pq = PQ.to(dev).requires_grad_(True)
@@ -123,7 +123,7 @@ def test_edge_table_sweep(monkeypatch, seed):
     types_slot = graph.to_slot_order(torch.randint(0, K, (E,), generator=gen).to(dev)).to(torch.int32).contiguous()
 
     def run(table_mode, rb="4"):
-        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        monkeypatch.setattr(dgn_amd._lib.options, "bwd_rows_per_wave", int(rb))
         x, pq, tb = X.to(dev).requires_grad_(True), PQ.to(dev).requires_grad_(True), table.to(dev).requires_grad_(True)
         if table_mode:
             y = directional_aggregate(graph, plan, 0.8, x_pair=pq, m_edge=tb, x_in=x, edge_type=types_slot, n_towers=T, tower_major=T > 1)

@@ -671,7 +671,7 @@ def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, ca
     PQ = torch.randn(N, 2 * F_, generator=gen)
 
     def run(rb):
-        monkeypatch.setenv("DGN_BWD_ROWS_PER_WAVE", rb)
+        monkeypatch.setattr(dgn_amd._lib.options, "bwd_rows_per_wave", int(rb))
         x = X.to(dev).requires_grad_(True)
         if case == "simple":
             y = directional_aggregate(graph, plan, 1.1, x_src=x, x_in=x)
@@ -912,7 +912,7 @@ def test_towers_layer_with_the_activation_mask_is_bitwise_the_layer_with_z(monke
     res = []
     for mask in (True, False):
         if not mask:
-            monkeypatch.setenv("DGN_NO_ZMASK", "1")
+            monkeypatch.setattr(dgn_amd._lib.options, "no_zmask", 1)
         lay = copy.deepcopy(layer).train()
         h = h0.clone().requires_grad_(True)
         y = lay(graph, h, None, snorm)
@@ -1027,56 +1027,3 @@ def test_whole_dense_layer_call_equals_per_kernel_route(monkeypatch, type_net, F
     for k in sa:
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
 
-
-@pytest.mark.parametrize("n_graphs,scalers,extra", [(300, "identity amplification attenuation", True), (7, "identity attenuation", False), (41, "identity", True)])
-def test_fused_backward_sweep_is_bitwise_the_separate_kernels(monkeypatch, n_graphs, scalers, extra):
-    """dgn_layer_fused_backward (the posttrans input-gradient product formed 64 rows at a time in LDS and consumed there by the grouped
-    short-row backward: the [T, N, K] gradient of the aggregate rows never reaches memory) against dgn_linear_combine_backward_input +
-    dgn_agg_backward: every gradient of the whole towers layer bit for bit.  Batches with a ragged last block of rows, isolated nodes
-    and a row of nine in-edges (those groups run the per-row routine on the LDS rows)."""
-    dev = _dev()
-    import copy
-    import dgn_amd
-    from dgn_amd import synth
-    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
-    b = synth.molecule_batch(n_graphs, seed=5, laplacian_eig=False)
-    src, dst, N = b["src"], b["dst"], int(b["num_nodes"])
-    snorm = b["snorm_n"]
-    eig = b["eig"]
-    if extra:          # two isolated nodes and one node with nine in-edges
-        k = 9
-        gen0 = torch.Generator().manual_seed(0)
-        src = torch.cat([src, torch.randint(0, N, (k,), generator=gen0)])
-        dst = torch.cat([dst, torch.full((k,), N + 2)])
-        N += 3
-        snorm = torch.cat([snorm, torch.full((3, 1), 0.5)])
-        eig = torch.cat([eig, torch.randn(3, eig.shape[1], generator=gen0)])
-    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
-    F_ = 70
-    torch.manual_seed(2)
-    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, "mean max min dir1-av dir1-dx", scalers, {"log": torch.tensor(1.2)}, "towers", True,
-                             towers=5, edge_features=False, edge_dim=0).model.to(dev)
-    gen = torch.Generator(device=dev).manual_seed(3)
-    with torch.no_grad():
-        for p in layer.parameters():
-            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=gen))
-    h0 = torch.randn(N, F_, device=dev, generator=gen)
-    ct = torch.randn(N, F_, device=dev, generator=gen)
-    lib = dgn_amd._lib.load()
-    res = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("DGN_FUSED_BACKWARD", fused)
-        lay = copy.deepcopy(layer).train()
-        h = h0.clone().requires_grad_(True)
-        y = lay(graph, h, None, snorm.to(dev))
-        y.backward(ct)
-        res[fused] = (h.grad, {k: v.grad for k, v in lay.named_parameters()})
-    (ga, pa), (gb, pb) = res["1"], res["0"]
-    assert torch.isfinite(ga).all()
-    assert torch.equal(ga, gb)
-    for k in pa:
-        assert torch.equal(pa[k], pb[k]), k
-    import ctypes as C
-    from dgn_amd.ops import _spec_structs
-    spec = _spec_structs(layer._kplan_x, 5, 1.2, N * layer._kplan_x.n_agg * 14)[0]
-    assert lib.dgn_layer_fused_backward_supported(C.byref(graph.c_graph), C.byref(spec), F_, len(scalers.split()), 14) == 1      # (the fused kernel did run)

@@ -122,7 +122,7 @@ def test_wide_gemm_vs_fp64(monkeypatch, M, k, n, tile):
     import ctypes as C
     from dgn_amd import _lib
     lib = _lib.load()
-    monkeypatch.setenv("DGN_TILE_GEMM", tile)
+    monkeypatch.setattr(_lib.options, "tile_gemm", int(tile))
     dev = torch.device("cuda")
     gen = torch.Generator(device=dev).manual_seed(M + k + n)
     xbig = torch.randn(M, k + 3, device=dev, generator=gen)
@@ -153,7 +153,7 @@ def test_wide_gemm_vs_fp64(monkeypatch, M, k, n, tile):
     for tw, with_bias in (("1", True), ("1", False), ("0", False), ("0", True)):
         if tw == "0" and n > 256:
             continue
-        monkeypatch.setenv("DGN_TILE_WGRAD", tw)
+        monkeypatch.setattr(_lib.options, "tile_wgrad", int(tw))
         outs = []
         for _ in range(2):
             gw = torch.full((n, k + 2), float("nan"), device=dev)                 # (row stride k + 2: the padding columns must stay untouched)
@@ -197,7 +197,7 @@ def test_gemm_wgrad_never_writes_past_its_workspace(M, k, n, tile, with_bias, mo
     lib = _lib.load()
     dev = torch.device("cuda")
     if tile is not None:
-        monkeypatch.setenv("DGN_TILE_WGRAD", tile)
+        monkeypatch.setattr(_lib.options, "tile_wgrad", int(tile))
     gen = torch.Generator(device=dev).manual_seed(k + n)
     x, g = torch.randn(M, k, device=dev, generator=gen), torch.randn(M, n, device=dev, generator=gen)
     st = torch.cuda.current_stream().cuda_stream
