@@ -19,7 +19,7 @@ ABI_VERSION = 23
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
-EXPORTS = ("dgn_abi_version", "dgn_last_error", "dgn_set_option", "dgn_get_option", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
+EXPORTS = ("dgn_abi_version", "dgn_sizeof", "dgn_last_error", "dgn_set_option", "dgn_get_option", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
            "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
@@ -45,7 +45,8 @@ class DgnGraph(C.Structure):
                 ("n_hub", C.c_int64), ("hub_rows", C.c_void_p), ("hub_chunk_ptr", C.c_void_p),
                 ("n_chunks", C.c_int64), ("chunk_hub", C.c_void_p), ("hub_threshold", C.c_int32),
                 ("hub_chunk", C.c_int32), ("csc_ptr", C.c_void_p), ("csc_pos", C.c_void_p), ("max_in_degree", C.c_int32),
-                ("n_src", C.c_int64), ("row_base", C.c_int64), ("blk_cut", C.c_void_p), ("blk_gap", C.c_int32)]
+                ("n_src", C.c_int64), ("row_base", C.c_int64), ("blk_cut", C.c_void_p), ("blk_gap", C.c_int32),
+                ("gblk_desc", C.c_void_p), ("n_gblk", C.c_int64), ("gblk_rows", C.c_int32), ("csc_order", C.c_void_p), ("dst_csr", C.c_void_p)]
 
 
 class DgnChannel(C.Structure):
@@ -163,6 +164,8 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         lib.dgn_abi_version.restype = C.c_int
         lib.dgn_last_error.restype = C.c_char_p
+        lib.dgn_sizeof.restype = C.c_size_t
+        lib.dgn_sizeof.argtypes = [C.c_char_p]
         lib.dgn_set_option.restype = C.c_int
         lib.dgn_set_option.argtypes = [C.c_char_p, C.c_int64]
         lib.dgn_get_option.restype = C.c_int64

@@ -95,4 +95,12 @@ extern "C" int64_t dgn_get_option(const char* name) {
 }
 
 extern "C" int dgn_abi_version(void) { return DGN_ABI_VERSION; }
+extern "C" size_t dgn_sizeof(const char* name) {
+#define DGN_SZ(T) if (name && !strcmp(name, #T)) return sizeof(T);
+    DGN_SZ(DgnGraph) DGN_SZ(DgnChannel) DGN_SZ(DgnAggSpec) DGN_SZ(DgnMsg) DGN_SZ(DgnMsgGrad) DGN_SZ(DgnBnGrad) DGN_SZ(DgnTowersLayer)
+    DGN_SZ(DgnTowersGrads) DGN_SZ(DgnDegreeClasses) DGN_SZ(DgnDcLayout) DGN_SZ(DgnDenseLayer) DGN_SZ(DgnDenseGrads) DGN_SZ(DgnBlockTable)
+    DGN_SZ(DgnBlockLayer) DGN_SZ(DgnBlockGrads)
+#undef DGN_SZ
+    return 0;
+}
 extern "C" const char* dgn_last_error(void) { return dgn::g_err; }

@@ -380,6 +380,16 @@ extern "C" int dgn_agg_backward_aux(const DgnGraph* g, const DgnAggSpec* spec, c
         if (brc != 1) return brc;
         p.blk_cut = nullptr;
     }
+    // Graph backward (dgn_agg_graph.hpp): graphs beyond a wave's LDS block (k-NN, SBM) -- a workgroup per graph, the destination rows'
+    // coefficient vectors in LDS, every source row gathering its out-edges: lists without max / min / std / var, same conditions otherwise
+    if (g->gblk_desc && g->n_gblk > 0 && g->csc_order && g->dst_csr && g->csc_ptr && g->n_edges > 0 && grads->accumulate == 0 && g->n_hub == 0 &&
+        tiles == 1 && vec == 2 && !msg->edge_type && !msg->m_edge && p.g_src && p.x_src && p.n_src == p.n_nodes && !p.g_edge && !short_rows(p)) {
+        p.gblk_desc = g->gblk_desc; p.n_gblk = (int32_t)g->n_gblk; p.gblk_rows = g->gblk_rows; p.csc_order = g->csc_order; p.dst_csr = g->dst_csr;
+        p.csc_ptr = g->csc_ptr;
+        const int grc = launch_agg_graph_v2(p, stream);
+        if (grc != 1) return grc;
+        p.gblk_desc = nullptr;
+    }
     rc = launch(vec, p, tiles, stream, true);
     if (rc || !msg->edge_type || !grads->g_edge) return rc;
     const int K = msg->n_edge_types, KF = K * (int)msg->F;

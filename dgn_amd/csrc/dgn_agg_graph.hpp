@@ -1,0 +1,221 @@
+// Backward of the sweep for batches of graphs too large for a wave's LDS block (k-NN superpixel graphs, data/superpixels.py:139-145:
+// 85 - 150 nodes; SBM graphs): ONE WORKGROUP owns a graph (DgnGraph.gblk_desc: whole graphs, every source of every row inside).
+//   phase 1  a wave per DESTINATION row: the row's coefficient vectors (make_coef: c0, cs_c, ca_c -- the arithmetic of the staged
+//            backward, dx signs from the forward's aux table, sum_j w_jc from the weights alone: no message is gathered) go to LDS
+//            ([rows][slots][F]: 118 x 3 x 66 floats = 93 KB for CIFAR10's list); d x_dst (the row sum of the per-edge gradients, in
+//            slot order: no var / std on these lists, hence no message term) and d x_in leave at once.
+//   phase 2  a wave per SOURCE row: its out-edges in (source, slot) order -- DgnGraph.csc_order -- each adding
+//            c0_i + sum_c (w_jc cs_ic + |w_jc| ca_ic) from the destination's LDS rows; d x_src[u] is written ONCE.
+// No float atomics, no [E, F] staging buffer (the staged path writes every per-edge gradient row and reads it back: 1.85x the
+// algorithmic bytes on CIFAR10's batch, profiles/r04), the adds in the staged path's own order: run-to-run reproducible.
+// Lists without max / min / std / var (their coefficient rows would not fit), messages x_src (+ x_dst), 8-byte lanes, one feature tile.
+// Reference semantics: autograd through nets/dgn_layer.py:183-186 (apply_edges gather + update_all reduce), nets/aggregators.py:35-71.
+#pragma once
+#include "dgn_agg_kernels.hpp"
+
+namespace dgn {
+
+constexpr int kGraphWaves = 8;
+
+template <class C>
+__host__ __device__ constexpr int graph_coef_slots() { return 1 + C::NCH * (C::AV ? 2 : 1); }
+
+template <class C, class O>
+__global__ __launch_bounds__(kWave * kGraphWaves) void agg_bwd_graph(const AggParams p) {
+    static_assert(C::VEC == 2 && !C::STATS, "8-byte lanes, lists without max / min / std / var");
+    constexpr int VEC = 2, NCO = graph_coef_slots<C>();
+    extern __shared__ float coef_lds[];
+    const int4 d = reinterpret_cast<const int4*>(p.gblk_desc)[blockIdx.x];
+    const int lo = d.x, hi = d.y;
+    const int Fs = (p.F + 1) & ~1;
+    float* GX = coef_lds + (size_t)p.gblk_rows * NCO * Fs;          // d x_in rows where d x_in aliases d x_src
+    const bool alias = p.g_in && p.g_in == p.g_src;
+    const int wave = uniform_i((int)threadIdx.x >> 6), lane = lane_id();
+    const int f0 = lane * VEC;
+    const bool active = f0 < p.F;
+    const bool signs = (p.need & NEED_RECOMP) != 0;          // (the host takes this kernel only with the aux table then)
+    // ---- phase 1: destination rows ----
+    for (int row = lo + wave; row < hi; row += kGraphWaves) {
+        const int beg = p.indptr[row], end = p.indptr[row + 1];
+        const int deg = end - beg;
+        const float logd = p.log_deg ? p.log_deg[row] : 0.f;
+        // sum_j w_jc in slot order (the order of Acc::add, i.e. of the staged backward: the same coefficient bits)
+        float sw[C::NW];
+#pragma unroll
+        for (int c = 0; c < C::NW; ++c) sw[c] = 0.f;
+        for (int base = beg; base < end; base += kWave) {
+            const int e = min(base + lane, end - 1), cnt = min(kWave, end - base);
+            float w[C::NW];
+#pragma unroll
+            for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + e];
+            for (int q = 0; q < cnt; ++q) {
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) sw[c] += bcast_f(w[c], q);
+            }
+        }
+        float* crow = coef_lds + (size_t)(row - lo) * NCO * Fs + f0;
+        const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+        float gxin[VEC] = {0.f, 0.f}, rsum[VEC] = {0.f, 0.f};
+        Coef<C> k;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) k.c0[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C::NW; ++c) {
+            k.cs[c][0] = 0.f; k.cs[c][1] = 0.f;
+            if constexpr (C::AV) { k.ca[c][0] = 0.f; k.ca[c][1] = 0.f; }
+        }
+        if (active) {
+            if (deg == 0) {
+                // no messages: zero coefficients; the x_in pass-through block still carries its gradient
+                if (p.need & NEED_XPASS) {
+                    for (int a = 0; a < O::n_agg(p); ++a)
+                        if (O::op(p, a) == DGN_AGG_X_IN) {
+                            float g[VEC];
+                            ldv<VEC>(g, grow + sa_col(p, 0, a));
+                            gxin[0] += g[0]; gxin[1] += g[1];
+                        }
+                }
+            } else {
+                Acc<C, true> acc;
+                acc.init();
+                float xin[VEC] = {0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) acc.sw[c] = sw[c];
+                if constexpr (C::NCH >= 1 && C::NCH <= 2) {
+                    if (signs) acc_signs_from_aux<C, true>(acc, load_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0));
+                }
+                make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
+            }
+            stv<VEC>(crow, k.c0);
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) {
+                stv<VEC>(crow + (1 + c) * Fs, k.cs[c]);
+                if constexpr (C::AV) stv<VEC>(crow + (1 + C::NCH + c) * Fs, k.ca[c]);
+            }
+        }
+        // d x_dst: the row's per-edge gradients summed in slot order (emit_batch's arithmetic, no message term on these lists)
+        if (p.g_dst) {
+            for (int base = beg; base < end; base += kWave) {
+                const int e = min(base + lane, end - 1), cnt = min(kWave, end - base);
+                float w[C::NW];
+#pragma unroll
+                for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + e];
+#pragma unroll
+                for (int c = 0; c < C::NW; ++c) asm volatile("" : "+v"(w[c]));      // (read across lanes below: see phase 2)
+                if (active) {
+                    for (int q = 0; q < cnt; ++q) {
+                        float gm[VEC] = {k.c0[0], k.c0[1]};
+#pragma unroll
+                        for (int c = 0; c < C::NCH; ++c) {
+                            const float wq = bcast_f(w[c], q);
+                            gm[0] = fmaf(wq, k.cs[c][0], gm[0]); gm[1] = fmaf(wq, k.cs[c][1], gm[1]);
+                            if constexpr (C::AV) { gm[0] = fmaf(fabsf(wq), k.ca[c][0], gm[0]); gm[1] = fmaf(fabsf(wq), k.ca[c][1], gm[1]); }
+                        }
+                        rsum[0] += gm[0]; rsum[1] += gm[1];
+                    }
+                }
+            }
+            if (active) stv<VEC>(p.g_dst + (int64_t)row * p.ldg_dst + f0, rsum);
+        }
+        if (active) {
+            if (alias) stv<VEC>(GX + (size_t)(row - lo) * Fs + f0, gxin);
+            else if (p.g_in) stv<VEC>(p.g_in + (int64_t)row * p.ldg_in + f0, gxin);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: source rows, out-edges in (source, slot) order ----
+    for (int u = lo + wave; u < hi; u += kGraphWaves) {
+        const int r0 = p.csc_ptr[u], r1 = p.csc_ptr[u + 1];
+        float a[VEC] = {0.f, 0.f};
+        for (int base = r0; base < r1; base += kWave) {
+            const int rank = min(base + lane, r1 - 1);
+            const int j = p.csc_order[rank];
+            const int i_loc = p.dst_csr[j] - lo;
+            float w[C::NW];
+#pragma unroll
+            for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + j];
+            const int cnt = min(kWave, r1 - base);
+            // (pinned HERE, for all 64 lanes: the values are read across lanes below (v_readlane ignores exec) by the active lanes only --
+            //  33 of 64 at F = 66 --, and a source with more out-edges than active lanes reads lanes the compiler would otherwise have
+            //  let skip the loads by sinking them into the branch: SBM rows with >= 34 out-edges came out wrong)
+            int i_pin = i_loc;
+            asm volatile("" : "+v"(i_pin));
+#pragma unroll
+            for (int c = 0; c < C::NW; ++c) asm volatile("" : "+v"(w[c]));
+            if (active) {
+                for (int q = 0; q < cnt; ++q) {
+                    const float* crow = coef_lds + (size_t)bcast_i(i_pin, q) * NCO * Fs + f0;
+                    float gm[VEC];
+                    ldv<VEC>(gm, crow);
+#pragma unroll
+                    for (int c = 0; c < C::NCH; ++c) {
+                        const float wq = bcast_f(w[c], q);
+                        float cs[VEC];
+                        ldv<VEC>(cs, crow + (1 + c) * Fs);
+                        gm[0] = fmaf(wq, cs[0], gm[0]); gm[1] = fmaf(wq, cs[1], gm[1]);
+                        if constexpr (C::AV) {
+                            float ca[VEC];
+                            ldv<VEC>(ca, crow + (1 + C::NCH + c) * Fs);
+                            gm[0] = fmaf(fabsf(wq), ca[0], gm[0]); gm[1] = fmaf(fabsf(wq), ca[1], gm[1]);
+                        }
+                    }
+                    a[0] += gm[0]; a[1] += gm[1];
+                }
+            }
+        }
+        if (active) {
+            if (alias) {
+                float gx[VEC];
+                ldv<VEC>(gx, GX + (size_t)(u - lo) * Fs + f0);
+                a[0] += gx[0]; a[1] += gx[1];
+            }
+            stv<VEC>(p.g_src + (int64_t)u * p.ldg_src + f0, a);
+        }
+    }
+}
+
+// DGN_OK when launched, 1 when this (list, graph) has no such kernel (the caller runs the staged path)
+template <class C, class O>
+int launch_backward_graph_cfg(const AggParams& p, hipStream_t stream) {
+    if constexpr (C::STATS || C::VEC != 2) {
+        return 1;
+    } else {
+        constexpr int NCO = graph_coef_slots<C>();
+        const int Fs = (p.F + 1) & ~1;
+        const bool alias = p.g_in && p.g_in == p.g_src;
+        const size_t lds = ((size_t)p.gblk_rows * NCO * Fs + (alias ? (size_t)p.gblk_rows * Fs : 0)) * sizeof(float);
+        if (lds > 160 * 1024 || ((p.need & NEED_RECOMP) && !(p.aux && p.aux_rows))) return 1;
+        static bool attr = false;
+        if (!attr) {
+            DGN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_bwd_graph<C, O>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        AggParams q = p;
+        q.stage = nullptr; q.fresh = true; q.seg_add = false;
+        hipLaunchKernelGGL((agg_bwd_graph<C, O>), dim3((unsigned)p.n_gblk), dim3(kWave * kGraphWaves), lds, stream, q);
+        DGN_HIP_CHECK(hipGetLastError());
+        return DGN_OK;
+    }
+}
+
+inline int launch_graph_v2(const AggParams& p, hipStream_t stream) {
+    static const bool no_hot = getenv("DGN_NO_HOT") != nullptr;
+    if (no_hot) return 1;
+#define DGN_HOT(NA, OPS, CHS, NS, SCS, N, S, A)                                                                  \
+    if (p.n_agg == NA && p.op_pack == OPS && p.ch_pack == CHS && p.n_scalers == NS && p.scaler_pack == SCS &&    \
+        p.agg_total == NA && p.agg_offset == 0 && p.n_ch == N) {                                                 \
+        using O = StaticOps<NA, OPS, CHS, NS, SCS>;                                                              \
+        return launch_backward_graph_cfg<Cfg<2, N, S, A>, O>(p, stream);                                         \
+    }
+#include "dgn_agg_hot.hpp"
+#undef DGN_HOT
+    return 1;
+}
+
+}  // namespace dgn

@@ -123,6 +123,10 @@ struct AggParams {
     const int32_t* blk_cut;
     int32_t blk_bin;
     int32_t blk_rows;     // LDS rows per workgroup (blk_bin + the largest gap between closed cuts - 1 fits)
+    // Graph backward (dgn_agg_graph.hpp): gblk_desc [n_gblk][4] = first row, end row, first slot, end slot of blocks of WHOLE graphs (one
+    // workgroup each, at most gblk_rows rows), csc_order[rank] = the CSR slot of (source, slot) rank `rank`, dst_csr[slot] = its row
+    const int32_t* gblk_desc; const int32_t* csc_order; const int32_t* dst_csr;
+    int32_t n_gblk, gblk_rows;
     // set per workgroup by the kernel (a copy of the parameter block):
     float* blk_lds;       // [blk_rows][F] accumulator of d x_src (+ d x_in when g_in aliases g_src)
     int32_t blk_lo, blk_hi;
@@ -2176,5 +2180,6 @@ int launch_agg_v4(const AggParams& p, unsigned tiles, hipStream_t stream, bool b
 // defined in dgn_agg_blk_v2.hip (dgn_agg_block.hpp): DGN_OK, an error, or 1 = no block kernel for this launch.  8-byte lanes only: with
 // 16-byte lanes (F > 128) a wave's 13 KB of LDS hold fewer rows than one molecule.
 int launch_agg_block_v2(const AggParams& p, int gap, hipStream_t stream);
+int launch_agg_graph_v2(const AggParams& p, hipStream_t stream);
 
 }  // namespace dgn

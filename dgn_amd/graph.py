@@ -31,6 +31,7 @@ HUB_CHUNK = 1024
 # False: the same arrays from ~40 torch ops (what CPU tensors -- the gloo tests -- always use).  Same results.
 NATIVE_BUILD = True
 DC_CLASSES, DC_UNIT = 32, 64      # include/dgn_hip.h: DGN_DC_CLASSES, DGN_DC_UNIT
+GRAPH_BLOCK_MAX_ROWS = 512       # largest graph (nodes) of a batch for which the graph backward is attached (the C side checks the LDS per list / width)
 BLOCK_MAX_GAP = 52         # largest graph of a batch (nodes) for which the block backward is tried (a wave's block is at most 56 rows: csrc/dgn_agg_block.hpp; the C side checks the LDS budget per F)
 DEFERRED_STATS = True      # DGNGraph.rebuild: the batch's (max in-degree, hub rows) are checked at the next load instead of with a host sync
 
@@ -180,6 +181,7 @@ class DGNGraph:
             self.__dict__.pop(k, None)
         if hasattr(self, "_c"):
             self._c.blk_cut, self._c.blk_gap = None, 0      # (the cut tensor is gone with "_blk": never leave its address behind)
+            self._c.gblk_desc, self._c.n_gblk, self._c.gblk_rows, self._c.dst_csr = None, 0, 0, None
 
     def _build_native(self, src, dst, num_nodes, hub_threshold, hub_chunk):
         """CSR by destination through dgn_graph_build: one C call, one read-back of (max in-degree, hub rows)."""
@@ -291,7 +293,7 @@ class DGNGraph:
         out_deg = torch.bincount(self.src.long(), minlength=self.num_src) if E else torch.zeros(self.num_src, dtype=torch.int64, device=dev)
         ptr = torch.zeros(self.num_src + 1, dtype=torch.int64, device=dev)
         ptr[1:] = torch.cumsum(out_deg, 0)
-        self.csc_ptr, self.csc_pos = ptr.int().contiguous(), pos.int().contiguous()
+        self.csc_ptr, self.csc_pos, self.csc_order = ptr.int().contiguous(), pos.int().contiguous(), order.int().contiguous()
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
         self._csc_ready = True
 
@@ -304,6 +306,7 @@ class DGNGraph:
         nbytes = lib.dgn_graph_build_workspace_bytes(N, E)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.csc_ptr, self.csc_pos, order = i32(N + 1), i32(E), i32(E)
+        self.csc_order = order                                  # (rank -> slot: the graph backward walks a source's out-edges with it)
         _lib.check(lib.dgn_graph_build_csc(N, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(), order.data_ptr(),
                                            ws.data_ptr(), nbytes, stream), "dgn_graph_build_csc")
         self._c.csc_ptr, self._c.csc_pos = self.csc_ptr.data_ptr(), self.csc_pos.data_ptr()
@@ -329,19 +332,20 @@ class DGNGraph:
         return self._blk
 
     # ---- block table of the graph-block layer (csrc/dgn_blk_layer.hip): whole graphs per workgroup -------------------------------------
-    def block_table(self, graph_sizes=None):
+    def block_table(self, graph_sizes=None, target_rows=None):
         """DgnBlockTable of this batch, or None (hub rows, a bipartite / sharded / padded CSR, no edges; inside a stream capture unless
         built before).  Blocks = runs of whole graphs: the closed cuts (``graph_sizes``: the batch's node counts when the caller knows
         them -- ``dgl.batch``'s ``batch_num_nodes`` --, else found by dgn_graph_build_cuts) greedily grouped so that a block has about
         N / 512 rows -- at the reference's batch of 128 graphs one graph per workgroup.  Built once per batch: a few small kernels and two
         read-backs (cuts, row pointers), on the loader's side of the step like the CSR itself.  Cached; the dict also carries
         ``max_rows`` / ``max_edges`` (what decides whether a block fits the LDS)."""
-        ent = self.__dict__.get("_blk_tables")
+        tables = self.__dict__.setdefault("_blk_tables", {})
+        ent = tables.get(target_rows)
         if ent is not None:
             return ent or None
         if not (self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None
                 and self.row_base == 0 and self.num_edges > 0 and self.num_nodes > 0):
-            self.__dict__["_blk_tables"] = {}
+            tables[target_rows] = {}
             return None
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -355,7 +359,7 @@ class DGNGraph:
             cut, _ = self._closed_cuts()
             cuts = torch.unique_consecutive(cut).cpu().numpy().astype(np.int64)
         indptr = self.indptr.cpu().numpy().astype(np.int64)
-        target = max(1, -(-N // 512))
+        target = max(1, -(-N // 512)) if target_rows is None else int(target_rows)      # (target_rows = 1: one graph per block)
         prev, bounds = 0, [0]
         for c in cuts[1:]:
             # the graph [prev, c) would take the running block [bounds[-1], prev) past the target: close the block first
@@ -371,7 +375,7 @@ class DGNGraph:
         st = _lib.DgnBlockTable(n_blocks=int(desc.shape[0]), max_rows=int((desc[:, 1] - desc[:, 0]).max()),
                                 max_edges=int((desc[:, 3] - desc[:, 2]).max()), desc=t.data_ptr())
         ent = dict(struct=st, desc=t, n_blocks=st.n_blocks, max_rows=st.max_rows, max_edges=st.max_edges)
-        self.__dict__["_blk_tables"] = ent
+        tables[target_rows] = ent
         return ent
 
     # ---- block description for the LDS-accumulating backward (csrc/dgn_agg_block.hpp) -----------------------------------------------
@@ -397,6 +401,24 @@ class DGNGraph:
             self._c.blk_cut, self._c.blk_gap = cut.data_ptr(), gap
         else:
             self._c.blk_cut, self._c.blk_gap = None, 0
+        self._ensure_graph_blocks(enabled)
+        return ok
+
+    def _ensure_graph_blocks(self, enabled: bool = True) -> bool:
+        """Attach (or detach) DgnGraph.gblk_desc / csc_order / dst_csr: one block per graph for the graph backward of batches whose graphs
+        are too large for a wave's LDS block (k-NN superpixels, SBM: more than 3 edges per node, graphs of up to GRAPH_BLOCK_MAX_ROWS nodes;
+        csrc/dgn_agg_graph.hpp).  Built on first use (the closed cuts: a few kernels and two read-backs), never inside a capture."""
+        ok = False
+        if enabled and self.src.is_cuda and self.num_src == self.num_nodes and self.n_hub == 0 and getattr(self, "_pad", None) is None \
+                and self.row_base == 0 and self.num_edges > 3 * self.num_nodes:
+            t = self.block_table(target_rows=1)
+            if t is not None and t["max_rows"] <= GRAPH_BLOCK_MAX_ROWS and getattr(self, "_csc_ready", False) and hasattr(self, "csc_order"):
+                self._closed_cuts()                      # (dst_csr)
+                self._c.gblk_desc, self._c.n_gblk, self._c.gblk_rows = t["desc"].data_ptr(), t["n_blocks"], t["max_rows"]
+                self._c.csc_order, self._c.dst_csr = self.csc_order.data_ptr(), self.dst_csr.data_ptr()
+                ok = True
+        if not ok:
+            self._c.gblk_desc, self._c.n_gblk, self._c.gblk_rows, self._c.csc_order, self._c.dst_csr = None, 0, 0, None, None
         return ok
 
     # ---- DGL-flavoured accessors used by the nets (duck typing) ----

@@ -118,6 +118,15 @@ typedef struct DgnGraph {
      * buffer, the adds in ascending (source, slot) order as in the staged path (run-to-run reproducible).                       */
     const int32_t* blk_cut;  /* [n_nodes+1] */
     int32_t blk_gap;
+    /* Optional (NULL = absent): batches of graphs too large for that (k-NN superpixel graphs, data/superpixels.py:139-145; SBM graphs).
+     * gblk_desc [n_gblk][4] int32, 16-byte aligned: first row, end row, first CSR slot, end CSR slot of blocks of WHOLE graphs that
+     * partition [0, n_nodes) in order, gblk_rows = the largest block; csc_order[k] = the CSR slot with (source, slot) rank k (the
+     * inverse of csc_pos), dst_csr[j] = the row of CSR slot j.  With them (and csc_ptr) dgn_agg_backward (define mode, baked-in lists
+     * without max / min / std / var, no edge term, the aux table where the list has a dx aggregator) runs ONE kernel, a workgroup per
+     * block: the destination rows' coefficient vectors in LDS, every source row gathering its out-edges -- no [E, F] staging buffer.  */
+    const int32_t* gblk_desc; int64_t n_gblk; int32_t gblk_rows;
+    const int32_t* csc_order;  /* [n_edges] */
+    const int32_t* dst_csr;    /* [n_edges] */
 } DgnGraph;
 
 typedef struct DgnChannel {
@@ -188,6 +197,7 @@ typedef struct DgnMsgGrad {
 } DgnMsgGrad;
 
 int dgn_abi_version(void);
+size_t dgn_sizeof(const char* struct_name);      /* sizeof of a struct of this header as the library was compiled ("DgnGraph", ...); 0: unknown */
 /* Process-wide library options (experiments and tests; every default is what the benchmarks run).  Each option takes its initial value
  * from an environment variable ONCE, when the library first looks; afterwards only dgn_set_option changes it -- no entry point reads the
  * environment on a launch path.  Names: "blk_lds_kb" (DGN_BLK_LDS_KB, 13), "blk_min_nodes" (DGN_BLK_MIN_NODES, 131072),

@@ -30,11 +30,15 @@ def test_header_symbols_are_exported(lib):
     assert lib.dgn_abi_version() == _lib.ABI_VERSION
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(lib):
     from dgn_amd import _lib
-    # sizes implied by include/dgn_hip.h on LP64
+    # every ctypes mirror against the sizeof the LIBRARY was compiled with (dgn_sizeof), then a few sizes spelled out for LP64
+    for name in ("DgnGraph", "DgnChannel", "DgnAggSpec", "DgnMsg", "DgnMsgGrad", "DgnBnGrad", "DgnTowersLayer", "DgnTowersGrads", "DgnDegreeClasses",
+                 "DgnDcLayout", "DgnDenseLayer", "DgnDenseGrads", "DgnBlockTable", "DgnBlockLayer", "DgnBlockGrads"):
+        assert C.sizeof(getattr(_lib, name)) == lib.dgn_sizeof(name.encode()) > 0, name
+    assert lib.dgn_sizeof(b"NoSuchStruct") == 0
     assert C.sizeof(_lib.DgnChannel) == 16
-    assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2 + 8 + 8 + 8 + 8 + 8                # (+ max_in_degree padded, n_src, row_base, blk_cut, blk_gap padded)
+    assert C.sizeof(_lib.DgnGraph) == 8 * 9 + 4 * 2 + 8 * 2 + 8 + 8 + 8 + 8 + 8 + 8 * 5       # (+ max_in_degree padded, n_src, row_base, blk_cut, blk_gap padded; gblk_desc, n_gblk, gblk_rows padded, csc_order, dst_csr)
     assert C.sizeof(_lib.DgnAggSpec) == 4 * (1 + 16 + 16 + 1 + 1 + 4 + 1 + 1 + 1 + 1 + 1) + 8
     assert C.sizeof(_lib.DgnMsg) == 8 * 9 + 8 + 8                               # (+ edge_type, n_edge_types padded)
     assert C.sizeof(_lib.DgnMsgGrad) == 8 * 8 + 8                                # (+ accumulate, padded)
