@@ -15,58 +15,61 @@
 
 namespace dgn {
 
-constexpr int kGraphWaves = 8;
+constexpr int kGraphThreads = 1024;
 
 template <class C>
 __host__ __device__ constexpr int graph_coef_slots() { return 1 + C::NCH * (C::AV ? 2 : 1); }
 
+// A thread owns a (row slot, feature pair): blockDim / ceil(F / 2) rows are in flight per pass (31 at F = 65), every lane works, and
+// the index chains of a row (row pointer -> slot -> destination / weights) are per-thread loads the compiler batches four edges deep --
+// the first version (a wave per row, slots broadcast across lanes) spent ~2 us of dependent load latency per row: 0.044 ms on
+// CIFAR10's batch where the staged path takes 0.026.
 template <class C, class O>
-__global__ __launch_bounds__(kWave * kGraphWaves) void agg_bwd_graph(const AggParams p) {
+__global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p) {
     static_assert(C::VEC == 2 && !C::STATS, "8-byte lanes, lists without max / min / std / var");
-    constexpr int VEC = 2, NCO = graph_coef_slots<C>();
+    constexpr int VEC = 2, NCO = graph_coef_slots<C>(), NCH = C::NCH;
     extern __shared__ float coef_lds[];
     const int4 d = reinterpret_cast<const int4*>(p.gblk_desc)[blockIdx.x];
-    const int lo = d.x, hi = d.y;
-    const int Fs = (p.F + 1) & ~1;
-    float* GX = coef_lds + (size_t)p.gblk_rows * NCO * Fs;          // d x_in rows where d x_in aliases d x_src
+    const int lo = d.x, hi = d.y, rows = hi - lo;
+    const int Fs = (p.F + 1) & ~1, NP = Fs >> 1;
     const bool alias = p.g_in && p.g_in == p.g_src;
-    const int wave = uniform_i((int)threadIdx.x >> 6), lane = lane_id();
-    const int f0 = lane * VEC;
-    const bool active = f0 < p.F;
+    float* GX = coef_lds + (size_t)p.gblk_rows * NCO * Fs;          // d x_in rows where d x_in aliases d x_src
+    float* SW = GX + (alias ? (size_t)p.gblk_rows * Fs : 0);        // sum_j w_jc per (row, channel)
+    const int tid = (int)threadIdx.x;
+    const int RS = (int)blockDim.x / NP;                            // row slots
+    const int slot = tid / NP, f0 = (tid - slot * NP) * VEC;
+    const bool on = slot < RS;
     const bool signs = (p.need & NEED_RECOMP) != 0;          // (the host takes this kernel only with the aux table then)
+    // ---- phase 0: sum_j w_jc in slot order (the order of Acc::add, i.e. of the staged backward: the same coefficient bits) ----
+    if constexpr (NCH > 0) {
+        for (int r = tid; r < rows * NCH; r += (int)blockDim.x) {
+            const int row = r / NCH, c = r - row * NCH;
+            const int beg = p.indptr[lo + row], end = p.indptr[lo + row + 1];
+            const float* w = p.w + (int64_t)c * p.ld_w;
+            float s = 0.f;
+#pragma unroll 8
+            for (int e = beg; e < end; ++e) s += w[e];
+            SW[r] = s;
+        }
+        __syncthreads();
+    }
     // ---- phase 1: destination rows ----
-    for (int row = lo + wave; row < hi; row += kGraphWaves) {
-        const int beg = p.indptr[row], end = p.indptr[row + 1];
-        const int deg = end - beg;
-        const float logd = p.log_deg ? p.log_deg[row] : 0.f;
-        // sum_j w_jc in slot order (the order of Acc::add, i.e. of the staged backward: the same coefficient bits)
-        float sw[C::NW];
+    if (on) {
+        for (int row = lo + slot; row < hi; row += RS) {
+            const int beg = p.indptr[row], end = p.indptr[row + 1];
+            const int deg = end - beg;
+            const float logd = p.log_deg ? p.log_deg[row] : 0.f;
+            float* crow = coef_lds + (size_t)(row - lo) * NCO * Fs + f0;
+            const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
+            float gxin[VEC] = {0.f, 0.f}, rsum[VEC] = {0.f, 0.f};
+            Coef<C> k;
 #pragma unroll
-        for (int c = 0; c < C::NW; ++c) sw[c] = 0.f;
-        for (int base = beg; base < end; base += kWave) {
-            const int e = min(base + lane, end - 1), cnt = min(kWave, end - base);
-            float w[C::NW];
+            for (int i = 0; i < VEC; ++i) k.c0[i] = 0.f;
 #pragma unroll
-            for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + e];
-            for (int q = 0; q < cnt; ++q) {
-#pragma unroll
-                for (int c = 0; c < C::NCH; ++c) sw[c] += bcast_f(w[c], q);
+            for (int c = 0; c < C::NW; ++c) {
+                k.cs[c][0] = 0.f; k.cs[c][1] = 0.f;
+                if constexpr (C::AV) { k.ca[c][0] = 0.f; k.ca[c][1] = 0.f; }
             }
-        }
-        float* crow = coef_lds + (size_t)(row - lo) * NCO * Fs + f0;
-        const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
-        float gxin[VEC] = {0.f, 0.f}, rsum[VEC] = {0.f, 0.f};
-        Coef<C> k;
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) k.c0[i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < C::NW; ++c) {
-            k.cs[c][0] = 0.f; k.cs[c][1] = 0.f;
-            if constexpr (C::AV) { k.ca[c][0] = 0.f; k.ca[c][1] = 0.f; }
-        }
-        if (active) {
             if (deg == 0) {
                 // no messages: zero coefficients; the x_in pass-through block still carries its gradient
                 if (p.need & NEED_XPASS) {
@@ -82,94 +85,63 @@ __global__ __launch_bounds__(kWave * kGraphWaves) void agg_bwd_graph(const AggPa
                 acc.init();
                 float xin[VEC] = {0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < C::NCH; ++c) acc.sw[c] = sw[c];
-                if constexpr (C::NCH >= 1 && C::NCH <= 2) {
+                for (int c = 0; c < NCH; ++c) acc.sw[c] = SW[(row - lo) * NCH + c];
+                if constexpr (NCH >= 1 && NCH <= 2) {
                     if (signs) acc_signs_from_aux<C, true>(acc, load_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0));
                 }
                 make_coef<C, O>(k, gxin, acc, p, grow, deg, xin, logd);
             }
             stv<VEC>(crow, k.c0);
 #pragma unroll
-            for (int c = 0; c < C::NCH; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 stv<VEC>(crow + (1 + c) * Fs, k.cs[c]);
-                if constexpr (C::AV) stv<VEC>(crow + (1 + C::NCH + c) * Fs, k.ca[c]);
+                if constexpr (C::AV) stv<VEC>(crow + (1 + NCH + c) * Fs, k.ca[c]);
             }
-        }
-        // d x_dst: the row's per-edge gradients summed in slot order (emit_batch's arithmetic, no message term on these lists)
-        if (p.g_dst) {
-            for (int base = beg; base < end; base += kWave) {
-                const int e = min(base + lane, end - 1), cnt = min(kWave, end - base);
-                float w[C::NW];
+            // d x_dst: the row's per-edge gradients summed in slot order (emit_batch's arithmetic, no message term on these lists)
+            if (p.g_dst) {
+#pragma unroll 4
+                for (int e = beg; e < end; ++e) {
+                    float gm[VEC] = {k.c0[0], k.c0[1]};
 #pragma unroll
-                for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
-#pragma unroll
-                for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + e];
-#pragma unroll
-                for (int c = 0; c < C::NW; ++c) asm volatile("" : "+v"(w[c]));      // (read across lanes below: see phase 2)
-                if (active) {
-                    for (int q = 0; q < cnt; ++q) {
-                        float gm[VEC] = {k.c0[0], k.c0[1]};
-#pragma unroll
-                        for (int c = 0; c < C::NCH; ++c) {
-                            const float wq = bcast_f(w[c], q);
-                            gm[0] = fmaf(wq, k.cs[c][0], gm[0]); gm[1] = fmaf(wq, k.cs[c][1], gm[1]);
-                            if constexpr (C::AV) { gm[0] = fmaf(fabsf(wq), k.ca[c][0], gm[0]); gm[1] = fmaf(fabsf(wq), k.ca[c][1], gm[1]); }
-                        }
-                        rsum[0] += gm[0]; rsum[1] += gm[1];
+                    for (int c = 0; c < NCH; ++c) {
+                        const float wq = p.w[(int64_t)c * p.ld_w + e];
+                        gm[0] = fmaf(wq, k.cs[c][0], gm[0]); gm[1] = fmaf(wq, k.cs[c][1], gm[1]);
+                        if constexpr (C::AV) { gm[0] = fmaf(fabsf(wq), k.ca[c][0], gm[0]); gm[1] = fmaf(fabsf(wq), k.ca[c][1], gm[1]); }
                     }
+                    rsum[0] += gm[0]; rsum[1] += gm[1];
                 }
+                stv<VEC>(p.g_dst + (int64_t)row * p.ldg_dst + f0, rsum);
             }
-            if (active) stv<VEC>(p.g_dst + (int64_t)row * p.ldg_dst + f0, rsum);
-        }
-        if (active) {
             if (alias) stv<VEC>(GX + (size_t)(row - lo) * Fs + f0, gxin);
             else if (p.g_in) stv<VEC>(p.g_in + (int64_t)row * p.ldg_in + f0, gxin);
         }
     }
     __syncthreads();
     // ---- phase 2: source rows, out-edges in (source, slot) order ----
-    for (int u = lo + wave; u < hi; u += kGraphWaves) {
-        const int r0 = p.csc_ptr[u], r1 = p.csc_ptr[u + 1];
-        float a[VEC] = {0.f, 0.f};
-        for (int base = r0; base < r1; base += kWave) {
-            const int rank = min(base + lane, r1 - 1);
-            const int j = p.csc_order[rank];
-            const int i_loc = p.dst_csr[j] - lo;
-            float w[C::NW];
+    if (on) {
+        for (int u = lo + slot; u < hi; u += RS) {
+            const int r0 = p.csc_ptr[u], r1 = p.csc_ptr[u + 1];
+            float a[VEC] = {0.f, 0.f};
+#pragma unroll 8
+            for (int rank = r0; rank < r1; ++rank) {
+                const int j = p.csc_order[rank];
+                const float* crow = coef_lds + (size_t)(p.dst_csr[j] - lo) * NCO * Fs + f0;
+                float gm[VEC];
+                ldv<VEC>(gm, crow);
 #pragma unroll
-            for (int c = 0; c < C::NW; ++c) w[c] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C::NCH; ++c) w[c] = p.w[(int64_t)c * p.ld_w + j];
-            const int cnt = min(kWave, r1 - base);
-            // (pinned HERE, for all 64 lanes: the values are read across lanes below (v_readlane ignores exec) by the active lanes only --
-            //  33 of 64 at F = 66 --, and a source with more out-edges than active lanes reads lanes the compiler would otherwise have
-            //  let skip the loads by sinking them into the branch: SBM rows with >= 34 out-edges came out wrong)
-            int i_pin = i_loc;
-            asm volatile("" : "+v"(i_pin));
-#pragma unroll
-            for (int c = 0; c < C::NW; ++c) asm volatile("" : "+v"(w[c]));
-            if (active) {
-                for (int q = 0; q < cnt; ++q) {
-                    const float* crow = coef_lds + (size_t)bcast_i(i_pin, q) * NCO * Fs + f0;
-                    float gm[VEC];
-                    ldv<VEC>(gm, crow);
-#pragma unroll
-                    for (int c = 0; c < C::NCH; ++c) {
-                        const float wq = bcast_f(w[c], q);
-                        float cs[VEC];
-                        ldv<VEC>(cs, crow + (1 + c) * Fs);
-                        gm[0] = fmaf(wq, cs[0], gm[0]); gm[1] = fmaf(wq, cs[1], gm[1]);
-                        if constexpr (C::AV) {
-                            float ca[VEC];
-                            ldv<VEC>(ca, crow + (1 + C::NCH + c) * Fs);
-                            gm[0] = fmaf(fabsf(wq), ca[0], gm[0]); gm[1] = fmaf(fabsf(wq), ca[1], gm[1]);
-                        }
+                for (int c = 0; c < NCH; ++c) {
+                    const float wq = p.w[(int64_t)c * p.ld_w + j];
+                    float cs[VEC];
+                    ldv<VEC>(cs, crow + (1 + c) * Fs);
+                    gm[0] = fmaf(wq, cs[0], gm[0]); gm[1] = fmaf(wq, cs[1], gm[1]);
+                    if constexpr (C::AV) {
+                        float ca[VEC];
+                        ldv<VEC>(ca, crow + (1 + NCH + c) * Fs);
+                        gm[0] = fmaf(fabsf(wq), ca[0], gm[0]); gm[1] = fmaf(fabsf(wq), ca[1], gm[1]);
                     }
-                    a[0] += gm[0]; a[1] += gm[1];
                 }
+                a[0] += gm[0]; a[1] += gm[1];
             }
-        }
-        if (active) {
             if (alias) {
                 float gx[VEC];
                 ldv<VEC>(gx, GX + (size_t)(u - lo) * Fs + f0);
@@ -189,7 +161,7 @@ int launch_backward_graph_cfg(const AggParams& p, hipStream_t stream) {
         constexpr int NCO = graph_coef_slots<C>();
         const int Fs = (p.F + 1) & ~1;
         const bool alias = p.g_in && p.g_in == p.g_src;
-        const size_t lds = ((size_t)p.gblk_rows * NCO * Fs + (alias ? (size_t)p.gblk_rows * Fs : 0)) * sizeof(float);
+        const size_t lds = ((size_t)p.gblk_rows * NCO * Fs + (alias ? (size_t)p.gblk_rows * Fs : 0) + (size_t)p.gblk_rows * C::NCH) * sizeof(float);
         if (lds > 160 * 1024 || ((p.need & NEED_RECOMP) && !(p.aux && p.aux_rows))) return 1;
         static bool attr = false;
         if (!attr) {
@@ -198,7 +170,7 @@ int launch_backward_graph_cfg(const AggParams& p, hipStream_t stream) {
         }
         AggParams q = p;
         q.stage = nullptr; q.fresh = true; q.seg_add = false;
-        hipLaunchKernelGGL((agg_bwd_graph<C, O>), dim3((unsigned)p.n_gblk), dim3(kWave * kGraphWaves), lds, stream, q);
+        hipLaunchKernelGGL((agg_bwd_graph<C, O>), dim3((unsigned)p.n_gblk), dim3(kGraphThreads), lds, stream, q);
         DGN_HIP_CHECK(hipGetLastError());
         return DGN_OK;
     }
