@@ -147,6 +147,8 @@ def pmc_traffic(tag, kernels):
     try:
         data = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[tag]["kernels"]
         have = [k for k in kernels if k in data]      # (an op is one of several kernels depending on the graph)
+        if "agg_bwd_graph" in have:                   # (k-NN / SBM batches from round 5 on: the graph backward alone)
+            have = ["agg_bwd_graph"]
         if not have:
             return None
         return sum(2 * 1024 * data[k]["FETCH_SIZE_KiB"] + 1024 * data[k]["WRITE_SIZE_KiB"] for k in have)
@@ -513,9 +515,10 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     # rows) or agg_fwd_rows; backward = agg_bwd_short (four short rows per wave) or agg_bwd_rows, + seg_sum_rows (second phase of the
     # atomic-free scatter)
     # -- or, on batches of small graphs from 131 072 nodes on, agg_bwd_block ALONE (one wave per run of whole graphs, d x_src in LDS)
-    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "seg_sum_rows", "agg_bwd_block"]}[dom]
+    # -- or, on k-NN / SBM batches (more than 3 edges per node, graphs of up to 512 nodes), agg_bwd_graph ALONE (a workgroup per graph)
+    launches = {"agg_fwd_rows": ["agg_fwd_rows", "agg_fwd_short"], "agg_bwd_rows": ["agg_bwd_rows", "agg_bwd_short", "seg_sum_rows", "agg_bwd_block", "agg_bwd_graph"]}[dom]
     label = {"agg_fwd_rows": "dgn_agg_forward (agg_fwd_short | agg_fwd_rows)",
-             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_block | agg_bwd_short + seg_sum_rows | agg_bwd_rows + seg_sum_rows)"}[dom]
+             "agg_bwd_rows": "dgn_agg_backward (agg_bwd_block | agg_bwd_graph | agg_bwd_short + seg_sum_rows | agg_bwd_rows + seg_sum_rows)"}[dom]
     triad = hbm_triad_GBps(dev)
     # The launched list carries the h_in pass-through block of the complex / towers layers as one more "aggregator"
     # (A = survey's A + 1: the sweep really writes that block).  The same launch priced with SURVEY 8(d)'s own A:

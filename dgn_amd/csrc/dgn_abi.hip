@@ -58,6 +58,7 @@ const OptDef kOpts[OPT_COUNT] = {
     {"tile_wgrad", "DGN_TILE_WGRAD", -1, false},                 // 0 / 1: force the strip / tile weight gradient (-1: by shape)
     {"no_zmask", "DGN_NO_ZMASK", 0, true},                       // towers layer: keep the mixing network's pre-activation instead of its sign mask
     {"linear_small_min_waves", "DGN_LINEAR_SMALL_MIN_WAVES", 8, false},
+    {"graph_bwd_tiles", "DGN_GRAPH_BWD_TILES", 0, false},        // feature tiles of the graph backward (0: by batch size and LDS)
 };
 std::atomic<int64_t> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;

@@ -20,48 +20,57 @@ constexpr int kGraphThreads = 1024;
 template <class C>
 __host__ __device__ constexpr int graph_coef_slots() { return 1 + C::NCH * (C::AV ? 2 : 1); }
 
-// A thread owns a (row slot, feature pair): blockDim / ceil(F / 2) rows are in flight per pass (31 at F = 65), every lane works, and
-// the index chains of a row (row pointer -> slot -> destination / weights) are per-thread loads the compiler batches four edges deep --
-// the first version (a wave per row, slots broadcast across lanes) spent ~2 us of dependent load latency per row: 0.044 ms on
-// CIFAR10's batch where the staged path takes 0.026.
+// A thread owns a (row slot, feature pair): blockDim / pairs rows are in flight per pass, every lane works, and the index chains of a
+// row (row pointer -> slot -> destination / weights) are per-thread loads the compiler batches eight edges deep -- the first version (a
+// wave per row, slots broadcast across lanes) spent ~2 us of dependent load latency per row: 0.044 ms on CIFAR10's batch where the
+// staged path takes 0.026.  blockIdx.y = a tile of feature pairs: batches of fewer graphs than CUs are split so the chip is covered
+// (the row sums of the weights are recomputed per tile: E floats).
+// d x_dst of a row = deg c0 + sum_c (sum_j w_jc) cs_c + (sum_j |w_jc|) ca_c: the row sum of the per-edge gradients in closed form.
 template <class C, class O>
-__global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p) {
+__global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p, const int pairs_per_tile) {
     static_assert(C::VEC == 2 && !C::STATS, "8-byte lanes, lists without max / min / std / var");
-    constexpr int VEC = 2, NCO = graph_coef_slots<C>(), NCH = C::NCH;
+    constexpr int VEC = 2, NCO = graph_coef_slots<C>(), NCH = C::NCH, NSW = NCH * (C::AV ? 2 : 1);
     extern __shared__ float coef_lds[];
     const int4 d = reinterpret_cast<const int4*>(p.gblk_desc)[blockIdx.x];
     const int lo = d.x, hi = d.y, rows = hi - lo;
-    const int Fs = (p.F + 1) & ~1, NP = Fs >> 1;
+    const int pair0 = (int)blockIdx.y * pairs_per_tile;
+    const int NP = min(pairs_per_tile, ((p.F + 1) >> 1) - pair0);      // this tile's pairs
+    const int Fl = pairs_per_tile * VEC;                                // floats of a coefficient vector in LDS
     const bool alias = p.g_in && p.g_in == p.g_src;
-    float* GX = coef_lds + (size_t)p.gblk_rows * NCO * Fs;          // d x_in rows where d x_in aliases d x_src
-    float* SW = GX + (alias ? (size_t)p.gblk_rows * Fs : 0);        // sum_j w_jc per (row, channel)
+    float* GX = coef_lds + (size_t)p.gblk_rows * NCO * Fl;          // d x_in rows where d x_in aliases d x_src
+    float* SW = GX + (alias ? (size_t)p.gblk_rows * Fl : 0);        // sum_j w_jc (and sum_j |w_jc|) per (row, channel)
     const int tid = (int)threadIdx.x;
     const int RS = (int)blockDim.x / NP;                            // row slots
-    const int slot = tid / NP, f0 = (tid - slot * NP) * VEC;
+    const int slot = tid / NP, fl = (tid - slot * NP) * VEC, f0 = pair0 * VEC + fl;
     const bool on = slot < RS;
     const bool signs = (p.need & NEED_RECOMP) != 0;          // (the host takes this kernel only with the aux table then)
-    // ---- phase 0: sum_j w_jc in slot order (the order of Acc::add, i.e. of the staged backward: the same coefficient bits) ----
+    // ---- phase 0: sum_j w_jc in slot order (the order of Acc::add: the forward's bits) ----
     if constexpr (NCH > 0) {
         for (int r = tid; r < rows * NCH; r += (int)blockDim.x) {
             const int row = r / NCH, c = r - row * NCH;
             const int beg = p.indptr[lo + row], end = p.indptr[lo + row + 1];
             const float* w = p.w + (int64_t)c * p.ld_w;
-            float s = 0.f;
+            float s = 0.f, sa = 0.f;
 #pragma unroll 8
-            for (int e = beg; e < end; ++e) s += w[e];
-            SW[r] = s;
+            for (int e = beg; e < end; ++e) {
+                const float we = w[e];
+                s += we;
+                if constexpr (C::AV) sa += fabsf(we);
+            }
+            SW[row * NSW + c] = s;
+            if constexpr (C::AV) SW[row * NSW + NCH + c] = sa;
         }
         __syncthreads();
     }
     // ---- phase 1: destination rows ----
     if (on) {
         for (int row = lo + slot; row < hi; row += RS) {
-            const int beg = p.indptr[row], end = p.indptr[row + 1];
-            const int deg = end - beg;
+            const int deg = p.indptr[row + 1] - p.indptr[row];
             const float logd = p.log_deg ? p.log_deg[row] : 0.f;
-            float* crow = coef_lds + (size_t)(row - lo) * NCO * Fs + f0;
+            float* crow = coef_lds + (size_t)(row - lo) * NCO * Fl + fl;
             const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
-            float gxin[VEC] = {0.f, 0.f}, rsum[VEC] = {0.f, 0.f};
+            const float* sw = SW + (row - lo) * NSW;
+            float gxin[VEC] = {0.f, 0.f};
             Coef<C> k;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) k.c0[i] = 0.f;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p
                 acc.init();
                 float xin[VEC] = {0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) acc.sw[c] = SW[(row - lo) * NCH + c];
+                for (int c = 0; c < NCH; ++c) acc.sw[c] = sw[c];
                 if constexpr (NCH >= 1 && NCH <= 2) {
                     if (signs) acc_signs_from_aux<C, true>(acc, load_aux_row<VEC>(p.aux + (int64_t)row * p.F + f0));
                 }
@@ -94,25 +103,21 @@ __global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p
             stv<VEC>(crow, k.c0);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                stv<VEC>(crow + (1 + c) * Fs, k.cs[c]);
-                if constexpr (C::AV) stv<VEC>(crow + (1 + NCH + c) * Fs, k.ca[c]);
+                stv<VEC>(crow + (1 + c) * Fl, k.cs[c]);
+                if constexpr (C::AV) stv<VEC>(crow + (1 + NCH + c) * Fl, k.ca[c]);
             }
-            // d x_dst: the row's per-edge gradients summed in slot order (emit_batch's arithmetic, no message term on these lists)
             if (p.g_dst) {
-#pragma unroll 4
-                for (int e = beg; e < end; ++e) {
-                    float gm[VEC] = {k.c0[0], k.c0[1]};
+                float rsum[VEC] = {(float)deg * k.c0[0], (float)deg * k.c0[1]};
+                if (deg > 0) {
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
-                        const float wq = p.w[(int64_t)c * p.ld_w + e];
-                        gm[0] = fmaf(wq, k.cs[c][0], gm[0]); gm[1] = fmaf(wq, k.cs[c][1], gm[1]);
-                        if constexpr (C::AV) { gm[0] = fmaf(fabsf(wq), k.ca[c][0], gm[0]); gm[1] = fmaf(fabsf(wq), k.ca[c][1], gm[1]); }
+                        rsum[0] = fmaf(sw[c], k.cs[c][0], rsum[0]); rsum[1] = fmaf(sw[c], k.cs[c][1], rsum[1]);
+                        if constexpr (C::AV) { rsum[0] = fmaf(sw[NCH + c], k.ca[c][0], rsum[0]); rsum[1] = fmaf(sw[NCH + c], k.ca[c][1], rsum[1]); }
                     }
-                    rsum[0] += gm[0]; rsum[1] += gm[1];
                 }
                 stv<VEC>(p.g_dst + (int64_t)row * p.ldg_dst + f0, rsum);
             }
-            if (alias) stv<VEC>(GX + (size_t)(row - lo) * Fs + f0, gxin);
+            if (alias) stv<VEC>(GX + (size_t)(row - lo) * Fl + fl, gxin);
             else if (p.g_in) stv<VEC>(p.g_in + (int64_t)row * p.ldg_in + f0, gxin);
         }
     }
@@ -125,18 +130,18 @@ __global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p
 #pragma unroll 8
             for (int rank = r0; rank < r1; ++rank) {
                 const int j = p.csc_order[rank];
-                const float* crow = coef_lds + (size_t)(p.dst_csr[j] - lo) * NCO * Fs + f0;
+                const float* crow = coef_lds + (size_t)(p.dst_csr[j] - lo) * NCO * Fl + fl;
                 float gm[VEC];
                 ldv<VEC>(gm, crow);
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const float wq = p.w[(int64_t)c * p.ld_w + j];
                     float cs[VEC];
-                    ldv<VEC>(cs, crow + (1 + c) * Fs);
+                    ldv<VEC>(cs, crow + (1 + c) * Fl);
                     gm[0] = fmaf(wq, cs[0], gm[0]); gm[1] = fmaf(wq, cs[1], gm[1]);
                     if constexpr (C::AV) {
                         float ca[VEC];
-                        ldv<VEC>(ca, crow + (1 + NCH + c) * Fs);
+                        ldv<VEC>(ca, crow + (1 + NCH + c) * Fl);
                         gm[0] = fmaf(fabsf(wq), ca[0], gm[0]); gm[1] = fmaf(fabsf(wq), ca[1], gm[1]);
                     }
                 }
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(kGraphThreads) void agg_bwd_graph(const AggParams p
             }
             if (alias) {
                 float gx[VEC];
-                ldv<VEC>(gx, GX + (size_t)(u - lo) * Fs + f0);
+                ldv<VEC>(gx, GX + (size_t)(u - lo) * Fl + fl);
                 a[0] += gx[0]; a[1] += gx[1];
             }
             stv<VEC>(p.g_src + (int64_t)u * p.ldg_src + f0, a);
@@ -158,10 +163,21 @@ int launch_backward_graph_cfg(const AggParams& p, hipStream_t stream) {
     if constexpr (C::STATS || C::VEC != 2) {
         return 1;
     } else {
-        constexpr int NCO = graph_coef_slots<C>();
-        const int Fs = (p.F + 1) & ~1;
+        constexpr int NCO = graph_coef_slots<C>(), NSW = C::NCH * (C::AV ? 2 : 1);
+        const int pairs = (p.F + 1) >> 1;
         const bool alias = p.g_in && p.g_in == p.g_src;
-        const size_t lds = ((size_t)p.gblk_rows * NCO * Fs + (alias ? (size_t)p.gblk_rows * Fs : 0) + (size_t)p.gblk_rows * C::NCH) * sizeof(float);
+        auto lds_of = [&](int ppt) { return ((size_t)p.gblk_rows * (NCO + (alias ? 1 : 0)) * ppt * 2 + (size_t)p.gblk_rows * NSW) * sizeof(float); };
+        // feature tiles: enough workgroups to cover the chip on small batches (CIFAR10's 128 graphs: 0.0199 -> 0.0143 ms, PATTERN's:
+        // 0.070 -> 0.044); large batches stay whole (two half-width workgroups per CU measured slower: 0.77 vs 0.71 ms on 8192 graphs)
+        int tiles = (int)option(OPT_GRAPH_BWD_TILES);
+        if (tiles <= 0) {
+            tiles = 1;
+            while (tiles < 4 && (int64_t)p.n_gblk * tiles < 256 && (pairs + 2 * tiles - 1) / (2 * tiles) >= 8) tiles *= 2;
+        }
+        tiles = std::min(tiles, pairs);
+        const int ppt = (pairs + tiles - 1) / tiles;
+        tiles = (pairs + ppt - 1) / ppt;
+        const size_t lds = lds_of(ppt);
         if (lds > 160 * 1024 || ((p.need & NEED_RECOMP) && !(p.aux && p.aux_rows))) return 1;
         static bool attr = false;
         if (!attr) {
@@ -170,7 +186,7 @@ int launch_backward_graph_cfg(const AggParams& p, hipStream_t stream) {
         }
         AggParams q = p;
         q.stage = nullptr; q.fresh = true; q.seg_add = false;
-        hipLaunchKernelGGL((agg_bwd_graph<C, O>), dim3((unsigned)p.n_gblk), dim3(kGraphThreads), lds, stream, q);
+        hipLaunchKernelGGL((agg_bwd_graph<C, O>), dim3((unsigned)p.n_gblk, (unsigned)tiles), dim3(kGraphThreads), lds, stream, q, ppt);
         DGN_HIP_CHECK(hipGetLastError());
         return DGN_OK;
     }

@@ -228,3 +228,27 @@ def test_graph_backward_matches_staged_and_is_reproducible(monkeypatch, gen, cas
     for a, c in zip(g1, g0):
         scale = max(1.0, float(c.abs().max()))
         np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("gen,case", [("knn", "cifar"), ("sbm", "cifar_complex")])
+def test_graph_backward_feature_tiles_agree_bitwise(monkeypatch, gen, case):
+    """The graph backward's feature tiles (blockIdx.y: 1, 2, 3 or 4 column ranges per graph, chosen by batch size and LDS) only decide
+    which workgroup owns a column: every tiling gives the same bits."""
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    dev = _dev()
+    b = synth.knn_batch(12, seed=5) if gen == "knn" else synth.sbm_batch(6, seed=5, n_lo=44, n_hi=90)
+    N = int(b["num_nodes"])
+    F_, T, plan, pair = _case(case)
+    gg = torch.Generator().manual_seed(9)
+    X, PQ = torch.randn(N, F_, generator=gg), torch.randn(N, 2 * F_, generator=gg)
+    ref = None
+    for tiles in (1, 2, 3, 4):
+        monkeypatch.setattr(_lib.options, "graph_bwd_tiles", tiles)
+        graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+        _, g = _grads(graph, plan, F_, T, pair, X, PQ)
+        assert graph.c_graph.gblk_desc
+        if ref is None:
+            ref = g
+        else:
+            assert all(torch.equal(a, c) for a, c in zip(g, ref)), f"tiles = {tiles} changed the gradients"
