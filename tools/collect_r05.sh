@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Round-5 evidence set, run ON THE GPU BOX from the repo root (gpurun):  tools/collect_r05.sh
+#   gpurun_out/r05_bench_default.json / _full.json   the default `python bench.py` line (compact) and its full record
+#   gpurun_out/r05_bench_all_extras.json             full record of `python bench.py --all-extras`
+#   gpurun_out/prof_<tag>/                           rocprofv3 --kernel-trace --stats (all tags) + FETCH_SIZE / WRITE_SIZE passes (c2, c3, c3_mega)
+# tools/profile_report.py <tag> r05 then turns the per-tag directories into profiles/r05_<tag>_kernel_stats.txt + profiles/pmc_traffic.json.
+set -uo pipefail
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err
+cp gpurun_out/bench_full.json gpurun_out/r05_bench_default_full.json
+for tag in c2 c3 c3_mega; do
+  tools/gpu_profile.sh $tag --workload $tag --no-extras --no-cpu-baseline > /dev/null 2>&1
+done
+for tag in c1 c4 pattern_json zinc_json; do
+  out="gpurun_out/prof_$tag"; mkdir -p "$out"
+  timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o "$tag" -- python bench.py --workload $tag --no-extras --no-cpu-baseline > "$out/trace.log" 2>&1
+done
+for tag in c2_b128 zinc_json_b128 c1_b128; do
+  out="gpurun_out/prof_$tag"; mkdir -p "$out"
+  timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o "$tag" -- python bench.py --workload $tag --no-extras --no-cpu-baseline --hipgraph --steps 200 --warmup 30 > "$out/trace.log" 2>&1
+done
+python bench.py --all-extras > gpurun_out/r05_bench_all_extras_line.json 2> gpurun_out/r05_bench_all_extras.err
+cp gpurun_out/bench_full.json gpurun_out/r05_bench_all_extras.json
+find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*.db" -delete
+du -sh gpurun_out; ls gpurun_out | head -60
