@@ -1005,6 +1005,16 @@ def run_extras(args, dev):
                 except Exception as exc:
                     extra[name]["captured_ms_per_step"] = None
                     extra[name]["captured_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                # ... and eager with autograd's backward on the CALLING thread (torch.autograd.set_multithreading_enabled(False), one line
+                # of a training script): the hand-over to the engine's device thread and back is 60-110 us of a 0.1 ms step
+                torch.autograd.set_multithreading_enabled(False)
+                try:
+                    rs, _ = run_layer_workload(args, dict(WORKLOADS[name]), 0, 1, dev, steps=steps, warmup=warmup, tag=name)
+                    extra[name]["eager_st_ms_per_step"] = rs["ms_per_step"]
+                except Exception as exc:
+                    extra[name]["eager_st_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                finally:
+                    torch.autograd.set_multithreading_enabled(True)
             if name == "c1" and not args.no_cpu_baseline:
                 # BASELINE configs[0] is quoted on the reference's CPU path: the same bounded CPU sample for it
                 extra[name]["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])), reps=3)
@@ -1073,7 +1083,7 @@ def compact_line(line):
             if "error" in e:
                 ex[name] = dict(error=str(e["error"])[:80])
                 continue
-            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step") if k in e}
+            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
                 if isinstance(e["roofline"].get("step"), dict):

@@ -202,7 +202,8 @@ size_t dgn_sizeof(const char* struct_name);      /* sizeof of a struct of this h
  * from an environment variable ONCE, when the library first looks; afterwards only dgn_set_option changes it -- no entry point reads the
  * environment on a launch path.  Names: "blk_lds_kb" (DGN_BLK_LDS_KB, 13), "blk_min_nodes" (DGN_BLK_MIN_NODES, 131072),
  * "bwd_rows_per_wave" (DGN_BWD_ROWS_PER_WAVE, 4), "tile_gemm" / "tile_wgrad" (DGN_TILE_GEMM / DGN_TILE_WGRAD, -1 = by shape),
- * "no_zmask" (DGN_NO_ZMASK set, 0), "linear_small_min_waves" (8).  dgn_set_option: DGN_ERR_INVALID for an unknown name;
+ * "no_zmask" (DGN_NO_ZMASK set, 0), "linear_small_min_waves" (8), "graph_bwd_tiles" (DGN_GRAPH_BWD_TILES, 0 = by batch size: feature tiles of
+ * the graph backward of the sweep).  dgn_set_option: DGN_ERR_INVALID for an unknown name;
  * dgn_get_option: INT64_MIN for an unknown name.                                                                            */
 int dgn_set_option(const char* name, int64_t value);
 int64_t dgn_get_option(const char* name);
