@@ -948,12 +948,12 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
                        "eager, graph preparation included")
 
 
-COMMITTED_LINE = os.path.join(ROOT, "profiles", "r04_bench_all_extras.json")
+COMMITTED_LINE = os.path.join(ROOT, "profiles", "r05_bench_all_extras.json")
 
 
 def regression_warnings(results, headline=None):
     """Measurement hygiene: every roofline fraction of this run is compared with the committed line of the same
-    command (profiles/r04_bench_all_extras.json); a leg that fell below half of its committed value gets a `warning` field instead of
+    command (profiles/r05_bench_all_extras.json); a leg that fell below half of its committed value gets a `warning` field instead of
     passing silently (a box with a disturbed clock, or a regression)."""
     try:
         ref = json.load(open(COMMITTED_LINE))
