@@ -104,7 +104,17 @@ bool plan_lds(const Dims& d, const DgnAggSpec* spec, bool bwd, Layout& L, int& R
     const int64_t wgs = (int64_t)d.n_blocks * d.T;
     const int by_threads = resident_per_cu(d, bwd);
     bool found = false; int64_t best_rounds = 0; Layout bestL{}; int best_rc = 0;
-    for (int rc : {64, 48, 32, 16}) {
+    // (the largest block's own row count is a candidate: a chunk costs the same ~20 us of job rounds whatever its rows, and with 32-row
+    //  chunks the 33 - 37-node molecules of a ZINC batch ran two of them -- the slowest workgroups, 55 us where the mean is 35)
+    int cand[5] = {64, 48, 32, 16, 0}, n_cand = 4;
+    if (R < 64 && (R & 15)) {
+        int at = 0;
+        while (at < n_cand && cand[at] > R) ++at;
+        for (int q = n_cand; q > at; --q) cand[q] = cand[q - 1];
+        cand[at] = R; ++n_cand;
+    }
+    for (int ci = 0; ci < n_cand; ++ci) {
+        const int rc = cand[ci];
         if (rc > 16 && rc >= R + 16) continue;              // (no point in a chunk a whole strip larger than the largest block)
         int off = 0;
         auto take = [&](int n) { const int at = off; off += up4(std::max(n, 0)); return at; };

@@ -852,6 +852,85 @@ __device__ __forceinline__ float edge_grad(const P& p, const Ctx& c, int mc, int
     return gm;
 }
 
+// posttrans' adjoint for NS 16-row strips of g_yr at once (gy: strip st's rows at gy + (16 st + i16) * ldy): acc[st][s] += W[:, s K + kk] . g_yr.
+// The weight columns -- global loads, the job's only memory latency -- are fetched ONCE per 16-n block instead of once per strip.
+// S == 0: one unscaled segment (the h block of posttrans' input), result in acc[st][0].
+template <int NS>
+__device__ __forceinline__ void mma_gs3_strips(f4 (&acc)[NS][3], const float* __restrict__ acol, int ld, int K, int S, const float* gy, int ldy,
+                                               int N, int i16, int g) {
+    const int S_ = max(S, 1);
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        float av[3][4];
+        int nc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * g + e;
+            nc[e] = min(n, N - 1);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const float a = acol[(int64_t)nc[e] * ld + min(s, S_ - 1) * K];
+                av[s][e] = n < N ? a : 0.f;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const float* brow = gy + (16 * st + i16) * ldy;
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float b = brow[nc[e]];
+                bv[e] = n0 + 4 * g + e < N ? b : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < S_) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[st][s] = mfma4(av[s][e], bv[e], acc[st][s]);
+                }
+            }
+        }
+    }
+}
+
+// d [h | aggregates] of a chunk of NS strips: d agg = sum_s scale_s (g_yr W_post[:, block s]), d h through posttrans' h block.  A job =
+// one 16-column tile for ALL strips (a job per (strip, tile) gave the largest blocks, three strips, five rounds of one-latency jobs on
+// four waves where the small blocks ran two).
+template <int NS, bool HAS_PRE>
+__device__ __forceinline__ void dagg_chunk(const P& p, const Ctx& c, float* XP, const float* __restrict__ wpost, const float* GY, int c0, int rc, int wave,
+                                           int nw, int i16, int g) {
+    // (XP, GY, c0: the pass's first row -- of the chunk's LDS rows, of g_yr, in the block; rc: rows from there to the chunk's end)
+    const int fi = p.fi, fo = p.fo, ldy = p.L.ldy, kp = p.L.kp;
+    const int ntk = (p.K + 15) >> 4, nth = HAS_PRE ? (fi + 15) >> 4 : 0;
+    for (int job = wave; job < ntk + nth; job += nw) {
+        f4 acc[NS][3];
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[st][q] = f4{0.f, 0.f, 0.f, 0.f};
+        if (job < ntk) {
+            const int tk = job, kk = tk * 16 + i16;
+            mma_gs3_strips<NS>(acc, wpost + p.h_off + min(kk, p.K - 1), p.ld_post, p.K, p.S, GY, ldy, fo, i16, g);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int m = st * 16 + i16;
+                const f4 fc = *reinterpret_cast<const f4*>(c.FAC + 4 * (c0 + min(m, rc - 1)));
+                f4 out = acc[st][0] * fc[0];
+                if (p.S > 1) out += acc[st][1] * fc[1];
+                if (p.S > 2) out += acc[st][2] * fc[2];
+                if (m < rc && p.L.ho + tk * 16 + 4 * g < kp) *reinterpret_cast<f4*>(XP + m * kp + p.L.ho + tk * 16 + 4 * g) = out;
+            }
+        } else {
+            const int th = job - ntk, kk = th * 16 + i16;
+            mma_gs3_strips<NS>(acc, wpost + min(kk, fi - 1), p.ld_post, 0, 0, GY, ldy, fo, i16, g);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int m = st * 16 + i16;
+                if (m < rc && th * 16 + 4 * g < p.L.ho) *reinterpret_cast<f4*>(XP + m * kp + th * 16 + 4 * g) = acc[st][0];
+            }
+        }
+    }
+}
+
 // ---- backward of a (block, tower) -------------------------------------------------------------------------------------------------
 template <class O, class C, bool HAS_PRE>
 __global__ __launch_bounds__(1024) void blk_backward(const P p) {
@@ -905,29 +984,11 @@ __global__ __launch_bounds__(1024) void blk_backward(const P p) {
         const int rc = min(RC, R - c0), rc16 = (rc + 15) & ~15;
         const float* GY = c.Y + c0 * ldy;
         // the gradient of the rows [h | aggregates]: d agg = sum_s scale_s (g_yr W_post[:, block s]), d h through posttrans' h block:
-        // jobs of (strip, 16-column tile of the aggregate blocks or of the h block)
-        {
-            const int nstrip = rc16 >> 4, ntk = (p.K + 15) >> 4, nth = HAS_PRE ? (fi + 15) >> 4 : 0;
-            for (int job = wave; job < nstrip * (ntk + nth); job += nw) {
-                const int tk = job % (ntk + nth), strip = job / (ntk + nth);
-                const int m = strip * 16 + i16;
-                const float* grow = GY + m * ldy;
-                if (tk < ntk) {
-                    const int kk = tk * 16 + i16;
-                    f4 acc3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                    mma_gs3_l(acc3, wpost + p.h_off + min(kk, p.K - 1), p.ld_post, p.K, p.S, grow, fo, g);
-                    const f4 fc = *reinterpret_cast<const f4*>(c.FAC + 4 * (c0 + min(m, rc - 1)));
-                    f4 out = acc3[0] * fc[0];
-                    if (p.S > 1) out += acc3[1] * fc[1];
-                    if (p.S > 2) out += acc3[2] * fc[2];
-                    if (m < rc && p.L.ho + tk * 16 + 4 * g < kp) *reinterpret_cast<f4*>(c.XP + m * kp + p.L.ho + tk * 16 + 4 * g) = out;
-                } else {
-                    const int th = tk - ntk, kk = th * 16 + i16;
-                    f4 acc = {0.f, 0.f, 0.f, 0.f};
-                    mma_gs_l(acc, wpost + min(kk, fi - 1), p.ld_post, grow, fo, g);
-                    if (m < rc && th * 16 + 4 * g < p.L.ho) *reinterpret_cast<f4*>(c.XP + m * kp + th * 16 + 4 * g) = acc;
-                }
-            }
+        // jobs of one 16-column tile of the aggregate blocks or of the h block, all strips of the chunk at once (dagg_chunk)
+        // (two strips per pass: the kernel sits at its 128-register cap, four strips' accumulators spill)
+        for (int s0 = 0; s0 < rc16; s0 += 32) {
+            if (rc16 - s0 >= 32) dagg_chunk<2, HAS_PRE>(p, c, c.XP + s0 * kp, wpost, GY + s0 * ldy, c0 + s0, rc - s0, wave, nw, i16, g);
+            else dagg_chunk<1, HAS_PRE>(p, c, c.XP + s0 * kp, wpost, GY + s0 * ldy, c0 + s0, rc - s0, wave, nw, i16, g);
         }
         __syncthreads();
         BLK_STAMP(6);
