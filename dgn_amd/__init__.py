@@ -9,7 +9,7 @@ from .graph import DGNGraph, as_dgn_graph, compute_edge_weights
 from .spec import AGGREGATOR_NAMES, SCALER_NAMES, make_plan
 from .ops import directional_aggregate
 from .layers import FCLayer, MLP, get_activation
-from .dgn_layer import (AGGREGATORS, SCALERS, DGNLayer, DGNLayerComplex, DGNLayerSimple, DGNLayerTower, DGNTower, EdgeTypeFeatures, reset_dropout_state)
+from .dgn_layer import (AGGREGATORS, SCALERS, DGNLayer, DGNLayerComplex, DGNLayerSimple, DGNLayerTower, DGNTower, EdgeTypeFeatures, get_dropout_state, reset_dropout_state, set_dropout_state)
 from .readout import VirtualNode, max_nodes, mean_nodes, readout, sum_nodes
 from .eig import laplacian_eigvecs
 

@@ -121,6 +121,10 @@ def _dropout(x, p, training):
     if training and p > 0 and x.is_cuda and x.dtype == torch.float32:
         st = _DROP_STATE.get(x.device)
         if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                # (the key would be allocated from the capture's private pool and drawn by a captured randint: every replay the same key)
+                raise RuntimeError("dgn_amd dropout: the first dropout call of a device must run outside a stream capture "
+                                   "(run one warm-up step, or call dgn_amd.dgn_layer.set_dropout_state(device, key, 0) first)")
             st = _DROP_STATE[x.device] = [torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device), 0]
         st[1] += 1
         y = _ops.dropout(x, p, True, seed=st[0], offset=st[1])
@@ -134,8 +138,28 @@ def _dropout(x, p, training):
 
 def reset_dropout_state():
     """Forget the per-device Philox keys (the next dropout draws new ones from torch's generators: call after ``torch.manual_seed``
-    to replay a run's masks)."""
+    to replay a run's masks).  The dropout masks are NOT part of torch's RNG state: ``torch.get_rng_state / set_rng_state`` do not
+    cover them -- a checkpoint that must resume with the same masks saves ``get_dropout_state`` next to them."""
     _DROP_STATE.clear()
+
+
+def get_dropout_state(device=None):
+    """(key, calls so far) of ``device``'s dropout stream as Python ints, or None before its first dropout (one read-back).  With
+    ``set_dropout_state`` this is what a checkpoint stores to resume with the masks the uninterrupted run would have drawn, and what
+    ``torch.utils.checkpoint``-style recomputation restores before re-running a forward (F.dropout replays its mask there by itself)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _DROP_STATE.get(dev)
+    return None if st is None else (int(st[0].item()), int(st[1]))
+
+
+def set_dropout_state(device, key: int, calls: int = 0):
+    """Install a dropout stream: Philox key ``key`` and ``calls`` calls already made (the next mask is number ``calls + 1``)."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    _DROP_STATE[dev] = [torch.tensor([int(key)], dtype=torch.int64, device=dev), int(calls)]
 
 
 class EdgeTypeFeatures:

@@ -158,3 +158,45 @@ def test_captured_dropout_draws_new_masks_per_replay():
     assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
     for m in masks:
         assert abs(float(m.float().mean()) - 0.7) < 0.01
+
+
+def test_dropout_state_get_set_replays_masks():
+    """The dropout stream lives outside torch's RNG state: (key, calls) saved with ``get_dropout_state`` and installed with
+    ``set_dropout_state`` replays the masks from that point on -- what a checkpoint resume or an activation recompute needs."""
+    import dgn_amd
+    from dgn_amd.dgn_layer import _dropout
+    dev = torch.device("cuda")
+    dgn_amd.reset_dropout_state()
+    assert dgn_amd.get_dropout_state(dev) is None
+    x = torch.ones(2048, 64, device=dev)
+    _dropout(x, 0.3, True)
+    key, calls = dgn_amd.get_dropout_state(dev)
+    assert calls == 1
+    a = [_dropout(x, 0.3, True).clone() for _ in range(3)]
+    assert not torch.equal(a[0], a[1])
+    dgn_amd.set_dropout_state(dev, key, calls)
+    b = [_dropout(x, 0.3, True).clone() for _ in range(3)]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert dgn_amd.get_dropout_state(dev) == (key, calls + 3)
+
+
+def test_first_dropout_inside_a_capture_is_refused():
+    import dgn_amd
+    from dgn_amd.dgn_layer import _dropout
+    dev = torch.device("cuda")
+    dgn_amd.reset_dropout_state()
+    x = torch.ones(1024, 64, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    raised = False
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                _dropout(x, 0.3, True)
+        except RuntimeError as exc:
+            raised = "outside a stream capture" in str(exc)
+    torch.cuda.current_stream().wait_stream(s)
+    assert raised
+    dgn_amd.reset_dropout_state()
