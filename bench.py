@@ -805,6 +805,14 @@ def run_inference(args, dev, steps=20, warmup=5):
     return out
 
 
+def _max_graph_edges(b):
+    """Largest number of directed edges of one graph of a synthetic batch (host side: what a data loader knows about its data set)."""
+    import numpy as np
+    cuts = np.concatenate([[0], np.cumsum(np.asarray(b["sizes"], dtype=np.int64))])
+    gid = np.searchsorted(cuts, b["dst"].numpy(), side="right") - 1
+    return int(np.bincount(gid, minlength=len(cuts) - 1).max())
+
+
 def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8, workload="c2_b128"):
     """The reference's operating point -- batches of 128 molecules whose node / edge counts differ from step to step -- on ONE
     captured HIP graph: the batch lives in static buffers at a fixed capacity (hipgraph.PaddedBatch), BatchNorm reads the number of
@@ -821,17 +829,21 @@ def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8, workload="c2_b128
     for b in raw:
         N = int(b["num_nodes"])
         data.append(dict(src=b["src"].to(dev), dst=b["dst"].to(dev), N=N, eig=b["eig"].to(dev), snorm=b["snorm_n"].to(dev),
+                         sizes=[int(x) for x in b["sizes"]], max_edges=_max_graph_edges(b),
                          h=torch.randn(N, F_, device=dev, generator=gen), ct=torch.randn(N, F_, device=dev, generator=gen)))
     torch.manual_seed(0)
     layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(1.0)}, wl["type_net"], True,
                              towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev).train()
     pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=raw[0]["eig"].shape[1])
+    # the static block table (one graph per block, capacity = the data set's largest graph): the captured step runs the graph-block route
+    pb.graph.set_block_capacity(max(len(d["sizes"]) for d in data), max(max(d["sizes"]) for d in data), max(d["max_edges"] for d in data))
     h_buf, sn_buf, ct_buf = pb.add_node_tensor("h", F_, requires_grad=True), pb.add_node_tensor("snorm", 1), pb.add_node_tensor("ct", F_)
     params = list(layer.parameters())
 
     def load(i):
         d = data[i % n_batches]
         pb.load(d["src"], d["dst"], d["N"], d["eig"], node=dict(h=d["h"], snorm=d["snorm"], ct=d["ct"]))
+        pb.graph.load_block_sizes(d["sizes"])
 
     def bare_step():
         pb.graph.invalidate_caches()              # edge weights and scaler tables are recomputed inside the captured region
@@ -889,7 +901,7 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
     batches = []
     for b in raw:
         N, E = int(b["num_nodes"]), b["src"].numel()
-        batches.append(dict(src=b["src"].to(dev), dst=b["dst"].to(dev), N=N, eig=b["eig"].to(dev), sizes=[int(x) for x in b["sizes"]],
+        batches.append(dict(src=b["src"].to(dev), dst=b["dst"].to(dev), N=N, eig=b["eig"].to(dev), sizes=[int(x) for x in b["sizes"]], max_edges=_max_graph_edges(b),
                             atoms=torch.randint(0, 28, (N,), generator=gen).to(dev), bonds=torch.randint(0, 4, (E,), generator=gen).to(dev),
                             snorm=b["snorm_n"].to(dev), y=torch.randn(len(b["sizes"]), 1, generator=gen).to(dev)))
 
@@ -918,7 +930,8 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
         try:
             from dgn_amd.hipgraph import CapturedNetStep, bucket_capacity
             n_cap, e_cap = bucket_capacity(max(b["N"] for b in batches), max(b["src"].numel() for b in batches))
-            cs = CapturedNetStep(net, n_cap, e_cap, g_cap=n_graphs + 1, eig_dim=batches[0]["eig"].shape[1], lr=1e-3)
+            cs = CapturedNetStep(net, n_cap, e_cap, g_cap=n_graphs + 1, eig_dim=batches[0]["eig"].shape[1], lr=1e-3,
+                                 max_graph_nodes=max(max(b["sizes"]) for b in batches), max_graph_edges=max(b["max_edges"] for b in batches))
             load = lambda b: cs.load(b["src"], b["dst"], b["N"], b["eig"], b["atoms"], b["snorm"], b["sizes"], b["y"])
             load(batches[0])
             cs.capture(warmup=3)

@@ -233,7 +233,7 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     p.save_mean = L->save_mean; p.save_invstd = L->save_invstd; p.running_mean = L->running_mean; p.running_var = L->running_var;
     p.nbt = L->num_batches_tracked; p.n_nbt = L->num_batches_tracked ? L->n_nbt : 0;
     p.momentum = L->momentum; p.bn_eps = L->eps;
-    p.N = d.N; p.tail_rows = d.tail_rows; p.n_tail = d.n_tail;
+    p.N = d.N; p.n_valid = L->n_valid; p.overflow = L->overflow; p.tail_rows = d.tail_rows; p.n_tail = d.n_tail;
     p.n_blk_param = d.n_blk_param; p.off_tower = d.off_tower;
     p.R = d.R; p.Emax = d.Emax;
     int rc = 0;

@@ -67,6 +67,8 @@ struct P {
     float* save_mean; float* save_invstd; float* running_mean; float* running_var; int64_t* nbt; int32_t n_nbt;
     float momentum, bn_eps;
     int64_t N;
+    const int64_t* n_valid;      // DEVICE: rows of the batch inside a buffer of N rows (padded batches, hipgraph.PaddedBatch); NULL: N
+    int32_t* overflow;           // DEVICE, may be NULL: set to 1 by a block larger than the LDS plan (padded batches: the table changes per batch)
     // tail
     int32_t tail_rows;           // rows per workgroup of the tail kernels
     int32_t n_tail;
@@ -86,6 +88,20 @@ struct P {
 
 // profiling: wall-clock stamp i of this workgroup (p.dbg_time == NULL: nothing)
 #define BLK_STAMP(i) do { if (p.dbg_time && threadIdx.x == 0) p.dbg_time[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = (int64_t)wall_clock64(); } while (0)
+
+// rows of the batch (padded batches: a device scalar)
+__device__ __forceinline__ int64_t valid_rows(const P& p) { return p.n_valid ? min(*p.n_valid, p.N) : p.N; }
+// a block's descriptor: first row, end row, first slot, end slot (negative slots: taken from the row pointers -- padded batches, whose
+// table is written by the host from the graph sizes alone); an EMPTY or over-sized block is skipped by its workgroups
+__device__ __forceinline__ int4 block_desc(const P& p) {
+    int4 d = reinterpret_cast<const int4*>(p.desc)[blockIdx.x];
+    if (d.z < 0 && d.y > d.x) { d.z = p.indptr[d.x]; d.w = p.indptr[d.y]; }
+    if (d.y - d.x > p.R || d.w - d.z > p.Emax) {
+        if (p.overflow && threadIdx.x == 0) *p.overflow = 1;
+        d.y = d.x;
+    }
+    return d;
+}
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -319,9 +335,8 @@ __device__ __forceinline__ float weight_from_stats(int kind, float alpha, float 
 // descriptor -> every operand of the (block, tower) in LDS: h rows, CSR rows re-based on the block, eig columns, scaler factors / graph
 // norm, biases, (backward) the transposed view; then the edge weights (aggregators.py:36-69) and P | Q.  Ends on a barrier.
 template <bool HAS_PRE>
-__device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, bool bwd) {
+__device__ __forceinline__ void block_prologue(const P& p, Ctx& c, float* lds, bool bwd, const int4 d) {
     const int tid = threadIdx.x, NT = blockDim.x;
-    const int4 d = reinterpret_cast<const int4*>(p.desc)[blockIdx.x];
     c.lo = d.x; c.e0 = d.z; c.R = d.y - d.x; c.Eb = d.w - d.z; c.t = blockIdx.y;
     const Layout& L = p.L;
     c.HB = lds + L.hb; c.PQ = lds + L.pq; c.EIG = lds + L.eig; c.W = lds + L.w; c.FAC = lds + L.fac; c.XP = lds + L.xp;
@@ -478,7 +493,15 @@ __global__ __launch_bounds__(512) void blk_forward(const P p) {
     extern __shared__ float lds[];
     Ctx c;
     BLK_STAMP(0);
-    block_prologue<HAS_PRE>(p, c, lds, false);
+    const int4 desc = block_desc(p);
+    if (desc.y <= desc.x) {      // (an unused entry of a padded batch's table: zero BatchNorm partials)
+        if ((int)threadIdx.x < p.fo) {
+            p.bn_part[((int64_t)blockIdx.x * 2 + 0) * p.Fo + blockIdx.y * p.fo + threadIdx.x] = 0.0;
+            p.bn_part[((int64_t)blockIdx.x * 2 + 1) * p.Fo + blockIdx.y * p.fo + threadIdx.x] = 0.0;
+        }
+        return;
+    }
+    block_prologue<HAS_PRE>(p, c, lds, false, desc);
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = uniform_i(tid >> 6), nw = NT >> 6, i16 = lane & 15, g = lane >> 4;
     const int R = c.R, fi = p.fi, fo = p.fo, RC = p.RC, ldh = p.L.ldh, ldy = p.L.ldy, kp = p.L.kp;
     const float* wpost = p.w_post[c.t];
@@ -638,9 +661,14 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
     float* WM = Y1 + RW * ldk;
     const int n_wm = p.mixing ? Fo * ldk : 0;
     double* RED = reinterpret_cast<double*>(lds + ((c4 + RW * ldk + n_wm + 1) & ~1));
-    const int64_t m0 = (int64_t)blockIdx.x * RW;
-    const int rows = (int)min((int64_t)RW, p.N - m0);
+    const int64_t m0 = (int64_t)blockIdx.x * RW, Nv = valid_rows(p);
+    const int rows = (int)max((int64_t)0, min((int64_t)RW, Nv - m0)), rows_buf = (int)min((int64_t)RW, p.N - m0);
     const RowStep st_ = rf_stride(NT, Fo);
+    if (rows < rows_buf) {      // padding rows of the buffer: zeros (their readers -- the readout's padding row -- must see finite values)
+        RowFeat x = rf_at(tid, Fo);
+        for (; x.r < rows_buf; rf_step(x, st_, Fo)) if (x.r >= rows) p.out[(m0 + x.r) * Fo + x.f] = 0.f;
+    }
+    if (rows == 0 && blockIdx.x != 0) return;
     {   // this workgroup's rows and the mixing weight are requested before the statistics are summed
         RowFeat x = rf_at(tid, Fo);
         for (; x.r < RW; rf_step(x, st_, Fo)) Y1[x.r * ldk + x.f] = x.r < rows ? p.y0[(m0 + x.r) * Fo + x.f] : 0.f;
@@ -651,7 +679,7 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
     }
     column_sums(p.bn_part, p.n_blocks, Fo, RED);
     if (tid < Fo) {
-        const double n = (double)p.N;
+        const double n = (double)Nv;
         const double mu = RED[tid] / n;
         double m2 = RED[Fo + tid] - mu * RED[tid];
         if (m2 < 0.0) m2 = 0.0;
@@ -660,7 +688,7 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
         GAM[tid] = col_param(p.gamma, tid, p.fo, p.T); BET[tid] = col_param(p.beta, tid, p.fo, p.T);
         if (blockIdx.x == 0) {
             p.save_mean[tid] = mean; p.save_invstd[tid] = invstd;
-            const float unbiased = (float)(p.N > 1 ? m2 / (n - 1.0) : m2 / n);
+            const float unbiased = (float)(Nv > 1 ? m2 / (n - 1.0) : m2 / n);
             p.running_mean[tid] = (1.f - p.momentum) * p.running_mean[tid] + p.momentum * mean;
             p.running_var[tid] = (1.f - p.momentum) * p.running_var[tid] + p.momentum * unbiased;
             if (tid < p.n_nbt) p.nbt[tid] += 1;
@@ -712,9 +740,14 @@ __global__ __launch_bounds__(512) void blk_tail_bwd(const P p) {
     const int Fo = p.Fo, RW = p.tail_rows, ldk = (Fo + 3) & ~3, c4 = (4 * Fo + 3) & ~3;
     float* MEAN = lds; float* INVSTD = lds + Fo; float* GAM = lds + 2 * Fo; float* BET = lds + 3 * Fo;
     float* XH = lds + c4; float* Y1 = XH + RW * ldk; float* GZ = Y1 + RW * ldk; float* GY1 = GZ + RW * ldk; float* WM = GY1 + RW * ldk;
-    const int64_t m0 = (int64_t)blockIdx.x * RW;
-    const int rows = (int)min((int64_t)RW, p.N - m0);
+    const int64_t m0 = (int64_t)blockIdx.x * RW, Nv = valid_rows(p);
+    const int rows = (int)max((int64_t)0, min((int64_t)RW, Nv - m0)), rows_buf = (int)min((int64_t)RW, p.N - m0);
     const RowStep st_ = rf_stride(NT, Fo);
+    if (rows < rows_buf) {      // padding rows: d h = 0 (no block owns them; their cotangent reaches the embedding's gradient otherwise)
+        RowFeat x = rf_at(tid, p.F);
+        const RowStep sf = rf_stride(NT, p.F);
+        for (; x.r < rows_buf; rf_step(x, sf, p.F)) if (x.r >= rows) p.g_h[(m0 + x.r) * p.F + x.f] = 0.f;
+    }
     if (tid < Fo) {
         MEAN[tid] = p.save_mean[tid]; INVSTD[tid] = p.save_invstd[tid];
         GAM[tid] = col_param(p.gamma, tid, p.fo, p.T); BET[tid] = col_param(p.beta, tid, p.fo, p.T);
@@ -940,17 +973,23 @@ __global__ __launch_bounds__(1024) void blk_backward(const P p) {
     const int t = blockIdx.y, yc0 = t * fo;
     Ctx c;
     BLK_STAMP(0);
+    const int4 desc = block_desc(p);
+    if (desc.y <= desc.x) {      // (an unused entry of a padded batch's table: a zero parameter-gradient partial)
+        float* bpart0 = p.blk_part + (int64_t)blockIdx.x * p.n_blk_param + t * p.off_tower;
+        for (int i = tid; i < p.off_tower; i += NT) bpart0[i] = 0.f;
+        return;
+    }
     {   // BatchNorm's column sums of this tower's columns (= d beta, d gamma) from the tail's partials
         double* RED = reinterpret_cast<double*>(lds + p.L.red);
         column_sums_cols(p.tail_part, p.n_tail, p.Fo, yc0, fo, RED);
         if (blockIdx.x == 0 && tid < fo) { p.g_beta[yc0 + tid] = (float)RED[tid]; p.g_gamma[yc0 + tid] = (float)RED[fo + tid]; }
     }
-    block_prologue<HAS_PRE>(p, c, lds, true);
+    block_prologue<HAS_PRE>(p, c, lds, true, desc);
     const int R = c.R;
     // BatchNorm constants of the tower's columns: [mean | invstd | gamma | beta | sum g / N | sum g xhat / N]
     float* BN = c.VEC + fi + fo;
     if (tid < fo) {
-        const float inv_n = 1.f / (float)p.N;
+        const float inv_n = 1.f / (float)valid_rows(p);
         BN[tid] = p.save_mean[yc0 + tid]; BN[fo + tid] = p.save_invstd[yc0 + tid];
         BN[2 * fo + tid] = p.gamma[t][tid]; BN[3 * fo + tid] = p.beta[t][tid];
         BN[4 * fo + tid] = (float)c.RED[tid] * inv_n; BN[5 * fo + tid] = (float)c.RED[fo + tid] * inv_n;

@@ -315,9 +315,10 @@ def _posttrans_split(posttrans: MLP, h, agg, in_dim):
 
 
 def _block_route_ok(layer, h) -> bool:
-    """Conditions every layer type shares for the graph-block route: a training step with BatchNorm on CUDA fp32 rows, no padded batch."""
+    """Conditions every layer type shares for the graph-block route: a training step with BatchNorm on CUDA fp32 rows (a padded batch
+    takes it when its graph carries a static block table: DGNGraph.set_block_capacity)."""
     return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training and torch.is_grad_enabled() and layer.batch_norm and h.is_cuda
-            and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES and _ops._N_VALID is None
+            and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES
             and all(bn.momentum is not None and bn.track_running_stats and bn.affine for bn in _bns_of(layer)))
 
 

@@ -120,7 +120,7 @@ class DGNGraph:
         pad = self._pad
         # The previous batch's deferred statistics are looked at BEFORE anything is overwritten: an error then leaves the object in the
         # (complete) state of the batch it is about, not half-way into the next one.  Callers run check_deferred() after the LAST batch.
-        self.check_deferred()
+        self.check_deferred(final=False)
         E, N = src.numel(), int(num_nodes)
         if N > pad["n_cap"] or E > pad["e_cap"]:
             raise ValueError(f"batch ({N} nodes, {E} edges) exceeds the capacity ({pad['n_cap']}, {pad['e_cap']})")
@@ -162,8 +162,18 @@ class DGNGraph:
         self.batch_nodes, self.batch_edges = N, E
         self.invalidate_caches()
 
-    def check_deferred(self) -> None:
-        """Look at the statistics of the batch loaded last (``rebuild`` without a host sync): raises if it had hub rows."""
+    def check_deferred(self, final: bool = True) -> None:
+        """Look at the statistics of the batch loaded last (``rebuild`` without a host sync): raises if it had hub rows, or if a step on
+        a static block table met a graph beyond its capacity.  ``final`` (the explicit call after the last batch): the block-overflow
+        flag is fetched as every step so far left it (one host sync); ``rebuild`` only looks at the copy made one load earlier."""
+        if self.__dict__.get("_blk_static") is not None:
+            ent = self._blk_static
+            self._check_block_overflow(ent)
+            if final:
+                ent["overflow_host"].copy_(ent["overflow"], non_blocking=True)
+                ent["overflow_event"].record(torch.cuda.current_stream(self.device))
+                ent["overflow_pending"] = True
+                self._check_block_overflow(ent)
         if not getattr(self, "_stats_pending", False):
             return
         self._stats_event.synchronize()
@@ -339,6 +349,9 @@ class DGNGraph:
         N / 512 rows -- at the reference's batch of 128 graphs one graph per workgroup.  Built once per batch: a few small kernels and two
         read-backs (cuts, row pointers), on the loader's side of the step like the CSR itself.  Cached; the dict also carries
         ``max_rows`` / ``max_edges`` (what decides whether a block fits the LDS)."""
+        if getattr(self, "_pad", None) is not None:
+            # a padded graph: the static table (set_block_capacity + load_block_sizes per batch), or none
+            return self.__dict__.get("_blk_static") if target_rows is None else None
         tables = self.__dict__.setdefault("_blk_tables", {})
         ent = tables.get(target_rows)
         if ent is not None:
@@ -377,6 +390,57 @@ class DGNGraph:
         ent = dict(struct=st, desc=t, n_blocks=st.n_blocks, max_rows=st.max_rows, max_edges=st.max_edges)
         tables[target_rows] = ent
         return ent
+
+    def set_block_capacity(self, g_cap: int, max_rows: int, max_edges: int) -> None:
+        """Padded graphs: a STATIC block table of ``g_cap`` entries -- one graph of the batch per block -- so that a step captured on this
+        object runs its layers on the graph-block route (csrc/dgn_blk_layer.hip) for every batch that fits.  ``max_rows`` / ``max_edges``:
+        the largest graph (nodes, directed edges) any batch will hold: the kernels' LDS plan is made for them once.  ``load_block_sizes``
+        writes a batch's table; a graph beyond the capacity is skipped by the kernels and reported by ``check_deferred`` (late, like the
+        hub statistics: no host sync per load)."""
+        if getattr(self, "_pad", None) is None:
+            raise ValueError("set_block_capacity is for padded graphs (DGNGraph.padded); others build their table from the batch")
+        dev, g_cap = self.device, int(g_cap)
+        desc = torch.zeros(g_cap, 4, dtype=torch.int32, device=dev)
+        st = _lib.DgnBlockTable(n_blocks=g_cap, max_rows=int(max_rows), max_edges=int(max_edges), desc=desc.data_ptr())
+        self._blk_static = dict(struct=st, desc=desc, n_blocks=g_cap, max_rows=int(max_rows), max_edges=int(max_edges),
+                                host=torch.zeros(g_cap, 4, dtype=torch.int32).pin_memory(), copied=torch.cuda.Event(),
+                                overflow=torch.zeros(1, dtype=torch.int32, device=dev), overflow_host=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                                overflow_event=torch.cuda.Event(), overflow_pending=False)
+
+    def load_block_sizes(self, sizes) -> None:
+        """The node counts of the loaded batch's graphs (host list / tensor, in batch order) -> the static block table: rows from the
+        sizes, slots left to the kernels (they read the row pointers).  One pinned-memory copy, no host sync."""
+        ent = self.__dict__.get("_blk_static")
+        if ent is None:
+            raise ValueError("load_block_sizes: call set_block_capacity first")
+        import numpy as np
+        sz = np.asarray(torch.as_tensor(sizes).cpu().numpy() if not isinstance(sizes, np.ndarray) else sizes, dtype=np.int64).reshape(-1)
+        G = int(sz.size)
+        if G > ent["n_blocks"]:
+            raise ValueError(f"{G} graphs exceed the block table's capacity ({ent['n_blocks']})")
+        if G and int(sz.max()) > ent["max_rows"]:
+            raise ValueError(f"a graph of {int(sz.max())} nodes exceeds the block capacity ({ent['max_rows']} rows)")
+        self._check_block_overflow(ent)
+        ent["copied"].synchronize()                       # (the previous batch's copy has left the pinned buffer long ago)
+        host = ent["host"].numpy()
+        host[:] = 0
+        cuts = np.concatenate([[0], np.cumsum(sz)])
+        host[:G, 0], host[:G, 1], host[:G, 2:] = cuts[:-1], cuts[1:], -1
+        ent["desc"].copy_(ent["host"], non_blocking=True)
+        ent["copied"].record(torch.cuda.current_stream(self.device))
+        # the overflow flag as the steps on the PREVIOUS batch left it travels to the host now and is looked at one load later
+        ent["overflow_host"].copy_(ent["overflow"], non_blocking=True)
+        ent["overflow_event"].record(torch.cuda.current_stream(self.device))
+        ent["overflow_pending"] = True
+
+    def _check_block_overflow(self, ent) -> None:
+        if ent.get("overflow_pending"):
+            ent["overflow_event"].synchronize()
+            ent["overflow_pending"] = False
+            if int(ent["overflow_host"][0]):
+                ent["overflow"].zero_()
+                raise _lib.DgnError(f"a batch held a graph beyond the block capacity ({ent['max_rows']} rows / {ent['max_edges']} edges): its rows "
+                                    "were skipped by the graph-block layer kernels (set_block_capacity with larger bounds)")
 
     # ---- block description for the LDS-accumulating backward (csrc/dgn_agg_block.hpp) -----------------------------------------------
     def ensure_blocks(self, enabled: bool = True) -> bool:

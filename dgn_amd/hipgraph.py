@@ -129,7 +129,11 @@ class CapturedNetStep:
     passed in, the net's Parameter objects are re-created on construction (``rewrap_parameters``: eager
     training steps on the default stream before a capture are otherwise fatal) and a capturable Adam is built on the new ones."""
 
-    def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None):
+    def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None,
+                 max_graph_nodes: Optional[int] = None, max_graph_edges: Optional[int] = None):
+        """``max_graph_nodes`` / ``max_graph_edges``: the largest graph (nodes, directed edges) of the dataset.  Given both, the padded graph
+        gets a static block table (``DGNGraph.set_block_capacity``) and the captured step runs its layers on the graph-block route -- five
+        launches per layer and step instead of ~28."""
         from .graph import DGNGraph
         dev = torch.device(device if device is not None else next(net.parameters()).device)
         if getattr(net, "edge_feat", False):
@@ -137,6 +141,8 @@ class CapturedNetStep:
                              "buffer); run them eagerly or build the net with edge_feat=False")
         self.net, self.device, self.g_cap = net, dev, int(g_cap)
         self.pb = PaddedBatch(n_cap, e_cap, dev, eig_dim)
+        if max_graph_nodes and max_graph_edges:
+            self.pb.graph.set_block_capacity(g_cap, max_graph_nodes, max_graph_edges)
         self.atoms = torch.zeros(n_cap, dtype=torch.int64, device=dev)
         self.snorm = self.pb.add_node_tensor("snorm", 1)
         self.targets = torch.zeros(g_cap, 1, device=dev)
@@ -181,6 +187,8 @@ class CapturedNetStep:
         if n_cap - int(num_nodes) > 2048:
             raise ValueError("more than 2048 padding nodes: pick a smaller capacity bucket (the padding row must not be a hub row)")
         self.pb.load(src, dst, num_nodes, eig, node={"snorm": snorm})
+        if self.pb.graph.__dict__.get("_blk_static") is not None:
+            self.pb.graph.load_block_sizes(sizes)
         self.atoms[:num_nodes].copy_(atoms, non_blocking=True)
         self.atoms[num_nodes:].zero_()
         # graph sizes -> the readout CSR, on the device: ONE copy from a pinned staging buffer (a pageable host tensor copied

@@ -1353,7 +1353,13 @@ def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, 
     L.running_mean, L.running_var = _ptr(rm), _ptr(rv)
     if nbt is not None:
         L.num_batches_tracked, L.n_nbt = nbt.data_ptr(), nbt.numel()
-    return L, (cg, tb, spec, chans, cols)
+    # padded batches (hipgraph.PaddedBatch): the valid-row count the layer announced, the static table's overflow flag
+    n_valid = _N_VALID
+    if n_valid is not None:
+        L.n_valid = n_valid.data_ptr()
+    if table.get("overflow") is not None:
+        L.overflow = table["overflow"].data_ptr()
+    return L, (cg, tb, spec, chans, cols, n_valid)
 
 
 def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:

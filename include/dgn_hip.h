@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 23
+#define DGN_ABI_VERSION 24
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -688,6 +688,12 @@ typedef struct DgnBlockLayer {
     float* y0; float* save_mean; float* save_invstd;      /* [N, T f_out], [T f_out] x 2: written by the forward, read by the backward */
     float* out;                  /* [N, T f_out] (forward)                                                                    */
     void* ws; size_t ws_bytes;   /* dgn_block_layer_{forward,backward}_workspace_bytes()                                      */
+    /* Padded batches (a captured step replayed over batches of different sizes: the buffers hold N = graph->n_nodes rows of which the
+     * first *n_valid are the batch): n_valid = DEVICE int64 scalar, NULL = every row is real.  BatchNorm counts *n_valid rows; out and
+     * g_h rows from *n_valid on are written as zeros.  The block table then changes per batch inside static buffers: entries with
+     * first row == end row are unused, negative slot fields are read from graph->indptr, and blocks->max_rows / max_edges are the
+     * CAPACITY the LDS plan is made for -- a block beyond it is skipped and *overflow (DEVICE int32, may be NULL) set to 1.          */
+    const int64_t* n_valid; int32_t* overflow;
     float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
     int64_t* dbg_time;           /* profiling only: [n_blocks][16] wall-clock stamps (100 MHz) of the block kernel's phases; NULL      */
 } DgnBlockLayer;

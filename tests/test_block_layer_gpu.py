@@ -246,3 +246,79 @@ def test_route_left_outside_its_domain(monkeypatch):
                           edge_dim=6).model.to(dev).train()
     le(graph, h, torch.randn(graph.num_edges, 6, device=dev), snorm)
     assert len(taken) == 1
+
+
+@pytest.mark.parametrize("type_net", ["towers", "complex"])
+def test_padded_batch_through_the_static_block_table(monkeypatch, type_net):
+    """A batch inside capacity-padded static buffers (hipgraph.PaddedBatch: what a captured step replays over) on the route: the table
+    is written from the graph sizes alone (slots from the row pointers, unused entries, BatchNorm over n_valid rows); valid rows and
+    every gradient equal the unpadded batch's, padding rows of the output and of d h are zeros, the running statistics agree."""
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.hipgraph import PaddedBatch
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(40, seed=17, extra_bonds=3.9, eig_dim=6)
+    N, E, sizes = int(b["num_nodes"]), b["src"].numel(), [int(s) for s in b["sizes"]]
+    F_ = 70 if type_net == "towers" else 45
+    aggs = "mean max min dir1-av dir1-dx" if type_net == "towers" else "mean dir1-dx dir1-av"
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer(type_net, F_, aggs, "identity amplification attenuation", True, avg, o1_weights=type_net != "towers")
+    layer = layer.to(dev).train()
+    layer_p = copy.deepcopy(layer)
+    h, ct = torch.randn(N, F_, generator=gen), torch.randn(N, F_, generator=gen)
+    taken = _count_route(monkeypatch)
+    # unpadded
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    y = layer(graph, hd, None, b["snorm_n"].to(dev))
+    y.backward(ct.to(dev))
+    assert len(taken) == 1
+    # padded
+    n_cap, e_cap, g_cap = N + 75, E + 120, 48
+    pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=6)
+    pb.graph.set_block_capacity(g_cap, max(sizes), 4 * max(sizes))
+    snorm = pb.add_node_tensor("snorm", 1)
+    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), node={"snorm": b["snorm_n"].to(dev)})
+    pb.graph.load_block_sizes(sizes)
+    hp = torch.zeros(n_cap, F_, device=dev)
+    hp[:N] = h.to(dev)
+    hp.requires_grad_(True)
+    ctp = torch.full((n_cap, F_), float("nan"), device=dev)     # (the padding rows' cotangent must never be read)
+    ctp[:N] = ct.to(dev)
+    yp = layer_p(pb.graph, hp, None, snorm)
+    yp.backward(ctp)
+    assert len(taken) == 2, "the padded batch left the route"
+    pb.graph.check_deferred()
+    assert torch.equal(yp.detach()[:N], y.detach()) and float(yp.detach()[N:].abs().max()) == 0.0
+    assert torch.equal(hp.grad[:N], hd.grad) and float(hp.grad[N:].abs().max()) == 0.0
+    for (k, a), (_, c) in zip(layer_p.named_parameters(), layer.named_parameters()):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), c.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * max(1.0, float(c.grad.abs().max())), err_msg=k)
+    for (k, a), (_, c) in zip(layer_p.state_dict().items(), layer.state_dict().items()):
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(a, c), k
+
+
+def test_padded_batch_beyond_the_block_capacity_is_reported(monkeypatch):
+    """A graph larger than the static table's capacity: too many rows are refused when the table is loaded (host side: the sizes are
+    known), too many edges are skipped by the kernels and reported by check_deferred."""
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    from dgn_amd.hipgraph import PaddedBatch
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(20, seed=3, extra_bonds=3.9, eig_dim=6)
+    N, E, sizes = int(b["num_nodes"]), b["src"].numel(), [int(s) for s in b["sizes"]]
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer("simple", 32, "mean dir1-dx", "identity", True, avg)
+    layer = layer.to(dev).train()
+    pb = PaddedBatch(N + 10, E + 10, dev, eig_dim=6)
+    pb.graph.set_block_capacity(24, max(sizes) - 1, 4 * max(sizes))
+    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev))
+    with pytest.raises(ValueError):
+        pb.graph.load_block_sizes(sizes)
+    pb.graph.set_block_capacity(24, max(sizes), 8)                 # (every molecule has more than 8 directed edges)
+    pb.graph.load_block_sizes(sizes)
+    snorm = torch.ones(N + 10, 1, device=dev)
+    layer(pb.graph, torch.randn(N + 10, 32, device=dev, requires_grad=True), None, snorm).sum().backward()
+    with pytest.raises(_lib.DgnError):
+        pb.graph.check_deferred()

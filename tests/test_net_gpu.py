@@ -62,12 +62,19 @@ def test_mlp_readout_keys_and_shapes():
 
 
 @gpu
-def test_captured_net_step_equals_eager_training():
+@pytest.mark.parametrize("block_route", [False, True])
+def test_captured_net_step_equals_eager_training(monkeypatch, block_route):
     """hipgraph.CapturedNetStep (whole training step of the net -- forward, masked L1 loss, backward, Adam -- as ONE HIP graph over
     capacity-padded static buffers) against eager training on the unpadded batches: per-step losses and the parameters after
-    several batches of different sizes."""
+    several batches of different sizes.  ``block_route``: both sides on the graph-block layer route (the captured side through the
+    padded graph's STATIC block table: unused entries, slots from the row pointers, BatchNorm over ``n_valid`` rows, zero padding rows)."""
     import copy
     import dgn_amd
+    taken = []
+    if block_route:
+        monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 32768)
+        real = dgn_amd.ops.block_layer
+        monkeypatch.setattr(dgn_amd.ops, "block_layer", lambda *a, **k: taken.append(a[0]) or real(*a, **k))
     from dgn_amd import synth
     from dgn_amd.hipgraph import CapturedNetStep
     from dgn_amd.nets import DGNNet
@@ -117,7 +124,8 @@ def test_captured_net_step_equals_eager_training():
     e_cap = max(b["src"].numel() for b in batches) + 64
     from dgn_amd.hipgraph import rewrap_parameters
     rewrap_parameters(net_c)
-    cs = CapturedNetStep(net_c, n_cap, e_cap, g_cap=40, eig_dim=batches[0]["eig"].shape[1], optimizer=torch.optim.SGD(net_c.parameters(), lr=1e-2))
+    caps = dict(max_graph_nodes=max(max(b["sizes"]) for b in batches), max_graph_edges=4 * max(max(b["sizes"]) for b in batches)) if block_route else {}
+    cs = CapturedNetStep(net_c, n_cap, e_cap, g_cap=40, eig_dim=batches[0]["eig"].shape[1], optimizer=torch.optim.SGD(net_c.parameters(), lr=1e-2), **caps)
     load = lambda b: cs.load(b["src"], b["dst"], b["N"], b["eig"], b["atoms"], b["snorm"], b["sizes"], b["y"])
     load(batches[0])
     cs.capture(warmup=2)                                          # two real steps on batch 0, then the capture (not executed)
@@ -126,6 +134,10 @@ def test_captured_net_step_equals_eager_training():
         load(batches[i])
         losses_c.append(float(cs.step()))
     np.testing.assert_allclose(losses_c, losses_e[2:], rtol=2e-4, atol=1e-5)
+    if block_route:
+        assert any(getattr(g, "_pad", None) is not None for g in taken), "the captured step did not take the graph-block route"
+        assert any(getattr(g, "_pad", None) is None for g in taken), "the eager steps did not take the graph-block route"
+        cs.pb.graph.check_deferred()                              # (no block beyond the capacity)
     for (k, a), (_, b) in zip(net_c.named_parameters(), net_e.named_parameters()):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
     for (k, a), (_, b) in zip(net_c.state_dict().items(), net_e.state_dict().items()):
