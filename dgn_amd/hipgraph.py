@@ -120,14 +120,16 @@ class CapturedNetStep:
     At the reference's batch size (128 molecules) the eager step is host-bound (~5 ms for ~1 ms of GPU work: per-parameter autograd and
     optimizer bookkeeping for the ~120 per-tower tensors of the reference's ``state_dict`` layout); the replay is GPU-bound.
 
-    Padding: node rows beyond the batch are isolated (``PaddedBatch``); graph rows beyond the batch are empty, and ALL padding nodes
-    belong to the last graph row, whose loss term is masked -- every slot of the readout CSR stays referenced, so its backward defines
+    Padding: node rows beyond the batch are isolated (``PaddedBatch``); graph rows beyond the batch are empty, and the padding nodes
+    are shared out among the last PAD_ROWS graph rows, whose loss terms are masked -- every slot of the readout CSR stays referenced, so its backward defines
     (zero) gradients for the padding rows.  The loss is the mean absolute error over the real graphs (``nets.DGNNet.loss``).
 
     An ``optimizer`` passed in must be capturable (``capturable=True`` for Adam-type optimizers; plain SGD is) and must have been built
     on parameters that never took part in a default-stream autograd pass (``rewrap_parameters`` first).  Unless an ``optimizer`` is
     passed in, the net's Parameter objects are re-created on construction (``rewrap_parameters``: eager
     training steps on the default stream before a capture are otherwise fatal) and a capturable Adam is built on the new ones."""
+
+    PAD_ROWS = 16      # readout rows behind the real graphs that share the padding nodes
 
     def __init__(self, net, n_cap: int, e_cap: int, g_cap: int, eig_dim: int, lr: float = 1e-3, optimizer=None, device=None,
                  max_graph_nodes: Optional[int] = None, max_graph_edges: Optional[int] = None):
@@ -139,7 +141,11 @@ class CapturedNetStep:
         if getattr(net, "edge_feat", False):
             raise ValueError("CapturedNetStep: nets with edge_feat=True are not supported (the captured step has no static bond-type "
                              "buffer); run them eagerly or build the net with edge_feat=False")
-        self.net, self.device, self.g_cap = net, dev, int(g_cap)
+        # graph rows of the readout: g_cap - 1 real graphs at most, then PAD_ROWS rows that share the padding nodes (ONE padding row was a
+        # single wave walking ~10 % of the batch's nodes in sequence: 40 us per direction of a 0.77 ms step)
+        self.g_cap = int(g_cap)
+        self.net, self.device = net, dev
+        g_cap = self.g_rows = self.g_cap - 1 + self.PAD_ROWS
         self.pb = PaddedBatch(n_cap, e_cap, dev, eig_dim)
         if max_graph_nodes and max_graph_edges:
             self.pb.graph.set_block_capacity(g_cap, max_graph_nodes, max_graph_edges)
@@ -179,13 +185,14 @@ class CapturedNetStep:
     @torch.no_grad()
     def load(self, src, dst, num_nodes: int, eig, atoms, snorm, sizes, targets) -> None:
         """sizes: nodes per graph (host list or tensor), targets [n_graphs, 1]."""
-        n_cap, g_cap, dev = self.pb.n_cap, self.g_cap, self.device
+        n_cap, g_cap, dev = self.pb.n_cap, self.g_rows, self.device
         sizes = torch.as_tensor(sizes, dtype=torch.int64)
         G = sizes.numel()
-        if G >= g_cap:
-            raise ValueError(f"{G} graphs need a capacity of at least {G + 1} graph rows (the last row collects the padding)")
-        if n_cap - int(num_nodes) > 2048:
-            raise ValueError("more than 2048 padding nodes: pick a smaller capacity bucket (the padding row must not be a hub row)")
+        if G >= self.g_cap:
+            raise ValueError(f"{G} graphs need a capacity of at least {G + 1} graph rows (rows behind the batch collect the padding)")
+        pad, R = n_cap - int(num_nodes), self.PAD_ROWS
+        if pad > 2048 * R:
+            raise ValueError(f"more than {2048 * R} padding nodes: pick a smaller capacity bucket (a padding row must not be a hub row)")
         self.pb.load(src, dst, num_nodes, eig, node={"snorm": snorm})
         if self.pb.graph.__dict__.get("_blk_static") is not None:
             self.pb.graph.load_block_sizes(sizes)
@@ -196,7 +203,8 @@ class CapturedNetStep:
         h = self._h_sizes
         h.zero_()
         h[:G] = sizes
-        h[g_cap - 1] = n_cap - int(num_nodes)                    # the padding row
+        h[g_cap - R:] = pad // R                                  # the padding rows
+        h[g_cap - R:g_cap - R + pad % R] += 1
         self._d_sizes.copy_(h, non_blocking=True)
         rg = self.rg
         rg.indptr[1:].copy_(torch.cumsum(self._d_sizes, 0))
