@@ -110,6 +110,10 @@ WORKLOADS = {
     "zinc_json_b128": dict(desc="the same ZINC json layer at the json's batch size (128 molecules)",
                            gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=45,
                            aggregators="mean dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
+    "hiv_json_b128": dict(desc="configs/molecules_graph_classification_DGN_HIV.json as shipped: simple, hidden 70, mean max min dir1-dx dir1-av x 3 scalers, "
+                               "dropout 0.3, batch 128 (graph-block route + bit-mask dropout)",
+                          gen=("molecules", dict(n_graphs=128, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple", hidden=70,
+                          aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1, graph_norm=False, dropout=0.3),
     "pattern_json": dict(desc="configs/SBMs_node_clustering_DGN_PATTERN.json as shipped: complex, hidden 47, mean dir1-dx dir2-dx x 3 scalers, "
                               "batch 128 of SBM graphs (~119 nodes, ~6.1 k directed edges each)",
                          gen=("sbm", dict(n_graphs=128)), type_net="complex", hidden=47,
@@ -995,7 +999,7 @@ def run_extras(args, dev):
     plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1)]
     if args.all_extras:
         plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
-                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30),
+                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30),
                 ("c5", 3, 1), ("c5_layer", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
@@ -1006,7 +1010,7 @@ def run_extras(args, dev):
             extra[name] = compact(res)
             extra[name]["config"] = wl["desc"]
             extra[name]["steps"], extra[name]["warmup"] = steps, warmup
-            if name in ("c3", "c4", "c2_b128", "zinc_json_b128", "c1_b128") and wl["type_net"] not in ("op", "layer_fwd"):
+            if name in ("c3", "c4", "c2_b128", "zinc_json_b128", "c1_b128", "hiv_json_b128") and wl["type_net"] not in ("op", "layer_fwd"):
                 # batch-128 / batch-2048 legs are host-bound when every kernel is launched from Python (the reference's own regime): the
                 # same step captured once into a HIP graph and replayed is what the GPU side costs
                 import copy

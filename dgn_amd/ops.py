@@ -1322,6 +1322,13 @@ def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm
 # Batches up to this many nodes take the graph-block route where it applies (whole graphs per workgroup, everything out of LDS; the
 # streaming kernels are built for batches that fill the chip).  0 switches the route off.
 BLOCK_LAYER_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_MAX_NODES", "32768"))
+# ... and only layers whose posttrans is small: a (block, tower) workgroup multiplies its rows by the tower's whole [f_out, (f_in +) S A f_in]
+# weight three times per step (forward, input gradient, weight gradient) with the scalers applied on the fly, and a batch of 128 graphs is
+# 128 workgroups per tower.  Measured captured steps at batch 128, block route vs streaming kernels: towers 5 x (224 x 14 = 3.1 k weights)
+# 0.103 vs 0.174 ms, ZINC json complex 45 (450 x 45 = 20 k) 0.100 vs 0.150, simple 75 (450 x 75 = 34 k) 0.115 vs 0.119, HIV json simple 70 with
+# five aggregators x three scalers (1050 x 70 = 74 k) 0.236 vs 0.149 -- the streaming route has the degree-class product (S times fewer
+# flops) and all CUs.
+BLOCK_LAYER_MAX_POST = int(os.environ.get("DGN_BLOCK_LAYER_MAX_POST", "40960"))
 _BLK_DBG = None      # tests: dict that receives the aggregate rows / their gradients of the next call
 
 
@@ -1365,6 +1372,8 @@ def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, 
 def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
     """Whether this (batch, layer shape) runs on the graph-block route: a block table whose largest block fits the LDS plan."""
     if BLOCK_LAYER_MAX_NODES <= 0 or graph.num_nodes > BLOCK_LAYER_MAX_NODES or len(plan.launches) != 1 or plan.n_channels > 3:
+        return False
+    if ((fi if type_net != 0 else 0) + plan.n_scalers * plan.n_agg * fi) * fo > BLOCK_LAYER_MAX_POST:
         return False
     table = graph.block_table()
     if table is None:

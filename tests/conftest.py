@@ -29,6 +29,13 @@ os.environ.setdefault("DGN_BLK_MIN_NODES", "0")
 @pytest.fixture(autouse=True)
 def _streaming_routes_outside_the_block_layer_tests(request, monkeypatch):
     if getattr(request.node, "module", None) is not None and request.node.module.__name__.endswith("test_block_layer_gpu"):
+        # (that module tests the route's KERNELS at every shape, also those the dispatch hands to the streaming kernels because their
+        #  posttrans is large -- ops.BLOCK_LAYER_MAX_POST, restored to the default in the test of the dispatch itself)
+        try:
+            import dgn_amd.ops as ops
+            monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_POST", 1 << 30)
+        except Exception:
+            pass
         yield
         return
     try:

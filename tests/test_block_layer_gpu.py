@@ -246,6 +246,19 @@ def test_route_left_outside_its_domain(monkeypatch):
                           edge_dim=6).model.to(dev).train()
     le(graph, h, torch.randn(graph.num_edges, 6, device=dev), snorm)
     assert len(taken) == 1
+    # a large posttrans (the HIV json's simple layer: hidden 70, five aggregators x three scalers = 1050 x 70 weights per workgroup) is
+    # left to the streaming kernels at the DEFAULT bound (measured: 0.236 ms on the route, 0.149 off it), taken when the bound is lifted
+    lh, _ = _make_layer("simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, avg)
+    lh = lh.to(dev).train()
+    h70 = torch.randn(N, 70, generator=gen).to(dev).requires_grad_(True)
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_POST", 40960)
+    graph2 = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))      # (a fresh table: the answer is cached per table)
+    lh(graph2, h70, None, snorm)
+    assert len(taken) == 1
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_POST", 1 << 30)
+    graph3 = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    lh(graph3, h70, None, snorm)
+    assert len(taken) == 2
 
 
 @pytest.mark.parametrize("type_net", ["towers", "complex"])
