@@ -1321,7 +1321,10 @@ def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm
 
 # Batches up to this many nodes take the graph-block route where it applies (whole graphs per workgroup, everything out of LDS; the
 # streaming kernels are built for batches that fill the chip).  0 switches the route off.
-BLOCK_LAYER_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_MAX_NODES", "32768"))
+# Measured captured steps, route vs streaming (tools/route_crossover.py): towers x 128 / 256 / 512 / 1024 graphs (3.0 k / 5.8 k / 11.9 k / 23.8 k
+# nodes) 0.103 / 0.154 / 0.320 / 0.658 vs 0.182 / 0.194 / 0.217 / 0.270 ms; ZINC json complex 45: 0.101 / 0.111 / 0.210 / 0.410 vs 0.150 / 0.162 /
+# 0.184 / 0.193 -- the route's time grows with the rounds of (block, tower) workgroups, the streaming kernels' barely at all.
+BLOCK_LAYER_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_MAX_NODES", "8192"))
 # ... and only layers whose posttrans is small: a (block, tower) workgroup multiplies its rows by the tower's whole [f_out, (f_in +) S A f_in]
 # weight three times per step (forward, input gradient, weight gradient) with the scalers applied on the fly, and a batch of 128 graphs is
 # 128 workgroups per tower.  Measured captured steps at batch 128, block route vs streaming kernels: towers 5 x (224 x 14 = 3.1 k weights)

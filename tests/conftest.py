@@ -22,7 +22,7 @@ os.environ.setdefault("DGN_DC_MIN_NODES", "0")
 os.environ.setdefault("DGN_BLK_MIN_NODES", "0")
 
 
-# Batches up to 32 768 nodes take the graph-block layer route by default (dgn_amd/ops.py: BLOCK_LAYER_MAX_NODES) -- which is every oracle-
+# Batches up to 8 192 nodes take the graph-block layer route by default (dgn_amd/ops.py: BLOCK_LAYER_MAX_NODES) -- which is every oracle-
 # sized batch of this suite.  tests/test_block_layer_gpu.py runs that route through the layers' default dispatch (and
 # test_shipped_configs_gpu.py::test_every_layer_type_on_the_default_routes_vs_oracle at the library's defaults); every other module keeps
 # testing the STREAMING kernels it was written for.

@@ -117,7 +117,7 @@ def test_every_layer_type_on_the_default_routes_vs_oracle(monkeypatch, type_net,
     import dgn_amd
     from dgn_amd import synth
     monkeypatch.setattr(dgn_amd.ops, "DC_MIN_NODES", 16384)
-    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 32768)      # (the default: this batch takes the graph-block route)
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 8192)       # (the default: this batch takes the graph-block route)
     monkeypatch.delenv("DGN_DC_MIN_NODES", raising=False)
     monkeypatch.setattr(dgn_amd._lib.options, "blk_min_nodes", 131072)
     b = synth.molecule_batch(150, seed=45, extra_bonds=3.9, eig_dim=6)
