@@ -335,3 +335,37 @@ def test_padded_batch_beyond_the_block_capacity_is_reported(monkeypatch):
     layer(pb.graph, torch.randn(N + 10, 32, device=dev, requires_grad=True), None, snorm).sum().backward()
     with pytest.raises(_lib.DgnError):
         pb.graph.check_deferred()
+
+
+def test_block_table_from_batch_num_nodes_needs_no_read_back(monkeypatch):
+    """With dgl.batch's graph sizes on the graph (``batch_num_nodes``) the table is rows only (slots = -1: the kernels read the row
+    pointers; the LDS plan uses rows x largest in-degree): same blocks, bit-identical layer output and gradients."""
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(50, seed=23, extra_bonds=3.9, eig_dim=6)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer("towers", 70, "mean max min dir1-av dir1-dx", "identity amplification attenuation", True, avg, o1_weights=False)
+    layer = layer.to(dev).train()
+    layer2 = copy.deepcopy(layer)
+    h, ct = torch.randn(N, 70, generator=gen).to(dev), torch.randn(N, 70, generator=gen).to(dev)
+    snorm = b["snorm_n"].to(dev)
+    taken = _count_route(monkeypatch)
+    g1 = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    g2 = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    g2.batch_num_nodes = [int(s) for s in b["sizes"]]
+    outs = []
+    for g, l in ((g1, layer), (g2, layer2)):
+        hd = h.clone().requires_grad_(True)
+        y = l(g, hd, None, snorm)
+        y.backward(ct)
+        outs.append((y.detach(), hd.grad, [p.grad for p in l.parameters()]))
+    assert len(taken) == 2
+    t1, t2 = g1.block_table(), g2.block_table()
+    assert torch.equal(t1["desc"][:, :2], t2["desc"][:, :2]) and int(t2["desc"][:, 2:].max()) == -1 and int(t1["desc"][:, 2:].min()) >= 0
+    assert t2["max_edges"] >= t1["max_edges"]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, c in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, c)
