@@ -135,7 +135,7 @@ class DgnBlockLayer(C.Structure):
                 ("gamma", C.POINTER(C.c_void_p)), ("beta", C.POINTER(C.c_void_p)), ("w_mix", C.c_void_p), ("b_mix", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("n_nbt", C.c_int32),
                 ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("n_valid", C.c_void_p), ("overflow", C.c_void_p),
+                ("n_valid", C.c_void_p), ("overflow", C.c_void_p), ("eval_mode", C.c_int32),
                 ("dbg_agg", C.c_void_p), ("dbg_gagg", C.c_void_p), ("dbg_time", C.c_void_p)]
 
 

@@ -210,7 +210,7 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
         }
     }
     p.log_deg = L->log_deg; p.snorm = L->snorm;
-    p.has_pre = d.has_pre; p.relu = d.relu; p.mixing = d.mixing; p.residual = L->residual;
+    p.has_pre = d.has_pre; p.relu = d.relu; p.mixing = d.mixing; p.residual = L->residual; p.eval_mode = L->eval_mode != 0;
     p.T = d.T; p.fi = d.fi; p.fo = d.fo; p.F = d.F; p.Fo = d.Fo; p.A = d.A; p.S = d.S; p.K = d.K; p.h_off = d.h_off;
     p.ld_pre = d.ld_pre; p.ld_post = d.ld_post;
     for (int s = 0; s < 3; ++s) p.sc_kind[s] = s < d.S ? spec->scaler[s] : DGN_SCALE_IDENTITY;
@@ -227,7 +227,8 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     }
     if (d.mixing && (!L->w_mix || !L->b_mix)) { set_error("%s: null mixing-network parameters", fn); return DGN_ERR_INVALID; }
     p.w_mix = L->w_mix; p.b_mix = L->b_mix; p.slope = L->slope;
-    if (!L->h || !L->y0 || !L->save_mean || !L->save_invstd) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
+    if (!L->h || !L->y0 || (!L->eval_mode && (!L->save_mean || !L->save_invstd))) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
+    if (L->eval_mode && bwd) { set_error("%s: eval_mode has no backward", fn); return DGN_ERR_INVALID; }
     if (L->residual && d.F != d.Fo) { set_error("%s: the residual needs equal input and output widths", fn); return DGN_ERR_INVALID; }
     p.h = L->h; p.y0 = L->y0; p.out = L->out;
     p.save_mean = L->save_mean; p.save_invstd = L->save_invstd; p.running_mean = L->running_mean; p.running_var = L->running_var;

@@ -56,7 +56,7 @@ struct P {
     const float* eig; int32_t ld_eig; int32_t n_ch;
     int32_t ch_kind[kMaxCh], ch_col[kMaxCh]; float ch_alpha[kMaxCh], ch_eps[kMaxCh];
     const float* log_deg; const float* snorm;
-    int32_t has_pre, relu, mixing, residual;
+    int32_t has_pre, relu, mixing, residual, eval_mode;
     int32_t T, fi, fo, F, Fo, A, S, K, h_off, ld_pre, ld_post;      // fi / fo: per tower; F = T fi, Fo = T fo: row strides of h / y0
     int32_t sc_kind[3]; float avg_log;
     const float* w_pre[kMaxT]; const float* b_pre[kMaxT]; const float* w_post[kMaxT]; const float* b_post[kMaxT];
@@ -677,6 +677,12 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
             for (; w.r < Fo; rf_step(w, st_, Fo)) WM[w.r * ldk + w.f] = p.w_mix[w.r * Fo + w.f];
         }
     }
+    if (p.eval_mode) {      // evaluation: the running statistics, nothing updated (nn.BatchNorm1d.eval())
+        if (tid < Fo) {
+            MEAN[tid] = p.running_mean[tid]; INVSTD[tid] = 1.f / sqrtf(p.running_var[tid] + p.bn_eps);
+            GAM[tid] = col_param(p.gamma, tid, p.fo, p.T); BET[tid] = col_param(p.beta, tid, p.fo, p.T);
+        }
+    } else {
     column_sums(p.bn_part, p.n_blocks, Fo, RED);
     if (tid < Fo) {
         const double n = (double)Nv;
@@ -693,6 +699,7 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
             p.running_var[tid] = (1.f - p.momentum) * p.running_var[tid] + p.momentum * unbiased;
             if (tid < p.n_nbt) p.nbt[tid] += 1;
         }
+    }
     }
     __syncthreads();
     {

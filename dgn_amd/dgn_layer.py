@@ -317,7 +317,9 @@ def _posttrans_split(posttrans: MLP, h, agg, in_dim):
 def _block_route_ok(layer, h) -> bool:
     """Conditions every layer type shares for the graph-block route: a training step with BatchNorm on CUDA fp32 rows (a padded batch
     takes it when its graph carries a static block table: DGNGraph.set_block_capacity)."""
-    return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training and torch.is_grad_enabled() and layer.batch_norm and h.is_cuda
+    # (a training step -- or the evaluation loops' regime: eval() under no_grad; the two mixed forms keep the streaming kernels)
+    return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training == torch.is_grad_enabled() and (layer.training or not h.requires_grad)
+            and layer.batch_norm and h.is_cuda
             and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES
             and all(bn.momentum is not None and bn.track_running_stats and bn.affine for bn in _bns_of(layer)))
 
@@ -384,7 +386,7 @@ class DGNLayerSimple(nn.Module):
             return None
         return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, (lin.weight, lin.bias, bn.weight, bn.bias), 0, 1, h.shape[1], lin.weight.shape[0],
-                                self.residual, bn.momentum, bn.eps)
+                                self.residual, bn.momentum, bn.eps, training=self.training)
 
     def _forward(self, g, h, e, snorm_n):
         y = self._block_layer(g, h, snorm_n)
@@ -499,7 +501,7 @@ class DGNLayerComplex(nn.Module):
             return None
         return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, (pre.weight, pre.bias, lin.weight, lin.bias, bn.weight, bn.bias), 1, 1, h.shape[1],
-                                lin.weight.shape[0], self.residual, bn.momentum, bn.eps)
+                                lin.weight.shape[0], self.residual, bn.momentum, bn.eps, training=self.training)
 
     def _forward(self, g, h, e, snorm_n):
         y = self._block_layer(g, h, snorm_n)
@@ -851,7 +853,7 @@ class DGNLayerTower(nn.Module):
         bns = [t.batchnorm_h for t in self.towers]
         rm, rv, nbt = self._linked_bn_stats(h.device)
         return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, rm, rv, nbt,
-                                (*plist, mix.weight, mix.bias), 2, T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1])
+                                (*plist, mix.weight, mix.bias), 2, T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], training=self.training)
 
     def _forward(self, g, h, e, snorm_n):
         h_in = h

@@ -1488,9 +1488,30 @@ class _BlockLayer(torch.autograd.Function):
         return (None, None, None, None, None, g_h, None, None, None, None, *grads)
 
 
+@torch.no_grad()
+def _block_layer_eval(graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, params):
+    """The evaluation-mode forward (BatchNorm with the running statistics, nothing updated, no autograd node): two launches."""
+    lib = _lib.load()
+    T, fo = cfg[1], cfg[3]
+    N, Fo, dev = h.shape[0], T * fo, h.device
+    table = graph.block_table()
+    h = h.contiguous()
+    params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)
+    L, keep = _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, None, params)
+    L.eval_mode = 1
+    ws_f = _block_sizes(lib, table, L, cfg, params)[0]
+    y0 = torch.empty(N * Fo + (ws_f + 3) // 4 + 64, dtype=torch.float32, device=dev)       # [y0 | (forward scratch)]
+    out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
+    L.y0, L.out = y0.data_ptr(), out.data_ptr()
+    L.ws, L.ws_bytes = (y0.data_ptr() + 4 * N * Fo + 255) & ~255, ws_f
+    _lib.check(lib.dgn_block_layer_forward(C.byref(L), _lib.stream_ptr(dev)), "dgn_block_layer_forward")
+    return out
+
+
 def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, rm, rv, nbt, params, type_net: int, n_towers: int, f_in: int,
-                f_out: int, residual: bool, momentum: float, eps: float, slope: float = 0.01) -> torch.Tensor:
-    """One DGN layer (nets/dgn_layer.py:103-132 complex, :178-202 simple, :254-276 + :309-325 towers; training mode) as ONE autograd node
+                f_out: int, residual: bool, momentum: float, eps: float, slope: float = 0.01, training: bool = True) -> torch.Tensor:
+    """One DGN layer (nets/dgn_layer.py:103-132 complex, :178-202 simple, :254-276 + :309-325 towers; training mode -- ``training=False``:
+    the evaluation-mode forward without gradients, BatchNorm on its running statistics) as ONE autograd node
     over ``dgn_block_layer_forward / _backward`` (``include/dgn_hip.h: DgnBlockLayer``): two launches forward, three backward.
     ``plan``: the layer's own list (aggregators x applied scalers, no pass-through block); ``params``: per tower (pretrans weight, bias --
     complex / towers --, posttrans weight, bias, BatchNorm weight, bias), then (towers) the mixing network's weight and bias, all in the
@@ -1505,6 +1526,8 @@ def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, r
     else:
         eig = None
     cfg = (int(type_net), int(n_towers), int(f_in), int(f_out), bool(residual), float(momentum), float(eps), float(slope))
+    if not training:
+        return _block_layer_eval(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, params)
     return _BlockLayer.apply(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, nbt, *params)
 
 

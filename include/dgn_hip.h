@@ -694,6 +694,11 @@ typedef struct DgnBlockLayer {
      * first row == end row are unused, negative slot fields are read from graph->indptr, and blocks->max_rows / max_edges are the
      * CAPACITY the LDS plan is made for -- a block beyond it is skipped and *overflow (DEVICE int32, may be NULL) set to 1.          */
     const int64_t* n_valid; int32_t* overflow;
+    /* eval_mode = 1 (dgn_block_layer_forward only): the layer in evaluation mode -- BatchNorm with the RUNNING statistics, which are
+     * read and not updated; num_batches_tracked, save_mean / save_invstd are not touched (may be NULL); y0 is still the hand-over
+     * buffer between the two launches.  nn.Module.eval() + torch.no_grad() of the reference's evaluation loops
+     * (train/train_molecules_graph_regression.py:47-66).                                                                         */
+    int32_t eval_mode;
     float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
     int64_t* dbg_time;           /* profiling only: [n_blocks][16] wall-clock stamps (100 MHz) of the block kernel's phases; NULL      */
 } DgnBlockLayer;

@@ -369,3 +369,44 @@ def test_block_table_from_batch_num_nodes_needs_no_read_back(monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for a, c in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("type_net,F_,aggs", [("towers", 70, "mean max min dir1-av dir1-dx"), ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean dir1-dx-no-abs")])
+def test_evaluation_forward_on_the_route(monkeypatch, type_net, F_, aggs):
+    """eval() under no_grad (the reference's evaluation loops, train/train_molecules_graph_regression.py:47-66): the route's forward with
+    BatchNorm on its RUNNING statistics -- against the oracle in evaluation mode and the streaming kernels; statistics and counters untouched."""
+    import copy
+    import dgn_amd
+    from dgn_amd import synth
+    from oracle import dgn_oracle as orc
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(60, seed=31, extra_bonds=3.9, eig_dim=6)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    scalers = "identity amplification attenuation"
+    layer, gen = _make_layer(type_net, F_, aggs, scalers, True, avg, o1_weights=type_net != "towers")
+    with torch.no_grad():      # running statistics that are not the initial (0, 1)
+        for k, v in layer.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(0.3 * torch.randn(v.shape, generator=gen))
+            elif k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+    h = torch.randn(N, F_, generator=gen)
+    sd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg), graph_norm=True, batch_norm=True, residual=True,
+               towers=5 if type_net == "towers" else 1, divide_input=True, edge_features=False)
+    yo, _ = orc.layer_forward(type_net, sd, cfg, b["src"], b["dst"], N, b["eig"], h, None, b["snorm_n"], training=False)
+    layer = layer.to(dev).eval()
+    before = {k: v.clone() for k, v in layer.state_dict().items()}
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    taken = _count_route(monkeypatch)
+    with torch.no_grad():
+        y = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+        assert len(taken) == 1, "the evaluation forward left the route"
+        monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 0)
+        ys = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+    assert len(taken) == 1
+    np.testing.assert_allclose(y.cpu().numpy(), yo.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), ys.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    for k, v in layer.state_dict().items():
+        assert torch.equal(v, before[k]), k
