@@ -846,8 +846,7 @@ def run_bucketed(args, dev, steps=200, warmup=30, n_batches=8, workload="c2_b128
 
     def load(i):
         d = data[i % n_batches]
-        pb.load(d["src"], d["dst"], d["N"], d["eig"], node=dict(h=d["h"], snorm=d["snorm"], ct=d["ct"]))
-        pb.graph.load_block_sizes(d["sizes"])
+        pb.load(d["src"], d["dst"], d["N"], d["eig"], node=dict(h=d["h"], snorm=d["snorm"], ct=d["ct"]), graph_sizes=d["sizes"])
 
     def bare_step():
         pb.graph.invalidate_caches()              # edge weights and scaler tables are recomputed inside the captured region

@@ -112,7 +112,7 @@ class DGNGraph:
         self.batch_nodes = self.batch_edges = 0
         return self
 
-    def rebuild(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None) -> None:
+    def rebuild(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None, graph_sizes=None) -> None:
         """Load a batch into a ``padded`` graph, in place (dgn_graph_build + dgn_graph_build_csc into the static arrays; no host
         sync: the batch's statistics are checked at the next load, see check_deferred).  Cached per-graph tables (edge weights, scaler tables) are dropped: a step function
         captured on this object must recompute them INSIDE the captured region (they then replay with every batch)."""
@@ -121,6 +121,9 @@ class DGNGraph:
         # The previous batch's deferred statistics are looked at BEFORE anything is overwritten: an error then leaves the object in the
         # (complete) state of the batch it is about, not half-way into the next one.  Callers run check_deferred() after the LAST batch.
         self.check_deferred(final=False)
+        if self.__dict__.get("_blk_static") is not None and graph_sizes is None:
+            # (a step captured on this object replays the block kernels whatever Python thinks: a stale table would be silent garbage)
+            raise ValueError("rebuild: this padded graph has a static block table (set_block_capacity): pass the batch's graph_sizes")
         E, N = src.numel(), int(num_nodes)
         if N > pad["n_cap"] or E > pad["e_cap"]:
             raise ValueError(f"batch ({N} nodes, {E} edges) exceeds the capacity ({pad['n_cap']}, {pad['e_cap']})")
@@ -134,6 +137,8 @@ class DGNGraph:
         _lib.check(lib.dgn_graph_build_csc(n_cap, E, self.src.data_ptr(), self.csc_ptr.data_ptr(), self.csc_pos.data_ptr(),
                                            self._csc_order.data_ptr(), pad["ws"].data_ptr(), pad["ws_bytes"], stream), "dgn_graph_build_csc")
         self.n_valid.fill_(N)
+        if graph_sizes is not None and self.__dict__.get("_blk_static") is not None:
+            self.load_block_sizes(graph_sizes)
         if E < pad["e_cap"]:
             # slots beyond the batch's edges: no row points at them, but per-edge tensors are e_cap rows long (to_slot_order gathers through
             # eid, the edge-feature Linear runs over all rows) -- keep the tail a valid, fixed gather of edge 0 instead of the previous batch's ids

@@ -77,9 +77,9 @@ class PaddedBatch:
 
     @torch.no_grad()
     def load(self, src: torch.Tensor, dst: torch.Tensor, num_nodes: int, eig: Optional[torch.Tensor] = None, node: Optional[dict] = None,
-             edge: Optional[dict] = None) -> None:
+             edge: Optional[dict] = None, graph_sizes=None) -> None:
         """Rebuild the graph in place and copy the batch's tensors into the static buffers (rows beyond the batch zeroed)."""
-        self.graph.rebuild(src, dst, num_nodes, eig)
+        self.graph.rebuild(src, dst, num_nodes, eig, graph_sizes=graph_sizes)      # (graph_sizes: required once set_block_capacity was called)
         for name, val in (node or {}).items():
             buf = self.node[name]
             buf[:num_nodes].copy_(val, non_blocking=True)
@@ -193,9 +193,7 @@ class CapturedNetStep:
         pad, R = n_cap - int(num_nodes), self.PAD_ROWS
         if pad > 2048 * R:
             raise ValueError(f"more than {2048 * R} padding nodes: pick a smaller capacity bucket (a padding row must not be a hub row)")
-        self.pb.load(src, dst, num_nodes, eig, node={"snorm": snorm})
-        if self.pb.graph.__dict__.get("_blk_static") is not None:
-            self.pb.graph.load_block_sizes(sizes)
+        self.pb.load(src, dst, num_nodes, eig, node={"snorm": snorm}, graph_sizes=sizes)
         self.atoms[:num_nodes].copy_(atoms, non_blocking=True)
         self.atoms[num_nodes:].zero_()
         # graph sizes -> the readout CSR, on the device: ONE copy from a pinned staging buffer (a pageable host tensor copied

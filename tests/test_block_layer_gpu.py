@@ -292,8 +292,9 @@ def test_padded_batch_through_the_static_block_table(monkeypatch, type_net):
     pb = PaddedBatch(n_cap, e_cap, dev, eig_dim=6)
     pb.graph.set_block_capacity(g_cap, max(sizes), 4 * max(sizes))
     snorm = pb.add_node_tensor("snorm", 1)
-    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), node={"snorm": b["snorm_n"].to(dev)})
-    pb.graph.load_block_sizes(sizes)
+    with pytest.raises(ValueError):              # (a static table and no sizes: refused, a stale table would be silent garbage)
+        pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), node={"snorm": b["snorm_n"].to(dev)})
+    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), node={"snorm": b["snorm_n"].to(dev)}, graph_sizes=sizes)
     hp = torch.zeros(n_cap, F_, device=dev)
     hp[:N] = h.to(dev)
     hp.requires_grad_(True)
@@ -326,11 +327,10 @@ def test_padded_batch_beyond_the_block_capacity_is_reported(monkeypatch):
     layer = layer.to(dev).train()
     pb = PaddedBatch(N + 10, E + 10, dev, eig_dim=6)
     pb.graph.set_block_capacity(24, max(sizes) - 1, 4 * max(sizes))
-    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev))
     with pytest.raises(ValueError):
-        pb.graph.load_block_sizes(sizes)
+        pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), graph_sizes=sizes)
     pb.graph.set_block_capacity(24, max(sizes), 8)                 # (every molecule has more than 8 directed edges)
-    pb.graph.load_block_sizes(sizes)
+    pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), graph_sizes=sizes)
     snorm = torch.ones(N + 10, 1, device=dev)
     layer(pb.graph, torch.randn(N + 10, 32, device=dev, requires_grad=True), None, snorm).sum().backward()
     with pytest.raises(_lib.DgnError):
