@@ -311,6 +311,13 @@ def test_padded_batch_through_the_static_block_table(monkeypatch, type_net):
     for (k, a), (_, c) in zip(layer_p.state_dict().items(), layer.state_dict().items()):
         if "running" in k or "num_batches" in k:
             assert torch.equal(a, c), k
+    # the evaluation forward over the same padded buffers (eval() under no_grad: running statistics, zero padding rows)
+    layer.eval(); layer_p.eval()
+    with torch.no_grad():
+        ye = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+        ype = layer_p(pb.graph, hp.detach(), None, snorm)
+    assert len(taken) == 4
+    assert torch.equal(ype[:N], ye) and float(ype[N:].abs().max()) == 0.0
 
 
 def test_padded_batch_beyond_the_block_capacity_is_reported(monkeypatch):
