@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -240,6 +241,8 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     int rc = 0;
     if (!plan_lds(d, spec, bwd, p.L, rc, p.cmap)) { set_error("%s: a block of %d rows / %d edges does not fit the LDS", fn, d.R, d.Emax); return DGN_ERR_INVALID; }
     p.RC = rc;
+    static const bool dbg_plan = getenv("DGN_BLK_DEBUG") != nullptr;      // (debug aid, read once: the LDS plan of every call on stderr)
+    if (dbg_plan) fprintf(stderr, "blk plan: bwd %d R %d Emax %d RC %d lds %d floats (%.1f KB) threads %d n_coef %d kp %d\n", (int)bwd, d.R, d.Emax, rc, p.L.total, p.L.total * 4 / 1024.0, block_threads(d, bwd), p.L.n_coef, p.L.kp);
     return DGN_OK;
 }
 
