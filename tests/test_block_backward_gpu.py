@@ -252,3 +252,54 @@ def test_graph_backward_feature_tiles_agree_bitwise(monkeypatch, gen, case):
             ref = g
         else:
             assert all(torch.equal(a, c) for a, c in zip(g, ref)), f"tiles = {tiles} changed the gradients"
+
+
+_GRAPH_BWD_LISTS = [(["mean", "dir1-dx", "dir2-dx"], False), (["mean", "dir1-dx", "dir2-dx"], True), (["mean", "dir1-dx", "dir1-av"], False),
+                    (["mean", "dir1-dx", "dir1-av"], True), (["mean", "dir1-av", "dir1-dx"], False), (["mean", "dir1-dx-no-abs"], False), (["mean"], False),
+                    (["mean", "dir1-dx"], False), (["mean", "dir1-av"], False)]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DGN_FUZZ_CASES", "24"))))
+def test_graph_backward_fuzz_vs_staged(monkeypatch, seed):
+    """Seeded shapes for the graph backward (csrc/dgn_agg_graph.hpp): every baked-in list without max / min / std / var, simple and pair
+    messages, even widths 2 .. 126 (one to 63 feature pairs: every tiling), k-NN graphs of 9 .. 150 nodes with 2 .. 12 neighbours and SBM
+    graphs, 1 .. 40 graphs (feature tiles on and off) -- against the staged scatter, and reproducible."""
+    import dgn_amd
+    from dgn_amd import synth
+    from dgn_amd.dgn_layer import X_IN_NAME
+    rng = np.random.default_rng(7000 + seed)
+    names, pair = _GRAPH_BWD_LISTS[int(rng.integers(0, len(_GRAPH_BWD_LISTS)))]
+    F_ = 2 * int(rng.integers(1, 64))
+    n_graphs = int(rng.integers(1, 41))
+    if rng.integers(0, 3) == 0:
+        b = synth.sbm_batch(max(1, n_graphs // 6), seed=int(rng.integers(0, 1 << 20)), n_lo=20, n_hi=int(rng.integers(30, 120)))
+    else:
+        n_lo = int(rng.integers(9, 60))
+        b = synth.knn_batch(n_graphs, seed=int(rng.integers(0, 1 << 20)), n_lo=n_lo, n_hi=n_lo + int(rng.integers(0, 90)), k=int(rng.integers(4, 13)))
+    N = int(b["num_nodes"])
+    if b["src"].dim() != 1 or b["src"].shape != b["dst"].shape or b["src"].numel() <= 3 * N:
+        pytest.skip("fewer than three edges per node (or a degenerate synthetic batch): not a graph-backward batch")
+    plan = dgn_amd.make_plan(names + ([X_IN_NAME] if pair else []), ["identity"])
+    dev = _dev()
+    gg = torch.Generator().manual_seed(seed)
+    X, PQ = torch.randn(N, F_, generator=gg), torch.randn(N, 2 * F_, generator=gg)
+    eig = b["eig"] if b["eig"].shape[1] >= 3 else torch.cat([b["eig"], torch.randn(N, 3 - b["eig"].shape[1], generator=gg)], dim=1)
+
+    def run(attach):
+        graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=eig.to(dev))
+        if not attach:
+            monkeypatch.setattr(dgn_amd.graph.DGNGraph, "_ensure_graph_blocks", lambda self, enabled=True: False)
+        y, g = _grads(graph, plan, F_, 1, pair, X, PQ)
+        monkeypatch.undo()
+        return graph, y, g
+
+    graph, y1, g1 = run(True)
+    if not graph.c_graph.gblk_desc:
+        pytest.skip("the graph description was not attached (graphs beyond 512 nodes)")
+    _, _, g1b = run(True)
+    assert all(torch.equal(a, c) for a, c in zip(g1, g1b)), "not run-to-run reproducible"
+    _, y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    for a, c in zip(g1, g0):
+        scale = max(1.0, float(c.abs().max()))
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-5, atol=4e-6 * scale, err_msg=f"{names} pair={pair} F={F_} N={N}")
