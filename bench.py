@@ -809,6 +809,32 @@ def run_inference(args, dev, steps=20, warmup=5):
     return out
 
 
+def eval_forward_ms(wl, dev, iters=300):
+    """The layer's evaluation-mode forward (eval() under no_grad: the reference's validation / test loops) on the workload's batch, eager."""
+    batch, graph = build_batch(wl, 41, dev)
+    F_, N = wl["hidden"], graph.num_nodes
+    avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, wl.get("dropout", 0.0), wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
+                             wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev).eval()
+    h = torch.randn(N, F_, device=dev)
+    snorm = batch["snorm_n"].to(dev)
+
+    def step():
+        graph._wcache.clear()
+        with torch.no_grad():
+            return layer(graph, h, None, snorm)
+
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3 / iters
+
+
 def _max_graph_edges(b):
     """Largest number of directed edges of one graph of a synthetic batch (host side: what a data loader knows about its data set)."""
     import numpy as np
@@ -1031,6 +1057,11 @@ def run_extras(args, dev):
                     extra[name]["eager_st_error"] = f"{type(exc).__name__}: {exc}"[:200]
                 finally:
                     torch.autograd.set_multithreading_enabled(True)
+                if name.endswith("_b128"):
+                    try:
+                        extra[name]["eval_fwd_ms"] = eval_forward_ms(dict(WORKLOADS[name]), dev)
+                    except Exception as exc:
+                        extra[name]["eval_fwd_error"] = f"{type(exc).__name__}: {exc}"[:200]
             if name == "c1" and not args.no_cpu_baseline:
                 # BASELINE configs[0] is quoted on the reference's CPU path: the same bounded CPU sample for it
                 extra[name]["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])), reps=3)
@@ -1099,7 +1130,7 @@ def compact_line(line):
             if "error" in e:
                 ex[name] = dict(error=str(e["error"])[:80])
                 continue
-            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step") if k in e}
+            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step", "eval_fwd_ms") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
                 if isinstance(e["roofline"].get("step"), dict):
