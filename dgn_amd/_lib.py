@@ -26,7 +26,7 @@ EXPORTS = ("dgn_abi_version", "dgn_sizeof", "dgn_last_error", "dgn_set_option", 
            "dgn_bias_act_forward", "dgn_bias_act_backward", "dgn_dropout_mask_bytes", "dgn_dropout_forward", "dgn_dropout_backward",
            "dgn_layer_fused_supported", "dgn_layer_fused_forward",
            "dgn_gemm_supported", "dgn_gemm_forward", "dgn_gemm_wgrad_workspace_bytes", "dgn_gemm_wgrad",
-           "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_cuts",
+           "dgn_agg_f_valid_supported", "dgn_graph_build_workspace_bytes", "dgn_graph_build", "dgn_graph_build_csc", "dgn_graph_build_cuts",
            "dgn_assemble_params", "dgn_towers_layer_supported", "dgn_towers_layer_forward_workspace_bytes", "dgn_towers_layer_forward",
            "dgn_towers_layer_backward_workspace_bytes", "dgn_towers_layer_backward",
            "dgn_linear_supported", "dgn_linear_forward", "dgn_linear_combine_forward", "dgn_linear_combine_backward_input", "dgn_linear_combine_backward_weight", "dgn_linear_wgrad_workspace_bytes", "dgn_linear_wgrad",
@@ -63,7 +63,7 @@ class DgnAggSpec(C.Structure):
 class DgnMsg(C.Structure):
     _fields_ = [("F", C.c_int64), ("x_src", C.c_void_p), ("ld_src", C.c_int64), ("x_dst", C.c_void_p),
                 ("ld_dst", C.c_int64), ("m_edge", C.c_void_p), ("ld_edge", C.c_int64), ("x_in", C.c_void_p),
-                ("ld_in", C.c_int64), ("edge_type", C.c_void_p), ("n_edge_types", C.c_int32)]
+                ("ld_in", C.c_int64), ("edge_type", C.c_void_p), ("n_edge_types", C.c_int32), ("f_valid", C.c_int32)]
 
 
 class DgnMsgGrad(C.Structure):

@@ -16,16 +16,17 @@ bool aligned(const void* ptr, int bytes) { return (reinterpret_cast<uintptr_t>(p
 int pick_vec(const DgnAggSpec* spec, const DgnMsg* msg, const float* out, int64_t ld_out, const DgnMsgGrad* gr) {
     const int64_t Ft = msg->F / spec->n_towers;
     for (int vec : {4, 2}) {
+        if (msg->f_valid && vec != 2) continue;      // (rows of an odd width: the 8-byte-lane kernels, whose last lane shifts its pair)
         bool ok = (msg->F % vec == 0) && (Ft % vec == 0) && (ld_out % vec == 0) && aligned(out, 4 * vec) && (spec->tower_stride % vec == 0);
         // keep more than half of the 64 lanes busy, unless the row is too narrow anyway
         if (msg->F / vec <= 32 && vec > 2) ok = false;
         auto chk = [&](const float* ptr, int64_t ld) {
             if (ptr && (!aligned(ptr, 4 * vec) || ld % vec != 0)) ok = false;
         };
-        chk(msg->x_src, msg->ld_src);
+        if (!msg->f_valid) chk(msg->x_src, msg->ld_src);      // (f_valid: 4-byte aligned rows at an odd stride)
         chk(msg->x_dst, msg->ld_dst);
         chk(msg->m_edge, msg->ld_edge);
-        chk(msg->x_in, msg->ld_in);
+        if (!msg->f_valid) chk(msg->x_in, msg->ld_in);
         if (gr) {
             chk(gr->g_src, gr->ld_src);
             chk(gr->g_dst, gr->ld_dst);
@@ -53,6 +54,10 @@ int validate(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg, const
     if (spec->n_scalers < 1 || spec->n_scalers > DGN_MAX_SCALERS) { set_error("n_scalers=%d outside 1..%d", spec->n_scalers, DGN_MAX_SCALERS); return DGN_ERR_INVALID; }
     if (spec->n_towers < 1 || msg->F < 1 || msg->F % spec->n_towers != 0) { set_error("F=%lld not divisible by n_towers=%d", (long long)msg->F, spec->n_towers); return DGN_ERR_INVALID; }
     if (!msg->x_src && !msg->x_dst && !msg->m_edge) { set_error("message has no term"); return DGN_ERR_INVALID; }
+    if (msg->f_valid != 0 && (msg->f_valid != msg->F - 1 || (msg->F & 1) || msg->F < 4 || !msg->x_src || msg->x_dst || msg->m_edge || spec->n_towers != 1 ||
+                              msg->ld_src < msg->f_valid || (msg->x_in && msg->ld_in < msg->f_valid) || g->n_hub > 0 || !dgn_agg_f_valid_supported(spec))) {
+        set_error("f_valid = %d: rows of an odd width need F = f_valid + 1 even, x_src (and x_in) alone, one tower, no hub rows, a list of dgn_agg_f_valid_supported()", msg->f_valid); return DGN_ERR_INVALID;
+    }
     if (msg->edge_type) {
         if (!msg->m_edge || !msg->x_src) { set_error("edge_type needs the table (m_edge) and x_src"); return DGN_ERR_INVALID; }
         if (msg->n_edge_types < 1 || (int64_t)msg->n_edge_types * msg->F > DGN_MAX_EDGE_TABLE) { set_error("edge-type table of %d x %lld floats outside 1..%d", msg->n_edge_types, (long long)msg->F, DGN_MAX_EDGE_TABLE); return DGN_ERR_INVALID; }
@@ -90,7 +95,7 @@ void fill_params(AggParams& p, const DgnGraph* g, const DgnAggSpec* spec, const 
     p.n_hub = g->n_hub; p.n_chunks = g->n_hub > 0 ? g->n_chunks : 0;
     p.hub_threshold = g->n_hub > 0 ? g->hub_threshold : INT32_MAX;
     p.hub_chunk = g->hub_chunk; p.hub_rows = g->hub_rows; p.hub_chunk_ptr = g->hub_chunk_ptr; p.chunk_hub = g->chunk_hub;
-    p.F = (int32_t)msg->F; p.Ft = (int32_t)(msg->F / spec->n_towers);
+    p.F = (int32_t)msg->F; p.Ft = (int32_t)(msg->F / spec->n_towers); p.Fv = msg->f_valid ? msg->f_valid : (int32_t)msg->F;
     p.x_src = msg->x_src; p.ld_src = (int32_t)msg->ld_src;
     p.x_dst = msg->x_dst; p.ld_dst = (int32_t)msg->ld_dst;
     p.m_edge = msg->m_edge; p.ld_edge = (int32_t)msg->ld_edge;
@@ -247,6 +252,20 @@ static bool agg_aux_supported(const AggParams& p, const DgnMsg* msg) {
 }
 // (row-major sign table of the row-per-wave kernels, see AggParams.aux_rows)
 static bool agg_aux_is_rows(const AggParams& p) { return !short_rows(p); }
+
+extern "C" int dgn_agg_f_valid_supported(const DgnAggSpec* spec) {
+    // (the lists with Cfg::ODD kernels, dgn_agg_kernels.hpp: odd_width_list; one identity scaler, the whole list in one launch, one tower)
+    static const bool no_hot = getenv("DGN_NO_HOT") != nullptr;
+    if (!spec || no_hot || spec->n_towers != 1 || spec->n_scalers != 1 || spec->scaler[0] != DGN_SCALE_IDENTITY ||
+        (spec->agg_total > 0 && (spec->agg_offset != 0 || spec->agg_total != spec->n_agg))) return 0;
+    uint64_t ops = 0, chs = 0;
+    for (int a = 0; a < spec->n_agg; ++a) {
+        const int op = spec->agg_op[a];
+        ops |= (uint64_t)op << (4 * a);
+        chs |= (uint64_t)((op >= DGN_AGG_DIR_AV && op <= DGN_AGG_DIR_DX_NO_ABS) ? spec->agg_ch[a] : 0) << (3 * a);
+    }
+    return odd_width_list(spec->n_agg, ops, chs) && spec->n_ch == (spec->n_agg == 2 ? 1 : 2) ? 1 : 0;
+}
 
 extern "C" size_t dgn_agg_aux_bytes(const DgnGraph* g, const DgnAggSpec* spec, const DgnMsg* msg) {
     if (!g || !spec || !msg || msg->F <= 0 || spec->n_agg < 1 || spec->n_agg > DGN_MAX_AGG || spec->n_towers < 1) return 0;

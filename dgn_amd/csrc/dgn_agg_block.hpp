@@ -112,6 +112,10 @@ int launch_block_vec(const AggParams& p, int gap, hipStream_t stream) {
     if (p.n_agg == NA && p.op_pack == OPS && p.ch_pack == CHS && p.n_scalers == NS && p.scaler_pack == SCS &&    \
         p.agg_total == NA && p.agg_offset == 0 && p.n_ch == N) {                                                 \
         using O = StaticOps<NA, OPS, CHS, NS, SCS>;                                                              \
+        if (p.Fv != p.F) {                                                                                       \
+            if constexpr (VEC == 2 && odd_width_list(NA, OPS, CHS)) return launch_backward_block_cfg<Cfg<VEC, N, S, A, true>, O>(p, gap, stream); \
+            return 1;                                                                                            \
+        }                                                                                                        \
         return launch_backward_block_cfg<Cfg<VEC, N, S, A>, O>(p, gap, stream);                                  \
     }
 #include "dgn_agg_hot.hpp"

@@ -62,6 +62,7 @@ struct AggParams {
     // message (all strides are int32: a 32x32->64 multiply is 2 scalar ops, a 64x64 one is 9)
     int32_t F;
     int32_t Ft;  // F / n_towers
+    int32_t Fv;  // columns the rows of x_src / x_in really hold (F, or F - 1: DgnMsg.f_valid, kernels with Cfg::ODD)
     const float* x_src;  int32_t ld_src;
     const float* x_dst;  int32_t ld_dst;
     const float* m_edge; int32_t ld_edge;
@@ -137,8 +138,10 @@ constexpr int SLOT_SUM = 0, SLOT_SQ = 1, SLOT_MAX = 2, SLOT_MIN = 3, SLOT_AMAX =
 // coefficient slot ids (backward hub path)
 constexpr int COEF_C0 = 0, COEF_CV = 1, COEF_GMAX = 2, COEF_GMIN = 3, COEF_AMAX = 4, COEF_AMIN = 5, COEF_W0 = 6;
 
-template <int VEC_, int NCH_, bool STATS_, bool AV_>
+// ODD_: the rows of x_src / x_in hold F - 1 columns at their own (odd) stride (DgnMsg.f_valid): the last lane of a row shifts its pair
+template <int VEC_, int NCH_, bool STATS_, bool AV_, bool ODD_ = false>
 struct Cfg {
+    static constexpr bool ODD = ODD_;
     static constexpr int VEC = VEC_;
     static constexpr int NCH = NCH_;
     static constexpr int NW = NCH_ > 0 ? NCH_ : 1;   // storage size (no zero-length arrays)
@@ -242,13 +245,13 @@ struct Acc {
 };
 
 // message of slot e coming from node s:  x_src[s] + x_dst[row] + m_edge[e]   (rounded in this order)
-template <int VEC>
+template <int VEC, bool ODD = false>
 __device__ __forceinline__ void load_msg(float (&m)[VEC], const AggParams& p, int s, int e, int f0, const float (&xd)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) m[i] = xd[i];
     if (p.x_src) {
         float t[VEC];
-        ldv<VEC>(t, p.x_src + (int64_t)s * p.ld_src + f0);
+        ldx<VEC, ODD>(t, p.x_src + (int64_t)s * p.ld_src, f0, p.Fv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) m[i] += t[i];
     }
@@ -266,16 +269,31 @@ __device__ __forceinline__ void load_msg(float (&m)[VEC], const AggParams& p, in
 // 0.25 ms for the ZINC-12k forward).  They first ISSUE a group of loads into a register tile and consume it
 // afterwards.  MsgSrc is the gathered part when there is exactly one (x_src rows by source id, or m_edge rows by
 // slot); messages with both parts use half the tile for each.
-template <int VEC>
+// VEC columns of a row of x_src / x_in from column f0 on.  ODD (rows of an odd width F - 1 = Fv at their own stride, 8-byte lanes): the lane
+// of the last pair loads (x[F - 3], x[F - 2]) -- inside the row, nothing past it -- and hands on (x[F - 2], 0): the zero-padded row without
+// the padded copy.  A compile-time flag: as a run-time select in every gather it cost the even widths 3 - 23 % of the forward sweep.
+template <int VEC, bool ODD>
+__device__ __forceinline__ void ldx(float (&d)[VEC], const float* row, int f0, int Fv) {
+    if constexpr (ODD && VEC == 2) {
+        const bool last = f0 + 1 >= Fv;
+        const float2 t = *reinterpret_cast<const float2*>(row + (last ? f0 - 1 : f0));
+        d[0] = last ? t.y : t.x;
+        d[1] = last ? 0.f : t.y;
+    } else {
+        ldv<VEC>(d, row + f0);
+    }
+}
+
+template <int VEC, bool ODD = false>
 struct MsgSrc {
     const float* base;
-    int ld;
+    int ld, Fv;
     bool by_src, both;
     __device__ __forceinline__ explicit MsgSrc(const AggParams& p)
-        : base(p.x_src ? p.x_src : p.m_edge), ld(p.x_src ? p.ld_src : p.ld_edge), by_src(p.x_src != nullptr),
+        : base(p.x_src ? p.x_src : p.m_edge), ld(p.x_src ? p.ld_src : p.ld_edge), Fv(p.Fv), by_src(p.x_src != nullptr),
           both(p.x_src != nullptr && p.m_edge != nullptr) {}
     __device__ __forceinline__ void load(float (&t)[VEC], int s, int e, int f0) const {
-        ldv<VEC>(t, base + (int64_t)(by_src ? s : e) * ld + f0);
+        ldx<VEC, ODD>(t, base + (int64_t)(by_src ? s : e) * ld, f0, Fv);
     }
 };
 
@@ -320,7 +338,7 @@ struct SlotBatch {
 // exists (loop condition), so its load is unconditional: the wait for the slot batch then sits on the common
 // path instead of behind every conditional load.
 template <class C, bool TRACK>
-__device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggParams& p, const MsgSrc<C::VEC>& src,
+__device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggParams& p, const MsgSrc<C::VEC, C::ODD>& src,
                                                  const SlotBatch<C::NCH, C::NW>& b, int base, int cnt, int f0,
                                                  const float (&xd)[C::VEC]) {
     constexpr int VEC = C::VEC, U = DGN_UNROLL, H = U / 2;
@@ -368,7 +386,7 @@ __device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggPa
 #pragma unroll
             for (int u = 0; u < H; ++u) {
                 if (u == 0 || k + u < cnt) {
-                    ldv<VEC>(t[u], p.x_src + (int64_t)bcast_i(b.src, k + u) * p.ld_src + f0);
+                    ldx<VEC, C::ODD>(t[u], p.x_src + (int64_t)bcast_i(b.src, k + u) * p.ld_src, f0, p.Fv);
                     ldv<VEC>(t[H + u], p.m_edge + (int64_t)bcast_i(b.et, k + u) * p.ld_edge + f0);
                 }
             }
@@ -389,7 +407,7 @@ __device__ __forceinline__ void accumulate_batch(Acc<C, TRACK>& acc, const AggPa
 template <class C, bool TRACK>
 __device__ __forceinline__ void accumulate_range(Acc<C, TRACK>& acc, const AggParams& p, int beg, int end, int f0,
                                                  bool active, const float (&xd)[C::VEC]) {
-    const MsgSrc<C::VEC> src(p);
+    const MsgSrc<C::VEC, C::ODD> src(p);
     for (int base = beg; base < end; base += kWave) {
         SlotBatch<C::NCH, C::NW> b;
         b.load(p, base, end);
@@ -748,7 +766,7 @@ __device__ __forceinline__ void fwd_one_row(const AggParams& p, int row, int f0,
     for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
     const float logd = p.log_deg ? p.log_deg[row] : 0.f;
     if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-    if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    if (active && (p.need & NEED_XIN)) ldx<VEC, C::ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     Acc<C, false> acc;
     acc.init();
     accumulate_range<C, false>(acc, p, beg, end, f0, active, xd);
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(256) void agg_fwd_rows(const AggParams p) {
 constexpr int kShortRows = 4, kShortDeg = 4;
 
 // side inputs of one row: x_dst (message part), x_in (epilogue), log-degree
-template <int VEC>
+template <int VEC, bool ODD = false>
 struct RowSide {
     float xd[VEC], xin[VEC], logd;
     __device__ __forceinline__ void load(const AggParams& p, int row, int f0, bool active) {
@@ -796,7 +814,7 @@ struct RowSide {
         for (int i = 0; i < VEC; ++i) { xd[i] = 0.f; xin[i] = 0.f; }
         logd = p.log_deg ? p.log_deg[row] : 0.f;
         if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-        if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+        if (active && (p.need & NEED_XIN)) ldx<VEC, ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     }
 };
 
@@ -850,14 +868,14 @@ __device__ __forceinline__ void short_group_to_lds(const AggParams& p, const Sho
         for (int r = 0; r < grp.nrows; ++r) fwd_one_row<C, O>(p, grp.row0 + r, f0, active, lds_rows + r * row_stride + lane_off);
         return;
     }
-    RowSide<VEC> side[R];
+    RowSide<VEC, C::ODD> side[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (r == 0 || r < grp.nrows) side[r].load(p, grp.row0 + r, f0, active);
     SlotBatch<C::NCH, C::NW> b;
     b.load(p, beg0, beg0 + lo[R - 1] + deg[R - 1]);
     if (!active) return;
-    const MsgSrc<VEC> src(p);
+    const MsgSrc<VEC, C::ODD> src(p);
     float t[R][J][VEC];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -920,7 +938,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     }
     // every load of the group is issued before the first store: a load waited for after a store drains the store
     // first (loads and stores share one in-order counter on gfx950), so the rows are finished from registers only
-    RowSide<VEC> side[R];
+    RowSide<VEC, C::ODD> side[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (r == 0 || r < grp.nrows) side[r].load(p, grp.row0 + r, f0, active);
@@ -943,7 +961,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
     int t_of = 0;                                                        // tower and in-tower feature of this lane
     if (staged) for (int q = 1; q < p.n_towers; ++q) t_of += (f0 >= q * p.Ft) ? 1 : 0;
     float* lds_row = slice + t_of * (grouped ? R : 1) * K + (f0 - t_of * p.Ft);
-    const MsgSrc<VEC> src(p);
+    const MsgSrc<VEC, C::ODD> src(p);
     // tile [row][j-th slot of the row]: the register index is static, the slot (= lane of the batch) is not --
     // one compare per tile instead of a range check of every slot against every row
     float t[R][J][VEC], t2[MEDGE ? R : 1][MEDGE ? J : 1][VEC];
@@ -955,7 +973,7 @@ __global__ __launch_bounds__(256) void agg_fwd_short(const AggParams p) {
             for (int j = 0; j < J; ++j) {
                 if (j < deg[r]) {
                     if constexpr (MEDGE) {
-                        ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                        ldx<VEC, C::ODD>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src, f0, p.Fv);
                         ldv<VEC>(t2[r][j], p.m_edge + (int64_t)(beg0 + lo[r] + j) * p.ld_edge + f0);
                     } else {
                         src.load(t[r][j], bcast_i(b.src, lo[r] + j), beg0 + lo[r] + j, f0);
@@ -1088,7 +1106,7 @@ __global__ __launch_bounds__(kBlock) void agg_fwd_hub_combine(const AggParams p)
     float xin[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) xin[i] = 0.f;
-    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    if (p.need & NEED_XIN) ldx<VEC, C::ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     write_row<C>(acc, p, p.out + (int64_t)row * p.ld_out + lane_col(p, f0), deg, xin, p.log_deg ? p.log_deg[row] : 0.f, true);
 }
 
@@ -1274,7 +1292,7 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
                                            const SlotBatch<C::NCH, C::NW>& b, int my_tpos, int base, int cnt, int f0,
                                            const float (&xd)[C::VEC]) {
     constexpr int VEC = C::VEC, U = DGN_UNROLL;
-    const MsgSrc<VEC> src(p);
+    const MsgSrc<VEC, C::ODD> src(p);
     for (int k0 = 0; k0 < cnt; k0 += U) {
         // var/std need the message again: the group's gathers are issued together, BEFORE the group's stores (a
         // load waited for after a store drains the store first: loads and stores share one in-order counter)
@@ -1288,7 +1306,7 @@ __device__ __forceinline__ void emit_batch(const Coef<C>& k, float (&rsum)[C::VE
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (u == 0 || k0 + u < cnt) {
-                        ldv<VEC>(t[u], p.x_src + (int64_t)bcast_i(b.src, k0 + u) * p.ld_src + f0);
+                        ldx<VEC, C::ODD>(t[u], p.x_src + (int64_t)bcast_i(b.src, k0 + u) * p.ld_src, f0, p.Fv);
                         ldv<VEC>(t2[u], p.m_edge + (int64_t)bcast_i(b.et, k0 + u) * p.ld_edge + f0);
                     }
                 }
@@ -1465,7 +1483,7 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
     if (!active) return;
     if (!signs) {
         if (p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-        if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+        if (p.need & NEED_XIN) ldx<VEC, C::ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     }
     constexpr bool PRE = O::kStatic && O::NA <= 8;
     float gpre[PRE ? O::NA : 1][VEC];
@@ -1476,7 +1494,7 @@ __device__ __forceinline__ void bwd_row_one_batch(const AggParams& p, int row, i
             for (int a = 0; a < O::NA; ++a) ldv<VEC>(gpre[a], grow + sa_col(p, 0, a));
         }
     }
-    const MsgSrc<VEC> src(p);
+    const MsgSrc<VEC, C::ODD> src(p);
     if (recomp) accumulate_batch<C, true>(acc, p, src, b, beg, deg, f0, xd);
     if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
         if (signs) {                   // sum_j w_jc in acc.add()'s order, the residual's sign from the table
@@ -1560,7 +1578,7 @@ __device__ __forceinline__ void bwd_any_row(const AggParams& p, int row, int f0,
     if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) signs = (p.need & NEED_RECOMP) && p.aux_rows != 0;
     if (!signs) {
         if (active && p.x_dst) ldv<VEC>(xd, p.x_dst + (int64_t)row * p.ld_dst + f0);
-        if (active && (p.need & NEED_XIN)) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+        if (active && (p.need & NEED_XIN)) ldx<VEC, C::ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     }
     if (signs) {
         if constexpr (!C::STATS && C::NCH >= 1 && C::NCH <= 2) {
@@ -1654,7 +1672,7 @@ __device__ __forceinline__ void load_group_rows(GroupRows<C, RB, n_gout_blocks<O
         R.logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
         if constexpr (!AUX) {
             if (p.x_dst) ldv<VEC>(R.xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0c);
-            if (p.need & NEED_XIN) ldv<VEC>(R.xin[r], p.x_in + (int64_t)row * p.ld_in + f0c);
+            if (p.need & NEED_XIN) ldx<VEC, C::ODD>(R.xin[r], p.x_in + (int64_t)row * p.ld_in, f0c, p.Fv);
         }
         const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0c);
 #pragma unroll
@@ -1735,7 +1753,7 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
             logd[r] = p.log_deg ? p.log_deg[row] : 0.f;
             if constexpr (!AUX) {
                 if (p.x_dst) ldv<VEC>(xd[r], p.x_dst + (int64_t)row * p.ld_dst + f0);
-                if (p.need & NEED_XIN) ldv<VEC>(xin[r], p.x_in + (int64_t)row * p.ld_in + f0);
+                if (p.need & NEED_XIN) ldx<VEC, C::ODD>(xin[r], p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
             }
             if constexpr (!GLDS) {
                 const float* grow = p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0);
@@ -1752,7 +1770,7 @@ __device__ __forceinline__ void bwd_short_group(const AggParams& p, int row0, in
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         if (j < deg[r]) {
-                            ldv<VEC>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src + f0);
+                            ldx<VEC, C::ODD>(t[r][j], p.x_src + (int64_t)bcast_i(b.src, lo[r] + j) * p.ld_src, f0, p.Fv);
                             if constexpr (EDGE) ldv<VEC>(t2[r][j], p.m_edge + (int64_t)bcast_i(b.et, lo[r] + j) * p.ld_edge + f0);
                         }
                     }
@@ -1904,7 +1922,7 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_hub_coef(const AggParams p) {
     float gxin[VEC], zero[VEC], xin[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { zero[i] = 0.f; xin[i] = 0.f; }
-    if (p.need & NEED_XIN) ldv<VEC>(xin, p.x_in + (int64_t)row * p.ld_in + f0);
+    if (p.need & NEED_XIN) ldx<VEC, C::ODD>(xin, p.x_in + (int64_t)row * p.ld_in, f0, p.Fv);
     make_coef<C>(k, gxin, acc, p, p.g_out + (int64_t)row * p.ld_gout + lane_col(p, f0), deg, xin,
                  p.log_deg ? p.log_deg[row] : 0.f);
     float* base = p.coef + (int64_t)hub * p.n_coef * p.F;
@@ -2130,6 +2148,10 @@ int launch_backward_cfg(const AggParams& p, unsigned tiles, hipStream_t stream) 
     return DGN_OK;
 }
 
+// the baked-in lists that have kernels for rows of an odd width (Cfg::ODD): the simple layers of the reference's configs at odd hidden
+// sizes -- mean dir1-dx-no-abs (ZINC simple, hidden 75) and mean dir1-dx dir2-dx (CIFAR10 / MNIST, hidden 65)
+constexpr bool odd_width_list(int na, uint64_t ops, uint64_t chs) { return (na == 2 && ops == 0x90ull && chs == 0x0ull) || (na == 3 && ops == 0x880ull && chs == 0x40ull); }
+
 // runtime (n_ch, stats, av) -> compile-time configuration
 template <int VEC, bool BWD>
 int launch_vec(const AggParams& p, unsigned tiles, hipStream_t stream) {
@@ -2141,11 +2163,20 @@ int launch_vec(const AggParams& p, unsigned tiles, hipStream_t stream) {
     if (!no_hot && p.n_agg == NA && p.op_pack == OPS && p.ch_pack == CHS && p.n_scalers == NS && p.scaler_pack == SCS && \
         p.agg_total == NA && p.agg_offset == 0 && p.n_ch == N) {                                                 \
         using O = StaticOps<NA, OPS, CHS, NS, SCS>;                                                              \
+        if (p.Fv != p.F) {      /* rows of an odd width (DgnMsg.f_valid): the two lists that meet them, 8-byte lanes */ \
+            if constexpr (VEC == 2 && odd_width_list(NA, OPS, CHS)) {                                            \
+                if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A, true>, O>(p, tiles, stream);     \
+                else return launch_forward_cfg<Cfg<VEC, N, S, A, true>, O>(p, tiles, stream);                    \
+            }                                                                                                    \
+            set_error("f_valid: no kernel for this aggregator list (dgn_agg_f_valid_supported)");               \
+            return DGN_ERR_INVALID;                                                                              \
+        }                                                                                                        \
         if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A>, O>(p, tiles, stream);                   \
         else return launch_forward_cfg<Cfg<VEC, N, S, A>, O>(p, tiles, stream);                                  \
     }
 #include "dgn_agg_hot.hpp"
 #undef DGN_HOT
+    if (p.Fv != p.F) { set_error("f_valid: no kernel for this aggregator list (dgn_agg_f_valid_supported)"); return DGN_ERR_INVALID; }
 #define DGN_GO(N, S, A)                                                                              \
     if (p.n_ch == N && stats == S && av == A) {                                                      \
         if constexpr (BWD) return launch_backward_cfg<Cfg<VEC, N, S, A>>(p, tiles, stream);          \

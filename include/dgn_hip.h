@@ -178,7 +178,13 @@ typedef struct DgnMsg {
      * [n_edges, F].  n_edge_types * F <= DGN_MAX_EDGE_TABLE floats.  The backward then needs the two-phase scatter (g->csc_*
      * and a workspace that includes dgn_agg_edge_table_workspace_bytes()); DgnMsgGrad.g_edge is the TABLE's gradient.       */
     const int32_t* edge_type; int32_t n_edge_types;
+    /* f_valid (0: every row holds F columns): the rows of x_src and x_in hold only f_valid = F - 1 columns (F even; dense rows of an ODD
+     * width at their own strides, 4-byte aligned) and the sweep reads the last column pair as (x[F - 2], 0) -- what a zero-padded copy of
+     * the rows would give, without the copy (the simple layer at hidden 75 / 65: configs ZINC simple, CIFAR10).  Only with x_src (and
+     * x_in) alone -- no x_dst, no m_edge, one tower -- and only for the aggregator lists dgn_agg_f_valid_supported() accepts.          */
+    int32_t f_valid;
 } DgnMsg;
+int dgn_agg_f_valid_supported(const DgnAggSpec* spec);      /* 1: this list has kernels for rows of an odd width (DgnMsg.f_valid) */
 #define DGN_MAX_EDGE_TABLE 8192
 
 /* Gradient sinks of dgn_agg_backward; NULL = not wanted.  g_edge is always overwritten.  g_src / g_dst / g_in:
@@ -203,7 +209,7 @@ size_t dgn_sizeof(const char* struct_name);      /* sizeof of a struct of this h
  * environment on a launch path.  Names: "blk_lds_kb" (DGN_BLK_LDS_KB, 13), "blk_min_nodes" (DGN_BLK_MIN_NODES, 131072),
  * "bwd_rows_per_wave" (DGN_BWD_ROWS_PER_WAVE, 4), "tile_gemm" / "tile_wgrad" (DGN_TILE_GEMM / DGN_TILE_WGRAD, -1 = by shape),
  * "no_zmask" (DGN_NO_ZMASK set, 0), "linear_small_min_waves" (8), "graph_bwd_tiles" (DGN_GRAPH_BWD_TILES, 0 = by batch size: feature tiles of
- * the graph backward of the sweep).  dgn_set_option: DGN_ERR_INVALID for an unknown name;
+ * the graph backward of the sweep), "odd_direct" (DGN_ODD_DIRECT, 1: DgnMsg.f_valid in the simple whole-layer call instead of a padded copy).  dgn_set_option: DGN_ERR_INVALID for an unknown name;
  * dgn_get_option: INT64_MIN for an unknown name.                                                                            */
 int dgn_set_option(const char* name, int64_t value);
 int64_t dgn_get_option(const char* name);

@@ -226,3 +226,36 @@ def test_isolated_nodes_through_the_degree_class_route_vs_oracle(monkeypatch, ty
     monkeypatch.setattr(dgn_amd.ops, "_degree_classes", lambda *a: taken.append(real(*a)) or taken[-1])
     _layer_vs_oracle(monkeypatch, type_net, 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", True, b, 0)
     assert taken and taken[0] is not None and int(taken[0][0]["present"][0]) > 50
+
+
+@pytest.mark.parametrize("hidden,aggs,gen", [(75, "mean dir1-dx-no-abs", "molecules"), (65, "mean dir1-dx dir2-dx", "knn"), (65, "mean dir1-dx dir2-dx", "molecules")])
+def test_odd_hidden_size_without_the_padded_copy_is_bitwise_the_padded_layer(monkeypatch, hidden, aggs, gen):
+    """Simple layers at odd hidden sizes (ZINC simple 75, CIFAR10 65): the sweep reads the un-padded rows itself (DgnMsg.f_valid, kernels
+    with Cfg::ODD: the last lane of a row shifts its pair and hands on a zero) -- output, d h and every parameter gradient carry the bits
+    of the layer run on a zero-padded copy (library option odd_direct = 0), molecule batches (four rows per wave, block backward lowered
+    to this size by the conftest) and k-NN batches (row kernels, graph backward)."""
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(90, seed=12, extra_bonds=3.9, eig_dim=6) if gen == "molecules" else synth.knn_batch(9, seed=12)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    torch.manual_seed(0)
+    scalers = "identity amplification attenuation" if hidden == 75 else "identity"
+    layer = dgn_amd.DGNLayer(hidden, hidden, 0.0, True, True, aggs, scalers, {"log": torch.tensor(avg)}, "simple", True, edge_features=False, edge_dim=0).model.to(dev).train()
+    gen_ = torch.Generator().manual_seed(3)
+    h, ct = torch.randn(N, hidden, generator=gen_).to(dev), torch.randn(N, hidden, generator=gen_).to(dev)
+    snorm = b["snorm_n"].to(dev)
+    sd0 = copy.deepcopy(layer.state_dict())
+    outs = []
+    for direct in (1, 0):
+        monkeypatch.setattr(_lib.options, "odd_direct", direct)
+        layer.load_state_dict(sd0)
+        graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+        hh = h.clone().requires_grad_(True)
+        y = layer(graph, hh, None, snorm)
+        g = torch.autograd.grad(y, [hh] + list(layer.parameters()), ct)
+        outs.append([y.detach()] + list(g))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
