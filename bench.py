@@ -715,17 +715,32 @@ def run_c5_layer(args, wl, rank, world, dev, steps=None, warmup=None, tag=None):
         agg = layer.aggregate(graph, h, plan, graph.ndata["eig"])
         parts["sweep (scalers folded: [N, 1024] aggregates written)"] = event_ms(lambda: layer.aggregate(graph, h, plan, graph.ndata["eig"]), steps, dev)
         parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] = event_ms(lambda: node_linear(agg, w_f), steps, dev)
+        from dgn_amd import ops as _ops
+        from dgn_amd.dgn_layer import _scale_table
+        split = None
+        if _ops.dc_posttrans_split_supported(graph, agg, F_, S_):
+            sc = _scale_table(graph, layer.plan.applied_scalers, layer._avg_log)
+            n_hub = int(graph.degree_classes_split()["hub_rows"].numel())
+            split_ms = event_ms(lambda: _ops.dc_posttrans_split(graph, agg, lin.weight, lin.bias, sc, None, A_, F_), steps, dev)
+            split = dict(ms=split_ms, hub_rows=n_hub, flops=2.0 * (N - n_hub) * (A_ * F_) * F_ + 2.0 * n_hub * (A_ * F_) * (S_ * F_))
         del agg
     A, S, Ku, x, r = plan_model(dgn_amd.make_plan(wl["aggregators"].split(), wl["scalers"].split()))
     fused_bytes = E * (4 + 4 * F_ + 4 * Ku) + N * (4 + 4 * Ku + 4 * F_ + 4 * F_)
     unfused_bytes = E * (4 + 4 * F_ + 4 * Ku) + N * (4 + 4 * Ku + 4 * F_) + 2 * N * 4 * A * F_ + 2 * N * 4 * S * F_ + N * 4 * 2 * F_
     flops = 2.0 * N * (A * F_) * (S * F_)
+    prod_key = "posttrans product 1024 -> 384 (exact-fp32 MFMA)"
+    if split is not None:      # the route the layer takes: the MFMA fraction is priced on ITS flops and time
+        parts["(not on the layer's route) folded product 1024 -> 384 on all rows"] = parts[prod_key]
+        parts[prod_key], flops = split["ms"], split["flops"]
     result = dict(ms_per_step=ms, value=E / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N, scaling="weak", parallelism="single GPU",
-                  roofline=dict(bound="mfma", kernel="posttrans product of the layer (tile_gemm / ts_gemm, v_mfma_f32_16x16x4_f32)",
+                  roofline=dict(bound="mfma", kernel="posttrans product of the layer (dc_gemm + tile_gemm on the hub rows, v_mfma_f32_16x16x4_f32)",
                                 achieved=flops / (parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12,
                                 unit="TFLOP/s", frac=flops / (parts["posttrans product 1024 -> 384 (exact-fp32 MFMA)"] * 1e-3) / MFMA_F32_PEAK, traffic=None,
                                 kernels={k: dict(ms=v) for k, v in parts.items()},
                                 model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, layer_flops=flops, fused_layer_bytes=fused_bytes,
+                                           hub_rows=None if split is None else split["hub_rows"],
+                                           posttrans_route="folded 1024 -> 384 product" if split is None else
+                                           "one 1024 -> 128 product per in-degree class below 32, folded product on the gathered hub rows",
                                            unfused_layer_bytes=unfused_bytes, sweep_only_bytes_c5=algorithmic_bytes(N, E, F_, A, S, Ku, x, r)[0],
                                            hbm_frac_on_fused_bytes=fused_bytes / (ms * 1e-3) / HBM_PEAK,
                                            mfma_floor_ms=flops / MFMA_F32_PEAK * 1e3)))

@@ -321,7 +321,8 @@ def _block_route_ok(layer, h) -> bool:
     return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training == torch.is_grad_enabled() and (layer.training or not h.requires_grad)
             and layer.batch_norm and h.is_cuda
             and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES
-            and all(bn.momentum is not None and bn.track_running_stats and bn.affine for bn in _bns_of(layer)))
+            and all(bn.momentum is not None and bn.track_running_stats and bn.affine and not _ops._spans_ranks(bn, layer.training)
+                    for bn in _bns_of(layer)))
 
 
 def _bns_of(layer):
@@ -411,6 +412,17 @@ class DGNLayerSimple(nn.Module):
                 # scalers folded behind the Linear: sweep without scalers -> one GEMM -> scale-combine (+bias, +snorm)
                 S = self.plan.n_scalers
                 agg = self.aggregate(graph, hp, self._kplan, eig)                             # [N, A*Fp]
+                if _ops.dc_posttrans_split_supported(graph, agg, fo, S):
+                    # inference on a graph that may hold hub rows: one product per in-degree class, the hubs on the folded product
+                    sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+                    h = _ops.dc_posttrans_split(graph, agg, lin.weight, lin.bias, sc, snorm_n if self.graph_norm else None, A, F0)
+                    del agg
+                    if self.batch_norm:
+                        h = bn_tail(h, self.batchnorm_h, self.training, relu=True, residual=h_in if self.residual else None)
+                    else:
+                        h = F.relu(h)
+                        h = h_in + h if self.residual else h
+                    return _dropout(h, self.dropout, self.training)
                 w = _pad_blocks(lin.weight, S * A, F0, Fp).reshape(fo, S, A * Fp).permute(1, 0, 2).reshape(S * fo, A * Fp)
                 z = node_linear(agg, w)
                 sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)

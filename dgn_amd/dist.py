@@ -157,6 +157,78 @@ class FlatGradAllReduce:
         torch._foreach_copy_(grads, self.views)
 
 
+# ---- SyncBN (optional): BatchNorm over the union of every rank's rows ---------------------------------------------------
+# Plain data parallelism normalises each shard with its own statistics (what FlatGradAllReduce's parity test pins).  With the modules
+# below, a step over W shards is the step of ONE process over the whole batch: per BatchNorm one all-reduce of [2 F + 1] sums forward
+# (sum, sum of squares, row count: shards are uneven) and one of [2 F] backward (sum g, sum g xhat), torch.nn.SyncBatchNorm's scheme on
+# any backend (gloo on CPU included, which torch's own module refuses).  The layer's fused tail / whole-layer / graph-block calls compute
+# their statistics in-kernel over the local rows, so layers holding these modules take the per-kernel route (ops.bn_tail_supported).
+
+class _SyncBN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, group):
+        F_ = x.shape[1]
+        stats = torch.empty(2 * F_ + 1, dtype=torch.float64 if x.dtype == torch.float64 else torch.float32, device=x.device)
+        stats[:F_], stats[F_:2 * F_], stats[2 * F_] = x.sum(0), (x * x).sum(0), float(x.shape[0])
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        n = stats[2 * F_]
+        mean = stats[:F_] / n
+        var = (stats[F_:2 * F_] / n - mean * mean).clamp_min(0)             # biased, as F.batch_norm normalises
+        invstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * invstd
+        ctx.save_for_backward(xhat, gamma, invstd, n)
+        ctx.group = group
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * gamma + beta, mean, var, n
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv, _gn):
+        xhat, gamma, invstd, n = ctx.saved_tensors
+        F_ = g.shape[1]
+        sums = torch.cat([g.sum(0), (g * xhat).sum(0)])
+        g_gamma, g_beta = sums[F_:].clone(), sums[:F_].clone()              # local sums: the gradient all-reduce averages them
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
+        g_x = (g - sums[:F_] / n - xhat * (sums[F_:] / n)) * (gamma * invstd)
+        return g_x, g_gamma, g_beta, None, None
+
+
+def sync_batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, group=None):
+    """Training-mode BatchNorm of ``x [n_local, F]`` over the rows of ALL ranks; running statistics updated in place with the global
+    mean and the unbiased global variance (torch's rule)."""
+    y, mean, var, n = _SyncBN.apply(x, gamma, beta, float(eps), group)
+    with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+        running_var.mul_(1 - momentum).add_((var * (n / (n - 1).clamp_min(1))).to(running_var.dtype), alpha=momentum)
+    return y
+
+
+class SyncBatchNorm1d(torch.nn.BatchNorm1d):
+    """``nn.BatchNorm1d`` with the same parameters, buffers and ``state_dict`` keys whose training-mode statistics span every rank."""
+    dgn_sync = True
+    process_group = None
+
+    def forward(self, x):
+        if not (self.training and dist.is_initialized() and dist.get_world_size(self.process_group) > 1 and self.affine
+                and self.track_running_stats and self.momentum is not None):
+            return super().forward(x)
+        self.num_batches_tracked.add_(1)
+        return sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, self.process_group)
+
+
+def convert_sync_batchnorm(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """Replace every ``nn.BatchNorm1d`` under ``module`` (the layers' ``batchnorm_h``, the MLPs' ``b_norm``) by a ``SyncBatchNorm1d``
+    that SHARES its parameters and buffers (optimizer state and ``state_dict`` stay valid).  Returns ``module``."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.BatchNorm1d) and not isinstance(child, SyncBatchNorm1d):
+            new = SyncBatchNorm1d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
+            new._parameters, new._buffers = child._parameters, child._buffers
+            new.training, new.process_group = child.training, process_group
+            setattr(module, name, new)
+        else:
+            convert_sync_batchnorm(child, process_group)
+    return module
+
+
 def gather_rank_stats(values: Sequence[float], device) -> List[List[float]]:
     """Every rank's list of numbers on every rank (one all-gather of a small fp64 tensor): per-rank shard sizes and collective
     timings for bench.py's line.  Without a process group: this rank's values alone."""

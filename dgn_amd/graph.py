@@ -192,7 +192,7 @@ class DGNGraph:
     def invalidate_caches(self) -> None:
         """Drop everything derived from the graph's content (edge weights, scaler tables, slot -> destination map)."""
         self._wcache.clear()
-        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_scale", "_blk", "_blk_tables"):
+        for k in ("_scale_cache", "_dst_slots", "_eig_norm", "_slot_types", "_dc", "_dc_split", "_dc_scale", "_blk", "_blk_tables"):
             self.__dict__.pop(k, None)
         if hasattr(self, "_c"):
             self._c.blk_cut, self._c.blk_gap = None, 0      # (the cut tensor is gone with "_blk": never leave its address behind)
@@ -291,6 +291,38 @@ class DGNGraph:
             rep = torch.where(counts > 0, order[first.clamp(max=N - 1)], torch.zeros_like(first))
             dc = dict(n_units=n_units, vperm=vperm, unit_class=uc.int().contiguous(), present=counts.int().contiguous(), rep=rep)
         self._dc = dc
+        return dc
+
+    def degree_classes_split(self):
+        """The virtual row space of ``degree_classes()`` for a graph WITH hub rows (power-law graphs: C5 has 6 % of its rows at an
+        in-degree >= ``DC_CLASSES``): the rows below that in-degree are sorted into the class units, the hub rows are left OUT of it
+        and returned as ``hub_rows`` (int64, ascending) -- their posttrans takes the folded product on the gathered rows
+        (ops.dc_posttrans_split).  ``None`` for padded / bipartite graphs.  Built once per graph (two host read-backs), torch ops."""
+        if "_dc_split" in self.__dict__:
+            return self._dc_split
+        dc = None
+        N = self.num_nodes
+        if N > 0 and self.in_degree is not None and getattr(self, "_pad", None) is None and self.num_src == self.num_nodes:
+            dev = self.device
+            key = self.in_degree.long().clamp(max=DC_CLASSES)               # (class DC_CLASSES: the hubs, sorted last, not placed)
+            skey, order = torch.sort(key, stable=True)
+            counts = torch.zeros(DC_CLASSES + 1, dtype=torch.int64, device=dev).scatter_add_(0, key, torch.ones_like(key))
+            n_hub = int(counts[DC_CLASSES].item())
+            counts = counts[:DC_CLASSES]
+            n_low = N - n_hub
+            padded = (counts + DC_UNIT - 1) // DC_UNIT * DC_UNIT
+            seg_end = torch.cumsum(padded, 0)
+            seg_start, first = seg_end - padded, torch.cumsum(counts, 0) - counts
+            n_units = int(seg_end[-1].item()) // DC_UNIT
+            lkey, lorder = skey[:n_low], order[:n_low]
+            pos = seg_start[lkey] + (torch.arange(n_low, device=dev) - first[lkey])
+            vperm = torch.full((max(n_units, 1) * DC_UNIT,), -1, dtype=torch.int32, device=dev)
+            vperm[pos] = lorder.int()
+            uc = torch.searchsorted(seg_end, torch.arange(n_units, device=dev) * DC_UNIT, right=True)
+            rep = torch.where(counts > 0, order[first.clamp(max=N - 1)], torch.zeros_like(first))
+            dc = dict(n_units=n_units, vperm=vperm, unit_class=uc.int().contiguous(), present=counts.int().contiguous(), rep=rep,
+                      hub_rows=order[n_low:].contiguous())                   # (stable sort: ascending node ids)
+        self._dc_split = dc
         return dc
 
     def ensure_csc(self) -> None:

@@ -610,10 +610,15 @@ def bn_tail_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, runn
     return y
 
 
+def _spans_ranks(bn, training: bool) -> bool:
+    """A dist.SyncBatchNorm1d in training mode: its statistics come from an all-reduce, not from the local rows the fused kernels see."""
+    return training and getattr(bn, "dgn_sync", False) and torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
 def bn_tail_supported(bns, x: torch.Tensor, training: bool, width: Optional[int] = None) -> bool:
     """What the fused tail kernels cover: affine BatchNorm with running statistics, F <= 1024 (``width``, default
     ``x.shape[1]``), and -- with gradients -- training mode."""
-    simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
+    simple = all(b.affine and b.track_running_stats and b.momentum is not None and not _spans_ranks(b, training) for b in bns)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
     return simple and (x.shape[1] if width is None else width) <= 1024 and (training or not needs_grad)
 
@@ -627,7 +632,7 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
     if not isinstance(bns, (list, tuple)):
         bns = [bns]
     b0 = bns[0]
-    simple = all(b.affine and b.track_running_stats and b.momentum is not None for b in bns)
+    simple = all(b.affine and b.track_running_stats and b.momentum is not None and not _spans_ranks(b, training) for b in bns)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in bns for p in b.parameters()))
     if not simple or x.shape[1] > 1024 or (not training and needs_grad):   # (fused: training-mode backward, F <= 1024)
         # configurations the fused kernels do not cover: plain torch modules
@@ -635,7 +640,17 @@ def bn_tail(x: torch.Tensor, bns, training: bool, relu: bool = False, residual: 
             raise _lib.DgnError("padded batch (n_valid): this BatchNorm configuration runs on plain torch modules, which would count the "
                                 "padding rows in the batch statistics; use affine BatchNorm with running statistics, width <= 1024")
         w = x.shape[1] // len(bns)
-        y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)
+        if len(bns) > 1 and all(_spans_ranks(b, training) and b.affine and b.track_running_stats and b.momentum is not None for b in bns):
+            # the towers' SyncBatchNorm1d modules as ONE BatchNorm of width T * fo: one all-reduce per direction instead of T
+            from .dist import sync_batch_norm
+            rm, rv = torch.cat([b.running_mean for b in bns]), torch.cat([b.running_var for b in bns])
+            y = sync_batch_norm(x, torch.cat([b.weight for b in bns]), torch.cat([b.bias for b in bns]), rm, rv, b0.momentum, b0.eps, b0.process_group)
+            with torch.no_grad():
+                torch._foreach_copy_([b.running_mean for b in bns], list(rm.split(w)))
+                torch._foreach_copy_([b.running_var for b in bns], list(rv.split(w)))
+                torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
+        else:
+            y = torch.cat([b(x[:, i * w:(i + 1) * w]) for i, b in enumerate(bns)], dim=1) if len(bns) > 1 else b0(x)
         y = torch.relu(y) if relu else y
         return y + residual if residual is not None else y
     cat = (lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts))
@@ -1204,6 +1219,58 @@ def _dc_struct(dc):
     g, cls_scale = dc
     return _lib.DgnDegreeClasses(n_units=g["n_units"], vperm=g["vperm"].data_ptr(), unit_class=g["unit_class"].data_ptr(),
                                  present=g["present"].data_ptr(), scale=cls_scale.data_ptr())
+
+
+# Graphs WITH hub rows (in-degree >= DGN_DC_CLASSES: power-law graphs), no gradients recorded: the rows below that in-degree take the
+# degree-class product, the hub rows the folded product on their gathered aggregate rows.  C5 (10 M rows, 6 % hubs, 8 aggregators x 3
+# scalers, hidden 128): 2 N_low K f_out + 2 N_hub K S f_out flops instead of 2 N K S f_out (0.37x).
+DC_SPLIT = os.environ.get("DGN_DC_SPLIT", "1") != "0"
+
+
+def dc_posttrans_split_supported(graph: DGNGraph, agg: torch.Tensor, fo: int, S: int) -> bool:
+    if not (DC_SPLIT and DC_POSTTRANS and S > 1 and agg.is_cuda and agg.dtype == torch.float32 and not torch.is_grad_enabled()
+            and graph.num_nodes >= DC_MIN_NODES and getattr(graph, "_pad", None) is None and graph.num_src == graph.num_nodes):
+        return False
+    return bool(_lib.load().dgn_dc_supported(agg.shape[1], fo))
+
+
+def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], scale: torch.Tensor,
+                       row_scale: Optional[torch.Tensor], n_agg: int, f_in: int) -> torch.Tensor:
+    """``snorm * posttrans(cat_s(scale_s * agg))`` (nets/dgn_layer.py:186-193 with the scalers of scalers.py:7-18) WITHOUT gradients on a
+    graph that may hold hub rows: ``agg [N, n_agg * f_pad]`` the scaler-free aggregates, ``weight [f_out, S * n_agg * f_in]`` the
+    posttrans Linear in the reference's layout, ``scale [N, S]`` the per-node scaler table.  Rows of in-degree < DGN_DC_CLASSES:
+    dgn_dc_fold + dgn_dc_gemm (one f_out-column product per in-degree class); hub rows: gathered, folded product (S f_out columns),
+    scale-combine, written back by row index."""
+    lib = _lib.load()
+    dc = graph.degree_classes_split()
+    if dc is None:
+        raise RuntimeError("dc_posttrans_split: the graph has no degree classes (padded or bipartite)")
+    N, K = agg.shape
+    fo, S = weight.shape[0], scale.shape[1]
+    f_pad = K // n_agg
+    weight = weight.contiguous()
+    row_scale = None if row_scale is None else row_scale.reshape(-1).contiguous()
+    y = torch.empty(N, fo, dtype=torch.float32, device=agg.device)
+    stream = _lib.stream_ptr(agg.device)
+    if dc["n_units"] > 0:
+        cls_scale = scale.index_select(0, dc["rep"]).contiguous()
+        s = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
+                                  present=dc["present"].data_ptr(), scale=cls_scale.data_ptr())
+        wc = torch.empty(2, _lib.DGN_DC_CLASSES, fo * K, dtype=torch.float32, device=agg.device)
+        lay = _lib.DgnDcLayout(n_agg=n_agg, f_pad=f_pad, f_in=f_in, h_off=0, id_slot=-1, ld=weight.stride(0))
+        _lib.check(lib.dgn_dc_fold(C.byref(s), S, fo, K, 1, weight.data_ptr(), C.byref(lay), wc[0].data_ptr(), wc[1].data_ptr(), stream), "dgn_dc_fold")
+        _lib.check(lib.dgn_dc_gemm(C.byref(s), K, fo, 1, agg.data_ptr(), agg.stride(0), 0, wc[0].data_ptr(), K, fo * K, 0, _ptr(bias), _ptr(row_scale),
+                                   y.data_ptr(), fo, 0, 0, stream), "dgn_dc_gemm")
+    hub = dc["hub_rows"]
+    if hub.numel():
+        w = weight.reshape(fo, S * n_agg, f_in)
+        if f_pad != f_in:
+            w = torch.nn.functional.pad(w, (0, f_pad - f_in))
+        w = w.reshape(fo, S, K).permute(1, 0, 2).reshape(S * fo, K).contiguous()
+        z = node_linear(agg.index_select(0, hub), w)
+        y_hub = scale_combine(z.unsqueeze(0), scale.index_select(0, hub), bias, None if row_scale is None else row_scale.index_select(0, hub))
+        y.index_copy_(0, hub, y_hub)
+    return y
 
 
 def _dense_sizes(cfg, N, dc=False):

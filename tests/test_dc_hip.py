@@ -187,3 +187,87 @@ def test_layer_with_degree_classes_equals_the_folded_route(type_net, F, aggs):
             continue                                                       # (towers: LeakyReLU flips leave no trace in y: next batch)
         return
     pytest.fail("no seeded batch on which the two routes agree in every gradient (ReLU flips cannot explain six batches)")
+
+
+# ---- graphs WITH hub rows (power-law graphs: C5): the rows below DGN_DC_CLASSES on the class product, the hubs on the folded product ----
+
+def _powerlaw(N, E, seed):
+    import dgn_amd
+    from dgn_amd import synth
+    indptr, src, eig = synth.powerlaw_csr(N, E, torch.device("cuda"), seed=seed)
+    return dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig), indptr, src, eig
+
+
+def test_virtual_row_space_with_hub_rows():
+    graph, indptr, _, _ = _powerlaw(30000, 600000, 3)
+    deg = (indptr[1:] - indptr[:-1]).cpu()
+    assert int(deg.max()) >= 32 and graph.degree_classes() is None          # (the plain layout refuses this graph)
+    dc = graph.degree_classes_split()
+    vperm, uc, hub = dc["vperm"].cpu(), dc["unit_class"].cpu(), dc["hub_rows"].cpu()
+    live = vperm[vperm >= 0].long()
+    assert hub.tolist() == torch.nonzero(deg >= 32).flatten().tolist()      # every hub row once, ascending
+    assert sorted(live.tolist()) == torch.nonzero(deg < 32).flatten().tolist()   # every other row exactly once
+    assert vperm.numel() == 64 * dc["n_units"] and bool((uc[1:] >= uc[:-1]).all())
+    for u in range(dc["n_units"]):
+        rows = vperm[64 * u: 64 * u + 64]
+        rows = rows[rows >= 0].long()
+        assert rows.numel() > 0 and bool((deg[rows] == uc[u]).all())
+    assert dc["present"].cpu().tolist() == torch.bincount(deg[deg < 32], minlength=32).tolist()
+
+
+@pytest.mark.parametrize("F,aggs,graph_norm", [(128, "mean max min sum std dir1-dx dir2-dx dir3-dx", False), (70, "mean max min dir1-dx dir1-av", True),
+                                               (75, "mean sum max dir1-dx", True)])
+def test_simple_layer_inference_on_a_hub_graph_vs_oracle_and_the_folded_route(F, aggs, graph_norm):
+    """``DGNLayerSimple.forward`` (nets/dgn_layer.py:178-202) in eval() under no_grad on a power-law graph (in-degrees from 1 to the
+    thousands): the split degree-class route against the oracle's layer and against the folded product + scale-combine."""
+    import numpy as np
+    import dgn_amd
+    from dgn_amd import ops
+    from oracle import dgn_oracle as orc
+    N = 20000
+    graph, indptr, src, eig = _powerlaw(N, 400000, 5)
+    scalers = "identity amplification attenuation"
+    deg = (indptr[1:] - indptr[:-1])
+    avg = float(torch.log(deg.double() + 1).mean())
+    torch.manual_seed(7)
+    layer = dgn_amd.DGNLayer(F, F, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(avg)}, "simple", True, towers=1, edge_features=False,
+                             edge_dim=0).model
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        layer.batchnorm_h.running_mean.copy_(torch.randn(F, generator=gen) * 0.1)
+        layer.batchnorm_h.running_var.copy_(torch.rand(F, generator=gen) + 0.5)
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    h = torch.randn(N, F, generator=gen)
+    snorm = torch.rand(N, 1, generator=gen) + 0.5
+    dst = torch.repeat_interleave(torch.arange(N), deg.cpu())
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg), graph_norm=graph_norm, batch_norm=True, residual=True, towers=1,
+               divide_input=False, edge_features=False)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        sdt = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+        c = dict(cfg, avg_log=cfg["avg_log"].to(dt))
+        res[dt] = orc.layer_forward("simple", sdt, c, src.cpu().long(), dst, N, eig.cpu().to(dt), h.to(dt), None, snorm.to(dt), training=False)[0]
+    layer = layer.cuda().eval()
+    out, calls = {}, []
+    real = ops.dc_posttrans_split
+    ops.dc_posttrans_split = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    min_default = ops.DC_MIN_NODES
+    try:
+        for on in (True, False):
+            ops.DC_SPLIT = on
+            with torch.no_grad():
+                out[on] = layer(graph, h.cuda(), None, snorm.cuda()).cpu()
+    finally:
+        ops.DC_SPLIT, ops.DC_MIN_NODES, ops.dc_posttrans_split = True, min_default, real
+    assert len(calls) == 1                                                   # the split route ran (and only when switched on)
+    _close(out[True], out[False].double(), 2e-5)
+    # against the oracle: as good as its own fp32 evaluation is against fp64 (max / min routing apart), or 1e-5 of the scale
+    r32, r64 = res[torch.float32].double(), res[torch.float64]
+    scale = float(r64.abs().max())
+    err = (out[True].double() - r64).abs()
+    bound = 1e-5 * scale + 4 * (r32 - r64).abs()
+    assert float((err > bound).float().mean()) <= 1e-4, float((err / scale).max())
+    np.testing.assert_allclose(out[True].numpy(), res[torch.float32].numpy(), rtol=2e-3, atol=2e-4 * scale)

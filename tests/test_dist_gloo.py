@@ -54,11 +54,12 @@ def _shard_batch(b, offs, edge_gid, h, graph_ids):
     return g, h[nodes], b["snorm_n"][nodes]
 
 
-def _build_layer():
+def _build_layer(type_net="towers"):
     import dgn_amd
     torch.manual_seed(3)
     layer = dgn_amd.DGNLayer(10, 10, 0.0, True, True, "mean max dir1-dx dir1-av", "identity amplification attenuation",
-                             {"log": torch.tensor(1.0)}, "towers", True, towers=5, edge_features=False, edge_dim=0).model
+                             {"log": torch.tensor(1.0)}, type_net, True, towers=5 if type_net == "towers" else 1, edge_features=False,
+                             edge_dim=0).model
     gen = torch.Generator().manual_seed(4)
     with torch.no_grad():
         for p in layer.parameters():
@@ -105,6 +106,62 @@ def _worker(rank, world, port, out_path):
         torch.save({n: p.grad.clone() for n, p in layer.named_parameters()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _sync_worker(rank, world, port, out_path, type_net):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from dgn_amd import dist as ddist
+    from dgn_amd import ops
+    import dgn_amd.dgn_layer as dl
+    ddist.init_from_env("gloo")
+    _install_oracle_backend()
+    dl.bn_tail = ops.bn_tail                      # (the product's own tail: with SyncBatchNorm1d modules it must leave the fused kernels)
+    b, offs, edge_gid, epg, h = _make_problem()
+    shards = ddist.shard_by_edges(epg, world)
+    layer = ddist.convert_sync_batchnorm(_build_layer(type_net))
+    assert all(type(m).__name__ != "BatchNorm1d" for m in layer.modules())
+    g, hs, sn = _shard_batch(b, offs, edge_gid, h, shards[rank])
+    _loss_backward(layer, g, hs, sn)
+    ddist.FlatGradAllReduce(layer.parameters())()
+    if rank == 0:
+        torch.save(dict(grads={n: p.grad.clone() for n, p in layer.named_parameters()}, buffers={n: v.clone() for n, v in layer.named_buffers()},
+                        keys=list(layer.state_dict().keys())), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,type_net", [(2, "towers"), (3, "simple")])
+def test_sync_batchnorm_equals_one_process_over_the_whole_batch(tmp_path, world, type_net):
+    """SURVEY 8(e), optional SyncBN: with ``dist.convert_sync_batchnorm`` a data-parallel step over (uneven) shards is the step of one
+    process over the union batch -- parameter gradients after the flat all-reduce, BatchNorm running statistics, state_dict keys."""
+    out_path = str(tmp_path / "sync.pt")
+    mp.spawn(_sync_worker, args=(world, _free_port(), out_path, type_net), nprocs=world, join=True)
+    got = torch.load(out_path)
+
+    from dgn_amd import dist as ddist
+    import dgn_amd.dgn_layer as dl
+    saved = (dl.directional_aggregate, dl.scale_combine, dl.bn_tail, dl.bn_tail_fused, dl.combine_bn_tail)
+    try:
+        _install_oracle_backend()
+        b, offs, edge_gid, epg, h = _make_problem()
+        shards = ddist.shard_by_edges(epg, world)
+        layer = _build_layer(type_net)
+        order = [gi for sh in shards for gi in sh]
+        g, hs, sn = _shard_batch(b, offs, edge_gid, h, order)                 # the union batch, graphs in shard order
+        y = layer(g, hs, None, sn)
+        rows = [sum(offs[gi + 1] - offs[gi] for gi in sh) for sh in shards]
+        loss = sum((part * part).mean() for part in torch.split(y, rows)) / world
+        loss.backward()
+    finally:
+        dl.directional_aggregate, dl.scale_combine, dl.bn_tail, dl.bn_tail_fused, dl.combine_bn_tail = saved
+    assert got["keys"] == list(layer.state_dict().keys())
+    for n, p in layer.named_parameters():
+        torch.testing.assert_close(got["grads"][n], p.grad, rtol=2e-5, atol=2e-6, msg=n)
+    for n, v in layer.named_buffers():
+        torch.testing.assert_close(got["buffers"][n], v, rtol=1e-5, atol=1e-6, msg=n)
 
 
 def test_shard_by_edges_balances():
