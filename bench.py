@@ -16,7 +16,8 @@ processes its own 12k-molecule batch (weak scaling: seed 41 + rank), or -- ``--s
 shard of ONE global batch (``dist.shard_by_edges``; SURVEY 8(e): ogbg-molhiv batch 2048 split over the ranks).
 The default single-GPU run also appends short sub-results (``extra``) for the other BASELINE configs (c1, c3, c4, c5) and for the
 headline layer and the shipped ZINC json layer AT THE REFERENCE'S OWN BATCH SIZE (c2_b128, zinc_json_b128: 128 molecules, the graph-block
-route of csrc/dgn_blk_layer.hip), the batch-sized legs both eager and as a captured HIP graph (``captured_ms_per_step``); ``--all-extras``
+route of csrc/dgn_blk_layer.hip), the batch-sized legs both eager and as a captured HIP graph (``captured_ms_per_step``), and the C5 graph
+through a whole simple layer forward (c5_layer: row f1; its ``frac`` is of the fp32 MFMA peak on the posttrans product); ``--all-extras``
 adds every other leg.
 
 Besides the contract keys the line carries
@@ -1036,7 +1037,8 @@ def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
     # default: the BASELINE five (c2 is the headline); everything else behind --all-extras (VERDICT r03 item 1)
-    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1)]
+    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1),
+            ("c5_layer", 3, 1)]      # (row f1 on the driver line: the C5 graph through a whole simple layer forward)
     if args.all_extras:
         plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
                 ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30),
@@ -1148,6 +1150,8 @@ def compact_line(line):
             ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step", "eval_fwd_ms") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
+                if e["roofline"].get("bound") == "mfma":      # (c5_layer: the fraction is of the fp32 MFMA peak, on the posttrans product)
+                    ee["bound"] = "mfma"
                 if isinstance(e["roofline"].get("step"), dict):
                     ee["step_frac"] = e["roofline"]["step"].get("frac")
             if e.get("cpu_baseline"):

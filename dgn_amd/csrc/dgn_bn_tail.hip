@@ -369,8 +369,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
-__global__ __launch_bounds__(256) void dropout_fwd(int64_t n, const float* __restrict__ x, uint32_t threshold, float scale,
-                                                   const int64_t* __restrict__ seed, uint64_t offset, float* __restrict__ y,
+__global__ __launch_bounds__(256) void dropout_fwd(int64_t n, const float* x /* may be y: in place */, uint32_t threshold, float scale,
+                                                   const int64_t* __restrict__ seed, uint64_t offset, float* y,
                                                    unsigned char* __restrict__ mask) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // group of 8 elements
     const int64_t e0 = g * 8;
@@ -409,8 +409,8 @@ __global__ __launch_bounds__(256) void dropout_fwd(int64_t n, const float* __res
         for (int i = 0; i < 8; ++i) if (e0 + i < n) y[e0 + i] = v[i];
     }
 }
-__global__ __launch_bounds__(256) void dropout_bwd(int64_t n, const float* __restrict__ gy, const unsigned char* __restrict__ mask, float scale,
-                                                   float* __restrict__ gx) {
+__global__ __launch_bounds__(256) void dropout_bwd(int64_t n, const float* gy /* may be gx: in place */, const unsigned char* __restrict__ mask, float scale,
+                                                   float* gx) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t e0 = g * 8;
     if (e0 >= n) return;

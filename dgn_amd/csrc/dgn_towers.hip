@@ -96,6 +96,18 @@ using namespace dgn;
         if (_rc != 0) return _rc; \
     } while (0)
 
+namespace {
+// DgnTowersLayer.drop_*: complete, a probability below 1, and the materialised normalised rows the mask is applied to
+bool drop_ok(const DgnTowersLayer* L, const char* fn, bool forward) {
+    if (L->drop_p == 0.0f) return true;
+    if (!(L->drop_p > 0.0f && L->drop_p < 1.0f) || !L->y1 || (forward && !L->drop_seed) || !L->drop_mask || L->zmask || !L->z) {
+        dgn::set_error("%s: dropout needs 0 < drop_p < 1, y1, z, drop_mask (the forward: drop_seed), and no zmask", fn);
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
 extern "C" int dgn_towers_layer_supported(int32_t n_towers, int32_t f_in, int32_t f_out, int32_t n_scalers, int32_t n_agg_total) {
     const int Fm = n_towers * f_in, Fo = n_towers * f_out, K = n_agg_total * f_in;
     return n_towers >= 1 && n_scalers >= 1 && n_scalers <= 3 && dgn_linear_supported(Fm, 2 * Fm, 1) && dgn_linear_supported(2 * Fm, Fm, 0) &&
@@ -133,6 +145,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     if (d.N == 0) return DGN_OK;
     if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || (!L->z && !L->zmask) || !L->out || !L->save_mean ||
         !L->save_invstd || (d.S > 1 && !L->scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
+    if (!drop_ok(L, fn, true)) return DGN_ERR_INVALID;
     const size_t bn_ws = up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
     if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
     char* ws = static_cast<char*>(L->ws);
@@ -151,6 +164,8 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     // (y1 == NULL: statistics only -- the mixing Linear normalises y0 while it stages its strips, the normalised tensor is never written)
     DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
                                 nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
+    // the towers' dropout, on the normalised rows in place                                   (:275)
+    if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_forward(d.N * d.Fo, L->y1, L->drop_p, L->drop_seed, L->drop_offset, L->y1, L->drop_mask, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
     static const bool no_mix_fused = getenv("DGN_NO_MIX_FUSED") != nullptr;
     const bool al = ((reinterpret_cast<uintptr_t>(L->z) | reinterpret_cast<uintptr_t>(L->zmask) | reinterpret_cast<uintptr_t>(L->out) |
@@ -210,6 +225,7 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     if (d.N == 0) return DGN_OK;
     if (!G->g_out || !G->g_h || !G->g_w_sd || !G->g_bias_sd || !G->g_w_post || !G->g_b_post || !G->g_gamma || !G->g_beta || !G->g_w_mix ||
         !G->g_b_mix) { set_error("%s: null gradient buffer", fn); return DGN_ERR_INVALID; }
+    if (!drop_ok(L, fn, false)) return DGN_ERR_INVALID;
     const BwdScratch s = bwd_scratch(L, d);
     if (!L->ws || L->ws_bytes < s.total) { set_error("%s: workspace too small (%zu < %zu)", fn, L->ws_bytes, s.total); return DGN_ERR_WORKSPACE; }
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -237,6 +253,8 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
         else DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, nullptr, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
                                          ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
     }
+    // the towers' dropout: the mask on the gradient of the normalised rows, in place         (:275)
+    if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_backward(d.N * d.Fo, g_y1, L->drop_mask, L->drop_p, g_y1, stream));
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
     DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
                                  G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));

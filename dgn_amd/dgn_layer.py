@@ -119,21 +119,31 @@ def _dropout(x, p, training):
     the run) and a call counter as the stream offset: no per-call seed kernel -- at the reference's batch sizes the layer is
     launch-bound and a ``torch.randint`` per layer call costs as much as the dropout itself."""
     if training and p > 0 and x.is_cuda and x.dtype == torch.float32:
-        st = _DROP_STATE.get(x.device)
-        if st is None:
-            if torch.cuda.is_current_stream_capturing():
-                # (the key would be allocated from the capture's private pool and drawn by a captured randint: every replay the same key)
-                raise RuntimeError("dgn_amd dropout: the first dropout call of a device must run outside a stream capture "
-                                   "(run one warm-up step, or call dgn_amd.dgn_layer.set_dropout_state(device, key, 0) first)")
-            st = _DROP_STATE[x.device] = [torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=x.device), 0]
-        st[1] += 1
-        y = _ops.dropout(x, p, True, seed=st[0], offset=st[1])
-        if torch.cuda.is_current_stream_capturing():
-            # inside a capture the call counter is frozen into the graph: the KEY moves instead, on the device, as part of the captured
-            # work -- every replay draws new masks (tests/test_dropout_gpu.py::test_captured_dropout_draws_new_masks_per_replay)
-            st[0].add_(1)
+        seed, offset = _next_dropout_key(x.device)
+        y = _ops.dropout(x, p, True, seed=seed, offset=offset)
+        _dropout_key_used(seed)
         return y
     return F.dropout(x, p, training=training)
+
+
+def _next_dropout_key(device):
+    """(key tensor, stream offset) of the next dropout call on ``device``; ``_dropout_key_used(key)`` after the kernels are enqueued."""
+    st = _DROP_STATE.get(device)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            # (the key would be allocated from the capture's private pool and drawn by a captured randint: every replay the same key)
+            raise RuntimeError("dgn_amd dropout: the first dropout call of a device must run outside a stream capture "
+                               "(run one warm-up step, or call dgn_amd.dgn_layer.set_dropout_state(device, key, 0) first)")
+        st = _DROP_STATE[device] = [torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device), 0]
+    st[1] += 1
+    return st[0], st[1]
+
+
+def _dropout_key_used(seed):
+    if torch.cuda.is_current_stream_capturing():
+        # inside a capture the call counter is frozen into the graph: the KEY moves instead, on the device, as part of the captured
+        # work -- every replay draws new masks (tests/test_dropout_gpu.py::test_captured_dropout_draws_new_masks_per_replay)
+        seed.add_(1)
 
 
 def reset_dropout_state():
@@ -818,10 +828,11 @@ class DGNLayerTower(nn.Module):
     def _whole_layer(self, g, h, snorm_n):
         """The layer through dgn_towers_layer_forward / _backward (one C call per direction), or None when the configuration
         is outside that entry point's domain: training-mode BatchNorm, mixing network Linear -> LeakyReLU, no edge features,
-        no dropout, identity among the scalers, widths the streaming Linear kernels take."""
+        identity among the scalers, widths the streaming Linear kernels take.  The towers' dropout (:275) rides in the call (the
+        normalised rows are then materialised and masked in place)."""
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
         if not (_ops.WHOLE_LAYER and self.training and torch.is_grad_enabled() and self.batch_norm and T > 1 and self.divide_input
-                and not self.edge_features and self.dropout == 0 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+                and not self.edge_features and 0 <= self.dropout < 1 and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
                 and _identity_slot(self.plan.applied_scalers) is not None and self._fusable()
                 and towers_layer_supported(T, fi, fo, self.plan.n_scalers, self._kplan_x.n_agg)):
             return None
@@ -837,9 +848,16 @@ class DGNLayerTower(nn.Module):
         rm, rv, nbt = self._linked_bn_stats(h.device)
         w_edge = graph.edge_weights(self._kplan_x, eig)
         mix = self.mixing_network.linear
-        return towers_layer(graph, self._kplan_x, self._avg_log, w_edge, h, snorm_n if self.graph_norm else None, sc, rm, rv, nbt,
-                            ops["w_sd"], ops["bias_sd"], ops["w"], ops["b_p"], ops["bn_gamma"], ops["bn_beta"], mix.weight, mix.bias,
-                            T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1])
+        drop = None
+        if self.dropout > 0:
+            seed, offset = _next_dropout_key(h.device)
+            drop = (float(self.dropout), seed, offset)
+        y = towers_layer(graph, self._kplan_x, self._avg_log, w_edge, h, snorm_n if self.graph_norm else None, sc, rm, rv, nbt,
+                         ops["w_sd"], ops["bias_sd"], ops["w"], ops["b_p"], ops["bn_gamma"], ops["bn_beta"], mix.weight, mix.bias,
+                         T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], dropout=drop)
+        if drop is not None:
+            _dropout_key_used(drop[1])
+        return y
 
     def forward(self, g, h, e, snorm_n):
         # (a batch padded to a fixed row capacity carries its valid-row count as a device scalar: BatchNorm must know, ops.padded_rows)

@@ -1059,7 +1059,8 @@ class _TowersLayer(torch.autograd.Function):
     def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var,
                 w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix):
         lib = _lib.load()
-        T, fi, fo, S, residual, momentum, eps, slope = cfg
+        global LAST_DROPOUT_MASK
+        T, fi, fo, S, residual, momentum, eps, slope, drop = cfg
         if not h.is_cuda:
             raise _lib.DgnError("towers_layer: CUDA tensors only (dgn_amd has no CPU path)")
         N, Fm, Fo = h.shape[0], T * fi, T * fo
@@ -1069,7 +1070,8 @@ class _TowersLayer(torch.autograd.Function):
         gamma, beta, w_mix, b_mix = gamma.contiguous(), beta.contiguous(), w_mix.contiguous(), b_mix.contiguous()
         # y1 = BatchNorm(y0) is not materialised (FUSE_BN_MIXING): the mixing Linear and its weight gradient normalise y0 while they
         # stage their strips (dgn_linear_forward_bn / dgn_linear_wgrad_bn) -- one pass and N * Fo saved floats per layer less
-        n_y1 = 0 if FUSE_BN_MIXING else N * Fo
+        # (with the towers' dropout the normalised rows ARE written: the mask is applied to them in place)
+        n_y1 = 0 if FUSE_BN_MIXING and drop is None else N * Fo
         # the mixing network's pre-activation is only needed for the sign of (z + b): where the fused kernels run it is kept as a byte
         # mask (DgnTowersLayer.zmask, 1/8 of the bytes) in the slot z would take
         use_mask = n_y1 == 0 and (h.data_ptr() & 15) == 0 and bool(lib.dgn_towers_layer_zmask_supported(T, fo))
@@ -1091,6 +1093,11 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
+        drop_mask = None
+        if drop is not None:
+            drop_mask = torch.empty(lib.dgn_dropout_mask_bytes(N * Fo), dtype=torch.uint8, device=dev)
+            L.drop_p, L.drop_seed, L.drop_offset, L.drop_mask = drop[0], drop[1].data_ptr(), int(drop[2]), drop_mask.data_ptr()
+            LAST_DROPOUT_MASK = drop_mask
         # what the backward sweep would recompute from the messages (first max / min slot, dx signs): one byte per (row, feature)
         n_aux = int(lib.dgn_towers_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0
         aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
@@ -1102,16 +1109,16 @@ class _TowersLayer(torch.autograd.Function):
         L.n_valid = _ptr(ctx.n_valid)
         stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_towers_layer_forward(C.byref(L), stream), "dgn_towers_layer_forward")
-        ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux)
+        ctx.save_for_backward(w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux, drop_mask)
         ctx.graph, ctx.plan, ctx.avg_log, ctx.cfg = graph, plan, avg_log, cfg
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load()
-        w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux = ctx.saved_tensors
+        w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux, drop_mask = ctx.saved_tensors
         graph, plan = ctx.graph, ctx.plan
-        T, fi, fo, S, residual, momentum, eps, slope = ctx.cfg
+        T, fi, fo, S, residual, momentum, eps, slope, drop = ctx.cfg
         N, Fm, Fo = h.shape[0], T * fi, T * fo
         K = plan.n_agg * fi
         dev = h.device
@@ -1139,6 +1146,8 @@ class _TowersLayer(torch.autograd.Function):
         L.z, L.zmask = (None, z.data_ptr()) if ctx.use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
         L.agg_aux = _ptr(aux)
+        if drop is not None:
+            L.drop_p, L.drop_mask = drop[0], drop_mask.data_ptr()
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
@@ -1157,16 +1166,18 @@ class _TowersLayer(torch.autograd.Function):
 
 def towers_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm, scale, running_mean, running_var, num_batches_tracked,
                  w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, n_towers: int, f_in: int, f_out: int, residual: bool,
-                 momentum: float, eps: float, slope: float) -> torch.Tensor:
+                 momentum: float, eps: float, slope: float, dropout=None) -> torch.Tensor:
     """``DGNLayerTower.forward`` (nets/dgn_layer.py:309-325) of the fused configuration as one autograd node: see
     ``include/dgn_hip.h: DgnTowersLayer`` for the operand layouts (those of ``DGNLayerTower._assemble``) and the sequence of
-    kernels.  Training mode; the BatchNorm running statistics and ``num_batches_tracked`` are updated in place."""
+    kernels.  Training mode; the BatchNorm running statistics and ``num_batches_tracked`` are updated in place.
+    ``dropout``: None, or ``(p, key tensor, offset)`` of the towers' F.dropout (:275) as ``ops.dropout`` takes them."""
     S = 1 if scale is None else scale.shape[1]
     if snorm is not None:
         snorm = snorm.reshape(-1).contiguous()
     if scale is not None:
         scale = scale.contiguous()
-    cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope))
+    drop = None if dropout is None else (float(dropout[0]), dropout[1], int(dropout[2]))
+    cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope), drop)
     out = _TowersLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, running_mean, running_var,
                              w_sd, bias_sd, w_post.contiguous(), b_post, gamma, beta, w_mix, b_mix)
     if num_batches_tracked is not None:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 24
+#define DGN_ABI_VERSION 25
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -328,7 +328,8 @@ int dgn_bias_act_backward(int64_t n_rows, int32_t F, const float* g_y, const flo
  * (nets/dgn_layer.py:130, :201, :275; configs HIV / PCBA / CIFAR10 ship dropout 0.3) -------------------------------------------------
  * y = keep ? x / (1 - p) : 0 over a CONTIGUOUS array; keep bits from Philox4x32-10 keyed by *seed (a DEVICE int64 scalar the caller
  * draws from its generator: capturable) and `offset`; mask: dgn_dropout_mask_bytes(n_elems) bytes, bit i of byte g = element 8 g + i,
- * what the backward re-applies: g_x = keep ? g_y / (1 - p) : 0.  The same (seed, offset) gives the same mask.                       */
+ * what the backward re-applies: g_x = keep ? g_y / (1 - p) : 0.  The same (seed, offset) gives the same mask.  y may be x and g_x
+ * may be g_y (in place).                                                                                                           */
 size_t dgn_dropout_mask_bytes(int64_t n_elems);
 int dgn_dropout_forward(int64_t n_elems, const float* x, float p, const int64_t* seed, uint64_t offset, float* y, unsigned char* mask,
                         void* stream);
@@ -534,6 +535,14 @@ typedef struct DgnTowersLayer {
     /* Optional: dgn_agg_aux_bytes(graph, spec, the sweep's message) bytes -- the forward sweep leaves its aux table here, the
      * backward sweep works from it (dgn_agg_forward_aux / dgn_agg_backward_aux).  NULL: the backward recomputes.                */
     unsigned char* agg_aux;
+    /* Optional: the towers' F.dropout(h, p, training) between BatchNorm and the mixing network (nets/dgn_layer.py:275).  drop_p > 0
+     * needs y1 (the normalised rows are then materialised: the mask is applied to them in place, the mixing Linear and its weight
+     * gradient read the dropped rows), drop_seed / drop_offset as dgn_dropout_forward takes them (forward only), and drop_mask of
+     * dgn_dropout_mask_bytes(N * T * f_out) bytes (written by the forward, read by the backward); zmask must be NULL.                */
+    float drop_p;
+    const int64_t* drop_seed;
+    uint64_t drop_offset;
+    unsigned char* drop_mask;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */

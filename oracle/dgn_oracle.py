@@ -272,7 +272,7 @@ def layer_forward(type_net: str, sd: Dict[str, torch.Tensor], cfg: dict, src, ds
 
     cfg keys: aggregators (str), scalers (str), avg_log, graph_norm, batch_norm, residual,
     edge_features, towers, divide_input; dropout is taken as 0 (parity runs) unless ``dropout = (p, keep)`` is
-    given for a simple / complex layer: the layer's last op ``F.dropout(h, p, training)`` (dgn_layer.py:130, :201)
+    given: the simple / complex layer's last op ``F.dropout(h, p, training)`` (dgn_layer.py:130, :201), every tower's last op (:275)
     with the Bernoulli draw replaced by the given keep mask [N, out_dim] -- ``h * keep / (1 - p)``, F.dropout's own
     arithmetic (torch: ``input * mask * (1 / (1 - p))``).
     Follows dgn_layer.py:178-202 (simple), :103-132 (complex), :254-276 + :309-325 (towers).
@@ -325,7 +325,7 @@ def layer_forward(type_net: str, sd: Dict[str, torch.Tensor], cfg: dict, src, ds
             msg = _pretrans_messages(sd, p, ht, e, src, dst, cfg.get("edge_features"))
             agg = aggregate_graph(src, dst, num_nodes, msg, eig, ht, aggs, scalers, avg_log)
             outs.append(tail(p, _mlp(sd, p + "posttrans", torch.cat([ht, agg], dim=1)), relu=False))
-        y = torch.cat(outs, dim=1)
+        y = drop(torch.cat(outs, dim=1))      # DGNTower's last op on every tower (dgn_layer.py:275): keep is [N, towers * out_tower]
         if towers > 1:
             # FCLayer(out_dim, out_dim, activation='LeakyReLU')  (dgn_layer.py:307, :318-319)
             y = F.leaky_relu(F.linear(y, sd["mixing_network.linear.weight"], sd["mixing_network.linear.bias"]))

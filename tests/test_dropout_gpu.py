@@ -200,3 +200,71 @@ def test_first_dropout_inside_a_capture_is_refused():
     torch.cuda.current_stream().wait_stream(s)
     assert raised
     dgn_amd.reset_dropout_state()
+
+
+def test_towers_layer_with_dropout_in_the_whole_layer_call_vs_oracle_with_the_same_mask(monkeypatch):
+    """``DGNTower``'s F.dropout between BatchNorm and the mixing network (nets/dgn_layer.py:275) inside dgn_towers_layer_forward /
+    _backward (DgnTowersLayer.drop_*): values, d h and every parameter gradient against the oracle fed the keep mask the kernel drew."""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    from oracle import dgn_oracle as orc
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(40, seed=9)
+    src, dst, N, eig, snorm = b["src"], b["dst"], int(b["num_nodes"]), b["eig"], b["snorm_n"]
+    F_, p = 70, 0.3
+    aggs, scalers = "mean max min dir1-av dir1-dx", "identity amplification attenuation"
+    torch.manual_seed(0)
+    layer = dgn_amd.DGNLayer(F_, F_, p, True, True, aggs, scalers, {"log": torch.tensor(1.2)}, "towers", True, towers=5, edge_features=False,
+                             edge_dim=0).model
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for q in layer.parameters():
+            if q.dim() == 2:
+                q.copy_(torch.randn(q.shape, generator=gen) / q.shape[1] ** 0.5)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    h = torch.randn(N, F_, generator=gen)
+    ct = torch.randn(N, F_, generator=gen)
+    layer = layer.to(dev).train()
+    calls = []
+    whole = type(layer)._whole_layer
+    monkeypatch.setattr(type(layer), "_whole_layer", lambda self, *a: calls.append(whole(self, *a)) or calls[-1])
+    monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 0)
+    graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
+    hd = h.to(dev).requires_grad_(True)
+    ops.LAST_DROPOUT_MASK = None
+    y = layer(graph, hd, None, snorm.to(dev))
+    assert calls and calls[-1] is not None, "the whole-layer call did not take the towers layer with dropout on"
+    keep = _bits(ops.LAST_DROPOUT_MASK, N * F_).reshape(N, F_)
+    assert 0.6 < float(keep.mean()) < 0.8
+    (y * ct.to(dev)).sum().backward()
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.2), graph_norm=True, batch_norm=True, residual=True, towers=5,
+               divide_input=True, edge_features=False)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        sdt = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+        ho = h.to(dt).requires_grad_(True)
+        leaves = [ho] + [v.requires_grad_(True) for k, v in sdt.items() if v.is_floating_point() and "running" not in k]
+        yo, _ = orc.layer_forward("towers", sdt, dict(cfg, avg_log=cfg["avg_log"].to(dt)), src, dst, N, eig.to(dt), ho, None, snorm.to(dt),
+                                  training=True, dropout=(p, keep.to(dt)))
+        res[dt] = (yo.detach(), torch.autograd.grad((yo * ct.to(dt)).sum(), leaves))
+    (yo32, go32), (yo64, go64) = res[torch.float32], res[torch.float64]
+
+    def close(a, r32, r64, tol, what):
+        a = a.detach().cpu().double()
+        err = (a - r64).abs()
+        bound = tol * (1.0 + r64.abs()) + 4 * (r32.double() - r64).abs()
+        assert float((err > bound).float().mean()) <= 2e-4, (what, float(err.max()))      # (a LeakyReLU kink within rounding flips a slope)
+
+    close(y, yo32, yo64, 2e-5, "y")
+    close(hd.grad, go32[0], go64[0], 1e-4 * float(go64[0].abs().max()), "d h")
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    params = dict(layer.named_parameters())
+    for i, k in enumerate(names):
+        close(params[k].grad, go32[1 + i], go64[1 + i], 1e-4 * max(1.0, float(go64[1 + i].abs().max())), k)
+    # a second step draws another mask; evaluation mode applies none
+    y2 = layer(graph, hd, None, snorm.to(dev))
+    assert not torch.equal(_bits(ops.LAST_DROPOUT_MASK, N * F_).reshape(N, F_), keep)
+    layer.eval()
+    with torch.no_grad():
+        ye, ye2 = layer(graph, hd, None, snorm.to(dev)), layer(graph, hd, None, snorm.to(dev))
+    assert torch.equal(ye, ye2) and y2.shape == ye.shape
