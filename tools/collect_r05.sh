@@ -16,6 +16,8 @@ for tag in c1 c4 pattern_json zinc_json; do
   out="gpurun_out/prof_$tag"; mkdir -p "$out"
   timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o "$tag" -- python bench.py --workload $tag --no-extras --no-cpu-baseline > "$out/trace.log" 2>&1
 done
+out="gpurun_out/prof_c5_layer"; mkdir -p "$out"
+timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o c5_layer -- python bench.py --workload c5_layer --steps 3 --warmup 1 --no-extras --no-cpu-baseline > "$out/trace.log" 2>&1
 for tag in c2_b128 zinc_json_b128 c1_b128; do
   out="gpurun_out/prof_$tag"; mkdir -p "$out"
   timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o "$tag" -- python bench.py --workload $tag --no-extras --no-cpu-baseline --hipgraph --steps 200 --warmup 30 > "$out/trace.log" 2>&1
