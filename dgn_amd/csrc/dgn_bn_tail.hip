@@ -191,24 +191,9 @@ __global__ __launch_bounds__(256) void bn_finalize(int64_t n_rows, int F, int G,
 }
 
 // normalise (+ReLU, +residual).  Training: mean / invstd from bn_finalize; eval (mean == NULL): running statistics.
-__global__ __launch_bounds__(256) void bn_apply(int64_t n_rows, int F, const float* __restrict__ x, int64_t ld,
-                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                                float eps, int relu, const float* __restrict__ residual, float* __restrict__ y) {
-    flat_loop(n_rows * F, F, [&](int64_t n, int c) {
-        const float mu = mean ? mean[c] : running_mean[c];
-        const float is = mean ? invstd[c] : 1.f / sqrtf(running_var[c] + eps);
-        float v = (x[n * ld + c] - mu) * is * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
-        if (relu) v = fmaxf(v, 0.f);
-        if (residual) v += residual[n * ld + c];
-        return v;
-    }, [&](int64_t n, int c, float v) { y[n * ld + c] = v; });
-}
-
-// The same pass, VEC columns per thread, the column constants once per workgroup in LDS (eval: 1 / sqrt(var + eps) was a square root and
-// a division per ELEMENT) and the (row, column) of a thread's next element by increments instead of a 64-bit division per element:
-// C5's [10 M, 128] rows 5.85 -> ms (2.6 TB/s before), ZINC-12k simple 75 (c1) 65 -> us.  Same arithmetic, element by element.
+// VEC columns per thread, the column constants once per workgroup in LDS (eval: 1 / sqrt(var + eps) was a square root and a division
+// per ELEMENT in the scalar round-1 kernel) and the (row, column) of a thread's next element by increments instead of a 64-bit division
+// per element: C5's [10 M, 128] rows 5.85 -> 2.3 ms.  Same arithmetic, element by element.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_vec(int64_t n_rows, int F, const float* __restrict__ x, int64_t ld,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -392,15 +377,9 @@ bool pairs_ok(int F, int64_t ld, const void* a, const void* b = nullptr, const v
 
 unsigned flat_grid(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32); }
 
-// widest vector the rows allow (F, ld and the three addresses), VEC = 1 otherwise; DGN_BN_APPLY_SCALAR=1: the round-1 kernel
+// widest vector the rows allow (F, ld and the three addresses), VEC = 1 otherwise
 void launch_bn_apply(hipStream_t stream, int64_t n_rows, int F, const float* x, int64_t ld, const float* gamma, const float* beta, const float* mean,
                      const float* invstd, const float* running_mean, const float* running_var, float eps, int relu, const float* residual, float* y) {
-    static const bool scalar = getenv("DGN_BN_APPLY_SCALAR") != nullptr;
-    if (scalar) {
-        hipLaunchKernelGGL(bn_apply, dim3(flat_grid(n_rows * F)), dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta, mean, invstd, running_mean,
-                           running_var, eps, relu, residual, y);
-        return;
-    }
     const uintptr_t bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual);
     const int vec = (F % 4 == 0 && ld % 4 == 0 && bits % 16 == 0) ? 4 : ((F % 2 == 0 && ld % 2 == 0 && bits % 8 == 0) ? 2 : 1);
     const dim3 grid(flat_grid(n_rows * (F / vec)));

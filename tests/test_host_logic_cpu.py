@@ -127,3 +127,28 @@ def test_degree_class_algebra_and_virtual_row_space():
     # a graph with an in-degree of 32 or more keeps the folded route
     dst2 = torch.cat([torch.zeros(40, dtype=torch.long), torch.arange(1, 50)])
     assert dgn_amd.DGNGraph(torch.randint(0, 50, (dst2.numel(),), generator=g), dst2, 50).degree_classes() is None
+
+
+def test_convert_sync_batchnorm_shares_parameters_and_is_plain_batchnorm_without_a_process_group():
+    """dist.convert_sync_batchnorm (optional SyncBN): same parameter / buffer OBJECTS and state_dict keys; without an
+    initialised process group (or in eval mode) the module is nn.BatchNorm1d."""
+    import torch
+    from dgn_amd import dist as ddist
+    from dgn_amd.layers import MLP
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(MLP(6, 8, 4, layers=2, mid_b_norm=True, last_b_norm=True), torch.nn.BatchNorm1d(4))
+    ref = torch.nn.Sequential(MLP(6, 8, 4, layers=2, mid_b_norm=True, last_b_norm=True), torch.nn.BatchNorm1d(4))
+    ref.load_state_dict(net.state_dict())
+    before = {n: p for n, p in net.named_parameters()}
+    keys = list(net.state_dict().keys())
+    ddist.convert_sync_batchnorm(net)
+    assert list(net.state_dict().keys()) == keys
+    assert all(p is before[n] for n, p in net.named_parameters())
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    assert len(bns) == 3 and all(isinstance(m, ddist.SyncBatchNorm1d) for m in bns)
+    x = torch.randn(10, 6)
+    for mode in (True, False):
+        net.train(mode), ref.train(mode)
+        torch.testing.assert_close(net(x), ref(x))
+    for (n, a), (_, b) in zip(net.state_dict().items(), ref.state_dict().items()):
+        torch.testing.assert_close(a, b, msg=n)
