@@ -550,6 +550,18 @@ class DGNLayerComplex(nn.Module):
                 w_agg, w_h = _pad_blocks(w_agg, S * len(self.aggregators), F0, Fp), F.pad(w_h, (0, 1))
             else:
                 aggx = self.aggregate(graph, h, e, self._kplan_x, eig)                     # [N, A*F | F]
+            if _ops.dc_posttrans_split_supported(graph, aggx, fo, S):
+                # inference on a graph that may hold hub rows: one product per in-degree class, the hubs on the folded product
+                sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)
+                h = _ops.dc_posttrans_split(graph, aggx, lin.weight, lin.bias, sc, snorm_n if self.graph_norm else None, len(self.aggregators), F0,
+                                            id_slot=id_slot)
+                del aggx
+                if self.batch_norm:
+                    h = bn_tail(h, self.batchnorm_h, self.training, relu=True, residual=h_in if self.residual else None)
+                else:
+                    h = F.relu(h)
+                    h = h_in + h if self.residual else h
+                return _dropout(h, self.dropout, self.training)
             w = _folded_weight(w_agg, w_h, S, id_slot)
             z = node_linear(aggx, w)
             sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log)

@@ -1246,19 +1246,22 @@ def dc_posttrans_split_supported(graph: DGNGraph, agg: torch.Tensor, fo: int, S:
 
 
 def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], scale: torch.Tensor,
-                       row_scale: Optional[torch.Tensor], n_agg: int, f_in: int) -> torch.Tensor:
+                       row_scale: Optional[torch.Tensor], n_agg: int, f_in: int, id_slot: int = -1) -> torch.Tensor:
     """``snorm * posttrans(cat_s(scale_s * agg))`` (nets/dgn_layer.py:186-193 with the scalers of scalers.py:7-18) WITHOUT gradients on a
     graph that may hold hub rows: ``agg [N, n_agg * f_pad]`` the scaler-free aggregates, ``weight [f_out, S * n_agg * f_in]`` the
     posttrans Linear in the reference's layout, ``scale [N, S]`` the per-node scaler table.  Rows of in-degree < DGN_DC_CLASSES:
     dgn_dc_fold + dgn_dc_gemm (one f_out-column product per in-degree class); hub rows: gathered, folded product (S f_out columns),
-    scale-combine, written back by row index."""
+    scale-combine, written back by row index.
+    ``id_slot >= 0``: the complex layer (:116-122): ``agg [N, (n_agg + 1) * f_pad]`` ends with the h_in pass-through block, ``weight`` is
+    ``[f_out, f_in + S * n_agg * f_in]`` and its h columns act through the identity scaler's slot ``id_slot``."""
     lib = _lib.load()
+    cx = id_slot >= 0
     dc = graph.degree_classes_split()
     if dc is None:
         raise RuntimeError("dc_posttrans_split: the graph has no degree classes (padded or bipartite)")
     N, K = agg.shape
     fo, S = weight.shape[0], scale.shape[1]
-    f_pad = K // n_agg
+    f_pad = K // (n_agg + (1 if cx else 0))
     weight = weight.contiguous()
     row_scale = None if row_scale is None else row_scale.reshape(-1).contiguous()
     y = torch.empty(N, fo, dtype=torch.float32, device=agg.device)
@@ -1268,16 +1271,19 @@ def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor,
         s = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
                                   present=dc["present"].data_ptr(), scale=cls_scale.data_ptr())
         wc = torch.empty(2, _lib.DGN_DC_CLASSES, fo * K, dtype=torch.float32, device=agg.device)
-        lay = _lib.DgnDcLayout(n_agg=n_agg, f_pad=f_pad, f_in=f_in, h_off=0, id_slot=-1, ld=weight.stride(0))
+        lay = _lib.DgnDcLayout(n_agg=n_agg, f_pad=f_pad, f_in=f_in, h_off=f_in if cx else 0, id_slot=id_slot if cx else -1, ld=weight.stride(0))
         _lib.check(lib.dgn_dc_fold(C.byref(s), S, fo, K, 1, weight.data_ptr(), C.byref(lay), wc[0].data_ptr(), wc[1].data_ptr(), stream), "dgn_dc_fold")
         _lib.check(lib.dgn_dc_gemm(C.byref(s), K, fo, 1, agg.data_ptr(), agg.stride(0), 0, wc[0].data_ptr(), K, fo * K, 0, _ptr(bias), _ptr(row_scale),
                                    y.data_ptr(), fo, 0, 0, stream), "dgn_dc_gemm")
     hub = dc["hub_rows"]
     if hub.numel():
-        w = weight.reshape(fo, S * n_agg, f_in)
-        if f_pad != f_in:
-            w = torch.nn.functional.pad(w, (0, f_pad - f_in))
-        w = w.reshape(fo, S, K).permute(1, 0, 2).reshape(S * fo, K).contiguous()
+        pad = (lambda t: torch.nn.functional.pad(t, (0, f_pad - f_in)) if f_pad != f_in else t)
+        w = pad(weight[:, f_in if cx else 0:].reshape(fo, S * n_agg, f_in)).reshape(fo, S, n_agg * f_pad).permute(1, 0, 2)      # [S, fo, A f_pad]
+        if cx:      # the h columns in the identity scaler's block, zero elsewhere (dgn_layer._folded_weight)
+            hcols = torch.zeros(S, fo, f_pad, dtype=w.dtype, device=w.device)
+            hcols[id_slot] = pad(weight[:, :f_in])
+            w = torch.cat([w, hcols], dim=2)
+        w = w.reshape(S * fo, K).contiguous()
         z = node_linear(agg.index_select(0, hub), w)
         y_hub = scale_combine(z.unsqueeze(0), scale.index_select(0, hub), bias, None if row_scale is None else row_scale.index_select(0, hub))
         y.index_copy_(0, hub, y_hub)

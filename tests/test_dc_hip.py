@@ -215,11 +215,13 @@ def test_virtual_row_space_with_hub_rows():
     assert dc["present"].cpu().tolist() == torch.bincount(deg[deg < 32], minlength=32).tolist()
 
 
-@pytest.mark.parametrize("F,aggs,graph_norm", [(128, "mean max min sum std dir1-dx dir2-dx dir3-dx", False), (70, "mean max min dir1-dx dir1-av", True),
-                                               (75, "mean sum max dir1-dx", True)])
-def test_simple_layer_inference_on_a_hub_graph_vs_oracle_and_the_folded_route(F, aggs, graph_norm):
-    """``DGNLayerSimple.forward`` (nets/dgn_layer.py:178-202) in eval() under no_grad on a power-law graph (in-degrees from 1 to the
-    thousands): the split degree-class route against the oracle's layer and against the folded product + scale-combine."""
+@pytest.mark.parametrize("type_net,F,aggs,graph_norm", [("simple", 128, "mean max min sum std dir1-dx dir2-dx dir3-dx", False),
+                                                        ("simple", 70, "mean max min dir1-dx dir1-av", True), ("simple", 75, "mean sum max dir1-dx", True),
+                                                        ("complex", 70, "mean max min dir1-av dir1-dx", True), ("complex", 45, "mean dir1-dx dir1-av", False)])
+def test_layer_inference_on_a_hub_graph_vs_oracle_and_the_folded_route(type_net, F, aggs, graph_norm):
+    """``DGNLayerSimple.forward`` / ``DGNLayerComplex.forward`` (nets/dgn_layer.py:178-202, :103-132) in eval() under no_grad on a
+    power-law graph (in-degrees from 1 to the thousands): the split degree-class route against the oracle's layer and against the folded
+    product + scale-combine."""
     import numpy as np
     import dgn_amd
     from dgn_amd import ops
@@ -230,7 +232,7 @@ def test_simple_layer_inference_on_a_hub_graph_vs_oracle_and_the_folded_route(F,
     deg = (indptr[1:] - indptr[:-1])
     avg = float(torch.log(deg.double() + 1).mean())
     torch.manual_seed(7)
-    layer = dgn_amd.DGNLayer(F, F, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(avg)}, "simple", True, towers=1, edge_features=False,
+    layer = dgn_amd.DGNLayer(F, F, 0.0, graph_norm, True, aggs, scalers, {"log": torch.tensor(avg)}, type_net, True, towers=1, edge_features=False,
                              edge_dim=0).model
     gen = torch.Generator().manual_seed(8)
     with torch.no_grad():
@@ -249,7 +251,7 @@ def test_simple_layer_inference_on_a_hub_graph_vs_oracle_and_the_folded_route(F,
     for dt in (torch.float32, torch.float64):
         sdt = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
         c = dict(cfg, avg_log=cfg["avg_log"].to(dt))
-        res[dt] = orc.layer_forward("simple", sdt, c, src.cpu().long(), dst, N, eig.cpu().to(dt), h.to(dt), None, snorm.to(dt), training=False)[0]
+        res[dt] = orc.layer_forward(type_net, sdt, c, src.cpu().long(), dst, N, eig.cpu().to(dt), h.to(dt), None, snorm.to(dt), training=False)[0]
     layer = layer.cuda().eval()
     out, calls = {}, []
     real = ops.dc_posttrans_split
