@@ -51,9 +51,35 @@ full = ddist.all_gather_rows(rows, [(0, 37)])
 w = torch.randn(37, 8, device=dev)
 (full * w).sum().backward()
 ok_gather = torch.equal(full.detach(), rows.detach()) and torch.allclose(rows.grad, w)
+# SyncBN: the two all-reduces of dist.sync_batch_norm on device statistics (world 1: the sums of this rank) against F.batch_norm
+x = torch.randn(501, 70, device=dev, requires_grad=True)
+x2 = x.detach().clone().requires_grad_(True)
+ga, be = torch.rand(70, device=dev) + 0.5, torch.randn(70, device=dev)
+rm, rv, rm2, rv2 = torch.zeros(70, device=dev), torch.ones(70, device=dev), torch.zeros(70, device=dev), torch.ones(70, device=dev)
+ct = torch.randn(501, 70, device=dev)
+ys = ddist.sync_batch_norm(x, ga, be, rm, rv, 0.1, 1e-5)
+yr = torch.nn.functional.batch_norm(x2, rm2, rv2, ga, be, True, 0.1, 1e-5)
+(ys * ct).sum().backward(); (yr * ct).sum().backward()
+ok_syncbn = (torch.allclose(ys, yr, rtol=1e-5, atol=1e-5) and torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-5)
+             and torch.allclose(rm, rm2, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5))
+# ... and a layer holding the converted modules leaves the fused calls in training (process group up) with the same results
+torch.manual_seed(0)
+layer2 = dgn_amd.DGNLayer(20, 20, 0.0, True, True, "mean max dir1-dx dir1-av", "identity amplification attenuation",
+                          {"log": torch.tensor(1.0)}, "towers", True, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+layer2.load_state_dict({k: v for k, v in layer.state_dict().items()}, strict=True)
+for m in layer2.modules():
+    if isinstance(m, torch.nn.BatchNorm1d):
+        m.reset_running_stats()
+ddist.convert_sync_batchnorm(layer2)
+from dgn_amd import ops
+assert ops._spans_ranks(layer2.towers[0].batchnorm_h, True) and not ops.bn_tail_supported([layer2.towers[0].batchnorm_h], h, True)
+y2 = layer2(g, h, None, b["snorm_n"].to(dev))
+(y2 * y2).mean().backward()
+ok_sync_layer = torch.allclose(y2, y, rtol=1e-4, atol=1e-5) and all(
+    torch.allclose(p.grad, before[n], rtol=2e-3, atol=1e-5 * max(1.0, float(before[n].abs().max()))) for n, p in layer2.named_parameters())
 ms = ddist.barrier_max_ms(1.25, dev)
-print("RESULT " + json.dumps(dict(ok_grad=bool(ok_grad), ok_gather=bool(ok_gather), ms=ms, backend=dist.get_backend(),
-                                  world=dist.get_world_size())))
+print("RESULT " + json.dumps(dict(ok_grad=bool(ok_grad), ok_gather=bool(ok_gather), ok_syncbn=bool(ok_syncbn), ok_sync_layer=bool(ok_sync_layer),
+                                  ms=ms, backend=dist.get_backend(), world=dist.get_world_size())))
 dist.destroy_process_group()
 """
 
@@ -66,7 +92,7 @@ def test_rccl_collectives_world1():
     p = subprocess.run([sys.executable, "-c", _NCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=550)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    assert res == dict(ok_grad=True, ok_gather=True, ms=1.25, backend="nccl", world=1)
+    assert res == dict(ok_grad=True, ok_gather=True, ok_syncbn=True, ok_sync_layer=True, ms=1.25, backend="nccl", world=1)
 
 
 @pytest.mark.gpu
