@@ -129,6 +129,10 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
         const int tiles = (n + 16 * nq - 1) / (16 * nq), cost = tiles * (16 * nq + 16);
         if (cost < best_cost) { best_nq = nq; best_tiles = tiles; best_cost = cost; }
     }
+    // 113 .. 128 columns (hidden 128: C5): ONE tile of 128 columns -- the A rows are fetched and staged once instead of twice, 128 MFMAs
+    // per k chunk and wave behind 12 LDS reads instead of 64 behind 8 (DGN_DC_NQ8=0: two tiles of 64)
+    static const bool nq8 = !(getenv("DGN_DC_NQ8") && atoi(getenv("DGN_DC_NQ8")) == 0);
+    if (nq8 && n > 112 && n <= 128) { best_nq = 8; best_tiles = 1; }
     p.n_slice = 16 * best_nq;
     // one workgroup per resident slot (two per CU), each with an equal range of units
     const int64_t slots_x = std::max<int64_t>(1, (int64_t)n_cus() * 2 / (best_tiles * towers));
@@ -146,6 +150,7 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
         case 4: hipLaunchKernelGGL(dc_gemm<4>, grid, dim3(256), 0, st, p); break;
         case 5: hipLaunchKernelGGL(dc_gemm<5>, grid, dim3(256), 0, st, p); break;
         case 6: hipLaunchKernelGGL(dc_gemm<6>, grid, dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL(dc_gemm<8>, grid, dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL(dc_gemm<7>, grid, dim3(256), 0, st, p); break;
     }
     DGN_HIP_CHECK(hipGetLastError());

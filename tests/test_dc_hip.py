@@ -70,7 +70,8 @@ def test_large_in_degree_keeps_the_folded_route():
 @pytest.mark.parametrize("N,k,n,max_deg,bias,rs", [(20000, 420, 70, 4, True, True), (3333, 70, 420, 6, False, False), (777, 46, 45, 3, True, False),
                                                    (300000, 152, 65, 8, True, True), (64, 8, 4, 2, True, True), (5000, 300, 75, 31, False, True),
                                                    (1, 16, 16, 1, True, True), (4000, 45, 184, 4, False, False), (4000, 184, 45, 4, True, True),
-                                                   (9000, 47, 141, 5, False, True)])
+                                                   (9000, 47, 141, 5, False, True), (20000, 1024, 128, 12, True, False), (5000, 300, 120, 31, True, True),
+                                                   (3000, 129, 113, 3, False, False)])      # (113 .. 128 columns: the one-tile dc_gemm<8>)
 def test_dc_gemm_matches_fp64(N, k, n, max_deg, bias, rs):
     from dgn_amd import _lib
     lib = _lib.load()
