@@ -143,6 +143,24 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
     const dim3 grid = p.col_tiles > 1 ? dim3((unsigned)((ranges + kXcds - 1) / kXcds * kXcds * best_tiles), 1, (unsigned)towers)
                                       : dim3((unsigned)ranges, (unsigned)best_tiles, (unsigned)towers);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // few units: one unit per workgroup, four workgroups per CU (dc_gemm_small) while every (unit, column tile) is resident at once
+    // (few ROWS is the criterion -- at most four units per CU --: column tiles multiply the workgroups of both kernels alike.  HIV batch 2048,
+    //  816 units, captured step 0.348 -> 0.338 ms with the forward and the input-gradient product on it; DGN_DC_SMALL=0: off)
+    static const bool small_on = !(getenv("DGN_DC_SMALL") && atoi(getenv("DGN_DC_SMALL")) == 0);
+    if (small_on && best_nq <= 6 && d->n_units * towers <= (int64_t)n_cus() * 4) {
+        const dim3 gs((unsigned)d->n_units, (unsigned)best_tiles, (unsigned)towers);
+        p.col_tiles = 1;
+        switch (best_nq) {
+            case 1: hipLaunchKernelGGL(dc_gemm_small<1>, gs, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL(dc_gemm_small<2>, gs, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL(dc_gemm_small<3>, gs, dim3(256), 0, st, p); break;
+            case 4: hipLaunchKernelGGL(dc_gemm_small<4>, gs, dim3(256), 0, st, p); break;
+            case 5: hipLaunchKernelGGL(dc_gemm_small<5>, gs, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL(dc_gemm_small<6>, gs, dim3(256), 0, st, p); break;
+        }
+        DGN_HIP_CHECK(hipGetLastError());
+        return DGN_OK;
+    }
     switch (best_nq) {
         case 1: hipLaunchKernelGGL(dc_gemm<1>, grid, dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(dc_gemm<2>, grid, dim3(256), 0, st, p); break;

@@ -92,13 +92,15 @@ struct DcGemmParams {
 };
 
 // One tile of 64 RT virtual rows (units u0 .. u0 + RT, all of one class) x 16 NQ columns.  Wave w owns rows 16 RT w .. of the tile.
-template <int NQ, int RT, bool DEEP = (NQ <= 6)>      // (NQ = 7: no registers left for the second set)
+// TM: rows the A staging buffers were sized for (dc_gemm: 256; dc_gemm_small: 64, RT = 1 only).
+template <int NQ, int RT, bool DEEP = (NQ <= 6), int TM = kTileM>      // (NQ = 7: no registers left for the second set)
 __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float* Bs, int64_t u0, const float* __restrict__ W, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int KB = (p.k + 15) >> 4;
     const int lr = tid >> 2, c4 = (tid & 3) * 4;
     constexpr int NBJ = (NQ * 16 + 63) / 64;
-    constexpr int kABuf = kTileM * kTKS, kBBuf = NQ * 16 * kTKS;
+    constexpr int kABuf = TM * kTKS, kBBuf = NQ * 16 * kTKS;
+    static_assert(64 * RT <= TM, "tile taller than its staging buffer");
     int node[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) node[j] = p.vperm[(u0 + j) * kUnit + lr];
@@ -238,6 +240,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         u += run;
     }
+}
+
+// Few units (HIV batch 2048: 816 units of 64 rows): dc_gemm's two 256-row workgroups per CU leave the chip a single, latency-bound round of
+// ~1.6 workgroups per CU, each walking its k chunks with two loads in flight.  Here a workgroup owns ONE unit (64 rows x 16 NQ columns,
+// 23 KB of LDS, <= 128 registers): four workgroups per CU, every unit resident at once, four times the loads in flight per CU.
+template <int NQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void dc_gemm_small(const DcGemmParams p_in) {
+    __shared__ float As[2 * 64 * kTKS];
+    __shared__ float Bs[2 * NQ * 16 * kTKS];
+    DcGemmParams p = p_in;
+    const int64_t u = blockIdx.x;
+    const int n0 = blockIdx.y * p.n_slice;
+    p.A += blockIdx.z * p.a_tower; p.W += blockIdx.z * p.w_tower; p.C += blockIdx.z * p.c_tower;
+    if (p.bias) p.bias += blockIdx.z * p.bias_tower;
+    const int c = uniform_i(p.unit_class[u]);
+    if (c < 0) return;
+    dc_tile<NQ, 1, true, 64>(p, As, Bs, u, p.W + (int64_t)c * p.class_stride, n0);
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------------------
