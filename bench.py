@@ -1075,6 +1075,20 @@ def run_extras(args, dev):
                 finally:
                     torch.autograd.set_multithreading_enabled(True)
                 if name.endswith("_b128"):
+                    # ... and, opt-in (dgn_amd.ops.DIRECT_PARAM_GRADS): the block route's backward assigns the parameters' .grad itself
+                    # instead of handing 33 gradients (towers) to autograd's AccumulateGrad nodes
+                    from dgn_amd import ops as _ops
+                    torch.autograd.set_multithreading_enabled(False)
+                    _ops.DIRECT_PARAM_GRADS = True
+                    try:
+                        rd, _ = run_layer_workload(args, dict(WORKLOADS[name]), 0, 1, dev, steps=steps, warmup=warmup, tag=name)
+                        extra[name]["eager_direct_ms_per_step"] = rd["ms_per_step"]
+                    except Exception as exc:
+                        extra[name]["eager_direct_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                    finally:
+                        _ops.DIRECT_PARAM_GRADS = False
+                        torch.autograd.set_multithreading_enabled(True)
+                if name.endswith("_b128"):
                     try:
                         extra[name]["eval_fwd_ms"] = eval_forward_ms(dict(WORKLOADS[name]), dev)
                     except Exception as exc:
@@ -1147,7 +1161,7 @@ def compact_line(line):
             if "error" in e:
                 ex[name] = dict(error=str(e["error"])[:80])
                 continue
-            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step", "eval_fwd_ms") if k in e}
+            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step", "eager_direct_ms_per_step", "eval_fwd_ms") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
                 if e["roofline"].get("bound") == "mfma":      # (c5_layer: the fraction is of the fp32 MFMA peak, on the posttrans product)

@@ -1417,6 +1417,12 @@ BLOCK_LAYER_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_MAX_NODES", "8192"))
 # flops) and all CUs.
 BLOCK_LAYER_MAX_POST = int(os.environ.get("DGN_BLOCK_LAYER_MAX_POST", "40960"))
 _BLK_DBG = None      # tests: dict that receives the aggregate rows / their gradients of the next call
+# Opt-in (False by default; also DGN_DIRECT_PARAM_GRADS=1): on the graph-block route the layer's parameters are NOT inputs of the autograd
+# node -- its backward assigns / accumulates their `.grad` itself.  A towers layer has 33 parameters; autograd's per-output work (gradient
+# validation + one AccumulateGrad node each, ~3.7 us apiece) is 0.12 ms of a step whose GPU side is 0.10 ms.  What is given up: parameter
+# hooks and anything built on AccumulateGrad (DistributedDataParallel: use dist.FlatGradAllReduce), `torch.autograd.grad(..., params)`,
+# double backward.  The gradients themselves are the same tensors, bit for bit.
+DIRECT_PARAM_GRADS = os.environ.get("DGN_DIRECT_PARAM_GRADS", "0") == "1"
 
 
 def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params):
@@ -1507,8 +1513,12 @@ class _BlockLayer(torch.autograd.Function):
     # The step is launch-bound on the host once the GPU side is ~0.1 ms: the struct built by the forward is kept for the backward, sizes
     # are cached per (batch, layer shape), scratch and saved tensors share allocations, the gradients leave as ONE split of a flat buffer.
     @staticmethod
-    def forward(ctx, graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, *params):
+    def forward(ctx, graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, direct, *params):
         lib = _lib.load()
+        # `direct` (DIRECT_PARAM_GRADS): the parameters as a TUPLE -- not inputs of the autograd node; the backward assigns their .grad
+        ctx.direct = direct
+        if direct is not None:
+            params = direct
         type_net, T, fi, fo = cfg[:4]
         N, Fo, dev = h.shape[0], T * fo, h.device
         table = graph.block_table()
@@ -1569,7 +1579,12 @@ class _BlockLayer(torch.autograd.Function):
         while q < n_w:
             grads.append(parts[q].view(shapes[q]) if len(shapes[q]) != 1 else parts[q])
             q += 1
-        return (None, None, None, None, None, g_h, None, None, None, None, *grads)
+        if ctx.direct is not None:
+            for p_, g_ in zip(ctx.direct, grads):
+                if p_.requires_grad:
+                    p_.grad = g_ if p_.grad is None else p_.grad + g_
+            return (None, None, None, None, None, g_h, None, None, None, None, None)
+        return (None, None, None, None, None, g_h, None, None, None, None, None, *grads)
 
 
 @torch.no_grad()
@@ -1612,7 +1627,9 @@ def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, r
     cfg = (int(type_net), int(n_towers), int(f_in), int(f_out), bool(residual), float(momentum), float(eps), float(slope))
     if not training:
         return _block_layer_eval(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, params)
-    return _BlockLayer.apply(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, nbt, *params)
+    if DIRECT_PARAM_GRADS and h.requires_grad:
+        return _BlockLayer.apply(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, nbt, tuple(params))
+    return _BlockLayer.apply(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, nbt, None, *params)
 
 
 # ---- the posttrans product inside the sweep (dgn_fused.hip) ---------------------------------------------------------------------

@@ -417,3 +417,40 @@ def test_evaluation_forward_on_the_route(monkeypatch, type_net, F_, aggs):
     np.testing.assert_allclose(y.cpu().numpy(), ys.cpu().numpy(), rtol=2e-5, atol=2e-5)
     for k, v in layer.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.parametrize("type_net,F_,aggs", [("towers", 70, "mean max min dir1-av dir1-dx"), ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean dir1-dx-no-abs")])
+def test_direct_parameter_gradients_are_the_autograd_ones(monkeypatch, type_net, F_, aggs):
+    """``ops.DIRECT_PARAM_GRADS`` (opt-in): the block route's backward assigns the parameters' ``.grad`` itself instead of returning 33
+    gradients through autograd.  Same kernels, so output, d h, every parameter gradient and the running statistics are BITWISE those of the
+    default path; a second backward accumulates as autograd does."""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    dev = torch.device("cuda")
+    b = synth.molecule_batch(64, seed=11)
+    N = int(b["num_nodes"])
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    res = {}
+    for direct in (False, True):
+        monkeypatch.setattr(ops, "DIRECT_PARAM_GRADS", direct)
+        taken = _count_route(monkeypatch)
+        layer, gen = _make_layer(type_net, F_, aggs, "identity amplification attenuation", True, avg)
+        layer = layer.to(dev).train()
+        graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+        graph.batch_num_nodes = b["sizes"].tolist()
+        h = torch.randn(N, F_, generator=gen).to(dev).requires_grad_(True)
+        ct = torch.randn(N, F_, generator=gen).to(dev)
+        snorm = b["snorm_n"].to(dev)
+        y = layer(graph, h, None, snorm)
+        assert taken, "the graph-block route was not taken"
+        y.backward(ct)
+        first = [p.grad.clone() for p in layer.parameters()]
+        y2 = layer(graph, h, None, snorm)
+        y2.backward(ct)                                                        # accumulates into .grad (h.grad too)
+        res[direct] = dict(y=y.detach().clone(), first=first, second=[p.grad.clone() for p in layer.parameters()], gh=h.grad.clone(),
+                           stats=[v.clone() for k, v in layer.state_dict().items() if "running" in k])
+    for key in ("first", "second", "stats"):
+        for a, r in zip(res[True][key], res[False][key]):
+            assert torch.equal(a, r), key
+    assert torch.equal(res[True]["y"], res[False]["y"]) and torch.equal(res[True]["gh"], res[False]["gh"])
+    assert all(g is not None and float(g.abs().max()) > 0 for g in res[True]["first"])
