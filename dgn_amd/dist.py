@@ -168,13 +168,16 @@ class _SyncBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, group):
         F_ = x.shape[1]
-        stats = torch.empty(2 * F_ + 1, dtype=torch.float64 if x.dtype == torch.float64 else torch.float32, device=x.device)
-        stats[:F_], stats[F_:2 * F_], stats[2 * F_] = x.sum(0), (x * x).sum(0), float(x.shape[0])
+        # (fp64 sums: E[x^2] - mean^2 over the rows of all ranks cancels in fp32 once |mean| >> std; the library's own bn_stats
+        #  accumulates in double as well)
+        stats = torch.empty(2 * F_ + 1, dtype=torch.float64, device=x.device)
+        stats[:F_], stats[F_:2 * F_], stats[2 * F_] = x.sum(0, dtype=torch.float64), (x * x).sum(0, dtype=torch.float64), float(x.shape[0])
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-        n = stats[2 * F_]
-        mean = stats[:F_] / n
-        var = (stats[F_:2 * F_] / n - mean * mean).clamp_min(0)             # biased, as F.batch_norm normalises
-        invstd = torch.rsqrt(var + eps)
+        n64 = stats[2 * F_]
+        mean64 = stats[:F_] / n64
+        var64 = (stats[F_:2 * F_] / n64 - mean64 * mean64).clamp_min(0)      # biased, as F.batch_norm normalises
+        n, mean, var = n64.to(x.dtype), mean64.to(x.dtype), var64.to(x.dtype)
+        invstd = torch.rsqrt(var64 + eps).to(x.dtype)
         xhat = (x - mean) * invstd
         ctx.save_for_backward(xhat, gamma, invstd, n)
         ctx.group = group
@@ -185,10 +188,11 @@ class _SyncBN(torch.autograd.Function):
     def backward(ctx, g, _gm, _gv, _gn):
         xhat, gamma, invstd, n = ctx.saved_tensors
         F_ = g.shape[1]
-        sums = torch.cat([g.sum(0), (g * xhat).sum(0)])
-        g_gamma, g_beta = sums[F_:].clone(), sums[:F_].clone()              # local sums: the gradient all-reduce averages them
+        sums = torch.cat([g.sum(0, dtype=torch.float64), (g * xhat).sum(0, dtype=torch.float64)])
+        g_gamma, g_beta = sums[F_:].to(g.dtype), sums[:F_].to(g.dtype)      # local sums: the gradient all-reduce averages them
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
-        g_x = (g - sums[:F_] / n - xhat * (sums[F_:] / n)) * (gamma * invstd)
+        sums = (sums / n.double()).to(g.dtype)
+        g_x = (g - sums[:F_] - xhat * sums[F_:]) * (gamma * invstd)
         return g_x, g_gamma, g_beta, None, None
 
 
