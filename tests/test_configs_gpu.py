@@ -227,3 +227,70 @@ def test_c5_full_graph_sampled_rows_and_properties():
                               torch.tensor(avg, dtype=torch.float64))[sub_rows]
     assert int((deg[sample_d] > graph.hub_threshold).sum()) >= 3               # hub rows are among the checked rows
     _as_good(got, y32, y64, 2e-5, 2e-5, "sampled C5 rows (incl. row N-1 at element offset %d)" % ((N - 1) * W))
+
+
+@pytest.mark.timeout(1800)
+def test_c5_full_graph_layer_forward_sampled_rows_vs_oracle():
+    """The FULL C5 graph through a whole ``DGNLayerSimple.forward`` (nets/dgn_layer.py:178-202, evaluation mode, C5's list, hidden 128):
+    sweep with the scalers folded -> one product per in-degree class on the rows below in-degree 32 + the folded product on the 6 % hub
+    rows (``ops.dc_posttrans_split``) -> BatchNorm on the running statistics -> ReLU -> residual.  Sampled rows -- low in-degrees, rows
+    past in-degree 31 (the folded product), rows past the sweep's hub threshold (sliced path), the first and last rows -- against the
+    oracle's layer on the extracted sub-problem."""
+    import dgn_amd
+    from dgn_amd import ops, synth
+    from oracle import dgn_oracle as orc
+    dev = _dev()
+    free, total = torch.cuda.mem_get_info(dev)
+    if total < 200 * 2 ** 30:
+        pytest.skip("needs the memory of an MI355X (the aggregate block alone is 41 GB)")
+    N, E_target, F_ = 10_000_000, 200_000_000, 128
+    indptr, src, eig = synth.powerlaw_csr(N, E_target, dev, seed=0)
+    graph = dgn_amd.DGNGraph.from_csr(indptr, src, eig=eig)
+    deg = graph.in_degree
+    avg = float(graph.log_deg.mean().item())
+    aggs, scalers = " ".join(C5_AGGS), " ".join(C5_SCALERS)
+    torch.manual_seed(3)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, False, True, aggs, scalers, {"log": torch.tensor(avg)}, "simple", True, towers=1, edge_features=False,
+                             edge_dim=0).model
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        layer.batchnorm_h.running_mean.copy_(torch.randn(F_, generator=gen) * 0.1)
+        layer.batchnorm_h.running_var.copy_(torch.rand(F_, generator=gen) + 0.5)
+        for p in layer.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=gen) / p.shape[1] ** 0.5)
+    sd = {k: v.clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev).eval()
+    X = torch.randn(N, F_, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    calls = []
+    real = ops.dc_posttrans_split
+    ops.dc_posttrans_split = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            out = layer(graph, X, None, None)
+    finally:
+        ops.dc_posttrans_split = real
+    assert len(calls) == 1, "the split degree-class route was not taken"
+    assert out.shape == (N, F_) and bool(torch.isfinite(out).all())
+    rs = torch.Generator().manual_seed(6)
+    sweep_hubs = torch.nonzero(deg > graph.hub_threshold).flatten()
+    small_hubs = sweep_hubs[torch.argsort(deg[sweep_hubs])][:3].cpu()
+    mid = torch.nonzero((deg >= 32) & (deg < 300)).flatten()
+    mid = mid[torch.randint(0, mid.numel(), (40,), generator=rs).to(dev)].cpu()
+    sample = torch.unique(torch.cat([torch.randint(0, N, (300,), generator=rs), torch.tensor([0, 1, N - 2, N - 1]), small_hubs, mid]))
+    sample_d = sample.to(dev)
+    d_s = deg[sample_d]
+    assert int((d_s < 32).sum()) >= 200 and int((d_s >= 32).sum()) >= 40 and int((d_s > graph.hub_threshold).sum()) >= 3
+    got = out[sample_d].cpu()
+    del out
+    torch.cuda.empty_cache()
+    sub_src, sub_dst, nodes, sub_rows = _extract_rows(indptr.cpu(), src.cpu(), sample)
+    Xs, eigs = X[nodes.to(dev)].cpu(), eig[nodes.to(dev)].cpu()
+    n_sub = nodes.numel()
+    cfg = dict(aggregators=aggs, scalers=scalers, graph_norm=False, batch_norm=True, residual=True, towers=1, divide_input=False, edge_features=False)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        sdt = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+        res[dt] = orc.layer_forward("simple", sdt, dict(cfg, avg_log=torch.tensor(avg, dtype=dt)), sub_src, sub_dst, n_sub, eigs.to(dt), Xs.to(dt), None,
+                                    None, training=False)[0][sub_rows]
+    _as_good(got, res[torch.float32], res[torch.float64], 2e-5, 2e-5, "sampled rows of the C5 layer forward (split degree-class route)")
