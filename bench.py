@@ -112,7 +112,7 @@ WORKLOADS = {
                            gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=45,
                            aggregators="mean dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
     "hiv_json_b128": dict(desc="configs/molecules_graph_classification_DGN_HIV.json as shipped: simple, hidden 70, mean max min dir1-dx dir1-av x 3 scalers, "
-                               "dropout 0.3, batch 128 (graph-block route + bit-mask dropout)",
+                               "dropout 0.3, batch 128 (streaming whole-layer route + bit-mask dropout: its 73 500-weight posttrans is over the graph-block route's limit)",
                           gen=("molecules", dict(n_graphs=128, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple", hidden=70,
                           aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1, graph_norm=False, dropout=0.3),
     "pattern_json": dict(desc="configs/SBMs_node_clustering_DGN_PATTERN.json as shipped: complex, hidden 47, mean dir1-dx dir2-dx x 3 scalers, "
