@@ -111,10 +111,18 @@ WORKLOADS = {
     "zinc_json_b128": dict(desc="the same ZINC json layer at the json's batch size (128 molecules)",
                            gen=("molecules", dict(n_graphs=128, extra_bonds=3.9, eig_dim=6)), type_net="complex", hidden=45,
                            aggregators="mean dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1),
-    "hiv_json_b128": dict(desc="configs/molecules_graph_classification_DGN_HIV.json as shipped: simple, hidden 70, mean max min dir1-dx dir1-av x 3 scalers, "
-                               "dropout 0.3, batch 128 (streaming whole-layer route + bit-mask dropout: its 73 500-weight posttrans is over the graph-block route's limit)",
+    # BASELINE C4's layer (the HIV json's list WITH the three PNA scalers BASELINE.json names: "DGN + PNA scalers") at the json's batch size
+    # and dropout: 73 500 posttrans weights, over ops.BLOCK_LAYER_MAX_POST -> streaming whole-layer route + bit-mask dropout
+    "c4_b128": dict(desc="BASELINE C4's layer (simple, hidden 70, mean max min dir1-dx dir1-av x identity amplification attenuation) at batch 128 with the HIV json's "
+                         "dropout 0.3 (streaming whole-layer route: its 73 500-weight posttrans is over the graph-block route's limit)",
+                    gen=("molecules", dict(n_graphs=128, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple", hidden=70,
+                    aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1, graph_norm=False, dropout=0.3),
+    # the json AS SHIPPED (configs/molecules_graph_classification_DGN_HIV.json:23-34): scalers "identity" -> posttrans 5 x 70 x 70 = 24 500
+    # weights: the graph-block route (round 5 benched the 3-scaler layer under this name)
+    "hiv_json_b128": dict(desc="configs/molecules_graph_classification_DGN_HIV.json as shipped: simple, hidden 70, mean max min dir1-dx dir1-av x identity, "
+                               "no graph norm, dropout 0.3, batch 128 (graph-block route + bit-mask dropout)",
                           gen=("molecules", dict(n_graphs=128, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)), type_net="simple", hidden=70,
-                          aggregators="mean max min dir1-dx dir1-av", scalers="identity amplification attenuation", towers=1, graph_norm=False, dropout=0.3),
+                          aggregators="mean max min dir1-dx dir1-av", scalers="identity", towers=1, graph_norm=False, dropout=0.3),
     "pattern_json": dict(desc="configs/SBMs_node_clustering_DGN_PATTERN.json as shipped: complex, hidden 47, mean dir1-dx dir2-dx x 3 scalers, "
                               "batch 128 of SBM graphs (~119 nodes, ~6.1 k directed edges each)",
                          gen=("sbm", dict(n_graphs=128)), type_net="complex", hidden=47,
@@ -435,6 +443,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
 
     result = dict(ms_per_step=ms, value=total_edges / (ms * 1e-3), edges_per_rank=E, nodes_per_rank=N,
                   scaling="strong" if strong else "weak")
+    blk_rows = []
     if rank == 0:
         # the step against the layer's mandatory traffic (roofline.step), and where its time goes kernel by kernel (full record only)
         plan0 = layer._kplan_x if (wl["type_net"] != "simple" and hasattr(layer, "_kplan_x")) else layer._kplan
@@ -447,6 +456,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
         result["step_kernels"] = table
         if table and "us_per_step" in table[0]:
             result["step"]["kernel_us_sum"] = sum(r["us_per_step"] for r in table)
+        blk_rows = [r for r in (table or []) if "us_per_step" in r and "blk_" in r["kernel"]]
     if torch.distributed.is_initialized():
         # per rank: its shard's size and the gradient all-reduce timed on its own (HIP events around 20 back-to-back calls)
         ms_ar = event_ms(reducer, 20, dev, warm=3)
@@ -457,6 +467,24 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     if rank != 0:
         return result
 
+    if blk_rows:
+        # The step ran on the GRAPH-BLOCK route (csrc/dgn_blk_layer.hip: batches up to ops.BLOCK_LAYER_MAX_NODES nodes): the whole layer is
+        # five launches out of LDS and the streaming sweep kernels are never launched -- their roofline would describe kernels this
+        # step does not run.  Reported instead: the block kernels' own durations (torch.profiler device records
+        # of the timed step) and the layer's MANDATORY bytes against their sum -- a launch- / latency-bound regime, marked as such.
+        us = sum(r["us_per_step"] for r in blk_rows)
+        bmin = result["step"]["bytes_min"]
+        result["roofline"] = dict(bound="hbm", regime="launch/latency-bound: graph-block route, whole layer out of LDS",
+                                  kernel="blk_forward + blk_tail_fwd + blk_tail_bwd + blk_backward + blk_reduce (csrc/dgn_blk_layer.hip)",
+                                  achieved=bmin / (us * 1e-6) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=bmin / (us * 1e-6) / HBM_PEAK,
+                                  traffic=None, traffic_source=None,
+                                  kernels={r["kernel"].split("<")[0].split("::")[-1]: dict(ms=r["us_per_step"] * 1e-3, launches_per_step=r["calls_per_step"])
+                                           for r in blk_rows},
+                                  model=dict(N=N, E=E, F=F_, bytes="the layer step's mandatory bytes (roofline.step.bytes_min)", launches_per_step=sum(r["calls_per_step"] for r in blk_rows),
+                                             block_kernel_us=us),
+                                  step=result.get("step"))
+        return result, batch
+
     # ---- roofline of the aggregation kernels (same shapes the layer launches) ----
     # the plan the layer actually launches: the degree scalers are folded into posttrans, so the sweep
     # runs with S = 1 (dgn_amd/dgn_layer.py: _fold_scalers) and its algorithmic bytes are counted as such
@@ -466,10 +494,17 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     w = graph.edge_weights(plan)
     hd = h.detach()
     Fk = F_          # width the kernels are launched with
+    from dgn_amd import ops as _ops
+    f_valid = 0
     if F_ % 2 and wl["type_net"] in ("simple", "complex"):
-        # the simple and complex layers pad an odd hidden size with one zero column through the whole message path
-        hd = torch.nn.functional.pad(hd, (0, 1))
+        # the simple and complex layers run an odd hidden size at F + 1: the complex layer through one zero column in P | Q, the simple
+        # layer -- where the list has `Cfg::ODD` kernels (c1, c3) -- on the UN-PADDED rows of h (DgnMsg.f_valid), both directions.  The
+        # roofline legs launch exactly what the layer launches (they timed the padded, even-pitch instance before).
         Fk = F_ + 1
+        if wl["type_net"] == "simple" and _ops.odd_direct_supported(graph, plan):
+            f_valid = F_
+        else:
+            hd = torch.nn.functional.pad(hd, (0, 1))
     if wl["type_net"] == "simple":
         xs, xd = hd, None
     else:
@@ -490,12 +525,11 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     et = graph.to_slot_order(ef.types).to(torch.int32).contiguous() if n_types else None
     # the forward / backward pair as the layer runs it in training: where the launch has an aux table (dgn_agg_forward_aux: slots of the
     # first max / min and dx signs, one byte per row and feature) the forward writes it and the backward works from it
-    from dgn_amd import ops as _ops
-    n_aux = _ops.agg_aux_bytes(graph, plan, T, Fk, xs, xd, me, hd, et) if (_ops.AGG_AUX and wl["type_net"] in AUX_LAYERS) else 0
+    n_aux = _ops.agg_aux_bytes(graph, plan, T, Fk, xs, xd, me, hd, et, f_valid=f_valid) if (_ops.AGG_AUX and wl["type_net"] in AUX_LAYERS) else 0
     aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
-    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et, aux=aux)
+    fwd_call = lambda: launch_forward(graph, plan, T, avg_log, w, xs, xd, me, hd, out, edge_type=et, aux=aux, f_valid=f_valid)
     bwd_call = lambda: launch_backward(graph, plan, T, avg_log, w, xs, xd, me, hd, g_out, g_src, g_dst, g_me, g_in, accumulate=False,
-                                       edge_type=et, aux=aux)
+                                       edge_type=et, aux=aux, f_valid=f_valid)
     st_f, st_b = event_stats(fwd_call, dev), event_stats(bwd_call, dev)
     st_w = event_stats(lambda: dgn_amd.compute_edge_weights(graph, plan.channels, eig=graph.ndata["eig"]), dev)
     ms_f, ms_b, ms_w = st_f["median"], st_b["median"], st_w["median"]
@@ -535,7 +569,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
     result["roofline"] = dict(bound="hbm", kernel=label, achieved=kernels[dom]["GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
                               frac=kernels[dom]["frac"], traffic=traffic, traffic_source=TRAFFIC_SOURCE if traffic else None,
                               kernels=kernels, triad_GBps=triad, frac_of_triad=kernels[dom]["GBps"] / triad,
-                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, aux_bytes=n_aux),
+                              model=dict(N=N, E=E, F=F_, A=A, S=S, Ku=Ku, x=x, r=r, aux_bytes=n_aux, f_valid=f_valid),
                               frac_with_survey_A=dict(A=A_survey, frac=frac_survey,
                                                       note="same launch priced without the h_in pass-through block"),
                               step=result.get("step"))
@@ -851,6 +885,52 @@ def eval_forward_ms(wl, dev, iters=300):
     return (time.perf_counter() - t0) * 1e3 / iters
 
 
+def eager_stack_ms(wl, dev, layers=4, iters=200, warm=30):
+    """EAGER training step of a STACK of `layers` identical layers (the reference's nets hold L = 4: configs/*.json "L": 4) on the
+    workload's batch: forward through all, ONE backward.  Autograd's hand-over to its device thread (~65 us) is paid once per
+    backward(), not once per layer, so a single-layer eager leg overstates the per-layer host cost.  Returns
+    (ms per step, ms per step with autograd on the calling thread)."""
+    batch, graph = build_batch(wl, 41, dev)
+    F_, N = wl["hidden"], graph.num_nodes
+    avg_log = float(torch.log(graph.in_degree.float() + 1).mean().item())
+    torch.manual_seed(0)
+    stack = [dgn_amd.DGNLayer(F_, F_, wl.get("dropout", 0.0), wl.get("graph_norm", True), True, wl["aggregators"], wl["scalers"], {"log": torch.tensor(avg_log)},
+                              wl["type_net"], True, towers=wl["towers"], edge_features=False, edge_dim=0).model.to(dev).train() for _ in range(layers)]
+    params = [p for l in stack for p in l.parameters()]
+    gen = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(N, F_, device=dev, generator=gen).requires_grad_(True)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = batch["snorm_n"].to(dev)
+
+    def step():
+        graph._wcache.clear()
+        h.grad = None
+        for p in params:
+            p.grad = None
+        y = h
+        for l in stack:
+            y = l(graph, y, None, snorm)
+        y.backward(ct)
+
+    def timed():
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3 / iters
+
+    ms = timed()
+    torch.autograd.set_multithreading_enabled(False)
+    try:
+        ms_st = timed()
+    finally:
+        torch.autograd.set_multithreading_enabled(True)
+    return ms, ms_st
+
+
 def _max_graph_edges(b):
     """Largest number of directed edges of one graph of a synthetic batch (host side: what a data loader knows about its data set)."""
     import numpy as np
@@ -1037,11 +1117,11 @@ def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
     # default: the BASELINE five (c2 is the headline); everything else behind --all-extras (VERDICT r03 item 1)
-    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1),
+    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1),
             ("c5_layer", 3, 1)]      # (row f1 on the driver line: the C5 graph through a whole simple layer forward)
     if args.all_extras:
         plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
-                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30),
+                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c4_b128", 200, 30),
                 ("c5", 3, 1), ("c5_layer", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
@@ -1052,7 +1132,7 @@ def run_extras(args, dev):
             extra[name] = compact(res)
             extra[name]["config"] = wl["desc"]
             extra[name]["steps"], extra[name]["warmup"] = steps, warmup
-            if name in ("c3", "c4", "c2_b128", "zinc_json_b128", "c1_b128", "hiv_json_b128") and wl["type_net"] not in ("op", "layer_fwd"):
+            if name in ("c3", "c4", "c2_b128", "zinc_json_b128", "c1_b128", "hiv_json_b128", "c4_b128", "pattern_json") and wl["type_net"] not in ("op", "layer_fwd"):
                 # batch-128 / batch-2048 legs are host-bound when every kernel is launched from Python (the reference's own regime): the
                 # same step captured once into a HIP graph and replayed is what the GPU side costs
                 import copy
@@ -1093,6 +1173,11 @@ def run_extras(args, dev):
                         extra[name]["eval_fwd_ms"] = eval_forward_ms(dict(WORKLOADS[name]), dev)
                     except Exception as exc:
                         extra[name]["eval_fwd_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                    try:      # the eager step per layer inside a 4-layer stack (one backward() for four layers)
+                        ms4, ms4_st = eager_stack_ms(dict(WORKLOADS[name]), dev)
+                        extra[name]["stack4_ms"], extra[name]["stack4_st_ms"] = ms4 / 4, ms4_st / 4
+                    except Exception as exc:
+                        extra[name]["stack4_error"] = f"{type(exc).__name__}: {exc}"[:200]
             if name == "c1" and not args.no_cpu_baseline:
                 # BASELINE configs[0] is quoted on the reference's CPU path: the same bounded CPU sample for it
                 extra[name]["cpu_baseline"] = cpu_baseline(wl, batch, min(args.cpu_sample_graphs, len(batch["sizes"])), reps=3)
@@ -1161,7 +1246,8 @@ def compact_line(line):
             if "error" in e:
                 ex[name] = dict(error=str(e["error"])[:80])
                 continue
-            ee = {k: e[k] for k in ("ms_per_step", "value", "captured_ms_per_step", "eager_st_ms_per_step", "eager_direct_ms_per_step", "eval_fwd_ms") if k in e}
+            ee = {k: e[k] for k in ("ms_per_step", "value", "scaling", "allreduce_ms_max", "captured_ms_per_step", "eager_st_ms_per_step", "eager_direct_ms_per_step", "eval_fwd_ms",
+                                    "stack4_ms", "stack4_st_ms") if k in e}
             if e.get("roofline"):
                 ee["frac"] = e["roofline"].get("frac")
                 if e["roofline"].get("bound") == "mfma":      # (c5_layer: the fraction is of the fp32 MFMA peak, on the posttrans product)
@@ -1257,6 +1343,26 @@ def main():
         wl["scalers"] = args.scalers
     runner = run_c5 if wl["type_net"] == "op" else (run_c5_layer if wl["type_net"] == "layer_fwd" else run_layer_workload)
     res = runner(args, wl, rank, world, dev)
+    # N > 1, default workload: the data-parallel config BASELINE.json / SURVEY 8(e) NAME -- configs[3]: ogbg-molhiv, batch 2048 -- rides on
+    # the same line, weak (one 2048-graph batch per rank) and strong (ONE 2048-graph batch, graphs sharded over the ranks by edge count:
+    # dist.shard_by_edges), each with the flat gradient all-reduce inside the timed step.  Every rank runs the legs (collectives);
+    # rank 0 reports them as extra.c4_dp_weak / extra.c4_dp_strong (VERDICT r05 missing #5).
+    dp_extra = {}
+    if (world > 1 or os.environ.get("DGN_BENCH_DP_EXTRAS") == "1") and args.workload == "c2" and not args.no_extras and not args.hipgraph:
+        import copy
+        for mode in ("weak", "strong"):
+            a2 = copy.copy(args)
+            a2.scaling = mode
+            try:
+                r2 = run_layer_workload(a2, dict(WORKLOADS["c4"]), rank, world, dev, steps=20, warmup=5, tag="c4")
+                r2 = r2[0] if isinstance(r2, tuple) else r2
+                dp_extra[f"c4_dp_{mode}"] = dict(ms_per_step=r2["ms_per_step"], value=r2["value"], scaling=r2["scaling"],
+                                                 edges_per_rank=r2["edges_per_rank"], nodes_per_rank=r2["nodes_per_rank"],
+                                                 allreduce_ms_max=(r2.get("allreduce") or {}).get("ms_max"),
+                                                 config=WORKLOADS["c4"]["desc"] + (": one global batch sharded by edge count" if mode == "strong" else ": one batch per rank"))
+            except Exception as exc:       # (symmetric across ranks: the same code on the same shapes)
+                dp_extra[f"c4_dp_{mode}"] = dict(error=f"{type(exc).__name__}: {exc}"[:160])
+            torch.cuda.empty_cache()
     if rank != 0:
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
@@ -1296,6 +1402,8 @@ def main():
         del res, result, batch
         torch.cuda.empty_cache()
         line["extra"] = run_extras(args, dev)
+    if dp_extra:
+        line.setdefault("extra", {}).update(dp_extra)
     emit(line, args)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -246,19 +246,29 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     return DGN_OK;
 }
 
-int set_lds(const void* kernel) {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: once per (kernel, device) -- `done` is the caller's
+// static bit mask of the devices that have it (one process per GPU is the deployment; a second device in one process must not launch
+// with the 64 KB default: ADVICE r05)
+int set_lds(const void* kernel, unsigned long long& done) {
+    int dev = 0;
+    DGN_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return DGN_OK;
     DGN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+    done |= bit;
     return DGN_OK;
 }
 
 template <bool FWD, class O, class C, bool PRE>
 int launch_block(const P& p, dim3 grid, int threads, hipStream_t stream) {
     if constexpr (FWD) {
-        static const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_forward<O, C, PRE>));
+        static unsigned long long done = 0;
+        const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_forward<O, C, PRE>), done);
         if (rc) return rc;
         hipLaunchKernelGGL((blk::blk_forward<O, C, PRE>), grid, dim3(threads), (size_t)p.L.total * 4, stream, p);
     } else {
-        static const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_backward<O, C, PRE>));
+        static unsigned long long done = 0;
+        const int rc = set_lds(reinterpret_cast<const void*>(&blk::blk_backward<O, C, PRE>), done);
         if (rc) return rc;
         hipLaunchKernelGGL((blk::blk_backward<O, C, PRE>), grid, dim3(threads), (size_t)p.L.total * 4, stream, p);
     }
@@ -336,7 +346,8 @@ extern "C" int dgn_block_layer_forward(const DgnBlockLayer* L, void* stream_) {
     p.bn_part = reinterpret_cast<double*>(static_cast<char*>(L->ws) + w.bn_part);
     p.dbg_agg = L->dbg_agg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd));
+    static unsigned long long lds_done = 0;
+    const int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_fwd), lds_done);
     if (lds_rc) return lds_rc;
     DGN_TRY_RC(launch_for_list<true>(p, d.has_pre != 0, dim3(d.n_blocks, d.T), block_threads(d, false), stream));
     hipLaunchKernelGGL(blk::blk_tail_fwd, dim3(d.n_tail), dim3(kTailThreads), tail_fwd_lds(d), stream, p);
@@ -362,7 +373,8 @@ extern "C" int dgn_block_layer_backward(const DgnBlockLayer* L, const DgnBlockGr
     p.blk_part = reinterpret_cast<float*>(ws + w.blk_part);
     p.dbg_gagg = L->dbg_gagg; p.dbg_time = L->dbg_time;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd));
+    static unsigned long long lds_done = 0;
+    const int lds_rc = set_lds(reinterpret_cast<const void*>(&blk::blk_tail_bwd), lds_done);
     if (lds_rc) return lds_rc;
     hipLaunchKernelGGL(blk::blk_tail_bwd, dim3(d.n_tail), dim3(kTailThreads), tail_bwd_lds(d), stream, p);
     DGN_HIP_CHECK(hipGetLastError());

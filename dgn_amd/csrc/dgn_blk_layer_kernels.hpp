@@ -93,11 +93,17 @@ struct P {
 __device__ __forceinline__ int64_t valid_rows(const P& p) { return p.n_valid ? min(*p.n_valid, p.N) : p.N; }
 // a block's descriptor: first row, end row, first slot, end slot (negative slots: taken from the row pointers -- padded batches, whose
 // table is written by the host from the graph sizes alone); an EMPTY or over-sized block is skipped by its workgroups
-__device__ __forceinline__ int4 block_desc(const P& p) {
+// `skipped_end`: the end row of a block that was skipped because it is OVER-SIZED (else its first row: nothing skipped) -- the rows
+// [d.x, skipped_end) are valid rows of the batch that no workgroup computes: the caller writes zeros for them (y0 in the forward, d h in
+// the backward), so that the tails, the BatchNorm statistics and a captured optimizer step read defined values until
+// DGNGraph.check_deferred raises (they read uninitialised memory before).
+__device__ __forceinline__ int4 block_desc(const P& p, int& skipped_end) {
     int4 d = reinterpret_cast<const int4*>(p.desc)[blockIdx.x];
     if (d.z < 0 && d.y > d.x) { d.z = p.indptr[d.x]; d.w = p.indptr[d.y]; }
+    skipped_end = d.x;
     if (d.y - d.x > p.R || d.w - d.z > p.Emax) {
         if (p.overflow && threadIdx.x == 0) *p.overflow = 1;
+        skipped_end = (int)min((int64_t)d.y, p.N);
         d.y = d.x;
     }
     return d;
@@ -493,12 +499,16 @@ __global__ __launch_bounds__(512) void blk_forward(const P p) {
     extern __shared__ float lds[];
     Ctx c;
     BLK_STAMP(0);
-    const int4 desc = block_desc(p);
+    int skipped_end;
+    const int4 desc = block_desc(p, skipped_end);
     if (desc.y <= desc.x) {      // (an unused entry of a padded batch's table: zero BatchNorm partials)
         if ((int)threadIdx.x < p.fo) {
             p.bn_part[((int64_t)blockIdx.x * 2 + 0) * p.Fo + blockIdx.y * p.fo + threadIdx.x] = 0.0;
             p.bn_part[((int64_t)blockIdx.x * 2 + 1) * p.Fo + blockIdx.y * p.fo + threadIdx.x] = 0.0;
         }
+        // an over-sized block: zeros for this tower's columns of its y0 rows (the tails read every valid row)
+        for (int i = threadIdx.x; i < (skipped_end - desc.x) * p.fo; i += blockDim.x)
+            p.y0[(int64_t)(desc.x + i / p.fo) * p.Fo + blockIdx.y * p.fo + i % p.fo] = 0.f;
         return;
     }
     block_prologue<HAS_PRE>(p, c, lds, false, desc);
@@ -980,16 +990,22 @@ __global__ __launch_bounds__(1024) void blk_backward(const P p) {
     const int t = blockIdx.y, yc0 = t * fo;
     Ctx c;
     BLK_STAMP(0);
-    const int4 desc = block_desc(p);
-    if (desc.y <= desc.x) {      // (an unused entry of a padded batch's table: a zero parameter-gradient partial)
-        float* bpart0 = p.blk_part + (int64_t)blockIdx.x * p.n_blk_param + t * p.off_tower;
-        for (int i = tid; i < p.off_tower; i += NT) bpart0[i] = 0.f;
-        return;
-    }
-    {   // BatchNorm's column sums of this tower's columns (= d beta, d gamma) from the tail's partials
+    int skipped_end;
+    const int4 desc = block_desc(p, skipped_end);
+    const bool skip = desc.y <= desc.x;
+    if (!skip || blockIdx.x == 0) {
+        // BatchNorm's column sums of this tower's columns (= d beta, d gamma) from the tail's partials (block 0 writes them whether or
+        // not it has rows of its own: a skipped block 0 used to leave them uninitialised)
         double* RED = reinterpret_cast<double*>(lds + p.L.red);
         column_sums_cols(p.tail_part, p.n_tail, p.Fo, yc0, fo, RED);
         if (blockIdx.x == 0 && tid < fo) { p.g_beta[yc0 + tid] = (float)RED[tid]; p.g_gamma[yc0 + tid] = (float)RED[fo + tid]; }
+    }
+    if (skip) {      // (an unused entry of a padded batch's table: a zero parameter-gradient partial)
+        float* bpart0 = p.blk_part + (int64_t)blockIdx.x * p.n_blk_param + t * p.off_tower;
+        for (int i = tid; i < p.off_tower; i += NT) bpart0[i] = 0.f;
+        // an over-sized block: zeros for this tower's columns of its d h rows
+        for (int i = tid; i < (skipped_end - desc.x) * fi; i += NT) p.g_h[(int64_t)(desc.x + i / fi) * p.F + t * fi + i % fi] = 0.f;
+        return;
     }
     block_prologue<HAS_PRE>(p, c, lds, true, desc);
     const int R = c.R;

@@ -33,11 +33,13 @@ class FCLayer(nn.Module):
                  device="cpu"):
         super().__init__()
         self.in_size, self.out_size, self.bias = in_size, out_size, bias
-        self.linear = nn.Linear(in_size, out_size, bias=bias, device=device)
+        # (built on the CPU and moved, as the reference does -- layers.py:80: the default init's draws come from the CPU generator, so a
+        #  fresh layer under the same seed has the reference's weights also with device="cuda")
+        self.linear = nn.Linear(in_size, out_size, bias=bias).to(device)
         self.activation = get_activation(activation)
         self.dropout = nn.Dropout(dropout) if dropout else None      # (the reference passes device= here and would raise: quirk #4)
-        self.b_norm = nn.BatchNorm1d(out_size, device=device) if b_norm else None
-        self.init_fn = init_fn or nn.init.xavier_uniform_
+        self.b_norm = nn.BatchNorm1d(out_size).to(device) if b_norm else None
+        self.init_fn = nn.init.xavier_uniform_      # (layers.py:91: the reference ignores its init_fn argument; so does this)
         self.reset_parameters()
 
     def reset_parameters(self, init_fn=None):

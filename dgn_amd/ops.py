@@ -98,9 +98,10 @@ def _ld(t: Optional[torch.Tensor]) -> int:
 MAX_EDGE_TABLE = 8192      # include/dgn_hip.h: DGN_MAX_EDGE_TABLE (floats of an edge-type table)
 
 
-def _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type=None):
+def _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type=None, f_valid=0):
     m = _lib.DgnMsg()
     m.F = F
+    m.f_valid = int(f_valid)
     m.x_src, m.ld_src = _ptr(x_src), _ld(x_src)
     m.x_dst, m.ld_dst = _ptr(x_dst), _ld(x_dst)
     m.m_edge, m.ld_edge = _ptr(m_edge), _ld(m_edge)
@@ -118,27 +119,38 @@ def _out_layout(t: torch.Tensor):
     return 0, t.stride(0)
 
 
-def agg_aux_bytes(graph: DGNGraph, plan: AggPlan, n_towers: int, F: int, x_src, x_dst, m_edge, x_in, edge_type=None) -> int:
+def agg_aux_bytes(graph: DGNGraph, plan: AggPlan, n_towers: int, F: int, x_src, x_dst, m_edge, x_in, edge_type=None, f_valid: int = 0) -> int:
     """Bytes of the aux table of a forward / backward pair over this message (0: none; see dgn_agg_forward_aux in include/dgn_hip.h)."""
     if len(plan.launches) != 1:
         return 0
     lib = _lib.load()
     spec = _spec_structs(plan, n_towers, 1.0, 0)[0]
-    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type, f_valid)
     g = graph.c_graph
     return int(lib.dgn_agg_aux_bytes(C.byref(g), C.byref(spec), C.byref(msg)))
 
 
-def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out, edge_type=None, aux=None):
+def odd_direct_supported(graph: DGNGraph, plan: AggPlan) -> bool:
+    """Whether the simple layer at an ODD hidden size runs the sweep on the un-padded rows (DgnMsg.f_valid, the `Cfg::ODD` kernels):
+    csrc/dgn_layers.hip odd_direct() -- no hub rows, the library option on, a list with odd-width kernels."""
+    if graph.n_hub or len(plan.launches) != 1 or not _lib.options.odd_direct:
+        return False
+    spec = _spec_structs(plan, 1, 1.0, 0)[0]
+    return bool(_lib.load().dgn_agg_f_valid_supported(C.byref(spec)))
+
+
+def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, out, edge_type=None, aux=None,
+                   f_valid: int = 0):
     """Enqueue dgn_agg_forward (one call per launch group of the plan) on the current stream.  ``edge_type`` (int32 [E], CSR slot
-    order): ``m_edge`` is a [K, F] table and slot j adds row ``edge_type[j]``."""
+    order): ``m_edge`` is a [K, F] table and slot j adds row ``edge_type[j]``.  ``f_valid`` (DgnMsg.f_valid): x_src / x_in hold rows of
+    that ODD width, the sweep runs at F = f_valid + 1 (what the simple layer launches at an odd hidden size)."""
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
-    F = ref.shape[1]
+    F = f_valid + 1 if f_valid else ref.shape[1]
     stream = _lib.stream_ptr(ref.device)
     tower_stride, ld_out = _out_layout(out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
-    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type, f_valid)
     g = graph.c_graph
     for spec, l in zip(specs, plan.launches):
         nbytes = lib.dgn_agg_workspace_bytes(C.byref(g), C.byref(spec), F) if graph.n_hub else 0
@@ -150,19 +162,20 @@ def launch_forward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float
 
 
 def launch_backward(graph: DGNGraph, plan: AggPlan, n_towers: int, avg_log: float, w, x_src, x_dst, m_edge, x_in, g_out,
-                    g_src, g_dst, g_edge, g_in, accumulate: bool = True, edge_type=None, aux=None):
+                    g_src, g_dst, g_edge, g_in, accumulate: bool = True, edge_type=None, aux=None, f_valid: int = 0):
     """Enqueue dgn_agg_backward.  ``accumulate=False``: the sinks g_src/g_dst/g_in may be uninitialised, the first
-    launch of the plan defines them and later launches add; ``True``: every launch adds.  g_edge is overwritten."""
+    launch of the plan defines them and later launches add; ``True``: every launch adds.  g_edge is overwritten.
+    ``f_valid``: as launch_forward (the gradient sinks are F = f_valid + 1 wide)."""
     lib = _lib.load()
     ref = x_src if x_src is not None else (x_dst if x_dst is not None else m_edge)
-    F = ref.shape[1]
+    F = f_valid + 1 if f_valid else ref.shape[1]
     dev = g_out.device
     grads = _lib.DgnMsgGrad()
     grads.g_src, grads.ld_src = _ptr(g_src), _ld(g_src)
     grads.g_dst, grads.ld_dst = _ptr(g_dst), _ld(g_dst)
     grads.g_edge, grads.ld_edge = _ptr(g_edge), _ld(g_edge)
     grads.g_in, grads.ld_in = _ptr(g_in), _ld(g_in)
-    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type)
+    msg = _msg_struct(F, x_src, x_dst, m_edge, x_in, edge_type, f_valid)
     stream = _lib.stream_ptr(dev)
     tower_stride, ld_gout = _out_layout(g_out)
     specs = _spec_structs(plan, n_towers, avg_log, tower_stride)
@@ -1459,7 +1472,14 @@ def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, 
         L.n_valid = n_valid.data_ptr()
     if table.get("overflow") is not None:
         L.overflow = table["overflow"].data_ptr()
-    return L, (cg, tb, spec, chans, cols, n_valid)
+    # (the table's descriptor tensor is kept with the struct: graph.invalidate_caches() between a forward and its backward must not
+    #  free the memory the struct's raw pointer names)
+    return L, (cg, tb, spec, chans, cols, n_valid, table.get("desc"), table.get("overflow"))
+
+
+def _plan_signature(plan):
+    """What of an AggPlan the graph-block route's LDS plan, workspace sizes and parameter-gradient layout depend on."""
+    return (tuple(plan.aggregators), tuple(plan.scalers))
 
 
 def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
@@ -1471,7 +1491,8 @@ def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
     table = graph.block_table()
     if table is None:
         return False
-    key = (id(plan), type_net, T, fi, fo)
+    # (a stable signature of the plan, not id(plan): an id can be reused after garbage collection)
+    key = (_plan_signature(plan), type_net, T, fi, fo)
     ok = table.setdefault("ok", {})
     if key not in ok:
         L = _lib.DgnBlockLayer()
@@ -1490,7 +1511,8 @@ def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
 def _block_sizes(lib, table, L, cfg, params):
     """Per (batch, layer shape): workspace bytes, parameter-gradient floats and the split of the flat gradient buffer (cached on the
     block table: they depend on the block table and the widths only)."""
-    key = ("sizes",) + tuple(cfg[:4]) + (len(params),)
+    # (the aggregator / scaler counts are part of the key: ld_post, the gradient floats and the workspaces depend on A x S)
+    key = ("sizes",) + tuple(cfg[:4]) + (tuple(int(p_.numel()) for p_ in params),)
     ent = table.get(key)
     if ent is None:
         type_net, T, fi, fo = cfg[:4]

@@ -4,14 +4,20 @@ itself is (x4): max / min / |.| routings flip between fp32 evaluations where two
 reference as much as here.  Every call REPORTS the achieved maximum error and how many entries needed the escape clause (pytest -rA
 shows the lines) -- apart from the entries on which the fp32 oracle itself left its fp64 evaluation by more than the tolerance, which
 are reported as the oracle's flips -- and asserts that they are at most 0.5 % of the tensor: a regression from 3e-6 to 1.9e-5, or a kernel that leans on
-the clause, no longer passes silently.  Tensors whose true value is numerically zero everywhere (the gradient of a bias in front of a
-BatchNorm) are exempt from the fraction: both evaluations return rounding noise there, entry by entry unrelated."""
+the clause, no longer passes silently.  The LOCAL clause is capped too (1 % of the tensor by default).  Only tensors whose true value is
+numerically ZERO everywhere -- the fp64 oracle's largest entry is at most 1e-6 of the upstream (cotangent) scale: the gradient of a bias
+in front of a BatchNorm -- are exempt from the fractions: both evaluations return rounding noise there, entry by entry unrelated
+(the round-5 exemption, "fp64 value <= 1e3 x the fp32 oracle's worst error", let any tensor with one max / min
+routing flip through).  ``max_escape_fraction = 0`` is what the BASELINE-config tests pass: no entry may need the tensor-wide clause;
+lists with ``std`` (ill-conditioned in the reference's own fp32 arithmetic, profiles/NOTES.md) name their looser caps explicitly."""
 import torch
 
 import os
 
 REPORT = []
 MAX_ESCAPE_FRACTION = 0.005
+MAX_LOCAL_FRACTION = 0.01
+ZERO_TENSOR = 1e-6          # max|fp64 value| <= ZERO_TENSOR x upstream scale: a numerically zero tensor
 REPORT_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
 
 
@@ -26,8 +32,11 @@ def _to_report_file(line):
         pass
 
 
-def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True):
-    """``|ours - r32| <= atol * scale + rtol * |r64|`` per entry (scale = max(1, max|r64|) unless given), or the fp64 clause."""
+def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True, max_escape_fraction=None, max_local_fraction=None,
+          upstream_scale=1.0):
+    """``|ours - r32| <= atol * scale + rtol * |r64|`` per entry (scale = max(1, max|r64|) unless given), or the fp64 clause.
+    ``upstream_scale``: the size of the cotangent the tensor's gradient was pulled back from (1 for the suite's unit-variance cotangents);
+    a tensor is "numerically zero" -- exempt from the clause caps -- when max|fp64 value| <= 1e-6 of it."""
     a, r32, r64 = ours.detach().cpu().double(), r32.detach().cpu().double(), r64.detach().cpu().double()
     scale = abs_scale if abs_scale is not None else max(1.0, float(r64.abs().max()) if r64.numel() else 1.0)
     tol = atol * scale + rtol * r64.abs()
@@ -54,8 +63,14 @@ def check(ours, r32, r64, name, rtol, atol, abs_scale=None, exempt_noise=True):
     print(line)
     _to_report_file(line)
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {n} entries off ({line})"
-    noise = exempt_noise and float(r64.abs().max() if n else 0.0) <= 1e3 * max(ref_err, 1e-12)
+    noise = exempt_noise and float(r64.abs().max() if n else 0.0) <= ZERO_TENSOR * max(float(upstream_scale), 1e-30)
     if not noise:
-        allowed = max(1, int(MAX_ESCAPE_FRACTION * n))
+        if max_escape_fraction is None:
+            allowed = max(1, int(MAX_ESCAPE_FRACTION * n))
+        else:
+            allowed = int(max_escape_fraction * n)
         assert escaped <= allowed, f"{name}: {escaped} of {n} entries needed the fp64 clause (allowed {allowed}): {line}"
+        cap = MAX_LOCAL_FRACTION if max_local_fraction is None else max_local_fraction
+        allowed_local = max(1, int(cap * n))
+        assert local <= allowed_local, f"{name}: {local} of {n} entries needed the local fp64 clause (allowed {allowed_local}): {line}"
     return escaped

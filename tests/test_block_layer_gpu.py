@@ -69,9 +69,10 @@ def _vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, b, towers=5
     assert bool(taken) == expect_route, "the graph-block route was " + ("not taken" if expect_route else "taken")
     params = dict(layer.named_parameters())
     gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
-    check(y, y32, y64, f"block {type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0)
+    strict = not any(a in ("std", "var") for a in aggs.split())      # (std / var lists: the reference's own fp32 evaluation is unstable)
+    check(y, y32, y64, f"block {type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0, max_escape_fraction=0.0 if strict else None)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
-        _check_grad(a, r32, r64, f"block {type_net} F={F_} {k}")
+        _check_grad(a, r32, r64, f"block {type_net} F={F_} {k}", strict=strict)
     for k, v in (stats or {}).items():
         np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
     for k, v in layer.state_dict().items():
@@ -339,7 +340,18 @@ def test_padded_batch_beyond_the_block_capacity_is_reported(monkeypatch):
     pb.graph.set_block_capacity(24, max(sizes), 8)                 # (every molecule has more than 8 directed edges)
     pb.load(b["src"].to(dev), b["dst"].to(dev), N, b["eig"].to(dev), graph_sizes=sizes)
     snorm = torch.ones(N + 10, 1, device=dev)
-    layer(pb.graph, torch.randn(N + 10, 32, device=dev, requires_grad=True), None, snorm).sum().backward()
+    # poison the caching allocator's free blocks: whatever the step leaves unwritten would come back as NaN (the skipped
+    # blocks' y0 / d h rows and -- block 0 skipped -- d gamma / d beta were uninitialised memory until check_deferred raised)
+    junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 20, 1 << 18, 1 << 16, (N + 10) * 32, (N + 10) * 32, 4096, 512, 64)]
+    del junk
+    hp = torch.randn(N + 10, 32, device=dev, requires_grad=True)
+    y = layer(pb.graph, hp, None, snorm)
+    y.sum().backward()
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(hp.grad).all())
+    for k, v in layer.named_parameters():
+        assert v.grad is not None and bool(torch.isfinite(v.grad).all()), k
+    for k, v in layer.state_dict().items():
+        assert bool(torch.isfinite(v.float()).all()), k
     with pytest.raises(_lib.DgnError):
         pb.graph.check_deferred()
 

@@ -195,7 +195,7 @@ def test_headline_config_layer_vs_oracle_on_molecules(monkeypatch, linear_min_ro
     np.testing.assert_allclose(y.detach().cpu().numpy(), y32.detach().numpy(), rtol=2e-5, atol=2e-5)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
         from parity_util import check
-        check(a, r32, r64, f"headline towers layer {k}", rtol=2e-4, atol=2e-5)
+        check(a, r32, r64, f"headline towers layer {k}", rtol=2e-4, atol=2e-5, max_escape_fraction=0.0)
         a = a.cpu().double()
         scale = max(1.0, float(r64.abs().max()))
         assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale, f"{k}: not close to the fp64 evaluation"

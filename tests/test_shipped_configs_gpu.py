@@ -18,11 +18,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _check_grad(a, r32, r64, name):
+def _check_grad(a, r32, r64, name, strict=True):
     """the headline test's criterion: within tolerance of the fp32 oracle, or as close to the fp64 oracle as the fp32 oracle is -- counted,
-    reported and bounded by parity_util.check; and never far from the fp64 evaluation"""
+    reported and bounded by parity_util.check; and never far from the fp64 evaluation.  ``strict`` (the BASELINE / shipped-json lists:
+    every config test of this module and of test_block_layer_gpu.py): NO entry may need the tensor-wide fp64 clause (DESIGN section 3's
+    claim, asserted); lists with ``std`` / ``var`` -- ill-conditioned in the reference's own fp32 arithmetic -- name looser caps."""
     from parity_util import check
-    check(a, r32, r64, name, rtol=1e-4, atol=2e-5)
+    if strict:
+        check(a, r32, r64, name, rtol=1e-4, atol=2e-5, max_escape_fraction=0.0)
+    else:
+        check(a, r32, r64, name, rtol=1e-4, atol=2e-5, max_escape_fraction=0.01, max_local_fraction=0.05)
     a, r32 = a.cpu().double(), r32.double()
     scale = max(1.0, float(r64.abs().max()))
     # (a max / min / |.| routing that flips between fp32 and fp64 moves a gradient entry by O(weight): with O(1) weights the fp32
@@ -71,7 +76,7 @@ def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch
     params = dict(layer.named_parameters())
     gd = torch.autograd.grad(y, [hd] + [params[k] for k in names], ct.to(dev))
     from parity_util import check
-    check(y, y32, y64, f"{type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0)
+    check(y, y32, y64, f"{type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0, max_escape_fraction=0.0)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
         _check_grad(a, r32, r64, k)
     for k, v in stats.items():
