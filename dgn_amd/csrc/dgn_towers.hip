@@ -49,6 +49,39 @@ __global__ __launch_bounds__(256) void assemble_params(int64_t n, const int64_t*
     out[i] = q < 0 ? 0.f : reinterpret_cast<const float*>(ptrs[q])[map_off[i]];
 }
 
+// Round 6: BatchNorm's backward column sums without a pass over the rows.  With z = y1 W_mix^T + b, y1 = gamma * xhat + beta:
+//     g_y1 = g_z W_mix   =>   sum_m g_y1[m][c]            = sum_o (sum_m g_z[m][o]) W[o][c]             = sum_o db[o] W[o][c]
+//                              sum_m g_y1[m][c] xhat[m][c] = sum_o (sum_m g_z[m][o] xhat[m][c]) W[o][c] = sum_o dWx[o][c] W[o][c]
+// where dWx = g_z^T xhat and db = g_z^T 1 are what the mixing network's weight-gradient pass accumulates anyway when its operand is
+// normalised WITHOUT the affine part (dgn_linear_wgrad_bn with gamma = beta = NULL); the weight gradient proper follows as
+//     d W_mix[o][c] = sum_m g_z[m][o] y1[m][c] = gamma[c] dWx[o][c] + beta[c] db[o].
+// A wave per column c, lane o (+ 64 q) a row of the weight, doubles for the two 70-term sums (added across the lanes in a fixed order):
+// replaces bn_bwd_stats (37 us on ZINC-12k: a read of g_y1 and y0) + bn_bwd_finalize.  (A first version -- one thread per column walking
+// the rows -- took 28 us: 70 dependent round trips.)  Reference: autograd through nn.BatchNorm1d at nets/dgn_layer.py:272-273.
+__global__ __launch_bounds__(64) void mix_bn_finalize(int Fo, const float* __restrict__ dwx, const float* __restrict__ db, const float* __restrict__ w,
+                                                      int64_t ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ g_w, int64_t ldgw, float* __restrict__ g_gamma, float* __restrict__ g_beta,
+                                                      float* __restrict__ sums) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+    for (int o = lane; o < Fo; o += 64) {
+        const float x = dwx[(int64_t)o * Fo + c], b = db[o], wv = w[(int64_t)o * ldw + c];
+        s0 += (double)b * (double)wv;
+        s1 += (double)x * (double)wv;
+        g_w[(int64_t)o * ldgw + c] = ga * x + be * b;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    if (lane == 0) {
+        sums[c] = (float)s0; sums[Fo + c] = (float)s1;
+        g_beta[c] = (float)s0; g_gamma[c] = (float)s1;
+    }
+}
+
 struct Dims {
     int64_t N;
     int T, fi, fo, S, Fm, Fo, K;
@@ -189,7 +222,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
 
 namespace {
 struct BwdScratch {
-    size_t g_z, g_y1, sums, g_yr, g_aggx, g_pq, g_in, g_hpq, bn_ws, comb_ws, wg_mix, wg_post, wg_sd, agg_ws, total;
+    size_t g_z, g_y1, sums, g_yr, g_aggx, g_pq, g_in, g_hpq, bn_ws, comb_ws, wg_mix, wg_post, wg_sd, agg_ws, dwx, total;
 };
 BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
     BwdScratch s{};
@@ -206,6 +239,7 @@ BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
     s.wg_post = take(dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T));
     s.wg_sd = take(std::max(dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1), dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi)));
     s.agg_ws = take(dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1));
+    s.dwx = take((size_t)d.Fo * d.Fo * 4);
     s.total = off;
     return s;
 }
@@ -237,11 +271,22 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // g_z = g_out * act'(z + b_mix) is formed while the strips are staged and leaves as a side output for the weight gradient, whose
     // ones-column delivers the bias gradient (the separate path: dgn_bias_act_backward, then the two products)
     const bool fused_act = L->y1 == nullptr && d.Fo % 16 != 0 && (reinterpret_cast<uintptr_t>(g_z) & 15) == 0 && dgn_linear_act_supported(d.Fo, d.Fo);
+    // (no dropout between BatchNorm and the mixing network, every row of the buffer a row of the batch: BatchNorm's column sums follow
+    //  from the mixing weight gradient, mix_bn_finalize above)
+    const bool bn_derived = fused_act && L->drop_p == 0.0f && !L->n_valid && option(OPT_BN_FROM_WGRAD) != 0;
     if (fused_act) {
         if (L->zmask) DGN_TRY(dgn_linear_forward_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
         else DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
-        DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
-                                    ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+        if (bn_derived) {
+            DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, f(s.dwx), d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, nullptr, nullptr,
+                                        ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+            hipLaunchKernelGGL(mix_bn_finalize, dim3(d.Fo), dim3(64), 0, st, d.Fo, (const float*)f(s.dwx), (const float*)G->g_b_mix, L->w_mix, (int64_t)d.Fo,
+                               L->bn_gamma, L->bn_beta, G->g_w_mix, (int64_t)d.Fo, G->g_gamma, G->g_beta, sums);
+            DGN_HIP_CHECK(hipGetLastError());
+        } else {
+            DGN_TRY(dgn_linear_wgrad_bn(d.N, d.Fo, d.Fo, g_z, L->y0, G->g_w_mix, d.Fo, G->g_b_mix, L->save_mean, L->save_invstd, L->bn_gamma, L->bn_beta,
+                                        ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+        }
     } else {
         if (!L->z) { set_error("%s: zmask without the fused activation-gradient kernel: give z", fn); return DGN_ERR_INVALID; }
         DGN_TRY(dgn_bias_act_backward(d.N, d.Fo, G->g_out, L->z, d.Fo, L->b_mix, 2, L->slope, g_z, G->g_b_mix, ws + s.bn_ws,
@@ -256,8 +301,9 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // the towers' dropout: the mask on the gradient of the normalised rows, in place         (:275)
     if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_backward(d.N * d.Fo, g_y1, L->drop_mask, L->drop_p, g_y1, stream));
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
-    DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
-                                 G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));
+    if (!bn_derived)
+        DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
+                                     G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));
     DgnBnGrad bn{};
     bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
     bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;

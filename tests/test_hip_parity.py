@@ -740,7 +740,13 @@ def test_whole_layer_call_equals_per_kernel_route(monkeypatch, residual, graph_n
     assert set(pa) == set(pb)
     for k in pa:
         assert pa[k] is not None and pb[k] is not None, k
-        _close(pa[k], pb[k], 1e-5, 1e-5 * max(1.0, float(pb[k].abs().max())), msg=k)
+        atol = 1e-5 * max(1.0, float(pb[k].abs().max()))
+        if "posttrans" in k and k.endswith("bias"):
+            # a bias in front of BatchNorm: its true gradient is ZERO; what either route returns is the rounding error of BatchNorm's
+            # backward column sums (x gamma invstd) -- the whole-layer call derives them from the mixing weight gradient's fp32 partials
+            # (round 6, csrc/dgn_towers.hip mix_bn_finalize), the per-kernel route from fp64 partials: both noise, N-row sums of O(1) terms
+            atol = 2e-7 * N
+        _close(pa[k], pb[k], 1e-5, atol, msg=k)
     for k in sa:
         _close(sa[k], sb[k], 1e-6, 1e-6, msg=k)
 
