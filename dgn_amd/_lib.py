@@ -14,13 +14,13 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
 # symbols include/dgn_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = ("dgn_abi_version", "dgn_sizeof", "dgn_last_error", "dgn_set_option", "dgn_get_option", "dgn_edge_weights_workspace_bytes", "dgn_edge_weights",
-           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_towers_layer_zmask_supported",
+           "dgn_agg_workspace_bytes", "dgn_agg_forward", "dgn_agg_aux_bytes", "dgn_agg_forward_aux", "dgn_agg_backward_aux", "dgn_towers_layer_agg_aux_bytes", "dgn_dense_layer_agg_aux_bytes", "dgn_agg_backward_workspace_bytes", "dgn_agg_edge_table_workspace_bytes", "dgn_agg_backward", "dgn_linear_forward_bn", "dgn_linear_wgrad_bn", "dgn_linear_forward_act", "dgn_linear_act_supported", "dgn_linear_forward_add", "dgn_linear_add_supported", "dgn_linear_forward_bn_act", "dgn_linear_act_mask_bytes", "dgn_linear_forward_bn_act_mask", "dgn_linear_forward_act_mask", "dgn_linear_bnb_supported", "dgn_linear_wgrad_bn_act_mask", "dgn_linear_forward_act_mask_bnb", "dgn_linear_combine_backward_weight_bias", "dgn_towers_layer_zmask_supported",
            "dgn_scale_combine_forward", "dgn_scale_combine_backward_workspace_bytes", "dgn_scale_combine_backward",
            "dgn_bn_tail_workspace_bytes", "dgn_bn_tail_forward", "dgn_bn_tail_backward",
            "dgn_bias_act_forward", "dgn_bias_act_backward", "dgn_dropout_mask_bytes", "dgn_dropout_forward", "dgn_dropout_backward",
@@ -87,7 +87,7 @@ class DgnTowersLayer(C.Structure):
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
                 ("zmask", C.c_void_p), ("agg_aux", C.c_void_p),
-                ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64), ("drop_mask", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64), ("drop_mask", C.c_void_p), ("id_slot1", C.c_int32)]
 
 
 class DgnTowersGrads(C.Structure):

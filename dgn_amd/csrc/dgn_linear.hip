@@ -40,10 +40,10 @@ extern "C" int dgn_linear_supported(int32_t k, int32_t n, int32_t wgrad) {
 static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.kp = lds_stride(p.k);
     const int NT = (p.n + 15) / 16, KB = (p.k + 15) / 16;
-    const bool bn = p.bn_mean != nullptr, actm = p.act_z != nullptr, addm = p.add1 != nullptr;
-    const bool mixm = p.out2 != nullptr, maskm = p.act_mask != nullptr;
-    const int mode = mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (maskm ? kActMask : (addm ? kAddPlain : kPlain))));
-    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0))) * 4;
+    const bool bn = p.bn_mean != nullptr && p.bnb_gz == nullptr, actm = p.act_z != nullptr, addm = p.add1 != nullptr;
+    const bool mixm = p.out2 != nullptr, maskm = p.act_mask != nullptr, bnbm = p.bnb_gz != nullptr;
+    const int mode = bnbm ? kActMaskBnb : (mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (maskm ? kActMask : (addm ? kAddPlain : kPlain)))));
+    const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bnbm ? 5 * NT * 16 : (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0)))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
@@ -62,6 +62,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     p.groups = groups;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const hipError_t e = p.ex.gy ? launch_linear_expand(NT, KB, p, waves * 64, lds, st)
+                       : bnbm    ? launch_linear_bnb(NT, KB, p, waves * 64, lds, st)
                        : p.S > 0 ? launch_linear_combine(NT, KB, p, waves * 64, lds, st)
                        : mixm    ? launch_linear_mix(NT, KB, p, waves * 64, lds, st)
                        : bn      ? launch_linear_bn(NT, KB, p, waves * 64, lds, st)
@@ -203,6 +204,35 @@ extern "C" int dgn_linear_forward_act_mask(int64_t n_rows, int32_t k, int32_t n,
     return launch_linear(fn, p, stream);
 }
 
+extern "C" int dgn_linear_bnb_supported(int32_t k, int32_t n) {
+    return dgn_linear_act_supported(k, n) && dgn_linear_add_supported(k, n) && linear_bnb_shape_ok((n + 15) / 16, (k + 15) / 16);
+}
+
+extern "C" int dgn_linear_forward_act_mask_bnb(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                               const float* w, int64_t ldw, int32_t w_is_kn, const float* y, const float* bn_mean, const float* bn_invstd,
+                                               const float* bn_gamma, const float* sums, const float* row_scale, int32_t f_out, float* gz,
+                                               int64_t stride_gz, void* stream) {
+    const char* fn = "dgn_linear_forward_act_mask_bnb";
+    if (n_rows < 0 || !dgn_linear_bnb_supported(k, n) || f_out < 2 || (f_out & 1) || n % f_out != 0 || n / f_out > 15) {
+        set_error("%s: widths outside the supported set (k=%d n=%d f_out=%d: even f_out dividing n, at most 15 towers)", fn, k, n, f_out);
+        return -1;
+    }
+    if (n_rows == 0) return 0;
+    if (!g || !zmask || !w || !y || !bn_mean || !bn_invstd || !sums || !gz) { set_error("%s: null operand", fn); return -1; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!aligned8(g) || (reinterpret_cast<uintptr_t>(zmask) & 1) || !al16(y) || !aligned8(gz) || (stride_gz & 1)) {
+        set_error("%s: g 8-byte, zmask 2-byte, y 16-byte, gz 8-byte aligned (dense rows, even tower stride)", fn);
+        return -1;
+    }
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = 1;
+    p.A = g; p.W = w; p.ldw = ldw; p.w_kn = w_is_kn;
+    p.act_mask = zmask; p.act_kind = act; p.act_slope = slope;
+    p.bnb_y = y; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bnb_sums = sums; p.rs = row_scale; p.fo = f_out;
+    p.bnb_gz = gz; p.bnb_sT = stride_gz;
+    return launch_linear(fn, p, stream);
+}
+
 extern "C" int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out,
                                           const float* a, int64_t stride_a, const float* w, int64_t ldw, int64_t stride_w,
                                           const float* scale, const float* bias, const float* row_scale, float* y, int64_t ld_y,
@@ -248,12 +278,12 @@ static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, in
     p.groups = wgrad_groups(p.M, k, n, batch);
     p.ones = dbias != nullptr;
     const int NT = (n + 15) / 16, KT = (k + 15) / 16;
-    size_t lds = std::max((size_t)4 * (strip_floats(n) + strip_floats(k) + 64), (size_t)NT * 16 * KT * 16) * 4;
+    size_t lds = std::max((size_t)4 * wgrad_wave_floats(n, k, p.g_mask != nullptr), (size_t)NT * 16 * KT * 16) * 4;
     if (p.bn_mean) {
         p.bn_off = (int)(lds / 4);
         lds += (size_t)4 * KT * 16 * 4;
     }
-    const hipError_t e = p.ex.gy ? launch_wgrad_expand(NT, KT, p, lds, st) : launch_wgrad_plain(NT, KT, p, lds, st);
+    const hipError_t e = p.ex.gy ? launch_wgrad_expand(NT, KT, p, lds, st) : (p.g_mask ? launch_wgrad_gmask(NT, KT, p, lds, st) : launch_wgrad_plain(NT, KT, p, lds, st));
     DGN_HIP_CHECK(e);
     const int64_t total = (int64_t)batch * n * (dbias ? k + 1 : k);
     hipLaunchKernelGGL(ts_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(64 * kFinWaves), 0, st, batch, n, k, p.groups,
@@ -308,6 +338,26 @@ extern "C" int dgn_linear_wgrad_bn(int64_t n_rows, int32_t k, int32_t n, const f
     return launch_wgrad(fn, p, dw, lddw, 0, dbias, 0, ws, ws_bytes, stream);
 }
 
+extern "C" int dgn_linear_wgrad_bn_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                            const float* x, float* dw, int64_t lddw, float* dbias, const float* bn_mean, const float* bn_invstd,
+                                            const float* bn_gamma, const float* bn_beta, void* ws, size_t ws_bytes, void* stream) {
+    const char* fn = "dgn_linear_wgrad_bn_act_mask";
+    if (dbias && k % 16 == 0) { set_error("%s: the bias gradient rides in X's padding column (k %% 16 != 0)", fn); return -1; }
+    if (n_rows < 0 || !dgn_linear_supported(k, n, 1)) { set_error("%s: need even k, n in [2, 160] and at most 45 tiles (k=%d n=%d)", fn, k, n); return -1; }
+    if (!dw) { set_error("%s: null output", fn); return -1; }
+    if (n_rows == 0) return zero_wgrad(dw, lddw, 0, dbias, 0, k, n, 1, static_cast<hipStream_t>(stream));
+    if (!g || !zmask || !x || !bn_mean || !bn_invstd || !aligned8(g) || !aligned8(x) || (reinterpret_cast<uintptr_t>(zmask) & 1)) {
+        set_error("%s: null or misaligned operand", fn);
+        return -1;
+    }
+    WgParams p{};
+    p.M = n_rows; p.n = n; p.k = k; p.T = 1;
+    p.G = g; p.X = x;
+    p.g_mask = zmask; p.act_kind = act; p.act_slope = slope;
+    p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta;
+    return launch_wgrad(fn, p, dw, lddw, 0, dbias, 0, ws, ws_bytes, stream);
+}
+
 static bool expand_ok(const char* fn, int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* gy,
                       int64_t stride_gy, const float* scale) {
     if (n_rows < 0 || n_towers < 1 || n_scalers < 1 || n_scalers > 3 || f_out < 2 || (f_out & 1)) {
@@ -343,17 +393,26 @@ extern "C" int dgn_linear_combine_backward_weight(int64_t n_rows, int32_t n_towe
                                                   const float* gy, int64_t stride_gy, const float* scale, const float* a,
                                                   int64_t stride_a, float* dw, int64_t lddw, int64_t stride_dw, void* ws,
                                                   size_t ws_bytes, void* stream) {
+    return dgn_linear_combine_backward_weight_bias(n_rows, n_towers, n_scalers, f_out, k, gy, stride_gy, scale, a, stride_a, dw, lddw, stride_dw,
+                                                   nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int dgn_linear_combine_backward_weight_bias(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k,
+                                                       const float* gy, int64_t stride_gy, const float* scale, const float* a,
+                                                       int64_t stride_a, float* dw, int64_t lddw, int64_t stride_dw, float* g_sum,
+                                                       void* ws, size_t ws_bytes, void* stream) {
     const char* fn = "dgn_linear_combine_backward_weight";
+    if (g_sum && k % 16 == 0) { set_error("%s: the column sums ride in A's padding column (k %% 16 != 0)", fn); return -1; }
     const int n = n_scalers * f_out;
     if (!expand_ok(fn, n_rows, n_towers, n_scalers, f_out, gy, stride_gy, scale)) return -1;
     if (!dgn_linear_supported(k, n, 1)) { set_error("%s: need even widths in [2, 160] and at most 45 tiles (k=%d S*f_out=%d)", fn, k, n); return -1; }
     if (!dw) { set_error("%s: null output", fn); return -1; }
-    if (n_rows == 0) return zero_wgrad(dw, lddw, stride_dw, nullptr, 0, k, n, n_towers, static_cast<hipStream_t>(stream));
+    if (n_rows == 0) return zero_wgrad(dw, lddw, stride_dw, g_sum, n, k, n, n_towers, static_cast<hipStream_t>(stream));
     if (!a || (stride_a & 1) || !aligned8(a)) { set_error("%s: null or misaligned operand", fn); return -1; }
     WgParams p{};
     p.M = n_rows; p.n = n; p.k = k; p.T = n_towers;
     p.X = a; p.sX = stride_a;
     if (n_scalers == 1) { p.G = gy; p.sG = stride_gy; }
     else { p.ex.gy = gy; p.ex.sT = stride_gy; p.ex.sc = scale; p.ex.S = n_scalers; p.ex.fo = f_out; }
-    return launch_wgrad(fn, p, dw, lddw, stride_dw, nullptr, 0, ws, ws_bytes, stream);
+    return launch_wgrad(fn, p, dw, lddw, stride_dw, g_sum, n, ws, ws_bytes, stream);
 }

@@ -69,10 +69,17 @@ struct LinParams {
     // kMixFwd: kBnPlain's prologue AND an epilogue that also delivers out2 = act(C + ep_bias[c]) (+ add1: the residual), C itself being
     // written as well (the pre-activation the backward needs): BatchNorm -> Linear -> bias + LeakyReLU + residual in one pass
     const float* ep_bias; float* out2;
+    // kActMaskBnb (round 6; the towers layer's mixing-network input gradient): kActMask's operand, and an epilogue that turns the product's
+    // rows g_y1 [M, n] straight into the gradient at posttrans' output -- BatchNorm's backward and the graph norm,
+    //     g_yr[m][c] = rs[m] * (gamma[c] * invstd[c] * (g_y1[m][c] - sums[c] / M - xhat[m][c] * sums[n + c] / M)),  xhat = (y[m][c] - mean[c]) * invstd[c]
+    // (dgn_combine.hip combine_bwd's arithmetic in its order) -- written TOWER-MAJOR: gz[t][m][o], c = t * fo + o, sT floats between
+    // towers.  bnb_y [M, n] dense is BatchNorm's input, bn_mean / bn_invstd / bn_gamma its tables (width n here), bnb_sums [2 n] the column
+    // sums (sum g_y1, sum g_y1 xhat); `rs` (may be NULL) and `fo` as in the combine epilogue.  g_y1 itself is never written.
+    const float* bnb_y; const float* bnb_sums; float* bnb_gz; int64_t bnb_sT;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
-constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 7 ? 2 * KB + 28 : (mode == 5 || mode == 6 ? 64 : 0))); }    // kBnPlain: column state; kActPlain: a second prefetched strip
+constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 7 ? 2 * KB + 28 : (mode == 8 ? 2 * KB + 28 + 64 : (mode == 5 || mode == 6 ? 64 : 0)))); }    // kBnPlain: column state; kActPlain: a second prefetched strip
 constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
@@ -228,12 +235,13 @@ __device__ __forceinline__ void store_strip_mask(float* Xl, const float2 (&pre)[
     }
 }
 
-enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6, kActMask = 7 };        // ts_linear variants
+enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6, kActMask = 7, kActMaskBnb = 8 };        // ts_linear variants
 
 template <int NT, int KB, int MODE>
 __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
-    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain, ADD = MODE == kAddPlain || MIX;
-    constexpr bool ACTM = MODE == kActMask;
+    constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain;
+    constexpr bool BNB = MODE == kActMaskBnb, ADD = MODE == kAddPlain || MIX || BNB;      // (BNB: the epilogue's strip-shaped operand is BatchNorm's input)
+    constexpr bool ACTM = MODE == kActMask || BNB;
     extern __shared__ float lds[];
     constexpr int NL = 2 * KB;                       // float2 loads per lane and strip: 16 * (k/2) / 64 <= 2 * KB
     constexpr int NLC = 2 * NT;                      // the same for a strip of C
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
     float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
     float* Bn = Cb + NT * 16;                        // kBnPlain: [4][KB*16] mean, invstd, gamma, beta of the operand's columns
-    float* Xl = Bn + (BNP ? 4 * KB * 16 : (ACT ? KB * 16 : 0)) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
+    float* Xl = Bn + (BNP ? 4 * KB * 16 : (ACT ? KB * 16 : (BNB ? 5 * NT * 16 : 0))) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
     float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
 
@@ -257,6 +265,11 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     // (branch-free: a conditional load would make the compiler wait for everything in flight where the branches join)
     const int S1 = COMBINE ? p.S : 1;
     auto load_fac = [&](int64_t strip) {
+        if constexpr (BNB) {                          // the row's graph-norm factor alone
+            const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
+            fac[3] = *(p.rs ? p.rs + row : A);
+            return;
+        }
         if constexpr (!COMBINE) return;
         const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
         const float* scp = p.sc ? p.sc + row * S1 : A;               // (absent factors: dummy loads, replaced by 1 where `fac` is consumed)
@@ -289,6 +302,18 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     if constexpr (MIX) {
         for (int i = tid; i < NT * 16; i += blockDim.x) Cb[i] = (i < n && p.ep_bias) ? p.ep_bias[i] : 0.f;
     }
+    if constexpr (BNB) {      // [mean | invstd | gamma * invstd | sum g / M | sum g xhat / M] of the OUTPUT's columns
+        const float inv_n = 1.f / (float)p.M;
+        for (int i = tid; i < NT * 16; i += blockDim.x) {
+            const bool in = i < n;
+            const float is = in ? p.bn_invstd[i] : 0.f;
+            Bn[i] = in ? p.bn_mean[i] : 0.f;
+            Bn[NT * 16 + i] = is;
+            Bn[2 * NT * 16 + i] = (in && p.bn_gamma) ? p.bn_gamma[i] : 1.f;
+            Bn[3 * NT * 16 + i] = in ? p.bnb_sums[i] * inv_n : 0.f;
+            Bn[4 * NT * 16 + i] = in ? p.bnb_sums[n + i] * inv_n : 0.f;
+        }
+    }
     if constexpr (BNP) {
         for (int i = tid; i < KB * 16; i += blockDim.x) {
             const bool in = i < k;
@@ -313,7 +338,51 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     int it = 0, out_it = 0;
     float2 pe1[ADD ? NLC : 1], pe2[ADD ? NLC : 1];
     const int mix_c4 = (4 * lane) % n, mix_d4 = 256 % n;       // kMixFwd: column of the lane's float4 number lane (+ 64 jq) of a result strip
+    // kActMaskBnb: where the two halves of the lane's float4 number jq * 64 + lane of a result strip lie -- row | column << 4 | tower << 12
+    // | column inside the tower << 16 -- the same for every strip (a strip is 16 whole rows)
+    unsigned bnb_at[BNB ? NLC : 1];
+    if constexpr (BNB) {
+#pragma unroll
+        for (int j = 0; j < NLC; ++j) {
+            const int flat = 4 * ((j >> 1) * 64 + lane) + 2 * (j & 1);
+            const int r = flat / n, cc = flat - r * n, t = cc / p.fo, o = cc - t * p.fo;
+            bnb_at[j] = (unsigned)(r & 15) | ((unsigned)cc << 4) | ((unsigned)t << 12) | ((unsigned)o << 16);
+        }
+    }
     auto store_out = [&]() {
+        if constexpr (BNB) {
+            const int64_t row0 = out_strip * kStrip;
+            const int rows_valid = (int)min((int64_t)kStrip, p.M - row0);
+            const float* F = Fl + (out_it & 1) * (kStrip * 4);
+            constexpr int T16 = NT * 16;
+#pragma unroll
+            for (int jq = 0; jq < NLC / 2; ++jq) {
+                if (jq * 64 + lane < (kStrip / 4) * n) {
+                    const float4 c = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const unsigned at = bnb_at[2 * jq + hf];
+                        const int r = at & 15, cc = (at >> 4) & 255, t = (at >> 12) & 15, o = at >> 16;
+                        const float2 yv = pe1[2 * jq + hf];
+                        const float rs = F[4 * r + 3];
+                        float out[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int ce = cc + e;
+                            const float is = Bn[T16 + ce], ga = Bn[2 * T16 + ce];
+                            const float xh = ((e ? yv.y : yv.x) - Bn[ce]) * is;
+                            float g = e ? (hf ? c.w : c.y) : (hf ? c.z : c.x);
+                            g = ga * is * (g - Bn[3 * T16 + ce] - xh * Bn[4 * T16 + ce]);
+                            if (p.rs) g *= rs;
+                            out[e] = g;
+                        }
+                        if (r < rows_valid)
+                            *reinterpret_cast<float2*>(p.bnb_gz + (int64_t)t * p.bnb_sT + (row0 + r) * p.fo + o) = make_float2(out[0], out[1]);
+                    }
+                }
+            }
+            return;
+        }
         if constexpr (COMBINE) {
             const int64_t row0 = out_strip * kStrip;
             const int fo2 = p.fo >> 1;                // (f_out is even: pairs of output columns, 8-byte stores)
@@ -387,6 +456,22 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     };
     // kAddPlain: the epilogue's two extra operands of strip `s_` in store_out's indexing (loaded one iteration ahead of their use)
     auto load_adds = [&](int64_t s_) {
+        if constexpr (BNB) {                          // BatchNorm's input rows of strip s_, float4 number q in pe1[2 jq], pe1[2 jq + 1] (also on the partial last strip)
+            const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
+            const float* b1 = p.bnb_y + s_ * kStrip * n;
+            if (cnt2 == kStrip * (n >> 1)) {
+                const int last4 = (kStrip / 4) * n - 1;
+#pragma unroll
+                for (int jq = 0; jq < NLC / 2; ++jq) {
+                    const float4 u = reinterpret_cast<const float4*>(b1)[min(jq * 64 + lane, last4)];
+                    pe1[2 * jq] = make_float2(u.x, u.y); pe1[2 * jq + 1] = make_float2(u.z, u.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NLC; ++j) pe1[j] = reinterpret_cast<const float2*>(b1)[min(2 * ((j >> 1) * 64 + lane) + (j & 1), cnt2 - 1)];
+            }
+            return;
+        }
         if constexpr (ADD) {
             const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
             const float* any = MIX ? p.out2 : C;                                      // (kMixFwd with a mask output has no C)
@@ -421,6 +506,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         else store_strip<NL>(Xl, pre, k, lane);
         if (COMBINE && lane < 16)
             *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = f4{p.sc ? fac[0] : 1.f, p.sc ? fac[1] : 1.f, p.sc ? fac[2] : 1.f, p.rs ? fac[3] : 1.f};
+        if (BNB && lane < 16) Fl[(it & 1) * (kStrip * 4) + 4 * lane + 3] = p.rs ? fac[3] : 1.f;
         if (out_strip >= 0) store_out();
         load_adds(strip);
         if (strip + step < n_strips) fetch(strip + step);
@@ -479,22 +565,36 @@ struct WgParams {
     // X := BatchNorm(X) formed while the strip is staged (bn_apply's arithmetic, see LinParams); tables live bn_off floats into the LDS
     const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_off;
     ExpandSrc ex;                                    // EXPAND: G is formed from ex (G, sG unused)
+    // GMASK (round 6): G := G * act'(.) with the derivative read from kMixFwd's byte mask (LinParams.act_mask: one byte per float2 of the
+    // dense [M, n] tensor) while the strip is staged -- the mixing network's weight gradient straight from the layer's output gradient,
+    // the masked tensor g_z is never written or re-read
+    const unsigned char* g_mask; int act_kind; float act_slope;
 };
 
 // One wave = one partial sum of the whole [n, k] gradient over its strips (NT x KT accumulator tiles); four waves
 // per workgroup, one per SIMD.  MFMA: D[n][k] += G[m][n] * X[m][k] with the strip's rows as the reduction index
 // (m = 4*(lane/16) + s for the s-th instruction).  Columns past n / k of a strip row alias the next row: they only
 // reach accumulator entries that are never read.
-template <int NT, int KT, bool EXPAND>
-__global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
+// GMASK: the strip's mask bytes (8 n per strip, contiguous) travel as ONE direct-to-LDS load per 64 pieces of 16 bytes
+// (global_load_lds_dwordx4: no registers -- five prefetched mask words per lane put the 70 x 70 shape at 262 registers, one wave per SIMD
+// instead of two, 104.7 us against the plain kernel's 65.8 on ZINC-12k), double-buffered per wave, read back when the strip is staged.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+constexpr int wgrad_wave_floats(int n, int k, bool gmask) { return strip_floats(n) + strip_floats(k) + 64 + (gmask ? 4 * n : 0); }
+// (GMASK at up to 25 accumulator tiles: bounded to the two waves per SIMD the plain kernel reaches on its own -- 254 registers there)
+constexpr int wgrad_min_blocks(int NT, int KT, bool GMASK) { return GMASK && NT == 5 && KT == 5 ? 2 : 1; }      // (hidden 65 .. 80: the shipped widths; 3 x 8 / 8 x 3 would spill)
+template <int NT, int KT, bool EXPAND, bool GMASK = false>
+__global__ __launch_bounds__(256, wgrad_min_blocks(NT, KT, GMASK)) void ts_wgrad(WgParams p) {
+    static_assert(!(EXPAND && GMASK), "one G prologue at a time");
     extern __shared__ float lds[];
     constexpr int NLG = 2 * NT, NLX = 2 * KT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int t = blockIdx.x % p.T, grp = blockIdx.x / p.T;
     const int n = p.n, k = p.k;
-    float* Gl = lds + wave * (strip_floats(n) + strip_floats(k) + 64);
+    float* Gl = lds + wave * wgrad_wave_floats(n, k, GMASK);
     float* Xl = Gl + strip_floats(n);
     float* Fl = Xl + strip_floats(k);                // 16 x f4 scale factors (EXPAND)
+    float* Ml = Fl + 64;                             // GMASK: two mask buffers of 8 n bytes (2 n floats) each
     for (int i = lane; i < strip_floats(n) + strip_floats(k); i += 64) Gl[i] = 0.f;
     const float* BnW = nullptr;
     if (!EXPAND && p.bn_mean) {                      // (uniform)
@@ -517,9 +617,23 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
 
     float2 pg[NLG], px[NLX];
     f4 fac = f4{1.f, 1.f, 1.f, 0.f};
+    int buf = 0;                                     // GMASK: the mask buffer the NEXT fetch lands in
     auto fetch_g = [&](int64_t strip) {
         if constexpr (EXPAND) load_expand<NLG>(pg, fac, p.ex, t, p.M, strip, lane);
         else load_strip<NLG>(pg, G, p.M, n, strip, lane);
+        if constexpr (GMASK) {
+            // 16-byte pieces of the strip's mask; the last strip's pieces past its rows repeat its last one (the allocation ends there)
+            const int rows_s = (int)min((int64_t)kStrip, p.M - strip * kStrip);
+            const int pieces = (rows_s * (n >> 1) + 15) >> 4;
+            const unsigned char* mb = p.g_mask + strip * (kStrip / 2) * n;
+#pragma unroll
+            for (int q = 0; q < (NT * 16 / 2 + 63) / 64; ++q) {
+                const int pi = q * 64 + lane;
+                if (pi < (n >> 1))
+                    __builtin_amdgcn_global_load_lds((glb_void_t*)(mb + 16 * min(pi, pieces - 1)), (lds_void_t*)(Ml + buf * 2 * n + q * 256), 16, 0, 0);
+            }
+            buf ^= 1;
+        }
     };
     f4 acc[NT][KT];
 #pragma unroll
@@ -542,7 +656,16 @@ __global__ __launch_bounds__(256) void ts_wgrad(WgParams p) {
                 for (int j = 0; j < NLG; ++j)
                     if (strip_idx2(j, lane) >= rows * (n >> 1)) pg[j] = make_float2(0.f, 0.f);
             }
-            store_strip<NLG>(Gl, pg, n, lane);
+            if constexpr (GMASK) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the direct-to-LDS mask of this strip has landed: nothing else is in flight here)
+                const unsigned short* mw = reinterpret_cast<const unsigned short*>(Ml + (buf ^ 1) * 2 * n);      // (buf names the NEXT fetch's buffer: this strip's is the other one)
+                unsigned gmz[NLG / 2];
+#pragma unroll
+                for (int jq = 0; jq < NLG / 2; ++jq) gmz[jq] = mw[min(jq * 64 + lane, 4 * n - 1)];
+                store_strip_mask<NLG>(Gl, pg, gmz, n, lane, p.act_kind, p.act_slope, nullptr, 0);
+            } else {
+                store_strip<NLG>(Gl, pg, n, lane);
+            }
         }
         if (BnW) store_strip_bn<NLX>(Xl, px, k, lane, BnW, KT * 16);
         else store_strip<NLX>(Xl, px, k, lane);
@@ -628,10 +751,13 @@ static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T
 // kActPlain holds two prefetched strips: the widest tile shapes would not fit the registers and are not instantiated
 constexpr bool linear_act_shape_ok(int NT, int KB) { return 4 * NT + 8 * KB <= 104; }
 constexpr bool linear_add_shape_ok(int NT, int KB) { return 16 * NT + 4 * KB <= 128; }      // (kAddPlain: two result-shaped strips per wave in registers)
+constexpr bool linear_bnb_shape_ok(int NT, int KB) { return NT <= 5 && KB <= 7; }              // (kActMaskBnb: the unrolled epilogue; wider shapes spill)
 
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
-    if constexpr (((MODE == kActPlain || MODE == kActMask) && !linear_act_shape_ok(NT, KB)) || ((MODE == kAddPlain || MODE == kMixFwd) && !linear_add_shape_ok(NT, KB))) {
+    if constexpr (((MODE == kActPlain || MODE == kActMask || MODE == kActMaskBnb) && !linear_act_shape_ok(NT, KB)) ||
+                  ((MODE == kAddPlain || MODE == kMixFwd || MODE == kActMaskBnb) && !linear_add_shape_ok(NT, KB)) ||
+                  (MODE == kActMaskBnb && !linear_bnb_shape_ok(NT, KB))) {
         return hipErrorInvalidValue;
     } else {
     static bool attr = false;
@@ -645,19 +771,19 @@ hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStr
     return hipGetLastError();
     }
 }
-template <int NT, int KT, bool EXPAND>
+template <int NT, int KT, bool EXPAND, bool GMASK = false>
 hipError_t launch_wgrad_nke(const WgParams& p, size_t lds, hipStream_t st) {
     if constexpr (NT * KT > kMaxWgradTiles) {
         return hipErrorInvalidValue;
     } else {
         static bool attr = false;
         if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_wgrad<NT, KT, EXPAND>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_wgrad<NT, KT, EXPAND, GMASK>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
             if (e != hipSuccess) return e;
             attr = true;
         }
-        hipLaunchKernelGGL((ts_wgrad<NT, KT, EXPAND>), dim3(p.T * p.groups), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((ts_wgrad<NT, KT, EXPAND, GMASK>), dim3(p.T * p.groups), dim3(256), lds, st, p);
         return hipGetLastError();
     }
 }
@@ -682,19 +808,19 @@ hipError_t launch_linear_grid(int nt, int kb, const LinParams& p, int threads, s
     }
     return hipErrorInvalidValue;
 }
-template <int NT, bool EXPAND>
+template <int NT, bool EXPAND, bool GMASK = false>
 hipError_t launch_wgrad_n(int kt, const WgParams& p, size_t lds, hipStream_t st) {
     switch (kt) {
-#define DGN_CASE(K) case K: return launch_wgrad_nke<NT, K, EXPAND>(p, lds, st);
+#define DGN_CASE(K) case K: return launch_wgrad_nke<NT, K, EXPAND, GMASK>(p, lds, st);
         DGN_LIN_CASES(DGN_CASE)
 #undef DGN_CASE
     }
     return hipErrorInvalidValue;
 }
-template <bool EXPAND>
+template <bool EXPAND, bool GMASK = false>
 hipError_t launch_wgrad_grid(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st) {
     switch (nt) {
-#define DGN_CASE(N) case N: return launch_wgrad_n<N, EXPAND>(kt, p, lds, st);
+#define DGN_CASE(N) case N: return launch_wgrad_n<N, EXPAND, GMASK>(kt, p, lds, st);
         DGN_LIN_CASES(DGN_CASE)
 #undef DGN_CASE
     }
@@ -710,8 +836,10 @@ hipError_t launch_linear_bn(int nt, int kb, const LinParams& p, int threads, siz
 hipError_t launch_linear_act(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_add(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_linear_mix(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
+hipError_t launch_linear_bnb(int nt, int kb, const LinParams& p, int threads, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_plain(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 hipError_t launch_wgrad_expand(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
+hipError_t launch_wgrad_gmask(int nt, int kt, const WgParams& p, size_t lds, hipStream_t st);
 
 }  // namespace lin
 }  // namespace dgn

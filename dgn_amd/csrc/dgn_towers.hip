@@ -82,6 +82,14 @@ __global__ __launch_bounds__(64) void mix_bn_finalize(int Fo, const float* __res
     }
 }
 
+// out[t * w + o] = in[t * ld + off + o]: the identity scaler's block of the column sums = d b_post (one tiny launch, capture-safe)
+__global__ __launch_bounds__(256) void pick_block(int T, int w, int ld, int off, const float* __restrict__ in, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * w) return;
+    const int t = i / w, o = i - t * w;
+    out[i] = in[t * ld + off + o];
+}
+
 struct Dims {
     int64_t N;
     int T, fi, fo, S, Fm, Fo, K;
@@ -222,7 +230,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
 
 namespace {
 struct BwdScratch {
-    size_t g_z, g_y1, sums, g_yr, g_aggx, g_pq, g_in, g_hpq, bn_ws, comb_ws, wg_mix, wg_post, wg_sd, agg_ws, dwx, total;
+    size_t g_z, g_y1, sums, g_yr, g_aggx, g_pq, g_in, g_hpq, bn_ws, comb_ws, wg_mix, wg_post, wg_sd, agg_ws, dwx, g_sum, total;
 };
 BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
     BwdScratch s{};
@@ -240,6 +248,7 @@ BwdScratch bwd_scratch(const DgnTowersLayer* L, const Dims& d) {
     s.wg_sd = take(std::max(dgn_linear_wgrad_workspace_bytes(d.N, d.Fm, 2 * d.Fm, 1), dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi)));
     s.agg_ws = take(dgn_agg_backward_workspace_bytes(L->graph, L->spec, d.Fm, 1));
     s.dwx = take((size_t)d.Fo * d.Fo * 4);
+    s.g_sum = take((size_t)d.T * d.S * d.fo * 4);
     s.total = off;
     return s;
 }
@@ -274,7 +283,21 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // (no dropout between BatchNorm and the mixing network, every row of the buffer a row of the batch: BatchNorm's column sums follow
     //  from the mixing weight gradient, mix_bn_finalize above)
     const bool bn_derived = fused_act && L->drop_p == 0.0f && !L->n_valid && option(OPT_BN_FROM_WGRAD) != 0;
-    if (fused_act) {
+    // Round 6, on top of that: the weight gradient FIRST, its G operand formed from g_out and the mask while staged (g_z is never
+    // written); with the column sums known, the input-gradient product turns its rows g_y1 into g_yr = snorm * BatchNorm'(g_y1) in its
+    // epilogue, tower-major (g_y1 is never written, the combine-backward pass is gone), and posttrans' bias gradient comes out of
+    // its weight-gradient pass as the identity scaler's column sums.  8 N Fo floats of traffic -> 5 N Fo, two launches less.
+    const bool mix_fused = bn_derived && L->zmask && L->id_slot1 >= 1 && L->id_slot1 <= d.S && d.K % 16 != 0 && d.T <= 15 &&
+                           (reinterpret_cast<uintptr_t>(L->y0) & 15) == 0 && dgn_linear_bnb_supported(d.Fo, d.Fo) && option(OPT_MIX_BWD_FUSED) != 0;
+    if (mix_fused) {
+        DGN_TRY(dgn_linear_wgrad_bn_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->y0, f(s.dwx), d.Fo, G->g_b_mix, L->save_mean,
+                                             L->save_invstd, nullptr, nullptr, ws + s.wg_mix, dgn_linear_wgrad_workspace_bytes(d.N, d.Fo, d.Fo, 1), stream));
+        hipLaunchKernelGGL(mix_bn_finalize, dim3(d.Fo), dim3(64), 0, st, d.Fo, (const float*)f(s.dwx), (const float*)G->g_b_mix, L->w_mix, (int64_t)d.Fo,
+                           L->bn_gamma, L->bn_beta, G->g_w_mix, (int64_t)d.Fo, G->g_gamma, G->g_beta, sums);
+        DGN_HIP_CHECK(hipGetLastError());
+        DGN_TRY(dgn_linear_forward_act_mask_bnb(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, L->y0, L->save_mean, L->save_invstd,
+                                                L->bn_gamma, sums, L->snorm, d.fo, g_yr, d.N * d.fo, stream));
+    } else if (fused_act) {
         if (L->zmask) DGN_TRY(dgn_linear_forward_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
         else DGN_TRY(dgn_linear_forward_act(d.N, d.Fo, d.Fo, G->g_out, L->z, L->b_mix, 2, L->slope, L->w_mix, d.Fo, 1, g_y1, g_z, stream));
         if (bn_derived) {
@@ -301,20 +324,29 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // the towers' dropout: the mask on the gradient of the normalised rows, in place         (:275)
     if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_backward(d.N * d.Fo, g_y1, L->drop_mask, L->drop_p, g_y1, stream));
     // BatchNorm: column sums + affine gradients; its input gradient is formed inside the combine backward
-    if (!bn_derived)
+    if (!bn_derived)      // (else: the sums came out of the mixing weight gradient above)
         DGN_TRY(dgn_bn_tail_backward(d.N, d.Fo, g_y1, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->save_mean, L->save_invstd, 0, nullptr, G->g_gamma,
                                      G->g_beta, sums, ws + s.bn_ws, dgn_bn_tail_workspace_bytes(d.N, d.Fo), L->n_valid, stream));
-    DgnBnGrad bn{};
-    bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
-    bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;
-    DGN_TRY(scale_combine_backward_impl(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
-                                       dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream, 1));
+    if (!mix_fused) {
+        DgnBnGrad bn{};
+        bn.g_out = g_y1; bn.y = L->y0; bn.ld = d.Fo; bn.gamma = L->bn_gamma; bn.beta = L->bn_beta; bn.mean = L->save_mean; bn.invstd = L->save_invstd;
+        bn.sums = sums; bn.relu = 0; bn.n_valid = L->n_valid;
+        DGN_TRY(scale_combine_backward_impl(d.N, d.T, 1, d.fo, nullptr, 0, nullptr, L->snorm, g_yr, G->g_b_post, ws + s.comb_ws,
+                                           dgn_scale_combine_backward_workspace_bytes(d.N, d.T, d.fo), &bn, stream, 1));
+    }
     // posttrans: the scaler expansion happens inside the two products
     DGN_TRY(dgn_linear_combine_backward_input(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->w_post, d.K, (int64_t)d.S * d.fo * d.K,
                                               g_aggx, d.N * d.K, stream));
-    DGN_TRY(dgn_linear_combine_backward_weight(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
-                                               (int64_t)d.S * d.fo * d.K, ws + s.wg_post,
-                                               dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
+    // (mix_fused: the column sums of the expanded gradient ride in the pass -- the identity scaler's block of them is d b_post)
+    float* g_sum = mix_fused ? f(s.g_sum) : nullptr;
+    DGN_TRY(dgn_linear_combine_backward_weight_bias(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
+                                                    (int64_t)d.S * d.fo * d.K, g_sum, ws + s.wg_post,
+                                                    dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
+    if (mix_fused) {
+        hipLaunchKernelGGL(pick_block, dim3((unsigned)((d.Fo + 255) / 256)), dim3(256), 0, st, d.T, d.fo, d.S * d.fo, (L->id_slot1 - 1) * d.fo, (const float*)g_sum,
+                           G->g_b_post);
+        DGN_HIP_CHECK(hipGetLastError());
+    }
     // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
     const DgnMsg msg = sweep_msg(L, d);
     DgnMsgGrad gr{};

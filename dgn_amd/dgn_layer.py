@@ -866,7 +866,8 @@ class DGNLayerTower(nn.Module):
             drop = (float(self.dropout), seed, offset)
         y = towers_layer(graph, self._kplan_x, self._avg_log, w_edge, h, snorm_n if self.graph_norm else None, sc, rm, rv, nbt,
                          ops["w_sd"], ops["bias_sd"], ops["w"], ops["b_p"], ops["bn_gamma"], ops["bn_beta"], mix.weight, mix.bias,
-                         T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], dropout=drop)
+                         T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], dropout=drop,
+                         id_slot=_identity_slot(self.plan.applied_scalers))
         if drop is not None:
             _dropout_key_used(drop[1])
         return y

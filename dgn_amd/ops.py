@@ -1073,7 +1073,7 @@ class _TowersLayer(torch.autograd.Function):
                 w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix):
         lib = _lib.load()
         global LAST_DROPOUT_MASK
-        T, fi, fo, S, residual, momentum, eps, slope, drop = cfg
+        T, fi, fo, S, residual, momentum, eps, slope, drop = cfg[:9]
         if not h.is_cuda:
             raise _lib.DgnError("towers_layer: CUDA tensors only (dgn_amd has no CPU path)")
         N, Fm, Fo = h.shape[0], T * fi, T * fo
@@ -1131,7 +1131,8 @@ class _TowersLayer(torch.autograd.Function):
         lib = _lib.load()
         w_edge, h, snorm, scale, w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, saved_buf, aux, drop_mask = ctx.saved_tensors
         graph, plan = ctx.graph, ctx.plan
-        T, fi, fo, S, residual, momentum, eps, slope, drop = ctx.cfg
+        T, fi, fo, S, residual, momentum, eps, slope, drop = ctx.cfg[:9]
+        id_slot = ctx.cfg[9] if len(ctx.cfg) > 9 else None
         N, Fm, Fo = h.shape[0], T * fi, T * fo
         K = plan.n_agg * fi
         dev = h.device
@@ -1159,6 +1160,7 @@ class _TowersLayer(torch.autograd.Function):
         L.z, L.zmask = (None, z.data_ptr()) if ctx.use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd = mean.data_ptr(), invstd.data_ptr()
         L.agg_aux = _ptr(aux)
+        L.id_slot1 = 0 if id_slot is None else int(id_slot) + 1
         if drop is not None:
             L.drop_p, L.drop_mask = drop[0], drop_mask.data_ptr()
         nbytes = lib.dgn_towers_layer_backward_workspace_bytes(C.byref(L))
@@ -1179,18 +1181,19 @@ class _TowersLayer(torch.autograd.Function):
 
 def towers_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm, scale, running_mean, running_var, num_batches_tracked,
                  w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix, n_towers: int, f_in: int, f_out: int, residual: bool,
-                 momentum: float, eps: float, slope: float, dropout=None) -> torch.Tensor:
+                 momentum: float, eps: float, slope: float, dropout=None, id_slot=None) -> torch.Tensor:
     """``DGNLayerTower.forward`` (nets/dgn_layer.py:309-325) of the fused configuration as one autograd node: see
     ``include/dgn_hip.h: DgnTowersLayer`` for the operand layouts (those of ``DGNLayerTower._assemble``) and the sequence of
     kernels.  Training mode; the BatchNorm running statistics and ``num_batches_tracked`` are updated in place.
-    ``dropout``: None, or ``(p, key tensor, offset)`` of the towers' F.dropout (:275) as ``ops.dropout`` takes them."""
+    ``dropout``: None, or ``(p, key tensor, offset)`` of the towers' F.dropout (:275) as ``ops.dropout`` takes them.  ``id_slot``: the
+    index of the identity scaler among the columns of ``scale`` (None: unknown; DgnTowersLayer.id_slot1)."""
     S = 1 if scale is None else scale.shape[1]
     if snorm is not None:
         snorm = snorm.reshape(-1).contiguous()
     if scale is not None:
         scale = scale.contiguous()
     drop = None if dropout is None else (float(dropout[0]), dropout[1], int(dropout[2]))
-    cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope), drop)
+    cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope), drop, (0 if S == 1 else id_slot))
     out = _TowersLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, running_mean, running_var,
                              w_sd, bias_sd, w_post.contiguous(), b_post, gamma, beta, w_mix, b_mix)
     if num_batches_tracked is not None:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 25
+#define DGN_ABI_VERSION 26
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -388,6 +388,28 @@ int dgn_linear_forward_bn_act_mask(int64_t n_rows, int32_t k, int32_t n, const f
                                    float slope, const float* residual, unsigned char* zmask_out, float* out, void* stream);
 int dgn_linear_forward_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
                                 const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);
+/* Round 6 -- the towers layer's mixing-network backward without the tensors between its steps (autograd through
+ * nets/dgn_layer.py:272-273 BatchNorm -> :319 mixing Linear -> LeakyReLU):
+ *   dgn_linear_wgrad_bn_act_mask     dw = (g * act'(mask))^T . BatchNorm(x), dbias = sum_m g * act'(mask): dgn_linear_wgrad_bn whose G
+ *                                    operand is formed from the layer's output gradient g [n_rows, n] and the forward's byte mask while
+ *                                    it is staged (the masked tensor g_z is never written or re-read);
+ *   dgn_linear_forward_act_mask_bnb  the input-gradient product g_y1 = (g * act'(mask)) . op(w) of dgn_linear_forward_act_mask with
+ *                                    BatchNorm's backward and the graph norm in its epilogue,
+ *                                        gz[t][m][o] = row_scale[m] * gamma[c] invstd[c] (g_y1[m][c] - sums[c] / M - xhat[m][c] sums[n + c] / M),
+ *                                        c = t f_out + o,  xhat = (y[m][c] - mean[c]) invstd[c]
+ *                                    (dgn_scale_combine_backward's fused form, same arithmetic and order), written tower-major
+ *                                    [n / f_out][n_rows][f_out] (stride_gz floats between towers): what dgn_linear_combine_backward_*
+ *                                    read.  y [n_rows, n] is BatchNorm's input, sums [2 n] = (sum g_y1, sum g_y1 xhat) -- e.g. from the
+ *                                    mixing weight gradient (csrc/dgn_towers.hip: mix_bn_finalize); g_y1 itself is never written.
+ * Widths: dgn_linear_bnb_supported (k, n <= 80 and the limits of dgn_linear_act_supported / _add_supported); f_out even, n / f_out <= 15.  */
+int dgn_linear_bnb_supported(int32_t k, int32_t n);
+int dgn_linear_wgrad_bn_act_mask(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                 const float* x, float* dw, int64_t lddw, float* dbias, const float* bn_mean, const float* bn_invstd,
+                                 const float* bn_gamma, const float* bn_beta, void* ws, size_t ws_bytes, void* stream);
+int dgn_linear_forward_act_mask_bnb(int64_t n_rows, int32_t k, int32_t n, const float* g, const unsigned char* zmask, int32_t act, float slope,
+                                    const float* w, int64_t ldw, int32_t w_is_kn, const float* y, const float* bn_mean, const float* bn_invstd,
+                                    const float* bn_gamma, const float* sums, const float* row_scale, int32_t f_out, float* gz,
+                                    int64_t stride_gz, void* stream);
 int dgn_linear_act_supported(int32_t k, int32_t n);      /* (the widest tile shapes are not: two prefetched strips per wave) */
 int dgn_linear_forward_act(int64_t n_rows, int32_t k, int32_t n, const float* g, const float* z, const float* act_bias, int32_t act,
                            float slope, const float* w, int64_t ldw, int32_t w_is_kn, float* c, float* gz_out, void* stream);
@@ -413,6 +435,12 @@ int dgn_linear_combine_backward_input(int64_t n_rows, int32_t n_towers, int32_t 
 int dgn_linear_combine_backward_weight(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
                                        int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
                                        int64_t stride_dw, void* ws, size_t ws_bytes, void* stream);
+/* ... and with g_sum [T][S*f_out] (may be NULL; needs k % 16 != 0): g_sum[t][s*f_out + o] = sum_m G[t][m][s*f_out + o], the column sums of the
+ * expanded gradient from a column of ones in a's padding -- for the identity scaler that is the gradient of posttrans' bias
+ * (sum_m row_scale[m] g_y[m, t*f_out + o]), at no cost.                                                                          */
+int dgn_linear_combine_backward_weight_bias(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
+                                            int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
+                                            int64_t stride_dw, float* g_sum, void* ws, size_t ws_bytes, void* stream);
 size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, int32_t n, int32_t batch);
 int dgn_linear_wgrad(int64_t n_rows, int32_t k, int32_t n, int32_t batch, const float* g, int64_t ldg, int64_t stride_g,
                      const float* x, int64_t ldx, int64_t stride_x, float* dw, int64_t lddw, int64_t stride_dw, float* dbias,
@@ -543,6 +571,11 @@ typedef struct DgnTowersLayer {
     const int64_t* drop_seed;
     uint64_t drop_offset;
     unsigned char* drop_mask;
+    /* Round 6 (ABI 26): 1 + the index of the IDENTITY scaler among the n_scalers (its block of w_post carries the h columns,
+     * dgn_amd/dgn_layer.py::_assemble); 0 (a zero-initialised struct): unknown -- the separate passes run.  With it the backward takes
+     * posttrans' bias gradient from the weight-gradient pass (dgn_linear_combine_backward_weight_bias) and BatchNorm's backward rides in
+     * the mixing network's input-gradient product (dgn_linear_forward_act_mask_bnb).                                                */
+    int32_t id_slot1;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */
