@@ -92,6 +92,7 @@ int launch_backward_block_cfg(const AggParams& p, int gap, hipStream_t stream) {
     q.blk_bin = plan.bin; q.blk_rows = plan.rows;
     const int64_t n_bins = (p.n_nodes + plan.bin - 1) / plan.bin;
     const dim3 grid((unsigned)xcd_grid(n_bins)), block(kWave);
+    plan.lds += (size_t)std::max<int64_t>(0, option(OPT_BLK_LDS_PAD_KB)) * 1024;      // (what-if: fewer resident waves, same work)
     if constexpr (C::NCH <= 2) {
         if (p.aux) {
             hipLaunchKernelGGL((agg_bwd_block<C, O, true>), grid, block, plan.lds, stream, q);

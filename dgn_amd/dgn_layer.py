@@ -383,6 +383,8 @@ class DGNLayerSimple(nn.Module):
             return None
         eig = g.ndata["eig"]
         graph = as_dgn_graph(g, h.device)
+        if _ops.split_training_route(graph, S):
+            return None      # (hub rows: the per-op route below runs posttrans per in-degree class + the folded product on the hubs alone)
         sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
         return _ops.dense_layer(graph, self._kplan, self._avg_log, graph.edge_weights(self._kplan, eig), h, snorm_n if self.graph_norm else None, sc, bn,
                                 None, None, lin.weight, lin.bias, 0, A, 0, self.residual)
@@ -507,6 +509,8 @@ class DGNLayerComplex(nn.Module):
             return None
         eig = g.ndata["eig"]
         graph = as_dgn_graph(g, h.device)
+        if _ops.split_training_route(graph, S):
+            return None      # (hub rows: see DGNLayerSimple._whole_layer)
         sc = _scale_table(graph, self.plan.applied_scalers, self._avg_log) if S > 1 else None
         return _ops.dense_layer(graph, self._kplan_x, self._avg_log, graph.edge_weights(self._kplan_x, eig), h, snorm_n if self.graph_norm else None, sc,
                                 bn, pre.weight, pre.bias, lin.weight, lin.bias, 1, A, id_slot, self.residual)

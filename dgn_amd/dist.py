@@ -125,7 +125,13 @@ def all_gather_rows(local: torch.Tensor, ranges: Sequence[Tuple[int, int]]) -> t
 
 
 class FlatGradAllReduce:
-    """Average the gradients of ``params`` across ranks with one all-reduce on one flat buffer."""
+    """Average the gradients of ``params`` across ranks with one all-reduce on one flat buffer.
+
+    EQUAL rank weights (sum / world), as DistributedDataParallel does: the result is the gradient of ``mean_r loss_r``.  With
+    ``shard_by_edges`` the ranks hold different NUMBERS of graphs (the shards balance edges, not graphs), so for a loss that is a mean
+    over the rank's graphs this is the global-batch gradient only when the shards hold equally many graphs; otherwise it is the
+    "mean of per-shard means" -- the definition tests/test_dist_gloo.py pins (sequential shards, averaged).  A loop that wants the exact
+    global-batch mean scales its local loss by ``n_local_graphs * world / n_global_graphs`` before ``backward()`` (one scalar)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]

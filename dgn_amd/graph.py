@@ -325,6 +325,11 @@ class DGNGraph:
         self._dc_split = dc
         return dc
 
+    def n_hub_rows_dc(self) -> int:
+        """Rows whose in-degree is outside the degree classes (>= DC_CLASSES): 0 for graphs ``degree_classes()`` takes whole."""
+        dc = self.degree_classes_split()
+        return 0 if dc is None else int(dc["hub_rows"].numel())
+
     def ensure_csc(self) -> None:
         """Transposed view for the atomic-free backward (built on first use, one extra sort per graph)."""
         if getattr(self, "_csc_ready", False):

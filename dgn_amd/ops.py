@@ -1255,10 +1255,88 @@ DC_SPLIT = os.environ.get("DGN_DC_SPLIT", "1") != "0"
 
 
 def dc_posttrans_split_supported(graph: DGNGraph, agg: torch.Tensor, fo: int, S: int) -> bool:
-    if not (DC_SPLIT and DC_POSTTRANS and S > 1 and agg.is_cuda and agg.dtype == torch.float32 and not torch.is_grad_enabled()
+    """Inference (no gradients recorded): any graph with degree classes.  Training (round 6): graphs WITH hub rows -- the whole-layer call
+    refuses those and its folded product is three times the flops; graphs without hubs keep the whole-layer degree-class call."""
+    if not (DC_SPLIT and DC_POSTTRANS and S > 1 and agg.is_cuda and agg.dtype == torch.float32
             and graph.num_nodes >= DC_MIN_NODES and getattr(graph, "_pad", None) is None and graph.num_src == graph.num_nodes):
         return False
-    return bool(_lib.load().dgn_dc_supported(agg.shape[1], fo))
+    lib = _lib.load()
+    K = agg.shape[1]
+    if not lib.dgn_dc_supported(K, fo):
+        return False
+    if torch.is_grad_enabled() and agg.requires_grad:
+        return bool(DC_SPLIT_TRAINING and graph.n_hub_rows_dc() > 0 and lib.dgn_dc_supported(fo, K) and lib.dgn_dc_wgrad_supported(K, fo))
+    return True
+
+
+DC_SPLIT_TRAINING = os.environ.get("DGN_DC_SPLIT_TRAINING", "1") != "0"
+
+
+def split_training_route(graph: DGNGraph, S: int) -> bool:
+    """Whether a TRAINING step of a simple / complex layer leaves the whole-layer call for the per-op route with the split degree-class
+    posttrans: a graph with hub rows (the whole-layer call would run the folded S f_out-column product on every row)."""
+    return bool(DC_SPLIT and DC_SPLIT_TRAINING and DC_POSTTRANS and S > 1 and graph.num_nodes >= DC_MIN_NODES and getattr(graph, "_pad", None) is None
+                and graph.num_src == graph.num_nodes and graph.degree_classes() is None and graph.n_hub_rows_dc() > 0)
+
+
+class _DcClassRows(torch.autograd.Function):
+    """The class rows' share of ``dc_posttrans_split`` with its backward (round 6: training on graphs with hub rows): forward
+    dgn_dc_fold + dgn_dc_gemm; backward d agg = (row_scale g) W_class (dgn_dc_gemm on the transposed class weights), d W in the
+    reference's layout by dgn_dc_wgrad, d bias = column sums.  Hub rows of y are left to the caller (index_copy), their rows of d agg
+    are zero here."""
+
+    @staticmethod
+    def forward(ctx, graph, agg, weight, bias, cls_scale, row_scale, n_agg, f_in, id_slot):
+        lib = _lib.load()
+        dc = graph.degree_classes_split()
+        N, K = agg.shape
+        fo, S = weight.shape[0], cls_scale.shape[1]
+        cx = id_slot >= 0
+        f_pad = K // (n_agg + (1 if cx else 0))
+        stream = _lib.stream_ptr(agg.device)
+        y = torch.empty(N, fo, dtype=torch.float32, device=agg.device)
+        s = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
+                                  present=dc["present"].data_ptr(), scale=cls_scale.data_ptr())
+        wc = torch.empty(2, _lib.DGN_DC_CLASSES, fo * K, dtype=torch.float32, device=agg.device)
+        lay = _lib.DgnDcLayout(n_agg=n_agg, f_pad=f_pad, f_in=f_in, h_off=f_in if cx else 0, id_slot=id_slot if cx else -1, ld=weight.stride(0))
+        _lib.check(lib.dgn_dc_fold(C.byref(s), S, fo, K, 1, weight.data_ptr(), C.byref(lay), wc[0].data_ptr(), wc[1].data_ptr(), stream), "dgn_dc_fold")
+        _lib.check(lib.dgn_dc_gemm(C.byref(s), K, fo, 1, agg.data_ptr(), agg.stride(0), 0, wc[0].data_ptr(), K, fo * K, 0, _ptr(bias), _ptr(row_scale),
+                                   y.data_ptr(), fo, 0, 0, stream), "dgn_dc_gemm")
+        ctx.save_for_backward(agg, weight, cls_scale, row_scale, wc)
+        ctx.meta = (graph, n_agg, f_in, id_slot, f_pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        lib = _lib.load()
+        agg, weight, cls_scale, row_scale, wc = ctx.saved_tensors
+        graph, n_agg, f_in, id_slot, f_pad, has_bias = ctx.meta
+        dc = graph.degree_classes_split()
+        N, K = agg.shape
+        fo, S = weight.shape[0], cls_scale.shape[1]
+        cx = id_slot >= 0
+        stream = _lib.stream_ptr(agg.device)
+        g = g_y.contiguous() if row_scale is None else (g_y * row_scale.unsqueeze(1)).contiguous()      # (hub rows arrive as zeros: index_copy's adjoint)
+        s = _lib.DgnDegreeClasses(n_units=dc["n_units"], vperm=dc["vperm"].data_ptr(), unit_class=dc["unit_class"].data_ptr(),
+                                  present=dc["present"].data_ptr(), scale=cls_scale.data_ptr())
+        g_agg = g_w = g_b = None
+        if ctx.needs_input_grad[1]:
+            g_agg = torch.empty(N, K, dtype=torch.float32, device=agg.device)
+            hub = dc["hub_rows"]
+            if hub.numel():
+                g_agg.index_fill_(0, hub, 0.0)                  # (dgn_dc_gemm writes the rows the virtual row space names)
+            _lib.check(lib.dgn_dc_gemm(C.byref(s), fo, K, 1, g.data_ptr(), fo, 0, wc[1].data_ptr(), fo, fo * K, 0, None, None, g_agg.data_ptr(), K, 0, 0,
+                                       stream), "dgn_dc_gemm")
+        if ctx.needs_input_grad[2]:
+            g_w = torch.zeros_like(weight)
+            lay = _lib.DgnDcLayout(n_agg=n_agg, f_pad=f_pad, f_in=f_in, h_off=f_in if cx else 0, id_slot=id_slot if cx else -1, ld=g_w.stride(0))
+            nbytes = lib.dgn_dc_wgrad_workspace_bytes(dc["n_units"], K, fo)
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=agg.device)
+            _lib.check(lib.dgn_dc_wgrad(C.byref(s), S, K, fo, g.data_ptr(), fo, agg.data_ptr(), agg.stride(0), g_w.data_ptr(), g_w.stride(0), C.byref(lay),
+                                        ws.data_ptr(), nbytes, stream), "dgn_dc_wgrad")
+        if has_bias and ctx.needs_input_grad[3]:
+            g_b = g.sum(0)
+        return None, g_agg, g_w, g_b, None, None, None, None, None
 
 
 def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], scale: torch.Tensor,
@@ -1280,6 +1358,18 @@ def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor,
     f_pad = K // (n_agg + (1 if cx else 0))
     weight = weight.contiguous()
     row_scale = None if row_scale is None else row_scale.reshape(-1).contiguous()
+    training = torch.is_grad_enabled() and (agg.requires_grad or weight.requires_grad)
+    if training:
+        # training (round 6): the class rows through _DcClassRows (its own backward), the hub rows through the differentiable folded product
+        hub = dc["hub_rows"]
+        y = None
+        if dc["n_units"] > 0:
+            cls_scale = scale.index_select(0, dc["rep"]).contiguous()
+            y = _DcClassRows.apply(graph, agg.contiguous(), weight, bias, cls_scale, row_scale, n_agg, f_in, id_slot)
+        if hub.numel():
+            y_hub = _split_hub_rows(agg, weight, bias, scale, row_scale, hub, n_agg, f_in, f_pad, id_slot, fo, S, K)
+            y = y_hub.new_zeros(N, fo).index_copy(0, hub, y_hub) if y is None else y.index_copy(0, hub, y_hub)
+        return y
     y = torch.empty(N, fo, dtype=torch.float32, device=agg.device)
     stream = _lib.stream_ptr(agg.device)
     if dc["n_units"] > 0:
@@ -1293,17 +1383,23 @@ def dc_posttrans_split(graph: DGNGraph, agg: torch.Tensor, weight: torch.Tensor,
                                    y.data_ptr(), fo, 0, 0, stream), "dgn_dc_gemm")
     hub = dc["hub_rows"]
     if hub.numel():
-        pad = (lambda t: torch.nn.functional.pad(t, (0, f_pad - f_in)) if f_pad != f_in else t)
-        w = pad(weight[:, f_in if cx else 0:].reshape(fo, S * n_agg, f_in)).reshape(fo, S, n_agg * f_pad).permute(1, 0, 2)      # [S, fo, A f_pad]
-        if cx:      # the h columns in the identity scaler's block, zero elsewhere (dgn_layer._folded_weight)
-            hcols = torch.zeros(S, fo, f_pad, dtype=w.dtype, device=w.device)
-            hcols[id_slot] = pad(weight[:, :f_in])
-            w = torch.cat([w, hcols], dim=2)
-        w = w.reshape(S * fo, K).contiguous()
-        z = node_linear(agg.index_select(0, hub), w)
-        y_hub = scale_combine(z.unsqueeze(0), scale.index_select(0, hub), bias, None if row_scale is None else row_scale.index_select(0, hub))
-        y.index_copy_(0, hub, y_hub)
+        y.index_copy_(0, hub, _split_hub_rows(agg, weight, bias, scale, row_scale, hub, n_agg, f_in, f_pad, id_slot, fo, S, K))
     return y
+
+
+def _split_hub_rows(agg, weight, bias, scale, row_scale, hub, n_agg, f_in, f_pad, id_slot, fo, S, K):
+    """The hub rows of dc_posttrans_split: gathered aggregate rows, the folded product (S f_out columns) and the scale-combine -- all
+    differentiable ops (index_select, node_linear, scale_combine)."""
+    cx = id_slot >= 0
+    pad = (lambda t: torch.nn.functional.pad(t, (0, f_pad - f_in)) if f_pad != f_in else t)
+    w = pad(weight[:, f_in if cx else 0:].reshape(fo, S * n_agg, f_in)).reshape(fo, S, n_agg * f_pad).permute(1, 0, 2)      # [S, fo, A f_pad]
+    if cx:      # the h columns in the identity scaler's block, zero elsewhere (dgn_layer._folded_weight)
+        hcols = [torch.zeros(fo, f_pad, dtype=w.dtype, device=w.device) for _ in range(S)]
+        hcols[id_slot] = pad(weight[:, :f_in])
+        w = torch.cat([w, torch.stack(hcols, dim=0)], dim=2)
+    w = w.reshape(S * fo, K).contiguous()
+    z = node_linear(agg.index_select(0, hub), w)
+    return scale_combine(z.unsqueeze(0), scale.index_select(0, hub), bias, None if row_scale is None else row_scale.index_select(0, hub))
 
 
 def _dense_sizes(cfg, N, dc=False):

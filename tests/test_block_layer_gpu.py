@@ -72,7 +72,10 @@ def _vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, b, towers=5
     strict = not any(a in ("std", "var") for a in aggs.split())      # (std / var lists: the reference's own fp32 evaluation is unstable)
     check(y, y32, y64, f"block {type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0, max_escape_fraction=0.0 if strict else None)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
-        _check_grad(a, r32, r64, f"block {type_net} F={F_} {k}", strict=strict)
+        if strict:
+            _check_grad(a, r32, r64, f"block {type_net} F={F_} {k}", strict=True)
+        else:      # (std / var lists: the looser caps, named)
+            check(a, r32, r64, f"block {type_net} F={F_} {k}", rtol=1e-4, atol=2e-5, max_escape_fraction=0.01, max_local_fraction=0.05)
     for k, v in (stats or {}).items():
         np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
     for k, v in layer.state_dict().items():

@@ -27,7 +27,7 @@ def _check_grad(a, r32, r64, name, strict=True):
     if strict:
         check(a, r32, r64, name, rtol=1e-4, atol=2e-5, max_escape_fraction=0.0)
     else:
-        check(a, r32, r64, name, rtol=1e-4, atol=2e-5, max_escape_fraction=0.01, max_local_fraction=0.05)
+        check(a, r32, r64, name, rtol=1e-4, atol=2e-5)
     a, r32 = a.cpu().double(), r32.double()
     scale = max(1.0, float(r64.abs().max()))
     # (a max / min / |.| routing that flips between fp32 and fp64 moves a gradient entry by O(weight): with O(1) weights the fp32
@@ -35,7 +35,7 @@ def _check_grad(a, r32, r64, name, strict=True):
     assert float((a - r64).abs().max()) <= 10 * 2e-5 * scale + 4 * float((r32 - r64).abs().max()), f"{name}: not close to the fp64 evaluation"
 
 
-def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch, min_rows):
+def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch, min_rows, strict=True):
     import dgn_amd
     from oracle import dgn_oracle as orc
     if min_rows is not None:
@@ -78,7 +78,7 @@ def _layer_vs_oracle(monkeypatch, type_net, F_, aggs, scalers, graph_norm, batch
     from parity_util import check
     check(y, y32, y64, f"{type_net} F={F_} y", rtol=2e-5, atol=2e-5, abs_scale=1.0, max_escape_fraction=0.0)
     for a, r32, r64, k in zip(gd, g32, g64, ["h"] + names):
-        _check_grad(a, r32, r64, k)
+        _check_grad(a, r32, r64, k, strict=strict)
     for k, v in stats.items():
         np.testing.assert_allclose(layer.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
@@ -212,6 +212,33 @@ def test_c4_at_the_default_threshold_takes_the_degree_class_route_vs_oracle(monk
     taken.clear()
     _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, small, None)
     assert taken and taken[0] is None                      # below the threshold: the folded route
+
+
+@pytest.mark.parametrize("n_graphs,expect_dc", [(450, False), (720, True)], ids=["11k-nodes-folded", "18k-nodes-degree-classes"])
+def test_molecule_batches_between_the_dispatch_thresholds_at_the_library_defaults_vs_oracle(monkeypatch, n_graphs, expect_dc):
+    """the gaps between the dispatch thresholds at the LIBRARY'S DEFAULTS (tests/conftest.py lowers three of them for
+    the rest of the suite).  A molecule batch above the graph-block route (8 192 nodes) and below the block backward (131 072 nodes) runs
+    the STAGED backward sweep (agg_bwd_short + seg_sum_rows); below 16 384 nodes posttrans is the folded product, above it one product per
+    in-degree class.  BASELINE C4's layer on (a) ~11.5 k nodes: folded posttrans + staged backward, (b) C4's own batch (2048 graphs,
+    ~52 k nodes: what bench.py's c4 leg runs): degree-class posttrans + staged backward -- values and every gradient vs the oracle."""
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    monkeypatch.setattr(dgn_amd.ops, "DC_MIN_NODES", 16384)
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 8192)
+    monkeypatch.setattr(_lib.options, "blk_min_nodes", 131072)
+    b = synth.molecule_batch(n_graphs, seed=43, n_lo=10, n_hi=41, extra_bonds=4.3, eig_dim=4)
+    N = int(b["num_nodes"])
+    assert 8192 < N < 131072 and (N >= 16384) == expect_dc
+    taken, blocks = [], []
+    real = dgn_amd.ops._degree_classes
+    monkeypatch.setattr(dgn_amd.ops, "_degree_classes", lambda *a: taken.append(real(*a)) or taken[-1])
+    real_blk = dgn_amd.ops.block_layer
+    monkeypatch.setattr(dgn_amd.ops, "block_layer", lambda *a, **k: blocks.append(1) or real_blk(*a, **k))
+    # (above 16 k nodes: the counted clause with its default caps, not the zero of the small config tests -- a few routings of the 1.3 M
+    #  gradient entries behind max / min flip between any two fp32 evaluations, the oracle's own included)
+    _layer_vs_oracle(monkeypatch, "simple", 70, "mean max min dir1-dx dir1-av", "identity amplification attenuation", False, b, None, strict=not expect_dc)
+    assert not blocks, "the graph-block route took a batch above its node limit"
+    assert taken and (taken[0] is not None) == expect_dc
 
 
 @pytest.mark.parametrize("type_net", ["simple", "complex"])
