@@ -188,6 +188,17 @@ def load() -> C.CDLL:
         lib.dgn_linear_forward_add.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp]
         lib.dgn_linear_forward_bn_act.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, C.c_float, vp, vp, vp, vp]
         lib.dgn_linear_wgrad_bn.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+        lib.dgn_linear_bnb_supported.restype = C.c_int
+        lib.dgn_linear_bnb_supported.argtypes = [C.c_int32, C.c_int32]
+        lib.dgn_linear_wgrad_bn_act_mask.restype = C.c_int
+        lib.dgn_linear_wgrad_bn_act_mask.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_float, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp,
+                                                     C.c_size_t, vp]
+        lib.dgn_linear_forward_act_mask_bnb.restype = C.c_int
+        lib.dgn_linear_forward_act_mask_bnb.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp,
+                                                        vp, C.c_int32, vp, C.c_int64, vp]
+        lib.dgn_linear_combine_backward_weight_bias.restype = C.c_int
+        lib.dgn_linear_combine_backward_weight_bias.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, C.c_int64, vp,
+                                                                C.c_int64, C.c_int64, vp, vp, C.c_size_t, vp]
         lib.dgn_linear_act_mask_bytes.restype = C.c_size_t
         lib.dgn_linear_act_mask_bytes.argtypes = [C.c_int64, C.c_int32]
         lib.dgn_linear_forward_bn_act_mask.restype = C.c_int

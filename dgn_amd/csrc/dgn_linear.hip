@@ -346,8 +346,8 @@ extern "C" int dgn_linear_wgrad_bn_act_mask(int64_t n_rows, int32_t k, int32_t n
     if (n_rows < 0 || !dgn_linear_supported(k, n, 1)) { set_error("%s: need even k, n in [2, 160] and at most 45 tiles (k=%d n=%d)", fn, k, n); return -1; }
     if (!dw) { set_error("%s: null output", fn); return -1; }
     if (n_rows == 0) return zero_wgrad(dw, lddw, 0, dbias, 0, k, n, 1, static_cast<hipStream_t>(stream));
-    if (!g || !zmask || !x || !bn_mean || !bn_invstd || !aligned8(g) || !aligned8(x) || (reinterpret_cast<uintptr_t>(zmask) & 1)) {
-        set_error("%s: null or misaligned operand", fn);
+    if (!g || !zmask || !x || !bn_mean || !bn_invstd || !aligned8(g) || !aligned8(x) || (reinterpret_cast<uintptr_t>(zmask) & 15)) {
+        set_error("%s: null or misaligned operand (g, x 8-byte; zmask 16-byte: its strips travel as 16-byte direct-to-LDS pieces)", fn);
         return -1;
     }
     WgParams p{};

@@ -287,7 +287,7 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     // written); with the column sums known, the input-gradient product turns its rows g_y1 into g_yr = snorm * BatchNorm'(g_y1) in its
     // epilogue, tower-major (g_y1 is never written, the combine-backward pass is gone), and posttrans' bias gradient comes out of
     // its weight-gradient pass as the identity scaler's column sums.  8 N Fo floats of traffic -> 5 N Fo, two launches less.
-    const bool mix_fused = bn_derived && L->zmask && L->id_slot1 >= 1 && L->id_slot1 <= d.S && d.K % 16 != 0 && d.T <= 15 &&
+    const bool mix_fused = bn_derived && L->zmask && (reinterpret_cast<uintptr_t>(L->zmask) & 15) == 0 && L->id_slot1 >= 1 && L->id_slot1 <= d.S && d.K % 16 != 0 && d.T <= 15 &&
                            (reinterpret_cast<uintptr_t>(L->y0) & 15) == 0 && dgn_linear_bnb_supported(d.Fo, d.Fo) && option(OPT_MIX_BWD_FUSED) != 0;
     if (mix_fused) {
         DGN_TRY(dgn_linear_wgrad_bn_act_mask(d.N, d.Fo, d.Fo, G->g_out, L->zmask, 2, L->slope, L->y0, f(s.dwx), d.Fo, G->g_b_mix, L->save_mean,

@@ -415,6 +415,65 @@ def test_activation_mask_round_trip_is_bitwise_the_z_path(shape, act, residual):
     assert torch.equal(c_ref, c_m)
 
 
+@pytest.mark.parametrize("M,n,fo,with_rs", [(4099, 70, 14, True), (16, 70, 14, False), (7, 70, 14, True), (1033, 64, 16, True), (515, 40, 10, False),
+                                           (2050, 80, 16, True), (300, 20, 10, True)])
+def test_mixing_backward_kernels_of_round_6_vs_the_separate_passes(M, n, fo, with_rs):
+    """dgn_linear_wgrad_bn_act_mask (the G operand of the weight gradient formed from g and the activation's byte mask, the mask through a
+    direct-to-LDS load) = dgn_linear_forward_act_mask's side output fed to dgn_linear_wgrad_bn, bit for bit; and
+    dgn_linear_forward_act_mask_bnb (BatchNorm's backward + row scale in the input-gradient product's epilogue, tower-major) = the product
+    followed by the elementwise formula in combine_bwd's order, bit for bit.  Row counts with partial last strips and single strips."""
+    from dgn_amd import _lib
+    lib = _lib.load()
+    k = n
+    if not lib.dgn_linear_bnb_supported(k, n):
+        pytest.skip("shape outside the supported set")
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(M + 7 * n)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()
+    g = torch.randn(M, n, device=dev, generator=gen)
+    z = torch.randn(M, n, device=dev, generator=gen)
+    y0 = torch.randn(M, k, device=dev, generator=gen) * 1.5 + 0.2
+    w = torch.randn(n, k, device=dev, generator=gen) / k ** 0.5            # mixing weight [out, in]
+    gamma = torch.rand(k, device=dev, generator=gen) + 0.5
+    mean, invstd = y0.mean(0), (y0.var(0, unbiased=False) + 1e-5).rsqrt()
+    rs = (torch.rand(M, device=dev, generator=gen) + 0.5) if with_rs else None
+    nb = lib.dgn_linear_act_mask_bytes(M, n)
+    pos = (z > 0).reshape(-1, 2)
+    mask = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    mask[:M * n // 2] = pos[:, 0].to(torch.uint8) | (pos[:, 1].to(torch.uint8) << 1)
+    slope = 0.01
+    # the separate passes: g_z as a tensor, the input-gradient product, the weight gradient on the normalised operand (no affine part)
+    g_y1, g_z = torch.empty(M, k, device=dev), torch.empty(M, n, device=dev)
+    _lib.check(lib.dgn_linear_forward_act_mask(M, n, k, g.data_ptr(), mask.data_ptr(), 2, slope, w.data_ptr(), k, 1, g_y1.data_ptr(), g_z.data_ptr(), st), "act_mask")
+    nbw = lib.dgn_linear_wgrad_workspace_bytes(M, k, n, 1)
+    ws = torch.empty(max(nbw, 1), dtype=torch.uint8, device=dev)
+    with_db = k % 16 != 0                                                   # (the bias gradient rides in the operand's padding column)
+    dw_ref, db_ref = torch.empty(n, k, device=dev), torch.zeros(n, device=dev)
+    _lib.check(lib.dgn_linear_wgrad_bn(M, k, n, g_z.data_ptr(), y0.data_ptr(), dw_ref.data_ptr(), k, db_ref.data_ptr() if with_db else None, mean.data_ptr(),
+                                       invstd.data_ptr(), None, None, ws.data_ptr(), nbw, st), "wgrad_bn")
+    dw, db = torch.full((n, k), float("nan"), device=dev), torch.zeros(n, device=dev)
+    for _ in range(2):      # (twice: bitwise reproducible)
+        _lib.check(lib.dgn_linear_wgrad_bn_act_mask(M, k, n, g.data_ptr(), mask.data_ptr(), 2, slope, y0.data_ptr(), dw.data_ptr(), k, db.data_ptr() if with_db else None,
+                                                    mean.data_ptr(), invstd.data_ptr(), None, None, ws.data_ptr(), nbw, st), "wgrad_bn_act_mask")
+        assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    # BatchNorm's backward on the product's rows, combine_bwd's order: ga * is * (g - s0 / M - xh * s1 / M), then the row scale
+    xh = (y0 - mean) * invstd
+    sums = torch.cat([g_y1.sum(0), (g_y1 * xh).sum(0)]).contiguous()
+    inv_n = torch.tensor(1.0, device=dev) / torch.tensor(float(M), device=dev)
+    c4, c5 = sums[:k] * inv_n, sums[k:] * inv_n
+    want = (gamma * invstd) * ((g_y1 - c4) - xh * c5)
+    if rs is not None:
+        want = want * rs.unsqueeze(1)
+    T = k // fo
+    gz = torch.full((T, M, fo), float("nan"), device=dev)
+    _lib.check(lib.dgn_linear_forward_act_mask_bnb(M, n, k, g.data_ptr(), mask.data_ptr(), 2, slope, w.data_ptr(), k, 1, y0.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                   gamma.data_ptr(), sums.data_ptr(), P(rs), fo, gz.data_ptr(), M * fo, st), "act_mask_bnb")
+    got = gz.permute(1, 0, 2).reshape(M, k)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 @pytest.mark.parametrize("T,fi,M", [(5, 14, 4099), (5, 14, 16), (5, 14, 1), (5, 10, 700), (5, 20, 1033), (5, 30, 515), (4, 14, 2000), (2, 14, 333)])
 def test_block_diagonal_pair_linear_vs_fp64(T, fi, M):
     """dgn_linear_bd_*: the towers' block-diagonal P|Q product, its input gradient (with the two-operand add epilogue) and its weight /
