@@ -227,6 +227,13 @@ def event_stats(fn, dev, warm=20, groups=20, per_group=5):
                 timed_calls=groups * per_group)
 
 
+def _blk_name(kernel):
+    """`blk_forward`, `blk_tail_fwd`, ... out of torch.profiler's kernel name."""
+    import re
+    m = re.search(r"blk_\w+", kernel)
+    return m.group(0) if m else kernel[:40]
+
+
 def step_min_bytes(N, E, F_in, F_out, Ku, n_params):
     """Mandatory HBM traffic of ONE layer step (forward + backward), whatever the kernels: inputs and outputs of both directions (h and
     g_out read, out and g_h written; h read again by the backward), the graph (row pointers and sources, both directions), the eig
@@ -478,7 +485,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
                                   kernel="blk_forward + blk_tail_fwd + blk_tail_bwd + blk_backward + blk_reduce (csrc/dgn_blk_layer.hip)",
                                   achieved=bmin / (us * 1e-6) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=bmin / (us * 1e-6) / HBM_PEAK,
                                   traffic=None, traffic_source=None,
-                                  kernels={r["kernel"].split("<")[0].split("::")[-1]: dict(ms=r["us_per_step"] * 1e-3, launches_per_step=r["calls_per_step"])
+                                  kernels={_blk_name(r["kernel"]): dict(ms=r["us_per_step"] * 1e-3, launches_per_step=r["calls_per_step"])
                                            for r in blk_rows},
                                   model=dict(N=N, E=E, F=F_, bytes="the layer step's mandatory bytes (roofline.step.bytes_min)", launches_per_step=sum(r["calls_per_step"] for r in blk_rows),
                                              block_kernel_us=us),
@@ -1086,12 +1093,12 @@ def run_net(args, dev, n_graphs=128, steps=60, warmup=15, layers=4, edge_feat=Fa
                        "eager, graph preparation included")
 
 
-COMMITTED_LINE = os.path.join(ROOT, "profiles", "r05_bench_all_extras.json")
+COMMITTED_LINE = os.path.join(ROOT, "profiles", "r06_bench_all_extras.json")
 
 
 def regression_warnings(results, headline=None):
     """Measurement hygiene: every roofline fraction of this run is compared with the committed line of the same
-    command (profiles/r05_bench_all_extras.json); a leg that fell below half of its committed value gets a `warning` field instead of
+    command (profiles/r06_bench_all_extras.json); a leg that fell below half of its committed value gets a `warning` field instead of
     passing silently (a box with a disturbed clock, or a regression)."""
     try:
         ref = json.load(open(COMMITTED_LINE))
