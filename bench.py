@@ -404,8 +404,9 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
         # Launch-bound batches (the reference's batch of 128 molecules: ~80 launches around 0.4 ms of kernels): the whole
         # step -- edge weights, forward, backward -- is captured ONCE into a HIP graph and replayed.  Only valid for
         # a fixed batch shape (every kernel argument is frozen), so it is an option, not the headline mode.
-        if reducer is not None:
+        if reducer is not None and world > 1:
             raise SystemExit("--hipgraph is a single-GPU mode (the gradient all-reduce is not captured)")
+        reducer = None      # (a forced single-rank process group: nothing to reduce)
         def bare_step():                   # (gradients stay None: the captured backward writes fresh ones per replay)
             graph._wcache.clear()
             layer(graph, h, ef, snorm).backward(ct)
@@ -464,7 +465,7 @@ def run_layer_workload(args, wl, rank, world, dev, steps=None, warmup=None, tag=
         if table and "us_per_step" in table[0]:
             result["step"]["kernel_us_sum"] = sum(r["us_per_step"] for r in table)
         blk_rows = [r for r in (table or []) if "us_per_step" in r and "blk_" in r["kernel"]]
-    if torch.distributed.is_initialized():
+    if torch.distributed.is_initialized() and reducer is not None:
         # per rank: its shard's size and the gradient all-reduce timed on its own (HIP events around 20 back-to-back calls)
         ms_ar = event_ms(reducer, 20, dev, warm=3)
         stats = ddist.gather_rank_stats([rank, N, E, ms_ar], dev)
