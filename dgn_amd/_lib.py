@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -137,7 +137,8 @@ class DgnBlockLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("n_nbt", C.c_int32),
                 ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
                 ("n_valid", C.c_void_p), ("overflow", C.c_void_p), ("eval_mode", C.c_int32),
-                ("dbg_agg", C.c_void_p), ("dbg_gagg", C.c_void_p), ("dbg_time", C.c_void_p)]
+                ("dbg_agg", C.c_void_p), ("dbg_gagg", C.c_void_p), ("dbg_time", C.c_void_p),
+                ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64), ("drop_mask", C.c_void_p)]
 
 
 class DgnBlockGrads(C.Structure):

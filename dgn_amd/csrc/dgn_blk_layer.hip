@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -236,6 +237,15 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     p.nbt = L->num_batches_tracked; p.n_nbt = L->num_batches_tracked ? L->n_nbt : 0;
     p.momentum = L->momentum; p.bn_eps = L->eps;
     p.N = d.N; p.n_valid = L->n_valid; p.overflow = L->overflow; p.tail_rows = d.tail_rows; p.n_tail = d.n_tail;
+    if (L->drop_p != 0.f && !L->eval_mode) {      // the towers' dropout inside the tails
+        if (!d.mixing || !(L->drop_p > 0.f && L->drop_p < 1.f) || !L->drop_mask || (!bwd && !L->drop_seed)) {
+            set_error("%s: dropout is the towers layer's (type 2): 0 < drop_p < 1, drop_mask, and -- forward -- drop_seed", fn);
+            return DGN_ERR_INVALID;
+        }
+        p.drop_scale = 1.f / (1.f - L->drop_p);
+        p.drop_threshold = (uint32_t)std::min<double>(4294967295.0, std::floor((double)L->drop_p * 4294967296.0));
+        p.drop_seed = L->drop_seed; p.drop_offset = L->drop_offset; p.drop_mask = L->drop_mask;
+    }
     p.n_blk_param = d.n_blk_param; p.off_tower = d.off_tower;
     p.R = d.R; p.Emax = d.Emax;
     int rc = 0;

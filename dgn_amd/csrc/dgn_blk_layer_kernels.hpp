@@ -67,6 +67,9 @@ struct P {
     float* save_mean; float* save_invstd; float* running_mean; float* running_var; int64_t* nbt; int32_t n_nbt;
     float momentum, bn_eps;
     int64_t N;
+    // towers' F.dropout between BatchNorm and the mixing network (nets/dgn_layer.py:275), inside the tails (round 6): drop_scale == 0: none.
+    // Philox keep bits as dgn_dropout_forward draws them (group g = 8 consecutive elements of the dense [N, Fo] tensor, one mask byte)
+    float drop_scale; uint32_t drop_threshold; const int64_t* drop_seed; uint64_t drop_offset; unsigned char* drop_mask;
     const int64_t* n_valid;      // DEVICE: rows of the batch inside a buffer of N rows (padded batches, hipgraph.PaddedBatch); NULL: N
     int32_t* overflow;           // DEVICE, may be NULL: set to 1 by a block larger than the LDS plan (padded batches: the table changes per batch)
     // tail
@@ -659,6 +662,56 @@ __device__ __forceinline__ float col_param(const float* const (&ptrs)[kMaxT], in
     return ptrs[t][col - t * fo];
 }
 
+// Philox4x32-10 exactly as dgn_bn_tail.hip's dropout_fwd keys it: counter = (group lo, group hi * 2 + half, offset lo, offset hi), key = *seed
+__device__ __forceinline__ void blk_philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// The tail's rows [m0, m0 + RW) of the dense [N, Fo] tensor are whole groups of 8 elements (RW is a multiple of 16).  `draw`: the keep
+// bits are drawn (forward) and the byte stored; else read back.  Every element of a kept position is scaled, a dropped one zeroed.
+__device__ __forceinline__ void blk_dropout_rows(const P& p, float* rows_lds, int ldk, int64_t m0, int rows, int RW, bool draw) {
+    const int Fo = p.Fo;
+    const int64_t g0 = m0 * Fo / 8;
+    const int n_groups = RW * Fo / 8;
+    uint64_t sd = 0;
+    if (draw) sd = (uint64_t)*p.drop_seed;
+    for (int gi = threadIdx.x; gi < n_groups; gi += blockDim.x) {
+        if ((gi * 8) / Fo >= rows) continue;                    // (groups wholly past the batch's rows: nothing drawn, nothing stored)
+        const int64_t gg = g0 + gi;
+        unsigned m;
+        if (draw) {
+            uint32_t r[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t c[4] = {(uint32_t)gg, (uint32_t)((uint64_t)gg >> 32) * 2u + (uint32_t)half, (uint32_t)p.drop_offset, (uint32_t)(p.drop_offset >> 32)};
+                blk_philox(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[4 * half + i] = c[i];
+            }
+            m = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m |= (r[i] >= p.drop_threshold ? 1u : 0u) << i;
+            p.drop_mask[gg] = (unsigned char)m;
+        } else {
+            m = p.drop_mask[gg];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = gi * 8 + i, r_ = e / Fo, c_ = e - r_ * Fo;
+            if (r_ < rows) {
+                float* at = rows_lds + r_ * ldk + c_;
+                *at = (m >> i) & 1u ? *at * p.drop_scale : 0.f;
+            }
+        }
+    }
+}
+
 // ---- forward tail: BatchNorm (training statistics) -> ReLU -> + h   or   -> mixing Linear -> LeakyReLU -> + h ------------------------
 // LDS: [mean | invstd | gamma | beta] (4 Fo floats, padded to a multiple of 4), Y1 [rows][ldk], W_mix [Fo][ldk] (towers; ldk = up4(Fo)),
 // then the reduction scratch (doubles)
@@ -727,6 +780,10 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
     }
     if (!p.mixing) return;
     __syncthreads();
+    if (p.drop_scale != 0.f && !p.eval_mode) {      // the towers' dropout on the normalised rows (:275)
+        blk_dropout_rows(p, Y1, ldk, m0, rows, RW, true);
+        __syncthreads();
+    }
     // out = LeakyReLU(y1 W_mix^T + b_mix) (+ h): jobs of (strip, 16-column tile)
     const int nstrip = RW >> 4, ntq = (Fo + 15) >> 4;
     for (int job = wave; job < nstrip * ntq; job += nw) {
@@ -795,6 +852,10 @@ __global__ __launch_bounds__(512) void blk_tail_bwd(const P p) {
         }
     }
     __syncthreads();
+    if (p.mixing && p.drop_scale != 0.f) {           // the mixing network saw the DROPPED normalised rows
+        blk_dropout_rows(p, Y1, ldk, m0, rows, RW, false);
+        __syncthreads();
+    }
     if (p.mixing) {
         const int nstrip = RW >> 4, ntq = (Fo + 15) >> 4;
         // g_z = g_out * LeakyReLU'(y1 W_mix^T + b_mix), in place over the staged g_out
@@ -859,6 +920,10 @@ __global__ __launch_bounds__(512) void blk_tail_bwd(const P p) {
             wpart[Fo * Fo + tid] = a;
         }
         __syncthreads();
+        if (p.drop_scale != 0.f) {                   // dropout's adjoint on the gradient of the normalised rows
+            blk_dropout_rows(p, GY1, ldk, m0, rows, RW, false);
+            __syncthreads();
+        }
     }
     {
         RowFeat x = rf_at(tid, Fo);

@@ -884,7 +884,7 @@ class DGNLayerTower(nn.Module):
     def _block_layer(self, g, h, snorm_n):
         """The layer on the graph-block route (ops.block_layer), or None: as _whole_layer's domain, per-tower parameters as they are."""
         T, fi, fo = len(self.towers), self.input_tower, self.output_tower
-        if not (_block_route_ok(self, h) and T > 1 and T <= 8 and self.divide_input and not self.edge_features and self.dropout == 0
+        if not (_block_route_ok(self, h) and T > 1 and T <= 8 and self.divide_input and not self.edge_features and 0 <= self.dropout < 1
                 and self._fusable()):
             return None
         act = self.mixing_network._fused_act()
@@ -899,8 +899,16 @@ class DGNLayerTower(nn.Module):
             return None
         bns = [t.batchnorm_h for t in self.towers]
         rm, rv, nbt = self._linked_bn_stats(h.device)
-        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, rm, rv, nbt,
-                                (*plist, mix.weight, mix.bias), 2, T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], training=self.training)
+        drop = None
+        if self.dropout > 0 and self.training:      # the towers' F.dropout (:275) inside the route's tail kernels (round 6)
+            seed, offset = _next_dropout_key(h.device)
+            drop = (float(self.dropout), seed, offset)
+        y = _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, rm, rv, nbt,
+                             (*plist, mix.weight, mix.bias), 2, T, fi, fo, self.residual, bns[0].momentum, bns[0].eps, act[1], training=self.training,
+                             dropout=drop)
+        if drop is not None:
+            _dropout_key_used(drop[1])
+        return y
 
     def _forward(self, g, h, e, snorm_n):
         h_in = h

@@ -1539,7 +1539,7 @@ DIRECT_PARAM_GRADS = os.environ.get("DGN_DIRECT_PARAM_GRADS", "0") == "1"
 
 def _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params):
     """DgnBlockLayer for one call (+ the ctypes objects it points to)."""
-    type_net, T, fi, fo, residual, momentum, eps, slope = cfg
+    type_net, T, fi, fo, residual, momentum, eps, slope = cfg[:8]
     from .graph import _channel_array
     spec = _spec_structs(plan, 1, avg_log, 0)[0]
     L = _lib.DgnBlockLayer()
@@ -1647,6 +1647,13 @@ class _BlockLayer(torch.autograd.Function):
         params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)
         L, keep = _block_struct(graph, table, plan, avg_log, eig, cfg, h, snorm, rm, rv, nbt, params)
         ws_f, ws_b, n_par, sizes, shapes = _block_sizes(lib, table, L, cfg, params)
+        drop = cfg[8] if len(cfg) > 8 else None
+        if drop is not None:      # the towers' dropout inside the tails: (p, key tensor, offset); the keep bits are kept for the backward
+            global LAST_DROPOUT_MASK
+            drop_mask = torch.empty(lib.dgn_dropout_mask_bytes(N * Fo), dtype=torch.uint8, device=dev)
+            L.drop_p, L.drop_seed, L.drop_offset, L.drop_mask = float(drop[0]), drop[1].data_ptr(), int(drop[2]), drop_mask.data_ptr()
+            keep = keep + (drop_mask, drop[1])
+            LAST_DROPOUT_MASK = drop_mask
         n_saved = N * Fo + 2 * Fo
         saved = torch.empty(n_saved + (ws_f + 3) // 4 + 64, dtype=torch.float32, device=dev)      # [y0 | mean | invstd | (forward scratch)]
         out = torch.empty((N, Fo), dtype=torch.float32, device=dev)
@@ -1729,7 +1736,7 @@ def _block_layer_eval(graph, plan, avg_log, eig, cfg, h, snorm, rm, rv, params):
 
 
 def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, rm, rv, nbt, params, type_net: int, n_towers: int, f_in: int,
-                f_out: int, residual: bool, momentum: float, eps: float, slope: float = 0.01, training: bool = True) -> torch.Tensor:
+                f_out: int, residual: bool, momentum: float, eps: float, slope: float = 0.01, training: bool = True, dropout=None) -> torch.Tensor:
     """One DGN layer (nets/dgn_layer.py:103-132 complex, :178-202 simple, :254-276 + :309-325 towers; training mode -- ``training=False``:
     the evaluation-mode forward without gradients, BatchNorm on its running statistics) as ONE autograd node
     over ``dgn_block_layer_forward / _backward`` (``include/dgn_hip.h: DgnBlockLayer``): two launches forward, three backward.
@@ -1746,6 +1753,8 @@ def block_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, eig, h, snorm, r
     else:
         eig = None
     cfg = (int(type_net), int(n_towers), int(f_in), int(f_out), bool(residual), float(momentum), float(eps), float(slope))
+    if training and dropout is not None:      # (towers: ``(p, key tensor, offset)`` as ops.dropout takes them; evaluation applies none)
+        cfg = cfg + ((float(dropout[0]), dropout[1], int(dropout[2])),)
     if not training:
         return _block_layer_eval(graph, plan, float(avg_log), eig, cfg, h, snorm, rm, rv, params)
     if DIRECT_PARAM_GRADS and h.requires_grad:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 26
+#define DGN_ABI_VERSION 27
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -749,6 +749,11 @@ typedef struct DgnBlockLayer {
     int32_t eval_mode;
     float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
     int64_t* dbg_time;           /* profiling only: [n_blocks][16] wall-clock stamps (100 MHz) of the block kernel's phases; NULL      */
+    /* Round 6 (ABI 27), towers only: F.dropout(h, p, training) between the towers' BatchNorm and the mixing network (nets/dgn_layer.py:275)
+     * inside the tail kernels.  drop_p in (0, 1): drop_seed (DEVICE int64 key; forward only) / drop_offset as dgn_dropout_forward takes
+     * them, drop_mask = dgn_dropout_mask_bytes(N * T * f_out) bytes, written by the forward (the very bits dgn_dropout_forward would
+     * draw for the dense [N, T f_out] tensor) and read by the backward.  drop_p = 0: none.  Ignored in eval_mode.                   */
+    float drop_p; const int64_t* drop_seed; uint64_t drop_offset; unsigned char* drop_mask;
 } DgnBlockLayer;
 typedef struct DgnBlockGrads {
     const float* g_out;          /* [N, T f_out]                                                                              */

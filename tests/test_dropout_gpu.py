@@ -202,9 +202,12 @@ def test_first_dropout_inside_a_capture_is_refused():
     dgn_amd.reset_dropout_state()
 
 
-def test_towers_layer_with_dropout_in_the_whole_layer_call_vs_oracle_with_the_same_mask(monkeypatch):
+@pytest.mark.parametrize("route", ["whole-layer", "graph-block"])
+def test_towers_layer_with_dropout_in_the_whole_layer_call_vs_oracle_with_the_same_mask(monkeypatch, route):
     """``DGNTower``'s F.dropout between BatchNorm and the mixing network (nets/dgn_layer.py:275) inside dgn_towers_layer_forward /
-    _backward (DgnTowersLayer.drop_*): values, d h and every parameter gradient against the oracle fed the keep mask the kernel drew."""
+    _backward (DgnTowersLayer.drop_*) and -- round 6 -- inside the graph-block route's tail kernels (DgnBlockLayer.drop_*): values, d h
+    and every parameter gradient against the oracle fed the keep mask the kernel drew; on the block route the mask must also be, bit for
+    bit, what dgn_dropout_forward draws for the same key and offset."""
     import dgn_amd
     from dgn_amd import ops, synth
     from oracle import dgn_oracle as orc
@@ -226,16 +229,26 @@ def test_towers_layer_with_dropout_in_the_whole_layer_call_vs_oracle_with_the_sa
     ct = torch.randn(N, F_, generator=gen)
     layer = layer.to(dev).train()
     calls = []
-    whole = type(layer)._whole_layer
-    monkeypatch.setattr(type(layer), "_whole_layer", lambda self, *a: calls.append(whole(self, *a)) or calls[-1])
-    monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 0)
+    if route == "whole-layer":
+        whole = type(layer)._whole_layer
+        monkeypatch.setattr(type(layer), "_whole_layer", lambda self, *a: calls.append(whole(self, *a)) or calls[-1])
+        monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 0)
+    else:
+        real = ops.block_layer
+        monkeypatch.setattr(ops, "block_layer", lambda *a, **k: calls.append(real(*a, **k)) or calls[-1])
+        monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 8192)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
     hd = h.to(dev).requires_grad_(True)
     ops.LAST_DROPOUT_MASK = None
     y = layer(graph, hd, None, snorm.to(dev))
-    assert calls and calls[-1] is not None, "the whole-layer call did not take the towers layer with dropout on"
-    keep = _bits(ops.LAST_DROPOUT_MASK, N * F_).reshape(N, F_)
+    assert calls and calls[-1] is not None, f"the {route} call did not take the towers layer with dropout on"
+    mask_bytes = ops.LAST_DROPOUT_MASK.clone()
+    keep = _bits(mask_bytes, N * F_).reshape(N, F_)
     assert 0.6 < float(keep.mean()) < 0.8
+    if route == "graph-block":      # the tails draw the bits dgn_dropout_forward draws for (key, offset) over the dense [N, T f_out] tensor
+        key, n_calls = dgn_amd.dgn_layer._DROP_STATE[torch.device("cuda", torch.cuda.current_device())]
+        ops.dropout(torch.ones(N, F_, device=dev), p, True, seed=key, offset=n_calls)
+        assert torch.equal(ops.LAST_DROPOUT_MASK[:(N * F_ + 7) // 8], mask_bytes[:(N * F_ + 7) // 8])
     (y * ct.to(dev)).sum().backward()
     cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.2), graph_norm=True, batch_norm=True, residual=True, towers=5,
                divide_input=True, edge_features=False)
