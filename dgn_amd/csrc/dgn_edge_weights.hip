@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "dgn_common.hpp"
 
@@ -208,19 +209,25 @@ __device__ __forceinline__ void range_write(const Stats (&st)[DGN_MAX_CH], const
 constexpr int kFlatMax = 4;
 constexpr int kGroup = 16;
 
+template <int FM>
 __device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64);
-__global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) { ew_flat_body(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ __launch_bounds__(256) void ew_rows_flat(const EwParams p) { ew_flat_body<kFlatMax>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+// Round 6: batches whose LARGEST in-degree is 5 .. 8 (k-NN graphs: CIFAR10 / MNIST superpixels, 8 neighbours) -- a thread per row there too,
+// eight gathers in flight per lane, one launch; the 16-lanes-per-row class walked four rows per one-wave workgroup, three dependent round
+// trips each (c3_mega, 960 k rows: 0.382 ms = 0.07 of the HBM roofline).
+__global__ __launch_bounds__(256) void ew_rows_flat8(const EwParams p) { ew_flat_body<8>(p, (int64_t)blockIdx.x * blockDim.x + threadIdx.x); }
+template <int FM>
 __device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64) {
     if (row64 >= p.n_nodes) return;
     const int row = (int)row64;
     const int beg = p.indptr[row], end = p.indptr[row + 1];
     const int deg = end - beg;
-    if (deg == 0 || deg > kFlatMax) return;
+    if (deg == 0 || deg > FM) return;
     RowEig re;
     re.load(p, row);
-    float dl[kFlatMax][DGN_MAX_CH];
+    float dl[FM][DGN_MAX_CH];
 #pragma unroll
-    for (int j = 0; j < kFlatMax; ++j) {           // all gathers issued before the first use
+    for (int j = 0; j < FM; ++j) {           // all gathers issued before the first use
 #pragma unroll
         for (int c = 0; c < DGN_MAX_CH; ++c) dl[j][c] = 0.f;
         if (j < deg) edge_deltas(dl[j], p, re, beg + j);
@@ -230,7 +237,7 @@ __device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64) {
         if (c >= p.n_ch) break;
         Stats st{0.f, 0.f, 0.f, -INFINITY, 0.f};
 #pragma unroll
-        for (int j = 0; j < kFlatMax; ++j) {       // slot order, as the reference's sum over the mailbox dimension
+        for (int j = 0; j < FM; ++j) {       // slot order, as the reference's sum over the mailbox dimension
             if (j < deg) {
                 const float d = dl[j][c];
                 st.sabs += fabsf(d); st.spos += fmaxf(d, 0.f); st.sneg += fmaxf(-d, 0.f);
@@ -239,11 +246,11 @@ __device__ __forceinline__ void ew_flat_body(const EwParams& p, int64_t row64) {
         }
         if (p.ch[c].kind == DGN_W_SOFTMAX) {
 #pragma unroll
-            for (int j = 0; j < kFlatMax; ++j)
+            for (int j = 0; j < FM; ++j)
                 if (j < deg) st.se += expf(p.ch[c].alpha * fabsf(dl[j][c]) - st.mx);
         }
 #pragma unroll
-        for (int j = 0; j < kFlatMax; ++j)
+        for (int j = 0; j < FM; ++j)
             if (j < deg) p.w[(int64_t)c * p.ld_w + beg + j] = weight_of(p.ch[c], st, dl[j][c]);
     }
 }
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(kWave) void ew_rows(const EwParams p) {
 __global__ __launch_bounds__(kWave) void ew_rows_small(const EwParams p, int nf, int ng) {
     __shared__ int list[kWave];
     const int b = blockIdx.x;
-    if (b < nf) ew_flat_body(p, (int64_t)b * kWave + threadIdx.x);
+    if (b < nf) ew_flat_body<kFlatMax>(p, (int64_t)b * kWave + threadIdx.x);
     else if (b < nf + ng) ew_g16_body<kWave / kGroup>(p, b - nf, list);
     else ew_rows_body<1>(p, b - nf - ng, list);
 }
@@ -509,9 +516,15 @@ extern "C" int dgn_edge_weights(const DgnGraph* g, const float* eig, const float
         p.slice_stats = static_cast<float*>(ws);
         p.hub_stats = reinterpret_cast<float*>(static_cast<char*>(ws) + up((size_t)g->n_chunks * DGN_MAX_CH * 5 * sizeof(float)));
     }
-    const bool big = p.n_nodes >= (1 << 20);       // row classes by ballot (64 candidate rows per wave) vs a wave / 16 lanes per row
+    // (round 6: 2^20 -> 2^19 rows.  Below it the three classes are one launch of N / 64 + N / 4 + N one-wave workgroups, most of which
+    //  leave at once: at 960 k k-NN rows (c3_mega) the dispatcher alone is 0.26 ms of a 0.383-ms launch; the ballot path takes 0.139)
+    static const int64_t big_min = getenv("DGN_EW_BIG_MIN") ? atoll(getenv("DGN_EW_BIG_MIN")) : (1 << 19);
+    const bool big = p.n_nodes >= big_min;         // row classes by ballot (64 candidate rows per wave) vs a wave / 16 lanes per row
     static const bool no_merge = getenv("DGN_EW_SEPARATE") != nullptr;
-    if (!big && !no_merge && (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)) {
+    static const bool no_flat8 = getenv("DGN_EW_NO_FLAT8") != nullptr;
+    if (!no_flat8 && g->max_in_degree > kFlatMax && g->max_in_degree <= 8) {      // every row at most 8 slots: a thread per row, one launch
+        hipLaunchKernelGGL(ew_rows_flat8, dim3((unsigned)((p.n_nodes + 255) / 256)), dim3(256), 0, stream, p);
+    } else if (!big && !no_merge && (g->max_in_degree == 0 || g->max_in_degree > kFlatMax)) {
         const int nf = (int)((p.n_nodes + kWave - 1) / kWave), ng = (int)((p.n_nodes + 3) / 4);
         const bool rows = g->max_in_degree == 0 || g->max_in_degree > kGroup;
         hipLaunchKernelGGL(ew_rows_small, dim3((unsigned)(nf + ng + (rows ? p.n_nodes : 0))), dim3(kWave), 0, stream, p, nf, ng);
