@@ -1180,11 +1180,13 @@ def run_extras(args, dev):
                     finally:
                         _ops.DIRECT_PARAM_GRADS = False
                         torch.autograd.set_multithreading_enabled(True)
-                if name.endswith("_b128"):
+                if name.endswith("_b128") or name == "c3":
+                    # (c3: CIFAR10's 8-NN graphs TRAIN on the streaming kernels, their evaluation forward takes the graph-block route -- round 6)
                     try:
                         extra[name]["eval_fwd_ms"] = eval_forward_ms(dict(WORKLOADS[name]), dev)
                     except Exception as exc:
                         extra[name]["eval_fwd_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                if name.endswith("_b128"):
                     try:      # the eager step per layer inside a 4-layer stack (one backward() for four layers)
                         ms4, ms4_st = eager_stack_ms(dict(WORKLOADS[name]), dev)
                         extra[name]["stack4_ms"], extra[name]["stack4_st_ms"] = ms4 / 4, ms4_st / 4

@@ -321,8 +321,12 @@ extern "C" int dgn_block_layer_supported(const DgnBlockLayer* L) {
     Dims d;
     if (!dims_of(L, d, "dgn_block_layer_supported")) return 0;
     Layout lay; int rc; int8_t cmap[blk::CF_SLOTS];
-    if (!plan_lds(d, L->spec, true, lay, rc, cmap) || !plan_lds(d, L->spec, false, lay, rc, cmap)) return 0;
+    // eval_mode (round 6): the evaluation forward needs the FORWARD plan alone -- 150-node k-NN graphs at hidden 65 (CIFAR10) fit it (132 KB)
+    // where the backward's 240 KB do not, so validation / test passes of those configs run the route's two launches
+    if (!plan_lds(d, L->spec, false, lay, rc, cmap)) return 0;
     if (L->residual && d.F != d.Fo) return 0;
+    if (L->eval_mode) return tail_fwd_lds(d) <= kLdsBytes;
+    if (!plan_lds(d, L->spec, true, lay, rc, cmap)) return 0;
     return tail_bwd_lds(d) <= kLdsBytes && tail_fwd_lds(d) <= kLdsBytes;
 }
 

@@ -330,7 +330,8 @@ def _block_route_ok(layer, h) -> bool:
     # (a training step -- or the evaluation loops' regime: eval() under no_grad; the two mixed forms keep the streaming kernels)
     return (_ops.BLOCK_LAYER_MAX_NODES > 0 and layer.training == torch.is_grad_enabled() and (layer.training or not h.requires_grad)
             and layer.batch_norm and h.is_cuda
-            and h.dtype == torch.float32 and h.dim() == 2 and 0 < h.shape[0] <= _ops.BLOCK_LAYER_MAX_NODES
+            and h.dtype == torch.float32 and h.dim() == 2
+            and 0 < h.shape[0] <= (_ops.BLOCK_LAYER_MAX_NODES if layer.training else max(_ops.BLOCK_LAYER_MAX_NODES, _ops.BLOCK_LAYER_EVAL_MAX_NODES))
             and all(bn.momentum is not None and bn.track_running_stats and bn.affine and not _ops._spans_ranks(bn, layer.training)
                     for bn in _bns_of(layer)))
 
@@ -395,7 +396,7 @@ class DGNLayerSimple(nn.Module):
         if not (_block_route_ok(self, h) and self.posttrans.is_single_affine() and lin.bias is not None):
             return None
         graph = as_dgn_graph(g, h.device)
-        if not _ops.block_layer_supported(graph, self.plan, 0, 1, h.shape[1], lin.weight.shape[0]):
+        if not _ops.block_layer_supported(graph, self.plan, 0, 1, h.shape[1], lin.weight.shape[0], eval_only=not self.training):
             return None
         return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, (lin.weight, lin.bias, bn.weight, bn.bias), 0, 1, h.shape[1], lin.weight.shape[0],
@@ -523,7 +524,7 @@ class DGNLayerComplex(nn.Module):
                 and lin.bias is not None and pre.bias is not None):
             return None
         graph = as_dgn_graph(g, h.device)
-        if not _ops.block_layer_supported(graph, self.plan, 1, 1, h.shape[1], lin.weight.shape[0]):
+        if not _ops.block_layer_supported(graph, self.plan, 1, 1, h.shape[1], lin.weight.shape[0], eval_only=not self.training):
             return None
         return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
                                 bn.num_batches_tracked, (pre.weight, pre.bias, lin.weight, lin.bias, bn.weight, bn.bias), 1, 1, h.shape[1],
@@ -895,7 +896,7 @@ class DGNLayerTower(nn.Module):
         if any(p is None for p in plist):
             return None
         graph = as_dgn_graph(g, h.device)
-        if not _ops.block_layer_supported(graph, self.plan, 2, T, fi, fo):
+        if not _ops.block_layer_supported(graph, self.plan, 2, T, fi, fo, eval_only=not self.training):
             return None
         bns = [t.batchnorm_h for t in self.towers]
         rm, rv, nbt = self._linked_bn_stats(h.device)

@@ -1581,20 +1581,33 @@ def _plan_signature(plan):
     return (tuple(plan.aggregators), tuple(plan.scalers))
 
 
-def block_layer_supported(graph, plan, type_net, T, fi, fo) -> bool:
-    """Whether this (batch, layer shape) runs on the graph-block route: a block table whose largest block fits the LDS plan."""
-    if BLOCK_LAYER_MAX_NODES <= 0 or graph.num_nodes > BLOCK_LAYER_MAX_NODES or len(plan.launches) != 1 or plan.n_channels > 3:
+# Evaluation forward (eval() under no_grad) of batches ABOVE BLOCK_LAYER_MAX_NODES: taken when every (block, tower) workgroup has a CU of
+# its own (one round) -- 128 k-NN / SBM graphs of 85-190 nodes (CIFAR10 / PATTERN at the json's batch size: 12-15 k nodes) --, up to this
+# many nodes.  The training limit above was measured on molecule batches, whose block count grows with the node count.
+BLOCK_LAYER_EVAL_MAX_NODES = int(os.environ.get("DGN_BLOCK_LAYER_EVAL_MAX_NODES", "32768"))
+
+
+def block_layer_supported(graph, plan, type_net, T, fi, fo, eval_only: bool = False) -> bool:
+    """Whether this (batch, layer shape) runs on the graph-block route: a block table whose largest block fits the LDS plan
+    (``eval_only``: the forward plan alone, dgn_block_layer_supported with eval_mode set)."""
+    if BLOCK_LAYER_MAX_NODES <= 0 or len(plan.launches) != 1 or plan.n_channels > 3:
+        return False
+    over = graph.num_nodes > BLOCK_LAYER_MAX_NODES
+    if over and not (eval_only and graph.num_nodes <= BLOCK_LAYER_EVAL_MAX_NODES):
         return False
     if ((fi if type_net != 0 else 0) + plan.n_scalers * plan.n_agg * fi) * fo > BLOCK_LAYER_MAX_POST:
         return False
     table = graph.block_table()
     if table is None:
         return False
+    if over and table["n_blocks"] * T > 256:
+        return False
     # (a stable signature of the plan, not id(plan): an id can be reused after garbage collection)
-    key = (_plan_signature(plan), type_net, T, fi, fo)
+    key = (_plan_signature(plan), type_net, T, fi, fo, bool(eval_only))
     ok = table.setdefault("ok", {})
     if key not in ok:
         L = _lib.DgnBlockLayer()
+        L.eval_mode = 1 if eval_only else 0
         spec = _spec_structs(plan, 1, 1.0, 0)[0]
         cg, tb = graph.c_graph, table["struct"]
         L.graph, L.blocks, L.spec = C.pointer(cg), C.pointer(tb), C.pointer(spec)

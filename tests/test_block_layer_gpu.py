@@ -434,6 +434,54 @@ def test_evaluation_forward_on_the_route(monkeypatch, type_net, F_, aggs):
         assert torch.equal(v, before[k]), k
 
 
+@pytest.mark.parametrize("kind,type_net,F_,scalers", [("knn", "simple", 65, "identity"), ("knn", "simple", 70, "identity amplification attenuation")])
+def test_evaluation_forward_of_knn_and_sbm_batches_on_the_route(monkeypatch, kind, type_net, F_, scalers):
+    """Round 6: CIFAR10-like 8-NN graphs (85-150 nodes, hidden 65) at the json's batch size -- above ops.BLOCK_LAYER_MAX_NODES, and their
+    BACKWARD does not fit the LDS (training keeps the streaming kernels; the COMPLEX layer's P | Q rows (170 KB) and PATTERN's SBM graphs,
+    ~6 000 edges each, do not fit the forward either) -- run their
+    EVALUATION forward (eval() under no_grad: the reference's validation / test loops, train/train_superpixels_graph_classification.py)
+    on the route: dgn_block_layer_supported with eval_mode needs the forward plan alone, and every (block, tower) workgroup has a CU
+    of its own.  Against the oracle in evaluation mode and the streaming kernels."""
+    import dgn_amd
+    from dgn_amd import synth
+    from oracle import dgn_oracle as orc
+    dev = torch.device("cuda")
+    b = synth.knn_batch(100, seed=41) if kind == "knn" else synth.sbm_batch(n_graphs=100, seed=41)
+    N = int(b["num_nodes"])
+    assert N > dgn_amd.ops.BLOCK_LAYER_MAX_NODES
+    aggs = "mean dir1-dx dir2-dx"
+    avg = float(torch.log(torch.bincount(b["dst"], minlength=N).float() + 1).mean())
+    layer, gen = _make_layer(type_net, F_, aggs, scalers, True, avg)
+    with torch.no_grad():
+        for k, v in layer.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(0.3 * torch.randn(v.shape, generator=gen))
+            elif k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+    h = torch.randn(N, F_, generator=gen)
+    sd = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(avg), graph_norm=True, batch_norm=True, residual=True, towers=1,
+               divide_input=True, edge_features=False)
+    yo, _ = orc.layer_forward(type_net, sd, cfg, b["src"], b["dst"], N, b["eig"], h, None, b["snorm_n"], training=False)
+    layer = layer.to(dev).eval()
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    taken = _count_route(monkeypatch)
+    with torch.no_grad():
+        y = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+        assert len(taken) == 1, "the evaluation forward of the k-NN / SBM batch did not take the route"
+        monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 0)
+        ys = layer(graph, h.to(dev), None, b["snorm_n"].to(dev))
+    assert len(taken) == 1
+    scale = max(1.0, float(yo.abs().max()))
+    np.testing.assert_allclose(y.cpu().numpy(), yo.numpy(), rtol=2e-5, atol=2e-5 * scale)
+    np.testing.assert_allclose(y.cpu().numpy(), ys.cpu().numpy(), rtol=2e-5, atol=2e-5 * scale)
+    # training on the same batch keeps the streaming kernels (the backward plan does not fit / the node limit)
+    layer.train()
+    monkeypatch.setattr(dgn_amd.ops, "BLOCK_LAYER_MAX_NODES", 8192)
+    layer(graph, h.to(dev).requires_grad_(True), None, b["snorm_n"].to(dev)).sum().backward()
+    assert len(taken) == 1
+
+
 @pytest.mark.parametrize("type_net,F_,aggs", [("towers", 70, "mean max min dir1-av dir1-dx"), ("complex", 45, "mean dir1-dx dir1-av"), ("simple", 75, "mean dir1-dx-no-abs")])
 def test_direct_parameter_gradients_are_the_autograd_ones(monkeypatch, type_net, F_, aggs):
     """``ops.DIRECT_PARAM_GRADS`` (opt-in): the block route's backward assigns the parameters' ``.grad`` itself instead of returning 33
