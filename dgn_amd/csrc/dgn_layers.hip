@@ -315,11 +315,14 @@ extern "C" int dgn_dense_layer_backward(const DgnDenseLayer* L, const DgnDenseGr
         DGN_TRY(dgn_dc_wgrad(L->dc, d.S, d.K, d.fo, g_z, d.fo, L->agg, d.K, G->g_w_post, 0, &lay, ws + s.wg_ws,
                              dgn_dc_wgrad_workspace_bytes(L->dc->n_units, d.K, d.fo), stream));
     } else {
-        DGN_TRY(scale_combine_backward_impl(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, G->g_b_post, ws + s.comb_ws,
+        // (one scaler: the bias gradient sum_m g_z[m, :] rides in the weight-gradient pass as its ones column -- no partial sums in the
+        //  combine backward, no bias_finalize launch: round 6, the 19-launch CIFAR10 step)
+        const bool bias_from_wgrad = d.S == 1;
+        DGN_TRY(scale_combine_backward_impl(d.N, 1, d.S, d.fo, nullptr, 0, L->scale, L->snorm, g_z, bias_from_wgrad ? nullptr : G->g_b_post, ws + s.comb_ws,
                                            dgn_scale_combine_backward_workspace_bytes(d.N, 1, d.fo), &bn, stream, 1));
         // posttrans: input gradient (on the transposed folded weight), weight gradient, un-folded into the reference's layout
         DGN_TRY(lin_fwd(d.N, d.n, d.K, g_z, wft, nullptr, g_agg, stream));
-        DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));
+        DGN_TRY(lin_wgrad(d.N, d.K, d.n, g_z, L->agg, g_wf, bias_from_wgrad ? G->g_b_post : nullptr, ws + s.wg_ws, wgrad_ws(d.N, d.K, d.n), stream));
     }
     if (!d.dc)
         hipLaunchKernelGGL(unfold_post, dim3(nblk((int64_t)d.fo * ld_post)), dim3(256), 0, st, d.S, d.fo, d.A, d.Ab, d.F0, d.Fp, hoff, d.cx ? L->id_slot : 0, ld_post,
