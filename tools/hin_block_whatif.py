@@ -22,8 +22,9 @@ pq = torch.randn(N, 2 * F_, device=dev, generator=gen)
 for name, plan in (("six blocks (with __x_in__)", layer._kplan_x), ("five blocks", layer._kplan)):
     w = graph.edge_weights(plan)
     K = plan.out_width(F_) // T
-    out = torch.empty(T, N, K, device=dev)
-    g_out = torch.randn(T, N, K, device=dev, generator=gen)
+    Np = N + (N & 1)                                            # (tower planes 16-byte aligned also for K = 70)
+    out = torch.empty(T, Np, K, device=dev)[:, :N]
+    g_out = torch.randn(T, Np, K, device=dev, generator=gen)[:, :N]
     n_aux = ops.agg_aux_bytes(graph, plan, T, F_, pq[:, :F_], pq[:, F_:], None, h)
     aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
     g_src, g_dst, g_in = (torch.zeros(N, F_, device=dev) for _ in range(3))
