@@ -46,6 +46,8 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bnbm ? 5 * NT * 16 : (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0)))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
+    p.wreg = (p.ex.gy || p.S > 0) && !bnbm && linear_wreg_ok(NT, KB, p.ex.gy ? kExpand : kCombine) && option(OPT_LIN_WREG) ? 1 : 0;
+    if (p.wreg) waves = std::min(waves, 4);
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
     const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
     {   // Small batches: 2 970 rows are 186 strips -- twelve 16-wave workgroups on twelve of 256 CUs.  Fewer waves per workgroup until
@@ -54,9 +56,10 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
         const int min_waves = (int)option(OPT_LINEAR_SMALL_MIN_WAVES);           // (4: no gain, 2 and 1: slower -- the weights are staged by too few threads)
         while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves /= 2;
     }
-    const size_t lds = w_bytes + waves * strip_bytes;
+    const size_t wl_bytes = (size_t)NT * 16 * p.kp * 4;
+    const size_t lds = p.wreg ? w_bytes - wl_bytes + std::max(wl_bytes, waves * strip_bytes) : w_bytes + waves * strip_bytes;
     if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
-    const int per_cu = std::max(1, std::min((int)(kLdsBudget / lds), 32 / waves));
+    const int per_cu = std::max(1, std::min({(int)(kLdsBudget / lds), 32 / waves, p.wreg ? 3 : 32}));      // (WREG: 3 waves per SIMD by registers)
     int groups = std::max(1, n_cus() * per_cu / p.T);
     groups = (int)std::min<int64_t>(groups, (n_strips + waves - 1) / waves);
     p.groups = groups;

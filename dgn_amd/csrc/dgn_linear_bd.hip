@@ -64,13 +64,14 @@ __device__ __forceinline__ void bd_store_out(const float* U, float* dst, int wid
     } else {
 #pragma unroll
         for (int j = 0; j < NLC; ++j) {
-            if (j * 64 + lane < cnt2) {
-                float2 c = reinterpret_cast<const float2*>(U)[j * 64 + lane];
+            const int i2 = ADD ? tail_idx2(j, lane) : j * 64 + lane;
+            if (i2 < cnt2) {
+                float2 c = reinterpret_cast<const float2*>(U)[i2];
                 if constexpr (ADD) {
                     c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
                     if (has2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
                 }
-                reinterpret_cast<float2*>(dst)[j * 64 + lane] = c;
+                reinterpret_cast<float2*>(dst)[i2] = c;
             }
         }
     }
@@ -185,7 +186,11 @@ __global__ __launch_bounds__(bd_bwd_threads(T, (FI + 15) / 16)) void bd_backward
     const int m = lane & 15, g = lane >> 4;
     const bool has1 = p.add1 != nullptr, has2 = p.add2 != nullptr;
     float2 pe1[NLC], pe2[NLC];
-    auto load_adds = [&](int64_t s_) {               // (branch-free loads; a NULL operand is not used)
+    auto load_adds = [&](int64_t s_) {               // (an absent operand reads zeros and is not used)
+#ifndef DGN_STRIP_GLOBAL_LOADS
+        load_strip<NLC>(pe1, p.add1, p.M, n, s_, lane, has1);
+        load_strip<NLC>(pe2, p.add2, p.M, n, s_, lane, has2);
+#else
         const int rows = (int)min((int64_t)kStrip, p.M - s_ * kStrip);
         const float* b1 = (has1 ? p.add1 : p.C) + s_ * kStrip * n;
         const float* b2 = (has2 ? p.add2 : (has1 ? p.add1 : p.C)) + s_ * kStrip * n;
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(bd_bwd_threads(T, (FI + 15) / 16)) void bd_backward
                 pe2[j] = reinterpret_cast<const float2*>(b2)[q];
             }
         }
+#endif
     };
     int64_t out_strip = -1;
     auto store_out = [&]() {

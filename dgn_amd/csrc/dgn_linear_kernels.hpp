@@ -76,6 +76,7 @@ struct LinParams {
     // towers.  bnb_y [M, n] dense is BatchNorm's input, bn_mean / bn_invstd / bn_gamma its tables (width n here), bnb_sums [2 n] the column
     // sums (sum g_y1, sum g_y1 xhat); `rs` (may be NULL) and `fo` as in the combine epilogue.  g_y1 itself is never written.
     const float* bnb_y; const float* bnb_sums; float* bnb_gz; int64_t bnb_sT;
+    int wreg;                                        // launch the WREG instance (set by launch_linear: shape, mode and option lin_wreg)
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
@@ -87,8 +88,29 @@ __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }  
 // 16-byte lanes, float4 number q = jq * 64 + lane living in pre[2 jq], pre[2 jq + 1] (NL = 2 KB is even).  The batch's last,
 // partial strip is read in 8-byte pieces with clamped indices instead (a 16-byte lane could reach past the tensor).
 __device__ __forceinline__ int strip_idx2(int j, int lane) { return 2 * ((j >> 1) * 64 + lane) + (j & 1); }   // float2 number held by pre[j]
+// float2 number of a result strip that a lane's j-th epilogue register (pe1[j] / pe2[j]) belongs to on the batch's partial last strip: with
+// buffer loads the partial strip has the full strip's register layout (float4 number jq * 64 + lane in registers 2 jq, 2 jq + 1)
+#ifdef DGN_STRIP_GLOBAL_LOADS
+__device__ __forceinline__ int tail_idx2(int j, int lane) { return j * 64 + lane; }
+#else
+__device__ __forceinline__ int tail_idx2(int j, int lane) { return strip_idx2(j, lane); }
+#endif
+// Round 6: the strip is read with BUFFER loads (one V# per strip: base = the strip's first row, num_records = its valid bytes) -- lanes past
+// the strip's end, and past the tensor's end on the batch's last, partial strip, read zeros by the range check (checked per dword), so the
+// loop has ONE load shape.  With global loads the full strip's 16-byte lanes and the partial strip's clamped 8-byte lanes were two branches
+// that the compiler merged into dword + dword + dwordx2 per lane: three memory instructions for one, on every strip of every kernel here.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<const float*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const float* base, int bytes) {      // (wave-uniform arguments)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
 template <int NL>
-__device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane) {
+__device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane, bool present = true) {      // (!present: an absent operand, all lanes read zeros)
+#ifdef DGN_STRIP_GLOBAL_LOADS
     const int64_t row0 = strip * kStrip;
     const float* base = A + row0 * k;                                             // wave-uniform
     const int n2 = (int)min((int64_t)kStrip, M - row0) * (k >> 1);               // float2's that exist
@@ -104,6 +126,18 @@ __device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, in
 #pragma unroll
         for (int j = 0; j < NL; ++j) pre[j] = reinterpret_cast<const float2*>(base)[min(strip_idx2(j, lane), n2 - 1)];
     }
+#else
+    const int64_t row0 = strip * kStrip;
+    const float* base = uniform_ptr(A + row0 * k);
+    const int rows = __builtin_amdgcn_readfirstlane((int)min((int64_t)kStrip, M - row0));
+    const __amdgpu_buffer_rsrc_t rs = strip_rsrc(base, present ? rows * k * 4 : 0);
+#pragma unroll
+    for (int jq = 0; jq < NL / 2; ++jq) {
+        const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (jq * 64 + lane) * 16, 0, 0));
+        pre[2 * jq] = make_float2(v[0], v[1]);
+        pre[2 * jq + 1] = make_float2(v[2], v[3]);
+    }
+#endif
 }
 template <int NL>
 __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], int k, int lane) {
@@ -237,8 +271,14 @@ __device__ __forceinline__ void store_strip_mask(float* Xl, const float2 (&pre)[
 
 enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddPlain = 5, kMixFwd = 6, kActMask = 7, kActMaskBnb = 8 };        // ts_linear variants
 
-template <int NT, int KB, int MODE>
-__global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinParams p) {
+// WREG (round 6): the lane's W operands of ALL 16-k blocks stay in registers (KB x NT f4) instead of being re-read from LDS for every strip --
+// the matrix pipe fed from LDS runs at 95 / 108 / 148 TFLOP/s with one ds_read_b128 per 4 / 8 / 16 MFMAs (profiles/r03_mfma_peak.txt), and
+// the strip products read NT + 1 operands per 4 NT MFMAs (posttrans of the towers: one per 3).  With WREG: one per 4 NT.  Costs the
+// registers of 4 NT KB floats: 512 threads per workgroup (256 registers per lane), shapes up to kWregTiles tiles.
+constexpr int kWregTiles = 18;
+constexpr bool linear_wreg_ok(int NT, int KB, int MODE) { return (MODE == 1 || MODE == 2) && NT * KB <= kWregTiles && NT * KB >= 6; }
+template <int NT, int KB, int MODE, bool WREG = false>
+__global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3 : 1) void ts_linear(LinParams p) {
     constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain;
     constexpr bool BNB = MODE == kActMaskBnb, ADD = MODE == kAddPlain || MIX || BNB;      // (BNB: the epilogue's strip-shaped operand is BatchNorm's input)
     constexpr bool ACTM = MODE == kActMask || BNB;
@@ -248,11 +288,13 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int t = blockIdx.x % p.T, grp = blockIdx.x / p.T;
     const int kp = p.kp, k = p.k, n = p.n;
-    float* Wl = lds;                                 // [NT*16][kp], zero beyond (n, k)
-    float* Bl = Wl + NT * 16 * kp;                   // [NT*16] bias
+    float* Bl = lds;                                 // [NT*16] bias
     float* Cb = Bl + NT * 16;                        // [NT*16] the combine epilogue's bias for this tower
     float* Bn = Cb + NT * 16;                        // kBnPlain: [4][KB*16] mean, invstd, gamma, beta of the operand's columns
-    float* Xl = Bn + (BNP ? 4 * KB * 16 : (ACT ? KB * 16 : (BNB ? 5 * NT * 16 : 0))) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
+    constexpr int kTabFloats = 2 * NT * 16 + (BNP ? 4 * KB * 16 : (ACT ? KB * 16 : (BNB ? 5 * NT * 16 : 0)));
+    float* Wl = lds + kTabFloats;                    // [NT*16][kp], zero beyond (n, k)
+    // (WREG: the weights are dead in LDS once every lane holds its operands -- the waves' strips lie over them)
+    float* Xl = (WREG ? Wl : Wl + NT * 16 * kp) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
     float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
 
@@ -286,7 +328,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     };
     if (first < n_strips) fetch(first);              // in flight while the weights are set up
 
-    for (int i = tid; i < NT * 16 * kp + 2 * NT * 16; i += blockDim.x) lds[i] = 0.f;
+    for (int i = tid; i < NT * 16 * kp + kTabFloats; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
     const float* Wg = p.W + (int64_t)t * p.sW;
     for (int i = tid; i < n * k; i += blockDim.x) {
@@ -329,6 +371,14 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
     const float* xrow = Xl + m * k + 4 * g;
     const float* wrow = Wl + m * kp + 4 * g;
     const bool k4 = (k & 3) == 0;
+    f4 wreg[WREG ? KB : 1][WREG ? NT : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) wreg[b][q] = *reinterpret_cast<const f4*>(wrow + 16 * q * kp + 16 * b);
+        __syncthreads();                             // (the strips overwrite the weights)
+    }
     // lane (m, g) holds C[row0 + m][16q + 4g .. + 3].  A strip's results are stored one iteration late, right before the
     // loads of the strip after next are issued: loads and stores retire through one in-order counter, so a wave that
     // stored at the end of an iteration would sit out the store acknowledgement (~2.5 us) before touching its prefetch.
@@ -431,31 +481,39 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         } else {
 #pragma unroll
             for (int j = 0; j < NLC; ++j) {
-                if (j * 64 + lane < cnt2) {
-                    float2 c = reinterpret_cast<const float2*>(Cl)[j * 64 + lane];
+                const int i2 = tail_idx2(j, lane);
+                if (i2 < cnt2) {
+                    float2 c = reinterpret_cast<const float2*>(Cl)[i2];
                     if constexpr (MIX) {
-                        const int cc = (2 * (j * 64 + lane)) % n;
+                        const int cc = (2 * (i2)) % n;
                         auto af = [&](float v) { return p.act_kind == 1 ? fmaxf(v, 0.f) : (p.act_kind == 2 ? (v > 0.f ? v : v * p.act_slope) : v); };
                         const float v0 = c.x + Cb[cc], v1 = c.y + Cb[cc + 1];
                         float2 o = make_float2(af(v0), af(v1));
                         if (p.add1) o = make_float2(o.x + pe1[j].x, o.y + pe1[j].y);
-                        reinterpret_cast<float2*>(p.out2 + out_strip * kStrip * n)[j * 64 + lane] = o;
+                        reinterpret_cast<float2*>(p.out2 + out_strip * kStrip * n)[i2] = o;
                         if (p.zmask_out) {
-                            p.zmask_out[out_strip * (kStrip / 2) * n + j * 64 + lane] = (unsigned char)((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u));
+                            p.zmask_out[out_strip * (kStrip / 2) * n + i2] = (unsigned char)((v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u));
                             continue;
                         }
                     } else if constexpr (ADD) {
                         c = make_float2(pe1[j].x + c.x, pe1[j].y + c.y);
                         if (p.add2) c = make_float2(c.x + pe2[j].x, c.y + pe2[j].y);
                     }
-                    if constexpr (EXPAND) st_stream(reinterpret_cast<float2*>(dst) + (j * 64 + lane), c);
-                    else reinterpret_cast<float2*>(dst)[j * 64 + lane] = c;
+                    if constexpr (EXPAND) st_stream(reinterpret_cast<float2*>(dst) + (i2), c);
+                    else reinterpret_cast<float2*>(dst)[i2] = c;
                 }
             }
         }
     };
     // kAddPlain: the epilogue's two extra operands of strip `s_` in store_out's indexing (loaded one iteration ahead of their use)
     auto load_adds = [&](int64_t s_) {
+#ifndef DGN_STRIP_GLOBAL_LOADS
+        if constexpr (BNB) { load_strip<NLC>(pe1, p.bnb_y, p.M, n, s_, lane); return; }      // BatchNorm's input rows of strip s_
+        if constexpr (ADD) {
+            load_strip<NLC>(pe1, p.add1, p.M, n, s_, lane, p.add1 != nullptr);
+            load_strip<NLC>(pe2, p.add2, p.M, n, s_, lane, p.add2 != nullptr);
+        }
+#else
         if constexpr (BNB) {                          // BatchNorm's input rows of strip s_, float4 number q in pe1[2 jq], pe1[2 jq + 1] (also on the partial last strip)
             const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
             const float* b1 = p.bnb_y + s_ * kStrip * n;
@@ -495,6 +553,7 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
                 }
             }
         }
+#endif
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
         if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
@@ -507,15 +566,18 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
         if (COMBINE && lane < 16)
             *reinterpret_cast<f4*>(Fl + (it & 1) * (kStrip * 4) + 4 * lane) = f4{p.sc ? fac[0] : 1.f, p.sc ? fac[1] : 1.f, p.sc ? fac[2] : 1.f, p.rs ? fac[3] : 1.f};
         if (BNB && lane < 16) Fl[(it & 1) * (kStrip * 4) + 4 * lane + 3] = p.rs ? fac[3] : 1.f;
+#ifndef DGN_EXP_NO_STORE
         if (out_strip >= 0) store_out();
+#endif
         load_adds(strip);
+#ifndef DGN_EXP_NO_FETCH
         if (strip + step < n_strips) fetch(strip + step);
+#endif
 
         f4 acc[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] = *reinterpret_cast<const f4*>(Bl + 16 * q + 4 * g);
-#pragma unroll 1
-        for (int b = 0; b < KB; ++b) {               // 16-k blocks: lane group g takes k = 16b + 4g + s in the s-th MFMA
+        auto load_x = [&](int b) {                   // 16-k blocks: lane group g takes k = 16b + 4g + s in the s-th MFMA
             f4 xv;
             if (k4) {
                 xv = *reinterpret_cast<const f4*>(xrow + 16 * b);
@@ -527,18 +589,35 @@ __global__ __launch_bounds__(linear_threads(NT, KB, MODE)) void ts_linear(LinPar
 #pragma unroll
                 for (int s = 0; s < 4; ++s) xv[s] = 16 * b + 4 * g + s < k ? xv[s] : 0.f;
             }
-            f4 wv[NT];
-#pragma unroll
-            for (int q = 0; q < NT; ++q) wv[q] = *reinterpret_cast<const f4*>(wrow + 16 * q * kp + 16 * b);
+            return xv;
+        };
 #ifdef DGN_EXP_MFMA_QUARTER
-            constexpr int SN = 1;                    // (what-if ablation: a quarter of the MFMA work, wrong results)
+        constexpr int SN = 1;                        // (what-if ablation: a quarter of the MFMA work, wrong results)
 #else
-            constexpr int SN = 4;
+        constexpr int SN = 4;
 #endif
+        if constexpr (WREG) {
+            f4 xq[KB];
 #pragma unroll
-            for (int s = 0; s < SN; ++s)             // s outer: consecutive MFMAs on one accumulator would wait for each other
+            for (int b = 0; b < KB; ++b) xq[b] = load_x(b);
 #pragma unroll
-                for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], xv[s], acc[q], 0, 0, 0);
+            for (int b = 0; b < KB; ++b)
+#pragma unroll
+                for (int s = 0; s < SN; ++s)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b][q][s], xq[b][s], acc[q], 0, 0, 0);
+        } else {
+#pragma unroll 1
+            for (int b = 0; b < KB; ++b) {
+                const f4 xv = load_x(b);
+                f4 wv[NT];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) wv[q] = *reinterpret_cast<const f4*>(wrow + 16 * q * kp + 16 * b);
+#pragma unroll
+                for (int s = 0; s < SN; ++s)         // s outer: consecutive MFMAs on one accumulator would wait for each other
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], xv[s], acc[q], 0, 0, 0);
+            }
         }
         float* c = Cl + m * n + 4 * g;
 #pragma unroll
@@ -760,6 +839,19 @@ hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStr
                   (MODE == kActMaskBnb && !linear_bnb_shape_ok(NT, KB))) {
         return hipErrorInvalidValue;
     } else {
+    if constexpr (linear_wreg_ok(NT, KB, MODE)) {
+        if (p.wreg) {
+            static bool attr_w = false;
+            if (!attr_w) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB, MODE, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+                if (e != hipSuccess) return e;
+                attr_w = true;
+            }
+            hipLaunchKernelGGL((ts_linear<NT, KB, MODE, true>), dim3(p.T * p.groups), dim3(threads), lds, st, p);
+            return hipGetLastError();
+        }
+    }
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ts_linear<NT, KB, MODE>),
