@@ -46,7 +46,7 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bnbm ? 5 * NT * 16 : (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0)))) * 4;
     const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
     int waves = linear_threads(NT, KB, mode) / 64;
-    p.wreg = (p.ex.gy || p.S > 0) && !bnbm && linear_wreg_ok(NT, KB, p.ex.gy ? kExpand : kCombine) && option(OPT_LIN_WREG) ? 1 : 0;
+    p.wreg = (p.ex.gy || p.S > 0) && !bnbm && linear_wreg_ok(NT, KB, p.ex.gy ? kExpand : kCombine) && (option(OPT_LIN_WREG) & (p.ex.gy ? 2 : 1)) ? 1 : 0;      // (bit 0: combine epilogue, bit 1: expanded operand)
     if (p.wreg) waves = std::min(waves, 4);
     while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
     const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
