@@ -48,13 +48,13 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     int waves = linear_threads(NT, KB, mode) / 64;
     p.wreg = (p.ex.gy || p.S > 0) && !bnbm && linear_wreg_ok(NT, KB, p.ex.gy ? kExpand : kCombine) && (option(OPT_LIN_WREG) & (p.ex.gy ? 2 : 1)) ? 1 : 0;      // (bit 0: combine epilogue, bit 1: expanded operand)
     if (p.wreg) waves = std::min(waves, 4);
-    while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves /= 2;
+    while (waves > 1 && w_bytes + waves * strip_bytes > (size_t)kLdsBudget) waves = waves == 12 ? 8 : waves / 2;
     const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
     {   // Small batches: 2 970 rows are 186 strips -- twelve 16-wave workgroups on twelve of 256 CUs.  Fewer waves per workgroup until
         // the strips cover the chip (every workgroup stages the weights itself: 20 KB from L2).
         static const bool keep = getenv("DGN_LINEAR_NO_SMALL") != nullptr;
         const int min_waves = (int)option(OPT_LINEAR_SMALL_MIN_WAVES);           // (4: no gain, 2 and 1: slower -- the weights are staged by too few threads)
-        while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves /= 2;
+        while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves = waves == 12 ? 8 : waves / 2;
     }
     const size_t wl_bytes = (size_t)NT * 16 * p.kp * 4;
     const size_t lds = p.wreg ? w_bytes - wl_bytes + std::max(wl_bytes, waves * strip_bytes) : w_bytes + waves * strip_bytes;

@@ -81,7 +81,10 @@ struct LinParams {
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
 constexpr int linear_extra_regs(int KB, int mode) { return mode == 3 ? 12 : (mode == 4 ? 4 * KB + 12 : (mode == 7 ? 2 * KB + 28 : (mode == 8 ? 2 * KB + 28 + 64 : (mode == 5 || mode == 6 ? 64 : 0)))); }    // kBnPlain: column state; kActPlain: a second prefetched strip
-constexpr int linear_threads(int NT, int KB, int mode = 0) { return 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode) <= 116 ? 1024 : 512; }
+constexpr int linear_threads(int NT, int KB, int mode = 0) {
+    const int est = 8 * NT + 4 * KB + 52 + linear_extra_regs(KB, mode);
+    return est <= 116 ? 1024 : (mode == 6 && est <= 180 && NT <= 5 ? 768 : 512);      // (kMixFwd at hidden 65 .. 80: 157 registers, three waves per SIMD)
+}
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
 // A strip is 16 * k consecutive floats of A (rows are dense: lda == k) starting at a multiple of 64 bytes: it is copied with
@@ -276,7 +279,12 @@ enum { kPlain = 0, kCombine = 1, kExpand = 2, kBnPlain = 3, kActPlain = 4, kAddP
 // the strip products read NT + 1 operands per 4 NT MFMAs (posttrans of the towers: one per 3).  With WREG: one per 4 NT.  Costs the
 // registers of 4 NT KB floats: 512 threads per workgroup (256 registers per lane), shapes up to kWregTiles tiles.
 constexpr int kWregTiles = 18;
-constexpr bool linear_wreg_ok(int NT, int KB, int MODE) { return (MODE == 1 || MODE == 2) && NT * KB <= kWregTiles && NT * KB >= 6; }
+// (12 .. 18 tiles; the shapes below need more than the 168 registers of three waves per SIMD -- the build refuses scratch)
+constexpr bool linear_wreg_ok(int NT, int KB, int MODE) {
+    if (!(MODE == 1 || MODE == 2) || NT * KB > kWregTiles || NT * KB < 12) return false;
+    if (MODE == 1) return !(NT == 2 && KB == 9);
+    return !((NT == 2 && KB >= 8) || (NT == 3 && KB == 6) || (NT == 9 && KB == 2));
+}
 template <int NT, int KB, int MODE, bool WREG = false>
 __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3 : 1) void ts_linear(LinParams p) {
     constexpr bool COMBINE = MODE == kCombine, EXPAND = MODE == kExpand, MIX = MODE == kMixFwd, BNP = MODE == kBnPlain || MIX, ACT = MODE == kActPlain;
