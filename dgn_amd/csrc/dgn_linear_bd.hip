@@ -187,32 +187,8 @@ __global__ __launch_bounds__(bd_bwd_threads(T, (FI + 15) / 16)) void bd_backward
     const bool has1 = p.add1 != nullptr, has2 = p.add2 != nullptr;
     float2 pe1[NLC], pe2[NLC];
     auto load_adds = [&](int64_t s_) {               // (an absent operand reads zeros and is not used)
-#ifndef DGN_STRIP_GLOBAL_LOADS
         load_strip<NLC>(pe1, p.add1, p.M, n, s_, lane, has1);
         load_strip<NLC>(pe2, p.add2, p.M, n, s_, lane, has2);
-#else
-        const int rows = (int)min((int64_t)kStrip, p.M - s_ * kStrip);
-        const float* b1 = (has1 ? p.add1 : p.C) + s_ * kStrip * n;
-        const float* b2 = (has2 ? p.add2 : (has1 ? p.add1 : p.C)) + s_ * kStrip * n;
-        if (rows == kStrip) {
-            const int last4 = (kStrip / 4) * n - 1;
-#pragma unroll
-            for (int jq = 0; jq < NLC / 2; ++jq) {
-                const int q = min(jq * 64 + lane, last4);
-                const float4 u = reinterpret_cast<const float4*>(b1)[q], v = reinterpret_cast<const float4*>(b2)[q];
-                pe1[2 * jq] = make_float2(u.x, u.y); pe1[2 * jq + 1] = make_float2(u.z, u.w);
-                pe2[2 * jq] = make_float2(v.x, v.y); pe2[2 * jq + 1] = make_float2(v.z, v.w);
-            }
-        } else {
-            const int last2 = rows * (n >> 1) - 1;
-#pragma unroll
-            for (int j = 0; j < NLC; ++j) {
-                const int q = min(j * 64 + lane, last2);
-                pe1[j] = reinterpret_cast<const float2*>(b1)[q];
-                pe2[j] = reinterpret_cast<const float2*>(b2)[q];
-            }
-        }
-#endif
     };
     int64_t out_strip = -1;
     auto store_out = [&]() {

@@ -88,16 +88,10 @@ constexpr int linear_threads(int NT, int KB, int mode = 0) {
 __host__ __device__ inline int strip_floats(int k) { return kStrip * k + 16; }     // + slack read by the last row's last block
 
 // A strip is 16 * k consecutive floats of A (rows are dense: lda == k) starting at a multiple of 64 bytes: it is copied with
-// 16-byte lanes, float4 number q = jq * 64 + lane living in pre[2 jq], pre[2 jq + 1] (NL = 2 KB is even).  The batch's last,
-// partial strip is read in 8-byte pieces with clamped indices instead (a 16-byte lane could reach past the tensor).
+// 16-byte lanes, float4 number q = jq * 64 + lane living in pre[2 jq], pre[2 jq + 1] (NL = 2 KB is even); the batch's last,
+// partial strip has the same layout, the lanes past its rows hold zeros.
 __device__ __forceinline__ int strip_idx2(int j, int lane) { return 2 * ((j >> 1) * 64 + lane) + (j & 1); }   // float2 number held by pre[j]
-// float2 number of a result strip that a lane's j-th epilogue register (pe1[j] / pe2[j]) belongs to on the batch's partial last strip: with
-// buffer loads the partial strip has the full strip's register layout (float4 number jq * 64 + lane in registers 2 jq, 2 jq + 1)
-#ifdef DGN_STRIP_GLOBAL_LOADS
-__device__ __forceinline__ int tail_idx2(int j, int lane) { return j * 64 + lane; }
-#else
-__device__ __forceinline__ int tail_idx2(int j, int lane) { return strip_idx2(j, lane); }
-#endif
+__device__ __forceinline__ int tail_idx2(int j, int lane) { return strip_idx2(j, lane); }                      // (the epilogue registers pe1[j] / pe2[j] likewise)
 // Round 6: the strip is read with BUFFER loads (one V# per strip: base = the strip's first row, num_records = its valid bytes) -- lanes past
 // the strip's end, and past the tensor's end on the batch's last, partial strip, read zeros by the range check (checked per dword), so the
 // loop has ONE load shape.  With global loads the full strip's 16-byte lanes and the partial strip's clamped 8-byte lanes were two branches
@@ -113,23 +107,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const float* base, 
 }
 template <int NL>
 __device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane, bool present = true) {      // (!present: an absent operand, all lanes read zeros)
-#ifdef DGN_STRIP_GLOBAL_LOADS
-    const int64_t row0 = strip * kStrip;
-    const float* base = A + row0 * k;                                             // wave-uniform
-    const int n2 = (int)min((int64_t)kStrip, M - row0) * (k >> 1);               // float2's that exist
-    if (n2 == kStrip * (k >> 1)) {
-        const int last4 = (kStrip / 4) * k - 1;                                    // 16 k floats = 4 k float4
-#pragma unroll
-        for (int jq = 0; jq < NL / 2; ++jq) {
-            const float4 v = reinterpret_cast<const float4*>(base)[min(jq * 64 + lane, last4)];
-            pre[2 * jq] = make_float2(v.x, v.y);
-            pre[2 * jq + 1] = make_float2(v.z, v.w);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) pre[j] = reinterpret_cast<const float2*>(base)[min(strip_idx2(j, lane), n2 - 1)];
-    }
-#else
     const int64_t row0 = strip * kStrip;
     const float* base = uniform_ptr(A + row0 * k);
     const int rows = __builtin_amdgcn_readfirstlane((int)min((int64_t)kStrip, M - row0));
@@ -140,7 +117,6 @@ __device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, in
         pre[2 * jq] = make_float2(v[0], v[1]);
         pre[2 * jq + 1] = make_float2(v[2], v[3]);
     }
-#endif
 }
 template <int NL>
 __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], int k, int lane) {
@@ -396,14 +372,17 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
     int it = 0, out_it = 0;
     float2 pe1[ADD ? NLC : 1], pe2[ADD ? NLC : 1];
     const int mix_c4 = (4 * lane) % n, mix_d4 = 256 % n;       // kMixFwd: column of the lane's float4 number lane (+ 64 jq) of a result strip
-    // kActMaskBnb: where the two halves of the lane's float4 number jq * 64 + lane of a result strip lie -- row | column << 4 | tower << 12
-    // | column inside the tower << 16 -- the same for every strip (a strip is 16 whole rows)
+    // kActMaskBnb: the epilogue walks a result strip TOWER-MAJOR, as the output lies in memory: float2 number i2 = j * 64 + lane is pair
+    // (i2 % fo2) of row (i2 / fo2) % 16 of tower i2 / (8 fo) -- a store instruction covers 512 contiguous bytes of a tower's [N][fo] plane
+    // instead of nine 56-byte pieces of it (the strip's own row-major order).  bnb_at[j] = row | column << 4 | tower << 12 | column inside
+    // the tower << 16, the same for every strip; BatchNorm's input rows are loaded in the same order (8-byte lanes of the strip's V#).
     unsigned bnb_at[BNB ? NLC : 1];
     if constexpr (BNB) {
+        const int fo2 = p.fo >> 1, per_t = kStrip * fo2;
 #pragma unroll
         for (int j = 0; j < NLC; ++j) {
-            const int flat = 4 * ((j >> 1) * 64 + lane) + 2 * (j & 1);
-            const int r = flat / n, cc = flat - r * n, t = cc / p.fo, o = cc - t * p.fo;
+            const int i2 = min(j * 64 + lane, kStrip * (n >> 1) - 1);
+            const int t = i2 / per_t, rem = i2 - t * per_t, r = rem / fo2, o = 2 * (rem - r * fo2), cc = t * p.fo + o;
             bnb_at[j] = (unsigned)(r & 15) | ((unsigned)cc << 4) | ((unsigned)t << 12) | ((unsigned)o << 16);
         }
     }
@@ -414,30 +393,25 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
             const float* F = Fl + (out_it & 1) * (kStrip * 4);
             constexpr int T16 = NT * 16;
 #pragma unroll
-            for (int jq = 0; jq < NLC / 2; ++jq) {
-                if (jq * 64 + lane < (kStrip / 4) * n) {
-                    const float4 c = reinterpret_cast<const float4*>(Cl)[jq * 64 + lane];
+            for (int j = 0; j < NLC; ++j) {
+                const unsigned at = bnb_at[j];
+                const int r = at & 15, cc = (at >> 4) & 255, t = (at >> 12) & 15, o = at >> 16;
+                const float2 c = *reinterpret_cast<const float2*>(Cl + r * n + cc);
+                const float2 yv = pe1[j];
+                const float rs = F[4 * r + 3];
+                float out[2];
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const unsigned at = bnb_at[2 * jq + hf];
-                        const int r = at & 15, cc = (at >> 4) & 255, t = (at >> 12) & 15, o = at >> 16;
-                        const float2 yv = pe1[2 * jq + hf];
-                        const float rs = F[4 * r + 3];
-                        float out[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int ce = cc + e;
-                            const float is = Bn[T16 + ce], ga = Bn[2 * T16 + ce];
-                            const float xh = ((e ? yv.y : yv.x) - Bn[ce]) * is;
-                            float g = e ? (hf ? c.w : c.y) : (hf ? c.z : c.x);
-                            g = ga * is * (g - Bn[3 * T16 + ce] - xh * Bn[4 * T16 + ce]);
-                            if (p.rs) g *= rs;
-                            out[e] = g;
-                        }
-                        if (r < rows_valid)
-                            *reinterpret_cast<float2*>(p.bnb_gz + (int64_t)t * p.bnb_sT + (row0 + r) * p.fo + o) = make_float2(out[0], out[1]);
-                    }
+                for (int e = 0; e < 2; ++e) {
+                    const int ce = cc + e;
+                    const float is = Bn[T16 + ce], ga = Bn[2 * T16 + ce];
+                    const float xh = ((e ? yv.y : yv.x) - Bn[ce]) * is;
+                    float g = e ? c.y : c.x;
+                    g = ga * is * (g - Bn[3 * T16 + ce] - xh * Bn[4 * T16 + ce]);
+                    if (p.rs) g *= rs;
+                    out[e] = g;
                 }
+                if (j * 64 + lane < kStrip * (n >> 1) && r < rows_valid)
+                    *reinterpret_cast<float2*>(p.bnb_gz + (int64_t)t * p.bnb_sT + (row0 + r) * p.fo + o) = make_float2(out[0], out[1]);
             }
             return;
         }
@@ -515,53 +489,22 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
     };
     // kAddPlain: the epilogue's two extra operands of strip `s_` in store_out's indexing (loaded one iteration ahead of their use)
     auto load_adds = [&](int64_t s_) {
-#ifndef DGN_STRIP_GLOBAL_LOADS
-        if constexpr (BNB) { load_strip<NLC>(pe1, p.bnb_y, p.M, n, s_, lane); return; }      // BatchNorm's input rows of strip s_
-        if constexpr (ADD) {
-            load_strip<NLC>(pe1, p.add1, p.M, n, s_, lane, p.add1 != nullptr);
-            load_strip<NLC>(pe2, p.add2, p.M, n, s_, lane, p.add2 != nullptr);
-        }
-#else
-        if constexpr (BNB) {                          // BatchNorm's input rows of strip s_, float4 number q in pe1[2 jq], pe1[2 jq + 1] (also on the partial last strip)
-            const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
-            const float* b1 = p.bnb_y + s_ * kStrip * n;
-            if (cnt2 == kStrip * (n >> 1)) {
-                const int last4 = (kStrip / 4) * n - 1;
+        if constexpr (BNB) {                          // BatchNorm's input rows of strip s_, in the epilogue's tower-major order
+            const int64_t row0 = s_ * kStrip;
+            const int rows = __builtin_amdgcn_readfirstlane((int)min((int64_t)kStrip, p.M - row0));
+            const __amdgpu_buffer_rsrc_t ry = strip_rsrc(uniform_ptr(p.bnb_y + row0 * n), rows * n * 4);
 #pragma unroll
-                for (int jq = 0; jq < NLC / 2; ++jq) {
-                    const float4 u = reinterpret_cast<const float4*>(b1)[min(jq * 64 + lane, last4)];
-                    pe1[2 * jq] = make_float2(u.x, u.y); pe1[2 * jq + 1] = make_float2(u.z, u.w);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NLC; ++j) pe1[j] = reinterpret_cast<const float2*>(b1)[min(2 * ((j >> 1) * 64 + lane) + (j & 1), cnt2 - 1)];
+            for (int j = 0; j < NLC; ++j) {
+                const unsigned at = bnb_at[j];
+                const unsigned long long v = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(ry, (int)(((at & 15) * n + ((at >> 4) & 255)) * 4), 0, 0));
+                pe1[j] = make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
             }
             return;
         }
         if constexpr (ADD) {
-            const int cnt2 = (int)min((int64_t)kStrip, p.M - s_ * kStrip) * (n >> 1);
-            const float* any = MIX ? p.out2 : C;                                      // (kMixFwd with a mask output has no C)
-            const float* b1 = (p.add1 ? p.add1 : any) + s_ * kStrip * n;             // (branch-free loads; a NULL operand is not used)
-            const float* b2 = (p.add2 ? p.add2 : (p.add1 ? p.add1 : any)) + s_ * kStrip * n;
-            if (cnt2 == kStrip * (n >> 1)) {
-                const int last4 = (kStrip / 4) * n - 1;
-#pragma unroll
-                for (int jq = 0; jq < NLC / 2; ++jq) {
-                    const int q = min(jq * 64 + lane, last4);
-                    const float4 u = reinterpret_cast<const float4*>(b1)[q], v = reinterpret_cast<const float4*>(b2)[q];
-                    pe1[2 * jq] = make_float2(u.x, u.y); pe1[2 * jq + 1] = make_float2(u.z, u.w);
-                    pe2[2 * jq] = make_float2(v.x, v.y); pe2[2 * jq + 1] = make_float2(v.z, v.w);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NLC; ++j) {
-                    const int q = min(j * 64 + lane, cnt2 - 1);
-                    pe1[j] = reinterpret_cast<const float2*>(b1)[q];
-                    pe2[j] = reinterpret_cast<const float2*>(b2)[q];
-                }
-            }
+            load_strip<NLC>(pe1, p.add1, p.M, n, s_, lane, p.add1 != nullptr);
+            load_strip<NLC>(pe2, p.add2, p.M, n, s_, lane, p.add2 != nullptr);
         }
-#endif
     };
     for (int64_t strip = first; strip < n_strips; strip += step) {
         if constexpr (EXPAND) store_expand<NL>(Xl, Fl, pre, fac, p.ex, kStrip, lane);
@@ -838,7 +781,7 @@ static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T
 // kActPlain holds two prefetched strips: the widest tile shapes would not fit the registers and are not instantiated
 constexpr bool linear_act_shape_ok(int NT, int KB) { return 4 * NT + 8 * KB <= 104; }
 constexpr bool linear_add_shape_ok(int NT, int KB) { return 16 * NT + 4 * KB <= 128; }      // (kAddPlain: two result-shaped strips per wave in registers)
-constexpr bool linear_bnb_shape_ok(int NT, int KB) { return NT <= 5 && KB <= 7; }              // (kActMaskBnb: the unrolled epilogue; wider shapes spill)
+constexpr bool linear_bnb_shape_ok(int NT, int KB) { return NT <= 5 && KB <= 7 && NT + KB <= 11; }              // (kActMaskBnb: the unrolled epilogue; wider shapes spill)
 
 template <int NT, int KB, int MODE>
 hipError_t launch_linear_nkm(const LinParams& p, int threads, size_t lds, hipStream_t st) {
