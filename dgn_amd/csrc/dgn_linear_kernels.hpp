@@ -105,6 +105,15 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const float* base, int bytes) {      // (wave-uniform arguments)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
 }
+// The S <= 3 scale factors of row row0 + (lane & 15) in ONE 12-byte buffer load (they were three dword loads): the V# covers the strip's rows of
+// the [M][S] table, so for S < 3 the extra components are the next row's factors (never used) and past the strip / the table they read
+// zero.  sc == NULL: zeros (not used either).
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f3v load_row_scales(const float* sc, int S, int64_t M, int64_t row0, int lane) {
+    const int rows = __builtin_amdgcn_readfirstlane((int)min((int64_t)kStrip, M - row0));
+    const __amdgpu_buffer_rsrc_t rs = strip_rsrc(uniform_ptr(sc + row0 * S), sc ? rows * S * 4 : 0);
+    return __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(rs, (lane & 15) * S * 4, 0, 0));
+}
 template <int NL>
 __device__ __forceinline__ void load_strip(float2 (&pre)[NL], const float* A, int64_t M, int k, int64_t strip, int lane, bool present = true) {      // (!present: an absent operand, all lanes read zeros)
     const int64_t row0 = strip * kStrip;
@@ -133,14 +142,15 @@ __device__ __forceinline__ void store_strip(float* Xl, const float2 (&pre)[NL], 
 // loads past the run repeat its last element (one cache line).
 template <int NL>
 __device__ __forceinline__ void load_expand(float2 (&pre)[NL], f4& fac, const ExpandSrc& e, int t, int64_t M, int64_t strip, int lane) {
-    const int64_t row0 = strip * kStrip;
-    const float2* base = reinterpret_cast<const float2*>(e.gy + t * e.sT + row0 * e.fo);        // wave-uniform; 16 * fo contiguous floats
-    const int last = (int)min((int64_t)kStrip, M - row0) * (e.fo >> 1) - 1;
+    // the tower's 16 * fo contiguous floats as 16-byte buffer lanes: float4 number jq * 64 + lane in pre[2 jq], pre[2 jq + 1] (S >= 2: the run is at
+    // most half the expanded width, NLE / 2 = ceil(NL / 4) lanes-of-64 cover it); rows past the batch's end read zeros
+    constexpr int NLE = 2 * ((NL + 3) / 4);
+    float2 run[NLE];
+    load_strip<NLE>(run, e.gy + t * e.sT, M, e.fo, strip, lane);
 #pragma unroll
-    for (int j = 0; j < (NL + 1) / 2; ++j) pre[j] = base[min(j * 64 + lane, last)];     // S >= 2: the run is at most half the expanded width
-    const int64_t row = min(row0 + (lane & 15), M - 1);
-    const float* scp = e.sc ? e.sc + row * e.S : e.gy;       // (branch-free; without a table the values are dummies: store_expand puts 1)
-    fac = f4{scp[0], scp[min(1, e.S - 1)], scp[min(2, e.S - 1)], 0.f};
+    for (int j = 0; j < NLE; ++j) pre[j] = run[j];
+    const f3v s3 = load_row_scales(e.sc, e.S, M, strip * kStrip, lane);       // (without a table the values are dummies: store_expand puts 1)
+    fac = f4{s3[0], s3[1], s3[2], 0.f};
 }
 // Xl: [16][S*fo]; Fl: 16 x f4 scratch of this wave.  Rows >= rows_valid become zero.
 template <int NL>
@@ -148,9 +158,10 @@ __device__ __forceinline__ void store_expand(float* Xl, float* Fl, const float2 
                                              int rows_valid, int lane) {
     if (lane < 16) *reinterpret_cast<f4*>(Fl + 4 * lane) = e.sc ? fac : f4{1.f, 1.f, 1.f, 0.f};
     const int fo2 = e.fo >> 1, width = e.S * e.fo;
+    constexpr int NLE = 2 * ((NL + 3) / 4);
 #pragma unroll
-    for (int j = 0; j < (NL + 1) / 2; ++j) {
-        const int idx = j * 64 + lane, r = idx / fo2, o2 = idx - r * fo2;
+    for (int j = 0; j < NLE; ++j) {
+        const int idx = strip_idx2(j, lane), r = idx / fo2, o2 = idx - r * fo2;
         if (idx < kStrip * fo2) {
             const f4 f = *reinterpret_cast<const f4*>(Fl + 4 * r);
             const float2 v = r < rows_valid ? pre[j] : make_float2(0.f, 0.f);
@@ -298,9 +309,9 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
         }
         if constexpr (!COMBINE) return;
         const int64_t row = min(strip * kStrip + (lane & 15), p.M - 1);
-        const float* scp = p.sc ? p.sc + row * S1 : A;               // (absent factors: dummy loads, replaced by 1 where `fac` is consumed)
+        const f3v s3 = load_row_scales(p.sc, S1, p.M, strip * kStrip, lane);          // (absent factors: dummy loads, replaced by 1 where `fac` is consumed)
         const float* rsp = p.rs ? p.rs + row : A;
-        fac = f4{scp[0], scp[min(1, S1 - 1)], scp[min(2, S1 - 1)], *rsp};
+        fac = f4{s3[0], s3[1], s3[2], *rsp};
     };
     float2 prez[ACT ? NL : 1];
     unsigned mz[ACTM ? NL / 2 : 1];
