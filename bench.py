@@ -1129,11 +1129,11 @@ def run_extras(args, dev):
     """Short runs of the other BASELINE configs appended to the default single-GPU line (driver-verifiable)."""
     extra = {}
     # default: the BASELINE five (c2 is the headline); everything else behind --all-extras (VERDICT r03 item 1)
-    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c1", 10, 3), ("c3", 50, 10), ("c4", 10, 3), ("c5", 3, 1),
+    plan = [("c2_b128", 200, 30), ("zinc_json_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c1", 50, 20), ("c3", 100, 30), ("c4", 50, 20), ("c5", 3, 1),
             ("c5_layer", 3, 1)]      # (row f1 on the driver line: the C5 graph through a whole simple layer forward)
     if args.all_extras:
-        plan = [("c1", 10, 3), ("c3", 10, 3), ("c3_drop", 10, 3), ("c4", 10, 3), ("c4_drop", 10, 3), ("c2c", 10, 3), ("c2e", 10, 3), ("c2et", 10, 3), ("zinc_json", 10, 3),
-                ("pattern_json", 20, 5), ("c3_mega", 10, 3), ("c4_mega", 10, 3), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c4_b128", 200, 30),
+        plan = [("c1", 50, 20), ("c3", 100, 30), ("c3_drop", 50, 20), ("c4", 50, 20), ("c4_drop", 50, 20), ("c2c", 50, 20), ("c2e", 50, 20), ("c2et", 50, 20), ("zinc_json", 50, 20),
+                ("pattern_json", 50, 20), ("c3_mega", 30, 10), ("c4_mega", 30, 10), ("zinc_json_b128", 200, 30), ("c2_b128", 200, 30), ("c1_b128", 200, 30), ("hiv_json_b128", 200, 30), ("c4_b128", 200, 30),
                 ("c5", 3, 1), ("c5_layer", 3, 1)]
     for name, steps, warmup in plan:
         wl = dict(WORKLOADS[name])
@@ -1339,7 +1339,7 @@ def run_dp_extras(args, rank, world, dev, line):
             a2 = copy.copy(args)
             a2.scaling = mode
             try:
-                r2 = run_layer_workload(a2, dict(WORKLOADS["c4"]), rank, world, dev, steps=20, warmup=5, tag="c4")
+                r2 = run_layer_workload(a2, dict(WORKLOADS["c4"]), rank, world, dev, steps=50, warmup=20, tag="c4")
                 r2 = r2[0] if isinstance(r2, tuple) else r2
                 dp_extra[f"c4_dp_{mode}"] = dict(ms_per_step=r2["ms_per_step"], value=r2["value"], scaling=r2["scaling"],
                                                  edges_per_rank=r2["edges_per_rank"], nodes_per_rank=r2["nodes_per_rank"],
@@ -1356,8 +1356,10 @@ def run_dp_extras(args, rank, world, dev, line):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: the device needs ~30 steps after the set-up's idle time to reach its steady clocks (tools/step_ramp.py, profiles/r06_step_ramp.txt:
+    # steps 6-25 average 1.5-2 % above steps 26+), so the default run warms up for 30 steps and times 100 (0.17 s of device time)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="layer workloads with --gpus > 1: 'weak' = every rank its own batch (default), 'strong' = one global "
