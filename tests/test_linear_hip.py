@@ -48,6 +48,26 @@ def test_linear_matches_fp64(T, M, k, n, bias):
         _close(br.grad, gb64)
 
 
+@pytest.mark.parametrize("M,k,n", [(100, 70, 70), (33, 6, 10), (17, 42, 84)])
+def test_operands_at_8_byte_alignment(M, k, n):
+    """Row views whose first element is only 8-byte aligned (the strips are read with 16-byte buffer lanes from the strip's own base):
+    forward, input gradient and weight gradient against fp64."""
+    from dgn_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xs = torch.randn(M + 1, k, device="cuda", generator=g)
+    gs = torch.randn(M + 1, n, device="cuda", generator=g)
+    x, gy = xs[1:], gs[1:]                              # storage offsets of k / n floats: k = 70, 6, 42 -> 8 bytes past a 16-byte boundary
+    assert x.data_ptr() % 16 == 8 and x.is_contiguous()
+    w = torch.randn(n, k, device="cuda", generator=g) / k ** 0.5
+    xr, wr = x.detach().requires_grad_(True), w.clone().requires_grad_(True)
+    y = ops.linear(xr, wr, None)
+    y.backward(gy)
+    y64, gx64, gw64, _ = _ref64(x.unsqueeze(0), w.unsqueeze(0), None, gy.unsqueeze(0))
+    _close(y, y64[0])
+    _close(xr.grad, gx64[0])
+    _close(wr.grad, gw64[0])
+
+
 def test_linear_2d_equals_torch_and_is_reproducible():
     import torch.nn.functional as F
     from dgn_amd import ops
