@@ -64,6 +64,7 @@ const OptDef kOpts[OPT_COUNT] = {
     {"mix_bwd_fused", "DGN_MIX_BWD_FUSED", 1, false},            // towers layer backward: mixing weight gradient straight from g_out + mask, BatchNorm's backward in the input-gradient product's epilogue (0: round 5's sequence)
     {"blk_lds_pad_kb", "DGN_BLK_LDS_PAD_KB", 0, false},          // experiments: unused LDS added to agg_bwd_block's allocation (fewer resident waves per CU: the occupancy what-if of profiles/NOTES.md)
     {"lin_wreg", "DGN_LIN_WREG", 3, false},                     // streaming posttrans products up to 18 tiles with the weights register-resident, 12 waves per CU: bit 0 the combine-epilogue product, bit 1 the expanded-operand product (0: weights re-read from LDS per strip, 16 waves)
+    {"bd_bwd_fused", "DGN_BD_BWD_FUSED", 1, false},             // towers layer backward: the block-diagonal pretrans product's input gradient and weight gradient in one pass over d(P|Q) (0: two kernels)
 };
 std::atomic<int64_t> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;

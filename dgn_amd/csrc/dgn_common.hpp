@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...);
 // Library options (dgn_set_option / dgn_get_option of the C ABI): process-wide switches the tests and experiments flip.  Each is
 // initialised ONCE from its environment variable when the library first looks (no getenv on any launch path) and changed only through
 // the setter.  -1 = "auto" where the library has a rule of its own.
-enum Opt { OPT_BLK_LDS_KB, OPT_BLK_MIN_NODES, OPT_BWD_ROWS_PER_WAVE, OPT_TILE_GEMM, OPT_TILE_WGRAD, OPT_NO_ZMASK, OPT_LINEAR_SMALL_MIN_WAVES, OPT_GRAPH_BWD_TILES, OPT_ODD_DIRECT, OPT_BN_FROM_WGRAD, OPT_MIX_BWD_FUSED, OPT_BLK_LDS_PAD_KB, OPT_LIN_WREG, OPT_COUNT };
+enum Opt { OPT_BLK_LDS_KB, OPT_BLK_MIN_NODES, OPT_BWD_ROWS_PER_WAVE, OPT_TILE_GEMM, OPT_TILE_WGRAD, OPT_NO_ZMASK, OPT_LINEAR_SMALL_MIN_WAVES, OPT_GRAPH_BWD_TILES, OPT_ODD_DIRECT, OPT_BN_FROM_WGRAD, OPT_MIX_BWD_FUSED, OPT_BLK_LDS_PAD_KB, OPT_LIN_WREG, OPT_BD_BWD_FUSED, OPT_COUNT };
 int64_t option(Opt o);
 int hip_fail(hipError_t e, const char* what);
 int zero_rows_async(float* p, int64_t rows, int64_t width, int64_t ld, hipStream_t stream);   // capture-safe zero fill (dgn_abi.hip)
@@ -27,6 +27,13 @@ int zero_rows_async(float* p, int64_t rows, int64_t width, int64_t ld, hipStream
 int scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* g_y, int64_t ld_gy, const float* scale,
                                 const float* row_scale, float* g_z, float* g_bias, void* ws, size_t ws_bytes, const DgnBnGrad* bn,
                                 void* stream, int set_bias);
+
+// input gradient + weight gradient of the towers' block-diagonal pretrans product in one pass (dgn_linear_bd.hip: bd_backward_both)
+namespace lin {
+int bd_backward_both_launch(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* g, const float* w, int64_t ldw, const float* x,
+                            const float* add1, const float* add2, float* g_h, float* dw, int64_t lddw, float* dbias, void* ws, size_t ws_bytes,
+                            void* stream);
+}
 
 #define DGN_HIP_CHECK(expr)                                         \
     do {                                                            \

@@ -327,6 +327,150 @@ __global__ __launch_bounds__(256, bd_wg_waves_per_simd(T, (FI + 15) / 16)) void 
     for (int i = tid; i < NTL * 64; i += blockDim.x) reinterpret_cast<f4*>(out)[i] = reinterpret_cast<const f4*>(red)[i];
 }
 
+// Round 6: the input gradient AND the weight gradient of the block-diagonal product in ONE pass over g = d(P|Q): bd_backward_input and
+// bd_wgrad each streamed the [M][2 Fm] gradient (both run at 5-6 TB/s: nothing left inside either), together they read it once --
+// 6 Fm instead of 8 Fm floats per row.  A wave stages the g strip and the h strip, issues bd_backward_input's MFMAs (rows of g against the
+// towers' W blocks), then bd_wgrad's (g^T h over the strip's rows, the ones column for the bias gradient), and writes the input-gradient
+// rows over the dead g strip; they leave one iteration later with the two epilogue operands added.  Same arithmetic, same order of
+// accumulation per input-gradient output as bd_backward_input (bit-identical); the weight-gradient partials meet in another order than bd_wgrad's
+// (other strip ownership: fp32 rounding, reproducible); 512 threads, one workgroup per CU.
+template <int T, int FI>
+__global__ __launch_bounds__(512) void bd_backward_both(BdParams p) {
+    extern __shared__ float lds[];
+    constexpr int FB = (FI + 15) / 16, fi = FI;
+    constexpr int KP2 = 32 * FB + 4, NTL = T * FB, NLG = 4 * T * FB, NLX = 2 * T * FB, NLC = 2 * T * FB, NTW = 2 * T * FB * FB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    constexpr int n = T * fi, k2 = 2 * n;
+    float* Wl = lds;                                 // [T][FB][16][KP2] as in bd_backward_input
+    float* U = Wl + NTL * 16 * KP2 + wave * (strip_floats(k2) + strip_floats(n));      // this wave's g strip, later its input-gradient rows
+    float* Xl = U + strip_floats(k2);                // this wave's h strip
+    const int64_t n_strips = (p.M + kStrip - 1) / kStrip;
+    const int64_t first = (int64_t)blockIdx.x * n_waves + wave, step = (int64_t)p.groups * n_waves;
+    float2 pg[NLG], px[NLX];
+    if (first < n_strips) {
+        load_strip<NLG>(pg, p.A, p.M, k2, first, lane);
+        load_strip<NLX>(px, p.X, p.M, n, first, lane);
+    }
+    for (int i = tid; i < NTL * 16 * KP2; i += blockDim.x) lds[i] = 0.f;
+    for (int i = lane; i < strip_floats(k2) + strip_floats(n); i += 64) U[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < 2 * T * fi * fi; i += blockDim.x) {
+        const int c = i % fi, r = (i / fi) % fi, tj = i / (fi * fi), t = tj >> 1, j = tj & 1;
+        Wl[((t * FB + (c >> 4)) * 16 + (c & 15)) * KP2 + j * 16 * FB + r] = p.W[(int64_t)(j * n + t * fi + r) * p.ldw + t * fi + c];
+    }
+    __syncthreads();
+
+    const int m = lane & 15, g = lane >> 4;           // (the weight gradient's (i16, mq) are the same two numbers)
+    const bool has1 = p.add1 != nullptr, has2 = p.add2 != nullptr;
+    float2 pe1[NLC], pe2[NLC];
+    f4 accw[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) accw[q] = f4{0.f, 0.f, 0.f, 0.f};
+    int64_t out_strip = -1;
+    auto store_out = [&]() {
+        const int rows = (int)min((int64_t)kStrip, p.M - out_strip * kStrip);
+        if (has1) bd_store_out<NLC, true>(U, p.C + out_strip * kStrip * n, n, rows, lane, pe1, pe2, has2);
+        else {
+            const float2 none[1] = {};
+            bd_store_out<NLC, false>(U, p.C + out_strip * kStrip * n, n, rows, lane, none, none, false);
+        }
+    };
+    for (int64_t strip = first; strip < n_strips; strip += step) {
+        if (out_strip >= 0) store_out();
+        store_strip<NLG>(U, pg, k2, lane);           // (rows past the batch's end were read as zeros)
+        store_strip<NLX>(Xl, px, n, lane);
+        load_strip<NLC>(pe1, p.add1, p.M, n, strip, lane, has1);
+        load_strip<NLC>(pe2, p.add2, p.M, n, strip, lane, has2);
+        if (strip + step < n_strips) {
+            load_strip<NLG>(pg, p.A, p.M, k2, strip + step, lane);
+            load_strip<NLX>(px, p.X, p.M, n, strip + step, lane);
+        }
+        // ---- input gradient: bd_backward_input's product
+        f4 acc[NTL];
+#pragma unroll
+        for (int q = 0; q < NTL; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+        const float* xrow = U + m * k2 + 4 * g;
+        f4 xn = bd_operand(xrow, fi - 4 * g), wn[FB];
+#pragma unroll
+        for (int q = 0; q < FB; ++q) wn[q] = *reinterpret_cast<const f4*>(Wl + (q * 16 + m) * KP2 + 4 * g);
+#pragma unroll
+        for (int u = 0; u < T * 2 * FB; ++u) {
+            const int t = u / (2 * FB);
+            const f4 xv = xn;
+            f4 wv[FB];
+#pragma unroll
+            for (int q = 0; q < FB; ++q) wv[q] = wn[q];
+            if (u + 1 < T * 2 * FB) {
+                const int t1 = (u + 1) / (2 * FB), j1 = ((u + 1) / FB) % 2, b1 = (u + 1) % FB;
+                xn = bd_operand(xrow + j1 * n + t1 * fi + 16 * b1, fi - 16 * b1 - 4 * g);
+#pragma unroll
+                for (int q = 0; q < FB; ++q) wn[q] = *reinterpret_cast<const f4*>(Wl + ((t1 * FB + q) * 16 + m) * KP2 + j1 * 16 * FB + 16 * b1 + 4 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < FB; ++q)
+                    acc[t * FB + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][s], xv[s], acc[t * FB + q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- weight gradient: bd_wgrad's product over the same two strips
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* grow = U + (4 * g + s) * k2 + m;
+            const float* xr = Xl + (4 * g + s) * n + m;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float xv[FB], gv[2 * FB];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    xv[b] = xr[t * fi + 16 * b];
+                    if (16 * b + m == fi) xv[b] = 1.f;                             // column f_in of the tile := 1: dW[:, f_in] = sum_m g[m, :]
+                }
+#pragma unroll
+                for (int ja = 0; ja < 2 * FB; ++ja) gv[ja] = grow[(ja / FB) * n + t * fi + 16 * (ja % FB)];
+#pragma unroll
+                for (int ja = 0; ja < 2 * FB; ++ja)
+#pragma unroll
+                    for (int b = 0; b < FB; ++b)
+                        accw[(t * 2 * FB + ja) * FB + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[ja], xv[b], accw[(t * 2 * FB + ja) * FB + b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the input-gradient rows over the (now dead) g strip
+        float* c = U + m * n + 4 * g;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int q = 0; q < FB; ++q) {
+                const f4 v = acc[t * FB + q];
+                const int col = 16 * q + 4 * g;
+                float* d = c + t * fi + 16 * q;
+                if (col < fi) *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+                if (col + 2 < fi) *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+            }
+        out_strip = strip;
+    }
+    if (out_strip >= 0) store_out();
+    // the workgroup's waves add their weight-gradient tiles up in LDS in wave order (bd_wgrad's epilogue)
+    __syncthreads();
+    float* red = lds;                                // [NTW][16][16]
+    for (int w = 0; w < n_waves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* d = red + q * 256 + (4 * g + r) * 16 + m;
+                    *d = w == 0 ? accw[q][r] : *d + accw[q][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = p.part + (int64_t)blockIdx.x * NTW * 256;
+    for (int i = tid; i < NTW * 64; i += blockDim.x) reinterpret_cast<f4*>(out)[i] = reinterpret_cast<const f4*>(red)[i];
+}
+
 // dW (dense [2 Fm][lddw]: diagonal blocks = the slot sums in a fixed order, everything else zero) and dbias [2 Fm]
 static __global__ __launch_bounds__(64 * kFinWaves) void bd_wgrad_finalize(int T, int fi, int FB, int slots, const float* __restrict__ part,
                                                                            float* __restrict__ dW, int64_t lddw, float* __restrict__ dbias) {
@@ -396,7 +540,7 @@ hipError_t bd_set_lds(K kernel) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
 }
 
-enum { kBdFwd = 0, kBdBwd = 1, kBdWg = 2 };
+enum { kBdFwd = 0, kBdBwd = 1, kBdWg = 2, kBdBoth = 3 };
 
 template <int T, int FI>
 hipError_t bd_launch_one(int which, const BdParams& p, int threads, size_t lds, hipStream_t st) {
@@ -406,11 +550,16 @@ hipError_t bd_launch_one(int which, const BdParams& p, int threads, size_t lds, 
         hipError_t e = bd_set_lds(&bd_forward<T, FI>);
         if (e == hipSuccess) e = bd_set_lds(&bd_backward_input<T, FI>);
         if (e == hipSuccess) e = bd_set_lds(&bd_wgrad<T, FI>);
+        if constexpr (FI <= 16) { if (e == hipSuccess) e = bd_set_lds(&bd_backward_both<T, FI>); }      // (two 16-column blocks per tower: 2 x the accumulators, spills)
         if (e != hipSuccess) return e;
         attr = true;
     }
     if (which == kBdFwd) hipLaunchKernelGGL((bd_forward<T, FI>), dim3(p.groups), dim3(threads), lds, st, p);
     else if (which == kBdBwd) hipLaunchKernelGGL((bd_backward_input<T, FI>), dim3(p.groups), dim3(threads), lds, st, p);
+    else if (which == kBdBoth) {
+        if constexpr (FI <= 16) hipLaunchKernelGGL((bd_backward_both<T, FI>), dim3(p.groups), dim3(threads), lds, st, p);
+        else return hipErrorInvalidValue;
+    }
     else hipLaunchKernelGGL((bd_wgrad<T, FI>), dim3(p.groups), dim3(256), lds, st, p);
     return hipGetLastError();
 }
@@ -521,3 +670,44 @@ extern "C" int dgn_linear_bd_wgrad(int64_t n_rows, int32_t n_towers, int32_t f_i
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
 }
+
+
+// Input gradient + weight gradient (+ bias gradient) of the block-diagonal product in one pass (bd_backward_both): the arguments of
+// dgn_linear_bd_backward_input and dgn_linear_bd_wgrad together, the workspace of dgn_linear_bd_wgrad_workspace_bytes().  Library-internal
+// (dgn_towers_layer_backward, option bd_bwd_fused); returns DGN_ERR_INVALID where the pair of calls has to be used instead.
+namespace dgn {
+namespace lin {
+int bd_backward_both_launch(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* g, const float* w, int64_t ldw, const float* x,
+                            const float* add1, const float* add2, float* g_h, float* dw, int64_t lddw, float* dbias, void* ws, size_t ws_bytes,
+                            void* stream) {
+    const char* fn = "bd_backward_both";
+    const int FB = bd_blocks(n_towers, f_in);
+    const int Fm = n_towers * f_in;
+    if (n_rows <= 0 || FB != 1 || !g || !w || !x || !g_h || !dw || !al16(g) || !al16(x) || !al16(g_h) || (add1 && !al16(add1)) || (add2 && !al16(add2)) ||
+        (add2 && !add1) || ldw < Fm || lddw < Fm) {
+        set_error("%s: unsupported shape or operand", fn);
+        return DGN_ERR_INVALID;
+    }
+    const size_t need = dgn_linear_bd_wgrad_workspace_bytes(n_rows, n_towers, f_in);
+    if (!ws || ws_bytes < need) { set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, need); return DGN_ERR_WORKSPACE; }
+    const int ntw = 2 * n_towers * FB * FB;
+    const size_t w_floats = (size_t)n_towers * FB * 16 * (32 * FB + 4), wave_floats = (size_t)strip_floats(2 * Fm) + strip_floats(Fm);
+    int waves = 8;
+    while (waves > 1 && (w_floats + waves * wave_floats) * 4 > (size_t)kLdsBudget) waves /= 2;
+    const size_t lds = std::max((w_floats + waves * wave_floats) * 4, (size_t)ntw * 256 * 4);
+    if (lds > (size_t)kLdsBudget) { set_error("%s: operands do not fit in LDS", fn); return DGN_ERR_INVALID; }
+    const int64_t n_strips = (n_rows + kStrip - 1) / kStrip;
+    BdParams p{};
+    p.M = n_rows; p.T = n_towers; p.fi = f_in; p.A = g; p.X = x; p.W = w; p.ldw = ldw; p.C = g_h; p.add1 = add1; p.add2 = add2;
+    p.part = static_cast<float*>(ws);
+    p.groups = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(bd_cus(), bd_wgrad_groups(n_rows)), (n_strips + waves - 1) / waves));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DGN_HIP_CHECK(bd_launch(kBdBoth, p, waves * 64, lds, st));
+    const int64_t total = (int64_t)2 * Fm * (Fm + 1);
+    hipLaunchKernelGGL(bd_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(64 * kFinWaves), 0, st, n_towers, f_in, FB, p.groups, p.part, dw, lddw,
+                       dbias);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+}  // namespace lin
+}  // namespace dgn

@@ -365,6 +365,12 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
     const bool fused_add = !no_add_epilogue && al && (reinterpret_cast<uintptr_t>(g_in) & 15) == 0 && dgn_linear_add_supported(2 * d.Fm, d.Fm);
     if (use_bd(L, d) && al && ((reinterpret_cast<uintptr_t>(g_in) | reinterpret_cast<uintptr_t>(g_pq)) & 15) == 0) {
         // the towers' own blocks only: (d h_in + (d P|Q) W_sd) + residual in the product's epilogue, add3's order
+        if (option(OPT_BD_BWD_FUSED) && d.fi <= 16 && (reinterpret_cast<uintptr_t>(L->h) & 15) == 0) {
+            // ... and its weight gradient in the same pass over d(P|Q) (round 6: bd_backward_both)
+            DGN_TRY(lin::bd_backward_both_launch(d.N, d.T, d.fi, g_pq, L->w_sd, d.Fm, L->h, g_in, res, G->g_h, G->g_w_sd, d.Fm, G->g_bias_sd, ws + s.wg_sd,
+                                                 dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), stream));
+            return DGN_OK;
+        }
         DGN_TRY(dgn_linear_bd_backward_input(d.N, d.T, d.fi, g_pq, L->w_sd, d.Fm, g_in, res, G->g_h, stream));
         DGN_TRY(dgn_linear_bd_wgrad(d.N, d.T, d.fi, g_pq, L->h, G->g_w_sd, d.Fm, G->g_bias_sd, ws + s.wg_sd,
                                     dgn_linear_bd_wgrad_workspace_bytes(d.N, d.T, d.fi), stream));

@@ -801,6 +801,60 @@ def test_towers_backward_with_the_fused_mixing_backward_is_bitwise_the_separate_
             assert torch.equal(pa[k], pb[k]), k
 
 
+@pytest.mark.parametrize("residual,n_graphs", [(True, 200), (False, 37), (True, 1)])
+def test_towers_backward_with_the_one_pass_pretrans_backward_is_bitwise_the_two_kernels(monkeypatch, residual, n_graphs):
+    """Round 6 (csrc/dgn_linear_bd.hip bd_backward_both, option bd_bwd_fused): the block-diagonal pretrans product's input gradient and its
+    weight / bias gradient in ONE pass over d(P|Q) against bd_backward_input + bd_wgrad -- the input gradient has the same bits (same MFMAs in
+    the same order per output); the weight gradient's partial sums meet in another order (fp32 rounding), reproducibly (partial last strips
+    and a single-graph batch included)."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER_MIN_ROWS", 0)
+    b = synth.molecule_batch(n_graphs, seed=31, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    F_ = 70
+    torch.manual_seed(6)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation", {"log": torch.tensor(1.1)},
+                             "towers", residual, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    h0 = torch.randn(N, F_, device=dev, generator=gen)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    res = {}
+    used = []
+    orig = dgn_amd.dgn_layer.towers_layer
+    monkeypatch.setattr(dgn_amd.dgn_layer, "towers_layer", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+    for fused in (1, 0):
+        monkeypatch.setattr(_lib.options, "bd_bwd_fused", fused)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        res[fused] = (y.detach(), h.grad, {k: v.grad for k, v in lay.named_parameters()})
+    assert len(used) == 2, "the whole-layer entry point was not taken"
+    (ya, ga, pa), (yb, gb, pb) = res[1], res[0]
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    for k in pa:
+        if "pretrans" in k:
+            # the one-pass kernel's workgroups own other strips than bd_wgrad's: the partial sums meet in another order (fp32 rounding only)
+            scale = float(pb[k].abs().max()) + 1e-30
+            assert float((pa[k] - pb[k]).abs().max()) <= 2e-6 * scale + 1e-6, k
+        else:
+            assert torch.equal(pa[k], pb[k]), k
+    # and it is reproducible run to run (fixed strip ownership, fixed summation order)
+    monkeypatch.setattr(_lib.options, "bd_bwd_fused", 1)
+    lay = copy.deepcopy(layer).train()
+    h = h0.clone().requires_grad_(True)
+    lay(graph, h, None, snorm).backward(ct)
+    assert torch.equal(h.grad, ga)
+    for k, v in lay.named_parameters():
+        assert torch.equal(v.grad, pa[k]), k
+
+
 @pytest.mark.parametrize("aggs,T", [("mean max min dir1-av dir1-dx", 5), ("mean max min dir1-dx dir1-av", 1), ("mean max min dir1-av dir1-dx", 1)])
 @pytest.mark.parametrize("ties", [False, True])
 def test_backward_from_the_aux_table_is_bitwise_the_recomputing_backward(monkeypatch, aggs, T, ties):
