@@ -14,7 +14,7 @@ import threading
 DGN_MAX_AGG = 16
 DGN_MAX_CH = 4
 DGN_MAX_SCALERS = 4
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 LIB_PATH = os.environ.get("DGN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdgn_hip.so")
 
@@ -87,7 +87,8 @@ class DgnTowersLayer(C.Structure):
                 ("pq", C.c_void_p), ("aggx", C.c_void_p), ("y0", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("y1", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("n_valid", C.c_void_p),
                 ("zmask", C.c_void_p), ("agg_aux", C.c_void_p),
-                ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64), ("drop_mask", C.c_void_p), ("id_slot1", C.c_int32)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("drop_offset", C.c_uint64), ("drop_mask", C.c_void_p), ("id_slot1", C.c_int32),
+                ("num_batches_tracked", C.c_void_p), ("n_nbt", C.c_int32)]
 
 
 class DgnTowersGrads(C.Structure):

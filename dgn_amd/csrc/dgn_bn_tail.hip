@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const flo
 __global__ __launch_bounds__(256) void bn_finalize(int64_t n_rows, int F, int G, const double* __restrict__ part,
                                                    float* running_mean, float* running_var, float momentum, float eps,
                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                   const int64_t* __restrict__ n_valid) {
+                                                   const int64_t* __restrict__ n_valid, int64_t* nbt = nullptr, int n_nbt = 0) {
     if (n_valid) n_rows = min(n_rows, *n_valid);
     const int c = (int)blockIdx.x;
+    if (c == 0 && (int)threadIdx.x < n_nbt) nbt[threadIdx.x] += 1;       // torch's num_batches_tracked += 1 (n_nbt <= 256 modules)
     double s0, s1;
     slot_sums(part, F, G, c, s0, s1);
     if (threadIdx.x != 0) return;
@@ -506,6 +507,16 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
                                    float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                                    int32_t relu, const float* residual, float* y, float* save_mean, float* save_invstd, void* ws,
                                    size_t ws_bytes, const int64_t* n_valid, void* stream_) {
+    return dgn::bn_tail_forward_nbt(n_rows, F, x, ld, gamma, beta, running_mean, running_var, momentum, eps, training, relu, residual, y, save_mean,
+                                    save_invstd, ws, ws_bytes, n_valid, nullptr, 0, stream_);
+}
+
+// ... with the modules' num_batches_tracked counters incremented by the statistics' finalize kernel (training only; library-internal)
+int dgn::bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual, float* y,
+                             float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, const int64_t* n_valid, int64_t* nbt, int32_t n_nbt,
+                             void* stream_) {
+    if (nbt && (n_nbt < 0 || n_nbt > 256)) { set_error("dgn_bn_tail_forward: at most 256 num_batches_tracked counters"); return DGN_ERR_INVALID; }
     if (n_rows < 0 || F < 1 || F > kMaxF || ld < F) { set_error("dgn_bn_tail_forward: bad shape (need 1 <= F <= 1024, ld >= F)"); return DGN_ERR_INVALID; }
     if (n_rows == 0) return DGN_OK;
     if (!x || (!y && !training)) { set_error("dgn_bn_tail_forward: null buffer"); return DGN_ERR_INVALID; }
@@ -518,7 +529,7 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
         if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
-                           running_var, momentum, eps, save_mean, save_invstd, n_valid);
+                           running_var, momentum, eps, save_mean, save_invstd, n_valid, nbt, nbt ? n_nbt : 0);
         // y == NULL: statistics only (the consumer normalises on the fly: dgn_linear_forward_bn / dgn_linear_wgrad_bn)
         if (y) launch_bn_apply(stream, n_rows, F, x, ld, gamma, beta, save_mean, save_invstd, nullptr, nullptr, eps, relu, residual, y);
     } else {

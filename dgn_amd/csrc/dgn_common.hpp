@@ -28,8 +28,17 @@ int scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int32_t f
                                 const float* row_scale, float* g_z, float* g_bias, void* ws, size_t ws_bytes, const DgnBnGrad* bn,
                                 void* stream, int set_bias);
 
+// dgn_bn_tail_forward + the BatchNorm modules' num_batches_tracked counters (dgn_bn_tail.hip)
+int bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual, float* y,
+                        float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, const int64_t* n_valid, int64_t* nbt, int32_t n_nbt,
+                        void* stream);
+
 // input gradient + weight gradient of the towers' block-diagonal pretrans product in one pass (dgn_linear_bd.hip: bd_backward_both)
 namespace lin {
+int combine_backward_weight_bias_pick(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
+                                      int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
+                                      int64_t stride_dw, float* g_sum, float* pick, int32_t pick_slot, void* ws, size_t ws_bytes, void* stream);
 int bd_backward_both_launch(int64_t n_rows, int32_t n_towers, int32_t f_in, const float* g, const float* w, int64_t ldw, const float* x,
                             const float* add1, const float* add2, float* g_h, float* dw, int64_t lddw, float* dbias, void* ws, size_t ws_bytes,
                             void* stream);

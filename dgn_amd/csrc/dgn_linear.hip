@@ -272,7 +272,7 @@ extern "C" size_t dgn_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t k, in
 }
 
 static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, int64_t stride_dw, float* dbias, int64_t stride_dbias,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        void* ws, size_t ws_bytes, void* stream, float* pick = nullptr, int pick_off = 0, int pick_w = 0) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int n = p.n, k = p.k, batch = p.T;
     const size_t need = dgn_linear_wgrad_workspace_bytes(p.M, k, n, batch);
@@ -290,7 +290,7 @@ static int launch_wgrad(const char* fn, WgParams& p, float* dw, int64_t lddw, in
     DGN_HIP_CHECK(e);
     const int64_t total = (int64_t)batch * n * (dbias ? k + 1 : k);
     hipLaunchKernelGGL(ts_wgrad_finalize, dim3((unsigned)((total + 63) / 64)), dim3(64 * kFinWaves), 0, st, batch, n, k, p.groups,
-                       NT * 16, KT * 16, p.part, dw, lddw, stride_dw, dbias, stride_dbias);
+                       NT * 16, KT * 16, p.part, dw, lddw, stride_dw, dbias, stride_dbias, dbias ? pick : nullptr, pick_off, pick_w);
     DGN_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -404,18 +404,32 @@ extern "C" int dgn_linear_combine_backward_weight_bias(int64_t n_rows, int32_t n
                                                        const float* gy, int64_t stride_gy, const float* scale, const float* a,
                                                        int64_t stride_a, float* dw, int64_t lddw, int64_t stride_dw, float* g_sum,
                                                        void* ws, size_t ws_bytes, void* stream) {
+    return dgn::lin::combine_backward_weight_bias_pick(n_rows, n_towers, n_scalers, f_out, k, gy, stride_gy, scale, a, stride_a, dw, lddw, stride_dw, g_sum,
+                                                       nullptr, 0, ws, ws_bytes, stream);
+}
+
+// ... with scaler slot `pick_slot`'s block of the column sums also written densely to pick [T][f_out] by the finalize kernel (library-internal:
+// dgn_towers_layer_backward's d b_post)
+int dgn::lin::combine_backward_weight_bias_pick(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
+                                                int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
+                                                int64_t stride_dw, float* g_sum, float* pick, int32_t pick_slot, void* ws, size_t ws_bytes,
+                                                void* stream) {
     const char* fn = "dgn_linear_combine_backward_weight";
     if (g_sum && k % 16 == 0) { set_error("%s: the column sums ride in A's padding column (k %% 16 != 0)", fn); return -1; }
     const int n = n_scalers * f_out;
     if (!expand_ok(fn, n_rows, n_towers, n_scalers, f_out, gy, stride_gy, scale)) return -1;
     if (!dgn_linear_supported(k, n, 1)) { set_error("%s: need even widths in [2, 160] and at most 45 tiles (k=%d S*f_out=%d)", fn, k, n); return -1; }
     if (!dw) { set_error("%s: null output", fn); return -1; }
-    if (n_rows == 0) return zero_wgrad(dw, lddw, stride_dw, g_sum, n, k, n, n_towers, static_cast<hipStream_t>(stream));
+    if (n_rows == 0) {
+        if (pick && zero_rows_async(pick, 1, (int64_t)n_towers * f_out, (int64_t)n_towers * f_out, static_cast<hipStream_t>(stream))) return DGN_ERR_HIP;
+        return zero_wgrad(dw, lddw, stride_dw, g_sum, n, k, n, n_towers, static_cast<hipStream_t>(stream));
+    }
     if (!a || (stride_a & 1) || !aligned8(a)) { set_error("%s: null or misaligned operand", fn); return -1; }
     WgParams p{};
     p.M = n_rows; p.n = n; p.k = k; p.T = n_towers;
     p.X = a; p.sX = stride_a;
     if (n_scalers == 1) { p.G = gy; p.sG = stride_gy; }
     else { p.ex.gy = gy; p.ex.sT = stride_gy; p.ex.sc = scale; p.ex.S = n_scalers; p.ex.fo = f_out; }
-    return launch_wgrad(fn, p, dw, lddw, stride_dw, g_sum, n, ws, ws_bytes, stream);
+    if (pick && (!g_sum || pick_slot < 0 || pick_slot >= n_scalers)) { set_error("%s: pick needs g_sum and a scaler slot", fn); return -1; }
+    return launch_wgrad(fn, p, dw, lddw, stride_dw, g_sum, n, ws, ws_bytes, stream, pick, pick_slot * f_out, f_out);
 }

@@ -755,7 +755,10 @@ __global__ __launch_bounds__(256, wgrad_min_blocks(NT, KT, GMASK)) void ts_wgrad
 constexpr int kFinWaves = 16;
 static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T, int n, int k, int slots, int npad, int kpad,
                                                          const float* __restrict__ part, float* __restrict__ dW,
-                                                         int64_t lddw, int64_t sdW, float* __restrict__ dbias, int64_t sdb) {
+                                                         int64_t lddw, int64_t sdW, float* __restrict__ dbias, int64_t sdb,
+                                                         float* __restrict__ pick = nullptr, int pick_off = 0, int pick_w = 0) {
+    // (pick: rows [pick_off, pick_off + pick_w) of every batch entry's bias gradient also go, densely, to pick[t * pick_w + ...]: the identity
+    //  scaler's block of the expanded gradient's column sums IS the posttrans bias gradient -- no launch of its own)
     __shared__ float red[kFinWaves][64];
     const int kk = dbias ? k + 1 : k;                // with the ones column: k + 1 columns per row, the last one is the bias gradient
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -783,7 +786,10 @@ static __global__ __launch_bounds__(64 * kFinWaves) void ts_wgrad_finalize(int T
 #pragma unroll
         for (int w = 0; w < kFinWaves; ++w) v += red[w][lane];
         if (c < k) dW[(int64_t)t * sdW + (int64_t)r * lddw + c] = v;
-        else dbias[(int64_t)t * sdb + r] = v;
+        else {
+            dbias[(int64_t)t * sdb + r] = v;
+            if (pick && r >= pick_off && r < pick_off + pick_w) pick[t * pick_w + r - pick_off] = v;
+        }
     }
 }
 

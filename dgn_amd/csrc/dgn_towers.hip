@@ -82,14 +82,6 @@ __global__ __launch_bounds__(64) void mix_bn_finalize(int Fo, const float* __res
     }
 }
 
-// out[t * w + o] = in[t * ld + off + o]: the identity scaler's block of the column sums = d b_post (one tiny launch, capture-safe)
-__global__ __launch_bounds__(256) void pick_block(int T, int w, int ld, int off, const float* __restrict__ in, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * w) return;
-    const int t = i / w, o = i - t * w;
-    out[i] = in[t * ld + off + o];
-}
-
 struct Dims {
     int64_t N;
     int T, fi, fo, S, Fm, Fo, K;
@@ -203,8 +195,8 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
     // (y1 == NULL: statistics only -- the mixing Linear normalises y0 while it stages its strips, the normalised tensor is never written)
-    DGN_TRY(dgn_bn_tail_forward(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
-                                nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, stream));
+    DGN_TRY(bn_tail_forward_nbt(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
+                                nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, L->num_batches_tracked, L->n_nbt, stream));
     // the towers' dropout, on the normalised rows in place                                   (:275)
     if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_forward(d.N * d.Fo, L->y1, L->drop_p, L->drop_seed, L->drop_offset, L->y1, L->drop_mask, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)
@@ -339,14 +331,10 @@ extern "C" int dgn_towers_layer_backward(const DgnTowersLayer* L, const DgnTower
                                               g_aggx, d.N * d.K, stream));
     // (mix_fused: the column sums of the expanded gradient ride in the pass -- the identity scaler's block of them is d b_post)
     float* g_sum = mix_fused ? f(s.g_sum) : nullptr;
-    DGN_TRY(dgn_linear_combine_backward_weight_bias(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
-                                                    (int64_t)d.S * d.fo * d.K, g_sum, ws + s.wg_post,
-                                                    dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
-    if (mix_fused) {
-        hipLaunchKernelGGL(pick_block, dim3((unsigned)((d.Fo + 255) / 256)), dim3(256), 0, st, d.T, d.fo, d.S * d.fo, (L->id_slot1 - 1) * d.fo, (const float*)g_sum,
-                           G->g_b_post);
-        DGN_HIP_CHECK(hipGetLastError());
-    }
+    // (... and the finalize kernel writes that block to g_b_post: no launch of its own)
+    DGN_TRY(lin::combine_backward_weight_bias_pick(d.N, d.T, d.S, d.fo, d.K, g_yr, d.N * d.fo, L->scale, L->aggx, d.N * d.K, G->g_w_post, d.K,
+                                                   (int64_t)d.S * d.fo * d.K, g_sum, mix_fused ? G->g_b_post : nullptr, mix_fused ? L->id_slot1 - 1 : 0,
+                                                   ws + s.wg_post, dgn_linear_wgrad_workspace_bytes(d.N, d.K, d.S * d.fo, d.T), stream));
     // the sweep: d P | d Q in one [N, 2 Fm] buffer, d h_in
     const DgnMsg msg = sweep_msg(L, d);
     DgnMsgGrad gr{};

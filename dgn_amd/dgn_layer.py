@@ -767,7 +767,9 @@ class DGNLayerTower(nn.Module):
                 cache[key] = (names, shapes, pos, sel, flat_ids.numel(), [math.prod(shp) for shp in shapes], native)
         names, shapes, pos, sel, total, sizes, native = cache[key]
         if native is not None and all(p.is_cuda and p.is_contiguous() for p in plist):
-            fused = _ops.assemble_operands(native, plist)
+            native.setdefault("op_sizes", sizes)
+            native.setdefault("op_shapes", shapes)
+            return dict(zip(names, _ops.assemble_operands(native, plist)))
         else:
             flat = torch.cat([p.reshape(-1) for p in plist])
             fused = flat.new_zeros(total).index_put((pos,), flat.index_select(0, sel))

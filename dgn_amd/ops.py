@@ -1069,7 +1069,7 @@ def _carve_ptrs(sizes, device, buf=None):
 
 class _TowersLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var,
+    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var, nbt,
                 w_sd, bias_sd, w_post, b_post, gamma, beta, w_mix, b_mix):
         lib = _lib.load()
         global LAST_DROPOUT_MASK
@@ -1106,6 +1106,8 @@ class _TowersLayer(torch.autograd.Function):
         L.pq, L.aggx, L.y0, L.y1 = pq.data_ptr(), aggx.data_ptr(), y0.data_ptr(), (y1.data_ptr() if n_y1 else None)
         L.z, L.zmask = (None, z.data_ptr()) if use_mask else (z.data_ptr(), None)
         L.save_mean, L.save_invstd, L.out = mean.data_ptr(), invstd.data_ptr(), out.data_ptr()
+        if nbt is not None:                              # (the counters ride in the statistics' finalize kernel: ABI 28)
+            L.num_batches_tracked, L.n_nbt = nbt.data_ptr(), nbt.numel()
         drop_mask = None
         if drop is not None:
             drop_mask = torch.empty(lib.dgn_dropout_mask_bytes(N * Fo), dtype=torch.uint8, device=dev)
@@ -1168,14 +1170,19 @@ class _TowersLayer(torch.autograd.Function):
         L.ws, L.ws_bytes = ws.data_ptr(), nbytes
         L.n_valid = _ptr(ctx.n_valid)
         g_h = torch.empty((N, Fm), dtype=torch.float32, device=dev)
-        _, (g_w_sd, g_bias_sd, g_w_post, g_b_post, g_gamma, g_beta, g_w_mix, g_b_mix) = _carve(
-            [2 * Fm * Fm, 2 * Fm, T * S * fo * K, Fo, Fo, Fo, Fo * Fo, Fo], dev)
+        # the six operand gradients back to back (no padding) in the order of DGNLayerTower._assemble's flat operand buffer: _AssembleOperands.backward
+        # finds them adjacent and gathers the parameter gradients out of this buffer without a concatenation
+        n_ops = [2 * Fm * Fm, 2 * Fm, Fo, Fo, Fo, T * S * fo * K]
+        n_flat = (sum(n_ops) + 63) & ~63
+        gbuf = torch.empty(n_flat + ((Fo * Fo + 63) & ~63) + Fo, dtype=torch.float32, device=dev)
+        g_w_sd, g_bias_sd, g_b_post, g_gamma, g_beta, g_w_post = gbuf[:sum(n_ops)].split(n_ops)
+        g_w_mix, g_b_mix = gbuf[n_flat:n_flat + Fo * Fo], gbuf[n_flat + ((Fo * Fo + 63) & ~63):]
         G = _lib.DgnTowersGrads(g_out=g_out.data_ptr(), g_h=g_h.data_ptr(), g_w_sd=g_w_sd.data_ptr(), g_bias_sd=g_bias_sd.data_ptr(),
                                 g_w_post=g_w_post.data_ptr(), g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(),
                                 g_beta=g_beta.data_ptr(), g_w_mix=g_w_mix.data_ptr(), g_b_mix=g_b_mix.data_ptr())
         stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_towers_layer_backward(C.byref(L), C.byref(G), stream), "dgn_towers_layer_backward")
-        return (None, None, None, None, None, g_h, None, None, None, None, g_w_sd.view(2 * Fm, Fm), g_bias_sd, g_w_post.view(T, S * fo, K),
+        return (None, None, None, None, None, g_h, None, None, None, None, None, g_w_sd.view(2 * Fm, Fm), g_bias_sd, g_w_post.view(T, S * fo, K),
                 g_b_post, g_gamma, g_beta, g_w_mix.view(Fo, Fo), g_b_mix)
 
 
@@ -1194,12 +1201,13 @@ def towers_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snor
         scale = scale.contiguous()
     drop = None if dropout is None else (float(dropout[0]), dropout[1], int(dropout[2]))
     cfg = (n_towers, f_in, f_out, S, bool(residual), float(momentum), float(eps), float(slope), drop, (0 if S == 1 else id_slot))
-    out = _TowersLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, running_mean, running_var,
-                             w_sd, bias_sd, w_post.contiguous(), b_post, gamma, beta, w_mix, b_mix)
-    if num_batches_tracked is not None:
+    nbt = num_batches_tracked
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64 and nbt.is_contiguous() and nbt.numel() <= 256):
         with torch.no_grad():
-            num_batches_tracked.add_(1)
-    return out
+            nbt.add_(1)
+        nbt = None
+    return _TowersLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, running_mean, running_var, nbt,
+                              w_sd, bias_sd, w_post.contiguous(), b_post, gamma, beta, w_mix, b_mix)
 
 
 # ---- the whole simple / complex layer as ONE autograd node over two C calls (dgn_layers.hip) ----------------------------------------
@@ -1838,14 +1846,32 @@ class _AssembleOperands(torch.autograd.Function):
         _lib.check(lib.dgn_assemble_params(maps["total"], maps["ptr_table"].data_ptr(), maps["map_param"].data_ptr(), maps["map_off"].data_ptr(),
                                            out.data_ptr(), stream), "dgn_assemble_params")
         ctx.maps = maps
-        return out
+        # the operands leave as views of the one buffer (no split node: its backward would concatenate the operand gradients -- a launch
+        # and a copy -- where the whole-layer backward already writes them back to back, see backward)
+        return tuple(part.view(shp) for part, shp in zip(out.split(maps["op_sizes"]), maps["op_shapes"]))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         maps = ctx.maps
-        g_flat = g.contiguous().index_select(0, maps["inv"])
+        sizes, total = maps["op_sizes"], maps["total"]
+        flat = None
+        if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 for g in gs):
+            # _TowersLayer.backward carves the operand gradients out of one buffer in this very order: use it as the flat gradient
+            st, at = gs[0].untyped_storage(), gs[0].data_ptr()
+            for g, n in zip(gs, sizes):
+                if g.data_ptr() != at or g.untyped_storage().data_ptr() != st.data_ptr():
+                    st = None
+                    break
+                at += 4 * n
+            if st is not None and (gs[0].storage_offset() + total) * 4 <= st.nbytes():
+                flat = torch.empty(0, dtype=torch.float32, device=gs[0].device).set_(st, gs[0].storage_offset(), (total,))
+        if flat is None:
+            dev = next(g.device for g in gs if g is not None)
+            flat = torch.cat([(g.reshape(-1) if g is not None else torch.zeros(n, dtype=torch.float32, device=dev)) for g, n in zip(gs, sizes)])
+        g_flat = flat.index_select(0, maps["inv"])
         return (None,) + tuple(part.view(shp) for part, shp in zip(g_flat.split(maps["sizes"]), maps["shapes"]))
 
 
-def assemble_operands(maps, params) -> torch.Tensor:
+def assemble_operands(maps, params):
+    """the operand tensors (views of one buffer, in the order of maps["op_sizes"] / maps["op_shapes"])"""
     return _AssembleOperands.apply(maps, *params)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DGN_ABI_VERSION 27
+#define DGN_ABI_VERSION 28
 
 #define DGN_MAX_AGG 16     /* aggregators per launch (the host splits longer lists)            */
 #define DGN_MAX_CH 4       /* edge-weight channels per launch                                   */
@@ -576,6 +576,11 @@ typedef struct DgnTowersLayer {
      * posttrans' bias gradient from the weight-gradient pass (dgn_linear_combine_backward_weight_bias) and BatchNorm's backward rides in
      * the mixing network's input-gradient product (dgn_linear_forward_act_mask_bnb).                                                */
     int32_t id_slot1;
+    /* Round 6 (ABI 28): the BatchNorm modules' num_batches_tracked counters (n_nbt of them, DEVICE memory; torch's
+     * `num_batches_tracked += 1` of a training-mode forward, torch/nn/modules/batchnorm.py) -- each is incremented by the forward's
+     * statistics kernel instead of by a launch of the caller's.  NULL / 0: not touched.                                            */
+    int64_t* num_batches_tracked;
+    int32_t n_nbt;
 } DgnTowersLayer;
 typedef struct DgnTowersGrads {
     const float* g_out;        /* [N, T*f_out]                                                              */
