@@ -65,6 +65,7 @@ const OptDef kOpts[OPT_COUNT] = {
     {"blk_lds_pad_kb", "DGN_BLK_LDS_PAD_KB", 0, false},          // experiments: unused LDS added to agg_bwd_block's allocation (fewer resident waves per CU: the occupancy what-if of profiles/NOTES.md)
     {"lin_wreg", "DGN_LIN_WREG", 3, false},                     // streaming posttrans products up to 18 tiles with the weights register-resident, 12 waves per CU: bit 0 the combine-epilogue product, bit 1 the expanded-operand product (0: weights re-read from LDS per strip, 16 waves)
     {"bd_bwd_fused", "DGN_BD_BWD_FUSED", 1, false},             // towers layer backward: the block-diagonal pretrans product's input gradient and weight gradient in one pass over d(P|Q) (0: two kernels)
+    {"bn_stats_fused", "DGN_BN_STATS_FUSED", 1, false},         // towers layer forward: BatchNorm's column sums ride in the posttrans product's combine epilogue (fp64 LDS cells; 0: bn_stats, a pass of its own over y0)
 };
 std::atomic<int64_t> g_opt[OPT_COUNT];
 std::once_flag g_opt_once;

@@ -511,6 +511,18 @@ extern "C" int dgn_bn_tail_forward(int64_t n_rows, int32_t F, const float* x, in
                                     save_invstd, ws, ws_bytes, n_valid, nullptr, 0, stream_);
 }
 
+int dgn::bn_finalize_launch(int64_t n_rows, int32_t F, int32_t G, const double* part, float* running_mean, float* running_var, float momentum, float eps,
+                            float* save_mean, float* save_invstd, int64_t* nbt, int32_t n_nbt, void* stream_) {
+    if (n_rows <= 0 || F < 1 || F > kMaxF || G < 1 || !part || !save_mean || !save_invstd || (nbt && (n_nbt < 0 || n_nbt > 256))) {
+        set_error("bn_finalize_launch: bad argument");
+        return DGN_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, static_cast<hipStream_t>(stream_), n_rows, F, G, part, running_mean, running_var, momentum, eps,
+                       save_mean, save_invstd, (const int64_t*)nullptr, nbt, nbt ? n_nbt : 0);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
 // ... with the modules' num_batches_tracked counters incremented by the statistics' finalize kernel (training only; library-internal)
 int dgn::bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual, float* y,

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...);
 // Library options (dgn_set_option / dgn_get_option of the C ABI): process-wide switches the tests and experiments flip.  Each is
 // initialised ONCE from its environment variable when the library first looks (no getenv on any launch path) and changed only through
 // the setter.  -1 = "auto" where the library has a rule of its own.
-enum Opt { OPT_BLK_LDS_KB, OPT_BLK_MIN_NODES, OPT_BWD_ROWS_PER_WAVE, OPT_TILE_GEMM, OPT_TILE_WGRAD, OPT_NO_ZMASK, OPT_LINEAR_SMALL_MIN_WAVES, OPT_GRAPH_BWD_TILES, OPT_ODD_DIRECT, OPT_BN_FROM_WGRAD, OPT_MIX_BWD_FUSED, OPT_BLK_LDS_PAD_KB, OPT_LIN_WREG, OPT_BD_BWD_FUSED, OPT_COUNT };
+enum Opt { OPT_BLK_LDS_KB, OPT_BLK_MIN_NODES, OPT_BWD_ROWS_PER_WAVE, OPT_TILE_GEMM, OPT_TILE_WGRAD, OPT_NO_ZMASK, OPT_LINEAR_SMALL_MIN_WAVES, OPT_GRAPH_BWD_TILES, OPT_ODD_DIRECT, OPT_BN_FROM_WGRAD, OPT_MIX_BWD_FUSED, OPT_BLK_LDS_PAD_KB, OPT_LIN_WREG, OPT_BD_BWD_FUSED, OPT_BN_STATS_FUSED, OPT_COUNT };
 int64_t option(Opt o);
 int hip_fail(hipError_t e, const char* what);
 int zero_rows_async(float* p, int64_t rows, int64_t width, int64_t ld, hipStream_t stream);   // capture-safe zero fill (dgn_abi.hip)
@@ -34,8 +34,19 @@ int bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, c
                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, const int64_t* n_valid, int64_t* nbt, int32_t n_nbt,
                         void* stream);
 
+// BatchNorm's finalize kernel alone (mean / invstd / running statistics / counters from G slots of column partials laid out as bn_stats
+// leaves them: part[(q F + c) G + g]) -- for a producer that computed the partials itself (lin::combine_forward_stats)
+int bn_finalize_launch(int64_t n_rows, int32_t F, int32_t G, const double* part, float* running_mean, float* running_var, float momentum, float eps,
+                       float* save_mean, float* save_invstd, int64_t* nbt, int32_t n_nbt, void* stream);
+
 // input gradient + weight gradient of the towers' block-diagonal pretrans product in one pass (dgn_linear_bd.hip: bd_backward_both)
 namespace lin {
+// dgn_linear_combine_forward with BatchNorm's column partials of y riding in the epilogue (LinParams.bn_part); *groups = the number of slots
+// written.  DGN_ERR_UNSUPPORTED-like return 1 (nothing launched, no error set) where the shape has no such instance: the caller runs the two passes.
+size_t combine_forward_stats_bytes(int32_t n_towers, int32_t f_out);
+int combine_forward_stats(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* a, int64_t stride_a,
+                          const float* w, int64_t ldw, int64_t stride_w, const float* scale, const float* bias, const float* row_scale, float* y,
+                          int64_t ld_y, double* part, size_t part_bytes, int* groups, void* stream);
 int combine_backward_weight_bias_pick(int64_t n_rows, int32_t n_towers, int32_t n_scalers, int32_t f_out, int32_t k, const float* gy,
                                       int64_t stride_gy, const float* scale, const float* a, int64_t stride_a, float* dw, int64_t lddw,
                                       int64_t stride_dw, float* g_sum, float* pick, int32_t pick_slot, void* ws, size_t ws_bytes, void* stream);
@@ -100,6 +111,11 @@ __device__ __forceinline__ void stv(float* p, const float (&d)[VEC]) {
 // (compile time) turns them into plain stores.
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 typedef float nt_f2 __attribute__((ext_vector_type(2)));
+// fire-and-forget fp64 add to an LDS cell (ds_add_f64: no register for a result, nothing to wait for)
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void st_stream(float4* p, const float4& v) {
 #ifdef DGN_NO_NT_STORES
     *p = v;

@@ -44,7 +44,9 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
     const bool mixm = p.out2 != nullptr, maskm = p.act_mask != nullptr, bnbm = p.bnb_gz != nullptr;
     const int mode = bnbm ? kActMaskBnb : (mixm ? kMixFwd : (bn ? kBnPlain : (actm ? kActPlain : (maskm ? kActMask : (addm ? kAddPlain : kPlain)))));
     const size_t w_bytes = ((size_t)NT * 16 * p.kp + 2 * NT * 16 + (bnbm ? 5 * NT * 16 : (bn ? 4 * KB * 16 : (actm ? KB * 16 : 0)))) * 4;
-    const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4;
+    // (LinParams.bn_part: 4 fp64 cells per lane and epilogue trip, per wave, behind everything else)
+    const size_t stat_bytes = p.bn_part ? (size_t)4 * ((kStrip * (p.fo >> 1) + 63) / 64) * 64 * sizeof(double) : 0;
+    const size_t strip_bytes = ((size_t)strip_floats(p.k) + kStrip * p.n + kFacFloats) * 4 + stat_bytes;
     int waves = linear_threads(NT, KB, mode) / 64;
     p.wreg = (p.ex.gy || p.S > 0) && !bnbm && linear_wreg_ok(NT, KB, p.ex.gy ? kExpand : kCombine) && (option(OPT_LIN_WREG) & (p.ex.gy ? 2 : 1)) ? 1 : 0;      // (bit 0: combine epilogue, bit 1: expanded operand)
     if (p.wreg) waves = std::min(waves, 4);
@@ -57,7 +59,12 @@ static int launch_linear(const char* fn, LinParams& p, void* stream) {
         while (!keep && waves > min_waves && n_strips * p.T < (int64_t)n_cus() * waves) waves = waves == 12 ? 8 : waves / 2;
     }
     const size_t wl_bytes = (size_t)NT * 16 * p.kp * 4;
-    const size_t lds = p.wreg ? w_bytes - wl_bytes + std::max(wl_bytes, waves * strip_bytes) : w_bytes + waves * strip_bytes;
+    size_t lds = p.wreg ? w_bytes - wl_bytes + std::max(wl_bytes, waves * (strip_bytes - stat_bytes)) : w_bytes + waves * (strip_bytes - stat_bytes);
+    if (p.bn_part) {
+        lds = (lds + 7) & ~(size_t)7;
+        p.st_off = (int)(lds / 4);
+        lds += waves * stat_bytes;
+    }
     if (lds > (size_t)kLdsBudget) { set_error("%s: weights do not fit in LDS", fn); return -1; }
     const int per_cu = std::max(1, std::min({(int)(kLdsBudget / lds), 32 / waves, p.wreg ? 3 : 32}));      // (WREG: 3 waves per SIMD by registers)
     int groups = std::max(1, n_cus() * per_cu / p.T);
@@ -256,6 +263,30 @@ extern "C" int dgn_linear_combine_forward(int64_t n_rows, int32_t k, int32_t n_t
     p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = 0;
     p.S = n_scalers; p.fo = f_out; p.sc = scale; p.rs = row_scale; p.cb = bias; p.Y = y; p.ldy = ld_y;
     return launch_linear(fn, p, stream);
+}
+
+size_t dgn::lin::combine_forward_stats_bytes(int32_t n_towers, int32_t f_out) {
+    return (size_t)2 * n_towers * f_out * std::max(1, n_cus() * 32) * sizeof(double);       // (groups * T <= CUs x the most workgroups a CU holds)
+}
+
+int dgn::lin::combine_forward_stats(int64_t n_rows, int32_t k, int32_t n_towers, int32_t n_scalers, int32_t f_out, const float* a, int64_t stride_a,
+                                    const float* w, int64_t ldw, int64_t stride_w, const float* scale, const float* bias, const float* row_scale,
+                                    float* y, int64_t ld_y, double* part, size_t part_bytes, int* groups, void* stream) {
+    const char* fn = "combine_forward_stats";
+    const int n = n_scalers * f_out;
+    if (n_rows <= 0 || n_towers < 1 || n_scalers < 1 || n_scalers > 3 || f_out < 2 || (f_out & 1) || !dgn_linear_supported(k, n, 0) || kStrip * (f_out >> 1) > 256 ||
+        !a || !w || !y || (n_scalers > 1 && !scale) || (ld_y & 1) || !aligned8(y) || (stride_a & 1) || !aligned8(a) || ld_y != (int64_t)n_towers * f_out || !part ||
+        part_bytes < combine_forward_stats_bytes(n_towers, f_out))
+        return 1;
+    LinParams p{};
+    p.M = n_rows; p.k = k; p.n = n; p.T = n_towers;
+    p.A = a; p.sA = stride_a;
+    p.W = w; p.ldw = ldw; p.sW = stride_w; p.w_kn = 0;
+    p.S = n_scalers; p.fo = f_out; p.sc = scale; p.rs = row_scale; p.cb = bias; p.Y = y; p.ldy = ld_y;
+    p.bn_part = part; p.bn_F = n_towers * f_out;
+    const int rc = launch_linear(fn, p, stream);
+    if (rc == 0) *groups = p.groups;
+    return rc;
 }
 
 static int wgrad_groups(int64_t n_rows, int32_t k, int32_t n, int32_t batch) {

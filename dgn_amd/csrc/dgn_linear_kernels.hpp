@@ -77,6 +77,11 @@ struct LinParams {
     // sums (sum g_y1, sum g_y1 xhat); `rs` (may be NULL) and `fo` as in the combine epilogue.  g_y1 itself is never written.
     const float* bnb_y; const float* bnb_sums; float* bnb_gz; int64_t bnb_sT;
     int wreg;                                        // launch the WREG instance (set by launch_linear: shape, mode and option lin_wreg)
+    // combine epilogue, round 6: BatchNorm's training statistics of the output ride in the pass -- every lane adds the y values it stores (and
+    // their squares) to fp64 cells of its own in LDS (ds_add_f64: no registers, nothing waits), the workgroup folds them per column at its
+    // end and leaves bn_part[(q * bn_F + t * fo + o) * groups + grp], q = 0 (sum y) / 1 (sum y^2): what bn_stats would have computed
+    // in a pass of its own over y, in the layout bn_finalize reads.  st_off: where the cells start in LDS (floats; set by launch_linear)
+    double* bn_part; int bn_F; int st_off;
 };
 
 // registers a lane needs: accumulators + one block of W operands + the prefetched strip
@@ -292,6 +297,12 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
     float* Xl = (WREG ? Wl : Wl + NT * 16 * kp) + wave * (strip_floats(k) + kStrip * n + kFacFloats);   // this wave's strip, as it lies in memory
     float* Cl = Xl + strip_floats(k);                // results of the previous strip, [16][n]
     float* Fl = Cl + kStrip * n;                     // [2][16][4] per-row factors of the combine epilogue (scale_0..2, row_scale)
+    // (LinParams.bn_part: this wave's statistics cells, [4 per epilogue trip][64 lanes] doubles -- each lane's own, the wave's LDS operations run in order)
+    const int st_cells = COMBINE ? 4 * ((kStrip * (p.fo >> 1) + 63) >> 6) * 64 : 0;
+    double* St = reinterpret_cast<double*>(lds + p.st_off) + wave * st_cells;
+    if constexpr (COMBINE) {
+        if (p.bn_part) for (int i = lane; i < st_cells; i += 64) St[i] = 0.0;
+    }
 
     const float* A = p.A + (int64_t)t * p.sA;
     float* C = p.C + (int64_t)t * p.sC;
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
             const int fo2 = p.fo >> 1;                // (f_out is even: pairs of output columns, 8-byte stores)
             const int cnt = (int)min((int64_t)kStrip, p.M - row0) * fo2;
             const float* F = Fl + (out_it & 1) * (kStrip * 4);
-            for (int idx = lane; idx < cnt; idx += 64) {
+            double* st = St + lane;
+            for (int idx = lane; idx < cnt; idx += 64, st += 256) {
                 const int r = idx / fo2, o = 2 * (idx - r * fo2);
                 const f4 f = *reinterpret_cast<const f4*>(F + 4 * r);
                 float2 v = *reinterpret_cast<const float2*>(Cb + o);
@@ -440,7 +452,14 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
                     v.x += f[s] * z.x;
                     v.y += f[s] * z.y;
                 }
-                *reinterpret_cast<float2*>(p.Y + (row0 + r) * p.ldy + t * p.fo + o) = make_float2(v.x * f[3], v.y * f[3]);
+                const float y0 = v.x * f[3], y1 = v.y * f[3];
+                *reinterpret_cast<float2*>(p.Y + (row0 + r) * p.ldy + t * p.fo + o) = make_float2(y0, y1);
+                if (p.bn_part) {                      // (uniform; bn_stats' per-element values: y and the fp32 square, added in fp64)
+                    lds_add_f64(st, (double)y0);
+                    lds_add_f64(st + 64, (double)y1);
+                    lds_add_f64(st + 128, (double)(y0 * y0));
+                    lds_add_f64(st + 192, (double)(y1 * y1));
+                }
             }
             return;
         }
@@ -592,6 +611,24 @@ __global__ __launch_bounds__(WREG ? 256 : linear_threads(NT, KB, MODE), WREG ? 3
         out_it = it++;
     }
     if (out_strip >= 0) store_out();
+    if constexpr (COMBINE) {
+        if (p.bn_part) {                              // (uniform) this workgroup's column partials: waves, then the 16 row slots of a column, in a fixed order
+            __syncthreads();
+            const int fo2 = p.fo >> 1;
+            if (tid < 2 * p.fo) {
+                const int q = tid / p.fo, c = tid - q * p.fo, c2 = c >> 1;
+                double a = 0.0;
+                for (int w = 0; w < n_waves; ++w) {
+                    const double* sw = reinterpret_cast<const double*>(lds + p.st_off) + w * st_cells;
+                    for (int r = 0; r < kStrip; ++r) {
+                        const int idx = r * fo2 + c2;
+                        a += sw[(4 * (idx >> 6) + 2 * q + (c & 1)) * 64 + (idx & 63)];
+                    }
+                }
+                p.bn_part[((int64_t)q * p.bn_F + t * p.fo + c) * p.groups + grp] = a;
+            }
+        }
+    }
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------

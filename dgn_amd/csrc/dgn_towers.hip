@@ -165,10 +165,13 @@ extern "C" int dgn_towers_layer_zmask_supported(int32_t n_towers, int32_t f_out)
     return !off && n_towers >= 1 && f_out >= 1 && Fo % 16 != 0 && dgn_linear_add_supported(Fo, Fo) && dgn_linear_act_supported(Fo, Fo);
 }
 
+// BatchNorm's part of the forward workspace: bn_stats' partials, or the slots the posttrans product's epilogue fills (lin::combine_forward_stats)
+static size_t fwd_bn_ws(const Dims& d) { return up256(std::max(dgn_bn_tail_workspace_bytes(d.N, d.Fo), lin::combine_forward_stats_bytes(d.T, d.fo))); }
+
 extern "C" size_t dgn_towers_layer_forward_workspace_bytes(const DgnTowersLayer* L) {
     Dims d;
     if (!dims_of(L, d, "dgn_towers_layer_forward_workspace_bytes")) return 0;
-    return up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo)) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fm));
+    return fwd_bn_ws(d) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fm));
 }
 
 extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
@@ -179,7 +182,7 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     if (!L->h || !L->w_sd || !L->w_post || !L->w_mix || !L->pq || !L->aggx || !L->y0 || (!L->z && !L->zmask) || !L->out || !L->save_mean ||
         !L->save_invstd || (d.S > 1 && !L->scale)) { set_error("%s: null operand", fn); return DGN_ERR_INVALID; }
     if (!drop_ok(L, fn, true)) return DGN_ERR_INVALID;
-    const size_t bn_ws = up256(dgn_bn_tail_workspace_bytes(d.N, d.Fo));
+    const size_t bn_ws = fwd_bn_ws(d);
     if (L->ws_bytes < dgn_towers_layer_forward_workspace_bytes(L) || (!L->ws && L->ws_bytes)) { set_error("%s: workspace too small", fn); return DGN_ERR_WORKSPACE; }
     char* ws = static_cast<char*>(L->ws);
     // P | Q = h [W_s | W_d]^T + [0 | b]                                                     (dgn_layer.py:226-231, decomposed)
@@ -191,12 +194,26 @@ extern "C" int dgn_towers_layer_forward(const DgnTowersLayer* L, void* stream) {
     const size_t agg_ws = L->ws_bytes - bn_ws;
     DGN_TRY(dgn_agg_forward_aux(L->graph, L->spec, &msg, L->w, L->ld_w, L->log_deg, L->aggx, d.K, L->agg_aux, ws + bn_ws, agg_ws, stream));
     // posttrans([h || agg]) with the folded scalers, bias and graph norm                     (:266-271)
+    // (round 6: BatchNorm's column sums of y0 ride in the product's epilogue where nothing else needs a pass over y0 -- no bn_stats launch)
+    int stat_slots = 0;
+    if (option(OPT_BN_STATS_FUSED) && !L->y1 && !L->n_valid) {
+        const int rc = lin::combine_forward_stats(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale, L->b_post,
+                                                  L->snorm, L->y0, d.Fo, reinterpret_cast<double*>(ws), bn_ws, &stat_slots, stream);
+        if (rc < 0) return DGN_ERR_HIP;
+        if (rc > 0) stat_slots = 0;
+    }
+    if (stat_slots > 0) {
+        // the towers' BatchNorm (training statistics)                                        (:272-273)
+        DGN_TRY(bn_finalize_launch(d.N, d.Fo, stat_slots, reinterpret_cast<const double*>(ws), L->running_mean, L->running_var, L->momentum, L->eps,
+                                   L->save_mean, L->save_invstd, L->num_batches_tracked, L->n_nbt, stream));
+    } else {
     DGN_TRY(dgn_linear_combine_forward(d.N, d.K, d.T, d.S, d.fo, L->aggx, d.N * d.K, L->w_post, d.K, (int64_t)d.S * d.fo * d.K, L->scale,
                                        L->b_post, L->snorm, L->y0, d.Fo, stream));
     // the towers' BatchNorm (training statistics)                                            (:272-273)
     // (y1 == NULL: statistics only -- the mixing Linear normalises y0 while it stages its strips, the normalised tensor is never written)
     DGN_TRY(bn_tail_forward_nbt(d.N, d.Fo, L->y0, d.Fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 0,
                                 nullptr, L->y1, L->save_mean, L->save_invstd, ws, bn_ws, L->n_valid, L->num_batches_tracked, L->n_nbt, stream));
+    }
     // the towers' dropout, on the normalised rows in place                                   (:275)
     if (L->drop_p > 0.0f) DGN_TRY(dgn_dropout_forward(d.N * d.Fo, L->y1, L->drop_p, L->drop_seed, L->drop_offset, L->y1, L->drop_mask, stream));
     // mixing network: Linear -> LeakyReLU, then the layer's residual                         (:318-324)

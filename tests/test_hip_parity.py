@@ -855,6 +855,66 @@ def test_towers_backward_with_the_one_pass_pretrans_backward_is_bitwise_the_two_
         assert torch.equal(v.grad, pa[k]), k
 
 
+@pytest.mark.parametrize("n_graphs,graph_norm", [(200, True), (37, False), (1, True)])
+def test_towers_forward_with_batchnorm_statistics_from_the_posttrans_epilogue(monkeypatch, n_graphs, graph_norm):
+    """Round 6 (csrc/dgn_linear_kernels.hpp ts_linear<.., kCombine>: LinParams.bn_part, option bn_stats_fused): BatchNorm's column sums of
+    the posttrans output ride in that product's epilogue (fp64 cells in LDS, per-workgroup partials, bn_finalize) instead of bn_stats' pass
+    over y0.  Same per-element values, another fp64 summation order: mean / invstd agree to fp32 rounding of an fp64 sum, the layer's
+    output, every gradient, the running statistics and num_batches_tracked with them; reproducible run to run."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER_MIN_ROWS", 0)
+    b = synth.molecule_batch(n_graphs, seed=17, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    F_ = 70
+    torch.manual_seed(9)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, graph_norm, True, "mean max min dir1-av dir1-dx", "identity amplification attenuation", {"log": torch.tensor(1.1)},
+                             "towers", True, towers=5, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    h0 = torch.randn(N, F_, device=dev, generator=gen) * 2.0 + 0.5
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    used = []
+    orig = dgn_amd.dgn_layer.towers_layer
+    monkeypatch.setattr(dgn_amd.dgn_layer, "towers_layer", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(_lib.options, "bn_stats_fused", fused)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        bufs = {k: v.clone() for k, v in lay.named_buffers()}
+        return y.detach(), h.grad, {k: v.grad for k, v in lay.named_parameters()}, bufs
+
+    ya, ga, pa, ba = run(1)
+    yb, gb, pb, bb = run(0)
+    assert len(used) == 2, "the whole-layer entry point was not taken"
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 4e-6 * scale + 1e-7, what
+    close(ya, yb, "y")
+    close(ga, gb, "d h")
+    for k in pa:
+        close(pa[k], pb[k], k)
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == int(bb[k]) == 1, k
+        else:
+            close(ba[k].float(), bb[k].float(), k)
+    yc, gc, pc, bc = run(1)
+    assert torch.equal(ya, yc) and torch.equal(ga, gc)
+    for k in pa:
+        assert torch.equal(pa[k], pc[k]), k
+    for k in ba:
+        assert torch.equal(ba[k], bc[k]), k
+
+
 @pytest.mark.parametrize("aggs,T", [("mean max min dir1-av dir1-dx", 5), ("mean max min dir1-dx dir1-av", 1), ("mean max min dir1-av dir1-dx", 1)])
 @pytest.mark.parametrize("ties", [False, True])
 def test_backward_from_the_aux_table_is_bitwise_the_recomputing_backward(monkeypatch, aggs, T, ties):
