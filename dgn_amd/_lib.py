@@ -113,7 +113,8 @@ class DgnDenseLayer(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("hp", C.c_void_p), ("pq", C.c_void_p), ("agg", C.c_void_p), ("y", C.c_void_p), ("wf", C.c_void_p), ("wsd", C.c_void_p),
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("out", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("n_valid", C.c_void_p), ("agg_aux", C.c_void_p), ("dc", C.POINTER(DgnDegreeClasses))]
+                ("n_valid", C.c_void_p), ("agg_aux", C.c_void_p), ("dc", C.POINTER(DgnDegreeClasses)),
+                ("num_batches_tracked", C.c_void_p)]
 
 
 class DgnDenseGrads(C.Structure):

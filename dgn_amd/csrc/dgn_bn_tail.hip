@@ -167,6 +167,85 @@ __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const flo
     }
 }
 
+// ---- dense rows of a width that is not a multiple of four (hidden 75, 65: the reference's simple-layer configs), 16-byte lanes ---------------
+// The [n_rows, F] tensor is ONE flat array when its rows are dense (ld == F): 16-byte chunk q covers floats 4q .. 4q + 3, whatever rows
+// they belong to.  A PERIOD of F / gcd(F, 4) chunks covers 4 / gcd(F, 4) whole rows, so a thread that always takes chunk j of a period
+// sees the same four columns (4j + e) mod F every time: per-thread column accumulators and column constants, as in the thread-per-column
+// kernels, with four times the bytes per load instruction (bn_stats<false> read 4-byte lanes: 3.9 TB/s on [275 k, 75]; this form: see
+// profiles/NOTES.md).  Thread (p, j): period b * P + p, + G * P, ...; the workgroup folds (p, the four (j, e) of a column) through LDS in
+// a fixed order; the rows behind the last whole period are added by workgroup 0's column threads.  fn(offset, e0 columns, v0[4], v1[4])
+// fills the two quantities of the chunk at float offset `offset`; fn1(row, c, v0, v1) the same for one element (the remainder rows).
+constexpr int kFlatUnroll = 4;
+__host__ __device__ inline int flat_gcd4(int F) { return (F & 3) == 0 ? 4 : ((F & 1) == 0 ? 2 : 1); }
+template <class Fn4, class Fn1>
+__device__ __forceinline__ void column_partials_flat4(int64_t n_rows, int F, double* __restrict__ part, Fn4&& fn4, Fn1&& fn1) {
+    __shared__ double red[8][256];
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int g4 = flat_gcd4(F), Pc = F / g4, R = 4 / g4;       // chunks and rows per period
+    const int P = 256 / Pc;                                      // periods per workgroup trip (F <= 256)
+    const int p = (int)threadIdx.x / Pc, j = (int)threadIdx.x - p * Pc;
+    const int64_t n_periods = n_rows / R, stride = (int64_t)G * P;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (p < P) {
+        for (int64_t s = (int64_t)b * P + p; s < n_periods; s += kFlatUnroll * stride) {
+            float v0[kFlatUnroll][4], v1[kFlatUnroll][4];
+#pragma unroll
+            for (int u = 0; u < kFlatUnroll; ++u) fn4(min(s + u * stride, n_periods - 1) * ((int64_t)R * F) + 4 * j, v0[u], v1[u]);
+#pragma unroll
+            for (int u = 0; u < kFlatUnroll; ++u) {
+                if (s + u * stride < n_periods) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] += (double)v0[u][e]; a[4 + e] += (double)v1[u][e]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[q][threadIdx.x] = a[q];
+    __syncthreads();
+    const int c = (int)threadIdx.x;
+    if (c < F) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int e = 0; e < 4; ++e) {
+            for (int k = 0; k <= 4; ++k) {                      // the chunk j of a period whose element e is column c: 4 j + e = c + k F
+                const int v = c - e + k * F;
+                if (v < 0 || (v & 3) || (v >> 2) >= Pc) continue;
+                for (int q = 0; q < P; ++q) { s0 += red[e][q * Pc + (v >> 2)]; s1 += red[4 + e][q * Pc + (v >> 2)]; }
+            }
+        }
+        if (b == 0) {
+            for (int64_t n = n_periods * R; n < n_rows; ++n) {
+                float v0, v1;
+                fn1(n, c, v0, v1);
+                s0 += (double)v0;
+                s1 += (double)v1;
+            }
+        }
+        part[(int64_t)c * G + b] = s0;
+        part[((int64_t)F + c) * G + b] = s1;
+    }
+}
+// (dense rows, a 16-byte aligned base, a width the thread-per-pair kernels do not take or take at 8 bytes only, a period within one workgroup)
+bool flat4_ok(int F, int64_t ld, const void* a, const void* b = nullptr) {
+    static const bool off = getenv("DGN_BN_NO_FLAT4") != nullptr;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return !off && ld == F && (F & 3) != 0 && F / flat_gcd4(F) <= 256 && al16(a) && al16(b);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_flat4(int64_t n_rows, int F, const float* __restrict__ x, double* __restrict__ part,
+                                                      const int64_t* __restrict__ n_valid) {
+    if (n_valid) n_rows = min(n_rows, *n_valid);
+    column_partials_flat4(n_rows, F, part, [&](int64_t off, float (&v0)[4], float (&v1)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(x + off);
+        v0[0] = v.x; v0[1] = v.y; v0[2] = v.z; v0[3] = v.w;
+        v1[0] = v.x * v.x; v1[1] = v.y * v.y; v1[2] = v.z * v.z; v1[3] = v.w * v.w;
+    }, [&](int64_t n, int c, float& v0, float& v1) {
+        const float v = x[n * F + c];
+        v0 = v;
+        v1 = v * v;
+    });
+}
+
 // mean / invstd per column, running statistics (unbiased variance, like torch)
 __global__ __launch_bounds__(256) void bn_finalize(int64_t n_rows, int F, int G, const double* __restrict__ part,
                                                    float* running_mean, float* running_var, float momentum, float eps,
@@ -235,6 +314,47 @@ __global__ __launch_bounds__(256) void bn_apply_vec(int64_t n_rows, int F, const
     }
 }
 
+// bn_apply_vec on dense rows of a width that is not a multiple of four: flat 16-byte chunks (see column_partials_flat4), the column of a
+// chunk's first element kept by increments; the (n_rows F) mod 4 floats behind the last chunk by the last workgroup's first threads
+__global__ __launch_bounds__(256) void bn_apply_flat4(int64_t n_rows, int F, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                                      int relu, const float* __restrict__ residual, float* __restrict__ y) {
+    __shared__ float s_a[kMaxF], s_b[kMaxF], s_mu[kMaxF], s_ga[kMaxF];
+    for (int c = threadIdx.x; c < F; c += 256) {
+        s_mu[c] = mean ? mean[c] : running_mean[c];
+        s_a[c] = mean ? invstd[c] : 1.f / sqrtf(running_var[c] + eps);
+        s_ga[c] = gamma ? gamma[c] : 1.f;
+        s_b[c] = beta ? beta[c] : 0.f;
+    }
+    __syncthreads();
+    auto one = [&](float v, float r, int c) {        // (bn_apply_vec's arithmetic, in its order)
+        float e = (v - s_mu[c]) * s_a[c] * s_ga[c] + s_b[c];
+        if (relu) e = fmaxf(e, 0.f);
+        if (residual) e += r;
+        return e;
+    };
+    const int64_t total = n_rows * F, chunks = total >> 2, stride = (int64_t)gridDim.x * 256;
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int c0 = (int)((4 * q) % F);
+    const int dc = (int)((4 * stride) % F);
+    for (; q < chunks; q += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[q];
+        float4 r = v;
+        if (residual) r = reinterpret_cast<const float4*>(residual)[q];
+        int c1 = c0 + 1; if (c1 >= F) c1 -= F;
+        int c2 = c1 + 1; if (c2 >= F) c2 -= F;
+        int c3 = c2 + 1; if (c3 >= F) c3 -= F;
+        reinterpret_cast<float4*>(y)[q] = make_float4(one(v.x, r.x, c0), one(v.y, r.y, c1), one(v.z, r.z, c2), one(v.w, r.w, c3));
+        c0 += dc;
+        if (c0 >= F) c0 -= F;
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        const int64_t i = 4 * chunks + threadIdx.x;
+        if (i < total) y[i] = one(x[i], residual ? residual[i] : 0.f, (int)(i % F));
+    }
+}
+
 // backward partials: sum g', sum g' * xhat      (g' = g masked by the ReLU)
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
@@ -271,6 +391,30 @@ __global__ __launch_bounds__(256) void bn_bwd_stats(int64_t n_rows, int F, const
         const Col k0 = col((int)threadIdx.x % F);
         column_partials(n_rows, F, part, [&](int64_t n, int c, float& v0, float& v1) { one(x[n * ld + c], gy[n * ld + c], fixed ? k0 : col(c), v0, v1); });
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_stats_flat4(int64_t n_rows, int F, const float* __restrict__ gy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                          double* __restrict__ part, const int64_t* __restrict__ n_valid) {
+    if (n_valid) n_rows = min(n_rows, *n_valid);
+    struct Col { float mu, is, ga, be; };
+    auto col = [&](int c) { return Col{mean[c], invstd[c], gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f}; };
+    auto one = [&](float xv, float g, const Col& k, float& v0, float& v1) {      // (bn_bwd_stats' arithmetic)
+        const float xh = (xv - k.mu) * k.is;
+        if (relu && !(xh * k.ga + k.be > 0.f)) g = 0.f;
+        v0 = g;
+        v1 = g * xh;
+    };
+    const int Pc = F / flat_gcd4(F), j = (int)threadIdx.x % Pc;
+    const Col k0 = col((4 * j) % F), k1 = col((4 * j + 1) % F), k2 = col((4 * j + 2) % F), k3 = col((4 * j + 3) % F);
+    column_partials_flat4(n_rows, F, part, [&](int64_t off, float (&v0)[4], float (&v1)[4]) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + off), g = *reinterpret_cast<const float4*>(gy + off);
+        one(xv.x, g.x, k0, v0[0], v1[0]);
+        one(xv.y, g.y, k1, v0[1], v1[1]);
+        one(xv.z, g.z, k2, v0[2], v1[2]);
+        one(xv.w, g.w, k3, v0[3], v1[3]);
+    }, [&](int64_t n, int c, float& v0, float& v1) { one(x[n * F + c], gy[n * F + c], col(c), v0, v1); });
 }
 
 // sums[c] = sum g' (= d beta), sums[F + c] = sum g' xhat (= d gamma)
@@ -382,6 +526,11 @@ unsigned flat_grid(int64_t total) { return (unsigned)std::min<int64_t>((total + 
 void launch_bn_apply(hipStream_t stream, int64_t n_rows, int F, const float* x, int64_t ld, const float* gamma, const float* beta, const float* mean,
                      const float* invstd, const float* running_mean, const float* running_var, float eps, int relu, const float* residual, float* y) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual);
+    if (flat4_ok(F, ld, x, y) && (reinterpret_cast<uintptr_t>(residual) & 15) == 0) {
+        hipLaunchKernelGGL(bn_apply_flat4, dim3(std::max(1u, flat_grid((n_rows * F) >> 2))), dim3(256), 0, stream, n_rows, F, x, gamma, beta, mean, invstd, running_mean,
+                           running_var, eps, relu, residual, y);
+        return;
+    }
     const int vec = (F % 4 == 0 && ld % 4 == 0 && bits % 16 == 0) ? 4 : ((F % 2 == 0 && ld % 2 == 0 && bits % 8 == 0) ? 2 : 1);
     const dim3 grid(flat_grid(n_rows * (F / vec)));
     if (vec == 4) hipLaunchKernelGGL(bn_apply_vec<4>, grid, dim3(256), 0, stream, n_rows, F, x, ld, gamma, beta, mean, invstd, running_mean, running_var, eps, relu, residual, y);
@@ -538,7 +687,8 @@ int dgn::bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t 
         if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bn_tail_forward: workspace too small"); return DGN_ERR_WORKSPACE; }
         double* part = static_cast<double*>(ws);
         const int G = stat_groups(n_rows, F);
-        if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
+        if (flat4_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats_flat4, dim3(G), dim3(256), 0, stream, n_rows, F, x, part, n_valid);
+        else if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd, n_valid, nbt, nbt ? n_nbt : 0);
@@ -564,7 +714,8 @@ extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y,
     double* part = static_cast<double*>(ws);
     float* sums = sums_out ? sums_out : reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
-    if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
+    if (flat4_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats_flat4, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
+    else if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     else hipLaunchKernelGGL(bn_bwd_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
     if (g_x)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "dgn_common.hpp"
 
@@ -215,6 +216,85 @@ __global__ __launch_bounds__(kThreads) void combine_bwd(int64_t n_nodes, int row
     }
 }
 
+// Round 6: the backward of a ONE-tower, scaler-free combine behind BatchNorm (the simple / complex layers on the degree-class route and the
+// identity-scaler configs: g_z [N, wy] = row_scale * BatchNorm-backward(g_out, y)) on dense rows of a width that is no multiple of four,
+// as ONE flat array of 16-byte chunks (dgn_bn_tail.hip: column_partials_flat4 -- a thread takes chunk j of every period of lcm(wy, 4) floats, so
+// its four columns, their BatchNorm constants and its row offsets inside the period never change).  combine_bwd staged 4-byte lanes
+// through an LDS slab: 2.5 TB/s on [275 k, 75]; this form streams 16-byte lanes.  The same arithmetic per element in the same order; the bias
+// gradient's per-workgroup partial is summed in another order (fp32, fixed: reproducible).
+constexpr int kFlatUnroll = 4;
+__global__ __launch_bounds__(kThreads) void combine_bwd_flat4(int64_t n_nodes, int wy, const float* __restrict__ row_scale, float* __restrict__ gz,
+                                                              float* __restrict__ bias_part, const DgnBnGrad bn) {
+    __shared__ float red[4][kThreads];
+    const int G = (int)gridDim.x, b = (int)blockIdx.x, F = wy;
+    const int g4 = (F & 1) ? 1 : 2, Pc = F / g4, R = 4 / g4;
+    const int P = kThreads / Pc;
+    const int p = (int)threadIdx.x / Pc, j = (int)threadIdx.x - p * Pc;
+    const int64_t n_valid = bn.n_valid ? *bn.n_valid : n_nodes;
+    const float inv_n = 1.f / (float)n_valid;
+    struct Col { float mu, is, ga, be, m1, m2; };
+    auto col = [&](int c) { return Col{bn.mean[c], bn.invstd[c], bn.gamma ? bn.gamma[c] : 1.f, bn.beta ? bn.beta[c] : 0.f, bn.sums[c] * inv_n, bn.sums[F + c] * inv_n}; };
+    auto one = [&](float yv, float g, const Col& k, int64_t row, float rs) {      // (combine_bwd's arithmetic)
+        const float xh = (yv - k.mu) * k.is;
+        if (bn.relu && !(xh * k.ga + k.be > 0.f)) g = 0.f;
+        g = k.ga * k.is * (g - k.m1 - xh * k.m2);
+        if (row >= n_valid) g = 0.f;
+        if (row_scale) g *= rs;
+        return g;
+    };
+    const int64_t n_periods = n_nodes / R, stride = (int64_t)G * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p < P) {
+        const Col k0 = col((4 * j) % F), k1 = col((4 * j + 1) % F), k2 = col((4 * j + 2) % F), k3 = col((4 * j + 3) % F);
+        const int ro0 = (4 * j) / F, ro1 = (4 * j + 1) / F, ro2 = (4 * j + 2) / F, ro3 = (4 * j + 3) / F;      // (a chunk touches at most two rows)
+        for (int64_t s = (int64_t)b * P + p; s < n_periods; s += kFlatUnroll * stride) {
+            float4 yv[kFlatUnroll], gv[kFlatUnroll];
+            float ra[kFlatUnroll], rb[kFlatUnroll];
+#pragma unroll
+            for (int u = 0; u < kFlatUnroll; ++u) {
+                const int64_t su = min(s + u * stride, n_periods - 1), off = su * ((int64_t)R * F) + 4 * j;
+                yv[u] = *reinterpret_cast<const float4*>(bn.y + off);
+                gv[u] = *reinterpret_cast<const float4*>(bn.g_out + off);
+                ra[u] = row_scale ? row_scale[su * R + ro0] : 1.f;
+                rb[u] = row_scale ? row_scale[su * R + ro3] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kFlatUnroll; ++u) {
+                if (s + u * stride < n_periods) {
+                    const int64_t r0 = (s + u * stride) * R;
+                    const float o0 = one(yv[u].x, gv[u].x, k0, r0 + ro0, ra[u]), o1 = one(yv[u].y, gv[u].y, k1, r0 + ro1, ro1 == ro0 ? ra[u] : rb[u]);
+                    const float o2 = one(yv[u].z, gv[u].z, k2, r0 + ro2, ro2 == ro0 ? ra[u] : rb[u]), o3 = one(yv[u].w, gv[u].w, k3, r0 + ro3, rb[u]);
+                    *reinterpret_cast<float4*>(gz + r0 * F + 4 * j) = make_float4(o0, o1, o2, o3);
+                    acc[0] += o0; acc[1] += o1; acc[2] += o2; acc[3] += o3;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[e][threadIdx.x] = acc[e];
+    __syncthreads();
+    const int c = (int)threadIdx.x;
+    if (c < F) {
+        float sum = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            for (int k = 0; k <= 4; ++k) {                      // the chunk of a period whose element e is column c: 4 j + e = c + k F
+                const int v = c - e + k * F;
+                if (v < 0 || (v & 3) || (v >> 2) >= Pc) continue;
+                for (int q = 0; q < P; ++q) sum += red[e][q * Pc + (v >> 2)];
+            }
+        }
+        if (b == 0) {                                            // the rows behind the last whole period
+            const Col kc = col(c);
+            for (int64_t n = n_periods * R; n < n_nodes; ++n) {
+                const float o = one(bn.y[n * F + c], bn.g_out[n * F + c], kc, n, row_scale ? row_scale[n] : 1.f);
+                gz[n * F + c] = o;
+                sum += o;
+            }
+        }
+        if (bias_part) bias_part[(int64_t)c * G + b] = sum;
+    }
+}
+
 // g_bias[c] += (set: =) sum of the G slots (one workgroup per column, fixed order)
 __global__ __launch_bounds__(kThreads) void bias_finalize(int wy, int G, const float* __restrict__ bias_part, float* __restrict__ g_bias, int set) {
     __shared__ float red[kThreads / 64];
@@ -297,6 +377,20 @@ int dgn::scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int3
     const size_t lds = ((size_t)rows * wy + (size_t)rows * S + wy + (bn ? 6 * (size_t)wy : 0)) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = g_bias ? static_cast<float*>(ws) : nullptr;
+    {   // one tower, no scaler table, dense rows of a width that is no multiple of four, 16-byte aligned: flat 16-byte chunks
+        static const bool off = getenv("DGN_COMBINE_NO_FLAT4") != nullptr;
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        if (!off && bn && T == 1 && S == 1 && !scale && (wy & 3) != 0 && bn->ld == wy && wy / ((wy & 1) ? 1 : 2) <= kThreads && al16(bn->y) && al16(bn->g_out) &&
+            al16(g_z)) {
+            const int g4 = (wy & 1) ? 1 : 2, P = kThreads / (wy / g4);
+            const int64_t n_periods = n_nodes / (4 / g4);
+            const int Gf = (int)std::max<int64_t>(1, std::min<int64_t>(G, (n_periods + (int64_t)P * kFlatUnroll * 2 - 1) / ((int64_t)P * kFlatUnroll * 2)));
+            hipLaunchKernelGGL(combine_bwd_flat4, dim3(Gf), dim3(kThreads), 0, st, n_nodes, wy, row_scale, g_z, part, *bn);
+            if (g_bias) hipLaunchKernelGGL(bias_finalize, dim3(wy), dim3(kThreads), 0, st, wy, Gf, (const float*)part, g_bias, set_bias);
+            DGN_HIP_CHECK(hipGetLastError());
+            return DGN_OK;
+        }
+    }
     const DgnBnGrad none{};
     hipLaunchKernelGGL(combine_bwd, dim3(G), dim3(kThreads), lds, st, n_nodes, rows, T, S, fo, g_y, ld_gy, scale, row_scale, g_z, part,
                        bn ? *bn : none, bn ? 1 : 0);

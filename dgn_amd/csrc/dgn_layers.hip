@@ -264,8 +264,9 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
         DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
     }
     // BatchNorm -> ReLU -> residual                                                             (:123-128 / :194-199)
-    DGN_TRY(dgn_bn_tail_forward(d.N, d.fo, L->y, d.fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 1,
-                                L->residual ? L->h : nullptr, L->out, L->save_mean, L->save_invstd, ws + z_b, bn_b, L->n_valid, stream));
+    DGN_TRY(bn_tail_forward_nbt(d.N, d.fo, L->y, d.fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 1,
+                                L->residual ? L->h : nullptr, L->out, L->save_mean, L->save_invstd, ws + z_b, bn_b, L->n_valid, L->num_batches_tracked,
+                                L->num_batches_tracked ? 1 : 0, stream));
     return DGN_OK;
 }
 

@@ -1441,7 +1441,7 @@ def _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_p
 
 class _DenseLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var, w_pre, b_pre, w_post, b_post, gamma, beta):
+    def forward(ctx, graph, plan, avg_log, w_edge, cfg, h, snorm, scale, running_mean, running_var, nbt, w_pre, b_pre, w_post, b_post, gamma, beta):
         lib = _lib.load()
         if not h.is_cuda:
             raise _lib.DgnError("dense_layer: CUDA tensors only (dgn_amd has no CPU path)")
@@ -1458,6 +1458,7 @@ class _DenseLayer(torch.autograd.Function):
         ctx.dc = dc
         L, keep = _dense_struct(graph, plan, avg_log, w_edge, cfg, h, snorm, scale, w_pre, b_pre, w_post, b_post, gamma, beta, bufs, ctx.n_valid, dc)
         L.running_mean, L.running_var, L.out = running_mean.data_ptr(), running_var.data_ptr(), out.data_ptr()
+        L.num_batches_tracked = _ptr(nbt)                # (the counter rides in the statistics' finalize kernel: ABI 28)
         n_aux = int(lib.dgn_dense_layer_agg_aux_bytes(C.byref(L))) if AGG_AUX else 0      # (see _TowersLayer)
         aux = torch.empty(n_aux, dtype=torch.uint8, device=dev) if n_aux else None
         L.agg_aux = _ptr(aux)
@@ -1496,7 +1497,7 @@ class _DenseLayer(torch.autograd.Function):
                                g_b_post=g_b_post.data_ptr(), g_gamma=g_gamma.data_ptr(), g_beta=g_beta.data_ptr())
         stream = _lib.stream_ptr(dev)
         _lib.check(lib.dgn_dense_layer_backward(C.byref(L), C.byref(G), stream), "dgn_dense_layer_backward")
-        return (None, None, None, None, None, g_h, None, None, None, None,
+        return (None, None, None, None, None, g_h, None, None, None, None, None,
                 g_w_pre.view_as(w_pre) if w_pre is not None else None, g_b_pre if (b_pre is not None and type_net == 1) else None,
                 g_w_post.view_as(w_post), g_b_post if b_post is not None else None, g_gamma, g_beta)
 
@@ -1514,11 +1515,13 @@ def dense_layer(graph: DGNGraph, plan: AggPlan, avg_log: float, w_edge, h, snorm
     if scale is not None:
         scale = scale.contiguous()
     cfg = (int(type_net), h.shape[1], w_post.shape[0], S, int(n_agg), int(id_slot), bool(residual), float(bn.momentum), float(bn.eps))
-    out = _DenseLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, bn.running_mean, bn.running_var, w_pre, b_pre, w_post, b_post,
-                            bn.weight, bn.bias)
-    with torch.no_grad():
-        bn.num_batches_tracked.add_(1)
-    return out
+    nbt = bn.num_batches_tracked
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1):
+        with torch.no_grad():
+            nbt.add_(1)
+        nbt = None
+    return _DenseLayer.apply(graph, plan, float(avg_log), w_edge, cfg, h, snorm, scale, bn.running_mean, bn.running_var, nbt, w_pre, b_pre, w_post, b_post,
+                             bn.weight, bn.bias)
 
 
 # ---- the graph-block layer: a batch at the reference's batch size as five launches per step (csrc/dgn_blk_layer.hip) -----------------

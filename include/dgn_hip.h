@@ -671,6 +671,7 @@ typedef struct DgnDenseLayer {
     const int64_t* n_valid;    /* DEVICE scalar or NULL (padded batches, see dgn_bn_tail_forward)            */
     unsigned char* agg_aux;    /* optional: dgn_dense_layer_agg_aux_bytes() bytes, the sweep's aux table (dgn_agg_forward_aux) */
     const DgnDegreeClasses* dc; /* optional (S > 1, f_out <= 128): degree-class posttrans; wf then holds (2 S + 2 DGN_DC_CLASSES) f_out K floats */
+    int64_t* num_batches_tracked; /* ABI 28: the BatchNorm module's counter (DEVICE; see DgnTowersLayer), incremented by the forward; NULL: not touched */
 } DgnDenseLayer;
 typedef struct DgnDenseGrads {
     const float* g_out;        /* [N, f_out]                                                                 */

@@ -630,6 +630,76 @@ def test_bn_tail_vs_torch_batchnorm():
             _close(bn_tail(x0.to(dev), mine if n_bn > 1 else mine[0], False, relu=relu), ye, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("N,W", [(1003, 75), (997, 65), (5, 75), (1, 65), (3, 70), (4099, 70), (2, 3), (77, 255), (1030, 130)])
+@pytest.mark.parametrize("relu,use_res", [(True, True), (False, False)])
+def test_bn_tail_on_widths_that_are_no_multiple_of_four(N, W, relu, use_res):
+    """Round 6 (csrc/dgn_bn_tail.hip column_partials_flat4 / bn_apply_flat4): dense rows of a width that is no multiple of four are read as
+    one flat array of 16-byte chunks (a thread's four columns repeat with the period of lcm(W, 4) floats).  Against nn.BatchNorm1d in
+    fp64: output, input / affine gradients, running statistics -- row counts that are no multiple of the period, fewer rows than a
+    period, a ragged last chunk."""
+    dev = _dev()
+    from dgn_amd.ops import bn_tail
+    gen = torch.Generator().manual_seed(N * 1000 + W)
+    x0 = torch.randn(N, W, generator=gen) * 2 + 0.7
+    res0, ct = torch.randn(N, W, generator=gen), torch.randn(N, W, generator=gen)
+    ref, mine = torch.nn.BatchNorm1d(W).double(), torch.nn.BatchNorm1d(W).to(dev)
+    with torch.no_grad():
+        ga, be = torch.rand(W, generator=gen) + 0.5, torch.randn(W, generator=gen)
+        for b in (ref, mine):
+            b.weight.copy_(ga)
+            b.bias.copy_(be)
+    if N == 1:
+        ref.eval(), mine.eval()                      # (torch refuses one row in training mode)
+    xr = x0.double().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr = yr + res0.double() if use_res else yr
+    yr.backward(ct.double())
+    xm = x0.to(dev).requires_grad_(True)
+    rm = res0.to(dev)
+    ym = bn_tail(xm, mine, mine.training, relu=relu, residual=rm if use_res else None)
+    ym.backward(ct.to(dev))
+    tol = 2e-4 if N < 8 else 2e-5                    # (a handful of rows: the variance is small against eps-free cancellation)
+    _close(ym, yr.float(), tol, tol)
+    _close(xm.grad, xr.grad.float(), 10 * tol, tol)
+    _close(mine.weight.grad, ref.weight.grad.float(), 10 * tol, 10 * tol)
+    _close(mine.bias.grad, ref.bias.grad.float(), 10 * tol, 10 * tol)
+    _close(mine.running_mean, ref.running_mean.float(), 1e-5, 1e-6)
+    _close(mine.running_var, ref.running_var.float(), 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("N,W", [(1003, 75), (997, 65), (5, 75), (3, 70), (4099, 70), (2, 3), (1030, 130)])
+@pytest.mark.parametrize("relu,with_rows", [(True, True), (False, False)])
+def test_one_tower_combine_bn_tail_on_widths_that_are_no_multiple_of_four(N, W, relu, with_rows):
+    """Round 6 (csrc/dgn_combine.hip combine_bwd_flat4): the backward of bias + graph norm + BatchNorm (+ ReLU) of a one-tower, scaler-free
+    posttrans output -- the simple / complex layers' tail -- on dense rows of a width that is no multiple of four runs on flat 16-byte
+    chunks.  Against torch in fp64: output, d z, d bias, the affine gradients; ragged row counts, fewer rows than a period."""
+    dev = _dev()
+    from dgn_amd import ops
+    gen = torch.Generator().manual_seed(N * 100 + W)
+    z0 = torch.randn(1, N, W, generator=gen) * 1.5 + 0.3
+    b0, rs0, ct = torch.randn(W, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, W, generator=gen)
+    ga0, be0 = torch.rand(W, generator=gen) + 0.5, torch.randn(W, generator=gen)
+    zr, br, gr, ber = (t.double().requires_grad_(True) for t in (z0, b0, ga0, be0))
+    yr = zr[0] + br
+    if with_rows:
+        yr = yr * rs0.double()[:, None]
+    mu, var = yr.mean(0), yr.var(0, unbiased=False)
+    yr = (yr - mu) / torch.sqrt(var + 1e-5) * gr + ber
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(ct.double())
+    zm, bm, gm, bem = (t.to(dev).requires_grad_(True) for t in (z0, b0, ga0, be0))
+    rm, rv = torch.zeros(W, device=dev), torch.ones(W, device=dev)
+    ym = ops.combine_bn_tail(zm, None, bm, rs0.to(dev) if with_rows else None, gm, bem, rm, rv, None, 0.1, 1e-5, relu=relu)
+    ym.backward(ct.to(dev))
+    tol = 5e-4 if N < 8 else 3e-5
+    _close(ym, yr.float(), tol, tol)
+    _close(zm.grad, zr.grad.float(), 10 * tol, tol)
+    _close(bm.grad, br.grad.float(), 10 * tol, 10 * tol)
+    _close(gm.grad, gr.grad.float(), 10 * tol, 10 * tol)
+    _close(bem.grad, ber.grad.float(), 10 * tol, 10 * tol)
+
+
 @pytest.mark.parametrize("rows_per_wave", ["4"])
 @pytest.mark.parametrize("case", ["towers", "pair_std", "simple", "edge_table"])
 def test_grouped_row_backward_equals_row_per_wave(monkeypatch, rows_per_wave, case):
