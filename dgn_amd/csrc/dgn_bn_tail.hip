@@ -672,6 +672,16 @@ int dgn::bn_finalize_launch(int64_t n_rows, int32_t F, int32_t G, const double* 
     return DGN_OK;
 }
 
+int dgn::bn_tail_forward_from_partials(int64_t n_rows, int32_t F, int32_t G, const double* part, const float* x, int64_t ld, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
+                                       const float* residual, float* y, float* save_mean, float* save_invstd, int64_t* nbt, int32_t n_nbt, void* stream_) {
+    if (!x || !y || ld < F) { set_error("bn_tail_forward_from_partials: bad argument"); return DGN_ERR_INVALID; }
+    if (int rc = bn_finalize_launch(n_rows, F, G, part, running_mean, running_var, momentum, eps, save_mean, save_invstd, nbt, n_nbt, stream_)) return rc;
+    launch_bn_apply(static_cast<hipStream_t>(stream_), n_rows, F, x, ld, gamma, beta, save_mean, save_invstd, nullptr, nullptr, eps, relu, residual, y);
+    DGN_HIP_CHECK(hipGetLastError());
+    return DGN_OK;
+}
+
 // ... with the modules' num_batches_tracked counters incremented by the statistics' finalize kernel (training only; library-internal)
 int dgn::bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual, float* y,

@@ -36,10 +36,21 @@ int bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, c
 
 // BatchNorm's finalize kernel alone (mean / invstd / running statistics / counters from G slots of column partials laid out as bn_stats
 // leaves them: part[(q F + c) G + g]) -- for a producer that computed the partials itself (lin::combine_forward_stats)
+// ... followed by the apply pass (dgn_bn_tail_forward's training mode without its statistics kernel)
+int bn_tail_forward_from_partials(int64_t n_rows, int32_t F, int32_t G, const double* part, const float* x, int64_t ld, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, int32_t relu, const float* residual, float* y,
+                                  float* save_mean, float* save_invstd, int64_t* nbt, int32_t n_nbt, void* stream);
 int bn_finalize_launch(int64_t n_rows, int32_t F, int32_t G, const double* part, float* running_mean, float* running_var, float momentum, float eps,
                        float* save_mean, float* save_invstd, int64_t* nbt, int32_t n_nbt, void* stream);
 
 // input gradient + weight gradient of the towers' block-diagonal pretrans product in one pass (dgn_linear_bd.hip: bd_backward_both)
+namespace dc {
+// dgn_dc_gemm with BatchNorm's column partials of C riding in the epilogue (dgn_dc.hip); part == NULL: dgn_dc_gemm itself
+size_t gemm_stats_bytes(int32_t n);
+int gemm_stats(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w, int64_t ldw,
+               int64_t class_stride, int64_t w_tower, const float* bias, const float* row_scale, float* c, int64_t ldc, int64_t c_tower, int32_t stream_out,
+               double* part, size_t part_bytes, int* slots, void* stream);
+}
 namespace lin {
 // dgn_linear_combine_forward with BatchNorm's column partials of y riding in the epilogue (LinParams.bn_part); *groups = the number of slots
 // written.  DGN_ERR_UNSUPPORTED-like return 1 (nothing launched, no error set) where the shape has no such instance: the caller runs the two passes.

@@ -114,7 +114,19 @@ extern "C" int dgn_dc_fold(const DgnDegreeClasses* d, int32_t S, int32_t n, int3
 extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w,
                            int64_t ldw, int64_t class_stride, int64_t w_tower, const float* bias, const float* row_scale, float* c, int64_t ldc,
                            int64_t c_tower, int32_t stream_out, void* stream) {
+    return dgn::dc::gemm_stats(d, k, n, towers, a, lda, a_tower, w, ldw, class_stride, w_tower, bias, row_scale, c, ldc, c_tower, stream_out, nullptr, 0, nullptr,
+                               stream);
+}
+
+// (the most slots gemm_stats writes: row ranges of dc_gemm -- at most two per CU, rounded up to the XCD count -- or units of dc_gemm_small -- at most four per CU)
+size_t dgn::dc::gemm_stats_bytes(int32_t n) { return (size_t)2 * n * ((size_t)n_cus() * 4 + kXcds) * sizeof(double); }
+
+// dgn_dc_gemm with BatchNorm's column partials of C riding in the epilogue (DcGemmParams.bn_part; one tower): *slots = the G bn_finalize reads
+int dgn::dc::gemm_stats(const DgnDegreeClasses* d, int32_t k, int32_t n, int32_t towers, const float* a, int64_t lda, int64_t a_tower, const float* w,
+                        int64_t ldw, int64_t class_stride, int64_t w_tower, const float* bias, const float* row_scale, float* c, int64_t ldc,
+                        int64_t c_tower, int32_t stream_out, double* part, size_t part_bytes, int* slots, void* stream) {
     const char* fn = "dgn_dc_gemm";
+    if (part && (towers != 1 || !slots || part_bytes < gemm_stats_bytes(n))) { set_error("%s: statistics need one tower and gemm_stats_bytes()", fn); return DGN_ERR_INVALID; }
     if (!check_classes(fn, d)) return DGN_ERR_INVALID;
     if (!dgn_dc_supported(k, n) || towers < 1 || towers > 64) { set_error("%s: widths outside 4..4096 (k=%d n=%d) or towers outside 1..64", fn, k, n); return DGN_ERR_INVALID; }
     if (d->n_units == 0) return DGN_OK;
@@ -143,6 +155,9 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
     const dim3 grid = p.col_tiles > 1 ? dim3((unsigned)((ranges + kXcds - 1) / kXcds * kXcds * best_tiles), 1, (unsigned)towers)
                                       : dim3((unsigned)ranges, (unsigned)best_tiles, (unsigned)towers);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    p.bn_part = best_nq <= 6 ? part : nullptr; p.bn_F = n;      // (wider tiles: no statistics, *slots = 0 -- the caller runs bn_stats)
+    p.bn_G = (int)(p.col_tiles > 1 ? grid.x / best_tiles : ranges);
+    if (part) *slots = p.bn_part ? p.bn_G : 0;
     // few units: one unit per workgroup, four workgroups per CU (dc_gemm_small) while every (unit, column tile) is resident at once
     // (few ROWS is the criterion -- at most four units per CU --: column tiles multiply the workgroups of both kernels alike.  HIV batch 2048,
     //  816 units, captured step 0.348 -> 0.338 ms with the forward and the input-gradient product on it; DGN_DC_SMALL=0: off)
@@ -150,6 +165,8 @@ extern "C" int dgn_dc_gemm(const DgnDegreeClasses* d, int32_t k, int32_t n, int3
     if (small_on && best_nq <= 6 && d->n_units * towers <= (int64_t)n_cus() * 4) {
         const dim3 gs((unsigned)d->n_units, (unsigned)best_tiles, (unsigned)towers);
         p.col_tiles = 1;
+        p.bn_G = (int)d->n_units;
+        if (part) *slots = p.bn_G;
         switch (best_nq) {
             case 1: hipLaunchKernelGGL(dc_gemm_small<1>, gs, dim3(256), 0, st, p); break;
             case 2: hipLaunchKernelGGL(dc_gemm_small<2>, gs, dim3(256), 0, st, p); break;

@@ -21,6 +21,8 @@
 #include "dgn_common.hpp"
 #include "dgn_load4.hpp"
 
+#include <type_traits>
+
 namespace dgn {
 namespace dc {
 
@@ -89,12 +91,27 @@ struct DcGemmParams {
     int stream_out;                  // nontemporal result stores
     int col_tiles;                   // > 1: 1-D grid of 8-aligned row ranges x column tiles (XCD-aware dealing), else blockIdx.y = 0
     int64_t a_tower, w_tower, c_tower, bias_tower;      // blockIdx.z = tower: element offsets of its A rows / weights / C columns / bias
+    // Round 6 (one tower): BatchNorm's training statistics of C ride in the epilogue -- a wave folds its rows' values (and their fp32 squares) over
+    // the sixteen lanes of a column group in fp64 and adds them to fp64 cells of its own in LDS; the workgroup leaves
+    // bn_part[(q * bn_F + column) * bn_G + slot], q = 0 (sum) / 1 (sum of squares), slot = its row range (dc_gemm) or unit (dc_gemm_small): what
+    // bn_stats would compute in a pass of its own over C, in the layout bn_finalize reads.  NULL: nothing.
+    double* bn_part; int bn_F, bn_G;
 };
+
+// sum over the sixteen lanes of a DPP row (every lane gets it): quad butterflies, then the two mirrors
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false)); };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+}
 
 // One tile of 64 RT virtual rows (units u0 .. u0 + RT, all of one class) x 16 NQ columns.  Wave w owns rows 16 RT w .. of the tile.
 // TM: rows the A staging buffers were sized for (dc_gemm: 256; dc_gemm_small: 64, RT = 1 only).
 template <int NQ, int RT, bool DEEP = (NQ <= 6), int TM = kTileM>      // (NQ = 7: no registers left for the second set)
-__device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float* Bs, int64_t u0, const float* __restrict__ W, int n0) {
+__device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float* Bs, int64_t u0, const float* __restrict__ W, int n0, double* St = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const int KB = (p.k + 15) >> 4;
     const int lr = tid >> 2, c4 = (tid & 3) * 4;
@@ -181,6 +198,36 @@ __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float*
             __syncthreads();
         }
     }
+    if constexpr (NQ <= 6) if (p.bn_part) {           // (uniform) column sums of what is stored below: St[(2 wave + q) * 16 NQ + column]
+        int nds[RT];
+        float rss[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            nds[rt] = p.vperm[u0 * kUnit + 16 * RT * wave + 16 * rt + i16];
+            rss[rt] = (p.row_scale && nds[rt] >= 0) ? p.row_scale[nds[rt]] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            // (the <= 64 rows a column group of this wave holds: fp32 over the lane's rows and the sixteen lanes -- DPP adds, no LDS traffic --, fp64 from there)
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if (nds[rt] >= 0) {                   // (padding rows of a unit hold copies of row 0: not part of the batch)
+                    f4 v = acc[rt][q];
+                    if (p.row_scale) v = v * rss[rt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+            if (i16 == 0) {
+                double* c1 = St + (2 * wave) * (16 * NQ) + 16 * q + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lds_add_f64(c1 + r, (double)s1[r]); lds_add_f64(c1 + 16 * NQ + r, (double)s2[r]); }
+            }
+        }
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int nd = p.vperm[u0 * kUnit + 16 * RT * wave + 16 * rt + i16];
@@ -206,11 +253,33 @@ __device__ __forceinline__ void dc_tile(const DcGemmParams& p, float* As, float*
 
 // A workgroup owns the units [blockIdx.x * units_per_block, + units_per_block) and walks them in tiles of up to four units of one class,
 // the range cut into the fewest tiles of nearly equal height (dgn_gemm_kernels.hpp: tile_gemm).
+// DcGemmParams.bn_part: the workgroup's four waves' cells, column by column, to slot `slot`
+template <int NQ>
+__device__ __forceinline__ void dc_stats_flush(const DcGemmParams& p, const double* St, int n0, int64_t slot) {
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (NQ <= 6 && tid < 2 * 16 * NQ) {
+        const int q = tid / (16 * NQ), c = tid - q * (16 * NQ);
+        if (n0 + c < p.n) {
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += St[(2 * w + q) * (16 * NQ) + c];
+            p.bn_part[((int64_t)q * p.bn_F + n0 + c) * p.bn_G + slot] = a;
+        }
+    }
+}
+
 template <int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dc_gemm(const DcGemmParams p_in) {
     __shared__ float As[2 * kTileM * kTKS];
     __shared__ float Bs[2 * NQ * 16 * kTKS];
+    __shared__ double St[NQ <= 6 ? 8 * 16 * NQ : 1];      // (the statistics ride in the tiles of up to 96 columns only: wider ones have no registers to spare)
     DcGemmParams p = p_in;
+    if constexpr (NQ > 6) p.bn_part = nullptr;
+    if (p.bn_part) {
+        for (int i = threadIdx.x; i < 8 * 16 * NQ; i += 256) St[i] = 0.0;
+        __syncthreads();
+    }
     // several column tiles: a 1-D grid dealt so that the column tiles of ONE row range are consecutive workgroups of ONE XCD (the
     // dispatcher places workgroup b on XCD b % 8): they run together and share the range's A rows in that XCD's L2
     int bx = blockIdx.x, by = blockIdx.y;
@@ -233,13 +302,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         while (run < h && uniform_i(p.unit_class[u + run]) == c) ++run;
         const float* W = p.W + (int64_t)c * p.class_stride;
         switch (run) {
-            case 4: dc_tile<NQ, 4>(p, As, Bs, u, W, n0); break;
-            case 3: dc_tile<NQ, 3>(p, As, Bs, u, W, n0); break;
-            case 2: dc_tile<NQ, 2>(p, As, Bs, u, W, n0); break;
-            default: dc_tile<NQ, 1>(p, As, Bs, u, W, n0); break;
+            case 4: dc_tile<NQ, 4>(p, As, Bs, u, W, n0, St); break;
+            case 3: dc_tile<NQ, 3>(p, As, Bs, u, W, n0, St); break;
+            case 2: dc_tile<NQ, 2>(p, As, Bs, u, W, n0, St); break;
+            default: dc_tile<NQ, 1>(p, As, Bs, u, W, n0, St); break;
         }
         u += run;
     }
+    if (p.bn_part) dc_stats_flush<NQ>(p, St, n0, bx);
 }
 
 // Few units (HIV batch 2048: 816 units of 64 rows): dc_gemm's two 256-row workgroups per CU leave the chip a single, latency-bound round of
@@ -249,14 +319,20 @@ template <int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void dc_gemm_small(const DcGemmParams p_in) {
     __shared__ float As[2 * 64 * kTKS];
     __shared__ float Bs[2 * NQ * 16 * kTKS];
+    __shared__ double St[NQ <= 6 ? 8 * 16 * NQ : 1];
     DcGemmParams p = p_in;
+    if constexpr (NQ > 6) p.bn_part = nullptr;
     const int64_t u = blockIdx.x;
     const int n0 = blockIdx.y * p.n_slice;
+    if (p.bn_part) {
+        for (int i = threadIdx.x; i < 8 * 16 * NQ; i += 256) St[i] = 0.0;
+        __syncthreads();
+    }
     p.A += blockIdx.z * p.a_tower; p.W += blockIdx.z * p.w_tower; p.C += blockIdx.z * p.c_tower;
     if (p.bias) p.bias += blockIdx.z * p.bias_tower;
     const int c = uniform_i(p.unit_class[u]);
-    if (c < 0) return;
-    dc_tile<NQ, 1, true, 64>(p, As, Bs, u, p.W + (int64_t)c * p.class_stride, n0);
+    if (c >= 0) dc_tile<NQ, 1, true, 64>(p, As, Bs, u, p.W + (int64_t)c * p.class_stride, n0, St);
+    if (p.bn_part) dc_stats_flush<NQ>(p, St, n0, u);      // (an unused unit leaves a slot of zeros)
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------------------

@@ -251,10 +251,13 @@ extern "C" int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_o
            K >= 4 && K <= 4096 && n >= 4 && n <= 4096 && Fp >= 4;
 }
 
+// BatchNorm's part of the forward workspace: bn_stats' partials, or the slots the degree-class product's epilogue fills (dc::gemm_stats)
+static size_t fwd_bn_ws(const Dims& d) { return up256(std::max(dgn_bn_tail_workspace_bytes(d.N, d.fo), d.dc ? dc::gemm_stats_bytes(d.fo) : (size_t)0)); }
+
 extern "C" size_t dgn_dense_layer_forward_workspace_bytes(const DgnDenseLayer* L) {
     Dims d;
     if (!dims_of(L, d, "dgn_dense_layer_forward_workspace_bytes")) return 0;
-    return up256(d.dc ? 0 : (size_t)d.N * d.n * 4) + up256(dgn_bn_tail_workspace_bytes(d.N, d.fo)) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fp));
+    return up256(d.dc ? 0 : (size_t)d.N * d.n * 4) + fwd_bn_ws(d) + up256(dgn_agg_workspace_bytes(L->graph, L->spec, d.Fp));
 }
 
 extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
@@ -269,7 +272,7 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(L->ws);
     float* z = reinterpret_cast<float*>(ws);
-    const size_t z_b = up256(d.dc ? 0 : (size_t)d.N * d.n * 4), bn_b = up256(dgn_bn_tail_workspace_bytes(d.N, d.fo));
+    const size_t z_b = up256(d.dc ? 0 : (size_t)d.N * d.n * 4), bn_b = fwd_bn_ws(d);
     const float* hp = L->h;
     if (padded && !odd_direct(L, d)) {
         hipLaunchKernelGGL(pad_rows, dim3(nblk(d.N * d.Fp)), dim3(256), 0, st, d.N, d.F0, d.Fp, L->h, L->hp);
@@ -302,7 +305,18 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
         float* wc = L->wf + (size_t)2 * d.n * d.K;
         float* wct = wc + (size_t)DGN_DC_CLASSES * d.fo * d.K;
         DGN_TRY(dgn_dc_fold(L->dc, d.S, d.fo, d.K, 1, L->w_post, &lay, wc, wct, stream));
-        DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, 1, L->agg, d.K, 0, wc, d.K, (int64_t)d.fo * d.K, 0, L->b_post, L->snorm, L->y, d.fo, 0, 0, stream));
+        // (round 6: BatchNorm's column sums of y ride in the product's epilogue -- no bn_stats pass; option bn_stats_fused)
+        if (option(OPT_BN_STATS_FUSED) && !L->n_valid) {
+            int slots = 0;
+            DGN_TRY(dc::gemm_stats(L->dc, d.K, d.fo, 1, L->agg, d.K, 0, wc, d.K, (int64_t)d.fo * d.K, 0, L->b_post, L->snorm, L->y, d.fo, 0, 0,
+                                   reinterpret_cast<double*>(ws + z_b), bn_b, &slots, stream));
+            // BatchNorm -> ReLU -> residual                                                     (:123-128 / :194-199)
+            if (slots > 0) return bn_tail_forward_from_partials(d.N, d.fo, slots, reinterpret_cast<const double*>(ws + z_b), L->y, d.fo, L->bn_gamma, L->bn_beta,
+                                                 L->running_mean, L->running_var, L->momentum, L->eps, 1, L->residual ? L->h : nullptr, L->out,
+                                                 L->save_mean, L->save_invstd, L->num_batches_tracked, L->num_batches_tracked ? 1 : 0, stream);
+        } else {
+            DGN_TRY(dgn_dc_gemm(L->dc, d.K, d.fo, 1, L->agg, d.K, 0, wc, d.K, (int64_t)d.fo * d.K, 0, L->b_post, L->snorm, L->y, d.fo, 0, 0, stream));
+        }
     } else {
         DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
         DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));

@@ -25,6 +25,8 @@ done
 python tools/ab_option.py mix_bwd_fused 0 1 --kernels > gpurun_out/r06_c2_ab_mix_bwd_fused.txt 2>&1
 python tools/ab_option.py bn_from_wgrad 0 1 > gpurun_out/r06_c2_ab_bn_from_wgrad.txt 2>&1
 python tools/ab_option.py lin_wreg 0 3 --kernels > gpurun_out/r06_c2_ab_lin_wreg.txt 2>&1
+python tools/ab_option.py bd_bwd_fused 0 1 --kernels > gpurun_out/r06_c2_ab_bd_bwd_fused.txt 2>&1
+python tools/ab_option.py bn_stats_fused 0 1 --kernels > gpurun_out/r06_c2_ab_bn_stats_fused.txt 2>&1
 python tools/hub_training_time.py > gpurun_out/r06_hub_training.txt 2>&1
 python bench.py --all-extras > gpurun_out/r06_bench_all_extras_line.json 2> gpurun_out/r06_bench_all_extras.err
 cp gpurun_out/bench_full.json gpurun_out/r06_bench_all_extras.json
