@@ -57,6 +57,36 @@ __global__ __launch_bounds__(256) void pad_rows(int64_t n, int F0, int Fp, const
     const int c = (int)(i - r * Fp);
     hp[i] = c < F0 ? h[r * F0 + c] : 0.f;
 }
+// The same, four padded outputs per thread (the dense [n, Fp] output as flat 16-byte chunks; the source row's floats as one 4-byte-aligned 16-byte
+// load where the chunk lies inside the row's F0 columns)
+typedef float f4u_pad_t __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void pad_rows4(int64_t n, int F0, int Fp, const float* __restrict__ h, float* __restrict__ hp) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = n * Fp, i = 4 * q;
+    if (i >= total) return;
+    const int64_t r = i / Fp;
+    const int c = (int)(i - r * Fp);
+    if (i + 3 < total) {
+        float v[4];
+        if (c + 3 < F0) {
+            const f4u_pad_t a = *reinterpret_cast<const f4u_pad_t*>(h + r * F0 + c);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ce = c + e >= Fp ? c + e - Fp : c + e;
+                const int64_t re = c + e >= Fp ? r + 1 : r;
+                v[e] = ce < F0 ? h[re * F0 + ce] : 0.f;
+            }
+        }
+        reinterpret_cast<float4*>(hp)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int64_t k = i; k < total; ++k) {
+            const int64_t rk = k / Fp;
+            const int ck = (int)(k - rk * Fp);
+            hp[k] = ck < F0 ? h[rk * F0 + ck] : 0.f;
+        }
+    }
+}
 // g_h[r][c] = g_hp[r][c] (+ g_pqh[r][c]) (+ g_res[r][c]): un-pad and join the contributions to d h
 __global__ __launch_bounds__(256) void unpad_add(int64_t n, int F0, int Fp, const float* __restrict__ g_hp, const float* __restrict__ g2,
                                                  const float* __restrict__ g_res, float* __restrict__ g_h) {
@@ -275,7 +305,10 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
     const size_t z_b = up256(d.dc ? 0 : (size_t)d.N * d.n * 4), bn_b = fwd_bn_ws(d);
     const float* hp = L->h;
     if (padded && !odd_direct(L, d)) {
-        hipLaunchKernelGGL(pad_rows, dim3(nblk(d.N * d.Fp)), dim3(256), 0, st, d.N, d.F0, d.Fp, L->h, L->hp);
+        if (d.Fp >= 4 && d.Fp - d.F0 < 4 && (reinterpret_cast<uintptr_t>(L->hp) & 15) == 0)
+            hipLaunchKernelGGL(pad_rows4, dim3(nblk((d.N * d.Fp + 3) / 4)), dim3(256), 0, st, d.N, d.F0, d.Fp, L->h, L->hp);
+        else
+            hipLaunchKernelGGL(pad_rows, dim3(nblk(d.N * d.Fp)), dim3(256), 0, st, d.N, d.F0, d.Fp, L->h, L->hp);
         hp = L->hp;
     }
     const int hoff = d.cx ? d.F0 : 0;
