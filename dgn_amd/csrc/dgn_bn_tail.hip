@@ -227,9 +227,8 @@ __device__ __forceinline__ void column_partials_flat4(int64_t n_rows, int F, dou
 }
 // (dense rows, a 16-byte aligned base, a width the thread-per-pair kernels do not take or take at 8 bytes only, a period within one workgroup)
 bool flat4_ok(int F, int64_t ld, const void* a, const void* b = nullptr) {
-    static const bool off = getenv("DGN_BN_NO_FLAT4") != nullptr;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    return !off && ld == F && (F & 3) != 0 && F / flat_gcd4(F) <= 256 && al16(a) && al16(b);
+    return ld == F && (F & 3) != 0 && F / flat_gcd4(F) <= 256 && al16(a) && al16(b);
 }
 
 __global__ __launch_bounds__(256) void bn_stats_flat4(int64_t n_rows, int F, const float* __restrict__ x, double* __restrict__ part,

@@ -31,7 +31,12 @@ template <int S_>
 __global__ __launch_bounds__(kThreads) void combine_fwd(int64_t n_nodes, int rows_per_block, int T, int S_rt, int fo,
                                                         const float* __restrict__ z, const float* __restrict__ scale,
                                                         const float* __restrict__ bias, const float* __restrict__ row_scale,
-                                                        float* __restrict__ y, int64_t ld_y) {
+                                                        float* __restrict__ y, int64_t ld_y, double* __restrict__ bn_part) {
+    // bn_part (round 6; width <= kThreads): BatchNorm's training statistics of y ride in the pass -- a thread's column is fixed, it adds the values it
+    // stores (and their fp32 squares) in fp64, the workgroup folds its row phases and leaves bn_part[(q * width + c) * gridDim.x + blockIdx.x]
+    // (q = 0 sum, 1 sum of squares): bn_stats' partials in bn_finalize's layout, without bn_stats' pass over y
+    __shared__ double red[2][kThreads];
+    double st0 = 0.0, st1 = 0.0;
     const int S = S_ ? S_ : S_rt;
     const int width = T * fo;
     const int P = max(1, kThreads / width);
@@ -74,8 +79,24 @@ __global__ __launch_bounds__(kThreads) void combine_fwd(int64_t n_nodes, int row
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const int64_t m = n + (int64_t)u * P;
-                if (m < r1) y[m * ld_y + c] = acc[u] * rs[u];
+                if (m < r1) {
+                    const float v = acc[u] * rs[u];
+                    y[m * ld_y + c] = v;
+                    st0 += (double)v;
+                    st1 += (double)(v * v);
+                }
             }
+        }
+    }
+    if (bn_part) {                                    // (uniform; width <= kThreads: one trip of the column loop, thread = (row phase, column))
+        red[0][threadIdx.x] = st0;
+        red[1][threadIdx.x] = st1;
+        __syncthreads();
+        const int c = (int)threadIdx.x;
+        if (c < width) {
+            for (int q = 1; q < P; ++q) { st0 += red[0][c + q * width]; st1 += red[1][c + q * width]; }
+            bn_part[(int64_t)c * gridDim.x + blockIdx.x] = st0;
+            bn_part[((int64_t)width + c) * gridDim.x + blockIdx.x] = st1;
         }
     }
 }
@@ -325,17 +346,27 @@ using namespace dgn;
 
 extern "C" int dgn_scale_combine_forward(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* z, const float* scale,
                                          const float* bias, const float* row_scale, float* y, int64_t ld_y, void* stream) {
+    return dgn::scale_combine_forward_stats(n_nodes, T, S, fo, z, scale, bias, row_scale, y, ld_y, nullptr, 0, nullptr, stream);
+}
+
+// ... with BatchNorm's column partials of y riding in the pass (combine_fwd: bn_part).  part == NULL: the plain pass.  *slots = the G bn_finalize
+// reads, or 0 where the statistics did not ride (rows wider than a workgroup, more slabs than `part` holds): the caller runs bn_stats.
+int dgn::scale_combine_forward_stats(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* z, const float* scale, const float* bias,
+                                     const float* row_scale, float* y, int64_t ld_y, double* part, size_t part_bytes, int* slots, void* stream) {
     if (int rc = check_shape("dgn_scale_combine_forward", n_nodes, T, S, fo, scale != nullptr)) return rc;
+    if (slots) *slots = 0;
     if (n_nodes == 0) return DGN_OK;
     if (!z || !y || ld_y < (int64_t)T * fo) { set_error("dgn_scale_combine_forward: null buffer or ld_y too small"); return DGN_ERR_INVALID; }
     const int rows = fwd_slab_rows(n_nodes);
     const dim3 grid((unsigned)((n_nodes + rows - 1) / rows)), block(kThreads);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    double* bp = (part && slots && T * fo <= kThreads && (size_t)2 * T * fo * grid.x * sizeof(double) <= part_bytes) ? part : nullptr;
+    if (bp) *slots = (int)grid.x;
     switch (S) {
-        case 1: hipLaunchKernelGGL(combine_fwd<1>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
-        case 2: hipLaunchKernelGGL(combine_fwd<2>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
-        case 3: hipLaunchKernelGGL(combine_fwd<3>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
-        default: hipLaunchKernelGGL(combine_fwd<0>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y); break;
+        case 1: hipLaunchKernelGGL(combine_fwd<1>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y, bp); break;
+        case 2: hipLaunchKernelGGL(combine_fwd<2>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y, bp); break;
+        case 3: hipLaunchKernelGGL(combine_fwd<3>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y, bp); break;
+        default: hipLaunchKernelGGL(combine_fwd<0>, grid, block, 0, st, n_nodes, rows, T, S, fo, z, scale, bias, row_scale, y, ld_y, bp); break;
     }
     DGN_HIP_CHECK(hipGetLastError());
     return DGN_OK;
@@ -378,9 +409,8 @@ int dgn::scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int3
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = g_bias ? static_cast<float*>(ws) : nullptr;
     {   // one tower, no scaler table, dense rows of a width that is no multiple of four, 16-byte aligned: flat 16-byte chunks
-        static const bool off = getenv("DGN_COMBINE_NO_FLAT4") != nullptr;
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-        if (!off && bn && T == 1 && S == 1 && !scale && (wy & 3) != 0 && bn->ld == wy && wy / ((wy & 1) ? 1 : 2) <= kThreads && al16(bn->y) && al16(bn->g_out) &&
+        if (bn && T == 1 && S == 1 && !scale && (wy & 3) != 0 && bn->ld == wy && wy / ((wy & 1) ? 1 : 2) <= kThreads && al16(bn->y) && al16(bn->g_out) &&
             al16(g_z)) {
             const int g4 = (wy & 1) ? 1 : 2, P = kThreads / (wy / g4);
             const int64_t n_periods = n_nodes / (4 / g4);

@@ -28,6 +28,9 @@ int scale_combine_backward_impl(int64_t n_nodes, int32_t T, int32_t S, int32_t f
                                 const float* row_scale, float* g_z, float* g_bias, void* ws, size_t ws_bytes, const DgnBnGrad* bn,
                                 void* stream, int set_bias);
 
+// dgn_scale_combine_forward with BatchNorm's column partials of y riding in the pass (dgn_combine.hip)
+int scale_combine_forward_stats(int64_t n_nodes, int32_t T, int32_t S, int32_t fo, const float* z, const float* scale, const float* bias,
+                                const float* row_scale, float* y, int64_t ld_y, double* part, size_t part_bytes, int* slots, void* stream);
 // dgn_bn_tail_forward + the BatchNorm modules' num_batches_tracked counters (dgn_bn_tail.hip)
 int bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t ld, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float momentum, float eps, int32_t training, int32_t relu, const float* residual, float* y,

@@ -282,7 +282,10 @@ extern "C" int dgn_dense_layer_supported(int32_t type, int32_t f_in, int32_t f_o
 }
 
 // BatchNorm's part of the forward workspace: bn_stats' partials, or the slots the degree-class product's epilogue fills (dc::gemm_stats)
-static size_t fwd_bn_ws(const Dims& d) { return up256(std::max(dgn_bn_tail_workspace_bytes(d.N, d.fo), d.dc ? dc::gemm_stats_bytes(d.fo) : (size_t)0)); }
+// (... or the combine pass': one slot per slab, at most 2 048 slabs ride)
+static size_t fwd_bn_ws(const Dims& d) {
+    return up256(std::max(dgn_bn_tail_workspace_bytes(d.N, d.fo), d.dc ? dc::gemm_stats_bytes(d.fo) : (size_t)2 * d.fo * 2048 * sizeof(double)));
+}
 
 extern "C" size_t dgn_dense_layer_forward_workspace_bytes(const DgnDenseLayer* L) {
     Dims d;
@@ -352,7 +355,14 @@ extern "C" int dgn_dense_layer_forward(const DgnDenseLayer* L, void* stream) {
         }
     } else {
         DGN_TRY(lin_fwd(d.N, d.K, d.n, L->agg, L->wf, nullptr, z, stream));
-        DGN_TRY(dgn_scale_combine_forward(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, stream));
+        // (round 6: BatchNorm's column sums of y ride in the combine pass where its slabs fit the statistics workspace -- no bn_stats launch)
+        int slots = 0;
+        const bool ride = option(OPT_BN_STATS_FUSED) && !L->n_valid;
+        DGN_TRY(scale_combine_forward_stats(d.N, 1, d.S, d.fo, z, L->scale, L->b_post, L->snorm, L->y, d.fo, ride ? reinterpret_cast<double*>(ws + z_b) : nullptr,
+                                            bn_b, &slots, stream));
+        if (slots > 0) return bn_tail_forward_from_partials(d.N, d.fo, slots, reinterpret_cast<const double*>(ws + z_b), L->y, d.fo, L->bn_gamma, L->bn_beta,
+                                                            L->running_mean, L->running_var, L->momentum, L->eps, 1, L->residual ? L->h : nullptr, L->out,
+                                                            L->save_mean, L->save_invstd, L->num_batches_tracked, L->num_batches_tracked ? 1 : 0, stream);
     }
     // BatchNorm -> ReLU -> residual                                                             (:123-128 / :194-199)
     DGN_TRY(bn_tail_forward_nbt(d.N, d.fo, L->y, d.fo, L->bn_gamma, L->bn_beta, L->running_mean, L->running_var, L->momentum, L->eps, 1, 1,
