@@ -985,6 +985,66 @@ def test_towers_forward_with_batchnorm_statistics_from_the_posttrans_epilogue(mo
         assert torch.equal(ba[k], bc[k]), k
 
 
+@pytest.mark.parametrize("type_net,F_,scalers,n_graphs", [("simple", 75, "identity amplification attenuation", 150), ("simple", 70, "identity amplification attenuation", 37),
+                                                         ("simple", 65, "identity", 150), ("complex", 46, "identity amplification attenuation", 90),
+                                                         ("complex", 45, "identity", 3)])
+def test_dense_layer_forward_with_batchnorm_statistics_from_the_posttrans_pass(monkeypatch, type_net, F_, scalers, n_graphs):
+    """Round 6 (option bn_stats_fused on the simple / complex whole-layer call): BatchNorm's column sums of the posttrans output ride in the
+    degree-class product's epilogue (csrc/dgn_dc_kernels.hpp dc_tile: DcGemmParams.bn_part -- three scalers) or in the scale-combine pass
+    (csrc/dgn_combine.hip combine_fwd: bn_part -- the folded route / one scaler) instead of bn_stats' pass over y.  Same values, another
+    summation order: output, every gradient and the running statistics agree to fp32 rounding, num_batches_tracked counts once, and the
+    result is reproducible run to run."""
+    dev = _dev()
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    monkeypatch.setattr(dgn_amd.ops, "LINEAR_MIN_ROWS", 0)
+    monkeypatch.setattr(dgn_amd.ops, "WHOLE_LAYER_MIN_ROWS", 0)
+    b = synth.molecule_batch(n_graphs, seed=23, laplacian_eig=False)
+    N = int(b["num_nodes"])
+    graph = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    torch.manual_seed(12)
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, "mean max min dir1-av dir1-dx", scalers, {"log": torch.tensor(1.1)},
+                             type_net, True, towers=1, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    h0 = torch.randn(N, F_, device=dev, generator=gen) * 1.5 + 0.4
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    used = []
+    orig = dgn_amd.ops.dense_layer
+    monkeypatch.setattr(dgn_amd.ops, "dense_layer", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(_lib.options, "bn_stats_fused", fused)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(graph, h, None, snorm)
+        y.backward(ct)
+        return y.detach(), h.grad, {k: v.grad for k, v in lay.named_parameters()}, {k: v.clone() for k, v in lay.named_buffers()}
+
+    ya, ga, pa, ba = run(1)
+    yb, gb, pb, bb = run(0)
+    assert len(used) == 2, "the whole-layer entry point was not taken"
+
+    def close(a, b, what):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 5e-6 * scale + 1e-7, what
+    close(ya, yb, "y")
+    close(ga, gb, "d h")
+    for k in pa:
+        if pa[k] is not None:
+            close(pa[k], pb[k], k)
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == int(bb[k]) == 1, k
+        else:
+            close(ba[k].float(), bb[k].float(), k)
+    yc, gc, pc, bc = run(1)
+    assert torch.equal(ya, yc) and torch.equal(ga, gc)
+    for k in ba:
+        assert torch.equal(ba[k], bc[k]), k
+
+
 @pytest.mark.parametrize("aggs,T", [("mean max min dir1-av dir1-dx", 5), ("mean max min dir1-dx dir1-av", 1), ("mean max min dir1-av dir1-dx", 1)])
 @pytest.mark.parametrize("ties", [False, True])
 def test_backward_from_the_aux_table_is_bitwise_the_recomputing_backward(monkeypatch, aggs, T, ties):
