@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_stats(int64_t n_rows, int F, const flo
 // The [n_rows, F] tensor is ONE flat array when its rows are dense (ld == F): 16-byte chunk q covers floats 4q .. 4q + 3, whatever rows
 // they belong to.  A PERIOD of F / gcd(F, 4) chunks covers 4 / gcd(F, 4) whole rows, so a thread that always takes chunk j of a period
 // sees the same four columns (4j + e) mod F every time: per-thread column accumulators and column constants, as in the thread-per-column
-// kernels, with four times the bytes per load instruction (bn_stats<false> read 4-byte lanes: 3.9 TB/s on [275 k, 75]; this form: see
+// kernels, with four times the bytes per load instruction (used by bn_bwd_stats_flat4 on large batches; the forward statistics gained nothing from it:
 // profiles/NOTES.md).  Thread (p, j): period b * P + p, + G * P, ...; the workgroup folds (p, the four (j, e) of a column) through LDS in
 // a fixed order; the rows behind the last whole period are added by workgroup 0's column threads.  fn(offset, e0 columns, v0[4], v1[4])
 // fills the two quantities of the chunk at float offset `offset`; fn1(row, c, v0, v1) the same for one element (the remainder rows).
@@ -229,20 +229,6 @@ __device__ __forceinline__ void column_partials_flat4(int64_t n_rows, int F, dou
 bool flat4_ok(int F, int64_t ld, const void* a, const void* b = nullptr) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     return ld == F && (F & 3) != 0 && F / flat_gcd4(F) <= 256 && al16(a) && al16(b);
-}
-
-__global__ __launch_bounds__(256) void bn_stats_flat4(int64_t n_rows, int F, const float* __restrict__ x, double* __restrict__ part,
-                                                      const int64_t* __restrict__ n_valid) {
-    if (n_valid) n_rows = min(n_rows, *n_valid);
-    column_partials_flat4(n_rows, F, part, [&](int64_t off, float (&v0)[4], float (&v1)[4]) {
-        const float4 v = *reinterpret_cast<const float4*>(x + off);
-        v0[0] = v.x; v0[1] = v.y; v0[2] = v.z; v0[3] = v.w;
-        v1[0] = v.x * v.x; v1[1] = v.y * v.y; v1[2] = v.z * v.z; v1[3] = v.w * v.w;
-    }, [&](int64_t n, int c, float& v0, float& v1) {
-        const float v = x[n * F + c];
-        v0 = v;
-        v1 = v * v;
-    });
 }
 
 // mean / invstd per column, running statistics (unbiased variance, like torch)
@@ -696,8 +682,7 @@ int dgn::bn_tail_forward_nbt(int64_t n_rows, int32_t F, const float* x, int64_t 
         if (ws_bytes < dgn_bn_tail_workspace_bytes(n_rows, F)) { set_error("dgn_bn_tail_forward: workspace too small"); return DGN_ERR_WORKSPACE; }
         double* part = static_cast<double*>(ws);
         const int G = stat_groups(n_rows, F);
-        if (flat4_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats_flat4, dim3(G), dim3(256), 0, stream, n_rows, F, x, part, n_valid);
-        else if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
+        if (pairs_ok(F, ld, x)) hipLaunchKernelGGL(bn_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         else hipLaunchKernelGGL(bn_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, x, ld, part, n_valid);
         hipLaunchKernelGGL(bn_finalize, dim3(F), dim3(256), 0, stream, n_rows, F, G, (const double*)part, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd, n_valid, nbt, nbt ? n_nbt : 0);
@@ -723,7 +708,9 @@ extern "C" int dgn_bn_tail_backward(int64_t n_rows, int32_t F, const float* g_y,
     double* part = static_cast<double*>(ws);
     float* sums = sums_out ? sums_out : reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(n_rows, F));
     const int G = stat_groups(n_rows, F);
-    if (flat4_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats_flat4, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
+    // (flat 16-byte chunks: odd widths of batches that fill the chip -- tools/bn_flat_vs_column.py: [275 k, 75] 47.0 -> 41.4 us, but [52 k, 70] 18.7 -> 23.0
+    //  and [15 k, 65] 10.9 -> 14.1 against the thread-per-column(-pair) kernels, whose fold at the end of a workgroup is shorter)
+    if ((F & 1) && n_rows >= 131072 && flat4_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats_flat4, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     else if (pairs_ok(F, ld, x, g_y)) hipLaunchKernelGGL(bn_bwd_stats<true>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     else hipLaunchKernelGGL(bn_bwd_stats<false>, dim3(G), dim3(256), 0, stream, n_rows, F, g_y, x, ld, gamma, beta, save_mean, save_invstd, relu, part, n_valid);
     hipLaunchKernelGGL(bn_bwd_finalize, dim3(F), dim3(256), 0, stream, F, G, (const double*)part, sums, g_gamma, g_beta);
