@@ -113,6 +113,66 @@ def test_zinc12k_gradient_of_linear_functional():
     assert int(g.in_degree.min()) >= 1
 
 
+@pytest.mark.parametrize("type_net,F_,towers", [("towers", 70, 5), ("simple", 75, 1)])
+def test_zinc12k_whole_layer_round6_kernel_sets_agree_and_are_reproducible(type_net, F_, towers):
+    """BASELINE configs[1] / configs[0] at FULL size (ZINC-12k as one batch: 275 k nodes), whole-layer training step: the round-6 kernels that
+    merged passes (option bd_bwd_fused: the block-diagonal pretrans backward in one pass; bn_stats_fused: BatchNorm's column sums riding in the
+    posttrans product's epilogue -- per-workgroup slots whose number depends on the batch size) against the separate passes: output, d h, every
+    parameter gradient and the running statistics agree to fp32 rounding of another summation order; a second run of the merged set has the
+    same bits."""
+    import copy
+    import dgn_amd
+    from dgn_amd import _lib, synth
+    dev = _dev()
+    b = synth.molecule_batch(12000, seed=41, extra_bonds=3.9)
+    N = int(b["num_nodes"])
+    g = dgn_amd.DGNGraph(b["src"].to(dev), b["dst"].to(dev), N, eig=b["eig"].to(dev))
+    torch.manual_seed(3)
+    aggs = "mean max min dir1-av dir1-dx" if type_net == "towers" else "mean dir1-dx-no-abs"
+    layer = dgn_amd.DGNLayer(F_, F_, 0.0, True, True, aggs, "identity amplification attenuation", {"log": torch.log(g.in_degree.float() + 1).mean().cpu()},
+                             type_net, True, towers=towers, edge_features=False, edge_dim=0).model.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    h0 = torch.randn(N, F_, device=dev, generator=gen)
+    ct = torch.randn(N, F_, device=dev, generator=gen)
+    snorm = b["snorm_n"].to(dev)
+    keep = {k: getattr(_lib.options, k) for k in ("bd_bwd_fused", "bn_stats_fused")}
+
+    def run(v):
+        for k in keep:
+            setattr(_lib.options, k, v)
+        lay = copy.deepcopy(layer).train()
+        h = h0.clone().requires_grad_(True)
+        y = lay(g, h, None, snorm)
+        y.backward(ct)
+        return y.detach(), h.grad, {k: p.grad for k, p in lay.named_parameters()}, {k: v_.clone() for k, v_ in lay.named_buffers()}
+    try:
+        ya, ga, pa, ba = run(1)
+        yb, gb, pb, bb = run(0)
+        yc, gc, pc, bc = run(1)
+    finally:
+        for k, v in keep.items():
+            setattr(_lib.options, k, v)
+
+    def close(a, c, what, tol=1e-5):
+        scale = float(c.abs().max()) + 1e-30
+        assert float((a - c).abs().max()) <= tol * scale + 1e-7, (what, float((a - c).abs().max()), scale)
+    close(ya, yb, "y")
+    close(ga, gb, "d h")
+    for k in pa:
+        if pa[k] is not None:
+            close(pa[k], pb[k], k, 5e-5)        # (sums over 275 k rows in two orders)
+    for k in ba:
+        if k.endswith("num_batches_tracked"):
+            assert int(ba[k]) == int(bb[k]) == 1, k
+        else:
+            close(ba[k].float(), bb[k].float(), k)
+    assert torch.equal(ya, yc) and torch.equal(ga, gc)
+    for k in pa:
+        if pa[k] is not None:
+            assert torch.equal(pa[k], pc[k]), k
+    assert bool(torch.isfinite(ya).all()) and bool(torch.isfinite(ga).all())
+
+
 def test_row_sharded_graph_equals_whole_graph():
     """One graph cut into destination-range shards (bipartite CSR: n_src, row_base) must reproduce the unsharded
     sweep: forward rows concatenate, d x_in rows concatenate, d x_src partials sum."""
