@@ -237,9 +237,9 @@ int fill(P& p, const DgnBlockLayer* L, const Dims& d, bool bwd, const char* fn) 
     p.nbt = L->num_batches_tracked; p.n_nbt = L->num_batches_tracked ? L->n_nbt : 0;
     p.momentum = L->momentum; p.bn_eps = L->eps;
     p.N = d.N; p.n_valid = L->n_valid; p.overflow = L->overflow; p.tail_rows = d.tail_rows; p.n_tail = d.n_tail;
-    if (L->drop_p != 0.f && !L->eval_mode) {      // the towers' dropout inside the tails
-        if (!d.mixing || !(L->drop_p > 0.f && L->drop_p < 1.f) || !L->drop_mask || (!bwd && !L->drop_seed)) {
-            set_error("%s: dropout is the towers layer's (type 2): 0 < drop_p < 1, drop_mask, and -- forward -- drop_seed", fn);
+    if (L->drop_p != 0.f && !L->eval_mode) {      // dropout inside the tails: the towers' (:275, before the mixing network) or the simple / complex layer's last op (:130, :201)
+        if (!(L->drop_p > 0.f && L->drop_p < 1.f) || !L->drop_mask || (!bwd && !L->drop_seed)) {
+            set_error("%s: dropout needs 0 < drop_p < 1, drop_mask, and -- forward -- drop_seed", fn);
             return DGN_ERR_INVALID;
         }
         p.drop_scale = 1.f / (1.f - L->drop_p);

@@ -68,6 +68,8 @@ struct P {
     float momentum, bn_eps;
     int64_t N;
     // towers' F.dropout between BatchNorm and the mixing network (nets/dgn_layer.py:275), inside the tails (round 6): drop_scale == 0: none.
+    // Simple / complex layers (!mixing): their F.dropout is the layer's LAST op (:130, :201) -- on the finished output rows in the forward tail; the
+    // backward tail masks the staged output gradient, blk_backward the residual's share of d h.
     // Philox keep bits as dgn_dropout_forward draws them (group g = 8 consecutive elements of the dense [N, Fo] tensor, one mask byte)
     float drop_scale; uint32_t drop_threshold; const int64_t* drop_seed; uint64_t drop_offset; unsigned char* drop_mask;
     const int64_t* n_valid;      // DEVICE: rows of the batch inside a buffer of N rows (padded batches, hipgraph.PaddedBatch); NULL: N
@@ -673,6 +675,14 @@ __device__ __forceinline__ void blk_philox(uint32_t (&c)[4], uint32_t k0, uint32
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+// the residual's share of d h at element `at` of the dense [N, F] tensors: the output gradient -- through the layer's final dropout where the simple /
+// complex layer has one (its keep bit from the mask the forward tail stored; blk_dropout_rows' arithmetic)
+__device__ __forceinline__ float residual_grad(const P& p, int64_t at) {
+    const float gv = p.g_out[at];
+    if (p.mixing || p.drop_scale == 0.f) return gv;
+    return (p.drop_mask[at >> 3] >> (at & 7)) & 1u ? gv * p.drop_scale : 0.f;
+}
+
 // The tail's rows [m0, m0 + RW) of the dense [N, Fo] tensor are whole groups of 8 elements (RW is a multiple of 16).  `draw`: the keep
 // bits are drawn (forward) and the byte stored; else read back.  Every element of a kept position is scaled, a dropped one zeroed.
 __device__ __forceinline__ void blk_dropout_rows(const P& p, float* rows_lds, int ldk, int64_t m0, int rows, int RW, bool draw) {
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
     const int64_t m0 = (int64_t)blockIdx.x * RW, Nv = valid_rows(p);
     const int rows = (int)max((int64_t)0, min((int64_t)RW, Nv - m0)), rows_buf = (int)min((int64_t)RW, p.N - m0);
     const RowStep st_ = rf_stride(NT, Fo);
+    const bool drop_last = !p.mixing && p.drop_scale != 0.f && !p.eval_mode;
     if (rows < rows_buf) {      // padding rows of the buffer: zeros (their readers -- the readout's padding row -- must see finite values)
         RowFeat x = rf_at(tid, Fo);
         for (; x.r < rows_buf; rf_step(x, st_, Fo)) if (x.r >= rows) p.out[(m0 + x.r) * Fo + x.f] = 0.f;
@@ -772,11 +783,20 @@ __global__ __launch_bounds__(512) void blk_tail_fwd(const P p) {
             if (!p.mixing) {
                 if (p.relu) v = fmaxf(v, 0.f);
                 const int64_t at = (m0 + x.r) * Fo + x.f;
-                p.out[at] = p.residual ? v + p.h[at] : v;
+                if (p.residual) v += p.h[at];
+                if (drop_last) Y1[x.r * ldk + x.f] = v;      // (the finished rows wait in LDS for their keep bits)
+                else p.out[at] = v;
             } else {
                 Y1[x.r * ldk + x.f] = v;
             }
         }
+    }
+    if (drop_last) {                                  // the layer's last op: F.dropout(h, p, training)     (:130, :201)
+        __syncthreads();
+        blk_dropout_rows(p, Y1, ldk, m0, rows, RW, true);
+        __syncthreads();
+        RowFeat x = rf_at(tid, Fo);
+        for (; x.r < rows; rf_step(x, st_, Fo)) p.out[(m0 + x.r) * Fo + x.f] = Y1[x.r * ldk + x.f];
     }
     if (!p.mixing) return;
     __syncthreads();
@@ -839,6 +859,10 @@ __global__ __launch_bounds__(512) void blk_tail_bwd(const P p) {
         }
     }
     __syncthreads();
+    if (!p.mixing && p.drop_scale != 0.f) {          // the layer's final dropout: its adjoint on the staged output gradient
+        blk_dropout_rows(p, GZ, ldk, m0, rows, RW, false);
+        __syncthreads();
+    }
     {
         RowFeat x = rf_at(tid, Fo);
         for (; x.r < RW; rf_step(x, st_, Fo)) {
@@ -1239,7 +1263,7 @@ __global__ __launch_bounds__(1024) void blk_backward(const P p) {
         const RowStep st_ = rf_stride(NT, fi);
         for (; x.r < R; rf_step(x, st_, fi)) {
             const int64_t at = (int64_t)(c.lo + x.r) * p.F + t * fi + x.f;
-            p.g_h[at] = c.GA[x.r * ldh + x.f] + (p.residual ? p.g_out[at] : 0.f);
+            p.g_h[at] = c.GA[x.r * ldh + x.f] + (p.residual ? residual_grad(p, at) : 0.f);
         }
     } else {
         // pretrans adjoint: d h = d P W_s + d Q W_d (+ posttrans' h block, d x_in, residual); d W_pre, d b_pre partials
@@ -1257,7 +1281,7 @@ __global__ __launch_bounds__(1024) void blk_backward(const P p) {
                     const int i2 = ti * 16 + 4 * g + u;
                     if (i2 < fi) {
                         const int64_t at = (int64_t)(c.lo + m) * p.F + t * fi + i2;
-                        p.g_h[at] = acc[u] + c.GC[m * ldh + i2] + (p.residual ? p.g_out[at] : 0.f);
+                        p.g_h[at] = acc[u] + c.GC[m * ldh + i2] + (p.residual ? residual_grad(p, at) : 0.f);
                     }
                 }
             }

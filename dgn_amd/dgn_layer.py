@@ -126,6 +126,15 @@ def _dropout(x, p, training):
     return F.dropout(x, p, training=training)
 
 
+def _block_dropout(layer, h):
+    """``(p, key tensor, offset)`` for ops.block_layer when the layer's F.dropout is active (training, 0 < p < 1), else None: the graph-block
+    route draws the keep bits inside its tail kernels -- the bits ops.dropout would draw for the same key and offset."""
+    if layer.training and 0 < layer.dropout < 1:
+        seed, offset = _next_dropout_key(h.device)
+        return (float(layer.dropout), seed, offset)
+    return None
+
+
 def _next_dropout_key(device):
     """(key tensor, stream offset) of the next dropout call on ``device``; ``_dropout_key_used(key)`` after the kernels are enqueued."""
     st = _DROP_STATE.get(device)
@@ -393,19 +402,24 @@ class DGNLayerSimple(nn.Module):
     def _block_layer(self, g, h, snorm_n):
         """The layer on the graph-block route (ops.block_layer: batches at the reference's batch size), or None."""
         bn, lin = self.batchnorm_h, self.posttrans.fully_connected[0].linear
-        if not (_block_route_ok(self, h) and self.posttrans.is_single_affine() and lin.bias is not None):
+        if not (_block_route_ok(self, h) and self.posttrans.is_single_affine() and lin.bias is not None and 0 <= self.dropout < 1):
             return None
         graph = as_dgn_graph(g, h.device)
         if not _ops.block_layer_supported(graph, self.plan, 0, 1, h.shape[1], lin.weight.shape[0], eval_only=not self.training):
             return None
-        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, (lin.weight, lin.bias, bn.weight, bn.bias), 0, 1, h.shape[1], lin.weight.shape[0],
-                                self.residual, bn.momentum, bn.eps, training=self.training)
+        drop = _block_dropout(self, h)      # the layer's last op (nets/dgn_layer.py:201) inside the route's tail kernels
+        y = _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked, (lin.weight, lin.bias, bn.weight, bn.bias), 0, 1, h.shape[1], lin.weight.shape[0],
+                             self.residual, bn.momentum, bn.eps, training=self.training, dropout=drop)
+        if drop is not None:
+            _dropout_key_used(drop[1])
+        return y
 
     def _forward(self, g, h, e, snorm_n):
         y = self._block_layer(g, h, snorm_n)
-        if y is None:
-            y = self._whole_layer(g, h, snorm_n)
+        if y is not None:
+            return y                                              # (dropout included)
+        y = self._whole_layer(g, h, snorm_n)
         if y is not None:
             return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:201: the layer's last op)
         h_in = h
@@ -521,19 +535,24 @@ class DGNLayerComplex(nn.Module):
         bn = self.batchnorm_h
         pre, lin = self.pretrans.fully_connected[0].linear, self.posttrans.fully_connected[0].linear
         if not (_block_route_ok(self, h) and not self.edge_features and self.posttrans.is_single_affine() and self.pretrans.is_single_affine()
-                and lin.bias is not None and pre.bias is not None):
+                and lin.bias is not None and pre.bias is not None and 0 <= self.dropout < 1):
             return None
         graph = as_dgn_graph(g, h.device)
         if not _ops.block_layer_supported(graph, self.plan, 1, 1, h.shape[1], lin.weight.shape[0], eval_only=not self.training):
             return None
-        return _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, (pre.weight, pre.bias, lin.weight, lin.bias, bn.weight, bn.bias), 1, 1, h.shape[1],
-                                lin.weight.shape[0], self.residual, bn.momentum, bn.eps, training=self.training)
+        drop = _block_dropout(self, h)      # the layer's last op (nets/dgn_layer.py:130) inside the route's tail kernels
+        y = _ops.block_layer(graph, self.plan, self._avg_log, g.ndata["eig"], h, snorm_n if self.graph_norm else None, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked, (pre.weight, pre.bias, lin.weight, lin.bias, bn.weight, bn.bias), 1, 1, h.shape[1],
+                             lin.weight.shape[0], self.residual, bn.momentum, bn.eps, training=self.training, dropout=drop)
+        if drop is not None:
+            _dropout_key_used(drop[1])
+        return y
 
     def _forward(self, g, h, e, snorm_n):
         y = self._block_layer(g, h, snorm_n)
-        if y is None:
-            y = self._whole_layer(g, h, snorm_n)
+        if y is not None:
+            return y                                              # (dropout included)
+        y = self._whole_layer(g, h, snorm_n)
         if y is not None:
             return _dropout(y, self.dropout, self.training)       # (nets/dgn_layer.py:130: the layer's last op)
         h_in = h

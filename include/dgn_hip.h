@@ -755,8 +755,9 @@ typedef struct DgnBlockLayer {
     int32_t eval_mode;
     float* dbg_agg; float* dbg_gagg;      /* tests only: [N, T n_agg f_in] aggregate rows (forward) / their gradients (backward); NULL */
     int64_t* dbg_time;           /* profiling only: [n_blocks][16] wall-clock stamps (100 MHz) of the block kernel's phases; NULL      */
-    /* Round 6 (ABI 27), towers only: F.dropout(h, p, training) between the towers' BatchNorm and the mixing network (nets/dgn_layer.py:275)
-     * inside the tail kernels.  drop_p in (0, 1): drop_seed (DEVICE int64 key; forward only) / drop_offset as dgn_dropout_forward takes
+    /* Round 6 (ABI 27): F.dropout(h, p, training) inside the tail kernels -- towers (type 2): between the towers' BatchNorm and the mixing
+     * network (nets/dgn_layer.py:275); simple / complex (types 0 / 1; ABI 28's library, same fields): the layer's LAST op, on the finished
+     * output rows (:130, :201; the backward masks the output gradient, the residual's share of d h included).  drop_p in (0, 1): drop_seed (DEVICE int64 key; forward only) / drop_offset as dgn_dropout_forward takes
      * them, drop_mask = dgn_dropout_mask_bytes(N * T * f_out) bytes, written by the forward (the very bits dgn_dropout_forward would
      * draw for the dense [N, T f_out] tensor) and read by the backward.  drop_p = 0: none.  Ignored in eval_mode.                   */
     float drop_p; const int64_t* drop_seed; uint64_t drop_offset; unsigned char* drop_mask;

@@ -67,18 +67,22 @@ def test_dropout_statistics():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("route", ["whole-layer", "graph-block"])
 @pytest.mark.parametrize("kind,F_,aggs", [("simple", 70, "mean max min dir1-dx dir1-av"), ("complex", 65, "mean dir1-dx dir2-dx"),
                                           ("simple", 65, "mean dir1-dx dir2-dx")])
-def test_layer_with_dropout_vs_oracle_with_the_same_mask(kind, F_, aggs, monkeypatch):
+def test_layer_with_dropout_vs_oracle_with_the_same_mask(kind, F_, aggs, route, monkeypatch):
     """HIV json (simple, hidden 70, 3 scalers, dropout 0.3, no graph norm) and CIFAR10 json (hidden 65, one scaler, dropout 0.3) through
-    the WHOLE-LAYER calls, against the oracle fed the keep mask the kernel drew."""
+    the WHOLE-LAYER calls (dropout = ops.dropout behind the call) and -- round 6, last session -- on the GRAPH-BLOCK route, where the layer's final
+    F.dropout (nets/dgn_layer.py:130, :201) runs inside the tail kernels (DgnBlockLayer.drop_* for types 0 / 1): against the oracle fed the keep
+    mask the kernel drew; on the block route the mask must also be, bit for bit, what dgn_dropout_forward draws for the same key and offset."""
     import dgn_amd
     from dgn_amd import ops, synth
     from oracle import dgn_oracle as orc
     dev = torch.device("cuda")
     monkeypatch.setattr(ops, "WIDE_MIN_ROWS", 0)
     monkeypatch.setenv("DGN_DC_MIN_NODES", "0")
-    b = synth.molecule_batch(30, seed=5) if F_ == 70 else synth.knn_batch(4, seed=5)
+    # (the graph-block route's LDS plan does not hold k-NN graphs of hidden 65: its variants run the same layers on a molecule batch)
+    b = synth.molecule_batch(30, seed=5) if (F_ == 70 or route == "graph-block") else synth.knn_batch(4, seed=5)
     src, dst, N, eig, snorm = b["src"], b["dst"], int(b["num_nodes"]), b["eig"], b["snorm_n"]
     scalers = "identity amplification attenuation" if F_ == 70 else "identity"
     p = 0.3
@@ -95,14 +99,27 @@ def test_layer_with_dropout_vs_oracle_with_the_same_mask(kind, F_, aggs, monkeyp
     ct = torch.randn(N, F_, generator=gen)
     layer = layer.to(dev).train()
     calls = []
-    whole = type(layer)._whole_layer
-    monkeypatch.setattr(type(layer), "_whole_layer", lambda self, *a: calls.append(whole(self, *a)) or calls[-1])
+    if route == "whole-layer":
+        whole = type(layer)._whole_layer
+        monkeypatch.setattr(type(layer), "_whole_layer", lambda self, *a: calls.append(whole(self, *a)) or calls[-1])
+        monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 0)
+    else:
+        real = ops.block_layer
+        monkeypatch.setattr(ops, "block_layer", lambda *a, **k: calls.append(real(*a, **k)) or calls[-1])
+        monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_NODES", 8192)
+        monkeypatch.setattr(ops, "BLOCK_LAYER_MAX_POST", 1 << 30)
     graph = dgn_amd.DGNGraph(src.to(dev), dst.to(dev), N, eig=eig.to(dev))
     hd = h.to(dev).requires_grad_(True)
+    ops.LAST_DROPOUT_MASK = None
     y = layer(graph, hd, None, snorm.to(dev))
-    assert calls and calls[-1] is not None, "the whole-layer call did not take the layer with dropout on"
-    keep = _bits(ops.LAST_DROPOUT_MASK, N * F_).reshape(N, F_)
+    assert calls and calls[-1] is not None, f"the {route} call did not take the layer with dropout on"
+    mask_bytes = ops.LAST_DROPOUT_MASK.clone()
+    keep = _bits(mask_bytes, N * F_).reshape(N, F_)
     assert 0.6 < float(keep.mean()) < 0.8
+    if route == "graph-block":      # the tail draws the bits dgn_dropout_forward draws for (key, offset) over the dense [N, f_out] tensor
+        key, n_calls = dgn_amd.dgn_layer._DROP_STATE[torch.device("cuda", torch.cuda.current_device())]
+        ops.dropout(torch.ones(N, F_, device=dev), p, True, seed=key, offset=n_calls)
+        assert torch.equal(ops.LAST_DROPOUT_MASK[:(N * F_ + 7) // 8], mask_bytes[:(N * F_ + 7) // 8])
     (y * ct.to(dev)).sum().backward()
     cfg = dict(aggregators=aggs, scalers=scalers, avg_log=torch.tensor(1.2), graph_norm=F_ != 70, batch_norm=True, residual=True, towers=1,
                divide_input=True, edge_features=False)
